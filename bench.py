@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ResNet-18 federated-client training throughput on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one synthetic batch on every client: forward, loss,
+backward, SGD (lr 1e-4, wd 5e-4 — the reference's pneumonia-resnet-pretrained.ini), plus, for
+N > 1, the FedAvg exchange every `sync_every_n_batch` = 3 steps (BASELINE.json configs[2]).
+N = 1 is BASELINE.json configs[1]: bf16, batch 256, 3x224x224 synthetic, inputs resident in HBM.
+
+Prints ONE JSON line (rank 0).  Besides the contract fields it carries
+  roofline     : MFMA roofline of the dominant convolution kernel, measured live with HIP events
+                 on the launch stream; algorithmic FLOPs = 2*MACs of the layers it ran
+                 (10.881 GFLOP / image over fwd + dgrad + wgrad)
+  cpu_baseline : the oracle (torch-CPU fp32 restatement of the reference step) timed on the host
+                 cores on a bounded sample, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md
+GFLOP_PER_IMAGE = 10.881                            # SURVEY.md §8d (fwd 3.627 + bwd 7.254)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--sync-every", type=int, default=3)
+    ap.add_argument("--secure-aggregation", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-batch", type=int, default=32)
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, size, budget_s=20.0):
+    """Oracle train step (torch-CPU fp32, what a PySyft VirtualWorker runs natively) on host cores."""
+    from oracle import train_oracle as O
+    from primia_amd import resnet_spec as rs
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"))
+    x = torch.randn(batch, 3, size, size)
+    y = torch.randint(0, 3, (batch,))
+    O.train_step(sd, x, y, 1e-4, 5e-4)  # warm-up
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.train_step(sd, x, y, 1e-4, 5e-4)
+        n += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 8:
+            break
+    return {"value": round(batch * n / el, 2), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} fp32 train steps of batch {batch} at {size}x{size} (oracle/train_oracle.py, torch-CPU)"}
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from primia_amd import fed
+    from primia_amd.engine import ResNet18Engine
+
+    dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    eng = ResNet18Engine(a.batch, 3, 3, a.size, "max", dtype=dtype, device=dev)
+    torch.manual_seed(42)           # the reference's default seed (pneumonia-resnet-pretrained.ini:17)
+    eng.init_weights()
+    g = torch.Generator().manual_seed(1000 + rank)
+    nbuf = 2
+    xs = [torch.randn(a.batch, 3, a.size, a.size, generator=g).to(dev) for _ in range(nbuf)]
+    ys = [torch.randint(0, 3, (a.batch,), generator=g).to(dev) for _ in range(nbuf)]
+    local_flat = torch.empty_like(eng.flat)
+    scratch = torch.empty(eng.flat.numel(), dtype=torch.int64, device=dev) if a.secure_aggregation else None
+    lr, wd = 1e-4, 5e-4
+
+    def step(i):
+        eng.forward(xs[i % nbuf])
+        eng.loss_backward(ys[i % nbuf])
+        eng.sgd_step(lr, wd)
+        if world > 1 and i > 0 and i % a.sync_every == 0:
+            fed.fedavg_allreduce(eng.flat, local_flat, None, a.secure_aggregation, 16, 10, None, None, scratch)
+            eng.flat.copy_(local_flat)
+            eng.refresh_weights()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    loss = eng.loss.item()
+
+    # ---- roofline leg: per-launch HIP events around every convolution kernel ----------------------
+    eng.prof = []
+    nprof = 3
+    for i in range(nprof):
+        step(i)
+    torch.cuda.synchronize()
+    agg = {}
+    for kind, name, flops, e0, e1 in eng.prof:
+        d = agg.setdefault(kind, {"ms": 0.0, "flops": 0.0, "launches": 0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["flops"] += flops
+        d["launches"] += 1
+    eng.prof = None
+    peak = MFMA_PEAK_TFLOPS[a.dtype]
+    kernels = {}
+    for kind, d in agg.items():
+        kernels[kind] = {"tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
+                         "ms_per_step": round(d["ms"] / nprof, 4),
+                         "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2)}
+    dom = max(agg, key=lambda k: agg[k]["ms"])
+    conv_ms = sum(d["ms"] for d in agg.values()) / nprof
+    conv_fl = sum(d["flops"] for d in agg.values()) / nprof
+    roof = {"bound": "mfma", "kernel": {"fwd": "conv_igemm_kernel<fwd>", "dgrad": "conv_igemm_kernel<dgrad>",
+                                        "wgrad": "conv_wgrad_kernel"}[dom],
+            "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
+            "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": None,
+            "all_conv": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 3),
+                         "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)},
+            "kernels": kernels}
+
+    ms_per_step = dt / a.steps * 1e3
+    total_ips = a.batch * world * a.steps / dt
+    out = {
+        "metric": "images_per_sec", "value": round(total_ips, 1), "unit": "images/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+        "config": {"workload": f"ResNet-18 federated-client training step (fwd+loss+bwd+SGD), batch {a.batch}/client, "
+                               f"3x{a.size}x{a.size}, 1 client per GPU"
+                               + (f", FedAvg every {a.sync_every} batches over RCCL" if world > 1 else ""),
+                   "batch_per_client": a.batch, "clients": world, "sync_every_n_batch": a.sync_every,
+                   "secure_aggregation": bool(a.secure_aggregation)},
+        "images_per_sec_per_client": round(total_ips / world, 1),
+        "step_tflops": round(GFLOP_PER_IMAGE * 1e9 * a.batch / (dt / a.steps) / 1e12, 2),
+        "step_mfma_frac": round(GFLOP_PER_IMAGE * 1e9 * a.batch / (dt / a.steps) / 1e12 / peak, 4),
+        "final_loss": round(loss, 5),
+        "roofline": roof,
+    }
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_batch, a.size)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,172 @@
+/*
+ * primia_hip.h — C ABI of libprimia_hip.so (MI355X / gfx950 only).
+ *
+ * Drop-in boundary for PriMIA's hot path.  The reference is pure Python; the
+ * seam an FFI would bind is (a) the top-level torch functions a PySyft worker executes for one
+ * plaintext training step (syft/generic/pointers/object_pointer.py:196-217 ships them whole;
+ * syft/workers/message_handler.py:59-142 executes them) and (b) the `@allow_command` per-share
+ * functions of the secure path (syft/generic/utils.py:27-55).  Every entry point below names
+ * the reference call it replaces.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
+ *     buffer, workspaces are passed explicitly, there is no hidden allocation or global state;
+ *   - `stream` is a hipStream_t (0 = default stream); all work is enqueued asynchronously;
+ *   - return value: PRIMIA_OK (0) or a negative PRIMIA_ERR_* code;
+ *   - float tensors are NHWC ("channels last") in `dtype` PRIMIA_F32 or PRIMIA_BF16; weights
+ *     handed over at the boundary keep the reference's OIHW / [out,in] fp32 layout;
+ *   - ring tensors are int64 two's complement, arithmetic mod 2^64.
+ */
+#ifndef PRIMIA_HIP_H
+#define PRIMIA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PRIMIA_OK 0
+#define PRIMIA_ERR_ARG (-1)         /* bad shape / null pointer / unsupported size */
+#define PRIMIA_ERR_LAUNCH (-2)      /* HIP launch or runtime error */
+#define PRIMIA_ERR_UNSUPPORTED (-3) /* valid request this build does not implement */
+#define PRIMIA_ERR_WORKSPACE (-4)   /* workspace too small */
+
+#define PRIMIA_F32 0
+#define PRIMIA_BF16 1
+
+typedef void* primia_stream_t; /* hipStream_t */
+
+int primia_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Layout conversion at the boundary.  The reference hands NCHW fp32 batches to the model
+ * (torchlib/utils.py:1169-1170); kernels run NHWC.  c_pad >= C pads channels with zeros
+ * (the stem runs with 3 -> 4 channels).
+ * ------------------------------------------------------------------------------------------ */
+int primia_nchw_to_nhwc(const float* src_nchw, void* dst_nhwc, int N, int C, int H, int W,
+                        int c_pad, int dtype, primia_stream_t stream);
+int primia_nhwc_to_nchw(const void* src_nhwc, float* dst_nchw, int N, int C, int H, int W,
+                        int c_pad, int dtype, primia_stream_t stream);
+/* dst[i] = (dtype) src[i] and back; n elements. */
+int primia_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, primia_stream_t stream);
+int primia_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, primia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution — replaces torch.nn.functional.conv2d forward and its autograd backward for
+ * nn.Conv2d(bias=False) (torchlib/models.py:219-235, 379-381).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct primia_conv_desc {
+    int32_t N, H, W, C;  /* input NHWC; C is the stored channel count (stem: 4)          */
+    int32_t K, R, S;     /* output channels, kernel height, kernel width                  */
+    int32_t stride, pad; /* same in both spatial dims (ResNet-18 only uses square convs)  */
+    int32_t Ho, Wo;      /* output spatial size = (H + 2*pad - R)/stride + 1              */
+} primia_conv_desc;
+
+/* Element count of the compute copies of one conv weight (fwd layout [K][R][Sp][C'] and dgrad
+ * layout [C][R][S][K]); Sp/C' include the stem's zero padding. */
+int64_t primia_conv_wfwd_elems(const primia_conv_desc* d);
+int64_t primia_conv_wdgrad_elems(const primia_conv_desc* d);
+
+/* fp32 OIHW master weight [K][c_real][R][S] -> compute-dtype copies.  w_dgrad may be NULL. */
+int primia_conv_weight_prepare(const primia_conv_desc* d, int c_real, const float* w_oihw,
+                               void* w_fwd, void* w_dgrad, int dtype, primia_stream_t stream);
+
+/* y[N,Ho,Wo,K] = conv(x[N,H,W,C], w). */
+int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
+                      int dtype, primia_stream_t stream);
+/* dx[N,H,W,C] = conv_transpose(dy[N,Ho,Wo,K], w).  If accumulate != 0, dx += (dx is read). */
+int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                        int accumulate, int dtype, primia_stream_t stream);
+/* dw_acc (fp32, fwd layout [K][R][Sp][C']) += sum over pixels.  Caller zeroes dw_acc first. */
+int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,
+                        int dtype, primia_stream_t stream);
+/* dw_oihw[K][c_real][R][S] = transpose(dw_acc) (drops padding). */
+int primia_conv_wgrad_finalize(const primia_conv_desc* d, int c_real, const float* dw_acc,
+                               float* dw_oihw, primia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm2d (+ fused ReLU / residual add) — replaces F.batch_norm, F.relu and Tensor.__iadd__
+ * (torchlib/models.py:261-264, 268-284, 382-383); torch defaults momentum 0.1, eps 1e-5.
+ * Tensors are [M, C] with M = N*H*W.
+ * ------------------------------------------------------------------------------------------ */
+int64_t primia_bn_workspace_bytes(int64_t M, int C);
+/* Training forward: batch statistics, running-stat EMA (unbiased variance), then
+ * z = act(gamma * (y - mean) * invstd + beta [+ residual]).  save_mean / save_invstd [C] are
+ * kept for backward. */
+int primia_bn_fwd_train(const void* y, const void* residual, void* z, const float* gamma,
+                        const float* beta, float* running_mean, float* running_var,
+                        float* save_mean, float* save_invstd, int64_t M, int C, float eps,
+                        float momentum, int relu, void* workspace, int64_t workspace_bytes,
+                        int dtype, primia_stream_t stream);
+/* Eval forward with running statistics. */
+int primia_bn_fwd_eval(const void* y, const void* residual, void* z, const float* gamma,
+                       const float* beta, const float* running_mean, const float* running_var,
+                       int64_t M, int C, float eps, int relu, int dtype, primia_stream_t stream);
+/* Backward.  dz is the gradient w.r.t. z; if relu != 0 it is masked with (z > 0) first.
+ * Outputs: dy (gradient w.r.t. the conv output y), dgamma, dbeta; if g_out != NULL the masked
+ * gradient is also written there (the residual branch's gradient; may alias dz). */
+int primia_bn_bwd(const void* y, const void* z, const void* dz, void* dy, void* g_out,
+                  const float* gamma, const float* save_mean, const float* save_invstd,
+                  float* dgamma, float* dbeta, int64_t M, int C, int relu, void* workspace,
+                  int64_t workspace_bytes, int dtype, primia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pooling — replaces F.max_pool2d(3,2,1) / F.avg_pool2d(3,2,1) (torchlib/models.py:384-389)
+ * and nn.AvgPool2d(7) + flatten (models.py:400-404, 477-478).
+ * ------------------------------------------------------------------------------------------ */
+int primia_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C,
+                            int dtype, primia_stream_t stream);
+int primia_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int N, int H, int W,
+                            int C, int dtype, primia_stream_t stream);
+int primia_avgpool3x3s2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype,
+                            primia_stream_t stream);
+int primia_avgpool3x3s2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype,
+                            primia_stream_t stream);
+/* feat[N,C] (fp32) = mean over HW of x[N,HW,C]; backward spreads dfeat/HW. */
+int primia_global_avgpool_fwd(const void* x, float* feat, int N, int HW, int C, int dtype,
+                              primia_stream_t stream);
+int primia_global_avgpool_bwd(const float* dfeat, void* dx, int N, int HW, int C, int dtype,
+                              primia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Classifier head and loss — replaces F.linear (models.py:479,495), nn.CrossEntropyLoss
+ * (train.py:335-340) and Cross_entropy_one_hot (torchlib/utils.py:404-441).  All fp32.
+ * ------------------------------------------------------------------------------------------ */
+int primia_linear_fwd(const float* x, const float* w, const float* b, float* y, int N, int in_f,
+                      int out_f, primia_stream_t stream);
+int primia_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                      float* db, int N, int in_f, int out_f, primia_stream_t stream);
+/* Hard labels: loss = sum_n w[t_n] * nll_n / sum_n w[t_n]; class_weight may be NULL. */
+int primia_xent_hard(const float* logits, const int64_t* target, const float* class_weight,
+                     float* loss, float* dlogits, int N, int C, primia_stream_t stream);
+/* Soft labels: loss = mean_n[(sum_c w_c t_nc) * (-sum_c t_nc * logsoftmax(o)_nc)]. */
+int primia_xent_soft(const float* logits, const float* target, const float* class_weight,
+                     float* loss, float* dlogits, int N, int C, primia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizers over a flat fp32 arena — replaces torch.optim.SGD(lr, weight_decay) without
+ * momentum and torch-1.4 torch.optim.Adam (train.py:280-303).
+ * ------------------------------------------------------------------------------------------ */
+int primia_sgd_step(float* p, const float* g, int64_t n, float lr, float weight_decay,
+                    primia_stream_t stream);
+int primia_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n,
+                     float lr, float beta1, float beta2, float eps, float weight_decay,
+                     int64_t step, primia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FedAvg helpers — the arithmetic of aggregation() (torchlib/utils.py:1000-1092) on the flat
+ * arena; the exchange itself is an RCCL all-reduce issued by the host.
+ * ------------------------------------------------------------------------------------------ */
+int primia_scale(float* x, int64_t n, float a, primia_stream_t stream);  /* x *= a   (theta_k * w_k) */
+int primia_divide(float* x, int64_t n, float d, primia_stream_t stream); /* x /= d   (sum / K)       */
+/* q = int64(trunc(float32(x) * float32(scale)))  (FixedPrecisionTensor.fix_precision,
+ * syft/frameworks/torch/tensors/interpreters/precision.py:117-132). */
+int primia_fx_encode(const float* x, int64_t* q, int64_t n, float scale, primia_stream_t stream);
+/* x = float32(q) / scale  (float_precision, precision.py:134-144). */
+int primia_fx_decode(const int64_t* q, float* x, int64_t n, float scale, primia_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PRIMIA_HIP_H */

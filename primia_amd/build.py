@@ -1,0 +1,71 @@
+"""Build libprimia_hip.so (gfx950) with hipcc.  `python -m primia_amd.build [--force]`.
+
+Each csrc/*.hip is compiled to an object (in parallel) and linked into ONE shared library that
+lives in-tree next to this file, so it travels with the repo snapshot to the GPU box.  hipcc
+cross-compiles without a GPU.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_build")
+LIB = os.path.join(HERE, "libprimia_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in ("/opt/rocm/bin/hipcc", "hipcc"):
+        if os.path.isabs(c) and os.path.exists(c):
+            return c
+    return "hipcc"
+
+
+def _newer(src, dst, deps=()):
+    if not os.path.exists(dst):
+        return True
+    t = os.path.getmtime(dst)
+    return any(os.path.getmtime(p) > t for p in (src, *deps))
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(HERE, "..", "include", "primia_hip.h"))
+    sources = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    jobs = []
+    for f in sources:
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f[:-4] + ".o")
+        if force or _newer(src, obj, headers):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return src, r.returncode, r.stdout + r.stderr
+
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for src, rc, out in ex.map(compile_one, jobs):
+                if verbose:
+                    print(f"[primia build] {os.path.basename(src)}: {'ok' if rc == 0 else 'FAILED'}")
+                if rc != 0:
+                    raise RuntimeError(f"hipcc failed for {src}:\n{out}")
+    objs = [os.path.join(OBJ, f[:-4] + ".o") for f in sources]
+    if jobs or force or not os.path.exists(LIB):
+        cmd = [_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+        if verbose:
+            print(f"[primia build] linked {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

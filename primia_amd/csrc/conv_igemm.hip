@@ -1,0 +1,354 @@
+// Implicit-GEMM convolution forward and data-gradient for NHWC tensors on gfx950 MFMA.
+//
+//   dst[m, n] = sum_{tap=(r,s)} sum_c  src[pix(m, tap), c] * wt[n, tap, c]
+//
+//   forward : dst = y [N*Ho*Wo, K], src = x,  pix = (ho*stride - pad + r, wo*stride - pad + s)
+//   dgrad   : dst = dx [N*H*W, C],  src = dy, pix = ((h + pad - r)/stride, (w + pad - s)/stride)
+//             taken only where the division is exact (wt is the [C][R][S][K] copy).
+//
+// Tiling: 256 threads = 4 waves (2 x 2); block tile BM pixels x BN channels; one k-step is 128
+// bytes of the reduction axis (64 bf16 / 32 f32).  Both operand tiles are staged global -> VGPR
+// -> LDS as rows of 128 B made of eight 16-B chunks; chunk c of row r lives at chunk slot
+// c ^ ((r >> 1) & 7), which makes the ds_read_b128 fragment reads (row = lane & 15, chunk =
+// 4*kk + (lane >> 4)) conflict-free for the hardware's 16-lane read groups.  The MFMA "A" operand
+// is the weight tile and "B" the pixel tile, so each lane ends up with 4 consecutive output
+// channels of one pixel and stores them with one 8-B (bf16) / 16-B (f32) store.
+// LDS is double buffered: the global loads of step t+1 are in flight while step t's MFMAs run.
+//
+// f32 uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) — the parity path; bf16 uses
+// v_mfma_f32_16x16x32_bf16 with fp32 accumulation — the throughput path.
+#include "conv_common.h"
+
+namespace primia {
+
+struct IgemmParams {
+    const void* src;
+    const void* wt;
+    void* dst;
+    int Nb;          // batch
+    int Hd, Wd, Nd;  // dst spatial size and channels
+    int Hs, Ws, Cs;  // src spatial size and channels (Cs = 4 for the stem)
+    int R, S, stride, pad;
+    int klen;        // weight row length in elements
+    int nsteps;      // k-steps
+    long Md;         // dst pixels
+    int accumulate;
+    int ntile_n;
+};
+
+template <typename T>
+struct MmaTraits;
+template <>
+struct MmaTraits<bf16> {
+    static constexpr int KE = 64;  // elements per k-step
+};
+template <>
+struct MmaTraits<float> {
+    static constexpr int KE = 32;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T, int BM, int BN, bool DGRAD, bool STEM>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
+    constexpr int KE = MmaTraits<T>::KE;
+    constexpr int CH = Elem<T>::kPerChunk;  // elements per 16-B chunk
+    constexpr int PR = BM / 32;             // pixel rows staged per thread
+    constexpr int WR = BN / 32;             // weight rows staged per thread
+    constexpr int FM = BN / 32;             // 16-channel fragments per wave
+    constexpr int FN = BM / 32;             // 16-pixel fragments per wave
+    constexpr int TILE_P = BM * 128, TILE_W = BN * 128;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // buffer b: pixel tile at smem + b*(TILE_P+TILE_W), weight tile right behind it.
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;  // wave position: pixels, channels
+
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
+    const long m0 = (long)tm * BM;
+    const int n0 = tn * BN;
+
+    const T* __restrict__ src = (const T*)p.src;
+    const T* __restrict__ wt = (const T*)p.wt;
+
+    // ---- per-thread staging coordinates -----------------------------------------------------
+    const int srow = tid >> 3, schunk = tid & 7;
+    int nb[PR], hb[PR], wb[PR];
+    bool mval[PR];
+#pragma unroll
+    for (int j = 0; j < PR; ++j) {
+        long m = m0 + srow + 32 * j;
+        mval[j] = m < p.Md;
+        if (!mval[j]) m = 0;
+        int wd = (int)(m % p.Wd);
+        long t = m / p.Wd;
+        int hd = (int)(t % p.Hd);
+        int n = (int)(t / p.Hd);
+        nb[j] = n * p.Hs * p.Ws;
+        if (DGRAD) {
+            hb[j] = hd + p.pad;
+            wb[j] = wd + p.pad;
+        } else {
+            hb[j] = hd * p.stride - p.pad;
+            wb[j] = wd * p.stride - p.pad;
+        }
+    }
+    const T* wrow[WR];
+#pragma unroll
+    for (int j = 0; j < WR; ++j) wrow[j] = wt + (long)(n0 + srow + 32 * j) * p.klen + schunk * CH;
+
+    u32x4 rp[PR], rw[WR];
+
+    auto load_global = [&](int step) {
+        if (STEM) {
+            // element e0 of the reduction axis -> kernel row r, first pixel sx inside the row.
+            const int e0 = step * KE + schunk * CH;
+            const int r = e0 >> 5, sx = (e0 & 31) >> 2;
+#pragma unroll
+            for (int j = 0; j < PR; ++j) {
+                const int hs = hb[j] + r;
+                const bool rowok = mval[j] && r < p.R && hs >= 0 && hs < p.Hs;
+                const int ws = wb[j] + sx;
+                const long base = ((long)nb[j] + (long)hs * p.Ws + ws) * 4;
+                if (sizeof(T) == 4) {
+                    u32x4 v = {0, 0, 0, 0};
+                    if (rowok && ws >= 0 && ws < p.Ws) v = *(const u32x4*)(src + base);
+                    rp[j] = v;
+                } else {
+                    u32x2 a = {0, 0}, b = {0, 0};
+                    if (rowok && ws >= 0 && ws < p.Ws) a = *(const u32x2*)(src + base);
+                    if (rowok && ws + 1 >= 0 && ws + 1 < p.Ws) b = *(const u32x2*)(src + base + 4);
+                    rp[j] = u32x4{a[0], a[1], b[0], b[1]};
+                }
+            }
+        } else {
+            const int kk = step * KE;
+            const int tap = kk / p.Cs;
+            const int c0 = kk - tap * p.Cs + schunk * CH;
+            const int r = tap / p.S, s = tap - r * p.S;
+#pragma unroll
+            for (int j = 0; j < PR; ++j) {
+                int hs, ws;
+                bool ok = mval[j];
+                if (DGRAD) {
+                    const int th = hb[j] - r, tw = wb[j] - s;
+                    ok = ok && th >= 0 && tw >= 0;
+                    if (p.stride == 2) {
+                        ok = ok && ((th | tw) & 1) == 0;
+                        hs = th >> 1;
+                        ws = tw >> 1;
+                    } else {
+                        hs = th;
+                        ws = tw;
+                    }
+                    ok = ok && hs < p.Hs && ws < p.Ws;
+                } else {
+                    hs = hb[j] + r;
+                    ws = wb[j] + s;
+                    ok = ok && hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws;
+                }
+                u32x4 v = {0, 0, 0, 0};
+                if (ok) v = *(const u32x4*)(src + ((long)nb[j] + (long)hs * p.Ws + ws) * p.Cs + c0);
+                rp[j] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < WR; ++j) rw[j] = *(const u32x4*)(wrow[j] + (long)step * KE);
+    };
+
+    auto store_lds = [&](int buf) {
+        char* lp = smem + buf * (TILE_P + TILE_W);
+        char* lw = lp + TILE_P;
+#pragma unroll
+        for (int j = 0; j < PR; ++j) *(u32x4*)(lp + lds_off(srow + 32 * j, schunk)) = rp[j];
+#pragma unroll
+        for (int j = 0; j < WR; ++j) *(u32x4*)(lw + lds_off(srow + 32 * j, schunk)) = rw[j];
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int prow0 = wm * (BM / 2) + fr;  // + 16*fn
+    const int crow0 = wn * (BN / 2) + fr;  // + 16*fm
+
+    auto compute = [&](int buf) {
+        const char* lp = smem + buf * (TILE_P + TILE_W);
+        const char* lw = lp + TILE_P;
+        if constexpr (sizeof(T) == 2) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8_t a[FM], b[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    a[i] = *(const bf16x8_t*)(lw + lds_off(crow0 + 16 * i, kk * 4 + fg));
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    b[j] = *(const bf16x8_t*)(lp + lds_off(prow0 + 16 * j, kk * 4 + fg));
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            // lane's k-set = floats of chunk fg and chunk fg+4 (any k order works as long as
+            // both operands agree); MFMA t consumes float t of every lane.
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                f32x4 a[FM], b[FN];
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    a[i] = *(const f32x4*)(lw + lds_off(crow0 + 16 * i, h * 4 + fg));
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    b[j] = *(const f32x4*)(lp + lds_off(prow0 + 16 * j, h * 4 + fg));
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int i = 0; i < FM; ++i)
+#pragma unroll
+                        for (int j = 0; j < FN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][t], b[j][t], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- main loop -----------------------------------------------------------------------------
+    load_global(0);
+    store_lds(0);
+    __syncthreads();
+    for (int step = 0; step < p.nsteps; ++step) {
+        const int cur = step & 1;
+        const bool more = step + 1 < p.nsteps;
+        if (more) load_global(step + 1);
+        compute(cur);
+        if (more) store_lds(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds 4 consecutive channels of one pixel per fragment -------------------
+    T* __restrict__ dst = (T*)p.dst;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const long m = m0 + wm * (BM / 2) + 16 * j + fr;
+        if (m >= p.Md) continue;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int ch = n0 + wn * (BN / 2) + 16 * i + fg * 4;
+            T* q = dst + m * p.Nd + ch;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (sizeof(T) == 4) {
+                if (p.accumulate) {
+                    const f32x4 o = *(const f32x4*)q;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) v[t] += o[t];
+                }
+                *(f32x4*)q = f32x4{v[0], v[1], v[2], v[3]};
+            } else {
+                if (p.accumulate) {
+                    const u32x2 o = *(const u32x2*)q;
+                    v[0] += __uint_as_float(o[0] << 16);
+                    v[1] += __uint_as_float(o[0] & 0xffff0000u);
+                    v[2] += __uint_as_float(o[1] << 16);
+                    v[3] += __uint_as_float(o[1] & 0xffff0000u);
+                }
+                u32x2 o;
+                o[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                o[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                *(u32x2*)q = o;
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN, bool DGRAD, bool STEM>
+static int launch_igemm(const IgemmParams& p, hipStream_t st) {
+    const int ntm = ceil_div(p.Md, BM);
+    IgemmParams q = p;
+    q.ntile_n = p.Nd / BN;
+    const int grid = ntm * q.ntile_n;
+    const size_t lds = 2 * (BM + BN) * 128;
+    auto kern = conv_igemm_kernel<T, BM, BN, DGRAD, STEM>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return PRIMIA_ERR_LAUNCH;
+    }
+    kern<<<grid, 256, lds, st>>>(q);
+    return launch_status();
+}
+
+template <typename T, bool DGRAD>
+static int dispatch_igemm(const IgemmParams& p, bool stem, hipStream_t st) {
+    if (stem) {
+        if (DGRAD) return PRIMIA_ERR_UNSUPPORTED;
+        return launch_igemm<T, 128, 64, false, true>(p, st);
+    }
+    if (p.Nd % 128 == 0) return launch_igemm<T, 128, 128, DGRAD, false>(p, st);
+    return launch_igemm<T, 128, 64, DGRAD, false>(p, st);
+}
+
+}  // namespace primia
+
+using namespace primia;
+
+extern "C" {
+
+int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
+                      int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && x && w_fwd && y);
+    ConvGeom g;
+    PRIMIA_REQUIRE(g.init(*d));
+    IgemmParams p;
+    p.src = x; p.wt = w_fwd; p.dst = y;
+    p.Nb = g.N; p.Hd = g.Ho; p.Wd = g.Wo; p.Nd = g.K;
+    p.Hs = g.H; p.Ws = g.W; p.Cs = g.C;
+    p.R = g.R; p.S = g.S; p.stride = g.stride; p.pad = g.pad;
+    p.klen = g.klen;
+    p.Md = (long)g.N * g.Ho * g.Wo;
+    p.accumulate = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32) {
+        p.nsteps = g.stem ? 7 : g.klen / 32;
+        return dispatch_igemm<float, false>(p, g.stem, st);
+    } else if (dtype == PRIMIA_BF16) {
+        p.nsteps = g.klen / 64;
+        return dispatch_igemm<bf16, false>(p, g.stem, st);
+    }
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                        int accumulate, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && dy && w_dgrad && dx);
+    ConvGeom g;
+    PRIMIA_REQUIRE(g.init(*d));
+    PRIMIA_REQUIRE(!g.stem && (g.stride == 1 || g.stride == 2));
+    IgemmParams p;
+    p.src = dy; p.wt = w_dgrad; p.dst = dx;
+    p.Nb = g.N; p.Hd = g.H; p.Wd = g.W; p.Nd = g.C;
+    p.Hs = g.Ho; p.Ws = g.Wo; p.Cs = g.K;
+    p.R = g.R; p.S = g.S; p.stride = g.stride; p.pad = g.pad;
+    p.klen = g.R * g.S * g.K;
+    p.Md = (long)g.N * g.H * g.W;
+    p.accumulate = accumulate;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32) {
+        p.nsteps = p.klen / 32;
+        return dispatch_igemm<float, true>(p, false, st);
+    } else if (dtype == PRIMIA_BF16) {
+        p.nsteps = p.klen / 64;
+        return dispatch_igemm<bf16, true>(p, false, st);
+    }
+    return PRIMIA_ERR_ARG;
+}
+
+}  // extern "C"

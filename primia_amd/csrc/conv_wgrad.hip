@@ -1,0 +1,290 @@
+// Weight-gradient convolution on gfx950 MFMA.
+//
+//   dw[k, (r,s,c)] += sum_m dy[m, k] * x[pix(m, r, s), c]        m = (n, ho, wo)
+//
+// GEMM view per kernel tap: D[64..128 out-chan][64..128 in-chan], reduction over pixels.  Both
+// operands are stored pixel-major (NHWC), i.e. the reduction index is the SLOW axis of both, so
+// the MFMA fragments (8 consecutive reduction elements per lane) need a transpose:
+//   bf16: tiles are staged to LDS as they are ([pixel][channel]) and read back with
+//         ds_read_b64_tr_b16 — each 16-lane group reads a 4-pixel x 16-channel block and every
+//         lane receives the 4 pixels of ITS channel; two reads give the 8 pixels of one MFMA
+//         operand (v_mfma_f32_16x16x32_bf16);
+//   f32 : v_mfma_f32_16x16x4_f32 takes one element per lane, read directly with ds_read_b32.
+// The pixel range is split over blocks (split-K); partial results are accumulated with fp32
+// atomics into a zeroed [K][klen] buffer (fwd weight layout, see conv_common.h).
+#include "conv_common.h"
+
+namespace primia {
+
+struct WgradParams {
+    const void* x;
+    const void* dy;
+    float* dw;
+    int N, H, W, C, K, R, S, stride, pad, Ho, Wo;
+    int klen;
+    long Md;           // N*Ho*Wo
+    int ntaps;         // R*S, or R for the stem
+    int nkt, nct;      // channel tiles
+    int nsplit;        // pixel splits
+    long pix_per_split;
+};
+
+template <typename T, int BMK, int BNC, bool STEM>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
+    constexpr int ES = sizeof(T);
+    constexpr int KP = (ES == 2) ? 64 : 32;  // pixels per step
+    constexpr int CH = 16 / ES;              // elements per 16-B chunk
+    constexpr int ROW_A = BMK * ES + 16;     // LDS row strides (bytes), padded
+    constexpr int ROW_B = BNC * ES + 16;
+    constexpr int CPR_A = BMK / CH, CPR_B = BNC / CH;  // chunks per row
+    constexpr int NA = (KP * CPR_A + 255) / 256;       // staged chunks per thread
+    constexpr int NB = (KP * CPR_B + 255) / 256;
+    constexpr int FM = BMK / 32, FN = BNC / 32;        // fragments per wave (2x2 waves)
+    static_assert(FN >= 1, "tile too small");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 * KP * (ROW_A + ROW_B) bytes
+    auto lds_a = [&](int buf) { return smem + buf * KP * (ROW_A + ROW_B); };
+    auto lds_b = [&](int buf) { return smem + buf * KP * (ROW_A + ROW_B) + KP * ROW_A; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 1, wn = wid & 1;
+
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = bid % p.nct; bid /= p.nct;
+    const int kt = bid % p.nkt; bid /= p.nkt;
+    const int tap = bid % p.ntaps;
+    const int split = bid / p.ntaps;
+    const int tr = STEM ? tap : tap / p.S;
+    const int ts = STEM ? 0 : tap - tr * p.S;
+
+    const long ms = (long)split * p.pix_per_split;
+    long me = ms + p.pix_per_split;
+    if (me > p.Md) me = p.Md;
+    const int nsteps = (int)((me - ms + KP - 1) / KP);
+
+    const T* __restrict__ x = (const T*)p.x;
+    const T* __restrict__ dy = (const T*)p.dy;
+
+    // ---- staging assignments -------------------------------------------------------------------
+    // A (dy): chunk id q = tid + 256*j -> pixel row q / CPR_A, chunk q % CPR_A.
+    // B (x):  same with CPR_B; needs the pixel's (n, ho, wo), tracked incrementally per step.
+    int b_row[NB], b_chunk[NB], b_wo[NB], b_ho[NB], b_n[NB];
+    bool b_use[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int q = tid + 256 * j;
+        b_use[j] = q < KP * CPR_B;
+        b_row[j] = q / CPR_B;
+        b_chunk[j] = q % CPR_B;
+        long m = ms + b_row[j];
+        if (m >= p.Md) m = p.Md - 1;
+        b_wo[j] = (int)(m % p.Wo);
+        long t = m / p.Wo;
+        b_ho[j] = (int)(t % p.Ho);
+        b_n[j] = (int)(t / p.Ho);
+    }
+
+    u32x4 ra[NA], rb[NB];
+
+    auto load_global = [&](int step) {
+        const long mb = ms + (long)step * KP;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int q = tid + 256 * j;
+            const int row = q / CPR_A, chunk = q % CPR_A;
+            const long m = mb + row;
+            u32x4 v = {0, 0, 0, 0};
+            if (q < KP * CPR_A && m < me) v = *(const u32x4*)(dy + m * p.K + kt * BMK + chunk * CH);
+            ra[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const long m = mb + b_row[j];
+            const bool ok = b_use[j] && m < me;
+            const int hs = b_ho[j] * p.stride - p.pad + tr;
+            u32x4 v = {0, 0, 0, 0};
+            if (STEM) {
+                // "channel" axis = 32 elements = 8 consecutive input pixels x 4 channels.
+                const int e0 = b_chunk[j] * CH;
+                const int ws = b_wo[j] * 2 - 3 + (e0 >> 2);
+                const bool rowok = ok && hs >= 0 && hs < p.H;
+                const long base = (((long)b_n[j] * p.H + hs) * p.W + ws) * 4;
+                if (ES == 4) {
+                    if (rowok && ws >= 0 && ws < p.W) v = *(const u32x4*)(x + base);
+                } else {
+                    u32x2 a = {0, 0}, b = {0, 0};
+                    if (rowok && ws >= 0 && ws < p.W) a = *(const u32x2*)(x + base);
+                    if (rowok && ws + 1 >= 0 && ws + 1 < p.W) b = *(const u32x2*)(x + base + 4);
+                    v = u32x4{a[0], a[1], b[0], b[1]};
+                }
+            } else {
+                const int ws = b_wo[j] * p.stride - p.pad + ts;
+                if (ok && hs >= 0 && hs < p.H && ws >= 0 && ws < p.W)
+                    v = *(const u32x4*)(x + (((long)b_n[j] * p.H + hs) * p.W + ws) * p.C + ct * BNC + b_chunk[j] * CH);
+            }
+            rb[j] = v;
+            // advance this row's pixel by KP for the next step
+            b_wo[j] += KP;
+            while (b_wo[j] >= p.Wo) {
+                b_wo[j] -= p.Wo;
+                if (++b_ho[j] == p.Ho) {
+                    b_ho[j] = 0;
+                    ++b_n[j];
+                }
+            }
+        }
+    };
+
+    auto store_lds = [&](int buf) {
+        char* la = lds_a(buf);
+        char* lb = lds_b(buf);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int q = tid + 256 * j;
+            if (q < KP * CPR_A) *(u32x4*)(la + (q / CPR_A) * ROW_A + (q % CPR_A) * 16) = ra[j];
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            if (b_use[j]) *(u32x4*)(lb + b_row[j] * ROW_B + b_chunk[j] * 16) = rb[j];
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int ca0 = wm * (BMK / 2), cb0 = wn * (BNC / 2);  // wave's channel offsets in the tiles
+
+    auto compute = [&](int buf) {
+        const char* la = lds_a(buf);
+        const char* lb = lds_b(buf);
+        if constexpr (ES == 2) {
+            // transpose-read: lane L of a 16-lane group supplies the address of pixel (L >> 2),
+            // channels 4*(L & 3)..+3 of the 4x16 block and receives the 4 pixels of channel L.
+            const int tp = fr >> 2, tc = (fr & 3) * 4;
+#pragma unroll
+            for (int kk = 0; kk < KP / 32; ++kk) {
+                bf16x8_t a[FM], b[FN];
+                const int prow = kk * 32 + fg * 8 + tp;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const char* q = la + prow * ROW_A + (ca0 + 16 * i + tc) * 2;
+                    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)q);
+                    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(q + 4 * ROW_A));
+                    a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    const char* q = lb + prow * ROW_B + (cb0 + 16 * j + tc) * 2;
+                    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)q);
+                    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(q + 4 * ROW_B));
+                    b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < KP / 4; ++t) {
+                float a[FM], b[FN];
+                const int prow = t * 4 + fg;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) a[i] = *(const float*)(la + prow * ROW_A + (ca0 + 16 * i + fr) * 4);
+#pragma unroll
+                for (int j = 0; j < FN; ++j) b[j] = *(const float*)(lb + prow * ROW_B + (cb0 + 16 * j + fr) * 4);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+
+    if (nsteps > 0) {
+        load_global(0);
+        store_lds(0);
+        __syncthreads();
+        for (int step = 0; step < nsteps; ++step) {
+            const int cur = step & 1;
+            const bool more = step + 1 < nsteps;
+            if (more) load_global(step + 1);
+            compute(cur);
+            if (more) store_lds(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- accumulate: lane holds rows (out-chan) fg*4+reg, column (in-chan) fr ---------------------
+    const int ebase = STEM ? tr * 32 : tap * p.C + ct * BNC;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = kt * BMK + ca0 + 16 * i + fg * 4 + r;
+                const int e = ebase + cb0 + 16 * j + fr;
+                unsafeAtomicAdd(p.dw + (long)k * p.klen + e, acc[i][j][r]);
+            }
+}
+
+template <typename T, int BMK, int BNC, bool STEM>
+static int launch_wgrad(WgradParams p, hipStream_t st) {
+    constexpr int KP = (sizeof(T) == 2) ? 64 : 32;
+    p.nkt = p.K / BMK;
+    p.nct = STEM ? 1 : p.C / BNC;
+    const int combos = p.ntaps * p.nkt * p.nct;
+    // enough blocks to fill 256 CUs a few times over, but at least 8 steps per block
+    long want = (4 * 256 + combos - 1) / combos;
+    long max_split = (p.Md + 8 * KP - 1) / (8 * KP);
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    long pps = (p.Md + want - 1) / want;
+    pps = (pps + KP - 1) / KP * KP;
+    p.pix_per_split = pps;
+    p.nsplit = (int)((p.Md + pps - 1) / pps);
+    const int grid = combos * p.nsplit;
+    const size_t lds = 2 * KP * ((BMK + BNC) * sizeof(T) + 32);
+    auto kern = conv_wgrad_kernel<T, BMK, BNC, STEM>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return PRIMIA_ERR_LAUNCH;
+    }
+    kern<<<grid, 256, lds, st>>>(p);
+    return launch_status();
+}
+
+}  // namespace primia
+
+using namespace primia;
+
+extern "C" int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy,
+                                   float* dw_acc, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && x && dy && dw_acc);
+    ConvGeom g;
+    PRIMIA_REQUIRE(g.init(*d));
+    WgradParams p;
+    p.x = x; p.dy = dy; p.dw = dw_acc;
+    p.N = g.N; p.H = g.H; p.W = g.W; p.C = g.C; p.K = g.K; p.R = g.R; p.S = g.S;
+    p.stride = g.stride; p.pad = g.pad; p.Ho = g.Ho; p.Wo = g.Wo;
+    p.klen = g.klen;
+    p.Md = (long)g.N * g.Ho * g.Wo;
+    p.ntaps = g.stem ? g.R : g.R * g.S;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32) {
+        if (g.stem) return launch_wgrad<float, 64, 32, true>(p, st);
+        if (g.K % 128 == 0 && g.C % 128 == 0) return launch_wgrad<float, 128, 128, false>(p, st);
+        return launch_wgrad<float, 64, 64, false>(p, st);
+    } else if (dtype == PRIMIA_BF16) {
+        if (g.stem) return launch_wgrad<bf16, 64, 32, true>(p, st);
+        if (g.K % 128 == 0 && g.C % 128 == 0) return launch_wgrad<bf16, 128, 128, false>(p, st);
+        return launch_wgrad<bf16, 64, 64, false>(p, st);
+    }
+    return PRIMIA_ERR_ARG;
+}

@@ -1,0 +1,211 @@
+// Boundary layout conversions: NCHW fp32 <-> NHWC compute dtype, OIHW fp32 master weights ->
+// compute-dtype implicit-GEMM layouts, and the wgrad accumulator -> OIHW gradient transpose.
+// All HBM-bound; sizes here are tiny next to the activations (11 M weights, one input batch).
+#include "common.h"
+#include "conv_common.h"
+
+namespace primia {
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src,
+                                                           T* __restrict__ dst, int C, int HW,
+                                                           int c_pad, long total) {
+    // One thread per (n, hw): reads C strided values (coalesced across hw), writes c_pad contiguous.
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long n = i / HW;
+    long hw = i - n * HW;
+    const float* s = src + n * (long)C * HW + hw;
+    T* d = dst + i * c_pad;
+    for (int c = 0; c < c_pad; ++c) Elem<T>::store(d + c, c < C ? s[(long)c * HW] : 0.f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src,
+                                                           float* __restrict__ dst, int C, int HW,
+                                                           int c_pad, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    long n = i / HW;
+    long hw = i - n * HW;
+    const T* s = src + i * c_pad;
+    float* d = dst + n * (long)C * HW + hw;
+    for (int c = 0; c < C; ++c) d[(long)c * HW] = Elem<T>::load(s + c);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void cast_from_f32_kernel(const float* __restrict__ src,
+                                                            T* __restrict__ dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) Elem<T>::store(dst + i, src[i]);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void cast_to_f32_kernel(const T* __restrict__ src,
+                                                          float* __restrict__ dst, long n) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long stride = (long)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) dst[i] = Elem<T>::load(src + i);
+}
+
+// One thread per element of the fwd-layout copy [K][klen] (klen includes zero padding).
+template <typename T>
+__global__ __launch_bounds__(256) void weight_fwd_kernel(const float* __restrict__ w_oihw,
+                                                         T* __restrict__ w_fwd, ConvGeom g,
+                                                         int c_real, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int k = (int)(i / g.klen);
+    int e = (int)(i - (long)k * g.klen);
+    int r, s, c;
+    g.decode_k(e, r, s, c);
+    float v = 0.f;
+    if (r < g.R && s < g.S && c < c_real)
+        v = w_oihw[(((long)k * c_real + c) * g.R + r) * g.S + s];
+    Elem<T>::store(w_fwd + i, v);
+}
+
+// dgrad layout [C][R][S][K]: one thread per element.
+template <typename T>
+__global__ __launch_bounds__(256) void weight_dgrad_kernel(const float* __restrict__ w_oihw,
+                                                           T* __restrict__ w_dg, int K, int C,
+                                                           int R, int S, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int k = (int)(i % K);
+    long t = i / K;
+    int s = (int)(t % S);
+    t /= S;
+    int r = (int)(t % R);
+    int c = (int)(t / R);
+    Elem<T>::store(w_dg + i, w_oihw[(((long)k * C + c) * R + r) * S + s]);
+}
+
+// dw_oihw[k][c][r][s] = dw_acc[k][e(r,s,c)].
+__global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __restrict__ dw_acc,
+                                                             float* __restrict__ dw_oihw,
+                                                             ConvGeom g, int c_real, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    int s = (int)(i % g.S);
+    long t = i / g.S;
+    int r = (int)(t % g.R);
+    t /= g.R;
+    int c = (int)(t % c_real);
+    int k = (int)(t / c_real);
+    dw_oihw[i] = dw_acc[(long)k * g.klen + g.encode_k(r, s, c)];
+}
+
+}  // namespace primia
+
+using namespace primia;
+
+extern "C" {
+
+int primia_abi_version(void) { return 1; }
+
+int primia_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W, int c_pad,
+                        int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && c_pad >= C);
+    long total = (long)N * H * W;
+    dim3 grid(ceil_div(total, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        nchw_to_nhwc_kernel<float><<<grid, block, 0, st>>>(src, (float*)dst, C, H * W, c_pad, total);
+    else if (dtype == PRIMIA_BF16)
+        nchw_to_nhwc_kernel<bf16><<<grid, block, 0, st>>>(src, (bf16*)dst, C, H * W, c_pad, total);
+    else
+        return PRIMIA_ERR_ARG;
+    return launch_status();
+}
+
+int primia_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W, int c_pad,
+                        int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && c_pad >= C);
+    long total = (long)N * H * W;
+    dim3 grid(ceil_div(total, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        nhwc_to_nchw_kernel<float><<<grid, block, 0, st>>>((const float*)src, dst, C, H * W, c_pad, total);
+    else if (dtype == PRIMIA_BF16)
+        nhwc_to_nchw_kernel<bf16><<<grid, block, 0, st>>>((const bf16*)src, dst, C, H * W, c_pad, total);
+    else
+        return PRIMIA_ERR_ARG;
+    return launch_status();
+}
+
+int primia_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(src && dst && n >= 0);
+    if (n == 0) return PRIMIA_OK;
+    int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        cast_from_f32_kernel<float><<<blocks, 256, 0, st>>>(src, (float*)dst, n);
+    else if (dtype == PRIMIA_BF16)
+        cast_from_f32_kernel<bf16><<<blocks, 256, 0, st>>>(src, (bf16*)dst, n);
+    else
+        return PRIMIA_ERR_ARG;
+    return launch_status();
+}
+
+int primia_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(src && dst && n >= 0);
+    if (n == 0) return PRIMIA_OK;
+    int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        cast_to_f32_kernel<float><<<blocks, 256, 0, st>>>((const float*)src, dst, n);
+    else if (dtype == PRIMIA_BF16)
+        cast_to_f32_kernel<bf16><<<blocks, 256, 0, st>>>((const bf16*)src, dst, n);
+    else
+        return PRIMIA_ERR_ARG;
+    return launch_status();
+}
+
+int64_t primia_conv_wfwd_elems(const primia_conv_desc* d) {
+    if (!d) return PRIMIA_ERR_ARG;
+    ConvGeom g;
+    if (!g.init(*d)) return PRIMIA_ERR_ARG;
+    return (int64_t)d->K * g.klen;
+}
+
+int64_t primia_conv_wdgrad_elems(const primia_conv_desc* d) {
+    if (!d) return PRIMIA_ERR_ARG;
+    return (int64_t)d->C * d->R * d->S * d->K;
+}
+
+int primia_conv_weight_prepare(const primia_conv_desc* d, int c_real, const float* w_oihw,
+                               void* w_fwd, void* w_dgrad, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && w_oihw && w_fwd && c_real > 0 && c_real <= d->C);
+    ConvGeom g;
+    PRIMIA_REQUIRE(g.init(*d));
+    hipStream_t st = (hipStream_t)stream;
+    long total = (long)d->K * g.klen;
+    if (dtype == PRIMIA_F32)
+        weight_fwd_kernel<float><<<ceil_div(total, 256), 256, 0, st>>>(w_oihw, (float*)w_fwd, g, c_real, total);
+    else if (dtype == PRIMIA_BF16)
+        weight_fwd_kernel<bf16><<<ceil_div(total, 256), 256, 0, st>>>(w_oihw, (bf16*)w_fwd, g, c_real, total);
+    else
+        return PRIMIA_ERR_ARG;
+    if (w_dgrad) {
+        PRIMIA_REQUIRE(!g.stem && c_real == d->C);
+        long t2 = (long)d->C * d->R * d->S * d->K;
+        if (dtype == PRIMIA_F32)
+            weight_dgrad_kernel<float><<<ceil_div(t2, 256), 256, 0, st>>>(w_oihw, (float*)w_dgrad, d->K, d->C, d->R, d->S, t2);
+        else
+            weight_dgrad_kernel<bf16><<<ceil_div(t2, 256), 256, 0, st>>>(w_oihw, (bf16*)w_dgrad, d->K, d->C, d->R, d->S, t2);
+    }
+    return launch_status();
+}
+
+int primia_conv_wgrad_finalize(const primia_conv_desc* d, int c_real, const float* dw_acc,
+                               float* dw_oihw, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && dw_acc && dw_oihw && c_real > 0 && c_real <= d->C);
+    ConvGeom g;
+    PRIMIA_REQUIRE(g.init(*d));
+    long total = (long)d->K * c_real * d->R * d->S;
+    wgrad_finalize_kernel<<<ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(dw_acc, dw_oihw, g, c_real, total);
+    return launch_status();
+}
+
+}  // extern "C"

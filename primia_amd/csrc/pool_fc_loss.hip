@@ -1,0 +1,378 @@
+// Pooling, classifier head and cross-entropy kernels (NHWC).  All are small next to the
+// convolutions: the 3x3/2 pools stream the stem activation once with 16-byte accesses, the head
+// works on [N, 512] fp32 features.
+#include "common.h"
+
+namespace primia {
+
+// ---- 3x3 stride-2 pad-1 pooling ----------------------------------------------------------------
+// One thread per (output pixel, 16-byte channel chunk).  Max: window scanned r-major with a strict
+// '>' so the FIRST maximum wins (at::max_pool2d semantics); its position r*3+s is kept as one
+// byte per element for the backward pass.
+template <typename T, bool IS_MAX>
+__global__ __launch_bounds__(256) void pool3x3s2_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                            uint8_t* __restrict__ argmax, int N, int H,
+                                                            int W, int C, int Ho, int Wo) {
+    constexpr int CH = Chunk<T>::N;
+    const int cpr = C / CH;
+    const long total = (long)N * Ho * Wo * cpr;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int cc = (int)(q % cpr);
+    long t = q / cpr;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    float best[CH];
+    int pos[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        best[i] = IS_MAX ? -INFINITY : 0.f;
+        pos[i] = -1;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int h = ho * 2 - 1 + r;
+        if (h < 0 || h >= H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int w = wo * 2 - 1 + s;
+            if (w < 0 || w >= W) continue;
+            float v[CH];
+            Chunk<T>::unpack(*(const u32x4*)(x + (((long)n * H + h) * W + w) * C + cc * CH), v);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (IS_MAX) {
+                    if (pos[i] < 0 || v[i] > best[i] || v[i] != v[i]) {
+                        best[i] = v[i];
+                        pos[i] = r * 3 + s;
+                    }
+                } else {
+                    best[i] += v[i];
+                }
+            }
+        }
+    }
+    if (!IS_MAX) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) best[i] *= (1.f / 9.f);  // count_include_pad=True
+    }
+    const long o = (((long)n * Ho + ho) * Wo + wo) * C + cc * CH;
+    *(u32x4*)(y + o) = Chunk<T>::pack(best);
+    if (IS_MAX) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) argmax[o + i] = (uint8_t)pos[i];
+    }
+}
+
+// Gather form: each input pixel sums the gradients of the (<= 4) windows that selected it.
+template <typename T, bool IS_MAX>
+__global__ __launch_bounds__(256) void pool3x3s2_bwd_kernel(const T* __restrict__ dy,
+                                                            const uint8_t* __restrict__ argmax,
+                                                            T* __restrict__ dx, int N, int H, int W, int C,
+                                                            int Ho, int Wo) {
+    constexpr int CH = Chunk<T>::N;
+    const int cpr = C / CH;
+    const long total = (long)N * H * W * cpr;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int cc = (int)(q % cpr);
+    long t = q / cpr;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float g[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) g[i] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int th = h + 1 - r;
+        if (th < 0 || (th & 1)) continue;
+        const int ho = th >> 1;
+        if (ho >= Ho) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int tw = w + 1 - s;
+            if (tw < 0 || (tw & 1)) continue;
+            const int wo = tw >> 1;
+            if (wo >= Wo) continue;
+            const long o = (((long)n * Ho + ho) * Wo + wo) * C + cc * CH;
+            float v[CH];
+            Chunk<T>::unpack(*(const u32x4*)(dy + o), v);
+            if (IS_MAX) {
+                // CH bytes of argmax codes
+                uint8_t code[CH];
+                if (CH == 8) {
+                    const u32x2 a = *(const u32x2*)(argmax + o);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        code[i] = (uint8_t)(a[0] >> (8 * i));
+                        code[4 + i] = (uint8_t)(a[1] >> (8 * i));
+                    }
+                } else {
+                    const uint32_t a = *(const uint32_t*)(argmax + o);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) code[i] = (uint8_t)(a >> (8 * i));
+                }
+#pragma unroll
+                for (int i = 0; i < CH; ++i)
+                    if (code[i] == r * 3 + s) g[i] += v[i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) g[i] += v[i] * (1.f / 9.f);
+            }
+        }
+    }
+    *(u32x4*)(dx + (((long)n * H + h) * W + w) * C + cc * CH) = Chunk<T>::pack(g);
+}
+
+// ---- global average pool: x[N, HW, C] -> feat[N, C] fp32 -----------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* __restrict__ x, float* __restrict__ feat,
+                                                      int HW, int C) {
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int p = 0; p < HW; ++p) s += Elem<T>::load(x + ((long)n * HW + p) * C + c);
+        feat[(long)n * C + c] = s / (float)HW;
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* __restrict__ dfeat, T* __restrict__ dx,
+                                                      int HW, int C, long total) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int c = (int)(i % C);
+    const long n = i / ((long)HW * C);
+    Elem<T>::store(dx + i, dfeat[n * C + c] / (float)HW);
+}
+
+// ---- linear --------------------------------------------------------------------------------------
+// One wave per sample; lanes stride the input features.
+__global__ __launch_bounds__(64) void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        const float* __restrict__ b, float* __restrict__ y,
+                                                        int in_f, int out_f) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    for (int j = 0; j < out_f; ++j) {
+        float s = 0.f;
+        for (int i = lane; i < in_f; i += 64) s += x[(long)n * in_f + i] * w[(long)j * in_f + i];
+        s = wave_sum(s);
+        if (lane == 0) y[(long)n * out_f + j] = s + (b ? b[j] : 0.f);
+    }
+}
+// dx[n][i] = sum_j dy[n][j] w[j][i]
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restrict__ w,
+                                                            const float* __restrict__ dy,
+                                                            float* __restrict__ dx, int N, int in_f,
+                                                            int out_f) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * in_f) return;
+    const int f = (int)(i % in_f);
+    const long n = i / in_f;
+    float s = 0.f;
+    for (int j = 0; j < out_f; ++j) s += dy[n * out_f + j] * w[(long)j * in_f + f];
+    dx[i] = s;
+}
+// dw[j][i] = sum_n dy[n][j] x[n][i]; db[j] = sum_n dy[n][j]  (thread per (j, i); i == in_f -> bias)
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ dy,
+                                                            float* __restrict__ dw, float* __restrict__ db,
+                                                            int N, int in_f, int out_f) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)out_f * (in_f + 1)) return;
+    const int j = (int)(t / (in_f + 1));
+    const int i = (int)(t % (in_f + 1));
+    float s = 0.f;
+    if (i < in_f) {
+        for (int n = 0; n < N; ++n) s += dy[(long)n * out_f + j] * x[(long)n * in_f + i];
+        dw[(long)j * in_f + i] = s;
+    } else if (db) {
+        for (int n = 0; n < N; ++n) s += dy[(long)n * out_f + j];
+        db[j] = s;
+    }
+}
+
+// ---- cross entropy (single block; N is a batch size) ---------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* sh) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    const float r = sh[0] + sh[1] + sh[2] + sh[3];
+    __syncthreads();
+    return r;
+}
+
+constexpr int kMaxClasses = 16;
+
+template <bool SOFT>
+__global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ logits, const void* target,
+                                                   const float* __restrict__ cw, float* __restrict__ loss,
+                                                   float* __restrict__ dlogits, int N, int C) {
+    __shared__ float sh[4];
+    // pass 1: weighted loss numerator and (hard) the weight normaliser
+    float num = 0.f, den = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* o = logits + (long)n * C;
+        float mx = o[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, o[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(o[c] - mx);
+        const float lse = mx + logf(se);
+        if (SOFT) {
+            const float* t = (const float*)target + (long)n * C;
+            float a = cw ? 0.f : 1.f, l = 0.f;
+            for (int c = 0; c < C; ++c) {
+                if (cw) a += cw[c] * t[c];
+                l -= t[c] * (o[c] - lse);
+            }
+            num += a * l;
+        } else {
+            const int t = (int)((const int64_t*)target)[n];
+            const float wt = cw ? cw[t] : 1.f;
+            num += wt * (lse - o[t]);
+            den += wt;
+        }
+    }
+    num = block_sum_256(num, sh);
+    den = SOFT ? (float)N : block_sum_256(den, sh);
+    if (threadIdx.x == 0) loss[0] = num / den;
+    if (!dlogits) return;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        const float* o = logits + (long)n * C;
+        float mx = o[0];
+        for (int c = 1; c < C; ++c) mx = fmaxf(mx, o[c]);
+        float se = 0.f;
+        for (int c = 0; c < C; ++c) se += expf(o[c] - mx);
+        const float inv = 1.f / se;
+        if (SOFT) {
+            const float* t = (const float*)target + (long)n * C;
+            float a = cw ? 0.f : 1.f, ts = 0.f;
+            for (int c = 0; c < C; ++c) {
+                if (cw) a += cw[c] * t[c];
+                ts += t[c];
+            }
+            for (int c = 0; c < C; ++c)
+                dlogits[(long)n * C + c] = a / den * (expf(o[c] - mx) * inv * ts - t[c]);
+        } else {
+            const int t = (int)((const int64_t*)target)[n];
+            const float wt = (cw ? cw[t] : 1.f) / den;
+            for (int c = 0; c < C; ++c)
+                dlogits[(long)n * C + c] = wt * (expf(o[c] - mx) * inv - (c == t ? 1.f : 0.f));
+        }
+    }
+}
+
+template <typename T>
+static int pool_launch(bool is_max, bool fwd, const void* a, void* b, uint8_t* argmax, int N, int H, int W,
+                       int C, hipStream_t st) {
+    constexpr int CH = Chunk<T>::N;
+    if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % CH) return PRIMIA_ERR_ARG;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * (fwd ? (long)Ho * Wo : (long)H * W) * (C / CH);
+    const int grid = ceil_div(total, 256);
+    if (fwd) {
+        if (is_max)
+            pool3x3s2_fwd_kernel<T, true><<<grid, 256, 0, st>>>((const T*)a, (T*)b, argmax, N, H, W, C, Ho, Wo);
+        else
+            pool3x3s2_fwd_kernel<T, false><<<grid, 256, 0, st>>>((const T*)a, (T*)b, nullptr, N, H, W, C, Ho, Wo);
+    } else {
+        if (is_max)
+            pool3x3s2_bwd_kernel<T, true><<<grid, 256, 0, st>>>((const T*)a, argmax, (T*)b, N, H, W, C, Ho, Wo);
+        else
+            pool3x3s2_bwd_kernel<T, false><<<grid, 256, 0, st>>>((const T*)a, nullptr, (T*)b, N, H, W, C, Ho, Wo);
+    }
+    return launch_status();
+}
+
+}  // namespace primia
+
+using namespace primia;
+
+extern "C" {
+
+int primia_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int N, int H, int W, int C,
+                            int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && y && argmax);
+    if (dtype == PRIMIA_F32) return pool_launch<float>(true, true, x, y, argmax, N, H, W, C, (hipStream_t)stream);
+    if (dtype == PRIMIA_BF16) return pool_launch<bf16>(true, true, x, y, argmax, N, H, W, C, (hipStream_t)stream);
+    return PRIMIA_ERR_ARG;
+}
+int primia_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int N, int H, int W,
+                            int C, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(dy && dx && argmax);
+    if (dtype == PRIMIA_F32) return pool_launch<float>(true, false, dy, dx, (uint8_t*)argmax, N, H, W, C, (hipStream_t)stream);
+    if (dtype == PRIMIA_BF16) return pool_launch<bf16>(true, false, dy, dx, (uint8_t*)argmax, N, H, W, C, (hipStream_t)stream);
+    return PRIMIA_ERR_ARG;
+}
+int primia_avgpool3x3s2_fwd(const void* x, void* y, int N, int H, int W, int C, int dtype,
+                            primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && y);
+    if (dtype == PRIMIA_F32) return pool_launch<float>(false, true, x, y, nullptr, N, H, W, C, (hipStream_t)stream);
+    if (dtype == PRIMIA_BF16) return pool_launch<bf16>(false, true, x, y, nullptr, N, H, W, C, (hipStream_t)stream);
+    return PRIMIA_ERR_ARG;
+}
+int primia_avgpool3x3s2_bwd(const void* dy, void* dx, int N, int H, int W, int C, int dtype,
+                            primia_stream_t stream) {
+    PRIMIA_REQUIRE(dy && dx);
+    if (dtype == PRIMIA_F32) return pool_launch<float>(false, false, dy, dx, nullptr, N, H, W, C, (hipStream_t)stream);
+    if (dtype == PRIMIA_BF16) return pool_launch<bf16>(false, false, dy, dx, nullptr, N, H, W, C, (hipStream_t)stream);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_global_avgpool_fwd(const void* x, float* feat, int N, int HW, int C, int dtype,
+                              primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && feat && N > 0 && HW > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        gap_fwd_kernel<float><<<N, 256, 0, st>>>((const float*)x, feat, HW, C);
+    else if (dtype == PRIMIA_BF16)
+        gap_fwd_kernel<bf16><<<N, 256, 0, st>>>((const bf16*)x, feat, HW, C);
+    else
+        return PRIMIA_ERR_ARG;
+    return launch_status();
+}
+int primia_global_avgpool_bwd(const float* dfeat, void* dx, int N, int HW, int C, int dtype,
+                              primia_stream_t stream) {
+    PRIMIA_REQUIRE(dfeat && dx && N > 0 && HW > 0 && C > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const long total = (long)N * HW * C;
+    if (dtype == PRIMIA_F32)
+        gap_bwd_kernel<float><<<ceil_div(total, 256), 256, 0, st>>>(dfeat, (float*)dx, HW, C, total);
+    else if (dtype == PRIMIA_BF16)
+        gap_bwd_kernel<bf16><<<ceil_div(total, 256), 256, 0, st>>>(dfeat, (bf16*)dx, HW, C, total);
+    else
+        return PRIMIA_ERR_ARG;
+    return launch_status();
+}
+
+int primia_linear_fwd(const float* x, const float* w, const float* b, float* y, int N, int in_f,
+                      int out_f, primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && w && y && N > 0 && in_f > 0 && out_f > 0);
+    linear_fwd_kernel<<<N, 64, 0, (hipStream_t)stream>>>(x, w, b, y, in_f, out_f);
+    return launch_status();
+}
+int primia_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
+                      float* db, int N, int in_f, int out_f, primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && w && dy && dw && N > 0 && in_f > 0 && out_f > 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (dx) linear_bwd_dx_kernel<<<ceil_div((long)N * in_f, 256), 256, 0, st>>>(w, dy, dx, N, in_f, out_f);
+    linear_bwd_dw_kernel<<<ceil_div((long)out_f * (in_f + 1), 256), 256, 0, st>>>(x, dy, dw, db, N, in_f, out_f);
+    return launch_status();
+}
+
+int primia_xent_hard(const float* logits, const int64_t* target, const float* class_weight,
+                     float* loss, float* dlogits, int N, int C, primia_stream_t stream) {
+    PRIMIA_REQUIRE(logits && target && loss && N > 0 && C > 0);
+    xent_kernel<false><<<1, 256, 0, (hipStream_t)stream>>>(logits, target, class_weight, loss, dlogits, N, C);
+    return launch_status();
+}
+int primia_xent_soft(const float* logits, const float* target, const float* class_weight,
+                     float* loss, float* dlogits, int N, int C, primia_stream_t stream) {
+    PRIMIA_REQUIRE(logits && target && loss && N > 0 && C > 0);
+    xent_kernel<true><<<1, 256, 0, (hipStream_t)stream>>>(logits, target, class_weight, loss, dlogits, N, C);
+    return launch_status();
+}
+
+}  // extern "C"

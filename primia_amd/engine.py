@@ -1,0 +1,382 @@
+"""Device-side ResNet-18 training engine: one federated client = one GPU.
+
+Replaces what a PySyft worker executes natively for one plaintext training step
+(SURVEY.md §8b "commands one worker receives per step"; reference call site
+torchlib/utils.py:1168-1174): forward, loss, backward and the optimizer step, all as HIP kernels
+called through the C ABI of libprimia_hip.so.  torch is used for device memory, streams and (in
+primia_amd.fed) torch.distributed — never for arithmetic.
+
+Memory layout (all on one GPU):
+  flat   fp32 [P + B]   parameters in reference named_parameters() order (OIHW conv weights), then
+                        the BatchNorm running_mean/var buffers — exactly the 11,187,651 elements
+                        FedAvg exchanges (torchlib/utils.py:1000-1092)
+  grads  fp32 [P]       same order as the parameter part of `flat`
+  per conv: compute-dtype weight copies in the implicit-GEMM layouts (+ fp32 wgrad accumulator)
+  activations / gradients: NHWC tensors in the compute dtype (bf16 for throughput, fp32 for parity)
+"""
+from collections import OrderedDict
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, call, query
+from .resnet_spec import NetSpec, bn_name, buffer_entries, init_state_dict, param_entries, resnet18_spec, state_dict_keys
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+class _Conv:
+    def __init__(self, spec, desc, c_real):
+        self.spec, self.desc, self.c_real = spec, desc, c_real
+
+
+class ResNet18Engine:
+    def __init__(self, batch_size, num_classes=3, in_channels=3, input_size=224, pooling="max",
+                 dtype=torch.bfloat16, device="cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.PrimiaError("ResNet18Engine needs a GPU (HIP kernels only, no CPU fallback)")
+        _lib.lib()
+        self.spec: NetSpec = resnet18_spec(num_classes, in_channels, input_size, pooling)
+        self.N = int(batch_size)
+        self.dtype = dtype
+        self.dt = _lib.dtype_code(dtype)
+        self.device = torch.device(device)
+        self.training = True
+        dev = self.device
+
+        # ---- flat arenas ---------------------------------------------------------------------
+        self.p_entries = param_entries(self.spec)
+        self.b_entries = buffer_entries(self.spec)
+        self.P = sum(int(torch.Size(s).numel()) for _, s in self.p_entries)
+        self.B = sum(int(torch.Size(s).numel()) for _, s in self.b_entries)
+        self.flat = torch.zeros(self.P + self.B, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(self.P, dtype=torch.float32, device=dev)
+        self.views, self.gviews = {}, {}
+        off = 0
+        for k, s in self.p_entries:
+            n = int(torch.Size(s).numel())
+            self.views[k] = self.flat[off:off + n].view(s)
+            self.gviews[k] = self.grads[off:off + n].view(s)
+            off += n
+        for k, s in self.b_entries:
+            n = int(torch.Size(s).numel())
+            self.views[k] = self.flat[off:off + n].view(s)
+            off += n
+        self.num_batches_tracked = {bn_name(c.name): 0 for c in self.spec.convs}
+        self.opt_state = None  # Adam moments, created lazily
+        self.opt_steps = 0
+
+        # ---- conv descriptors, weight copies --------------------------------------------------
+        N = self.N
+        self.convs = {}
+        H = input_size
+        stem = self.spec.stem
+        if in_channels > 4:
+            raise _lib.PrimiaError("stem supports in_channels <= 4")
+        self.convs[stem.name] = _Conv(stem, ConvDesc.make(N, H, H, 4, 64, 7, 7, 2, 3), in_channels)
+        H = self.convs[stem.name].desc.Ho  # 112
+        self.stem_hw = H
+        H = (H + 2 - 3) // 2 + 1           # 56 after the 3x3/2 pool
+        self.pool_hw = H
+        for blk in self.spec.blocks:
+            c1 = blk.conv1
+            d1 = ConvDesc.make(N, H, H, c1.cin, c1.cout, 3, 3, c1.stride, 1)
+            self.convs[c1.name] = _Conv(c1, d1, c1.cin)
+            if blk.down is not None:
+                dd = ConvDesc.make(N, H, H, blk.down.cin, blk.down.cout, 1, 1, blk.down.stride, 0)
+                self.convs[blk.down.name] = _Conv(blk.down, dd, blk.down.cin)
+            H = d1.Ho
+            c2 = blk.conv2
+            self.convs[c2.name] = _Conv(c2, ConvDesc.make(N, H, H, c2.cin, c2.cout, 3, 3, 1, 1), c2.cin)
+        self.final_hw = H
+        if self.final_hw != input_size // 32:
+            raise _lib.PrimiaError("input_size must be a multiple of 32")
+
+        acc_total = 0
+        for c in self.convs.values():
+            c.wfwd_n = query("primia_conv_wfwd_elems", c.desc)
+            c.acc_off = acc_total
+            acc_total += (c.wfwd_n + 3) // 4 * 4
+        self.dw_acc = torch.zeros(acc_total, dtype=torch.float32, device=dev)
+        for c in self.convs.values():
+            c.w_fwd = torch.empty(c.wfwd_n, dtype=dtype, device=dev)
+            c.w_dgrad = None
+            if c.spec.name != stem.name:
+                c.w_dgrad = torch.empty(query("primia_conv_wdgrad_elems", c.desc), dtype=dtype, device=dev)
+            c.acc = self.dw_acc[c.acc_off:c.acc_off + c.wfwd_n]
+
+        # ---- activations ------------------------------------------------------------------------
+        def act(hw, ch):
+            return torch.empty(N * hw * hw, ch, dtype=dtype, device=dev)
+
+        self.x0 = torch.empty(N * input_size * input_size, 4, dtype=dtype, device=dev)
+        self.t = {}  # named tensors
+        t = self.t
+        t["stem.y"] = act(self.stem_hw, 64)
+        t["stem.z"] = act(self.stem_hw, 64)
+        t["stem.dz"] = act(self.stem_hw, 64)
+        t["stem.dy"] = act(self.stem_hw, 64)
+        t["pool.out"] = act(self.pool_hw, 64)
+        self.pool_argmax = torch.empty(N * self.pool_hw * self.pool_hw * 64, dtype=torch.uint8, device=dev)
+        for blk in self.spec.blocks:
+            p = blk.prefix
+            d1 = self.convs[blk.conv1.name].desc
+            hw, ch = d1.Ho, blk.conv1.cout
+            for nm in ("y1", "a1", "y2", "out", "dy1", "da1", "dy2"):
+                t[f"{p}.{nm}"] = act(hw, ch)
+            if blk.down is not None:
+                for nm in ("yd", "idn", "dyd"):
+                    t[f"{p}.{nm}"] = act(hw, ch)
+        # Gradient w.r.t. each block's output.  An identity block accumulates its input gradient in
+        # place (masked residual gradient + conv1 dgrad), so its input-gradient buffer IS its own
+        # `dout`; a projection block gets a fresh buffer of the input's shape.
+        blocks = self.spec.blocks
+        for i in range(len(blocks) - 1, -1, -1):
+            blk = blocks[i]
+            d1 = self.convs[blk.conv1.name].desc
+            key = blk.prefix + ".dout"
+            if key not in t:
+                t[key] = act(d1.Ho, blk.conv1.cout)
+            din = t[key] if blk.down is None else act(d1.H, blk.conv1.cin)
+            t[(blocks[i - 1].prefix + ".dout") if i > 0 else "pool.dout"] = din
+        self.save = {}
+        for c in self.spec.convs:
+            b = bn_name(c.name)
+            self.save[b] = (torch.empty(c.cout, dtype=torch.float32, device=dev),
+                            torch.empty(c.cout, dtype=torch.float32, device=dev))
+        self.bn_ws_bytes = query("primia_bn_workspace_bytes", 1, 512)
+        self.bn_ws = torch.empty(self.bn_ws_bytes, dtype=torch.uint8, device=dev)
+        self.feat = torch.empty(N, 512, dtype=torch.float32, device=dev)
+        self.dfeat = torch.empty(N, 512, dtype=torch.float32, device=dev)
+        self.logits = torch.empty(N, num_classes, dtype=torch.float32, device=dev)
+        self.dlogits = torch.empty(N, num_classes, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.class_weight = None  # optional fp32 [classes] device tensor (CrossEntropyLoss weight)
+
+    # ------------------------------------------------------------------------------------------
+    # state
+    # ------------------------------------------------------------------------------------------
+    def init_weights(self):
+        """Draw fresh weights from the global torch RNG the way the reference constructor does."""
+        self.load_state_dict(init_state_dict(self.spec))
+
+    def state_dict(self):
+        """Reference-compatible state dict (CPU tensors, OIHW, 122 keys incl. num_batches_tracked)."""
+        host = self.flat.detach().cpu()
+        sd = OrderedDict()
+        off = {}
+        o = 0
+        for k, s in self.p_entries + self.b_entries:
+            n = int(torch.Size(s).numel())
+            off[k] = (o, n, s)
+            o += n
+        for k in state_dict_keys(self.spec):
+            if k.endswith("num_batches_tracked"):
+                sd[k] = torch.tensor(self.num_batches_tracked[k.rsplit(".", 1)[0]], dtype=torch.long)
+            else:
+                o, n, s = off[k]
+                sd[k] = host[o:o + n].view(s).clone()
+        return sd
+
+    def load_state_dict(self, sd):
+        keys = state_dict_keys(self.spec)
+        missing = [k for k in keys if k not in sd]
+        extra = [k for k in sd if k not in keys]
+        if missing or extra:
+            raise KeyError(f"state_dict mismatch: missing {missing[:3]} unexpected {extra[:3]}")
+        for k in keys:
+            if k.endswith("num_batches_tracked"):
+                self.num_batches_tracked[k.rsplit(".", 1)[0]] = int(sd[k])
+                continue
+            v = sd[k]
+            if tuple(v.shape) != tuple(self.views[k].shape):
+                raise ValueError(f"shape mismatch for {k}: {tuple(v.shape)} vs {tuple(self.views[k].shape)}")
+            self.views[k].copy_(v.to(torch.float32))
+        self.refresh_weights()
+
+    def refresh_weights(self):
+        """fp32 master (OIHW) -> compute-dtype implicit-GEMM copies; call after any change of `flat`."""
+        for c in self.convs.values():
+            call("primia_conv_weight_prepare", c.desc, c.c_real, self.views[c.spec.name + ".weight"], c.w_fwd,
+                 c.w_dgrad, self.dt)
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ------------------------------------------------------------------------------------------
+    # forward
+    # ------------------------------------------------------------------------------------------
+    def _bn(self, conv_name, y, z, residual, relu):
+        b = bn_name(conv_name)
+        C = y.shape[1]
+        M = y.shape[0]
+        g, be = self.views[b + ".weight"], self.views[b + ".bias"]
+        rm, rv = self.views[b + ".running_mean"], self.views[b + ".running_var"]
+        if self.training:
+            sm, si = self.save[b]
+            call("primia_bn_fwd_train", y, residual, z, g, be, rm, rv, sm, si, M, C, BN_EPS, BN_MOMENTUM,
+                 int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
+            self.num_batches_tracked[b] += 1
+        else:
+            call("primia_bn_fwd_eval", y, residual, z, g, be, rm, rv, M, C, BN_EPS, int(relu), self.dt)
+
+    # Optional per-launch timing of the convolution kernels (bench.py roofline leg): when
+    # `self.prof` is a list, every conv launch is bracketed by events on the launch stream.
+    prof = None
+
+    def _timed(self, kind, c, fn):
+        if self.prof is None:
+            return fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        d = c.desc
+        macs = d.N * d.Ho * d.Wo * d.K * c.c_real * d.R * d.S
+        self.prof.append((kind, c.spec.name, 2.0 * macs, e0, e1))
+
+    def _conv_fwd(self, name, x, y):
+        c = self.convs[name]
+        self._timed("fwd", c, lambda: call("primia_conv2d_fwd", c.desc, x, c.w_fwd, y, self.dt))
+
+    def forward(self, x_nchw):
+        """x_nchw: fp32 [N, in_channels, S, S] on this GPU.  Returns fp32 logits [N, classes]."""
+        N, S, t = self.N, self.spec.input_size, self.t
+        if tuple(x_nchw.shape) != (N, self.spec.in_channels, S, S) or x_nchw.dtype != torch.float32:
+            raise ValueError(f"expected fp32 input {(N, self.spec.in_channels, S, S)}, got {tuple(x_nchw.shape)}")
+        x_nchw = x_nchw.contiguous()
+        call("primia_nchw_to_nhwc", x_nchw, self.x0, N, self.spec.in_channels, S, S, 4, self.dt)
+        self._conv_fwd("conv1", self.x0, t["stem.y"])
+        self._bn("conv1", t["stem.y"], t["stem.z"], None, True)
+        hw = self.stem_hw
+        if self.spec.pooling == "max":
+            call("primia_maxpool3x3s2_fwd", t["stem.z"], t["pool.out"], self.pool_argmax, N, hw, hw, 64, self.dt)
+        else:
+            call("primia_avgpool3x3s2_fwd", t["stem.z"], t["pool.out"], N, hw, hw, 64, self.dt)
+        x = t["pool.out"]
+        for blk in self.spec.blocks:
+            p = blk.prefix
+            self._conv_fwd(blk.conv1.name, x, t[p + ".y1"])
+            self._bn(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], None, True)
+            self._conv_fwd(blk.conv2.name, t[p + ".a1"], t[p + ".y2"])
+            idn = x
+            if blk.down is not None:
+                self._conv_fwd(blk.down.name, x, t[p + ".yd"])
+                self._bn(blk.down.name, t[p + ".yd"], t[p + ".idn"], None, False)
+                idn = t[p + ".idn"]
+            self._bn(blk.conv2.name, t[p + ".y2"], t[p + ".out"], idn, True)
+            x = t[p + ".out"]
+        hw = self.final_hw
+        call("primia_global_avgpool_fwd", x, self.feat, N, hw * hw, 512, self.dt)
+        call("primia_linear_fwd", self.feat, self.views["fc.weight"], self.views["fc.bias"], self.logits, N, 512,
+             self.spec.num_classes)
+        return self.logits
+
+    __call__ = forward
+
+    # ------------------------------------------------------------------------------------------
+    # loss + backward
+    # ------------------------------------------------------------------------------------------
+    def loss_backward(self, target, soft=False):
+        """Cross entropy (hard int64 labels, or soft [N, classes] fp32 targets as in
+        Cross_entropy_one_hot) + full backward into `grads`.  Returns the device loss scalar."""
+        if soft:
+            call("primia_xent_soft", self.logits, target, self.class_weight, self.loss, self.dlogits, self.N,
+                 self.spec.num_classes)
+        else:
+            call("primia_xent_hard", self.logits, target, self.class_weight, self.loss, self.dlogits, self.N,
+                 self.spec.num_classes)
+        self.backward()
+        return self.loss
+
+    def _bn_bwd(self, conv_name, y, z, dz, dy, g_out, relu):
+        b = bn_name(conv_name)
+        sm, si = self.save[b]
+        call("primia_bn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, self.gviews[b + ".weight"],
+             self.gviews[b + ".bias"], y.shape[0], y.shape[1], int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
+
+    def _wgrad(self, name, x, dy):
+        c = self.convs[name]
+        self._timed("wgrad", c, lambda: call("primia_conv2d_wgrad", c.desc, x, dy, c.acc, self.dt))
+
+    def _dgrad(self, name, dy, dx, accumulate):
+        c = self.convs[name]
+        self._timed("dgrad", c,
+                    lambda: call("primia_conv2d_dgrad", c.desc, dy, c.w_dgrad, dx, int(accumulate), self.dt))
+
+    def backward(self):
+        N, t = self.N, self.t
+        nc = self.spec.num_classes
+        self.dw_acc.zero_()
+        call("primia_linear_bwd", self.feat, self.views["fc.weight"], self.dlogits, self.dfeat,
+             self.gviews["fc.weight"], self.gviews["fc.bias"], N, 512, nc)
+        last = self.spec.blocks[-1].prefix
+        hw = self.final_hw
+        call("primia_global_avgpool_bwd", self.dfeat, t[last + ".dout"], N, hw * hw, 512, self.dt)
+        blocks = self.spec.blocks
+        for i in range(len(blocks) - 1, -1, -1):
+            blk = blocks[i]
+            p = blk.prefix
+            x_in = t[blocks[i - 1].prefix + ".out"] if i > 0 else t["pool.out"]
+            dx_in = t[blocks[i - 1].prefix + ".dout"] if i > 0 else t["pool.dout"]
+            dout = t[p + ".dout"]
+            # bn2 (+residual, relu): dy2, and the masked gradient g written back over dout
+            self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True)
+            self._wgrad(blk.conv2.name, t[p + ".a1"], t[p + ".dy2"])
+            self._dgrad(blk.conv2.name, t[p + ".dy2"], t[p + ".da1"], False)
+            self._bn_bwd(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], t[p + ".da1"], t[p + ".dy1"], None, True)
+            self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
+            if blk.down is not None:
+                self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, False)
+                self._bn_bwd(blk.down.name, t[p + ".yd"], None, dout, t[p + ".dyd"], None, False)
+                self._wgrad(blk.down.name, x_in, t[p + ".dyd"])
+                self._dgrad(blk.down.name, t[p + ".dyd"], dx_in, True)
+            else:
+                # identity skip: dx_in aliases dout, which now holds the masked gradient g
+                self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, True)
+        hw = self.stem_hw
+        if self.spec.pooling == "max":
+            call("primia_maxpool3x3s2_bwd", t["pool.dout"], self.pool_argmax, t["stem.dz"], N, hw, hw, 64, self.dt)
+        else:
+            call("primia_avgpool3x3s2_bwd", t["pool.dout"], t["stem.dz"], N, hw, hw, 64, self.dt)
+        self._bn_bwd("conv1", t["stem.y"], t["stem.z"], t["stem.dz"], t["stem.dy"], None, True)
+        self._wgrad("conv1", self.x0, t["stem.dy"])
+        for c in self.convs.values():
+            call("primia_conv_wgrad_finalize", c.desc, c.c_real, c.acc, self.gviews[c.spec.name + ".weight"])
+
+    # ------------------------------------------------------------------------------------------
+    # optimizer
+    # ------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def reset_optimizer(self):
+        """The reference re-creates its optimizers at every FedAvg sync (utils.py:1131-1145,1208-1218)."""
+        self.opt_state = None
+        self.opt_steps = 0
+
+    def sgd_step(self, lr, weight_decay=0.0):
+        call("primia_sgd_step", self.flat, self.grads, self.P, float(lr), float(weight_decay))
+        self.refresh_weights()
+
+    def adam_step(self, lr, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+        if self.opt_state is None:
+            self.opt_state = (torch.zeros_like(self.grads), torch.zeros_like(self.grads))
+            self.opt_steps = 0
+        self.opt_steps += 1
+        m, v = self.opt_state
+        call("primia_adam_step", self.flat, self.grads, m, v, self.P, float(lr), float(betas[0]), float(betas[1]),
+             float(eps), float(weight_decay), self.opt_steps)
+        self.refresh_weights()
+
+    def train_step(self, x_nchw, target, lr, weight_decay=0.0, soft=False):
+        """forward + loss + backward + SGD: the body of the reference's per-batch loop."""
+        self.forward(x_nchw)
+        self.loss_backward(target, soft=soft)
+        self.sgd_step(lr, weight_decay)
+        return self.loss

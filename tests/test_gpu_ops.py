@@ -1,0 +1,329 @@
+"""GPU parity tests, one per training kernel, called through the C ABI.
+
+Oracle for each op = the native torch-CPU fp32 op the reference's workers execute
+(SURVEY.md §8a T2-T8).  Tolerances:
+  fp32 kernels : 1e-5 relative (north_star), measured as ||a-b|| / ||b|| over the tensor;
+  bf16 kernels : inputs are rounded to bf16 first and the fp32 oracle runs on the ROUNDED values,
+                 so the only differences are accumulation order and the final bf16 store
+                 (<= 2^-8 relative per element) — bound 1e-2 normwise, stated per test.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from primia_amd import _lib  # noqa: E402
+from primia_amd._lib import ConvDesc, call, query  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dtype):
+    return 1e-5 if dtype == torch.float32 else 1e-2
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def rnd(x, dtype):
+    """Round to the compute dtype and come back to fp32 (what the kernel will see)."""
+    return x.to(dtype).to(torch.float32)
+
+
+def to_nhwc(x, dtype, dev, c_pad=None):
+    """CPU NCHW fp32 -> device [N*H*W, C] in dtype (test-side conversion)."""
+    N, C, H, W = x.shape
+    y = x.permute(0, 2, 3, 1).contiguous()
+    if c_pad and c_pad > C:
+        y = F.pad(y, (0, c_pad - C))
+    return y.reshape(N * H * W, -1).to(dtype).to(dev)
+
+
+def from_nhwc(y, N, H, W):
+    C = y.shape[1]
+    return y.to(torch.float32).cpu().view(N, H, W, C).permute(0, 3, 1, 2).contiguous()
+
+
+CONV_CASES = [
+    # N, H, C, K, R, stride, pad
+    (2, 16, 64, 64, 3, 1, 1),
+    (2, 16, 64, 128, 3, 2, 1),
+    (2, 16, 64, 128, 1, 2, 0),
+    (1, 10, 128, 128, 3, 1, 1),   # M = 100: ragged pixel tile
+    (3, 7, 256, 512, 3, 2, 1),    # odd size, stride 2
+    (2, 8, 512, 512, 3, 1, 1),
+]
+
+
+def prep_weights(desc, w, dtype, dev, c_real, need_dgrad=True):
+    wf = torch.empty(query("primia_conv_wfwd_elems", desc), dtype=dtype, device=dev)
+    wd = torch.empty(query("primia_conv_wdgrad_elems", desc), dtype=dtype, device=dev) if need_dgrad else None
+    call("primia_conv_weight_prepare", desc, c_real, w.to(dev), wf, wd, _lib.dtype_code(dtype))
+    return wf, wd
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(cuda, dtype, case):
+    N, H, C, K, R, s, p = case
+    g = torch.Generator().manual_seed(1234 + H + C)
+    x = rnd(torch.randn(N, C, H, H, generator=g), dtype)
+    w = rnd(torch.randn(K, C, R, R, generator=g) * 0.05, dtype)
+    desc = ConvDesc.make(N, H, H, C, K, R, R, s, p)
+    dt = _lib.dtype_code(dtype)
+    wf, wd = prep_weights(desc, w, dtype, cuda, C)
+
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, None, s, p)
+    dy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(dy)
+
+    xd = to_nhwc(x, dtype, cuda)
+    y = torch.empty(N * desc.Ho * desc.Wo, K, dtype=dtype, device=cuda)
+    call("primia_conv2d_fwd", desc, xd, wf, y, dt)
+    assert relerr(from_nhwc(y, N, desc.Ho, desc.Wo), y_ref.detach()) < tol(dtype)
+
+    dyd = to_nhwc(dy, dtype, cuda)
+    dx = torch.empty(N * H * H, C, dtype=dtype, device=cuda)
+    call("primia_conv2d_dgrad", desc, dyd, wd, dx, 0, dt)
+    assert relerr(from_nhwc(dx, N, H, H), xr.grad) < tol(dtype)
+    # accumulate form: dx2 = base + dgrad
+    base = rnd(torch.randn(N, C, H, H, generator=g), dtype)
+    dx2 = to_nhwc(base, dtype, cuda)
+    call("primia_conv2d_dgrad", desc, dyd, wd, dx2, 1, dt)
+    assert relerr(from_nhwc(dx2, N, H, H), xr.grad + base) < tol(dtype)
+
+    acc = torch.zeros(query("primia_conv_wfwd_elems", desc), dtype=torch.float32, device=cuda)
+    call("primia_conv2d_wgrad", desc, xd, dyd, acc, dt)
+    dw = torch.empty(K, C, R, R, dtype=torch.float32, device=cuda)
+    call("primia_conv_wgrad_finalize", desc, C, acc, dw)
+    # wgrad accumulates in fp32 in both modes (inputs already rounded) -> fp32-class tolerance
+    assert relerr(dw, wr.grad) < (1e-5 if dtype == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H", [(2, 32), (1, 18)])
+def test_stem_conv(cuda, dtype, N, H):
+    g = torch.Generator().manual_seed(99)
+    x = rnd(torch.randn(N, 3, H, H, generator=g), dtype)
+    w = rnd(torch.randn(64, 3, 7, 7, generator=g) * 0.1, dtype)
+    desc = ConvDesc.make(N, H, H, 4, 64, 7, 7, 2, 3)
+    dt = _lib.dtype_code(dtype)
+    wf, _ = prep_weights(desc, w, dtype, cuda, 3, need_dgrad=False)
+    wr = w.clone().requires_grad_(True)
+    y_ref = F.conv2d(x, wr, None, 2, 3)
+    dy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(dy)
+
+    # boundary conversion kernel: NCHW fp32 -> NHWC (3 -> 4 channels)
+    xd = torch.empty(N * H * H, 4, dtype=dtype, device=cuda)
+    call("primia_nchw_to_nhwc", x.to(cuda), xd, N, 3, H, H, 4, dt)
+    assert torch.equal(xd.cpu(), to_nhwc(x, dtype, "cpu", c_pad=4))
+    back = torch.empty(N, 3, H, H, dtype=torch.float32, device=cuda)
+    call("primia_nhwc_to_nchw", xd, back, N, 3, H, H, 4, dt)
+    assert torch.equal(back.cpu(), x)
+
+    y = torch.empty(N * desc.Ho * desc.Wo, 64, dtype=dtype, device=cuda)
+    call("primia_conv2d_fwd", desc, xd, wf, y, dt)
+    assert relerr(from_nhwc(y, N, desc.Ho, desc.Wo), y_ref.detach()) < tol(dtype)
+
+    acc = torch.zeros(query("primia_conv_wfwd_elems", desc), dtype=torch.float32, device=cuda)
+    call("primia_conv2d_wgrad", desc, xd, to_nhwc(dy, dtype, cuda), acc, dt)
+    dw = torch.empty(64, 3, 7, 7, dtype=torch.float32, device=cuda)
+    call("primia_conv_wgrad_finalize", desc, 3, acc, dw)
+    assert relerr(dw, wr.grad) < (1e-5 if dtype == torch.float32 else 1e-4)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,relu,res", [(64, 1, 0), (128, 1, 1), (512, 0, 0), (256, 1, 1)])
+def test_batchnorm_train(cuda, dtype, C, relu, res):
+    N, H = 3, 9
+    M = N * H * H
+    g = torch.Generator().manual_seed(5 + C)
+    y = rnd(torch.randn(N, C, H, H, generator=g) * 2 + 0.5, dtype)
+    r = rnd(torch.randn(N, C, H, H, generator=g), dtype) if res else None
+    gamma = torch.rand(C, generator=g) + 0.5
+    beta = torch.randn(C, generator=g)
+    rm0, rv0 = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    dt = _lib.dtype_code(dtype)
+
+    yr = y.clone().requires_grad_(True)
+    gr = gamma.clone().requires_grad_(True)
+    br = beta.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    rm, rv = rm0.clone(), rv0.clone()
+    z_ref = F.batch_norm(yr, rm, rv, gr, br, True, 0.1, 1e-5)
+    if res:
+        z_ref = z_ref + rr
+    if relu:
+        z_ref = F.relu(z_ref)
+    dz = rnd(torch.randn(z_ref.shape, generator=g), dtype)
+    z_ref.backward(dz)
+
+    ws_bytes = query("primia_bn_workspace_bytes", M, C)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=cuda)
+    yd = to_nhwc(y, dtype, cuda)
+    rd = to_nhwc(r, dtype, cuda) if res else None
+    z = torch.empty_like(yd)
+    d_rm, d_rv = rm0.to(cuda), rv0.to(cuda)
+    sm = torch.empty(C, device=cuda)
+    si = torch.empty(C, device=cuda)
+    call("primia_bn_fwd_train", yd, rd, z, gamma.to(cuda), beta.to(cuda), d_rm, d_rv, sm, si, M, C, 1e-5, 0.1,
+         relu, ws, ws_bytes, dt)
+    assert relerr(from_nhwc(z, N, H, H), z_ref.detach()) < tol(dtype)
+    assert relerr(d_rm, rm) < 1e-5 and relerr(d_rv, rv) < 1e-5
+
+    # backward uses the kernel's own z for the ReLU mask
+    dzd = to_nhwc(dz, dtype, cuda)
+    dy = torch.empty_like(yd)
+    dgam = torch.empty(C, device=cuda)
+    dbet = torch.empty(C, device=cuda)
+    g_out = torch.empty_like(yd) if res else None
+    call("primia_bn_bwd", yd, z if relu else None, dzd, dy, g_out, gamma.to(cuda), sm, si, dgam, dbet, M, C, relu,
+         ws, ws_bytes, dt)
+    t = tol(dtype)
+    assert relerr(from_nhwc(dy, N, H, H), yr.grad) < (2e-5 if dtype == torch.float32 else 2e-2)
+    assert relerr(dgam, gr.grad) < (1e-5 if dtype == torch.float32 else 5e-3)
+    assert relerr(dbet, br.grad) < (1e-5 if dtype == torch.float32 else 5e-3)
+    if res:
+        assert relerr(from_nhwc(g_out, N, H, H), rr.grad) < t
+
+    # eval mode
+    z2 = torch.empty_like(yd)
+    call("primia_bn_fwd_eval", yd, rd, z2, gamma.to(cuda), beta.to(cuda), d_rm, d_rv, M, C, 1e-5, relu, dt)
+    ze = F.batch_norm(y, d_rm.cpu(), d_rv.cpu(), gamma, beta, False, 0.1, 1e-5)
+    if res:
+        ze = ze + r
+    if relu:
+        ze = F.relu(ze)
+    assert relerr(from_nhwc(z2, N, H, H), ze) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,kind", [(2, 16, "max"), (1, 9, "max"), (2, 12, "avg")])
+def test_pool3x3s2(cuda, dtype, N, H, kind):
+    C = 64
+    g = torch.Generator().manual_seed(3)
+    # ReLU-like input with many exact ties at 0 (the stem feeds post-ReLU activations)
+    x = rnd(F.relu(torch.randn(N, C, H, H, generator=g)), dtype)
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.max_pool2d(xr, 3, 2, 1) if kind == "max" else F.avg_pool2d(xr, 3, 2, 1)
+    dy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(dy)
+    Ho = y_ref.shape[2]
+    dt = _lib.dtype_code(dtype)
+    xd = to_nhwc(x, dtype, cuda)
+    y = torch.empty(N * Ho * Ho, C, dtype=dtype, device=cuda)
+    dx = torch.empty_like(xd)
+    if kind == "max":
+        am = torch.empty(N * Ho * Ho * C, dtype=torch.uint8, device=cuda)
+        call("primia_maxpool3x3s2_fwd", xd, y, am, N, H, H, C, dt)
+        call("primia_maxpool3x3s2_bwd", to_nhwc(dy, dtype, cuda), am, dx, N, H, H, C, dt)
+        assert torch.equal(from_nhwc(y, N, Ho, Ho), y_ref.detach())  # a max is exact
+    else:
+        call("primia_avgpool3x3s2_fwd", xd, y, N, H, H, C, dt)
+        call("primia_avgpool3x3s2_bwd", to_nhwc(dy, dtype, cuda), dx, N, H, H, C, dt)
+        assert relerr(from_nhwc(y, N, Ho, Ho), y_ref.detach()) < tol(dtype)
+    assert relerr(from_nhwc(dx, N, H, H), xr.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_head(cuda, dtype):
+    N, HW, C, NC = 5, 4, 512, 3
+    g = torch.Generator().manual_seed(11)
+    x = rnd(torch.randn(N, C, 2, 2, generator=g), dtype)
+    w = torch.randn(NC, C, generator=g) * 0.05
+    b = torch.randn(NC, generator=g)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    feat_ref = torch.flatten(F.avg_pool2d(xr, 2), 1)
+    logits_ref = F.linear(feat_ref, wr, br)
+    dl = torch.randn(N, NC, generator=g)
+    logits_ref.backward(dl)
+    dt = _lib.dtype_code(dtype)
+    xd = to_nhwc(x, dtype, cuda)
+    feat = torch.empty(N, C, device=cuda)
+    call("primia_global_avgpool_fwd", xd, feat, N, HW, C, dt)
+    logits = torch.empty(N, NC, device=cuda)
+    call("primia_linear_fwd", feat, w.to(cuda), b.to(cuda), logits, N, C, NC)
+    assert relerr(logits, logits_ref.detach()) < 1e-5
+    dfeat = torch.empty(N, C, device=cuda)
+    dw = torch.empty(NC, C, device=cuda)
+    db = torch.empty(NC, device=cuda)
+    call("primia_linear_bwd", feat, w.to(cuda), dl.to(cuda), dfeat, dw, db, N, C, NC)
+    assert relerr(dw, wr.grad) < 1e-5 and relerr(db, br.grad) < 1e-5
+    dx = torch.empty_like(xd)
+    call("primia_global_avgpool_bwd", dfeat, dx, N, HW, C, dt)
+    assert relerr(from_nhwc(dx, N, 2, 2), xr.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_xent(cuda, weighted):
+    import sys, os
+    from oracle import train_oracle as O
+
+    N, C = 37, 3
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(N, C, generator=g) * 3
+    cw = torch.tensor([0.5, 1.0, 2.0]) if weighted else None
+    tgt = torch.randint(0, C, (N,), generator=g)
+    lr = logits.clone().requires_grad_(True)
+    loss_ref = F.cross_entropy(lr, tgt, weight=cw)
+    loss_ref.backward()
+    loss = torch.zeros(1, device=cuda)
+    dl = torch.empty(N, C, device=cuda)
+    call("primia_xent_hard", logits.to(cuda), tgt.to(cuda), cw.to(cuda) if weighted else None, loss, dl, N, C)
+    assert abs(loss.item() - loss_ref.item()) < 1e-5 * abs(loss_ref.item())
+    assert relerr(dl, lr.grad) < 1e-5
+    soft = torch.rand(N, C, generator=g)
+    soft = soft / soft.sum(1, keepdim=True)
+    lr2 = logits.clone().requires_grad_(True)
+    l2 = O.cross_entropy_one_hot(lr2, soft, cw)
+    l2.backward()
+    call("primia_xent_soft", logits.to(cuda), soft.to(cuda), cw.to(cuda) if weighted else None, loss, dl, N, C)
+    assert abs(loss.item() - l2.item()) < 1e-5 * abs(l2.item())
+    assert relerr(dl, lr2.grad) < 1e-5
+
+
+def test_optimizers_and_fx(cuda):
+    from oracle import train_oracle as O
+
+    n = 100003  # not a multiple of 4: exercises the scalar tail
+    g = torch.Generator().manual_seed(8)
+    p0, gr = torch.randn(n, generator=g), torch.randn(n, generator=g)
+    p = p0.clone()
+    O.sgd_step([p], [gr], 1e-2, 5e-4)
+    pd = p0.to(cuda)
+    call("primia_sgd_step", pd, gr.to(cuda), n, 1e-2, 5e-4)
+    assert relerr(pd, p) < 1e-6
+    # Adam, 3 steps
+    p = p0.clone()
+    st = {}
+    pd, m, v = p0.to(cuda), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    for step in range(1, 4):
+        gs = torch.randn(n, generator=g)
+        O.adam_step([p], [gs], st, 1e-3, (0.5, 0.99), 1e-8, 5e-4)
+        call("primia_adam_step", pd, gs.to(cuda), m, v, n, 1e-3, 0.5, 0.99, 1e-8, 5e-4, step)
+    assert relerr(pd, p) < 1e-5
+    # fixed-precision encode/decode (precision.py:117-144) at the literal 10^16 and at 10^3
+    x = torch.cat([torch.randn(1000, generator=g) * 1e-3, torch.tensor([0.0, -0.5, 0.5, 1e-17, -123.456])])
+    for pf in (16, 3):
+        if pf == 16:
+            xs = x.clamp(-900, 900)
+        else:
+            xs = x
+        q_ref = O.fix_encode(xs, 10, pf)
+        q = torch.empty(xs.numel(), dtype=torch.int64, device=cuda)
+        call("primia_fx_encode", xs.to(cuda), q, xs.numel(), float(10 ** pf))
+        assert torch.equal(q.cpu(), q_ref)
+        back = torch.empty(xs.numel(), device=cuda)
+        call("primia_fx_decode", q, back, xs.numel(), float(10 ** pf))
+        assert torch.equal(back.cpu(), O.fix_decode(q_ref, 10, pf))
+    y = torch.randn(n, generator=g)
+    yd = y.to(cuda)
+    call("primia_scale", yd, n, 0.125)
+    assert torch.equal(yd.cpu(), y * 0.125)

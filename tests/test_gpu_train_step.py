@@ -1,0 +1,122 @@
+"""GPU parity of the whole training step (forward, loss, backward, optimizer) against
+ (a) the golden vectors minted from the reference's torchlib/models.py (fp32 engine, 1e-5), and
+ (b) the CPU oracle run live on identical batches (bf16 engine, bf16-level tolerance)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import train_oracle as O  # noqa: E402
+from primia_amd import resnet_spec as rs  # noqa: E402
+from primia_amd.engine import ResNet18Engine  # noqa: E402
+
+CASES = {
+    # name: pooling, optimizer, lr, wd, class weights, soft targets
+    "sgd_hard_64": ("max", "SGD", 1e-2, 5e-4, [0.5, 1.0, 2.0], False),
+    "adam_soft_64": ("avg", "Adam", 1e-3, 5e-4, [0.5, 1.0, 2.0], True),
+    "sgd_hard_224": ("max", "SGD", 1e-4, 5e-4, None, False),
+}
+
+
+def summary(t, n=8):
+    f = t.detach().double().flatten().cpu()
+    return np.array([f.norm().item(), f.sum().item()] + f[:n].tolist() + [0.0] * max(0, n - f.numel()))
+
+
+def check_summary(got, want, rtol, what):
+    # [0] = L2 norm, [1] = sum, [2:] = leading values.  Norm to rtol; leading values to rtol of the
+    # tensor's scale (norm / sqrt(n) is not stored, so use max |leading| as the scale).
+    assert abs(got[0] - want[0]) <= rtol * max(abs(want[0]), 1e-12), f"{what}: norm {got[0]} vs {want[0]}"
+    scale = max(np.abs(want[2:]).max(), 1e-12)
+    assert np.abs(got[2:] - want[2:]).max() <= 20 * rtol * scale + 1e-9, f"{what}: leading values"
+
+
+@pytest.mark.parametrize("name", ["sgd_hard_64", "adam_soft_64", "sgd_hard_224"])
+def test_fp32_engine_matches_reference_golden(cuda, golden_dir, name):
+    pooling, optimizer, lr, wd, cw, soft = CASES[name]
+    gold = np.load(os.path.join(golden_dir, f"train_{name}.npz"))
+    seed, batch, size, steps = [int(v) for v in gold["meta"]]
+    eng = ResNet18Engine(batch, 3, 3, size, pooling, dtype=torch.float32, device=cuda)
+    torch.manual_seed(seed)
+    eng.init_weights()  # consumes the RNG exactly like the reference constructor
+    if cw:
+        eng.class_weight = torch.tensor(cw, dtype=torch.float32, device=cuda)
+    g = torch.Generator().manual_seed(seed + 1)
+    for step in range(steps):
+        x = torch.randn(batch, 3, size, size, generator=g)
+        if soft:
+            y = torch.rand(batch, 3, generator=g)
+            y = y / y.sum(1, keepdim=True)
+        else:
+            y = torch.randint(0, 3, (batch,), generator=g)
+        logits = eng.forward(x.to(cuda))
+        loss = eng.loss_backward(y.to(cuda), soft=soft)
+        want = gold[f"s{step}.logits"]
+        err = np.linalg.norm(logits.double().cpu().numpy() - want) / np.linalg.norm(want)
+        assert err < 1e-5, f"step {step} logits rel err {err}"
+        wl = float(gold[f"s{step}.loss"])
+        assert abs(loss.item() - wl) <= 1e-5 * abs(wl)
+        for k, _ in eng.p_entries:
+            check_summary(summary(eng.gviews[k]), gold[f"s{step}.grad.{k}"], 2e-5, f"step {step} grad {k}")
+        if optimizer == "SGD":
+            eng.sgd_step(lr, wd)
+        else:
+            eng.adam_step(lr, (0.5, 0.99), 1e-8, wd)
+        sd = eng.state_dict()
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == step + 1
+            else:
+                check_summary(summary(v), gold[f"s{step}.post.{k}"], 1e-5, f"step {step} post {k}")
+
+
+def test_bf16_engine_tracks_oracle(cuda):
+    """bf16 storage / fp32 accumulate: compare with the fp32 oracle on the same batch.
+    Tolerance: logits 3e-2 of their norm, loss 2e-2, per-tensor gradient cosine > 0.98."""
+    batch, size = 8, 64
+    torch.manual_seed(123)
+    spec = rs.resnet18_spec(3, 3, size, "max")
+    sd = rs.init_state_dict(spec)
+    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.bfloat16, device=cuda)
+    eng.load_state_dict(sd)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    y = torch.randint(0, 3, (batch,), generator=g)
+    logits = eng.forward(x.to(cuda)).cpu()
+    loss = eng.loss_backward(y.to(cuda)).item()
+    ologits, oloss, ograds = O.train_step(sd, x, y, 0.0, 0.0)
+    assert (logits - ologits).norm() / ologits.norm() < 3e-2
+    assert abs(loss - oloss.item()) < 2e-2 * abs(oloss.item())
+    worst = 1.0
+    for k, _ in eng.p_entries:
+        a, b = eng.gviews[k].double().cpu().flatten(), ograds[k].double().flatten()
+        if b.norm() < 1e-8:
+            continue
+        cos = (a @ b / (a.norm() * b.norm())).item()
+        worst = min(worst, cos)
+        assert cos > 0.98, f"{k}: cosine {cos}"
+        assert abs(a.norm() / b.norm() - 1) < 0.1, k
+
+
+def test_state_dict_roundtrip_and_eval(cuda):
+    batch, size = 2, 64
+    torch.manual_seed(1)
+    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda)
+    eng.init_weights()
+    sd = eng.state_dict()
+    assert list(sd.keys()) == rs.state_dict_keys(eng.spec)
+    eng2 = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda)
+    eng2.load_state_dict(sd)
+    x = torch.randn(batch, 3, size, size)
+    eng.eval()
+    eng2.eval()
+    a = eng.forward(x.to(cuda)).cpu()
+    b = eng2.forward(x.to(cuda)).cpu()
+    assert torch.equal(a, b)
+    ref = O.forward({k: v.clone() for k, v in sd.items()}, x, training=False, input_size=size)
+    assert (a - ref).norm() / ref.norm() < 1e-5
+    with pytest.raises(KeyError):
+        eng.load_state_dict({"conv1.weight": sd["conv1.weight"]})
