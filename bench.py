@@ -51,7 +51,9 @@ def cpu_baseline(batch, size, budget_s=20.0):
     from oracle import train_oracle as O
     from primia_amd import resnet_spec as rs
 
-    cores = os.cpu_count() or 1
+    # torch-CPU scales poorly past a few dozen threads on this workload (256 threads measured
+    # slower than 32), so cap the pool; `cores` reports the threads actually used.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     sd = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"))

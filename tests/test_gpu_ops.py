@@ -55,6 +55,10 @@ CONV_CASES = [
     (1, 10, 128, 128, 3, 1, 1),   # M = 100: ragged pixel tile
     (3, 7, 256, 512, 3, 2, 1),    # odd size, stride 2
     (2, 8, 512, 512, 3, 1, 1),
+    (4, 14, 256, 512, 3, 2, 1),   # layer4.0.conv1 at batch 4 (ragged: 784 / 196 pixels)
+    (4, 14, 256, 512, 1, 2, 0),   # layer4.0.downsample
+    (4, 28, 128, 256, 3, 2, 1),   # layer3.0.conv1
+    (4, 7, 512, 512, 3, 1, 1),    # layer4.1
 ]
 
 
@@ -139,9 +143,10 @@ def test_stem_conv(cuda, dtype, N, H):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C,relu,res", [(64, 1, 0), (128, 1, 1), (512, 0, 0), (256, 1, 1)])
-def test_batchnorm_train(cuda, dtype, C, relu, res):
-    N, H = 3, 9
+@pytest.mark.parametrize("C,relu,res,N,H", [(64, 1, 0, 3, 9), (128, 1, 1, 3, 9), (512, 0, 0, 3, 9),
+                                               (256, 1, 1, 3, 9), (256, 1, 1, 4, 14), (512, 1, 1, 4, 7),
+                                               (64, 1, 0, 2, 56)])
+def test_batchnorm_train(cuda, dtype, C, relu, res, N, H):
     M = N * H * H
     g = torch.Generator().manual_seed(5 + C)
     y = rnd(torch.randn(N, C, H, H, generator=g) * 2 + 0.5, dtype)
