@@ -95,33 +95,46 @@ struct BwdFn {
     }
 };
 
-// One block; thread per channel.  mode 0: batch statistics -> mean / invstd / running stats.
+// Combine the per-block partials in fp64.  Block = 16 channels x 16 partial-slices; the slices are
+// reduced through LDS.  mode 0: batch statistics -> mean / invstd / running stats.
 // mode 1: backward sums -> dbeta (sum g) / dgamma (sum g*xhat).
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk,
                                                           int C, long M, int mode, float eps,
                                                           float momentum, float* out1, float* out2,
                                                           float* running_mean, float* running_var) {
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double a = 0.0, b = 0.0;
-        for (int k = 0; k < nblk; ++k) {
+    __shared__ double sa[16][17], sb[16][17];
+    const int cl = threadIdx.x & 15, ks = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a = 0.0, b = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int k = ks; k < nblk; k += 16) {
             a += (double)partials[((long)k * 2 + 0) * C + c];
             b += (double)partials[((long)k * 2 + 1) * C + c];
         }
-        if (mode == 0) {
-            const double mean = a / (double)M;
-            double var = b / (double)M - mean * mean;
-            if (var < 0.0) var = 0.0;
-            out1[c] = (float)mean;
-            out2[c] = (float)(1.0 / sqrt(var + (double)eps));
-            if (running_mean) {
-                const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
-                running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + (double)momentum * mean);
-                running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + (double)momentum * unb);
-            }
-        } else {
-            out1[c] = (float)a;  // dbeta
-            out2[c] = (float)b;  // dgamma
+    }
+    sa[ks][cl] = a;
+    sb[ks][cl] = b;
+    __syncthreads();
+    if (ks != 0 || c >= C) return;
+    for (int k = 1; k < 16; ++k) {
+        a += sa[k][cl];
+        b += sb[k][cl];
+    }
+    if (mode == 0) {
+        const double mean = a / (double)M;
+        double var = b / (double)M - mean * mean;
+        if (var < 0.0) var = 0.0;
+        out1[c] = (float)mean;
+        out2[c] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean) {
+            const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
+            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + (double)momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + (double)momentum * unb);
         }
+    } else {
+        out1[c] = (float)a;  // dbeta
+        out2[c] = (float)b;  // dgamma
     }
 }
 
@@ -236,7 +249,7 @@ static int bn_fwd_train_impl(const void* y, const void* residual, void* z, const
     reduce_geometry(M, C, nblk, rpb);
     StatsFn<T> f{(const T*)y};
     colreduce2_kernel<T, StatsFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
-    bn_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
+    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
                                            running_mean, running_var);
     const long nchunks = M * C / Chunk<T>::N;
     bn_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>((const T*)y, (const T*)residual, (T*)z, gamma,
@@ -255,7 +268,7 @@ static int bn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
     reduce_geometry(M, C, nblk, rpb);
     BwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, save_mean, save_invstd};
     colreduce2_kernel<T, BwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
-    bn_finalize_kernel<<<1, 256, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
+    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
     const long nchunks = M * C / Chunk<T>::N;
     bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
         (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean,
