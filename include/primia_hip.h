@@ -166,6 +166,98 @@ int primia_fx_encode(const float* x, int64_t* q, int64_t n, float scale, primia_
 /* x = float32(q) / scale  (float_precision, precision.py:134-144). */
 int primia_fx_decode(const int64_t* q, float* x, int64_t n, float scale, primia_stream_t stream);
 
+
+/* ==========================================================================================
+ * Encrypted-inference path: fixed-precision additive secret sharing over Z_2^64 (int64 with
+ * wrap-around), Beaver triples and Function Secret Sharing — the per-share functions PySyft
+ * registers with @allow_command and runs on each party (syft/generic/utils.py:27-55).
+ * Every function below is PARTY-LOCAL: it sees one party's shares / keys plus opened (public)
+ * values; the exchange ("open" = sum of the two parties' buffers) is done by the host.
+ * All tensors int64 unless stated; n = element count.
+ * ========================================================================================== */
+
+/* out[i] = a[i] (+|-|*) b[i % nb]  mod 2^64.  nb == n: plain element-wise; nb < n broadcasts b
+ * over the leading dims ([HW, C] op [C], additive_shared.py:489-524, beaver.py:33-53). */
+int primia_ring_add(const int64_t* a, const int64_t* b, int64_t* out, int64_t n, int64_t nb,
+                    primia_stream_t stream);
+int primia_ring_sub(const int64_t* a, const int64_t* b, int64_t* out, int64_t n, int64_t nb,
+                    primia_stream_t stream);
+int primia_ring_mul(const int64_t* a, const int64_t* b, int64_t* out, int64_t n, int64_t nb,
+                    primia_stream_t stream);
+/* out[i] = a[i] * k  (public integer scalar, AST._public_mul). */
+int primia_ring_scale(const int64_t* a, int64_t k, int64_t* out, int64_t n, primia_stream_t stream);
+/* out[i] = x[i] / d with C truncation toward zero — each party divides ITS OWN share
+ * (FixedPrecisionTensor.truncate -> AST._public_div, precision.py:146-160,
+ * additive_shared.py:672-678; torch-1.4 integer `/`). */
+int primia_trunc_div(const int64_t* x, int64_t d, int64_t* out, int64_t n, primia_stream_t stream);
+/* out[r] = sum_{k < w} x[r*w + k]  (per-share window sum of AST.mean, additive_shared.py:719-729). */
+int primia_ring_rowsum(const int64_t* x, int64_t* out, int64_t rows, int64_t w, primia_stream_t stream);
+
+/* out[r][j] = x[r][start + j], j < len: contiguous copy of a column range of x [rows, w]
+ * (the tensor4d[:, :, :, a:b] slices of max_half_split, nn/functional.py:489-495). */
+int primia_ring_slice_cols(const int64_t* x, int64_t* out, int64_t rows, int64_t w, int64_t start,
+                           int64_t len, primia_stream_t stream);
+
+/* C[M,N] = A[M,K] @ B[K,N]  (+ C if accumulate) mod 2^64 — torch.matmul on LongTensors
+ * (mpc/spdz.py:54-59). */
+int primia_ring_matmul(const int64_t* A, const int64_t* B, int64_t* C, int M, int K, int N,
+                       int accumulate, primia_stream_t stream);
+
+/* _pre_conv (nn/functional.py:78-166): x [B,C,H,W] -> im [B, Ho*Wo, C*R*S], rows ordered
+ * (ho, wo), columns (c, r, s); zero padding. */
+int primia_im2col_syft(const int64_t* x, int64_t* im, int B, int C, int H, int W, int R, int S,
+                       int stride, int pad, primia_stream_t stream);
+/* _post_conv (nn/functional.py:169-201): res [B, Ho*Wo, O] (+ bias[O]) -> [B, O, Ho, Wo]. */
+int primia_col2out_syft(const int64_t* res, const int64_t* bias, int64_t* out, int B, int HoWo,
+                        int O, primia_stream_t stream);
+/* _pre_pool (nn/functional.py:311-393): x [B,C,H,W] -> [B, C, Ho*Wo, k*k], zero padding. */
+int primia_pool_unroll_syft(const int64_t* x, int64_t* out, int B, int C, int H, int W, int k,
+                            int stride, int pad, primia_stream_t stream);
+
+/* spdz_compute (mpc/spdz.py:63-122), party j in {0,1}:
+ *   mul   : z = delta*b + a*eps + c (+ delta*eps if j == 0), element-wise; b / eps hold nb
+ *           elements and broadcast over the leading dims when nb < n;
+ *   matmul: z[M,N] = delta[M,K] @ b[K,N] + a[M,K] @ eps[K,N] + c (+ delta @ eps if j == 0);
+ *           `scratch` holds K*N int64 (b + eps for party 0).
+ * spdz_mask (spdz.py:21-45) is primia_ring_sub. */
+int primia_beaver_combine_mul(int j, const int64_t* delta, const int64_t* eps, const int64_t* a,
+                              const int64_t* b, const int64_t* c, int64_t* z, int64_t n,
+                              int64_t nb, primia_stream_t stream);
+int primia_beaver_combine_matmul(int j, const int64_t* delta, const int64_t* eps, const int64_t* a,
+                                 const int64_t* b, const int64_t* c, int64_t* z, int64_t* scratch,
+                                 int M, int K, int N, primia_stream_t stream);
+
+/* ---- Function Secret Sharing (mpc/fss.py), n comparisons, lambda = 127, 32-bit inputs --------
+ * Key layout (struct of arrays, comparison index fastest):
+ *   s0        uint64 [2][n]        party's initial seed (word 0 has 63 bits)
+ *   cw_bits   uint8  [32][n]       DIF: bit0 tauL, bit1 tL, bit2 tauR, bit3 tR;  DPF: bit0 tL, bit1 tR
+ *   cw_sigma  uint64 [32][2][n]    DIF only
+ *   cw_s      uint64 [32][2][n]
+ *   cw_leaf   int32  [33][n]       DIF;  DPF: int64 [n]
+ * = the content of the reference key tuple (alpha, s0, *_CW, CW_leaf), 1,204 B per DIF key. */
+/* mask_builder (fss.py:189-204): r = (x1 - x2) + alpha_share. */
+int primia_fss_mask(const int64_t* x1, const int64_t* x2, const uint64_t* alpha_share, int64_t* r,
+                    int64_t n, primia_stream_t stream);
+/* opened mask: x = (r0 + r1) mod 2^32 (fss.py:158). */
+int primia_fss_open(const int64_t* r0, const int64_t* r1, uint32_t* x, int64_t n,
+                    primia_stream_t stream);
+/* DIF.eval (fss.py:400-428): out = party b's int64 share of [x <= alpha]. */
+int primia_dif_eval(int b, const uint32_t* x, const uint64_t* s0, const uint8_t* cw_bits,
+                    const uint64_t* cw_sigma, const uint64_t* cw_s, const int32_t* cw_leaf,
+                    int64_t* out, int64_t n, primia_stream_t stream);
+/* DPF.eval (fss.py:320-338): share of [x == alpha]. */
+int primia_dpf_eval(int b, const uint32_t* x, const uint64_t* s0, const uint8_t* cw_bits,
+                    const uint64_t* cw_s, const int64_t* cw_n, int64_t* out, int64_t n,
+                    primia_stream_t stream);
+/* Dealer: DIF.keygen / DPF.keygen (fss.py:344-398, 286-318) from explicit randomness:
+ * alpha uint64 [n] (< 2^32), s0_pair uint64 [2 parties][2][n].  Correction words are common to
+ * both parties; party b's key = (s0_pair[b], cw_*). */
+int primia_dif_keygen(const uint64_t* alpha, const uint64_t* s0_pair, uint8_t* cw_bits,
+                      uint64_t* cw_sigma, uint64_t* cw_s, int32_t* cw_leaf, int64_t n,
+                      primia_stream_t stream);
+int primia_dpf_keygen(const uint64_t* alpha, const uint64_t* s0_pair, uint8_t* cw_bits,
+                      uint64_t* cw_s, int64_t* cw_n, int64_t n, primia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,315 @@
+// Z_2^64 ring kernels for the encrypted-inference path: element-wise share arithmetic, per-share
+// truncation, the PySyft im2col / pool-unroll layouts, the int64 ring GEMM and the Beaver
+// (SPDZ) combine step.  Integer work: results are bit-exact by construction (unsigned wrap-around
+// arithmetic on the int64 bit patterns).  Everything except the GEMM is an HBM streaming pass.
+#include "common.h"
+
+namespace primia {
+
+typedef unsigned long long u64;
+
+template <int OP>
+__global__ __launch_bounds__(256) void ring_ew_kernel(const u64* __restrict__ a, const u64* __restrict__ b,
+                                                      u64* __restrict__ out, long n, long nb) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const u64 x = a[i], y = b[nb == n ? i : i % nb];
+        out[i] = OP == 0 ? x + y : (OP == 1 ? x - y : x * y);
+    }
+}
+
+__global__ __launch_bounds__(256) void ring_scale_kernel(const u64* __restrict__ a, u64 k, u64* __restrict__ out,
+                                                         long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) out[i] = a[i] * k;
+}
+
+__global__ __launch_bounds__(256) void trunc_div_kernel(const int64_t* __restrict__ x, int64_t d,
+                                                        int64_t* __restrict__ out, long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        // C++ integer division truncates toward zero; do it on magnitudes so INT64_MIN is defined.
+        const int64_t v = x[i];
+        const u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
+        const u64 q = mag / (u64)d;
+        out[i] = v < 0 ? (int64_t)((u64)0 - q) : (int64_t)q;
+    }
+}
+
+__global__ __launch_bounds__(256) void ring_rowsum_kernel(const u64* __restrict__ x, u64* __restrict__ out,
+                                                          long rows, long w) {
+    const long r = (long)blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    u64 s = 0;
+    for (long k = 0; k < w; ++k) s += x[r * w + k];
+    out[r] = s;
+}
+
+__global__ __launch_bounds__(256) void ring_slice_cols_kernel(const u64* __restrict__ x, u64* __restrict__ out,
+                                                              long rows, long w, long start, long len) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * len) return;
+    const long r = i / len, j = i - r * len;
+    out[i] = x[r * w + start + j];
+}
+
+// ---- layouts -------------------------------------------------------------------------------------
+// im[b][ho*Wo + wo][(c*R + r)*S + s] = xpad[b][c][ho*stride + r][wo*stride + s]
+__global__ __launch_bounds__(256) void im2col_syft_kernel(const u64* __restrict__ x, u64* __restrict__ im, int B,
+                                                          int C, int H, int W, int R, int S, int stride,
+                                                          int pad, int Ho, int Wo) {
+    const long K = (long)C * R * S;
+    const long total = (long)B * Ho * Wo * K;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int k = (int)(i % K);
+    long t = i / K;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    const int s = k % S, r = (k / S) % R, c = k / (S * R);
+    const int h = ho * stride - pad + r, w = wo * stride - pad + s;
+    u64 v = 0;
+    if (h >= 0 && h < H && w >= 0 && w < W) v = x[(((long)b * C + c) * H + h) * W + w];
+    im[i] = v;
+}
+
+// out[b][o][p] = res[b][p][o] + bias[o]
+__global__ __launch_bounds__(256) void col2out_syft_kernel(const u64* __restrict__ res, const u64* __restrict__ bias,
+                                                           u64* __restrict__ out, int B, int P, int O) {
+    const long total = (long)B * P * O;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int p = (int)(i % P);
+    long t = i / P;
+    const int o = (int)(t % O);
+    const int b = (int)(t / O);
+    out[i] = res[((long)b * P + p) * O + o] + (bias ? bias[o] : (u64)0);
+}
+
+// out[b][c][ho*Wo + wo][r*k + s] = xpad[b][c][ho*stride + r][wo*stride + s]
+__global__ __launch_bounds__(256) void pool_unroll_kernel(const u64* __restrict__ x, u64* __restrict__ out, int B,
+                                                          int C, int H, int W, int k, int stride, int pad,
+                                                          int Ho, int Wo) {
+    const long total = (long)B * C * Ho * Wo * k * k;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int e = (int)(i % (k * k));
+    long t = i / (k * k);
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    t /= Ho;  // t = b*C + c
+    const int r = e / k, s = e % k;
+    const int h = ho * stride - pad + r, w = wo * stride - pad + s;
+    u64 v = 0;
+    if (h >= 0 && h < H && w >= 0 && w < W) v = x[(t * H + h) * W + w];
+    out[i] = v;
+}
+
+// ---- Beaver element-wise combine -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void beaver_mul_kernel(int j, const u64* __restrict__ delta,
+                                                         const u64* __restrict__ eps, const u64* __restrict__ a,
+                                                         const u64* __restrict__ b, const u64* __restrict__ c,
+                                                         u64* __restrict__ z, long n, long nb) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const long ib = nb == n ? i : i % nb;
+        const u64 d = delta[i], e = eps[ib];
+        u64 v = d * b[ib] + a[i] * e + c[i];
+        if (j == 0) v += d * e;
+        z[i] = v;
+    }
+}
+
+// ---- int64 ring GEMM: C = C0 + A1@B1 + A2@B2 ---------------------------------------------------------
+// 64x64 output tile per 256-thread block, 4x4 outputs per thread, k-step 16 staged through LDS.
+// There is no 64-bit integer MFMA; the products run on the vector ALU (v_mad_u64_u32 chains).
+struct GemmPair {
+    const u64* A;
+    const u64* B;
+};
+
+__global__ __launch_bounds__(256) void ring_gemm_kernel(GemmPair p1, GemmPair p2, const u64* __restrict__ C0,
+                                                        u64* __restrict__ C, int M, int K, int N) {
+    __shared__ u64 sa[16][64 + 1];
+    __shared__ u64 sb[16][64];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    u64 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+    for (int pair = 0; pair < 2; ++pair) {
+        const u64* __restrict__ A = pair == 0 ? p1.A : p2.A;
+        const u64* __restrict__ Bm = pair == 0 ? p1.B : p2.B;
+        if (!A) continue;
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            // A tile: 64 rows x 16 k (transposed into sa[k][m]); B tile: 16 k x 64 cols
+#pragma unroll
+            for (int l = 0; l < 4; ++l) {
+                const int idx = threadIdx.x + 256 * l;
+                const int am = idx >> 4, ak = idx & 15;
+                const int gm = m0 + am, gk = k0 + ak;
+                sa[ak][am] = (gm < M && gk < K) ? A[(long)gm * K + gk] : (u64)0;
+                const int bk = idx >> 6, bn = idx & 63;
+                const int gn = n0 + bn, gk2 = k0 + bk;
+                sb[bk][bn] = (gn < N && gk2 < K) ? Bm[(long)gk2 * N + gn] : (u64)0;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk) {
+                u64 av[4], bv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) av[i] = sa[kk][ty * 4 + i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) bv[j] = sb[kk][tx + 16 * j];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] += av[i] * bv[j];
+            }
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int gm = m0 + ty * 4 + i;
+        if (gm >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int gn = n0 + tx + 16 * j;
+            if (gn >= N) continue;
+            const long o = (long)gm * N + gn;
+            C[o] = acc[i][j] + (C0 ? C0[o] : (u64)0);
+        }
+    }
+}
+
+static inline int ew_blocks(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+static int launch_gemm(GemmPair p1, GemmPair p2, const u64* C0, u64* C, int M, int K, int N, hipStream_t st) {
+    dim3 grid((N + 63) / 64, (M + 63) / 64);
+    ring_gemm_kernel<<<grid, 256, 0, st>>>(p1, p2, C0, C, M, K, N);
+    return launch_status();
+}
+
+}  // namespace primia
+
+using namespace primia;
+
+extern "C" {
+
+#define RING_EW(NAME, OP)                                                                                   \
+    int NAME(const int64_t* a, const int64_t* b, int64_t* out, int64_t n, int64_t nb, primia_stream_t st) { \
+        PRIMIA_REQUIRE(a && b && out && n >= 0 && nb > 0 && nb <= n && (n == 0 || n % nb == 0));           \
+        if (n == 0) return PRIMIA_OK;                                                                       \
+        ring_ew_kernel<OP><<<ew_blocks(n), 256, 0, (hipStream_t)st>>>((const u64*)a, (const u64*)b,         \
+                                                                      (u64*)out, n, nb);                    \
+        return launch_status();                                                                             \
+    }
+RING_EW(primia_ring_add, 0)
+RING_EW(primia_ring_sub, 1)
+RING_EW(primia_ring_mul, 2)
+
+int primia_ring_scale(const int64_t* a, int64_t k, int64_t* out, int64_t n, primia_stream_t st) {
+    PRIMIA_REQUIRE(a && out && n >= 0);
+    if (n == 0) return PRIMIA_OK;
+    ring_scale_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)st>>>((const u64*)a, (u64)k, (u64*)out, n);
+    return launch_status();
+}
+
+int primia_trunc_div(const int64_t* x, int64_t d, int64_t* out, int64_t n, primia_stream_t st) {
+    PRIMIA_REQUIRE(x && out && n >= 0 && d > 0);
+    if (n == 0) return PRIMIA_OK;
+    trunc_div_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)st>>>(x, d, out, n);
+    return launch_status();
+}
+
+int primia_ring_rowsum(const int64_t* x, int64_t* out, int64_t rows, int64_t w, primia_stream_t st) {
+    PRIMIA_REQUIRE(x && out && rows > 0 && w > 0);
+    ring_rowsum_kernel<<<ceil_div(rows, 256), 256, 0, (hipStream_t)st>>>((const u64*)x, (u64*)out, rows, w);
+    return launch_status();
+}
+
+int primia_ring_slice_cols(const int64_t* x, int64_t* out, int64_t rows, int64_t w, int64_t start, int64_t len,
+                           primia_stream_t st) {
+    PRIMIA_REQUIRE(x && out && rows > 0 && w > 0 && start >= 0 && len > 0 && start + len <= w);
+    ring_slice_cols_kernel<<<ceil_div(rows * len, 256), 256, 0, (hipStream_t)st>>>((const u64*)x, (u64*)out, rows, w,
+                                                                                   start, len);
+    return launch_status();
+}
+
+int primia_ring_matmul(const int64_t* A, const int64_t* B, int64_t* C, int M, int K, int N, int accumulate,
+                       primia_stream_t st) {
+    PRIMIA_REQUIRE(A && B && C && M > 0 && K > 0 && N > 0);
+    return launch_gemm(GemmPair{(const u64*)A, (const u64*)B}, GemmPair{nullptr, nullptr},
+                       accumulate ? (const u64*)C : nullptr, (u64*)C, M, K, N, (hipStream_t)st);
+}
+
+int primia_im2col_syft(const int64_t* x, int64_t* im, int B, int C, int H, int W, int R, int S, int stride,
+                       int pad, primia_stream_t st) {
+    PRIMIA_REQUIRE(x && im && B > 0 && C > 0 && H > 0 && W > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0);
+    const int Ho = (H + 2 * pad - R) / stride + 1, Wo = (W + 2 * pad - S) / stride + 1;
+    PRIMIA_REQUIRE(Ho > 0 && Wo > 0);
+    const long total = (long)B * Ho * Wo * C * R * S;
+    im2col_syft_kernel<<<ceil_div(total, 256), 256, 0, (hipStream_t)st>>>((const u64*)x, (u64*)im, B, C, H, W, R, S,
+                                                                           stride, pad, Ho, Wo);
+    return launch_status();
+}
+
+int primia_col2out_syft(const int64_t* res, const int64_t* bias, int64_t* out, int B, int HoWo, int O,
+                        primia_stream_t st) {
+    PRIMIA_REQUIRE(res && out && B > 0 && HoWo > 0 && O > 0);
+    const long total = (long)B * HoWo * O;
+    col2out_syft_kernel<<<ceil_div(total, 256), 256, 0, (hipStream_t)st>>>((const u64*)res, (const u64*)bias,
+                                                                            (u64*)out, B, HoWo, O);
+    return launch_status();
+}
+
+int primia_pool_unroll_syft(const int64_t* x, int64_t* out, int B, int C, int H, int W, int k, int stride,
+                            int pad, primia_stream_t st) {
+    PRIMIA_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0 && k > 0 && stride > 0 && pad >= 0);
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    PRIMIA_REQUIRE(Ho > 0 && Wo > 0);
+    const long total = (long)B * C * Ho * Wo * k * k;
+    pool_unroll_kernel<<<ceil_div(total, 256), 256, 0, (hipStream_t)st>>>((const u64*)x, (u64*)out, B, C, H, W, k,
+                                                                           stride, pad, Ho, Wo);
+    return launch_status();
+}
+
+int primia_beaver_combine_mul(int j, const int64_t* delta, const int64_t* eps, const int64_t* a,
+                              const int64_t* b, const int64_t* c, int64_t* z, int64_t n, int64_t nb,
+                              primia_stream_t st) {
+    PRIMIA_REQUIRE((j == 0 || j == 1) && delta && eps && a && b && c && z && n >= 0 && nb > 0 && nb <= n);
+    PRIMIA_REQUIRE(n == 0 || n % nb == 0);
+    if (n == 0) return PRIMIA_OK;
+    beaver_mul_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)st>>>(j, (const u64*)delta, (const u64*)eps,
+                                                                  (const u64*)a, (const u64*)b, (const u64*)c,
+                                                                  (u64*)z, n, nb);
+    return launch_status();
+}
+
+int primia_beaver_combine_matmul(int j, const int64_t* delta, const int64_t* eps, const int64_t* a,
+                                 const int64_t* b, const int64_t* c, int64_t* z, int64_t* scratch, int M, int K,
+                                 int N, primia_stream_t st) {
+    PRIMIA_REQUIRE((j == 0 || j == 1) && delta && eps && a && b && c && z && M > 0 && K > 0 && N > 0);
+    hipStream_t s = (hipStream_t)st;
+    // z = c + delta @ (b [+ eps]) + a @ eps  — ring-identical to the reference's three products
+    const u64* b2 = (const u64*)b;
+    if (j == 0) {
+        PRIMIA_REQUIRE(scratch);
+        const long kn = (long)K * N;
+        ring_ew_kernel<0><<<ew_blocks(kn), 256, 0, s>>>((const u64*)b, (const u64*)eps, (u64*)scratch, kn, kn);
+        b2 = (const u64*)scratch;
+    }
+    return launch_gemm(GemmPair{(const u64*)delta, b2}, GemmPair{(const u64*)a, (const u64*)eps}, (const u64*)c,
+                       (u64*)z, M, K, N, s);
+}
+
+}  // extern "C"
