@@ -473,8 +473,11 @@ class ReplayDealer:
 
     def triple(self, op, xshape, yshape):
         _, eop, t = self._next("triple")
-        assert eop == op and tuple(t[0][0].shape) == tuple(xshape) and tuple(t[0][1].shape) == tuple(yshape)
-        return t
+        assert eop == op and t[0][0].size == int(np.prod(xshape)) and t[0][1].size == int(np.prod(yshape))
+        # the producer may have used a flattened view of the same elements (e.g. [rows, w] for
+        # [B, C, P, w]); element order is identical, so only the shape is restored here
+        cshape = np.broadcast_shapes(tuple(xshape), tuple(yshape)) if op == "mul" else tuple(xshape[:-1]) + (yshape[-1],)
+        return [(tj[0].reshape(xshape), tj[1].reshape(yshape), tj[2].reshape(cshape)) for tj in t]
 
     def dif_keys(self, n):
         _, en, alpha, s0, r = self._next("dif")
