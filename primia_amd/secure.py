@@ -46,6 +46,7 @@ class Dealer:
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed)
         self.log = None  # set to a list to record every primitive handed out (tests replay it)
+        self.tape = None  # set to a list to keep every primitive ON THE DEVICE (offline phase, see PreloadedDealer)
 
     def rand64(self, *shape):
         return torch.randint(-2 ** 63, 2 ** 63 - 1, shape, dtype=I64, device=self.device, generator=self.gen)
@@ -71,6 +72,8 @@ class Dealer:
         t = [(sa[j], sb[j], sc[j]) for j in range(2)]
         if self.log is not None:
             self.log.append(("triple", op, [tuple(x.cpu().numpy() for x in t[j]) for j in range(2)]))
+        if self.tape is not None:
+            self.tape.append(t)
         return t
 
     def dif_keys(self, n):
@@ -89,13 +92,40 @@ class Dealer:
                 for b in range(2)]
         if self.log is not None:
             self.log.append(("dif", n, alpha.cpu().numpy(), s0.cpu().numpy(), r.cpu().numpy()))
+        if self.tape is not None:
+            self.tape.append(keys)
         return keys
 
     def const_mask(self, *shape):
         r = self.rand64(*shape)
         if self.log is not None:
             self.log.append(("mask", r.cpu().numpy()))
+        if self.tape is not None:
+            self.tape.append(r)
         return r
+
+
+class PreloadedDealer:
+    """Online phase only: hands out primitives that a Dealer generated earlier (its `tape`), in
+    the same order — the reference's pre-provisioned crypto store (mpc/primitives.py:161-235)."""
+
+    def __init__(self, tape, device):
+        self.tape, self.pos, self.device = tape, 0, torch.device(device)
+        self.log = None
+
+    def _next(self):
+        v = self.tape[self.pos]
+        self.pos += 1
+        return v
+
+    def triple(self, op, xshape, yshape):
+        return self._next()
+
+    def dif_keys(self, n):
+        return self._next()
+
+    def const_mask(self, *shape):
+        return self._next()
 
 
 class LocalOpener:
