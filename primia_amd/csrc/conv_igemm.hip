@@ -17,6 +17,8 @@
 //
 // f32 uses v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain) — the parity path; bf16 uses
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation — the throughput path.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace primia {
@@ -47,26 +49,33 @@ struct MmaTraits<float> {
     static constexpr int KE = 32;
 };
 
+// 16 zero bytes every padded / out-of-range DMA lane reads from.
+__device__ __attribute__((aligned(16))) const unsigned char kZeroPage[16] = {0};
+
 __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename T, int BM, int BN, bool DGRAD, bool STEM>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
+// WM x WN waves per block (pixels x channels); STAGES LDS buffers (STAGES-1 k-steps of DMA in flight).
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool DGRAD, bool STEM>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p) {
+    constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int KE = MmaTraits<T>::KE;
     constexpr int CH = Elem<T>::kPerChunk;  // elements per 16-B chunk
-    constexpr int PR = BM / 32;             // pixel rows staged per thread
-    constexpr int WR = BN / 32;             // weight rows staged per thread
-    constexpr int FM = BN / 32;             // 16-channel fragments per wave
-    constexpr int FN = BM / 32;             // 16-pixel fragments per wave
+    constexpr int PR = BM * 8 / NT;         // pixel rows (= 16-B chunks) staged per thread
+    constexpr int WR = BN * 8 / NT;         // weight rows staged per thread
+    constexpr int FM = BN / WN / 16;        // 16-channel fragments per wave
+    constexpr int FN = BM / WM / 16;        // 16-pixel fragments per wave
     constexpr int TILE_P = BM * 128, TILE_W = BN * 128;
+    static_assert(PR >= 1 && WR >= 1 && FM >= 1 && FN >= 1, "tile too small for the wave grid");
+    static_assert(!STEM || (NT == 256 && STAGES == 2), "stem path is written for 256 threads, 2 stages");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // buffer b: pixel tile at smem + b*(TILE_P+TILE_W), weight tile right behind it.
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const int wm = wid >> 1, wn = wid & 1;  // wave position: pixels, channels
+    const int wm = wid / WN, wn = wid % WN;  // wave position: pixels, channels
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
@@ -77,12 +86,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     const T* __restrict__ wt = (const T*)p.wt;
 
     // ---- per-thread staging coordinates -----------------------------------------------------
-    const int srow = tid >> 3, schunk = tid & 7;
+    // Register staging (stem): thread t owns rows t/8 + 32j, chunk t%8.
+    // LDS-DMA staging (all other convs): one global_load_lds_dwordx4 moves 8 rows x 128 B per
+    // wave; wave w issues groups w*PR + j, lane l lands in row 8*(w*PR+j) + l/8, chunk SLOT l%8,
+    // and — the destination being lane-linear — fetches the global chunk slot ^ ((row>>1)&7), so
+    // the LDS image carries the same XOR swizzle the fragment reads expect.
+    constexpr bool GLDS = !STEM;
+    const int srow = GLDS ? 0 : (tid >> 3), schunk = tid & 7;
     int nb[PR], hb[PR], wb[PR];
     bool mval[PR];
 #pragma unroll
     for (int j = 0; j < PR; ++j) {
-        long m = m0 + srow + 32 * j;
+        const int row = GLDS ? ((wid * PR + j) * 8 + (lane >> 3)) : (srow + 32 * j);
+        long m = m0 + row;
         mval[j] = m < p.Md;
         if (!mval[j]) m = 0;
         int wd = (int)(m % p.Wd);
@@ -100,61 +116,111 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     }
     const T* wrow[WR];
 #pragma unroll
-    for (int j = 0; j < WR; ++j) wrow[j] = wt + (long)(n0 + srow + 32 * j) * p.klen + schunk * CH;
+    for (int j = 0; j < WR; ++j) {
+        if (GLDS) {
+            const int row = (wid * WR + j) * 8 + (lane >> 3);
+            wrow[j] = wt + (long)(n0 + row) * p.klen + ((lane & 7) ^ ((row >> 1) & 7)) * CH;
+        } else {
+            wrow[j] = wt + (long)(n0 + srow + 32 * j) * p.klen + schunk * CH;
+        }
+    }
 
     u32x4 rp[PR], rw[WR];
 
-    auto load_global = [&](int step) {
-        if (STEM) {
-            // element e0 of the reduction axis -> kernel row r, first pixel sx inside the row.
-            const int e0 = step * KE + schunk * CH;
-            const int r = e0 >> 5, sx = (e0 & 31) >> 2;
+    // ---- LDS-DMA stage ------------------------------------------------------------------------
+    // Everything that depends on the lane is folded ONCE into (poff, pmask) per staged row:
+    //   source element offset of tap (r,s), channel c0  =  poff[j] + tapoff(r,s) + c0
+    //   row j takes part in tap t                        =  bit t of pmask[j]
+    // with a wave-uniform tapoff: forward (r*Ws + s)*Cs; data-gradient -( (r/stride)*Ws + s/stride )*Cs
+    // (for stride 2 the taps of the right parity are exactly those with (hb - r) even, and then
+    // (hb - r)/2 = (hb >> 1) - (r >> 1)).  The per-step work is one add, one bit test and a select.
+    int poff[PR];
+    unsigned pmask[PR];
+    if constexpr (GLDS) {
 #pragma unroll
-            for (int j = 0; j < PR; ++j) {
-                const int hs = hb[j] + r;
-                const bool rowok = mval[j] && r < p.R && hs >= 0 && hs < p.Hs;
-                const int ws = wb[j] + sx;
-                const long base = ((long)nb[j] + (long)hs * p.Ws + ws) * 4;
-                if (sizeof(T) == 4) {
-                    u32x4 v = {0, 0, 0, 0};
-                    if (rowok && ws >= 0 && ws < p.Ws) v = *(const u32x4*)(src + base);
-                    rp[j] = v;
-                } else {
-                    u32x2 a = {0, 0}, b = {0, 0};
-                    if (rowok && ws >= 0 && ws < p.Ws) a = *(const u32x2*)(src + base);
-                    if (rowok && ws + 1 >= 0 && ws + 1 < p.Ws) b = *(const u32x2*)(src + base + 4);
-                    rp[j] = u32x4{a[0], a[1], b[0], b[1]};
-                }
-            }
-        } else {
-            const int kk = step * KE;
-            const int tap = kk / p.Cs;
-            const int c0 = kk - tap * p.Cs + schunk * CH;
-            const int r = tap / p.S, s = tap - r * p.S;
-#pragma unroll
-            for (int j = 0; j < PR; ++j) {
-                int hs, ws;
-                bool ok = mval[j];
-                if (DGRAD) {
-                    const int th = hb[j] - r, tw = wb[j] - s;
-                    ok = ok && th >= 0 && tw >= 0;
-                    if (p.stride == 2) {
-                        ok = ok && ((th | tw) & 1) == 0;
-                        hs = th >> 1;
-                        ws = tw >> 1;
+        for (int j = 0; j < PR; ++j) {
+            const int row = (wid * PR + j) * 8 + (lane >> 3);
+            const int chunk = (lane & 7) ^ ((row >> 1) & 7);
+            unsigned mask = 0;
+            for (int r = 0; r < p.R; ++r)
+                for (int s2 = 0; s2 < p.S; ++s2) {
+                    bool ok = mval[j];
+                    if (DGRAD) {
+                        const int th = hb[j] - r, tw = wb[j] - s2;
+                        ok = ok && th >= 0 && tw >= 0;
+                        if (p.stride == 2) ok = ok && ((th | tw) & 1) == 0;
+                        const int hs = p.stride == 2 ? th >> 1 : th, ws = p.stride == 2 ? tw >> 1 : tw;
+                        ok = ok && hs < p.Hs && ws < p.Ws;
                     } else {
-                        hs = th;
-                        ws = tw;
+                        const int hs = hb[j] + r, ws = wb[j] + s2;
+                        ok = ok && hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws;
                     }
-                    ok = ok && hs < p.Hs && ws < p.Ws;
-                } else {
-                    hs = hb[j] + r;
-                    ws = wb[j] + s;
-                    ok = ok && hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws;
+                    if (ok) mask |= 1u << (r * p.S + s2);
                 }
+            pmask[j] = mask;
+            const int h0 = (DGRAD && p.stride == 2) ? hb[j] >> 1 : hb[j];
+            const int w0 = (DGRAD && p.stride == 2) ? wb[j] >> 1 : wb[j];
+            poff[j] = (nb[j] + h0 * p.Ws + w0) * p.Cs + chunk * CH;
+        }
+    }
+    // wave-uniform walk over the reduction axis: (tap, c0) and the tap's source offset
+    int st_tap = 0, st_r = 0, st_s = 0, st_c0 = 0, st_tapoff = 0, st_step = 0;
+    auto stage_glds = [&](int step, int buf) {
+        (void)step;  // stages are issued in order; the walk state below IS the step
+        char* lp = smem + buf * (TILE_P + TILE_W);
+        char* lw = lp + TILE_P;
+        const int uoff = st_tapoff + st_c0;
+        const unsigned tbit = 1u << st_tap;
+#pragma unroll
+        for (int j = 0; j < PR; ++j) {
+            const T* g = (pmask[j] & tbit) ? src + (poff[j] + uoff) : (const T*)kZeroPage;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(lp + (wid * PR + j) * 1024),
+                                             16, 0, 0);
+        }
+        const int woff = st_step * KE;
+#pragma unroll
+        for (int j = 0; j < WR; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[j] + woff),
+                                             (__attribute__((address_space(3))) void*)(lw + (wid * WR + j) * 1024),
+                                             16, 0, 0);
+        // advance
+        ++st_step;
+        st_c0 += KE;
+        if (st_c0 == p.Cs) {
+            st_c0 = 0;
+            ++st_tap;
+            if (++st_s == p.S) {
+                st_s = 0;
+                ++st_r;
+            }
+            if (DGRAD)
+                st_tapoff = -(((p.stride == 2 ? st_r >> 1 : st_r) * p.Ws + (p.stride == 2 ? st_s >> 1 : st_s)) * p.Cs);
+            else
+                st_tapoff = (st_r * p.Ws + st_s) * p.Cs;
+        }
+    };
+
+    auto load_global = [&](int step) {
+        // register staging, stem only: element e0 of the reduction axis -> kernel row r, first
+        // pixel sx inside the row; each 8-byte pixel is predicated on its own.
+        const int e0 = step * KE + schunk * CH;
+        const int r = e0 >> 5, sx = (e0 & 31) >> 2;
+#pragma unroll
+        for (int j = 0; j < PR; ++j) {
+            const int hs = hb[j] + r;
+            const bool rowok = mval[j] && r < p.R && hs >= 0 && hs < p.Hs;
+            const int ws = wb[j] + sx;
+            const long base = ((long)nb[j] + (long)hs * p.Ws + ws) * 4;
+            if (sizeof(T) == 4) {
                 u32x4 v = {0, 0, 0, 0};
-                if (ok) v = *(const u32x4*)(src + ((long)nb[j] + (long)hs * p.Ws + ws) * p.Cs + c0);
+                if (rowok && ws >= 0 && ws < p.Ws) v = *(const u32x4*)(src + base);
                 rp[j] = v;
+            } else {
+                u32x2 a = {0, 0}, b = {0, 0};
+                if (rowok && ws >= 0 && ws < p.Ws) a = *(const u32x2*)(src + base);
+                if (rowok && ws + 1 >= 0 && ws + 1 < p.Ws) b = *(const u32x2*)(src + base + 4);
+                rp[j] = u32x4{a[0], a[1], b[0], b[1]};
             }
         }
 #pragma unroll
@@ -177,8 +243,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
         for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int fr = lane & 15, fg = lane >> 4;
-    const int prow0 = wm * (BM / 2) + fr;  // + 16*fn
-    const int crow0 = wn * (BN / 2) + fr;  // + 16*fm
+    const int prow0 = wm * (BM / WM) + fr;  // + 16*fn
+    const int crow0 = wn * (BN / WN) + fr;  // + 16*fm
 
     auto compute = [&](int buf) {
         const char* lp = smem + buf * (TILE_P + TILE_W);
@@ -223,27 +289,53 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     };
 
     // ---- main loop -----------------------------------------------------------------------------
-    load_global(0);
-    store_lds(0);
-    __syncthreads();
-    for (int step = 0; step < p.nsteps; ++step) {
-        const int cur = step & 1;
-        const bool more = step + 1 < p.nsteps;
-        if (more) load_global(step + 1);
-        compute(cur);
-        if (more) store_lds(cur ^ 1);
+    if constexpr (GLDS) {
+        // STAGES-deep LDS ring fed by LDS-DMA.  Per k-step ONE raw barrier: a counted vmcnt leaves the
+        // newer stages' DMA in flight across it (a plain __syncthreads() would drain them).
+        constexpr int NLOAD = PR + WR;  // DMA instructions per wave per stage
+#pragma unroll
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < p.nsteps) stage_glds(s, s);
+        int cur = 0, nxt = STAGES - 1;
+        for (int step = 0; step < p.nsteps; ++step) {
+            // stages step+1 .. step+STAGES-2 may still be in flight
+            int ahead = p.nsteps - 1 - step;
+            if (ahead > STAGES - 2) ahead = STAGES - 2;
+            if (STAGES >= 4 && ahead >= 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
+            else if (STAGES >= 3 && ahead >= 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLOAD) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // stage `step` visible to all; buffer `nxt` no longer read
+            if (step + STAGES - 1 < p.nsteps) stage_glds(step + STAGES - 1, nxt);
+            compute(cur);
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+        }
+    } else {
+        load_global(0);
+        store_lds(0);
         __syncthreads();
+        for (int step = 0; step < p.nsteps; ++step) {
+            const int cur = step & 1;
+            const bool more = step + 1 < p.nsteps;
+            if (more) load_global(step + 1);
+            compute(cur);
+            if (more) store_lds(cur ^ 1);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue: lane holds 4 consecutive channels of one pixel per fragment -------------------
     T* __restrict__ dst = (T*)p.dst;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const long m = m0 + wm * (BM / 2) + 16 * j + fr;
+        const long m = m0 + wm * (BM / WM) + 16 * j + fr;
         if (m >= p.Md) continue;
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
-            const int ch = n0 + wn * (BN / 2) + 16 * i + fg * 4;
+            const int ch = n0 + wn * (BN / WN) + 16 * i + fg * 4;
             T* q = dst + m * p.Nd + ch;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (sizeof(T) == 4) {
@@ -270,30 +362,56 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(IgemmParams p) {
     }
 }
 
-template <typename T, int BM, int BN, bool DGRAD, bool STEM>
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool DGRAD, bool STEM>
 static int launch_igemm(const IgemmParams& p, hipStream_t st) {
     const int ntm = ceil_div(p.Md, BM);
     IgemmParams q = p;
     q.ntile_n = p.Nd / BN;
     const int grid = ntm * q.ntile_n;
-    const size_t lds = 2 * (BM + BN) * 128;
-    auto kern = conv_igemm_kernel<T, BM, BN, DGRAD, STEM>;
-    if (lds > 48 * 1024) {
+    const size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, DGRAD, STEM>;
+    static bool attr_set = false;  // once per instantiation (not per launch: keeps graph capture legal)
+    if (lds > 48 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
     }
-    kern<<<grid, 256, lds, st>>>(q);
+    kern<<<grid, 64 * WM * WN, lds, st>>>(q);
     return launch_status();
 }
 
+// Tile choice.  Default 'e': 128-pixel tile, 8 waves (4 x 2), double-buffered LDS-DMA, 2 blocks/CU —
+// measured fastest on the ResNet-18 shapes (profiles/r01_conv_layers_*.txt): the kernel is bound by
+// the L2 -> LDS fill rate per CU, so waves in flight beat pipeline depth (the 3-stage variants lose
+// the second resident block).  PRIMIA_CONV_CFG=<letter> selects an alternative for A/B runs:
+//   a 128 px 2x2 waves 2 stages | b 128 px 2x2 3 stages | c 256 px 4x2 2 stages | d 256 px 4x2 3 stages
+//   e 128 px 4x2 waves 2 stages | f 128 px 4x2 3 stages
 template <typename T, bool DGRAD>
 static int dispatch_igemm(const IgemmParams& p, bool stem, hipStream_t st) {
     if (stem) {
         if (DGRAD) return PRIMIA_ERR_UNSUPPORTED;
-        return launch_igemm<T, 128, 64, false, true>(p, st);
+        return launch_igemm<T, 128, 64, 2, 2, 2, false, true>(p, st);
     }
-    if (p.Nd % 128 == 0) return launch_igemm<T, 128, 128, DGRAD, false>(p, st);
-    return launch_igemm<T, 128, 64, DGRAD, false>(p, st);
+    if ((long)p.Nb * p.Hs * p.Ws * p.Cs >= (1L << 31)) return PRIMIA_ERR_ARG;  // 32-bit element offsets
+    static const char cfg = getenv("PRIMIA_CONV_CFG") ? getenv("PRIMIA_CONV_CFG")[0] : 'e';
+    const bool wide = p.Nd % 128 == 0;
+#define PRIMIA_IGEMM_CASE(L, BM, WM_, WN_, ST)                                                   \
+    case L:                                                                                      \
+        return wide ? launch_igemm<T, BM, 128, WM_, WN_, ST, DGRAD, false>(p, st)                \
+                    : launch_igemm<T, BM, 64, WM_, WN_, ST, DGRAD, false>(p, st);
+    switch (cfg) {
+        PRIMIA_IGEMM_CASE('a', 128, 2, 2, 2)
+        PRIMIA_IGEMM_CASE('b', 128, 2, 2, 3)
+        PRIMIA_IGEMM_CASE('c', 256, 4, 2, 2)
+        PRIMIA_IGEMM_CASE('d', 256, 4, 2, 3)
+        PRIMIA_IGEMM_CASE('e', 128, 4, 2, 2)
+        PRIMIA_IGEMM_CASE('f', 128, 4, 2, 3)
+        default:
+            break;
+    }
+#undef PRIMIA_IGEMM_CASE
+    return wide ? launch_igemm<T, 128, 128, 4, 2, 2, DGRAD, false>(p, st)
+                : launch_igemm<T, 128, 64, 4, 2, 2, DGRAD, false>(p, st);
 }
 
 }  // namespace primia

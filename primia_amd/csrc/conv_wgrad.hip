@@ -252,9 +252,11 @@ static int launch_wgrad(WgradParams p, hipStream_t st) {
     const int grid = combos * p.nsplit;
     const size_t lds = 2 * KP * ((BMK + BNC) * sizeof(T) + 32);
     auto kern = conv_wgrad_kernel<T, BMK, BNC, STEM>;
-    if (lds > 48 * 1024) {
+    static bool attr_set = false;  // once per instantiation (not per launch: keeps graph capture legal)
+    if (lds > 48 * 1024 && !attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
     }
     kern<<<grid, 256, lds, st>>>(p);
     return launch_status();
