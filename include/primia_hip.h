@@ -160,6 +160,8 @@ int primia_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq
  * ------------------------------------------------------------------------------------------ */
 int primia_scale(float* x, int64_t n, float a, primia_stream_t stream);  /* x *= a   (theta_k * w_k) */
 int primia_divide(float* x, int64_t n, float d, primia_stream_t stream); /* x /= d   (sum / K)       */
+/* y += a * x — in-process clients: sum_k theta_k * w_k without a collective (utils.py:1087-1090). */
+int primia_axpy(float* y, const float* x, int64_t n, float a, primia_stream_t stream);
 /* q = int64(trunc(float32(x) * float32(scale)))  (FixedPrecisionTensor.fix_precision,
  * syft/frameworks/torch/tensors/interpreters/precision.py:117-132). */
 int primia_fx_encode(const float* x, int64_t* q, int64_t n, float scale, primia_stream_t stream);

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""PriMIA-compatible inference CLI (inference.py:47-76, 279-323 of the reference).
+
+    python inference.py --model_weights model_weights/final_*.pt [--data_dir DIR|synthetic]
+                        [--encrypted_inference] [--cuda] [--websockets_config CSV] [--http_protocol]
+
+Plain inference runs the HIP engine in eval mode.  `--encrypted_inference` shares the model and
+each image between model_owner and data_owner (fixed precision 10^16, protocol "fss", a dealer as
+crypto provider) and runs the secret-shared forward of primia_amd.secure, image by image like the
+reference's loop.  Output: the reference's JSON on stdout, {"Inference Results": {index: class}}.
+"""
+import argparse
+import json
+import os
+import sys
+from datetime import datetime
+
+import torch
+
+from primia_amd.engine import ResNet18Engine
+from primia_amd.secure import Dealer, SecureContext, SecureResNet18
+from primia_amd.torchlib_compat import Arguments  # noqa: F401  (checkpoints pickle an Arguments instance)
+
+
+def load_images(data_dir, n, size, seed=0):
+    """Folder of images -> fp32 [n,3,S,S]; 'synthetic' (or a missing folder) -> seeded noise."""
+    if data_dir and os.path.isdir(data_dir):
+        try:
+            from PIL import Image
+            import numpy as np
+
+            files = sorted(f for f in os.listdir(data_dir) if f.lower().endswith((".png", ".jpg", ".jpeg")))[:n]
+            out = []
+            for f in files:
+                im = Image.open(os.path.join(data_dir, f)).convert("RGB").resize((size, size))
+                out.append(torch.from_numpy(np.asarray(im, dtype="float32") / 255.0).permute(2, 0, 1))
+            if out:
+                return torch.stack(out)
+        except ImportError:
+            pass
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(n, 3, size, size, generator=g)
+
+
+if __name__ == "__main__":
+    start_time = datetime.now()
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--data_dir", default=None, help="data to classify")
+    parser.add_argument("--model_weights", type=str, required=True, help="model weights to use")
+    parser.add_argument("--encrypted_inference", action="store_true", help="Perform encrypted inference")
+    parser.add_argument("--websockets_config", default=None, help="accepted for compatibility (in-process parties)")
+    parser.add_argument("--cuda", action="store_true", help="Use GPU acceleration (always on here).")
+    parser.add_argument("--http_protocol", action="store_true", help="accepted for compatibility")
+    parser.add_argument("--num_images", type=int, default=4)
+    cmd_args = parser.parse_args()
+    if not torch.cuda.is_available():
+        raise SystemExit("primia_amd runs inference on the GPU only (HIP kernels); no GPU visible")
+    device = torch.device("cuda:0")
+    state = torch.load(cmd_args.model_weights, map_location="cpu", weights_only=False)
+    args = state["args"]
+    if not isinstance(args, Arguments):
+        args = Arguments.from_namespace(args)
+    args.from_previous_checkpoint(cmd_args)
+    size = getattr(args, "inference_resolution", args.train_resolution)
+    sd = state["model_state_dict"]
+    mean, std = state.get("val_mean_std", (torch.zeros(3), torch.ones(3)))
+    images = load_images(cmd_args.data_dir, cmd_args.num_images, size)
+    images = (images - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1)
+    total_pred = []
+    if args.encrypted_inference:
+        # inference.py:279-286: fix_precision(precision_fractional=16, dtype="long").share(..., protocol="fss")
+        ctx = SecureContext(Dealer(device, seed=0), base=10, precision_fractional=16)
+        model = SecureResNet18(ctx, sd, input_size=size)
+        for i in range(images.shape[0]):
+            out = model(images[i:i + 1].to(device))
+            total_pred.append(int(out.argmax(dim=1).item()))
+    else:
+        eng = ResNet18Engine(1, sd["fc.weight"].shape[0], sd["conv1.weight"].shape[1], size,
+                             getattr(args, "pooling_type", "max"), dtype=torch.float32, device=device)
+        eng.load_state_dict(sd)
+        eng.eval()
+        for i in range(images.shape[0]):
+            total_pred.append(int(eng.forward(images[i:i + 1].to(device)).argmax(dim=1).item()))
+    print(json.dumps({"Inference Results": {i: p for i, p in enumerate(total_pred)}}))
+    print("Took {:s} seconds.".format(str(datetime.now() - start_time)), file=sys.stderr)

@@ -71,6 +71,20 @@ struct ScaleFn {
     __device__ __forceinline__ void one(long i) const { x[i] *= a; }
 };
 
+struct AxpyFn {
+    float* y;
+    const float* x;
+    float a;
+    __device__ __forceinline__ void vec(long q) const {
+        f32x4 v = ((f32x4*)y)[q];
+        const f32x4 u = ((const f32x4*)x)[q];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = __fadd_rn(v[i], __fmul_rn(u[i], a));  // product rounded first, as torch
+        ((f32x4*)y)[q] = v;
+    }
+    __device__ __forceinline__ void one(long i) const { y[i] = __fadd_rn(y[i], __fmul_rn(x[i], a)); }
+};
+
 struct DivFn {
     float* x;
     float d;
@@ -138,6 +152,14 @@ int primia_scale(float* x, int64_t n, float a, primia_stream_t stream) {
     PRIMIA_REQUIRE(x && n >= 0 && aligned16(x));
     if (n == 0) return PRIMIA_OK;
     ScaleFn f{x, a};
+    flat_kernel<<<flat_blocks(n), 256, 0, (hipStream_t)stream>>>(f, n);
+    return launch_status();
+}
+
+int primia_axpy(float* y, const float* x, int64_t n, float a, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && x && n >= 0 && aligned16(y) && aligned16(x));
+    if (n == 0) return PRIMIA_OK;
+    AxpyFn f{y, x, a};
     flat_kernel<<<flat_blocks(n), 256, 0, (hipStream_t)stream>>>(f, n);
     return launch_status();
 }

@@ -49,3 +49,323 @@ class LearningRateScheduler:
         else:
             optimizer.lr = new_lr
         return new_lr
+
+
+# ---------------------------------------------------------------------------------------------
+# Arguments (torchlib/utils.py:92-267): the INI + CLI attribute bag, same names and fallbacks.
+# ---------------------------------------------------------------------------------------------
+_REQ = object()
+# (section, key, attribute, kind, fallback)  — _REQ = no fallback, configparser raises if absent
+_CONFIG_KEYS = [
+    ("config", "batch_size", "batch_size", "int", _REQ),
+    ("config", "test_batch_size", "test_batch_size", "int", _REQ),
+    ("config", "train_resolution", "train_resolution", "int", _REQ),
+    ("config", "validation_split", "validation_split", "int", _REQ),
+    ("config", "epochs", "epochs", "int", _REQ),
+    ("config", "lr", "lr", "float", _REQ),
+    ("config", "deterministic", "deterministic", "bool", _REQ),
+    ("config", "restarts", "restarts", "int", _REQ),
+    ("config", "seed", "seed", "int", 1),
+    ("config", "test_interval", "test_interval", "int", 1),
+    ("config", "log_interval", "log_interval", "int", 10),
+    ("config", "optimizer", "optimizer", "str", _REQ),
+    ("config", "differentially_private", "differentially_private", "bool", False),
+    ("config", "model", "model", "str", _REQ),
+    ("config", "pooling_type", "pooling_type", "str", "max"),
+    ("config", "pretrained", "pretrained", "bool", _REQ),
+    ("config", "weight_decay", "weight_decay", "float", _REQ),
+    ("config", "weight_classes", "weight_classes", "bool", _REQ),
+    ("augmentation", "rotation", "rotation", "float", _REQ),
+    ("augmentation", "translate", "translate", "float", _REQ),
+    ("augmentation", "scale", "scale", "float", _REQ),
+    ("augmentation", "shear", "shear", "float", _REQ),
+    ("albumentations", "overall_prob", "albu_prob", "float", _REQ),
+    ("albumentations", "individual_probs", "individual_albu_probs", "float", _REQ),
+    ("albumentations", "noise_std", "noise_std", "float", _REQ),
+    ("albumentations", "noise_prob", "noise_prob", "float", _REQ),
+] + [("albumentations", k, k, "bool", _REQ) for k in (
+    "clahe", "randomgamma", "randombrightness", "blur", "elastic", "optical_distortion", "grid_distortion",
+    "grid_shuffle", "hsv", "invert", "cutout", "shadow", "fog", "sun_flare", "solarize", "equalize",
+    "grid_dropout")] + [
+    ("augmentation", "mixup", "mixup", "bool", _REQ),
+    ("augmentation", "mixup_prob", "mixup_prob", "float", _REQ),
+    ("augmentation", "mixup_lambda", "mixup_lambda", "float", None),
+]
+_FEDERATED_KEYS = [
+    ("federated", "sync_every_n_batch", "sync_every_n_batch", "int", _REQ),
+    ("federated", "wait_interval", "wait_interval", "float", 0.1),
+    ("federated", "keep_optim_dict", "keep_optim_dict", "bool", _REQ),
+    ("federated", "repetitions_dataset", "repetitions_dataset", "int", _REQ),
+    ("federated", "weighted_averaging", "weighted_averaging", "bool", _REQ),
+    ("federated", "precision_fractional", "precision_fractional", "float", 16),
+]
+
+
+def _cfg_get(config, section, key, kind, fallback):
+    getter = {"int": config.getint, "float": config.getfloat, "bool": config.getboolean, "str": config.get}[kind]
+    if fallback is _REQ:
+        return getter(section, key)
+    return getter(section, key, fallback=fallback)
+
+
+class Arguments:
+    """Same attributes, fallbacks and side effects as the reference's Arguments."""
+
+    def __init__(self, cmd_args, config, mode: str = "train", verbose: bool = True):
+        assert mode in ["train", "inference"], "no other mode known"
+        self.name = cmd_args.training_name if getattr(cmd_args, "training_name", None) else "default"
+        self.save_file = getattr(cmd_args, "save_file", "model_weights/completed_trainings.csv")
+        for section, key, attr, kind, fb in _CONFIG_KEYS:
+            setattr(self, attr, _cfg_get(config, section, key, kind, fb))
+        self.inference_resolution = config.getint("config", "inference_resolution", fallback=self.train_resolution)
+        if self.train_resolution != self.inference_resolution:
+            from warnings import warn
+
+            warn("We are not supporting different train and inference resolutions although it works for some "
+                 "scenarios.", category=UserWarning)
+        self.end_lr = config.getfloat("config", "end_lr", fallback=self.lr)
+        assert self.optimizer in ["SGD", "Adam"], "Unknown optimizer"
+        if self.optimizer == "Adam":
+            self.beta1 = config.getfloat("config", "beta1", fallback=0.9)
+            self.beta2 = config.getfloat("config", "beta2", fallback=0.999)
+        assert self.model in ["simpleconv", "resnet-18", "vgg16"]
+        if self.mixup and self.mixup_prob == 1.0:
+            self.batch_size *= 2
+            print("Doubled batch size because of mixup")
+        train = mode == "train"
+        self.train_federated = cmd_args.train_federated if train else False
+        self.unencrypted_aggregation = cmd_args.unencrypted_aggregation if train else False
+        if self.train_federated:
+            for section, key, attr, kind, fb in _FEDERATED_KEYS:
+                setattr(self, attr, _cfg_get(config, section, key, kind, fb))
+            if self.repetitions_dataset > 1:
+                self.epochs = int(self.epochs / self.repetitions_dataset)
+                if verbose:
+                    print("Number of epochs was decreased to {:d} because of {:d} repetitions of dataset".format(
+                        self.epochs, self.repetitions_dataset))
+        self.visdom = cmd_args.visdom if train else False
+        self.encrypted_inference = cmd_args.encrypted_inference if mode == "inference" else False
+        self.data_dir = cmd_args.data_dir
+        self.cuda = cmd_args.cuda
+        self.websockets = cmd_args.websockets if train else False
+        if self.websockets:
+            assert self.train_federated, "If you use websockets it must be federated"
+        self.num_threads = config.getint("system", "num_threads", fallback=0)
+
+    @classmethod
+    def from_namespace(cls, args):
+        obj = cls.__new__(cls)
+        for attr in dir(args):
+            if not attr.startswith("__") and not callable(getattr(args, attr)):
+                setattr(obj, attr, getattr(args, attr))
+        return obj
+
+    def from_previous_checkpoint(self, cmd_args):
+        self.visdom = False
+        if hasattr(cmd_args, "encrypted_inference"):
+            self.encrypted_inference = cmd_args.encrypted_inference
+        self.cuda = cmd_args.cuda
+        self.websockets = getattr(cmd_args, "websockets", False)
+
+    def incorporate_cmd_args(self, cmd_args):
+        for k, v in vars(cmd_args).items():
+            setattr(self, k, v)
+
+    def __str__(self):
+        width = max(len(k) for k in vars(self))
+        return "\n".join("{:>{w}}: {}".format(k, v, w=width) for k, v in sorted(vars(self).items()))
+
+
+def read_websocket_config(path: str):
+    """torchlib/run_websocket_server.py:6-8 — `read_csv(path, header=None, index_col=0).to_dict()`:
+    the CSV has one ROW per field (id / host / port) and one COLUMN per worker, so the result is
+    {column_number: {"id": ..., "host": ..., "port": ...}} with column numbers starting at 1."""
+    import csv
+
+    with open(path, newline="") as f:
+        rows = [r for r in csv.reader(f) if r]
+    out = {}
+    for row in rows:
+        field = row[0].strip()
+        for col, value in enumerate(row[1:], start=1):
+            v = value.strip()
+            out.setdefault(col, {})[field] = int(v) if v.isdigit() else v
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Federated epoch for clients that live in THIS process (one engine per client), the layout the
+# reference uses with VirtualWorkers (torchlib/utils.py:936-1233).  The per-rank / RCCL form of the
+# same control flow is primia_amd.fed.federated_epoch.
+# ---------------------------------------------------------------------------------------------
+def aggregation(local_model, models, workers, crypto_provider, args, test_params, weights=None, secure=True):
+    """torchlib/utils.py:1000-1092 on flat arenas.  `models` maps worker id -> engine,
+    `local_model` is the engine receiving the average.  Returns local_model."""
+    import torch
+
+    from . import _lib
+
+    ids = [w if isinstance(w, str) else w.id for w in workers]
+    shapes = {models[i].flat.numel() for i in ids}
+    assert len(shapes) == 1 and local_model.flat.numel() == next(iter(shapes)), "Shape mismatch BEFORE sending and getting"
+    n = local_model.flat.numel()
+    out = local_model.flat
+    if secure:
+        pf = getattr(args, "precision_fractional", 16)
+        scale = float(10 ** pf)
+        acc = torch.zeros(n, dtype=torch.int64, device=out.device)
+        q = torch.empty(n, dtype=torch.int64, device=out.device)
+        tmp = torch.empty_like(out)
+        for i in ids:
+            tmp.copy_(models[i].flat)
+            if weights:
+                _lib.call("primia_scale", tmp, n, float(weights[i]))
+            _lib.call("primia_fx_encode", tmp, q, n, scale)
+            _lib.call("primia_ring_add", acc, q, acc, n, n)
+        _lib.call("primia_fx_decode", acc, out, n, scale)
+    else:
+        tmp = torch.zeros_like(out)
+        for i in ids:
+            _lib.call("primia_axpy", tmp, models[i].flat, n, float(weights[i]) if weights else 1.0)
+        out.copy_(tmp)
+    if not weights:
+        _lib.call("primia_divide", out, n, float(len(ids)))
+    local_model.refresh_weights()
+    return local_model
+
+
+def send_new_models(local_model, models):
+    """torchlib/utils.py:1095-1105: every listed worker model takes the averaged arena."""
+    for worker, m in models.items():
+        if worker == "local_model":
+            continue
+        m.flat.copy_(local_model.flat)
+        m.refresh_weights()
+    return models
+
+
+def secure_aggregation_epoch(args, models, device, train_loaders, optimizers, epoch, loss_fns, crypto_provider,
+                             weights=None, test_params=None, verbose=True, privacy_engines=None):
+    """torchlib/utils.py:1108-1233.  train_loaders: {worker: iterable of (data, target)};
+    optimizers: {worker_id: {"lr": ...}} (an optimizer here is just its hyper-parameters: the state
+    lives in the engine and is reset at every sync unless keep_optim_dict)."""
+    import numpy as np
+
+    def wid(w):
+        return w if isinstance(w, str) else w.id
+
+    def step(engine, opt):
+        if args.optimizer == "SGD":
+            engine.sgd_step(opt["lr"], args.weight_decay)
+        else:
+            engine.adam_step(opt["lr"], (args.beta1, args.beta2), 1e-8, args.weight_decay)
+
+    if not args.keep_optim_dict:
+        for w in optimizers:
+            models[w].reset_optimizer()
+    avg_loss = []
+    num_batches = {wid(w): len(tl) for w, tl in train_loaders.items()}
+    loaders = {w: iter(tl) for w, tl in train_loaders.items()}
+    secure = not args.unencrypted_aggregation
+    for batch_idx in range(max(num_batches.values())):
+        for w, it in loaders.items():
+            i = wid(w)
+            if batch_idx >= num_batches[i]:
+                continue
+            data, target = next(it)
+            models[i].forward(data)
+            loss = models[i].loss_backward(target, soft=getattr(loss_fns.get(i), "soft", False) if loss_fns else False)
+            step(models[i], optimizers[i])
+            avg_loss.append(loss.item())
+        if batch_idx > 0 and batch_idx % args.sync_every_n_batch == 0:
+            models["local_model"] = aggregation(models["local_model"], models, train_loaders.keys(), crypto_provider,
+                                                args, test_params, weights=weights, secure=secure)
+            send_new_models(models["local_model"],
+                            {w: m for w, m in models.items() if w in num_batches and num_batches[w] > batch_idx})
+            if not args.keep_optim_dict:
+                for w in optimizers:
+                    models[w].reset_optimizer()
+    models["local_model"] = aggregation(models["local_model"], models, train_loaders.keys(), crypto_provider, args,
+                                        test_params, weights=weights, secure=secure)
+    models = send_new_models(models["local_model"], models)
+    return models, float(np.mean(avg_loss))
+
+
+def train_federated(args, model, device, train_loaders, optimizer, epoch, loss_fn, crypto_provider,
+                    test_params=None, vis_params=None, verbose=True, privacy_engines=None):
+    """torchlib/utils.py:936-988."""
+    total_batches = sum(len(tl) for tl in train_loaders.values())
+    w_dict = None
+    if args.weighted_averaging:
+        w_dict = {(w if isinstance(w, str) else w.id): len(tl) / total_batches for w, tl in train_loaders.items()}
+    model, avg_loss = secure_aggregation_epoch(args, model, device, train_loaders, optimizer, epoch, loss_fn,
+                                               crypto_provider, test_params=test_params, weights=w_dict)
+    if verbose:
+        print("Train Epoch: {} \tLoss: {:.6f}".format(epoch, avg_loss))
+    return model
+
+
+def train(args, model, device, train_loader, optimizer, epoch, loss_fn, num_classes=3, vis_params=None,
+          verbose=True):
+    """torchlib/utils.py:1236-1292 — local (non-federated) epoch."""
+    losses = []
+    for batch_idx, (data, target) in enumerate(train_loader):
+        model.forward(data)
+        loss = model.loss_backward(target)
+        if args.optimizer == "SGD":
+            model.sgd_step(optimizer["lr"], args.weight_decay)
+        else:
+            model.adam_step(optimizer["lr"], (args.beta1, args.beta2), 1e-8, args.weight_decay)
+        if batch_idx % args.log_interval == 0:
+            losses.append(loss.item())
+            if verbose:
+                print("Train Epoch: {} [{}/{}]\tLoss: {:.6f}".format(epoch, batch_idx, len(train_loader), losses[-1]))
+    return model
+
+
+def matthews_corrcoef(y_true, y_pred, num_classes):
+    """Multi-class MCC (what sklearn.metrics.matthews_corrcoef computes) from the confusion matrix."""
+    import numpy as np
+
+    c = np.zeros((num_classes, num_classes), dtype=np.float64)
+    for t, p in zip(y_true, y_pred):
+        c[int(t), int(p)] += 1
+    t_k, p_k, n, tr = c.sum(1), c.sum(0), c.sum(), np.trace(c)
+    num = tr * n - t_k @ p_k
+    den = np.sqrt(n * n - p_k @ p_k) * np.sqrt(n * n - t_k @ t_k)
+    return float(num / den) if den > 0 else 0.0
+
+
+def test(args, model, device, val_loader, epoch, loss_fn, num_classes, verbose=True, vis_params=None,
+         class_names=None):
+    """torchlib/utils.py:1354-1467 reduced to what the training loop consumes: (loss, objective)."""
+    import numpy as np
+    import torch
+
+    model.eval()
+    losses, preds, tgts = [], [], []
+    for data, target in val_loader:
+        logits = model.forward(data)
+        ls = torch.log_softmax(logits, dim=1)
+        losses.append(float(-ls.gather(1, target.view(-1, 1)).mean().item()))
+        preds += logits.argmax(1).tolist()
+        tgts += target.tolist()
+    model.train()
+    acc = float(np.mean(np.array(preds) == np.array(tgts)))
+    mcc = matthews_corrcoef(tgts, preds, num_classes)
+    if verbose:
+        print("Test set: Epoch: {:d} Average loss: {:.4f}, Accuracy: {:.1f}%\tMCC: {:.3f}".format(
+            epoch, float(np.mean(losses)), 100 * acc, mcc))
+    return float(np.mean(losses)), mcc
+
+
+def save_model(model, optim, path, args, epoch, val_mean_std):
+    """torchlib/utils.py:1470-1493 — same checkpoint keys, so reference tooling reads it."""
+    import os
+
+    import torch
+
+    os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+    opt_state_dict = {name: dict(o) for name, o in optim.items()} if args.train_federated else dict(optim)
+    torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optim_state_dict": opt_state_dict,
+                "args": args, "val_mean_std": val_mean_std}, path)
