@@ -137,6 +137,24 @@ class LocalOpener:
         return out
 
 
+class DistOpener:
+    """One party per rank (party j = rank j of a 2-rank group, e.g. two GPUs over xGMI): every rank
+    passes ITS share in slot `rank` and a dummy in the other; open = all_reduce(SUM) of the local
+    share — the 2-party exchange the reference routes through the orchestrator
+    (mpc/spdz.py:162-176, mpc/fss.py:158-170)."""
+
+    def __init__(self, group=None):
+        import torch.distributed as dist
+
+        self.dist, self.group = dist, group
+        self.rank = dist.get_rank(group)
+
+    def open(self, s0, s1):
+        mine = (s0, s1)[self.rank].clone()
+        self.dist.all_reduce(mine, op=self.dist.ReduceOp.SUM, group=self.group)  # int64 sum wraps mod 2^64
+        return mine
+
+
 class SecureContext:
     def __init__(self, dealer, base=10, precision_fractional=16, opener=None):
         self.dealer = dealer
