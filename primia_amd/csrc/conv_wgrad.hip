@@ -12,6 +12,8 @@
 //   f32 : v_mfma_f32_16x16x4_f32 takes one element per lane, read directly with ds_read_b32.
 // The pixel range is split over blocks (split-K); partial results are accumulated with fp32
 // atomics into a zeroed [K][klen] buffer (fwd weight layout, see conv_common.h).
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 namespace primia {
@@ -264,6 +266,9 @@ static int launch_wgrad(WgradParams p, hipStream_t st) {
 
 }  // namespace primia
 
+namespace primia {
+int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st);
+}
 using namespace primia;
 
 extern "C" int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy,
@@ -284,9 +289,213 @@ extern "C" int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, con
         if (g.K % 128 == 0 && g.C % 128 == 0) return launch_wgrad<float, 128, 128, false>(p, st);
         return launch_wgrad<float, 64, 64, false>(p, st);
     } else if (dtype == PRIMIA_BF16) {
+        // Measured per layer (profiles/r01_conv_layers_*): the LDS-DMA kernel wins on the wide, few-pixel
+        // layers (layer3/4); the register-staged kernel on layer1/2.  PRIMIA_WGRAD=old|dma forces one.
+        static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+        const bool dma = force == 'd' || (force != 'o' && (g.C >= 256 || (g.K >= 256 && g.C >= 128)));
+        if (!g.stem && dma) return wgrad_dma_dispatch(p, st);
         if (g.stem) return launch_wgrad<bf16, 64, 32, true>(p, st);
         if (g.K % 128 == 0 && g.C % 128 == 0) return launch_wgrad<bf16, 128, 128, false>(p, st);
         return launch_wgrad<bf16, 64, 64, false>(p, st);
     }
     return PRIMIA_ERR_ARG;
 }
+
+// =================================================================================================
+// LDS-DMA weight gradient (bf16, every non-stem conv).  Same GEMM as above, but
+//   * both tiles are staged with global_load_lds_dwordx4 into linear rows whose 32-byte pair-chunks
+//     are XOR-permuted on the SOURCE side, so the ds_read_b64_tr_b16 transposing reads (4 pixel
+//     rows x 32 B per 16-lane group, two groups per LDS cycle) fall on distinct banks;
+//   * 8 waves (2 x 4) per block for latency hiding; per-step address math is one reciprocal
+//     division per staged row instead of carried (n, ho, wo) counters.
+// (A variant that shares one activation tile between the three taps of a kernel row was measured
+//  slower — profiles/r01_wgrad_rowtap_negative_result.txt — and is not kept.)
+// =================================================================================================
+namespace primia {
+
+__device__ __attribute__((aligned(16))) const unsigned char kWgZeroPage[16] = {0};
+
+template <int ROWB>
+__device__ __forceinline__ int wg_swz(int row) {
+    // pair-chunk (32 B) permutation key: 8 slots per 256-B row, 4 per 128-B row
+    return ROWB == 256 ? ((row & 3) | (((row >> 3) & 1) << 2)) : (((row >> 1) & 1) | (((row >> 3) & 1) << 1));
+}
+
+// q = m / d, rem = m % d for 0 <= m < 2^24 (all ResNet-18 pixel counts at batch <= 1024)
+__device__ __forceinline__ int fast_div(int m, int d, float rcp, int& rem) {
+    int q = (int)((float)m * rcp);
+    rem = m - q * d;
+    if (rem >= d) {
+        ++q;
+        rem -= d;
+    } else if (rem < 0) {
+        --q;
+        rem += d;
+    }
+    return q;
+}
+
+template <int BMK, int BNC>
+__global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradParams p) {
+    constexpr int KP = 64;  // pixels per k-step
+    constexpr int ROW_A = BMK * 2, ROW_B = BNC * 2;
+    constexpr int RPI_A = 1024 / ROW_A, RPI_B = 1024 / ROW_B;  // rows per DMA instruction
+    constexpr int NA = KP / RPI_A, NX = KP / RPI_B;
+    constexpr int STAGE = KP * (ROW_A + ROW_B);
+    constexpr int FM = BMK / 2 / 16, FN = BNC / 4 / 16;  // waves: 2 (k) x 4 (c)
+    static_assert(FM >= 1 && FN >= 1, "tile too small");
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int wm = wid >> 2, wn = wid & 3;
+
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = bid % p.nct; bid /= p.nct;
+    const int kt = bid % p.nkt; bid /= p.nkt;
+    const int tap = bid % p.ntaps;
+    const int split = bid / p.ntaps;
+    const int tr = tap / p.S, ts = tap - tr * p.S;
+    const int ms = (int)((long)split * p.pix_per_split);
+    int me = ms + (int)p.pix_per_split;
+    if (me > (int)p.Md) me = (int)p.Md;
+    const int nsteps = (me - ms + KP - 1) / KP;
+    const float rcp_wo = 1.0f / (float)p.Wo, rcp_ho = 1.0f / (float)p.Ho;
+
+    const bf16* __restrict__ x = (const bf16*)p.x;
+    const bf16* __restrict__ dy = (const bf16*)p.dy;
+
+    auto stage = [&](int step, int buf) {
+        char* base = smem + buf * STAGE;
+        const int p0 = ms + step * KP;
+        for (int idx = wid; idx < NA + NX; idx += 8) {
+            if (idx < NA) {
+                const int row = idx * RPI_A + lane / (ROW_A / 16);
+                const int sl = lane % (ROW_A / 16);
+                const int chunk = ((((sl >> 1) ^ wg_swz<ROW_A>(row)) << 1) | (sl & 1));
+                const int m = p0 + row;
+                const bf16* g = m < me ? dy + (long)m * p.K + kt * BMK + chunk * 8 : (const bf16*)kWgZeroPage;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(base + idx * 1024), 16, 0, 0);
+            } else {
+                const int j = idx - NA;
+                const int row = j * RPI_B + lane / (ROW_B / 16);
+                const int sl = lane % (ROW_B / 16);
+                const int chunk = ((((sl >> 1) ^ wg_swz<ROW_B>(row)) << 1) | (sl & 1));
+                const int m = p0 + row;
+                int wo, ho;
+                const int t = fast_div(m, p.Wo, rcp_wo, wo);
+                const int n = fast_div(t, p.Ho, rcp_ho, ho);
+                const int hs = ho * p.stride - p.pad + tr, ws = wo * p.stride - p.pad + ts;
+                const bool ok = m < me && hs >= 0 && hs < p.H && ws >= 0 && ws < p.W;
+                const bf16* g = ok ? x + ((long)(n * p.H + hs) * p.W + ws) * p.C + ct * BNC + chunk * 8
+                                   : (const bf16*)kWgZeroPage;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(base + KP * ROW_A + j * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tp = fr >> 2, tc8 = (fr & 3) * 8;  // transpose-read: row offset / byte offset inside the 32-B block
+    const int ka0 = wm * (BMK / 2), cb0 = wn * (BNC / 4);
+
+    auto compute = [&](int buf) {
+        const char* la = smem + buf * STAGE;
+        const char* lb = la + KP * ROW_A;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t a[FM], b[FN];
+            const int r0 = kk * 32 + fg * 8 + tp, r1 = r0 + 4;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int pc = (ka0 + 16 * i) >> 4;
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds4_t)(la + r0 * ROW_A + ((pc ^ wg_swz<ROW_A>(r0)) << 5) + tc8));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds4_t)(la + r1 * ROW_A + ((pc ^ wg_swz<ROW_A>(r1)) << 5) + tc8));
+                a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int pc = (cb0 + 16 * j) >> 4;
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds4_t)(lb + r0 * ROW_B + ((pc ^ wg_swz<ROW_B>(r0)) << 5) + tc8));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds4_t)(lb + r1 * ROW_B + ((pc ^ wg_swz<ROW_B>(r1)) << 5) + tc8));
+                b[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nsteps > 0) {
+        stage(0, 0);
+        __syncthreads();
+        for (int step = 0; step < nsteps; ++step) {
+            const int cur = step & 1;
+            if (step + 1 < nsteps) stage(step + 1, cur ^ 1);
+            compute(cur);
+            __syncthreads();
+        }
+    }
+
+    const int ebase = tap * p.C + ct * BNC;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int k = kt * BMK + ka0 + 16 * i + fg * 4 + t;
+                const int e = ebase + cb0 + 16 * j + fr;
+                unsafeAtomicAdd(p.dw + (long)k * p.klen + e, acc[i][j][t]);
+            }
+}
+
+template <int BMK, int BNC>
+static int launch_wgrad_dma(WgradParams p, hipStream_t st) {
+    constexpr int KP = 64;
+    if (p.Md >= (1L << 24)) return PRIMIA_ERR_ARG;  // fast_div range
+    p.nkt = p.K / BMK;
+    p.nct = p.C / BNC;
+    const int combos = p.ntaps * p.nkt * p.nct;
+    static const int target_blocks = getenv("PRIMIA_WG_BLOCKS") ? atoi(getenv("PRIMIA_WG_BLOCKS")) : 1024;
+    long want = (target_blocks + combos - 1) / combos;
+    long max_split = (p.Md + 8 * KP - 1) / (8 * KP);
+    if (want > max_split) want = max_split;
+    if (want < 1) want = 1;
+    long pps = (p.Md + want - 1) / want;
+    pps = (pps + KP - 1) / KP * KP;
+    p.pix_per_split = pps;
+    p.nsplit = (int)((p.Md + pps - 1) / pps);
+    const int grid = combos * p.nsplit;
+    const size_t lds = 2 * (size_t)KP * (BMK + BNC) * 2;
+    auto kern = conv_wgrad_dma_kernel<BMK, BNC>;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    kern<<<grid, 512, lds, st>>>(p);
+    return launch_status();
+}
+
+int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st) {
+    if (p.K % 128 == 0 && p.C % 128 == 0) return launch_wgrad_dma<128, 128>(p, st);
+    return launch_wgrad_dma<64, 64>(p, st);
+}
+
+}  // namespace primia
