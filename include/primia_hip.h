@@ -72,6 +72,15 @@ int64_t primia_conv_wdgrad_elems(const primia_conv_desc* d);
 int primia_conv_weight_prepare(const primia_conv_desc* d, int c_real, const float* w_oihw,
                                void* w_fwd, void* w_dgrad, int dtype, primia_stream_t stream);
 
+/* Batched forms of the two calls around them (one launch for all convolutions of a network, <= 24):
+ * arrays of n descriptors / channel counts / pointers live on the HOST. */
+int primia_conv_weight_prepare_many(const primia_conv_desc* descs_host, const int* c_real_host,
+                                    const float* const* w_oihw_host, void* const* w_fwd_host,
+                                    void* const* w_dgrad_host, int n, int dtype, primia_stream_t stream);
+int primia_conv_wgrad_finalize_many(const primia_conv_desc* descs_host, const int* c_real_host,
+                                    const float* const* dw_acc_host, float* const* dw_oihw_host, int n,
+                                    primia_stream_t stream);
+
 /* y[N,Ho,Wo,K] = conv(x[N,H,W,C], w). */
 int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
                       int dtype, primia_stream_t stream);

@@ -96,6 +96,71 @@ __global__ __launch_bounds__(256) void wgrad_finalize_kernel(const float* __rest
     dw_oihw[i] = dw_acc[(long)k * g.klen + g.encode_k(r, s, c)];
 }
 
+// ---- batched weight refresh / gradient finalize: one launch for the whole network ------------------
+constexpr int kMaxConvs = 24;
+struct ManyEntry {
+    ConvGeom g;
+    int c_real;
+    const float* src;  // w_oihw | dw_acc
+    void* dst;         // w_fwd  | dw_oihw
+    void* dst2;        // w_dgrad or null
+    long begin;        // first flat work index of this entry
+};
+struct ManyArgs {
+    ManyEntry e[kMaxConvs];
+    int n;
+    long total;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prepare_many_kernel(ManyArgs a) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += stride) {
+        int c = 0;
+        while (c + 1 < a.n && i >= a.e[c + 1].begin) ++c;
+        const ManyEntry& en = a.e[c];
+        const long j = i - en.begin;
+        const long nfwd = (long)en.g.K * en.g.klen;
+        if (j < nfwd) {
+            const int k = (int)(j / en.g.klen), e = (int)(j - (long)k * en.g.klen);
+            int r, s, ch;
+            en.g.decode_k(e, r, s, ch);
+            float v = 0.f;
+            if (r < en.g.R && s < en.g.S && ch < en.c_real)
+                v = en.src[(((long)k * en.c_real + ch) * en.g.R + r) * en.g.S + s];
+            Elem<T>::store((T*)en.dst + j, v);
+        } else {
+            // dgrad layout [C][R][S][K]
+            const long q = j - nfwd;
+            const int K = en.g.K, C = en.g.C, R = en.g.R, S = en.g.S;
+            const int k = (int)(q % K);
+            long t = q / K;
+            const int s = (int)(t % S);
+            t /= S;
+            const int r = (int)(t % R);
+            const int ch = (int)(t / R);
+            Elem<T>::store((T*)en.dst2 + q, en.src[(((long)k * C + ch) * R + r) * S + s]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_finalize_many_kernel(ManyArgs a) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += stride) {
+        int c = 0;
+        while (c + 1 < a.n && i >= a.e[c + 1].begin) ++c;
+        const ManyEntry& en = a.e[c];
+        const long j = i - en.begin;
+        const int s = (int)(j % en.g.S);
+        long t = j / en.g.S;
+        const int r = (int)(t % en.g.R);
+        t /= en.g.R;
+        const int ch = (int)(t % en.c_real);
+        const int k = (int)(t / en.c_real);
+        ((float*)en.dst)[j] = en.src[(long)k * en.g.klen + en.g.encode_k(r, s, ch)];
+    }
+}
+
 }  // namespace primia
 
 using namespace primia;
@@ -205,6 +270,56 @@ int primia_conv_wgrad_finalize(const primia_conv_desc* d, int c_real, const floa
     PRIMIA_REQUIRE(g.init(*d));
     long total = (long)d->K * c_real * d->R * d->S;
     wgrad_finalize_kernel<<<ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(dw_acc, dw_oihw, g, c_real, total);
+    return launch_status();
+}
+
+int primia_conv_weight_prepare_many(const primia_conv_desc* descs, const int* c_real, const float* const* w_oihw,
+                                    void* const* w_fwd, void* const* w_dgrad, int n, int dtype,
+                                    primia_stream_t stream) {
+    PRIMIA_REQUIRE(descs && c_real && w_oihw && w_fwd && w_dgrad && n > 0 && n <= kMaxConvs);
+    ManyArgs a;
+    a.n = n;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        PRIMIA_REQUIRE(a.e[i].g.init(descs[i]) && w_oihw[i] && w_fwd[i] && c_real[i] > 0 && c_real[i] <= descs[i].C);
+        PRIMIA_REQUIRE(!w_dgrad[i] || (!a.e[i].g.stem && c_real[i] == descs[i].C));
+        a.e[i].c_real = c_real[i];
+        a.e[i].src = w_oihw[i];
+        a.e[i].dst = w_fwd[i];
+        a.e[i].dst2 = w_dgrad[i];
+        a.e[i].begin = total;
+        total += (long)descs[i].K * a.e[i].g.klen;
+        if (w_dgrad[i]) total += (long)descs[i].C * descs[i].R * descs[i].S * descs[i].K;
+    }
+    a.total = total;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    if (dtype == PRIMIA_F32)
+        weight_prepare_many_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
+    else if (dtype == PRIMIA_BF16)
+        weight_prepare_many_kernel<bf16><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
+    else
+        return PRIMIA_ERR_ARG;
+    return launch_status();
+}
+
+int primia_conv_wgrad_finalize_many(const primia_conv_desc* descs, const int* c_real, const float* const* dw_acc,
+                                    float* const* dw_oihw, int n, primia_stream_t stream) {
+    PRIMIA_REQUIRE(descs && c_real && dw_acc && dw_oihw && n > 0 && n <= kMaxConvs);
+    ManyArgs a;
+    a.n = n;
+    long total = 0;
+    for (int i = 0; i < n; ++i) {
+        PRIMIA_REQUIRE(a.e[i].g.init(descs[i]) && dw_acc[i] && dw_oihw[i] && c_real[i] > 0 && c_real[i] <= descs[i].C);
+        a.e[i].c_real = c_real[i];
+        a.e[i].src = dw_acc[i];
+        a.e[i].dst = dw_oihw[i];
+        a.e[i].dst2 = nullptr;
+        a.e[i].begin = total;
+        total += (long)descs[i].K * c_real[i] * descs[i].R * descs[i].S;
+    }
+    a.total = total;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    wgrad_finalize_many_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a);
     return launch_status();
 }
 

@@ -175,22 +175,25 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* __restr
     for (int j = 0; j < out_f; ++j) s += dy[n * out_f + j] * w[(long)j * in_f + f];
     dx[i] = s;
 }
-// dw[j][i] = sum_n dy[n][j] x[n][i]; db[j] = sum_n dy[n][j]  (thread per (j, i); i == in_f -> bias)
-__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* __restrict__ x,
-                                                            const float* __restrict__ dy,
-                                                            float* __restrict__ dw, float* __restrict__ db,
-                                                            int N, int in_f, int out_f) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long)out_f * (in_f + 1)) return;
-    const int j = (int)(t / (in_f + 1));
-    const int i = (int)(t % (in_f + 1));
+// dw[j][i] = sum_n dy[n][j] x[n][i]; db[j] = sum_n dy[n][j].  Block = (output j, 64 inputs); 16 groups of
+// 64 lanes each take every 16th sample and are combined through LDS; column in_f carries the bias.
+__global__ __launch_bounds__(1024) void linear_bwd_dw_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ dy,
+                                                             float* __restrict__ dw, float* __restrict__ db,
+                                                             int N, int in_f, int out_f) {
+    __shared__ float red[16][64];
+    const int j = blockIdx.y, i = blockIdx.x * 64 + (threadIdx.x & 63), ng = threadIdx.x >> 6;
     float s = 0.f;
-    if (i < in_f) {
-        for (int n = 0; n < N; ++n) s += dy[(long)n * out_f + j] * x[(long)n * in_f + i];
-        dw[(long)j * in_f + i] = s;
-    } else if (db) {
-        for (int n = 0; n < N; ++n) s += dy[(long)n * out_f + j];
-        db[j] = s;
+    if (i <= in_f)
+        for (int n = ng; n < N; n += 16) s += dy[(long)n * out_f + j] * (i < in_f ? x[(long)n * in_f + i] : 1.f);
+    red[ng][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ng == 0 && i <= in_f) {
+        for (int g = 1; g < 16; ++g) s += red[g][threadIdx.x & 63];
+        if (i < in_f)
+            dw[(long)j * in_f + i] = s;
+        else if (db)
+            db[j] = s;
     }
 }
 
@@ -358,7 +361,7 @@ int primia_linear_bwd(const float* x, const float* w, const float* dy, float* dx
     PRIMIA_REQUIRE(x && w && dy && dw && N > 0 && in_f > 0 && out_f > 0);
     hipStream_t st = (hipStream_t)stream;
     if (dx) linear_bwd_dx_kernel<<<ceil_div((long)N * in_f, 256), 256, 0, st>>>(w, dy, dx, N, in_f, out_f);
-    linear_bwd_dw_kernel<<<ceil_div((long)out_f * (in_f + 1), 256), 256, 0, st>>>(x, dy, dw, db, N, in_f, out_f);
+    linear_bwd_dw_kernel<<<dim3((in_f + 1 + 63) / 64, out_f), 1024, 0, st>>>(x, dy, dw, db, N, in_f, out_f);
     return launch_status();
 }
 

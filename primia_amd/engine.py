@@ -195,11 +195,27 @@ class ResNet18Engine:
             self.views[k].copy_(v.to(torch.float32))
         self.refresh_weights()
 
+    def _many_args(self):
+        """Host-side argument arrays of the batched weight-refresh / wgrad-finalize calls (built once)."""
+        if getattr(self, "_many", None) is None:
+            import ctypes
+
+            cs = list(self.convs.values())
+            n = len(cs)
+            vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+            self._many = dict(
+                n=n, descs=(ConvDesc * n)(*[c.desc for c in cs]), creal=(ctypes.c_int * n)(*[c.c_real for c in cs]),
+                w=(ctypes.c_void_p * n)(*[vp(self.views[c.spec.name + ".weight"]) for c in cs]),
+                wf=(ctypes.c_void_p * n)(*[vp(c.w_fwd) for c in cs]),
+                wd=(ctypes.c_void_p * n)(*[vp(c.w_dgrad) for c in cs]),
+                acc=(ctypes.c_void_p * n)(*[vp(c.acc) for c in cs]),
+                gw=(ctypes.c_void_p * n)(*[vp(self.gviews[c.spec.name + ".weight"]) for c in cs]))
+        return self._many
+
     def refresh_weights(self):
         """fp32 master (OIHW) -> compute-dtype implicit-GEMM copies; call after any change of `flat`."""
-        for c in self.convs.values():
-            call("primia_conv_weight_prepare", c.desc, c.c_real, self.views[c.spec.name + ".weight"], c.w_fwd,
-                 c.w_dgrad, self.dt)
+        m = self._many_args()
+        call("primia_conv_weight_prepare_many", m["descs"], m["creal"], m["w"], m["wf"], m["wd"], m["n"], self.dt)
 
     def train(self, mode=True):
         self.training = mode
@@ -346,8 +362,8 @@ class ResNet18Engine:
             call("primia_avgpool3x3s2_bwd", t["pool.dout"], t["stem.dz"], N, hw, hw, 64, self.dt)
         self._bn_bwd("conv1", t["stem.y"], t["stem.z"], t["stem.dz"], t["stem.dy"], None, True)
         self._wgrad("conv1", self.x0, t["stem.dy"])
-        for c in self.convs.values():
-            call("primia_conv_wgrad_finalize", c.desc, c.c_real, c.acc, self.gviews[c.spec.name + ".weight"])
+        m = self._many_args()
+        call("primia_conv_wgrad_finalize_many", m["descs"], m["creal"], m["acc"], m["gw"], m["n"])
 
     # ------------------------------------------------------------------------------------------
     # optimizer
