@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--sync-every", type=int, default=3)
     ap.add_argument("--secure-aggregation", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secure", action="store_true", help="skip the encrypted-inference leg (second BASELINE metric)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-baseline-batch", type=int, default=32)
     return ap.parse_args()
@@ -197,6 +198,21 @@ def main():
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_batch, a.size)
+    if rank == 0 and world == 1 and not a.no_secure:
+        # second BASELINE.json metric: encrypted-inference ms/image (3 roles on this GPU), as a child
+        # process so that its allocations never share the training engine's pool
+        import subprocess
+
+        cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_secure.py"), "--images", "2"]
+        if not a.no_cpu_baseline:
+            cmd.append("--cpu-sample")
+        del eng, xs, ys
+        torch.cuda.empty_cache()
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        try:
+            out["encrypted_inference"] = json.loads(r.stdout.strip().splitlines()[-1])
+        except Exception:  # noqa: BLE001 - the primary metric must still be reported
+            out["encrypted_inference"] = {"error": (r.stderr or r.stdout)[-300:]}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -558,11 +558,12 @@ class OracleContext:
             x = self.trunc(self.fpt_mul(y, x), C)
         return x
 
-    def batch_norm_eval(self, x, mean, var, weight, bias):
-        """nn/functional.py:44-75, eval branch."""
+    def batch_norm_eval(self, x, mean, var, weight, bias, inv=None):
+        """nn/functional.py:44-75, eval branch.  `inv` = shares of newton(var) if computed earlier."""
         shp = x[0].shape
         rows = [np.ascontiguousarray(np.transpose(x[j], (1, 0, 2, 3)).reshape(shp[1], -1).T) for j in range(2)]
-        inv = self.reciprocal_newton(var)
+        if inv is None:
+            inv = self.reciprocal_newton(var)
         normalized = self.fpt_mul(inv, self.sub(rows, mean))
         result = self.add(self.fpt_mul(normalized, weight), bias)
         return [np.ascontiguousarray(np.transpose(result[j].T.reshape(shp[1], shp[0], shp[2], shp[3]), (1, 0, 2, 3)))
@@ -608,10 +609,24 @@ def secure_resnet_forward(ctx, state_dict, image, blocks=None):
     if blocks is None:
         blocks = [(f"layer{li}.{bi}", (2 if (li > 1 and bi == 0) else 1)) for li in range(1, 5) for bi in range(2)]
     x = ctx.share(fix_encode(image, ctx.base, ctx.pf))
+    # newton(running_var) is image independent and element-wise: all BatchNorm layers are run as ONE
+    # vector (same per-channel arithmetic as the reference's layer-by-layer calls,
+    # nn/functional.py:62-69; only the grouping of the dealer's primitives differs).
+    names = ["bn1"]
+    for prefix, _ in blocks:
+        names += [prefix + ".bn1", prefix + ".bn2"]
+        if (prefix + ".downsample.0.weight") in p:
+            names.append(prefix + ".downsample.1")
+    inv_all = ctx.reciprocal_newton([np.concatenate([p[n + ".running_var"][j] for n in names]) for j in range(2)])
+    inv, off = {}, 0
+    for n in names:
+        k = p[n + ".running_var"][0].size
+        inv[n] = [inv_all[j][off:off + k] for j in range(2)]
+        off += k
 
     def bn(t, prefix):
         return ctx.batch_norm_eval(t, p[prefix + ".running_mean"], p[prefix + ".running_var"], p[prefix + ".weight"],
-                                   p[prefix + ".bias"])
+                                   p[prefix + ".bias"], inv=inv[prefix])
 
     x = ctx.conv2d(x, p["conv1.weight"], 2, 3)
     x = bn(x, "bn1")

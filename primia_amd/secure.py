@@ -353,16 +353,21 @@ class SecureContext:
             x = self.trunc(self.fpt_mul(y, x), C)
         return x
 
-    def batch_norm_eval(self, x, mean, var, weight, bias):
-        """batch_norm in eval mode (nn/functional.py:44-75): ((x - mean) * newton(1/var)) * w + b on
-        [H*W, C] rows — no sqrt and no eps, exactly as the reference computes it."""
+    def batch_norm_eval(self, x, mean, var, weight, bias, inv=None):
+        """batch_norm in eval mode (nn/functional.py:44-75): ((x - mean) * newton(var)) * w + b on
+        [H*W, C] rows — no explicit sqrt and no eps, exactly as the reference computes it (its
+        "newton" iteration converges to var^-1/2).  `inv` may carry shares of newton(var) computed
+        earlier (see SecureResNet18.precompute_inv)."""
         B, C, H, W = x[0].shape
+        if B != 1:
+            raise ValueError("encrypted inference runs one image at a time (inference.py:292)")
         rows = []
         for j in range(2):  # permute(1,0,2,3).reshape(C,-1).t()  -> [B*H*W, C]  (B == 1)
             o = torch.empty(B * H * W, C, dtype=I64, device=x[j].device)
             call("primia_col2out_syft", x[j], None, o, 1, C, B * H * W)
             rows.append(o)
-        inv = self.reciprocal_newton(var)
+        if inv is None:
+            inv = self.reciprocal_newton(var)
         normalized = self.fpt_mul(inv, self.sub(rows, mean))
         result = self.add(self.fpt_mul(normalized, weight), bias)
         out = []
@@ -436,13 +441,41 @@ class SecureResNet18:
         self.blocks = blocks if blocks is not None else [
             (f"layer{li}.{bi}", (2 if (li > 1 and bi == 0) else 1)) for li in range(1, 5) for bi in range(2)]
 
+    def bn_prefixes(self):
+        out = ["bn1"]
+        for prefix, _ in self.blocks:
+            out += [prefix + ".bn1", prefix + ".bn2"]
+            if (prefix + ".downsample.0.weight") in self.p:
+                out.append(prefix + ".downsample.1")
+        return out
+
+    def precompute_inv(self):
+        """newton(running_var) of every BatchNorm layer in ONE batched 80-step iteration.
+
+        The reference recomputes it layer by layer inside each forward (nn/functional.py:62-69);
+        it does not depend on the image, and the iteration is element-wise, so running all layers'
+        channels as one vector performs exactly the same arithmetic per channel — it only turns
+        20 x 80 x 3 tiny Beaver rounds into 80 x 3 (the per-element randomness is whatever slice of
+        the batched triple that channel receives)."""
+        c = self.ctx
+        names = self.bn_prefixes()
+        var = [torch.cat([self.p[n + ".running_var"][j] for n in names]) for j in range(2)]
+        inv = c.reciprocal_newton(var)
+        out, off = {}, 0
+        for n in names:
+            k = self.p[n + ".running_var"][0].numel()
+            out[n] = [inv[j][off:off + k].contiguous() for j in range(2)]
+            off += k
+        return out
+
     def _bn(self, x, prefix):
         p = self.p
         return self.ctx.batch_norm_eval(x, p[prefix + ".running_mean"], p[prefix + ".running_var"],
-                                        p[prefix + ".weight"], p[prefix + ".bias"])
+                                        p[prefix + ".weight"], p[prefix + ".bias"], inv=self._inv[prefix])
 
     def forward_shares(self, x):
         c, p = self.ctx, self.p
+        self._inv = self.precompute_inv()
         x = c.conv2d(x, p["conv1.weight"], 2, 3)
         x = self._bn(x, "bn1")
         x = c.max_pool2d_3x3s2(x)      # swapped stem (inference.py:289)
