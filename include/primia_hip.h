@@ -84,6 +84,12 @@ int primia_conv_wgrad_finalize_many(const primia_conv_desc* descs_host, const in
 /* y[N,Ho,Wo,K] = conv(x[N,H,W,C], w). */
 int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
                       int dtype, primia_stream_t stream);
+/* Same, and the per-channel sum / sum of squares of y (values as stored) — the batch statistics of the
+ * BatchNorm that follows — are accumulated into stat_sums, laid out [slots][2][K] with
+ * slots = primia_conv_stat_slots() partial sums (spread to keep atomics uncontended); caller zeroes it. */
+int primia_conv_stat_slots(void);
+int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
+                            float* stat_sums, int dtype, primia_stream_t stream);
 /* dx[N,H,W,C] = conv_transpose(dy[N,Ho,Wo,K], w).  If accumulate != 0, dx += (dx is read). */
 int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                         int accumulate, int dtype, primia_stream_t stream);
@@ -108,6 +114,13 @@ int primia_bn_fwd_train(const void* y, const void* residual, void* z, const floa
                         float* save_mean, float* save_invstd, int64_t M, int C, float eps,
                         float momentum, int relu, void* workspace, int64_t workspace_bytes,
                         int dtype, primia_stream_t stream);
+/* As primia_bn_fwd_train, with the batch sums already known (primia_conv2d_fwd_stats):
+ * sums = [slots][2][C] partial sums, combined in fp64. */
+int primia_bn_fwd_train_from_sums(const void* y, const void* residual, void* z, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var,
+                                  float* save_mean, float* save_invstd, const float* sums, int slots,
+                                  int64_t M, int C, float eps, float momentum, int relu, int dtype,
+                                  primia_stream_t stream);
 /* Eval forward with running statistics. */
 int primia_bn_fwd_eval(const void* y, const void* residual, void* z, const float* gamma,
                        const float* beta, const float* running_mean, const float* running_var,

@@ -306,6 +306,33 @@ int primia_bn_fwd_train(const void* y, const void* residual, void* z, const floa
     return PRIMIA_ERR_ARG;
 }
 
+int primia_bn_fwd_train_from_sums(const void* y, const void* residual, void* z, const float* gamma,
+                                  const float* beta, float* running_mean, float* running_var, float* save_mean,
+                                  float* save_invstd, const float* sums, int slots, int64_t M, int C, float eps,
+                                  float momentum, int relu, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && z && gamma && beta && save_mean && save_invstd && sums && slots >= 1);
+    PRIMIA_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype));
+    hipStream_t st = (hipStream_t)stream;
+    // `sums` has the layout of the partial blocks: [slots][2][C]
+    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(sums, slots, C, M, 0, eps, momentum, save_mean, save_invstd,
+                                                       running_mean, running_var);
+    if (dtype == PRIMIA_F32) {
+        const long nchunks = M * C / 4;
+        bn_apply_kernel<float><<<stream_blocks(nchunks), 256, 0, st>>>((const float*)y, (const float*)residual,
+                                                                       (float*)z, gamma, beta, save_mean, save_invstd,
+                                                                       eps, 0, nchunks, C, relu);
+    } else if (dtype == PRIMIA_BF16) {
+        const long nchunks = M * C / 8;
+        bn_apply_kernel<bf16><<<stream_blocks(nchunks), 256, 0, st>>>((const bf16*)y, (const bf16*)residual, (bf16*)z,
+                                                                      gamma, beta, save_mean, save_invstd, eps, 0,
+                                                                      nchunks, C, relu);
+    } else {
+        return PRIMIA_ERR_ARG;
+    }
+    return launch_status();
+}
+
 int primia_bn_fwd_eval(const void* y, const void* residual, void* z, const float* gamma,
                        const float* beta, const float* running_mean, const float* running_var,
                        int64_t M, int C, float eps, int relu, int dtype, primia_stream_t stream) {

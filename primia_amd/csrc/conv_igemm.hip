@@ -36,6 +36,7 @@ struct IgemmParams {
     long Md;         // dst pixels
     int accumulate;
     int ntile_n;
+    float* stat_sums;  // optional [2][Nd]: per-channel sum and sum of squares of the stored output
 };
 
 template <typename T>
@@ -48,6 +49,9 @@ template <>
 struct MmaTraits<float> {
     static constexpr int KE = 32;
 };
+
+// Fused BatchNorm statistics are spread over this many partial slots ([kStatSlots][2][C] floats).
+constexpr int kStatSlots = 64;
 
 // 16 zero bytes every padded / out-of-range DMA lane reads from.
 __device__ __attribute__((aligned(16))) const unsigned char kZeroPage[16] = {0};
@@ -328,7 +332,15 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     }
 
     // ---- epilogue: lane holds 4 consecutive channels of one pixel per fragment -------------------
+    // Optionally (stat_sums != null) the per-channel sum / sum of squares of the values AS STORED are
+    // accumulated for the BatchNorm that follows: 16-lane shuffle reduction over the pixels a wave owns,
+    // then one atomic per channel per wave — this replaces a full read pass over the conv output.
     T* __restrict__ dst = (T*)p.dst;
+    float s1[FM][4], s2[FM][4];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s1[i][t] = s2[i][t] = 0.f;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
         const long m = m0 + wm * (BM / WM) + 16 * j + fr;
@@ -353,11 +365,52 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
                     v[2] += __uint_as_float(o[1] << 16);
                     v[3] += __uint_as_float(o[1] & 0xffff0000u);
                 }
+                uint16_t h[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    h[t] = f32_to_bf16(v[t]);
+                    v[t] = bf16_to_f32(h[t]);
+                }
                 u32x2 o;
-                o[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                o[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                o[0] = (uint32_t)h[0] | ((uint32_t)h[1] << 16);
+                o[1] = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
                 *(u32x2*)q = o;
             }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s1[i][t] += v[t];
+                s2[i][t] += v[t] * v[t];
+            }
+        }
+    }
+    if (p.stat_sums) {
+        // block-level combine in LDS (the staging buffers are dead by now), then ONE global atomic per
+        // channel per block into partial slot (tile % kStatSlots): keeps same-address contention low.
+        float* red = (float*)smem;  // [2][BN]
+        __syncthreads();
+        for (int c = tid; c < 2 * BN; c += NT) red[c] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                float a = s1[i][t], b = s2[i][t];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    a += __shfl_xor(a, o, 64);
+                    b += __shfl_xor(b, o, 64);
+                }
+                if (fr == 0) {
+                    const int cl = wn * (BN / WN) + 16 * i + fg * 4 + t;
+                    atomicAdd(red + cl, a);
+                    atomicAdd(red + BN + cl, b);
+                }
+            }
+        __syncthreads();
+        float* slot = p.stat_sums + (long)(tile % kStatSlots) * 2 * p.Nd;
+        for (int c = tid; c < 2 * BN; c += NT) {
+            const int q = c / BN, cl = c - q * BN;
+            unsafeAtomicAdd(slot + q * p.Nd + n0 + cl, red[c]);
         }
     }
 }
@@ -420,8 +473,8 @@ using namespace primia;
 
 extern "C" {
 
-int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
-                      int dtype, primia_stream_t stream) {
+static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stat_sums,
+                           int dtype, primia_stream_t stream) {
     PRIMIA_REQUIRE(d && x && w_fwd && y);
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
@@ -433,6 +486,7 @@ int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fw
     p.klen = g.klen;
     p.Md = (long)g.N * g.Ho * g.Wo;
     p.accumulate = 0;
+    p.stat_sums = stat_sums;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         p.nsteps = g.stem ? 7 : g.klen / 32;
@@ -442,6 +496,19 @@ int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fw
         return dispatch_igemm<bf16, false>(p, g.stem, st);
     }
     return PRIMIA_ERR_ARG;
+}
+
+int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y, int dtype,
+                      primia_stream_t stream) {
+    return conv2d_fwd_impl(d, x, w_fwd, y, nullptr, dtype, stream);
+}
+
+int primia_conv_stat_slots(void) { return kStatSlots; }
+
+int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stat_sums,
+                            int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(stat_sums);
+    return conv2d_fwd_impl(d, x, w_fwd, y, stat_sums, dtype, stream);
 }
 
 int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
@@ -458,6 +525,7 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
     p.klen = g.R * g.S * g.K;
     p.Md = (long)g.N * g.H * g.W;
     p.accumulate = accumulate;
+    p.stat_sums = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         p.nsteps = p.klen / 32;

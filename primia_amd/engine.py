@@ -140,6 +140,17 @@ class ResNet18Engine:
                 t[key] = act(d1.Ho, blk.conv1.cout)
             din = t[key] if blk.down is None else act(d1.H, blk.conv1.cin)
             t[(blocks[i - 1].prefix + ".dout") if i > 0 else "pool.dout"] = din
+        # Fused BN statistics: the conv epilogue can accumulate the batch sums (primia_conv2d_fwd_stats).
+        # Measured on MI355X at batch 256 it is a wash — the epilogue reduction costs the forward kernels
+        # +0.38 ms/step, the separate statistics pass it removes costs 0.39 ms/step — so it stays off.
+        self.fuse_stats = False
+        self.stat_slots = query("primia_conv_stat_slots")
+        per = lambda c: self.stat_slots * 2 * c.cout
+        self.stat_sums = torch.zeros(sum(per(c) for c in self.spec.convs), dtype=torch.float32, device=dev)
+        off = 0
+        for c in self.spec.convs:
+            self.convs[c.name].sums = self.stat_sums[off:off + per(c)]
+            off += per(c)
         self.save = {}
         for c in self.spec.convs:
             b = bn_name(c.name)
@@ -235,8 +246,12 @@ class ResNet18Engine:
         rm, rv = self.views[b + ".running_mean"], self.views[b + ".running_var"]
         if self.training:
             sm, si = self.save[b]
-            call("primia_bn_fwd_train", y, residual, z, g, be, rm, rv, sm, si, M, C, BN_EPS, BN_MOMENTUM,
-                 int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
+            if self.fuse_stats:
+                call("primia_bn_fwd_train_from_sums", y, residual, z, g, be, rm, rv, sm, si,
+                     self.convs[conv_name].sums, self.stat_slots, M, C, BN_EPS, BN_MOMENTUM, int(relu), self.dt)
+            else:
+                call("primia_bn_fwd_train", y, residual, z, g, be, rm, rv, sm, si, M, C, BN_EPS, BN_MOMENTUM,
+                     int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
             self.num_batches_tracked[b] += 1
         else:
             call("primia_bn_fwd_eval", y, residual, z, g, be, rm, rv, M, C, BN_EPS, int(relu), self.dt)
@@ -258,7 +273,10 @@ class ResNet18Engine:
 
     def _conv_fwd(self, name, x, y):
         c = self.convs[name]
-        self._timed("fwd", c, lambda: call("primia_conv2d_fwd", c.desc, x, c.w_fwd, y, self.dt))
+        if self.training and self.fuse_stats:
+            self._timed("fwd", c, lambda: call("primia_conv2d_fwd_stats", c.desc, x, c.w_fwd, y, c.sums, self.dt))
+        else:
+            self._timed("fwd", c, lambda: call("primia_conv2d_fwd", c.desc, x, c.w_fwd, y, self.dt))
 
     def forward(self, x_nchw):
         """x_nchw: fp32 [N, in_channels, S, S] on this GPU.  Returns fp32 logits [N, classes]."""
@@ -266,6 +284,8 @@ class ResNet18Engine:
         if tuple(x_nchw.shape) != (N, self.spec.in_channels, S, S) or x_nchw.dtype != torch.float32:
             raise ValueError(f"expected fp32 input {(N, self.spec.in_channels, S, S)}, got {tuple(x_nchw.shape)}")
         x_nchw = x_nchw.contiguous()
+        if self.training and self.fuse_stats:
+            self.stat_sums.zero_()
         call("primia_nchw_to_nhwc", x_nchw, self.x0, N, self.spec.in_channels, S, S, 4, self.dt)
         self._conv_fwd("conv1", self.x0, t["stem.y"])
         self._bn("conv1", t["stem.y"], t["stem.z"], None, True)

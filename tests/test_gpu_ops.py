@@ -332,3 +332,39 @@ def test_optimizers_and_fx(cuda):
     yd = y.to(cuda)
     call("primia_scale", yd, n, 0.125)
     assert torch.equal(yd.cpu(), y * 0.125)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(2, 16, 64, 64, 3, 1, 1), (1, 10, 128, 128, 3, 1, 1), (4, 14, 256, 512, 3, 2, 1)])
+def test_conv_fwd_fused_bn_stats(cuda, dtype, case):
+    """conv forward that also accumulates the BatchNorm batch sums, then BN from those sums ==
+    conv followed by batch_norm(training) on the CPU."""
+    N, H, C, K, R, s, p = case
+    g = torch.Generator().manual_seed(77 + H)
+    x = rnd(torch.randn(N, C, H, H, generator=g), dtype)
+    w = rnd(torch.randn(K, C, R, R, generator=g) * 0.05, dtype)
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    desc = ConvDesc.make(N, H, H, C, K, R, R, s, p)
+    dt = _lib.dtype_code(dtype)
+    wf, _ = prep_weights(desc, w, dtype, cuda, C, need_dgrad=False)
+    M = N * desc.Ho * desc.Wo
+    y = torch.empty(M, K, dtype=dtype, device=cuda)
+    slots = query("primia_conv_stat_slots")
+    part = torch.zeros(slots, 2, K, device=cuda)
+    call("primia_conv2d_fwd_stats", desc, to_nhwc(x, dtype, cuda), wf, y, part, dt)
+    sums = part.double().sum(0).reshape(-1)
+    y_ref = F.conv2d(x, w, None, s, p)
+    y_st = from_nhwc(y, N, desc.Ho, desc.Wo)          # statistics are taken over the STORED values
+    assert relerr(y_st, y_ref) < tol(dtype)
+    s1 = y_st.double().sum(dim=(0, 2, 3))
+    s2 = (y_st.double() ** 2).sum(dim=(0, 2, 3))
+    assert relerr(sums[:K], s1) < 2e-5 and relerr(sums[K:], s2) < 2e-5
+    z = torch.empty_like(y)
+    rm, rv = torch.zeros(K, device=cuda), torch.ones(K, device=cuda)
+    sm, si = torch.empty(K, device=cuda), torch.empty(K, device=cuda)
+    call("primia_bn_fwd_train_from_sums", y, None, z, gamma.to(cuda), beta.to(cuda), rm, rv, sm, si, part, slots, M, K,
+         1e-5, 0.1, 1, dt)
+    rm_ref, rv_ref = torch.zeros(K), torch.ones(K)
+    z_ref = F.relu(F.batch_norm(y_st, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
+    assert relerr(from_nhwc(z, N, desc.Ho, desc.Wo), z_ref) < (5e-5 if dtype == torch.float32 else 1e-2)
+    assert relerr(rm, rm_ref) < 1e-4 and relerr(rv, rv_ref) < 1e-4
