@@ -36,7 +36,9 @@ struct IgemmParams {
     long Md;         // dst pixels
     int accumulate;
     int ntile_n;
-    float* stat_sums;  // optional [2][Nd]: per-channel sum and sum of squares of the stored output
+    float* stat_sums;  // optional [slots][2][Nd]: per-channel sum and sum of squares of the stored output
+    int s2_classes;    // data-gradient of a stride-2 conv: dst pixels are processed in 4 parity classes
+    int ntm_class;     // pixel tiles per class
 };
 
 template <typename T>
@@ -82,9 +84,36 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     const int wm = wid / WN, wn = wid % WN;  // wave position: pixels, channels
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
-    const long m0 = (long)tm * BM;
+    const int tn = tile % p.ntile_n;
+    int tm = tile / p.ntile_n;
     const int n0 = tn * BN;
+    // Stride-2 data-gradient: a dst pixel (h, w) only receives taps with r = (h + pad) mod 2, s = (w + pad)
+    // mod 2, so the pixels are split into 4 parity classes, each a dense problem over its own taps
+    // (1 + 2 + 2 + 4 = 9 tap-GEMMs on quarter-size pixel sets instead of 9 on the full set).
+    int cls_ph = 0, cls_pw = 0;
+    if (DGRAD && p.s2_classes) {
+        const int cls = tm / p.ntm_class;
+        tm -= cls * p.ntm_class;
+        cls_ph = cls >> 1;
+        cls_pw = cls & 1;
+    }
+    const long m0 = (long)tm * BM;
+    const int Hc = (DGRAD && p.s2_classes) ? p.Hd >> 1 : p.Hd, Wc = (DGRAD && p.s2_classes) ? p.Wd >> 1 : p.Wd;
+    const long Mc = (DGRAD && p.s2_classes) ? (long)p.Nb * Hc * Wc : p.Md;
+    // row index inside the (class) pixel set -> dst pixel (n, hd, wd)
+    auto dst_pixel = [&](long m, int& n, int& hd, int& wd) {
+        const int w2 = (int)(m % Wc);
+        const long t = m / Wc;
+        const int h2 = (int)(t % Hc);
+        n = (int)(t / Hc);
+        if (DGRAD && p.s2_classes) {
+            hd = 2 * h2 + ((cls_ph + p.pad) & 1);
+            wd = 2 * w2 + ((cls_pw + p.pad) & 1);
+        } else {
+            hd = h2;
+            wd = w2;
+        }
+    };
 
     const T* __restrict__ src = (const T*)p.src;
     const T* __restrict__ wt = (const T*)p.wt;
@@ -103,12 +132,10 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     for (int j = 0; j < PR; ++j) {
         const int row = GLDS ? ((wid * PR + j) * 8 + (lane >> 3)) : (srow + 32 * j);
         long m = m0 + row;
-        mval[j] = m < p.Md;
+        mval[j] = m < Mc;
         if (!mval[j]) m = 0;
-        int wd = (int)(m % p.Wd);
-        long t = m / p.Wd;
-        int hd = (int)(t % p.Hd);
-        int n = (int)(t / p.Hd);
+        int n, hd, wd;
+        dst_pixel(m, n, hd, wd);
         nb[j] = n * p.Hs * p.Ws;
         if (DGRAD) {
             hb[j] = hd + p.pad;
@@ -168,7 +195,11 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
         }
     }
     // wave-uniform walk over the reduction axis: (tap, c0) and the tap's source offset
-    int st_tap = 0, st_r = 0, st_s = 0, st_c0 = 0, st_tapoff = 0, st_step = 0;
+    const int tstep = (DGRAD && p.s2_classes) ? 2 : 1;  // class taps: r = ph, ph+2, ... ; s = pw, pw+2, ...
+    int st_r = cls_ph, st_s = cls_pw, st_c0 = 0;
+    int st_tap = st_r * p.S + st_s;
+    int st_tapoff = DGRAD ? -(((p.stride == 2 ? st_r >> 1 : st_r) * p.Ws + (p.stride == 2 ? st_s >> 1 : st_s)) * p.Cs)
+                          : (st_r * p.Ws + st_s) * p.Cs;
     auto stage_glds = [&](int step, int buf) {
         (void)step;  // stages are issued in order; the walk state below IS the step
         char* lp = smem + buf * (TILE_P + TILE_W);
@@ -182,22 +213,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
                                              (__attribute__((address_space(3))) void*)(lp + (wid * PR + j) * 1024),
                                              16, 0, 0);
         }
-        const int woff = st_step * KE;
+        const int woff = st_tap * p.Cs + st_c0;
 #pragma unroll
         for (int j = 0; j < WR; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow[j] + woff),
                                              (__attribute__((address_space(3))) void*)(lw + (wid * WR + j) * 1024),
                                              16, 0, 0);
         // advance
-        ++st_step;
         st_c0 += KE;
         if (st_c0 == p.Cs) {
             st_c0 = 0;
-            ++st_tap;
-            if (++st_s == p.S) {
-                st_s = 0;
-                ++st_r;
+            st_s += tstep;
+            if (st_s >= p.S) {
+                st_s = cls_pw;
+                st_r += tstep;
             }
+            st_tap = st_r * p.S + st_s;
             if (DGRAD)
                 st_tapoff = -(((p.stride == 2 ? st_r >> 1 : st_r) * p.Ws + (p.stride == 2 ? st_s >> 1 : st_s)) * p.Cs);
             else
@@ -293,17 +324,22 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     };
 
     // ---- main loop -----------------------------------------------------------------------------
+    int nsteps = p.nsteps;
+    if (DGRAD && p.s2_classes) {
+        const int nr = cls_ph < p.R ? (p.R - cls_ph + 1) / 2 : 0, ns = cls_pw < p.S ? (p.S - cls_pw + 1) / 2 : 0;
+        nsteps = nr * ns * (p.Cs / KE);
+    }
     if constexpr (GLDS) {
         // STAGES-deep LDS ring fed by LDS-DMA.  Per k-step ONE raw barrier: a counted vmcnt leaves the
         // newer stages' DMA in flight across it (a plain __syncthreads() would drain them).
         constexpr int NLOAD = PR + WR;  // DMA instructions per wave per stage
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s)
-            if (s < p.nsteps) stage_glds(s, s);
+            if (s < nsteps) stage_glds(s, s);
         int cur = 0, nxt = STAGES - 1;
-        for (int step = 0; step < p.nsteps; ++step) {
+        for (int step = 0; step < nsteps; ++step) {
             // stages step+1 .. step+STAGES-2 may still be in flight
-            int ahead = p.nsteps - 1 - step;
+            int ahead = nsteps - 1 - step;
             if (ahead > STAGES - 2) ahead = STAGES - 2;
             if (STAGES >= 4 && ahead >= 2)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NLOAD) : "memory");
@@ -312,7 +348,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();  // stage `step` visible to all; buffer `nxt` no longer read
-            if (step + STAGES - 1 < p.nsteps) stage_glds(step + STAGES - 1, nxt);
+            if (step + STAGES - 1 < nsteps) stage_glds(step + STAGES - 1, nxt);
             compute(cur);
             cur = cur + 1 == STAGES ? 0 : cur + 1;
             nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
@@ -343,8 +379,14 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
         for (int t = 0; t < 4; ++t) s1[i][t] = s2[i][t] = 0.f;
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-        const long m = m0 + wm * (BM / WM) + 16 * j + fr;
-        if (m >= p.Md) continue;
+        const long mc = m0 + wm * (BM / WM) + 16 * j + fr;
+        if (mc >= Mc) continue;
+        long m = mc;
+        if (DGRAD && p.s2_classes) {
+            int n, hd, wd;
+            dst_pixel(mc, n, hd, wd);
+            m = ((long)n * p.Hd + hd) * p.Wd + wd;
+        }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
             const int ch = n0 + wn * (BN / WN) + 16 * i + fg * 4;
@@ -417,9 +459,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
 
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool DGRAD, bool STEM>
 static int launch_igemm(const IgemmParams& p, hipStream_t st) {
-    const int ntm = ceil_div(p.Md, BM);
     IgemmParams q = p;
     q.ntile_n = p.Nd / BN;
+    int ntm = ceil_div(p.Md, BM);
+    if (DGRAD && p.s2_classes) {
+        q.ntm_class = ceil_div((long)p.Nb * (p.Hd / 2) * (p.Wd / 2), BM);
+        ntm = 4 * q.ntm_class;
+    }
     const int grid = ntm * q.ntile_n;
     const size_t lds = (size_t)STAGES * (BM + BN) * 128;
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, DGRAD, STEM>;
@@ -487,6 +533,8 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
     p.Md = (long)g.N * g.Ho * g.Wo;
     p.accumulate = 0;
     p.stat_sums = stat_sums;
+    p.s2_classes = 0;
+    p.ntm_class = 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         p.nsteps = g.stem ? 7 : g.klen / 32;
@@ -526,6 +574,9 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
     p.Md = (long)g.N * g.H * g.W;
     p.accumulate = accumulate;
     p.stat_sums = nullptr;
+    static const bool no_classes = getenv("PRIMIA_DGRAD_CLASSES") && getenv("PRIMIA_DGRAD_CLASSES")[0] == '0';
+    p.s2_classes = (g.stride == 2 && g.H % 2 == 0 && g.W % 2 == 0 && !no_classes) ? 1 : 0;
+    p.ntm_class = 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         p.nsteps = p.klen / 32;
