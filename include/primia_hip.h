@@ -96,6 +96,10 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
 /* dw_acc (fp32, fwd layout [K][R][Sp][C']) += sum over pixels.  Caller zeroes dw_acc first. */
 int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,
                         int dtype, primia_stream_t stream);
+/* Per-sample weight gradients for DP-SGD: dw_ps [N][K][klen] (fwd layout, fp32, zeroed by the caller),
+ * image n's gradient in slab n. */
+int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,
+                                  float* dw_ps, int dtype, primia_stream_t stream);
 /* dw_oihw[K][c_real][R][S] = transpose(dw_acc) (drops padding). */
 int primia_conv_wgrad_finalize(const primia_conv_desc* d, int c_real, const float* dw_acc,
                                float* dw_oihw, primia_stream_t stream);
@@ -132,6 +136,42 @@ int primia_bn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
                   const float* gamma, const float* save_mean, const float* save_invstd,
                   float* dgamma, float* dbeta, int64_t M, int C, int relu, void* workspace,
                   int64_t workspace_bytes, int dtype, primia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * GroupNorm (+ fused ReLU / residual) and the per-sample pieces of DP-SGD — BASELINE.json
+ * configs[3].  The reference attaches pytorch-dp's PrivacyEngine (alphas [1,10,100], noise_multiplier
+ * 1.3, max_grad_norm 1.0; train.py:325-334), which rejects BatchNorm (train.py:308); ResNet's
+ * `norm_layer` hook (torchlib/models.py:355,362-364) takes GroupNorm instead.  x is [N, HW, C],
+ * G groups of C/G consecutive channels, statistics per (sample, group), eps inside the sqrt.
+ * ------------------------------------------------------------------------------------------ */
+int64_t primia_gn_workspace_bytes(int N, int C, int G);
+int primia_gn_fwd(const void* y, const void* residual, void* z, const float* gamma, const float* beta,
+                  float* save_mean, float* save_invstd, int N, int HW, int C, int G, float eps, int relu,
+                  void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream);
+/* Backward: dy, optional masked gradient g_out, and PER-SAMPLE affine gradients ps_dgamma / ps_dbeta
+ * [N][C] (summed over samples they are the usual dgamma / dbeta). */
+int primia_gn_bwd(const void* y, const void* z, const void* dz, void* dy, void* g_out, const float* gamma,
+                  const float* save_mean, const float* save_invstd, float* ps_dgamma, float* ps_dbeta,
+                  int N, int HW, int C, int G, int relu, void* workspace, int64_t workspace_bytes,
+                  int dtype, primia_stream_t stream);
+/* sq_acc[n] += sum_j x[n][j]^2 (fp64): per-sample squared gradient norm, accumulated layer by layer. */
+int primia_persample_sqnorm(const float* x, int N, int64_t per_sample, double* sq_acc,
+                            primia_stream_t stream);
+/* clip[n] = min(1, max_grad_norm / (sqrt(sq[n]) + 1e-6)). */
+int primia_dp_clip_factors(const double* sq, float* clip, int N, float max_grad_norm,
+                           primia_stream_t stream);
+/* x[n][:] *= s[n] for N consecutive blocks of elems_per_sample elements (dtype tensor, in place). */
+int primia_scale_rows(void* x, const float* s, int N, int64_t elems_per_sample, int dtype,
+                      primia_stream_t stream);
+/* out[c] = sum_n w[n] * x[n][c]. */
+int primia_weighted_colsum(const float* x, const float* w, float* out, int N, int C,
+                           primia_stream_t stream);
+/* ps[n] = [dy[n]^T x[n] flattened (out_f*in_f) | dy[n] (out_f)]: per-sample gradients of nn.Linear. */
+int primia_fc_persample_grads(const float* x, const float* dy, float* ps, int N, int in_f, int out_f,
+                              primia_stream_t stream);
+/* g = (g + noise * sigma) * inv_batch — the Gaussian mechanism on the summed clipped gradient. */
+int primia_dp_add_noise(float* g, const float* noise, int64_t n, float sigma, float inv_batch,
+                        primia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pooling — replaces F.max_pool2d(3,2,1) / F.avg_pool2d(3,2,1) (torchlib/models.py:384-389)

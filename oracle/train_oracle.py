@@ -31,6 +31,10 @@ BLOCKS = [("layer1", 64, 1), ("layer2", 128, 2), ("layer3", 256, 2), ("layer4", 
 
 
 def _bn(x, sd, prefix, training, momentum=0.1, eps=1e-5):
+    if (prefix + ".running_mean") not in sd:
+        # norm_layer = GroupNorm(32, C) (torchlib/models.py:355,362-364): the BN-free network of the DP
+        # configuration (train.py:308 rejects BatchNorm under the PrivacyEngine)
+        return F.group_norm(x, 32, sd[prefix + ".weight"], sd[prefix + ".bias"], eps)
     # F.batch_norm updates running stats in place when training (models.py:261-264 via nn.BatchNorm2d)
     out = F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
                        sd[prefix + ".bias"], training, momentum, eps)
@@ -200,3 +204,33 @@ def fedavg_secure(state_dicts, weights=None, precision_fractional=16, base=10):
         dec = fix_decode(s, base, precision_fractional)
         out[key] = dec if weights else dec / K
     return out
+
+
+def dp_gradients(sd, x, target, max_grad_norm=1.0, noise_multiplier=1.3, noise=None, pooling="max"):
+    """DP-SGD gradient as pytorch-dp 0.1b1's PrivacyEngine computes it for the optimizer
+    (parameter values: train.py:325-334): per-sample gradients of each sample's own loss, flat L2
+    clip to C with factor min(1, C / (norm + 1e-6)), sum, + N(0, (noise_multiplier*C)^2), / batch.
+    pytorch-dp is not in the reference tree (environment_torch.yml:136) — parity unpinned; the
+    GroupNorm network makes samples independent, so per-sample gradients are batch-of-1 gradients.
+    `noise`: dict key -> standard-normal tensor (explicit randomness).  Returns (grads, norms, clip)."""
+    keys = param_keys(sd)
+    B = x.shape[0]
+    per = []
+    for n in range(B):
+        for k in keys:
+            sd[k].requires_grad_(True)
+            sd[k].grad = None
+        logits = forward(sd, x[n:n + 1], True, pooling, x.shape[-1])
+        F.cross_entropy(logits, target[n:n + 1]).backward()
+        per.append(OrderedDict((k, sd[k].grad.detach().clone()) for k in keys))
+    for k in keys:
+        sd[k].requires_grad_(False)
+    norms = torch.stack([torch.sqrt(sum((g[k].double() ** 2).sum() for k in keys)) for g in per])
+    clip = torch.clamp(max_grad_norm / (norms + 1e-6), max=1.0)
+    out = OrderedDict()
+    for k in keys:
+        s = sum(clip[n].to(per[n][k].dtype) * per[n][k] for n in range(B))
+        if noise is not None:
+            s = s + noise[k] * (noise_multiplier * max_grad_norm)
+        out[k] = s / B
+    return out, norms, clip

@@ -29,6 +29,9 @@ struct WgradParams {
     int nkt, nct;      // channel tiles
     int nsplit;        // pixel splits
     long pix_per_split;
+    long split_stride;  // 0: every split accumulates into dw; else split i writes dw + i*split_stride
+                        // (per-sample gradients for DP-SGD: one split per image, stride K*klen)
+    int persample;
 };
 
 template <typename T, int BMK, int BNC, bool STEM>
@@ -232,7 +235,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int k = kt * BMK + ca0 + 16 * i + fg * 4 + r;
                 const int e = ebase + cb0 + 16 * j + fr;
-                unsafeAtomicAdd(p.dw + (long)k * p.klen + e, acc[i][j][r]);
+                unsafeAtomicAdd(p.dw + (long)split * p.split_stride + (long)k * p.klen + e, acc[i][j][r]);
             }
 }
 
@@ -249,8 +252,10 @@ static int launch_wgrad(WgradParams p, hipStream_t st) {
     if (want < 1) want = 1;
     long pps = (p.Md + want - 1) / want;
     pps = (pps + KP - 1) / KP * KP;
+    if (p.persample) pps = (long)p.Ho * p.Wo;  // one split per image
     p.pix_per_split = pps;
     p.nsplit = (int)((p.Md + pps - 1) / pps);
+    p.split_stride = p.persample ? (long)p.K * p.klen : 0;
     const int grid = combos * p.nsplit;
     const size_t lds = 2 * KP * ((BMK + BNC) * sizeof(T) + 32);
     auto kern = conv_wgrad_kernel<T, BMK, BNC, STEM>;
@@ -271,8 +276,21 @@ int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st);
 }
 using namespace primia;
 
-extern "C" int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy,
-                                   float* dw_acc, int dtype, primia_stream_t stream) {
+static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc, int persample,
+                             int dtype, primia_stream_t stream);
+
+extern "C" int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,
+                                   int dtype, primia_stream_t stream) {
+    return conv2d_wgrad_impl(d, x, dy, dw_acc, 0, dtype, stream);
+}
+
+extern "C" int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,
+                                             float* dw_ps, int dtype, primia_stream_t stream) {
+    return conv2d_wgrad_impl(d, x, dy, dw_ps, 1, dtype, stream);
+}
+
+static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc, int persample,
+                             int dtype, primia_stream_t stream) {
     PRIMIA_REQUIRE(d && x && dy && dw_acc);
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
@@ -283,6 +301,8 @@ extern "C" int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, con
     p.klen = g.klen;
     p.Md = (long)g.N * g.Ho * g.Wo;
     p.ntaps = g.stem ? g.R : g.R * g.S;
+    p.persample = persample;
+    p.split_stride = 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         if (g.stem) return launch_wgrad<float, 64, 32, true>(p, st);
@@ -460,7 +480,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradParams p) {
             for (int t = 0; t < 4; ++t) {
                 const int k = kt * BMK + ka0 + 16 * i + fg * 4 + t;
                 const int e = ebase + cb0 + 16 * j + fr;
-                unsafeAtomicAdd(p.dw + (long)k * p.klen + e, acc[i][j][t]);
+                unsafeAtomicAdd(p.dw + (long)split * p.split_stride + (long)k * p.klen + e, acc[i][j][t]);
             }
 }
 
@@ -478,8 +498,10 @@ static int launch_wgrad_dma(WgradParams p, hipStream_t st) {
     if (want < 1) want = 1;
     long pps = (p.Md + want - 1) / want;
     pps = (pps + KP - 1) / KP * KP;
+    if (p.persample) pps = (long)p.Ho * p.Wo;
     p.pix_per_split = pps;
     p.nsplit = (int)((p.Md + pps - 1) / pps);
+    p.split_stride = p.persample ? (long)p.K * p.klen : 0;
     const int grid = combos * p.nsplit;
     const size_t lds = 2 * (size_t)KP * (BMK + BNC) * 2;
     auto kern = conv_wgrad_dma_kernel<BMK, BNC>;

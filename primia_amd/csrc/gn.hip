@@ -1,0 +1,420 @@
+// GroupNorm (+ fused ReLU / residual) on NHWC tensors and the per-sample pieces of DP-SGD.
+//
+// The reference's DP wiring (train.py:304-334: pytorch-dp PrivacyEngine, max_grad_norm 1.0,
+// noise_multiplier 1.3) rejects BatchNorm (train.py:308), and ResNet takes a `norm_layer` hook
+// (torchlib/models.py:355,362-364, GroupNorm init :411) — so the DP configuration of the build
+// (BASELINE.json configs[3]) runs ResNet-18 with GroupNorm(32, C), whose statistics are per sample
+// and therefore keep per-sample gradients independent.
+//
+// Layout: x [N, HW, C]; group g owns channels g*cpg .. g*cpg+cpg-1.  All kernels are HBM streaming
+// passes; reductions are two-level (per-slab fp32 partials -> fp64 combine), like csrc/bn.hip.
+#include "common.h"
+
+namespace primia {
+
+constexpr int kGnSlabs = 32;  // pixel slabs per sample in the reduction passes
+
+// partials[n][slab][q][c], q in {0,1}: two per-element quantities reduced over a slab of pixels
+template <typename T, typename F>
+__global__ __launch_bounds__(256) void gn_colreduce2_kernel(F f, int HW, int C, int rows_per_slab,
+                                                            float* __restrict__ partials) {
+    constexpr int CH = Chunk<T>::N;
+    const int tpr = C / CH, rpp = 256 / tpr;
+    const int rg = threadIdx.x / tpr, cc = threadIdx.x % tpr;
+    const int n = blockIdx.y, slab = blockIdx.x;
+    const int r0 = slab * rows_per_slab;
+    int r1 = r0 + rows_per_slab;
+    if (r1 > HW) r1 = HW;
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) s1[i] = s2[i] = 0.f;
+    for (int r = r0 + rg; r < r1; r += rpp) f(((long)n * HW + r) * C + cc * CH, n, cc * CH, s1, s2);
+    __shared__ float red[2][256 * CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        red[0][rg * C + cc * CH + i] = s1[i];
+        red[1][rg * C + cc * CH + i] = s2[i];
+    }
+    __syncthreads();
+    float* out = partials + ((long)n * gridDim.x + slab) * 2 * C;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f;
+        for (int g = 0; g < rpp; ++g) {
+            a += red[0][g * C + c];
+            b += red[1][g * C + c];
+        }
+        out[c] = a;
+        out[C + c] = b;
+    }
+}
+
+template <typename T>
+struct GnStatsFn {
+    const T* y;
+    __device__ __forceinline__ void operator()(long off, int, int, float* s1, float* s2) const {
+        constexpr int CH = Chunk<T>::N;
+        float v[CH];
+        Chunk<T>::unpack(*(const u32x4*)(y + off), v);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            s1[i] += v[i];
+            s2[i] += v[i] * v[i];
+        }
+    }
+};
+
+template <typename T>
+struct GnBwdFn {
+    const T* y;
+    const T* z;  // null: no relu
+    const T* dz;
+    const float* mean;    // [N][G]
+    const float* invstd;  // [N][G]
+    int G, cpg;
+    __device__ __forceinline__ void operator()(long off, int n, int c0, float* s1, float* s2) const {
+        constexpr int CH = Chunk<T>::N;
+        float vy[CH], vg[CH];
+        Chunk<T>::unpack(*(const u32x4*)(y + off), vy);
+        Chunk<T>::unpack(*(const u32x4*)(dz + off), vg);
+        if (z) {
+            float vz[CH];
+            Chunk<T>::unpack(*(const u32x4*)(z + off), vz);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int g = (c0 + i) / cpg;
+            const float xh = (vy[i] - mean[n * G + g]) * invstd[n * G + g];
+            s1[i] += vg[i];
+            s2[i] += vg[i] * xh;
+        }
+    }
+};
+
+// mode 0: partial (sum, sumsq) -> mean / invstd per (n, g).
+__global__ __launch_bounds__(256) void gn_stats_finalize_kernel(const float* __restrict__ partials, int nslab, int C,
+                                                                int G, long count, float eps, float* __restrict__ mean,
+                                                                float* __restrict__ invstd, int NG) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NG) return;
+    const int n = i / G, g = i % G, cpg = C / G;
+    double a = 0.0, b = 0.0;
+    for (int s = 0; s < nslab; ++s) {
+        const float* p = partials + ((long)n * nslab + s) * 2 * C;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            a += (double)p[c];
+            b += (double)p[C + c];
+        }
+    }
+    const double m = a / (double)count;
+    double var = b / (double)count - m * m;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)m;
+    invstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// mode 1: partial (sum g, sum g*xhat) per (n, c) -> per-sample dbeta/dgamma [N][C] and the group sums
+// A[n,g] = sum_c gamma_c * s1, B[n,g] = sum_c gamma_c * s2 used by the input gradient.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ partials, int nslab, int C,
+                                                              int G, const float* __restrict__ gamma,
+                                                              float* __restrict__ ps_dbeta, float* __restrict__ ps_dgamma,
+                                                              float* __restrict__ gA, float* __restrict__ gB, int NG) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= NG) return;
+    const int n = i / G, g = i % G, cpg = C / G;
+    double A = 0.0, B = 0.0;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+        double a = 0.0, b = 0.0;
+        for (int s = 0; s < nslab; ++s) {
+            const float* p = partials + ((long)n * nslab + s) * 2 * C;
+            a += (double)p[c];
+            b += (double)p[C + c];
+        }
+        ps_dbeta[(long)n * C + c] = (float)a;
+        ps_dgamma[(long)n * C + c] = (float)b;
+        A += (double)gamma[c] * a;
+        B += (double)gamma[c] * b;
+    }
+    gA[i] = (float)A;
+    gB[i] = (float)B;
+}
+
+// z = act((y - mean[n,g]) * invstd[n,g] * gamma_c + beta_c [+ residual])
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res,
+                                                       T* __restrict__ z, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, long nchunks, int HW, int C,
+                                                       int G, int relu) {
+    constexpr int CH = Chunk<T>::N;
+    const int cpr = C / CH, cpg = C / G;
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nchunks; q += stride) {
+        const int c0 = (int)(q % cpr) * CH;
+        const int n = (int)(q / ((long)cpr * HW));
+        float v[CH];
+        Chunk<T>::unpack(*(const u32x4*)(y + q * CH), v);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int g = (c0 + i) / cpg;
+            v[i] = (v[i] - mean[n * G + g]) * (invstd[n * G + g] * gamma[c0 + i]) + beta[c0 + i];
+        }
+        if (res) {
+            float r[CH];
+            Chunk<T>::unpack(*(const u32x4*)(res + q * CH), r);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] += r[i];
+        }
+        if (relu) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) v[i] = fmaxf(v[i], 0.f);
+        }
+        *(u32x4*)(z + q * CH) = Chunk<T>::pack(v);
+    }
+}
+
+// dy = invstd * (gamma_c*g - A/m - xhat*B/m); optionally g_out = masked g.
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ z, const T* dz,
+                                                           T* __restrict__ dy, T* g_out, const float* __restrict__ gamma,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           const float* __restrict__ gA, const float* __restrict__ gB,
+                                                           float inv_m, long nchunks, int HW, int C, int G) {
+    constexpr int CH = Chunk<T>::N;
+    const int cpr = C / CH, cpg = C / G;
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nchunks; q += stride) {
+        const int c0 = (int)(q % cpr) * CH;
+        const int n = (int)(q / ((long)cpr * HW));
+        float vy[CH], vg[CH];
+        Chunk<T>::unpack(*(const u32x4*)(y + q * CH), vy);
+        Chunk<T>::unpack(*(const u32x4*)(dz + q * CH), vg);
+        if (z) {
+            float vz[CH];
+            Chunk<T>::unpack(*(const u32x4*)(z + q * CH), vz);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        }
+        if (g_out) *(u32x4*)(g_out + q * CH) = Chunk<T>::pack(vg);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int g = (c0 + i) / cpg, ng = n * G + g;
+            const float xh = (vy[i] - mean[ng]) * invstd[ng];
+            vy[i] = invstd[ng] * (gamma[c0 + i] * vg[i] - gA[ng] * inv_m - xh * gB[ng] * inv_m);
+        }
+        *(u32x4*)(dy + q * CH) = Chunk<T>::pack(vy);
+    }
+}
+
+// ---- DP-SGD per-sample pieces -------------------------------------------------------------------------
+// out[n] += sum_j x[n][j]^2   (block per (sample, chunk); fp64 block sum, one atomic per block)
+__global__ __launch_bounds__(256) void persample_sqnorm_kernel(const float* __restrict__ x, long per, double* out) {
+    const int n = blockIdx.y;
+    const float* p = x + (long)n * per;
+    double s = 0.0;
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < per; j += (long)gridDim.x * 256) {
+        const double v = (double)p[j];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + n, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// clip[n] = min(1, C / (sqrt(sq[n]) + 1e-6))   (pytorch-dp's per-sample clip factor)
+__global__ void dp_clip_factor_kernel(const double* __restrict__ sq, float* __restrict__ clip, int N, float max_norm) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const double f = (double)max_norm / (sqrt(sq[n]) + 1e-6);
+    clip[n] = (float)(f < 1.0 ? f : 1.0);
+}
+
+// x[row][:] *= s[row / rows_per_sample]
+template <typename T>
+__global__ __launch_bounds__(256) void scale_rows_kernel(T* x, const float* __restrict__ s, long nchunks, long chunks_per_sample) {
+    constexpr int CH = Chunk<T>::N;
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nchunks; q += stride) {
+        const float a = s[q / chunks_per_sample];
+        float v[CH];
+        Chunk<T>::unpack(*(const u32x4*)(x + q * CH), v);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] *= a;
+        *(u32x4*)(x + q * CH) = Chunk<T>::pack(v);
+    }
+}
+
+// out[c] = sum_n w[n] * x[n][c]
+__global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              float* __restrict__ out, int N, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int n = 0; n < N; ++n) s += (double)w[n] * (double)x[(long)n * C + c];
+    out[c] = (float)s;
+}
+
+// ps[n] = [ outer(dy[n], x[n]) (out_f x in_f) | dy[n] (out_f) ]: per-sample fc gradients
+__global__ __launch_bounds__(256) void fc_persample_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ ps, int N, int in_f, int out_f) {
+    const long per = (long)out_f * in_f + out_f;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long)N * per) return;
+    const long n = i / per, j = i - n * per;
+    if (j < (long)out_f * in_f)
+        ps[i] = dy[n * out_f + j / in_f] * x[n * in_f + j % in_f];
+    else
+        ps[i] = dy[n * out_f + (j - (long)out_f * in_f)];
+}
+
+// g = (g + noise * sigma) * inv_b
+__global__ __launch_bounds__(256) void dp_noise_kernel(float* __restrict__ g, const float* __restrict__ noise, long n,
+                                                       float sigma, float inv_b) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) g[i] = (g[i] + noise[i] * sigma) * inv_b;
+}
+
+static inline int gn_stream_blocks(long nchunks) {
+    long b = (nchunks + 255) / 256;
+    return (int)(b < 2048 ? (b < 1 ? 1 : b) : 2048);
+}
+static inline bool gn_shape_ok(int N, int HW, int C, int G, int dtype) {
+    const int ch = dtype == PRIMIA_F32 ? 4 : 8;
+    return N > 0 && HW > 0 && C > 0 && C <= 512 && G > 0 && C % G == 0 && C % ch == 0 && 256 % (C / ch) == 0;
+}
+
+template <typename T>
+static int gn_fwd_impl(const void* y, const void* res, void* z, const float* gamma, const float* beta, float* mean,
+                       float* invstd, int N, int HW, int C, int G, float eps, int relu, float* partials, hipStream_t st) {
+    const int rps = (HW + kGnSlabs - 1) / kGnSlabs;
+    const int nslab = (HW + rps - 1) / rps;
+    GnStatsFn<T> f{(const T*)y};
+    gn_colreduce2_kernel<T, GnStatsFn<T>><<<dim3(nslab, N), 256, 0, st>>>(f, HW, C, rps, partials);
+    gn_stats_finalize_kernel<<<(N * G + 255) / 256, 256, 0, st>>>(partials, nslab, C, G, (long)HW * (C / G), eps, mean,
+                                                                  invstd, N * G);
+    const long nchunks = (long)N * HW * C / Chunk<T>::N;
+    gn_apply_kernel<T><<<gn_stream_blocks(nchunks), 256, 0, st>>>((const T*)y, (const T*)res, (T*)z, gamma, beta, mean,
+                                                                  invstd, nchunks, HW, C, G, relu);
+    return launch_status();
+}
+
+template <typename T>
+static int gn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, void* g_out, const float* gamma,
+                       const float* mean, const float* invstd, float* ps_dgamma, float* ps_dbeta, int N, int HW, int C,
+                       int G, int relu, float* partials, hipStream_t st) {
+    const int rps = (HW + kGnSlabs - 1) / kGnSlabs;
+    const int nslab = (HW + rps - 1) / rps;
+    GnBwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, mean, invstd, G, C / G};
+    gn_colreduce2_kernel<T, GnBwdFn<T>><<<dim3(nslab, N), 256, 0, st>>>(f, HW, C, rps, partials);
+    float* gA = partials + (long)N * nslab * 2 * C;  // group sums live behind the partials
+    float* gB = gA + (long)N * G;
+    gn_bwd_finalize_kernel<<<(N * G + 255) / 256, 256, 0, st>>>(partials, nslab, C, G, gamma, ps_dbeta, ps_dgamma, gA, gB,
+                                                                N * G);
+    const long nchunks = (long)N * HW * C / Chunk<T>::N;
+    gn_bwd_apply_kernel<T><<<gn_stream_blocks(nchunks), 256, 0, st>>>(
+        (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, mean, invstd, gA, gB,
+        (float)(1.0 / ((double)HW * (C / G))), nchunks, HW, C, G);
+    return launch_status();
+}
+
+}  // namespace primia
+
+using namespace primia;
+
+extern "C" {
+
+int64_t primia_gn_workspace_bytes(int N, int C, int G) {
+    return ((int64_t)N * kGnSlabs * 2 * C + 2 * (int64_t)N * G) * sizeof(float);
+}
+
+int primia_gn_fwd(const void* y, const void* residual, void* z, const float* gamma, const float* beta,
+                  float* save_mean, float* save_invstd, int N, int HW, int C, int G, float eps, int relu,
+                  void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && z && gamma && beta && save_mean && save_invstd && workspace);
+    PRIMIA_REQUIRE(gn_shape_ok(N, HW, C, G, dtype));
+    if (workspace_bytes < primia_gn_workspace_bytes(N, C, G)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return gn_fwd_impl<float>(y, residual, z, gamma, beta, save_mean, save_invstd, N, HW, C, G, eps, relu,
+                                  (float*)workspace, st);
+    if (dtype == PRIMIA_BF16)
+        return gn_fwd_impl<bf16>(y, residual, z, gamma, beta, save_mean, save_invstd, N, HW, C, G, eps, relu,
+                                 (float*)workspace, st);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_gn_bwd(const void* y, const void* z, const void* dz, void* dy, void* g_out, const float* gamma,
+                  const float* save_mean, const float* save_invstd, float* ps_dgamma, float* ps_dbeta, int N, int HW,
+                  int C, int G, int relu, void* workspace, int64_t workspace_bytes, int dtype,
+                  primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && dz && dy && gamma && save_mean && save_invstd && ps_dgamma && ps_dbeta && workspace);
+    PRIMIA_REQUIRE(!relu || z);
+    PRIMIA_REQUIRE(gn_shape_ok(N, HW, C, G, dtype));
+    if (workspace_bytes < primia_gn_workspace_bytes(N, C, G)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return gn_bwd_impl<float>(y, z, dz, dy, g_out, gamma, save_mean, save_invstd, ps_dgamma, ps_dbeta, N, HW, C, G,
+                                  relu, (float*)workspace, st);
+    if (dtype == PRIMIA_BF16)
+        return gn_bwd_impl<bf16>(y, z, dz, dy, g_out, gamma, save_mean, save_invstd, ps_dgamma, ps_dbeta, N, HW, C, G,
+                                 relu, (float*)workspace, st);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_persample_sqnorm(const float* x, int N, int64_t per_sample, double* sq_acc, primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && sq_acc && N > 0 && per_sample > 0);
+    long b = (per_sample + 255) / 256;
+    if (b > 64) b = 64;
+    persample_sqnorm_kernel<<<dim3((int)b, N), 256, 0, (hipStream_t)stream>>>(x, per_sample, sq_acc);
+    return launch_status();
+}
+
+int primia_dp_clip_factors(const double* sq, float* clip, int N, float max_grad_norm, primia_stream_t stream) {
+    PRIMIA_REQUIRE(sq && clip && N > 0 && max_grad_norm > 0.f);
+    dp_clip_factor_kernel<<<(N + 255) / 256, 256, 0, (hipStream_t)stream>>>(sq, clip, N, max_grad_norm);
+    return launch_status();
+}
+
+int primia_scale_rows(void* x, const float* s, int N, int64_t elems_per_sample, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && s && N > 0 && elems_per_sample > 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32) {
+        PRIMIA_REQUIRE(elems_per_sample % 4 == 0);
+        const long cps = elems_per_sample / 4, nch = cps * N;
+        scale_rows_kernel<float><<<gn_stream_blocks(nch), 256, 0, st>>>((float*)x, s, nch, cps);
+    } else if (dtype == PRIMIA_BF16) {
+        PRIMIA_REQUIRE(elems_per_sample % 8 == 0);
+        const long cps = elems_per_sample / 8, nch = cps * N;
+        scale_rows_kernel<bf16><<<gn_stream_blocks(nch), 256, 0, st>>>((bf16*)x, s, nch, cps);
+    } else {
+        return PRIMIA_ERR_ARG;
+    }
+    return launch_status();
+}
+
+int primia_weighted_colsum(const float* x, const float* w, float* out, int N, int C, primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && w && out && N > 0 && C > 0);
+    weighted_colsum_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, w, out, N, C);
+    return launch_status();
+}
+
+int primia_fc_persample_grads(const float* x, const float* dy, float* ps, int N, int in_f, int out_f,
+                              primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && dy && ps && N > 0 && in_f > 0 && out_f > 0);
+    const long total = (long)N * ((long)out_f * in_f + out_f);
+    fc_persample_kernel<<<ceil_div(total, 256), 256, 0, (hipStream_t)stream>>>(x, dy, ps, N, in_f, out_f);
+    return launch_status();
+}
+
+int primia_dp_add_noise(float* g, const float* noise, int64_t n, float sigma, float inv_batch, primia_stream_t stream) {
+    PRIMIA_REQUIRE(g && noise && n >= 0);
+    if (n == 0) return PRIMIA_OK;
+    long b = (n + 255) / 256;
+    dp_noise_kernel<<<(int)(b > 4096 ? 4096 : b), 256, 0, (hipStream_t)stream>>>(g, noise, n, sigma, inv_batch);
+    return launch_status();
+}
+
+}  // extern "C"

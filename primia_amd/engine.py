@@ -33,11 +33,17 @@ class _Conv:
 
 class ResNet18Engine:
     def __init__(self, batch_size, num_classes=3, in_channels=3, input_size=224, pooling="max",
-                 dtype=torch.bfloat16, device="cuda:0"):
+                 dtype=torch.bfloat16, device="cuda:0", norm="batch", groups=32):
+        """norm="batch": the reference model.  norm="group": GroupNorm(groups, C) in place of every
+        BatchNorm (ResNet's `norm_layer` hook, torchlib/models.py:355) — the BN-free network the
+        DP-SGD configuration needs (train.py:308)."""
         if not torch.cuda.is_available():
             raise _lib.PrimiaError("ResNet18Engine needs a GPU (HIP kernels only, no CPU fallback)")
         _lib.lib()
         self.spec: NetSpec = resnet18_spec(num_classes, in_channels, input_size, pooling)
+        if norm not in ("batch", "group"):
+            raise ValueError("norm must be 'batch' or 'group'")
+        self.norm, self.groups = norm, int(groups)
         self.N = int(batch_size)
         self.dtype = dtype
         self.dt = _lib.dtype_code(dtype)
@@ -47,7 +53,7 @@ class ResNet18Engine:
 
         # ---- flat arenas ---------------------------------------------------------------------
         self.p_entries = param_entries(self.spec)
-        self.b_entries = buffer_entries(self.spec)
+        self.b_entries = buffer_entries(self.spec, norm)
         self.P = sum(int(torch.Size(s).numel()) for _, s in self.p_entries)
         self.B = sum(int(torch.Size(s).numel()) for _, s in self.b_entries)
         self.flat = torch.zeros(self.P + self.B, dtype=torch.float32, device=dev)
@@ -157,7 +163,18 @@ class ResNet18Engine:
             self.save[b] = (torch.empty(c.cout, dtype=torch.float32, device=dev),
                             torch.empty(c.cout, dtype=torch.float32, device=dev))
         self.bn_ws_bytes = query("primia_bn_workspace_bytes", 1, 512)
+        if norm == "group":
+            self.bn_ws_bytes = max(self.bn_ws_bytes, query("primia_gn_workspace_bytes", N, 512, self.groups))
+            # statistics are per (sample, group); per-sample affine gradients [N][C] per layer
+            self.save = {bn_name(c.name): (torch.empty(N * self.groups, dtype=torch.float32, device=dev),
+                                           torch.empty(N * self.groups, dtype=torch.float32, device=dev))
+                         for c in self.spec.convs}
+            self.ps_affine = {bn_name(c.name): (torch.empty(N, c.cout, dtype=torch.float32, device=dev),
+                                                torch.empty(N, c.cout, dtype=torch.float32, device=dev))
+                              for c in self.spec.convs}
+            self.ones_n = torch.ones(N, dtype=torch.float32, device=dev)
         self.bn_ws = torch.empty(self.bn_ws_bytes, dtype=torch.uint8, device=dev)
+        self.dp = None  # set by dp_backward: {"wgrads": [...]} defers the weight gradients
         self.feat = torch.empty(N, 512, dtype=torch.float32, device=dev)
         self.dfeat = torch.empty(N, 512, dtype=torch.float32, device=dev)
         self.logits = torch.empty(N, num_classes, dtype=torch.float32, device=dev)
@@ -170,7 +187,7 @@ class ResNet18Engine:
     # ------------------------------------------------------------------------------------------
     def init_weights(self):
         """Draw fresh weights from the global torch RNG the way the reference constructor does."""
-        self.load_state_dict(init_state_dict(self.spec))
+        self.load_state_dict(init_state_dict(self.spec, self.norm))
 
     def state_dict(self):
         """Reference-compatible state dict (CPU tensors, OIHW, 122 keys incl. num_batches_tracked)."""
@@ -182,7 +199,7 @@ class ResNet18Engine:
             n = int(torch.Size(s).numel())
             off[k] = (o, n, s)
             o += n
-        for k in state_dict_keys(self.spec):
+        for k in state_dict_keys(self.spec, self.norm):
             if k.endswith("num_batches_tracked"):
                 sd[k] = torch.tensor(self.num_batches_tracked[k.rsplit(".", 1)[0]], dtype=torch.long)
             else:
@@ -191,7 +208,7 @@ class ResNet18Engine:
         return sd
 
     def load_state_dict(self, sd):
-        keys = state_dict_keys(self.spec)
+        keys = state_dict_keys(self.spec, self.norm)
         missing = [k for k in keys if k not in sd]
         extra = [k for k in sd if k not in keys]
         if missing or extra:
@@ -243,6 +260,11 @@ class ResNet18Engine:
         C = y.shape[1]
         M = y.shape[0]
         g, be = self.views[b + ".weight"], self.views[b + ".bias"]
+        if self.norm == "group":  # identical in train and eval mode: no running statistics
+            sm, si = self.save[b]
+            call("primia_gn_fwd", y, residual, z, g, be, sm, si, self.N, M // self.N, C, self.groups, BN_EPS, int(relu),
+                 self.bn_ws, self.bn_ws_bytes, self.dt)
+            return
         rm, rv = self.views[b + ".running_mean"], self.views[b + ".running_var"]
         if self.training:
             sm, si = self.save[b]
@@ -333,11 +355,23 @@ class ResNet18Engine:
     def _bn_bwd(self, conv_name, y, z, dz, dy, g_out, relu):
         b = bn_name(conv_name)
         sm, si = self.save[b]
+        if self.norm == "group":
+            psg, psb = self.ps_affine[b]
+            C = y.shape[1]
+            call("primia_gn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, psg, psb, self.N,
+                 y.shape[0] // self.N, C, self.groups, int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
+            if self.dp is None:  # plain training: dgamma / dbeta = sum over samples
+                call("primia_weighted_colsum", psg, self.ones_n, self.gviews[b + ".weight"], self.N, C)
+                call("primia_weighted_colsum", psb, self.ones_n, self.gviews[b + ".bias"], self.N, C)
+            return
         call("primia_bn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, self.gviews[b + ".weight"],
              self.gviews[b + ".bias"], y.shape[0], y.shape[1], int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
 
     def _wgrad(self, name, x, dy):
         c = self.convs[name]
+        if self.dp is not None:  # DP-SGD: weight gradients wait for the per-sample clip factors
+            self.dp["wgrads"].append((name, x, dy))
+            return
         self._timed("wgrad", c, lambda: call("primia_conv2d_wgrad", c.desc, x, dy, c.acc, self.dt))
 
     def _dgrad(self, name, dy, dx, accumulate):
@@ -349,6 +383,7 @@ class ResNet18Engine:
         N, t = self.N, self.t
         nc = self.spec.num_classes
         self.dw_acc.zero_()
+        # (under DP-SGD fc.weight / fc.bias gradients are overwritten later from the clipped dlogits)
         call("primia_linear_bwd", self.feat, self.views["fc.weight"], self.dlogits, self.dfeat,
              self.gviews["fc.weight"], self.gviews["fc.bias"], N, 512, nc)
         last = self.spec.blocks[-1].prefix
@@ -382,8 +417,73 @@ class ResNet18Engine:
             call("primia_avgpool3x3s2_bwd", t["pool.dout"], t["stem.dz"], N, hw, hw, 64, self.dt)
         self._bn_bwd("conv1", t["stem.y"], t["stem.z"], t["stem.dz"], t["stem.dy"], None, True)
         self._wgrad("conv1", self.x0, t["stem.dy"])
+        if self.dp is None:
+            self._finalize_wgrads()
+
+    def _finalize_wgrads(self):
         m = self._many_args()
         call("primia_conv_wgrad_finalize_many", m["descs"], m["creal"], m["acc"], m["gw"], m["n"])
+
+    # ------------------------------------------------------------------------------------------
+    # DP-SGD (BASELINE.json configs[3]; parameter values of train.py:325-334)
+    # ------------------------------------------------------------------------------------------
+    def dp_loss_backward(self, target, max_grad_norm=1.0, noise_multiplier=1.3, noise=None, generator=None):
+        """Per-sample gradient clipping + Gaussian noise, pytorch-dp semantics:
+            g = (1/B) * ( sum_n min(1, C / (||g_n|| + 1e-6)) * g_n  +  N(0, (noise_multiplier*C)^2 I) )
+        with g_n the gradient of sample n's OWN loss over all 62 parameter tensors (flat L2 norm).
+        Needs norm="group".  `noise` (fp32 [P], standard normal) may be given for reproducibility.
+
+        How: one ordinary backward pass yields every layer's activation gradient dy (samples are
+        independent under GroupNorm).  Pass 1 forms per-sample weight gradients layer by layer in a
+        scratch slab (one wgrad split per image) only to accumulate ||g_n||^2; then each sample's rows of
+        dy are scaled by its clip factor and the ordinary batched wgrad — linear in dy — produces
+        sum_n clip_n * g_n directly."""
+        if self.norm != "group":
+            raise _lib.PrimiaError("DP-SGD needs the BatchNorm-free network: ResNet18Engine(norm='group')")
+        N, nc, dev = self.N, self.spec.num_classes, self.device
+        # per-sample loss gradients: softmax - onehot (xent gives them divided by the batch size)
+        call("primia_xent_hard", self.logits, target, None, self.loss, self.dlogits, N, nc)
+        call("primia_scale", self.dlogits, self.dlogits.numel(), float(N))
+        self.dp = {"wgrads": []}
+        try:
+            self.backward()
+            sq = torch.zeros(N, dtype=torch.float64, device=dev)
+            # fc: g_W[n] = dlogits[n]^T feat[n], g_b[n] = dlogits[n]
+            ps_fc = torch.empty(N, nc * 512 + nc, dtype=torch.float32, device=dev)
+            call("primia_fc_persample_grads", self.feat, self.dlogits, ps_fc, N, 512, nc)
+            call("primia_persample_sqnorm", ps_fc, N, nc * 512 + nc, sq)
+            for b, (psg, psb) in self.ps_affine.items():
+                call("primia_persample_sqnorm", psg, N, psg.shape[1], sq)
+                call("primia_persample_sqnorm", psb, N, psb.shape[1], sq)
+            need = max(self.convs[n].wfwd_n for n, _, _ in self.dp["wgrads"]) * N
+            if getattr(self, "_ps_scratch", None) is None or self._ps_scratch.numel() < need:
+                self._ps_scratch = torch.empty(need, dtype=torch.float32, device=dev)
+            for name, x, dy in self.dp["wgrads"]:
+                c = self.convs[name]
+                slab = self._ps_scratch[:N * c.wfwd_n]
+                slab.zero_()
+                call("primia_conv2d_wgrad_persample", c.desc, x, dy, slab, self.dt)
+                call("primia_persample_sqnorm", slab, N, c.wfwd_n, sq)  # zero padding adds nothing
+            clip = torch.empty(N, dtype=torch.float32, device=dev)
+            call("primia_dp_clip_factors", sq, clip, N, float(max_grad_norm))
+            # clipped sums
+            for name, x, dy in self.dp["wgrads"]:
+                c = self.convs[name]
+                call("primia_scale_rows", dy, clip, N, dy.numel() // N, self.dt)
+                call("primia_conv2d_wgrad", c.desc, x, dy, c.acc, self.dt)
+            self._finalize_wgrads()
+            for b, (psg, psb) in self.ps_affine.items():
+                call("primia_weighted_colsum", psg, clip, self.gviews[b + ".weight"], N, psg.shape[1])
+                call("primia_weighted_colsum", psb, clip, self.gviews[b + ".bias"], N, psb.shape[1])
+            call("primia_weighted_colsum", ps_fc, clip, self.gviews["fc.weight"].view(-1), N, nc * 512)
+            call("primia_weighted_colsum", ps_fc[:, nc * 512:].contiguous(), clip, self.gviews["fc.bias"], N, nc)
+        finally:
+            self.dp = None
+        if noise is None:
+            noise = torch.randn(self.P, dtype=torch.float32, device=dev, generator=generator)
+        call("primia_dp_add_noise", self.grads, noise, self.P, float(noise_multiplier * max_grad_norm), 1.0 / N)
+        self.dp_stats = {"sq_norms": sq, "clip": clip}
+        return self.loss
 
     # ------------------------------------------------------------------------------------------
     # optimizer

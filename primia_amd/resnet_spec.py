@@ -105,9 +105,12 @@ def param_entries(spec: NetSpec):
     return out
 
 
-def buffer_entries(spec: NetSpec):
-    """(key, shape) of the float buffers (running_mean, running_var) in reference order."""
+def buffer_entries(spec: NetSpec, norm: str = "batch"):
+    """(key, shape) of the float buffers (running_mean, running_var) in reference order.
+    GroupNorm (norm="group", the DP configuration) has none."""
     out = []
+    if norm == "group":
+        return out
     for c in spec.convs:
         b = bn_name(c.name)
         out.append((b + ".running_mean", (c.cout,)))
@@ -115,14 +118,16 @@ def buffer_entries(spec: NetSpec):
     return out
 
 
-def state_dict_keys(spec: NetSpec):
-    """Key order of the reference model's state_dict() (122 keys for ResNet-18)."""
+def state_dict_keys(spec: NetSpec, norm: str = "batch"):
+    """Key order of the reference model's state_dict() (122 keys for ResNet-18 with BatchNorm; with
+    `norm_layer` = GroupNorm the running statistics and counters do not exist)."""
     keys = []
 
     def conv_bn(c: ConvSpec):
         b = bn_name(c.name)
-        keys.extend([c.name + ".weight", b + ".weight", b + ".bias", b + ".running_mean", b + ".running_var",
-                     b + ".num_batches_tracked"])
+        keys.extend([c.name + ".weight", b + ".weight", b + ".bias"])
+        if norm == "batch":
+            keys.extend([b + ".running_mean", b + ".running_var", b + ".num_batches_tracked"])
 
     conv_bn(spec.stem)
     for blk in spec.blocks:
@@ -148,7 +153,7 @@ def _linear_init(out_f, in_f):
     return w, b
 
 
-def init_state_dict(spec: NetSpec) -> "OrderedDict[str, torch.Tensor]":
+def init_state_dict(spec: NetSpec, norm: str = "batch") -> "OrderedDict[str, torch.Tensor]":
     """Fresh CPU state dict drawn from the global torch RNG exactly as the reference constructor
     does (torchlib/models.py:379-413, 495): default Conv2d/Linear initialisers run first in
     construction order, then every conv is re-drawn with kaiming_normal_(fan_out, relu), BN is
@@ -169,7 +174,7 @@ def init_state_dict(spec: NetSpec) -> "OrderedDict[str, torch.Tensor]":
     fc_w, fc_b = _linear_init(spec.num_classes, 512)
 
     sd = OrderedDict()
-    for key in state_dict_keys(spec):
+    for key in state_dict_keys(spec, norm):
         mod, leaf = key.rsplit(".", 1)
         if key == "fc.weight":
             sd[key] = fc_w

@@ -1,0 +1,111 @@
+"""GPU: GroupNorm network and the DP-SGD gradient (BASELINE configs[3]) against
+the oracle.  pytorch-dp is not in the reference tree, so this row is 'parity unpinned': the oracle
+restates the documented algorithm (per-sample clip to C = 1.0, noise multiplier 1.3)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import train_oracle as O  # noqa: E402
+from primia_amd import _lib, resnet_spec as rs  # noqa: E402
+from primia_amd._lib import call, query  # noqa: E402
+from primia_amd.engine import ResNet18Engine  # noqa: E402
+
+
+def rel(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("C,relu,res", [(64, 1, 0), (128, 1, 1), (512, 0, 0)])
+def test_groupnorm_kernels(cuda, dtype, C, relu, res):
+    N, H, G = 3, 6, 32
+    HW = H * H
+    g = torch.Generator().manual_seed(C)
+    rnd = lambda t: t.to(dtype).float()
+    y = rnd(torch.randn(N, C, H, H, generator=g) * 2 + 0.3)
+    r = rnd(torch.randn(N, C, H, H, generator=g)) if res else None
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    yr = y.clone().requires_grad_(True)
+    zr = F.group_norm(yr, G, gamma, beta, 1e-5)
+    if res:
+        zr = zr + r
+    if relu:
+        zr = F.relu(zr)
+    dz = rnd(torch.randn(zr.shape, generator=g))
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(N * HW, C).contiguous().to(dtype).to(cuda)
+    back = lambda t: t.float().cpu().view(N, H, H, C).permute(0, 3, 1, 2)
+    dt = _lib.dtype_code(dtype)
+    wsb = query("primia_gn_workspace_bytes", N, C, G)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    z = torch.empty(N * HW, C, dtype=dtype, device=cuda)
+    sm, si = torch.empty(N * G, device=cuda), torch.empty(N * G, device=cuda)
+    call("primia_gn_fwd", nhwc(y), nhwc(r) if res else None, z, gamma.to(cuda), beta.to(cuda), sm, si, N, HW, C, G, 1e-5,
+         relu, ws, wsb, dt)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel(back(z), zr.detach()) < tol
+    # backward incl. per-sample affine gradients
+    per_g, per_b = [], []
+    for n in range(N):
+        yn = y[n:n + 1].clone().requires_grad_(True)
+        gn_, bn_ = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        zn = F.group_norm(yn, G, gn_, bn_, 1e-5)
+        if res:
+            zn = zn + r[n:n + 1]
+        if relu:
+            zn = F.relu(zn)
+        zn.backward(dz[n:n + 1])
+        per_g.append(gn_.grad)
+        per_b.append(bn_.grad)
+    zr.backward(dz)
+    dy = torch.empty_like(z)
+    psg, psb = torch.empty(N, C, device=cuda), torch.empty(N, C, device=cuda)
+    call("primia_gn_bwd", nhwc(y), z if relu else None, nhwc(dz), dy, None, gamma.to(cuda), sm, si, psg, psb, N, HW, C, G,
+         relu, ws, wsb, dt)
+    assert rel(back(dy), yr.grad) < (2e-5 if dtype == torch.float32 else 2e-2)
+    assert rel(psg, torch.stack(per_g)) < (2e-5 if dtype == torch.float32 else 1e-2)
+    assert rel(psb, torch.stack(per_b)) < (2e-5 if dtype == torch.float32 else 1e-2)
+
+
+def test_dp_sgd_gradient_matches_oracle(cuda):
+    """fp32 engine, GroupNorm ResNet-18, batch 4 at 64x64: per-sample norms, clip factors and the
+    noised clipped gradient vs the oracle's per-sample (batch-of-1) restatement."""
+    batch, size = 4, 64
+    torch.manual_seed(9)
+    spec = rs.resnet18_spec(3, 3, size, "max")
+    sd = rs.init_state_dict(spec, "group")
+    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda, norm="group")
+    eng.load_state_dict(sd)
+    g = torch.Generator().manual_seed(10)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    y = torch.randint(0, 3, (batch,), generator=g)
+    noise_flat = torch.randn(eng.P, generator=g)
+    noise, off = {}, 0
+    for k, s in eng.p_entries:
+        n = int(torch.Size(s).numel())
+        noise[k] = noise_flat[off:off + n].view(s)
+        off += n
+    # plain (non-private) step on the GroupNorm network first
+    logits = eng.forward(x.to(cuda)).cpu()
+    eng.loss_backward(y.to(cuda))
+    ologits, _, ograds = O.train_step({k: v.clone() for k, v in sd.items()}, x, y, 0.0, 0.0)
+    assert rel(logits, ologits) < 1e-5
+    for k in ("conv1.weight", "bn1.weight", "layer3.0.downsample.0.weight", "layer4.1.bn2.bias", "fc.weight"):
+        assert rel(eng.gviews[k], ograds[k]) < 1e-2, k
+    # DP-SGD gradient
+    eng.forward(x.to(cuda))
+    eng.dp_loss_backward(y.to(cuda), max_grad_norm=1.0, noise_multiplier=1.3, noise=noise_flat.to(cuda))
+    want, norms, clip = O.dp_gradients({k: v.clone() for k, v in sd.items()}, x, y, 1.0, 1.3, noise)
+    got_norms = eng.dp_stats["sq_norms"].sqrt().cpu()
+    assert torch.allclose(got_norms, norms, rtol=5e-3), (got_norms, norms)
+    assert torch.allclose(eng.dp_stats["clip"].cpu().double(), clip, rtol=5e-3)
+    assert (clip < 1).any(), "test should exercise clipping"
+    for k, _ in eng.p_entries:
+        # noise (std 1.3/4 per element) dominates most tensors: compare on the full vector
+        assert rel(eng.gviews[k], want[k]) < 5e-3, k
+    # without noise the result is the mean of clipped per-sample gradients: norm <= C
+    eng.forward(x.to(cuda))
+    eng.dp_loss_backward(y.to(cuda), 1.0, 0.0, noise=torch.zeros(eng.P, device=cuda))
+    assert eng.grads.double().norm().item() <= 1.0 + 1e-4
