@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--sync-every", type=int, default=3)
     ap.add_argument("--secure-aggregation", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp", action="store_true", help="DP-SGD step (GroupNorm net, clip 1.0, noise 1.3): BASELINE configs[3]")
     ap.add_argument("--no-secure", action="store_true", help="skip the encrypted-inference leg (second BASELINE metric)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-baseline-batch", type=int, default=32)
@@ -99,7 +100,9 @@ def main():
     from primia_amd.engine import ResNet18Engine
 
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    eng = ResNet18Engine(a.batch, 3, 3, a.size, "max", dtype=dtype, device=dev)
+    eng = ResNet18Engine(a.batch, 3, 3, a.size, "max", dtype=dtype, device=dev, norm="group" if a.dp else "batch")
+    if a.dp:
+        eng.dp_params = {"max_grad_norm": 1.0, "noise_multiplier": 1.3}   # train.py:325-334
     torch.manual_seed(42)           # the reference's default seed (pneumonia-resnet-pretrained.ini:17)
     eng.init_weights()
     g = torch.Generator().manual_seed(1000 + rank)
@@ -124,6 +127,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if a.dp:
+        a.no_graph = True  # the DP step draws its noise through torch's generator: launch it eagerly
     # The step is ~190 kernel launches; replaying it as a hipGraph (one per input buffer) removes the
     # host launch cost from the launch-bound stretches (BN finalize, weight refresh).  Single-GPU
     # only: the FedAvg all-reduce stays outside graphs.
@@ -202,7 +207,7 @@ def main():
                                f"3x{a.size}x{a.size}, 1 client per GPU"
                                + (f", FedAvg every {a.sync_every} batches over RCCL" if world > 1 else ""),
                    "batch_per_client": a.batch, "clients": world, "sync_every_n_batch": a.sync_every,
-                   "secure_aggregation": bool(a.secure_aggregation)},
+                   "secure_aggregation": bool(a.secure_aggregation), "dp_sgd": bool(a.dp)},
         "images_per_sec_per_client": round(total_ips / world, 1),
         "step_tflops": round(GFLOP_PER_IMAGE * 1e9 * a.batch / (dt / a.steps) / 1e12, 2),
         "step_mfma_frac": round(GFLOP_PER_IMAGE * 1e9 * a.batch / (dt / a.steps) / 1e12 / peak, 4),

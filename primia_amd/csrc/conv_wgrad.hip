@@ -110,16 +110,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             u32x4 v = {0, 0, 0, 0};
             if (STEM) {
                 // "channel" axis = 32 elements = 8 consecutive input pixels x 4 channels.
+                // The 8th pixel of a row group (s == 7) belongs to no kernel tap: it is loaded as zero so
+                // the padded accumulator slots stay exactly 0 (per-sample norms sum the whole slab).
                 const int e0 = b_chunk[j] * CH;
-                const int ws = b_wo[j] * 2 - 3 + (e0 >> 2);
+                const int sx = e0 >> 2;
+                const int ws = b_wo[j] * 2 - 3 + sx;
                 const bool rowok = ok && hs >= 0 && hs < p.H;
                 const long base = (((long)b_n[j] * p.H + hs) * p.W + ws) * 4;
                 if (ES == 4) {
-                    if (rowok && ws >= 0 && ws < p.W) v = *(const u32x4*)(x + base);
+                    if (rowok && sx < p.S && ws >= 0 && ws < p.W) v = *(const u32x4*)(x + base);
                 } else {
                     u32x2 a = {0, 0}, b = {0, 0};
-                    if (rowok && ws >= 0 && ws < p.W) a = *(const u32x2*)(x + base);
-                    if (rowok && ws + 1 >= 0 && ws + 1 < p.W) b = *(const u32x2*)(x + base + 4);
+                    if (rowok && sx < p.S && ws >= 0 && ws < p.W) a = *(const u32x2*)(x + base);
+                    if (rowok && sx + 1 < p.S && ws + 1 >= 0 && ws + 1 < p.W) b = *(const u32x2*)(x + base + 4);
                     v = u32x4{a[0], a[1], b[0], b[1]};
                 }
             } else {

@@ -340,9 +340,15 @@ class ResNet18Engine:
     # ------------------------------------------------------------------------------------------
     # loss + backward
     # ------------------------------------------------------------------------------------------
+    dp_params = None  # e.g. {"max_grad_norm": 1.0, "noise_multiplier": 1.3}: loss_backward() becomes DP-SGD
+
     def loss_backward(self, target, soft=False):
         """Cross entropy (hard int64 labels, or soft [N, classes] fp32 targets as in
         Cross_entropy_one_hot) + full backward into `grads`.  Returns the device loss scalar."""
+        if self.dp_params is not None:
+            if soft:
+                raise _lib.PrimiaError("DP-SGD path takes hard labels")
+            return self.dp_loss_backward(target, **self.dp_params)
         if soft:
             call("primia_xent_soft", self.logits, target, self.class_weight, self.loss, self.dlogits, self.N,
                  self.spec.num_classes)
@@ -451,10 +457,18 @@ class ResNet18Engine:
             # fc: g_W[n] = dlogits[n]^T feat[n], g_b[n] = dlogits[n]
             ps_fc = torch.empty(N, nc * 512 + nc, dtype=torch.float32, device=dev)
             call("primia_fc_persample_grads", self.feat, self.dlogits, ps_fc, N, 512, nc)
+            trace = getattr(self, "dp_trace", None)  # optional {name: cumulative sq norms} for debugging
+
+            def mark(name):
+                if trace is not None:
+                    trace[name] = sq.clone()
+
             call("primia_persample_sqnorm", ps_fc, N, nc * 512 + nc, sq)
+            mark("fc")
             for b, (psg, psb) in self.ps_affine.items():
                 call("primia_persample_sqnorm", psg, N, psg.shape[1], sq)
                 call("primia_persample_sqnorm", psb, N, psb.shape[1], sq)
+                mark(b)
             need = max(self.convs[n].wfwd_n for n, _, _ in self.dp["wgrads"]) * N
             if getattr(self, "_ps_scratch", None) is None or self._ps_scratch.numel() < need:
                 self._ps_scratch = torch.empty(need, dtype=torch.float32, device=dev)
@@ -464,6 +478,7 @@ class ResNet18Engine:
                 slab.zero_()
                 call("primia_conv2d_wgrad_persample", c.desc, x, dy, slab, self.dt)
                 call("primia_persample_sqnorm", slab, N, c.wfwd_n, sq)  # zero padding adds nothing
+                mark(name)
             clip = torch.empty(N, dtype=torch.float32, device=dev)
             call("primia_dp_clip_factors", sq, clip, N, float(max_grad_norm))
             # clipped sums
@@ -475,7 +490,8 @@ class ResNet18Engine:
             for b, (psg, psb) in self.ps_affine.items():
                 call("primia_weighted_colsum", psg, clip, self.gviews[b + ".weight"], N, psg.shape[1])
                 call("primia_weighted_colsum", psb, clip, self.gviews[b + ".bias"], N, psb.shape[1])
-            call("primia_weighted_colsum", ps_fc, clip, self.gviews["fc.weight"].view(-1), N, nc * 512)
+            call("primia_weighted_colsum", ps_fc[:, :nc * 512].contiguous(), clip, self.gviews["fc.weight"].view(-1), N,
+                 nc * 512)
             call("primia_weighted_colsum", ps_fc[:, nc * 512:].contiguous(), clip, self.gviews["fc.bias"], N, nc)
         finally:
             self.dp = None

@@ -75,8 +75,13 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
     n_batches = int(os.environ.get("PRIMIA_SYNTHETIC_BATCHES", 8))
 
     def make_engine():
-        return ResNet18Engine(args.batch_size, num_classes, 3 if args.pretrained else 1, size, args.pooling_type,
-                              dtype=dtype, device=device)
+        # differentially_private = yes (train.py:304-334 of the reference): BatchNorm is rejected by the
+        # PrivacyEngine, so the network is built with GroupNorm and every step clips / noises per sample
+        eng = ResNet18Engine(args.batch_size, num_classes, 3 if args.pretrained else 1, size, args.pooling_type,
+                             dtype=dtype, device=device, norm="group" if args.differentially_private else "batch")
+        if args.differentially_private:
+            eng.dp_params = {"max_grad_norm": 1.0, "noise_multiplier": 1.3}
+        return eng
 
     local = make_engine()
     local.init_weights()
