@@ -132,11 +132,16 @@ struct GemmPair {
 };
 
 __global__ __launch_bounds__(256) void ring_gemm_kernel(GemmPair p1, GemmPair p2, const u64* __restrict__ C0,
-                                                        u64* __restrict__ C, int M, int K, int N) {
+                                                        u64* __restrict__ C, int M, int K, int N, int ksplit) {
     __shared__ u64 sa[16][64 + 1];
     __shared__ u64 sb[16][64];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
     const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    // split-K: slice z covers k in [kb, ke); slices are combined with 64-bit atomics (ring addition is
+    // associative, so the result is bit-identical whatever the order)
+    const int kchunk = ((K + ksplit - 1) / ksplit + 15) / 16 * 16;
+    const int kb = blockIdx.z * kchunk;
+    const int ke = kb + kchunk < K ? kb + kchunk : K;
     u64 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -146,17 +151,17 @@ __global__ __launch_bounds__(256) void ring_gemm_kernel(GemmPair p1, GemmPair p2
         const u64* __restrict__ A = pair == 0 ? p1.A : p2.A;
         const u64* __restrict__ Bm = pair == 0 ? p1.B : p2.B;
         if (!A) continue;
-        for (int k0 = 0; k0 < K; k0 += 16) {
+        for (int k0 = kb; k0 < ke; k0 += 16) {
             // A tile: 64 rows x 16 k (transposed into sa[k][m]); B tile: 16 k x 64 cols
 #pragma unroll
             for (int l = 0; l < 4; ++l) {
                 const int idx = threadIdx.x + 256 * l;
                 const int am = idx >> 4, ak = idx & 15;
                 const int gm = m0 + am, gk = k0 + ak;
-                sa[ak][am] = (gm < M && gk < K) ? A[(long)gm * K + gk] : (u64)0;
+                sa[ak][am] = (gm < M && gk < ke) ? A[(long)gm * K + gk] : (u64)0;
                 const int bk = idx >> 6, bn = idx & 63;
                 const int gn = n0 + bn, gk2 = k0 + bk;
-                sb[bk][bn] = (gn < N && gk2 < K) ? Bm[(long)gk2 * N + gn] : (u64)0;
+                sb[bk][bn] = (gn < N && gk2 < ke) ? Bm[(long)gk2 * N + gn] : (u64)0;
             }
             __syncthreads();
 #pragma unroll
@@ -183,7 +188,10 @@ __global__ __launch_bounds__(256) void ring_gemm_kernel(GemmPair p1, GemmPair p2
             const int gn = n0 + tx + 16 * j;
             if (gn >= N) continue;
             const long o = (long)gm * N + gn;
-            C[o] = acc[i][j] + (C0 ? C0[o] : (u64)0);
+            if (ksplit == 1)
+                C[o] = acc[i][j] + (C0 ? C0[o] : (u64)0);
+            else
+                atomicAdd(C + o, acc[i][j]);  // C was initialised with C0 (or zero) by the launcher
         }
     }
 }
@@ -194,8 +202,26 @@ static inline int ew_blocks(long n) {
 }
 
 static int launch_gemm(GemmPair p1, GemmPair p2, const u64* C0, u64* C, int M, int K, int N, hipStream_t st) {
-    dim3 grid((N + 63) / 64, (M + 63) / 64);
-    ring_gemm_kernel<<<grid, 256, 0, st>>>(p1, p2, C0, C, M, K, N);
+    const int tiles = ((N + 63) / 64) * ((M + 63) / 64);
+    // few output tiles (the N = 1 image has M = 49..784 rows in layer3/4): split K to fill the chip
+    int ksplit = 1;
+    if (tiles < 256) {
+        ksplit = (512 + tiles - 1) / tiles;
+        const int kmax = (K + 63) / 64;  // >= 64 k per slice
+        if (ksplit > kmax) ksplit = kmax;
+        if (ksplit < 1) ksplit = 1;
+    }
+    if (ksplit > 1) {
+        const size_t bytes = (size_t)M * N * sizeof(u64);
+        hipError_t e = hipSuccess;
+        if (!C0)
+            e = hipMemsetAsync(C, 0, bytes, st);
+        else if (C0 != C)
+            e = hipMemcpyAsync(C, C0, bytes, hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) return PRIMIA_ERR_LAUNCH;
+    }
+    dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
+    ring_gemm_kernel<<<grid, 256, 0, st>>>(p1, p2, C0, C, M, K, N, ksplit);
     return launch_status();
 }
 
