@@ -12,7 +12,10 @@
  *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
  *     buffer, workspaces are passed explicitly, there is no hidden allocation or global state;
  *   - `stream` is a hipStream_t (0 = default stream); all work is enqueued asynchronously;
- *   - return value: PRIMIA_OK (0) or a negative PRIMIA_ERR_* code;
+ *   - return value: PRIMIA_OK (0) or a negative PRIMIA_ERR_* code; bad arguments are reported,
+ *     never dereferenced;
+ *   - element-wise entry points taking a count `n` accept n == 0 as a successful no-op (pointers
+ *     may then be null), like the torch ops they replace do on empty tensors;
  *   - float tensors are NHWC ("channels last") in `dtype` PRIMIA_F32 or PRIMIA_BF16; weights
  *     handed over at the boundary keep the reference's OIHW / [out,in] fp32 layout;
  *   - ring tensors are int64 two's complement, arithmetic mod 2^64.

@@ -344,6 +344,7 @@ extern "C" {
 
 int primia_fss_mask(const int64_t* x1, const int64_t* x2, const uint64_t* alpha_share, int64_t* r, int64_t n,
                     primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(x1 && x2 && alpha_share && r && n >= 0);
     if (n == 0) return PRIMIA_OK;
     long b = (n + 255) / 256;
@@ -353,6 +354,7 @@ int primia_fss_mask(const int64_t* x1, const int64_t* x2, const uint64_t* alpha_
 }
 
 int primia_fss_open(const int64_t* r0, const int64_t* r1, uint32_t* x, int64_t n, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(r0 && r1 && x && n >= 0);
     if (n == 0) return PRIMIA_OK;
     long b = (n + 255) / 256;
@@ -362,6 +364,7 @@ int primia_fss_open(const int64_t* r0, const int64_t* r1, uint32_t* x, int64_t n
 
 int primia_dif_eval(int b, const uint32_t* x, const uint64_t* s0, const uint8_t* cw_bits, const uint64_t* cw_sigma,
                     const uint64_t* cw_s, const int32_t* cw_leaf, int64_t* out, int64_t n, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE((b == 0 || b == 1) && x && s0 && cw_bits && cw_sigma && cw_s && cw_leaf && out && n >= 0);
     if (n == 0) return PRIMIA_OK;
     dif_eval_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)st>>>(b, x, (const u64*)s0, cw_bits, (const u64*)cw_sigma,
@@ -371,6 +374,7 @@ int primia_dif_eval(int b, const uint32_t* x, const uint64_t* s0, const uint8_t*
 
 int primia_dpf_eval(int b, const uint32_t* x, const uint64_t* s0, const uint8_t* cw_bits, const uint64_t* cw_s,
                     const int64_t* cw_n, int64_t* out, int64_t n, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE((b == 0 || b == 1) && x && s0 && cw_bits && cw_s && cw_n && out && n >= 0);
     if (n == 0) return PRIMIA_OK;
     dpf_eval_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)st>>>(b, x, (const u64*)s0, cw_bits, (const u64*)cw_s,
@@ -380,6 +384,7 @@ int primia_dpf_eval(int b, const uint32_t* x, const uint64_t* s0, const uint8_t*
 
 int primia_dif_keygen(const uint64_t* alpha, const uint64_t* s0_pair, uint8_t* cw_bits, uint64_t* cw_sigma,
                       uint64_t* cw_s, int32_t* cw_leaf, int64_t n, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(alpha && s0_pair && cw_bits && cw_sigma && cw_s && cw_leaf && n >= 0);
     if (n == 0) return PRIMIA_OK;
     dif_keygen_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)st>>>((const u64*)alpha, (const u64*)s0_pair, cw_bits,
@@ -389,6 +394,7 @@ int primia_dif_keygen(const uint64_t* alpha, const uint64_t* s0_pair, uint8_t* c
 
 int primia_dpf_keygen(const uint64_t* alpha, const uint64_t* s0_pair, uint8_t* cw_bits, uint64_t* cw_s,
                       int64_t* cw_n, int64_t n, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(alpha && s0_pair && cw_bits && cw_s && cw_n && n >= 0);
     if (n == 0) return PRIMIA_OK;
     dpf_keygen_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)st>>>((const u64*)alpha, (const u64*)s0_pair, cw_bits,

@@ -410,6 +410,7 @@ int primia_fc_persample_grads(const float* x, const float* dy, float* ps, int N,
 }
 
 int primia_dp_add_noise(float* g, const float* noise, int64_t n, float sigma, float inv_batch, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(g && noise && n >= 0);
     if (n == 0) return PRIMIA_OK;
     long b = (n + 255) / 256;

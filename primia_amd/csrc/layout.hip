@@ -200,6 +200,7 @@ int primia_nhwc_to_nchw(const void* src, float* dst, int N, int C, int H, int W,
 }
 
 int primia_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(src && dst && n >= 0);
     if (n == 0) return PRIMIA_OK;
     int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
@@ -214,6 +215,7 @@ int primia_cast_from_f32(const float* src, void* dst, int64_t n, int dtype, prim
 }
 
 int primia_cast_to_f32(const void* src, float* dst, int64_t n, int dtype, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(src && dst && n >= 0);
     if (n == 0) return PRIMIA_OK;
     int blocks = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);

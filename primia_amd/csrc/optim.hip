@@ -127,6 +127,7 @@ extern "C" {
 
 int primia_sgd_step(float* p, const float* g, int64_t n, float lr, float weight_decay,
                     primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(p && g && n >= 0 && aligned16(p) && aligned16(g));
     if (n == 0) return PRIMIA_OK;
     SgdFn f{p, g, lr, weight_decay};
@@ -137,6 +138,7 @@ int primia_sgd_step(float* p, const float* g, int64_t n, float lr, float weight_
 int primia_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n,
                      float lr, float beta1, float beta2, float eps, float weight_decay,
                      int64_t step, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(p && g && exp_avg && exp_avg_sq && n >= 0 && step >= 1);
     PRIMIA_REQUIRE(aligned16(p) && aligned16(g) && aligned16(exp_avg) && aligned16(exp_avg_sq));
     if (n == 0) return PRIMIA_OK;
@@ -149,6 +151,7 @@ int primia_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq
 }
 
 int primia_scale(float* x, int64_t n, float a, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(x && n >= 0 && aligned16(x));
     if (n == 0) return PRIMIA_OK;
     ScaleFn f{x, a};
@@ -157,6 +160,7 @@ int primia_scale(float* x, int64_t n, float a, primia_stream_t stream) {
 }
 
 int primia_axpy(float* y, const float* x, int64_t n, float a, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(y && x && n >= 0 && aligned16(y) && aligned16(x));
     if (n == 0) return PRIMIA_OK;
     AxpyFn f{y, x, a};
@@ -165,6 +169,7 @@ int primia_axpy(float* y, const float* x, int64_t n, float a, primia_stream_t st
 }
 
 int primia_divide(float* x, int64_t n, float d, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(x && n >= 0 && aligned16(x) && d != 0.f);
     if (n == 0) return PRIMIA_OK;
     DivFn f{x, d};
@@ -173,12 +178,14 @@ int primia_divide(float* x, int64_t n, float d, primia_stream_t stream) {
 }
 
 int primia_fx_encode(const float* x, int64_t* q, int64_t n, float scale, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(x && q && n >= 0);
     if (n == 0) return PRIMIA_OK;
     fx_encode_kernel<<<flat_blocks(n * 4), 256, 0, (hipStream_t)stream>>>(x, q, n, scale);
     return launch_status();
 }
 int primia_fx_decode(const int64_t* q, float* x, int64_t n, float scale, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(x && q && n >= 0);
     if (n == 0) return PRIMIA_OK;
     fx_decode_kernel<<<flat_blocks(n * 4), 256, 0, (hipStream_t)stream>>>(q, x, n, scale);

@@ -233,6 +233,7 @@ extern "C" {
 
 #define RING_EW(NAME, OP)                                                                                   \
     int NAME(const int64_t* a, const int64_t* b, int64_t* out, int64_t n, int64_t nb, primia_stream_t st) { \
+        if (n == 0) return PRIMIA_OK; /* empty input: no-op */                                             \
         PRIMIA_REQUIRE(a && b && out && n >= 0 && nb > 0 && nb <= n && (n == 0 || n % nb == 0));           \
         if (n == 0) return PRIMIA_OK;                                                                       \
         ring_ew_kernel<OP><<<ew_blocks(n), 256, 0, (hipStream_t)st>>>((const u64*)a, (const u64*)b,         \
@@ -244,6 +245,7 @@ RING_EW(primia_ring_sub, 1)
 RING_EW(primia_ring_mul, 2)
 
 int primia_ring_scale(const int64_t* a, int64_t k, int64_t* out, int64_t n, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(a && out && n >= 0);
     if (n == 0) return PRIMIA_OK;
     ring_scale_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)st>>>((const u64*)a, (u64)k, (u64*)out, n);
@@ -251,6 +253,7 @@ int primia_ring_scale(const int64_t* a, int64_t k, int64_t* out, int64_t n, prim
 }
 
 int primia_trunc_div(const int64_t* x, int64_t d, int64_t* out, int64_t n, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE(x && out && n >= 0 && d > 0);
     if (n == 0) return PRIMIA_OK;
     trunc_div_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)st>>>(x, d, out, n);
@@ -312,6 +315,7 @@ int primia_pool_unroll_syft(const int64_t* x, int64_t* out, int B, int C, int H,
 int primia_beaver_combine_mul(int j, const int64_t* delta, const int64_t* eps, const int64_t* a,
                               const int64_t* b, const int64_t* c, int64_t* z, int64_t n, int64_t nb,
                               primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;  // empty input: no-op, pointers may be null
     PRIMIA_REQUIRE((j == 0 || j == 1) && delta && eps && a && b && c && z && n >= 0 && nb > 0 && nb <= n);
     PRIMIA_REQUIRE(n == 0 || n % nb == 0);
     if (n == 0) return PRIMIA_OK;
