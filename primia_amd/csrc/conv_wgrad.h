@@ -1,0 +1,27 @@
+// Launch parameters shared by the weight-gradient kernels (conv_wgrad.hip, conv_wgrad_patch.hip).
+#pragma once
+#include "conv_common.h"
+
+namespace primia {
+
+struct WgradParams {
+    const void* x;
+    const void* dy;
+    float* dw;
+    int N, H, W, C, K, R, S, stride, pad, Ho, Wo;
+    int klen;
+    long Md;           // N*Ho*Wo
+    int ntaps;         // R*S, or R for the stem
+    int nkt, nct;      // channel tiles
+    int nsplit;        // pixel splits
+    long pix_per_split;
+    long split_stride;  // 0: every split accumulates into dw; else split i writes dw + i*split_stride
+                        // (per-sample gradients for DP-SGD: one split per image, stride K*klen)
+    int persample;
+};
+
+int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st);
+// halo-patch kernel (3x3, stride 1, bf16); returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered
+int wgrad_patch_dispatch(const WgradParams& p, hipStream_t st);
+
+}  // namespace primia

@@ -14,25 +14,10 @@
 // atomics into a zeroed [K][klen] buffer (fwd weight layout, see conv_common.h).
 #include <stdlib.h>
 
-#include "conv_common.h"
+#include "conv_wgrad.h"
 
 namespace primia {
 
-struct WgradParams {
-    const void* x;
-    const void* dy;
-    float* dw;
-    int N, H, W, C, K, R, S, stride, pad, Ho, Wo;
-    int klen;
-    long Md;           // N*Ho*Wo
-    int ntaps;         // R*S, or R for the stem
-    int nkt, nct;      // channel tiles
-    int nsplit;        // pixel splits
-    long pix_per_split;
-    long split_stride;  // 0: every split accumulates into dw; else split i writes dw + i*split_stride
-                        // (per-sample gradients for DP-SGD: one split per image, stride K*klen)
-    int persample;
-};
 
 template <typename T, int BMK, int BNC, bool STEM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
@@ -274,9 +259,6 @@ static int launch_wgrad(WgradParams p, hipStream_t st) {
 
 }  // namespace primia
 
-namespace primia {
-int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st);
-}
 using namespace primia;
 
 static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc, int persample,
@@ -312,10 +294,16 @@ static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const voi
         if (g.K % 128 == 0 && g.C % 128 == 0) return launch_wgrad<float, 128, 128, false>(p, st);
         return launch_wgrad<float, 64, 64, false>(p, st);
     } else if (dtype == PRIMIA_BF16) {
-        // Measured per layer (profiles/r01_conv_layers_*): the LDS-DMA kernel wins on the wide, few-pixel
-        // layers (layer3/4); the register-staged kernel on layer1/2.  PRIMIA_WGRAD=old|dma forces one.
+        // Measured per layer (profiles/r01_conv_layers_*): the halo-patch kernel (conv_wgrad_patch.hip) wins
+        // on every 3x3 / stride-1 layer; of the per-tap kernels the LDS-DMA one wins on the wide, few-pixel
+        // layers (layer3/4) and the register-staged one elsewhere.  PRIMIA_WGRAD=old|dma|tap forces one
+        // (tap = per-tap kernels with the default old/dma choice).
         static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
         const bool dma = force == 'd' || (force != 'o' && (g.C >= 256 || (g.K >= 256 && g.C >= 128)));
+        if (!force && !g.stem) {
+            const int rc = wgrad_patch_dispatch(p, st);
+            if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+        }
         if (!g.stem && dma) return wgrad_dma_dispatch(p, st);
         if (g.stem) return launch_wgrad<bf16, 64, 32, true>(p, st);
         if (g.K % 128 == 0 && g.C % 128 == 0) return launch_wgrad<bf16, 128, 128, false>(p, st);

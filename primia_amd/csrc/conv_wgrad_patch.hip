@@ -1,0 +1,319 @@
+// Weight gradient of the 3x3 / stride-1 convolutions as a halo-patch kernel (bf16, gfx950).
+//
+//   dw[k, (r,s,c)] += sum_m dy[m, k] * x[pix(m, r, s), c]
+//
+// The per-tap kernels of conv_wgrad.hip stage a dy tile and an x tile per (tap, pixel step): every
+// activation and every output gradient travels L2 -> LDS nine times.  Here one block owns a
+// [64 out-chan] x [9 taps x 64 in-chan] slab of dw and walks 2-D sub-patches of 32 output pixels
+// (SH x SW = 4x8 or 2x16).  Per sub-patch it stages
+//     dy : 32 pixels x 64 channels                       (once, shared by the 9 taps)
+//     x  : (SH+2) x (SW+2) halo pixels x 64 channels     (once, shared by the 9 taps)
+// and the nine taps read the SAME LDS halo at shifted pixel slots.  The block has 8 waves: wave
+// (kh, cq) owns out-channels 32*kh..+31 and in-channels 16*cq..+15 of all nine taps (72 accumulator
+// registers), so per k-step (32 pixels) it issues 2 dy-fragment + 9 x-fragment transposing reads
+// (ds_read_b64_tr_b16 pairs) for 18 MFMAs; L2 -> LDS traffic drops from 9x to ~1.9x of the tensors.
+//
+// Staging is LDS-DMA (global_load_lds_dwordx4): one wave instruction fills 8 pixel slots of
+// 128 B.  The 32-B channel groups of a slot are XOR-permuted on the SOURCE side with a key chosen
+// so that the 8 slots x 32 B touched by one LDS cycle of a transposing read cover all 64 banks:
+//     dy slots (linear k)          key = bit1(slot) | bit3(slot) << 1
+//     x halo, SW = 8 (row 12 slots) key = (slot >> 1) & 3
+//     x halo, SW = 16 (row 18 slots) key = bit1(slot) | bit3(slot) << 1
+// Out-of-image halo pixels (the conv's zero padding), ragged patch edges and the tail of a block's
+// range are loaded from a zero page.
+#include <stdlib.h>
+
+#include "conv_wgrad.h"
+
+namespace primia {
+
+__device__ __attribute__((aligned(16))) const unsigned char kWpZeroPage[16] = {0};
+
+// LDS-DMA issued as inline asm: the compiler's waitcnt pass does not see an LDS write, so it does not
+// drain vmcnt before every LDS read of the compute phase (it does for the builtin); the kernel orders
+// DMA and reads itself with counted s_waitcnt vmcnt + s_barrier.  M0 carries the wave-uniform LDS
+// base of the 1-KiB destination; nothing else in this kernel uses M0.
+__device__ __forceinline__ void dma16(const void* g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+}
+
+__device__ __forceinline__ int key_lin(int slot) { return ((slot >> 1) & 1) | (((slot >> 3) & 1) << 1); }
+
+template <int SW>
+__device__ __forceinline__ int key_halo(int slot) {
+    return SW == 8 ? ((slot >> 1) & 3) : key_lin(slot);
+}
+
+struct PatchParams {
+    const bf16* x;
+    const bf16* dy;
+    float* dw;
+    int H, W, C, K, klen;     // stride 1, pad 1: Ho == H, Wo == W
+    int nct, nkt;
+    int PH, PW, PPI;          // sub-patches per image column / row / image
+    int total;                // sub-patches overall
+    int per_block;            // sub-patches per block (even)
+    long split_stride;
+    int debug_skip_epilogue;  // timing experiments only (PRIMIA_WGP_NOEPI=1)
+};
+
+template <int SW, int STAGES>
+__global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(PatchParams p) {
+    constexpr int SH = 32 / SW;
+    constexpr int HR = SH + 2;                  // halo rows
+    constexpr int HS = SW == 8 ? 12 : 18;       // halo row stride in pixel slots
+    constexpr int XSLOTS = HR * HS;             // 72 for both shapes = 9 DMA instructions
+    static_assert(XSLOTS == 72, "halo must fill whole DMA instructions");
+    constexpr int X_BYTES = XSLOTS * 128;       // one sub-patch halo
+    constexpr int DY_BYTES = 64 * 128;          // two sub-patches of dy
+    constexpr int STAGE = 2 * X_BYTES + DY_BYTES;
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay SALU
+    const int kh = wave >> 2, wid = wave & 3;                   // out-chan half, in-chan quarter
+
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ct = bid % p.nct; bid /= p.nct;
+    const int kt = bid % p.nkt;
+    const int split = bid / p.nkt;
+    const int t0 = split * p.per_block;
+    int t1 = t0 + p.per_block;
+    if (t1 > p.total) t1 = p.total;
+    const int nstages = (t1 - t0 + 1) >> 1;
+
+    const bf16* __restrict__ x = p.x + ct * 64;
+    const bf16* __restrict__ dy = p.dy + kt * 64;
+
+    // ---- staging: 26 DMA instructions per stage (2 x 9 halo + 8 dy), round-robin over the 8 waves ----
+    // Everything that does not depend on the sub-patch is computed once: per DMA instruction `it` of this
+    // wave the lane's pixel offset inside the sub-patch (drow, dcol), its element offset `rel` and the
+    // swizzled source channel.  Per stage only the two sub-patch origins change (scalar).
+    int drow[4], dcol[4], rel[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = wave + 8 * it;
+        const int sl = lane & 7;
+        if (idx < 18) {
+            const int j = idx >= 9 ? idx - 9 : idx;
+            const int slot = j * 8 + (lane >> 3);
+            const int hy = slot / HS, hx = slot - hy * HS;
+            const int chunk = ((((sl >> 1) ^ key_halo<SW>(slot)) << 1) | (sl & 1));
+            drow[it] = hy - 1;
+            dcol[it] = hx < SW + 2 ? hx - 1 : (1 << 20);      // pad slots of the halo row: never valid
+            rel[it] = ((hy - 1) * p.W + (hx - 1)) * p.C + chunk * 8;
+        } else {
+            const int slot = (idx - 18) * 8 + (lane >> 3);
+            const int k = slot & 31;
+            const int py = SW == 8 ? (k >> 3) : (k >> 4), px = SW == 8 ? (k & 7) : (k & 15);
+            const int chunk = ((((sl >> 1) ^ key_lin(slot)) << 1) | (sl & 1));
+            drow[it] = py;
+            dcol[it] = px;
+            rel[it] = (py * p.W + px) * p.K + chunk * 8;
+        }
+    }
+    // running origin of the next sub-patch to stage (stages are issued strictly in order)
+    int sn, sph, spw;
+    {
+        sn = t0 / p.PPI;
+        const int rem = t0 - sn * p.PPI;
+        sph = rem / p.PW;
+        spw = rem - sph * p.PW;
+    }
+    int st = t0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto stage = [&](int buf) {
+        int rb[2], cb[2], pixbase[2];
+        bool live[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            live[q] = st < t1;
+            rb[q] = sph * SH;
+            cb[q] = spw * SW;
+            pixbase[q] = (sn * p.H + rb[q]) * p.W + cb[q];
+            ++st;
+            if (++spw == p.PW) {
+                spw = 0;
+                if (++sph == p.PH) {
+                    sph = 0;
+                    ++sn;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = wave + 8 * it;      // wave-uniform
+            if (idx >= 26) break;
+            const bool isx = idx < 18;
+            const int q = isx ? (idx >= 9) : (idx >= 22);
+            const int dst = isx ? q * X_BYTES + (idx - 9 * q) * 1024 : 2 * X_BYTES + (idx - 18) * 1024;
+            const int row = rb[q] + drow[it], col = cb[q] + dcol[it];
+            const bool ok = live[q] && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
+            const bf16* src = isx ? x : dy;
+            const int elem = pixbase[q] * (isx ? p.C : p.K) + rel[it];
+            const bf16* g = ok ? src + elem : (const bf16*)kWpZeroPage;
+            dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + dst));
+        }
+    };
+
+    f32x4 acc[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- per-lane LDS byte offsets of the transposing reads (constant over the whole kernel) --------
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tp = fr >> 2, tc8 = (fr & 3) * 8;
+    // dy: slot = 8*fg + tp (+4); channel group i
+    int offa[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) offa[h] = 8 * fg + tp + 4 * h;   // slot index; swizzle applied per fragment
+    // x: k = 8*fg + tp (+4) -> (py, px); slot = (py + r)*HS + px + s; this wave's channel group = wid
+    int offx[9][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int r = t / 3, s = t - 3 * r;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int k = 8 * fg + tp + 4 * h;
+            const int py = SW == 8 ? (k >> 3) : (k >> 4), px = SW == 8 ? (k & 7) : (k & 15);
+            const int slot = (py + r) * HS + px + s;
+            offx[t][h] = slot * 128 + ((wid ^ key_halo<SW>(slot)) << 5) + tc8;
+        }
+    }
+
+    // One stage = two k-steps.  All 44 fragment reads of the stage are issued up front (the LDS queue
+    // throttles itself at 15 outstanding), then the 36 MFMAs consume them in issue order: the LDS latency
+    // is paid once per stage instead of once per tap.
+    auto compute = [&](int buf) {
+        const char* sb = smem + buf * STAGE;
+        bf16x8_t a[2][2], b[2][9];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const char* lx = sb + q * X_BYTES;
+            const char* la = sb + 2 * X_BYTES + q * 32 * 128;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                // key_lin(slot) is the same for slot and slot + 32*q (bits 1 and 3 only)
+                const int cg = 2 * kh + i;  // 16-channel group of dy
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds4_t)(la + offa[0] * 128 + ((cg ^ key_lin(offa[0])) << 5) + tc8));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds4_t)(la + offa[1] * 128 + ((cg ^ key_lin(offa[1])) << 5) + tc8));
+                a[q][i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(lx + offx[t][0]));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(lx + offx[t][1]));
+                b[q][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q][i], b[q][t], acc[t][i], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // STAGES-deep LDS ring, one raw barrier per stage; a counted vmcnt keeps the newer stage's DMA in
+    // flight across it (waves 0,1 issue 4 DMA instructions per stage, waves 2..7 issue 3).
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nstages) stage(s);
+    int cur = 0, nxt = STAGES - 1;
+    for (int s = 0; s < nstages; ++s) {
+        int ahead = nstages - 1 - s;            // newer stages that may stay in flight
+        if (ahead > STAGES - 2) ahead = STAGES - 2;
+        if (ahead >= 2) {
+            if (wave < 2)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (ahead == 1) {
+            if (wave < 2)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // stage s visible to all waves; buffer `nxt` no longer read
+        if (s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2)) stage(nxt);
+        if (!(p.debug_skip_epilogue & 4)) compute(cur);
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+    }
+
+    // ---- accumulate: lane holds out-chan rows 32*kh + 16*i + fg*4 + j, in-chan column 16*wid + fr ----
+    if ((p.debug_skip_epilogue & 1) && acc[0][0][0] != 12345.f) return;
+    float* out = p.dw + (long)split * p.split_stride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = kt * 64 + 32 * kh + 16 * i + fg * 4 + j;
+                const int e = t * p.C + ct * 64 + 16 * wid + fr;
+                unsafeAtomicAdd(out + (long)k * p.klen + e, acc[t][i][j]);
+            }
+}
+
+template <int SW>
+static int launch_patch(const WgradParams& w, hipStream_t st) {
+    constexpr int SH = 32 / SW;
+    PatchParams p;
+    p.x = (const bf16*)w.x; p.dy = (const bf16*)w.dy; p.dw = w.dw;
+    p.H = w.H; p.W = w.W; p.C = w.C; p.K = w.K; p.klen = w.klen;
+    p.nct = w.C / 64; p.nkt = w.K / 64;
+    p.PH = (w.H + SH - 1) / SH; p.PW = (w.W + SW - 1) / SW; p.PPI = p.PH * p.PW;
+    p.total = w.N * p.PPI;
+    const int combos = p.nct * p.nkt;
+    // one 8-wave block per CU
+    static const int target_blocks = getenv("PRIMIA_WGP_BLOCKS") ? atoi(getenv("PRIMIA_WGP_BLOCKS")) : 0;
+    const int target = target_blocks ? target_blocks : 256;
+    long want = (target + combos - 1) / combos;
+    if (want < 1) want = 1;
+    long per = (p.total + want - 1) / want;
+    per = (per + 1) & ~1L;
+    if (per < 2) per = 2;
+    if (w.persample) per = p.PPI;  // one split per image
+    p.per_block = (int)per;
+    const long nsplit = (p.total + per - 1) / per;
+    p.split_stride = w.persample ? (long)w.K * w.klen : 0;
+    static const int noepi = getenv("PRIMIA_WGP_NOEPI") ? atoi(getenv("PRIMIA_WGP_NOEPI")) : 0;
+    p.debug_skip_epilogue = noepi;
+    constexpr int XS = (SH + 2) * (SW == 8 ? 12 : 18);
+    static const int stages = getenv("PRIMIA_WGP_STAGES") ? atoi(getenv("PRIMIA_WGP_STAGES")) : 3;
+    const size_t lds = (size_t)(stages == 4 ? 4 : 3) * (2 * XS * 128 + 64 * 128);
+    auto kern = stages == 4 ? conv_wgrad_patch_kernel<SW, 4> : conv_wgrad_patch_kernel<SW, 3>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    kern<<<(unsigned)(combos * nsplit), 512, lds, st>>>(p);
+    return launch_status();
+}
+
+int wgrad_patch_dispatch(const WgradParams& w, hipStream_t st) {
+    if (w.R != 3 || w.S != 3 || w.stride != 1 || w.pad != 1 || w.C % 64 || w.K % 64) return PRIMIA_ERR_UNSUPPORTED;
+    if ((long)w.N * w.H * w.W * (w.C > w.K ? w.C : w.K) >= (1L << 31)) return PRIMIA_ERR_UNSUPPORTED;
+    // 16-wide sub-patches when they waste fewer slots on the ragged right edge (W = 14: 16 vs 2 x 8)
+    const int waste8 = (w.W + 7) / 8 * 8 - w.W, waste16 = (w.W + 15) / 16 * 16 - w.W;
+    const int rows8 = (w.H + 3) / 4 * 4 - w.H, rows16 = (w.H + 1) / 2 * 2 - w.H;
+    const long slots8 = (long)(w.W + waste8) * (w.H + rows8), slots16 = (long)(w.W + waste16) * (w.H + rows16);
+    static const char force = getenv("PRIMIA_WGP_SW") ? getenv("PRIMIA_WGP_SW")[0] : 0;  // '8' | '1'(6)
+    const bool wide = force ? force == '1' : slots16 < slots8;
+    return wide ? launch_patch<16>(w, st) : launch_patch<8>(w, st);
+}
+
+}  // namespace primia

@@ -59,6 +59,9 @@ CONV_CASES = [
     (4, 14, 256, 512, 1, 2, 0),   # layer4.0.downsample
     (4, 28, 128, 256, 3, 2, 1),   # layer3.0.conv1
     (4, 7, 512, 512, 3, 1, 1),    # layer4.1
+    (3, 14, 256, 256, 3, 1, 1),   # layer3.1 (16-wide sub-patches in the halo-patch wgrad)
+    (2, 28, 128, 128, 3, 1, 1),   # layer2.1 (ragged right edge: 28 = 3.5 x 8)
+    (1, 56, 64, 64, 3, 1, 1),     # layer1 (exact 4x8 tiling)
 ]
 
 
