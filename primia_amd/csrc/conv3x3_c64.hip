@@ -1,0 +1,292 @@
+// 3x3 / stride-1 / pad-1 convolution with 64 input and 64 output channels (ResNet-18 layer1: forward
+// and data gradient), bf16, gfx950 — weight-stationary halo-patch kernel.
+//
+// The generic implicit GEMM (conv_igemm.hip) re-stages a 128-pixel activation tile for every one
+// of the 9 taps: each activation travels L2 -> LDS nine times and the K = 64 tile leaves only 2x2
+// fragments per wave.  For C = K = 64 the whole filter (64 x 576 bf16 = 72 KiB) fits in the
+// REGISTERS of one 8-wave block:
+//     wave (kh, pq):  out-channels 32*kh .. +31  x  all 576 reduction elements  = 144 VGPRs
+// so the block is persistent, loads its weights once, and then streams 8x8 output patches:
+//     stage  : the patch's 10x10 halo x 64 channels (12.5 KiB) by LDS-DMA, ONCE for all 9 taps
+//     compute: wave (kh, pq) owns patch rows 2*pq, 2*pq+1 (16 pixels = one MFMA column block);
+//              per tap and channel half ONE ds_read_b128 feeds two MFMAs (A = weights in registers)
+//     store  : 4 consecutive out-channels per lane, straight from the accumulators.
+// L2 -> LDS traffic is 1.56x the activation tensor instead of 9x, LDS reads are 1 per 2 MFMAs and
+// there is no weight traffic at all inside the loop.
+//
+// Data gradient = the same kernel on (dy, w_dgrad): the w_dgrad layout keeps the forward tap order,
+// the source pixel of tap (r, s) is (h + 1 - r, w + 1 - s), i.e. halo slot (2 - r, 2 - s) (`flip`).
+//
+// LDS layout of a halo: slot = hy*10 + hx (pixel), 128 B per slot = 8 chunks of 16 B; chunk c of a
+// slot is stored at chunk (c ^ key(slot)), key from a 10-entry table (period 20 slots) found by
+// exhaustive search: with it every ds_read_b128 of the compute phase (16 pixels of two patch rows x
+// 4 chunks, any tap shift) is bank-conflict free.  The permutation is applied on the SOURCE side of
+// the DMA (lane-linear destination).
+#include <stdlib.h>
+
+#include "conv_common.h"
+
+namespace primia {
+
+__device__ __attribute__((aligned(16))) const unsigned char kC64ZeroPage[16] = {0};
+
+// see conv_wgrad_patch.hip: inline-asm LDS-DMA keeps the compiler from draining vmcnt before LDS reads
+__device__ __forceinline__ void c64_dma16(const void* g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+}
+
+__device__ __forceinline__ int c64_key(int slot) {
+    // table {0,1,2,4,1,5,6,2,6,4}[(slot >> 1) % 10], 3 bits per entry
+    return (0x265a9888u >> (3 * ((slot >> 1) % 10))) & 7;
+}
+
+struct C64Params {
+    const bf16* src;
+    const bf16* wt;   // [64][576] forward-layout weights (fwd: w_fwd, dgrad: w_dgrad)
+    bf16* dst;
+    int N, H, W;
+    int flip;         // 0 forward, 1 data gradient
+    int accumulate;   // dst += result
+    int PH, PW, PPI;  // 8x8 patches per image column / row / image
+    int total;        // patches overall
+    int per_block;    // patches per block (even)
+    int debug;        // timing experiments only (PRIMIA_C64_DEBUG): 1 no stores, 2 no staging, 4 no MFMA loop
+};
+
+template <bool ACC>
+__global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
+    constexpr int STAGES = 3;
+    constexpr int HALO = 13 * 1024;        // 100 slots used, 104 staged (13 DMA instructions)
+    constexpr int STAGE = 2 * HALO;        // two patches per stage
+    constexpr int OUTB = 2 * 64 * 128;     // output rows of one stage: 2 patches x 64 pixels x 128 B
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE + 2 * OUTB
+    char* const sout = smem + STAGES * STAGE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, pq = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+
+    const int t0 = blockIdx.x * p.per_block;
+    int t1 = t0 + p.per_block;
+    if (t1 > p.total) t1 = p.total;
+    const int nstages = (t1 - t0 + 1) >> 1;
+    if (nstages <= 0) return;
+
+    // ---- weights -> registers: A fragment (i, j): row 32*kh + 16*i + fr, elements j*32 + 8*fg .. +7 -------
+    bf16x8_t wreg[18][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const bf16* wrow = p.wt + (long)(32 * kh + 16 * i + fr) * 576 + 8 * fg;
+#pragma unroll
+        for (int j = 0; j < 18; ++j) wreg[j][i] = *(const bf16x8_t*)(wrow + j * 32);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights resident before any counted wait below
+
+    // patch cursor: (n, ph, pw) of consecutive patch ids, advanced by one
+    struct Cursor {
+        int n, ph, pw, t;
+    };
+    auto make_cursor = [&](int t) {
+        Cursor c;
+        c.t = t;
+        c.n = t / p.PPI;
+        const int rem = t - c.n * p.PPI;
+        c.ph = rem / p.PW;
+        c.pw = rem - c.ph * p.PW;
+        return c;
+    };
+    auto advance = [&](Cursor& c) {
+        ++c.t;
+        if (++c.pw == p.PW) {
+            c.pw = 0;
+            if (++c.ph == p.PH) {
+                c.ph = 0;
+                ++c.n;
+            }
+        }
+    };
+    Cursor cs = make_cursor(t0), co = make_cursor(t0), cw = make_cursor(t0);  // staging / compute / write-back
+
+    // ---- staging: 26 DMA instructions per stage (2 patches x 13), round-robin over the 8 waves -----------
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto stage = [&](int buf) {
+        int rb[2], cb[2], pixbase[2];
+        bool live[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            live[q] = cs.t < t1;
+            rb[q] = cs.ph * 8;
+            cb[q] = cs.pw * 8;
+            pixbase[q] = (cs.n * p.H + rb[q]) * p.W + cb[q];
+            advance(cs);
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = wave + 8 * it;  // wave-uniform
+            if (idx >= 26) break;
+            const int q = idx >= 13;
+            const int slot = (idx - 13 * q) * 8 + (lane >> 3);
+            const int hy = slot / 10, hx = slot - hy * 10;
+            const int chunk = (lane & 7) ^ c64_key(slot);
+            const int row = rb[q] + hy - 1, col = cb[q] + hx - 1;
+            const bool ok = live[q] && slot < 100 && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
+            const bf16* g = ok ? p.src + ((pixbase[q] + (hy - 1) * p.W + (hx - 1)) * 64 + chunk * 8)
+                               : (const bf16*)kC64ZeroPage;
+            c64_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + idx * 1024));
+        }
+    };
+
+    // ---- per-lane LDS offsets of the B fragments: pixel (2*pq + (fr >> 3), fr & 7), tap shift, chunk fg ----
+    int offb[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int r = t / 3, s = t - 3 * r;
+        const int rr = p.flip ? 2 - r : r, ss = p.flip ? 2 - s : s;
+        const int slot = (2 * pq + (fr >> 3) + rr) * 10 + (fr & 7) + ss;
+        offb[t] = slot * 128 + ((fg ^ c64_key(slot)) << 4);   // channel half 1: offb ^ 64
+    }
+    // output staging: pixel opix = 16*pq + fr of the patch, 8-byte column 8*kh + 4*i + fg of its 128-B row,
+    // stored at 16-B chunk (col >> 1) ^ ((opix >> 1) & 7): conflict-free ds_write_b64 / ds_read_b128
+    const int opix = 16 * pq + fr;
+    const int opy = opix >> 3, opx = opix & 7;
+
+    auto compute = [&](int buf, int obuf) {
+        const char* sb = smem + buf * STAGE;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // B fragments: 3-deep register ring, reads run two steps ahead of the MFMAs that consume them
+        bf16x8_t bq[3][2];
+        auto rd = [&](int step, int slot) {
+            const int o = offb[step >> 1] ^ ((step & 1) * 64);
+            bq[slot][0] = *(const bf16x8_t*)(sb + o);
+            bq[slot][1] = *(const bf16x8_t*)(sb + HALO + o);
+        };
+        if (!(p.debug & 4)) {
+            rd(0, 0);
+            rd(1, 1);
+#pragma unroll
+            for (int step = 0; step < 18; ++step) {
+                if (step + 2 < 18) rd(step + 2, (step + 2) % 3);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[step][i], bq[step % 3][0], acc[0][i], 0, 0, 0);
+                    acc[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[step][i], bq[step % 3][1], acc[1][i], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- results -> LDS rows (bf16); the accumulate form adds the old values first (fp32, one rounding) --
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int ho = co.ph * 8 + opy, wo = co.pw * 8 + opx;
+            const bool inb = co.t < t1 && ho < p.H && wo < p.W;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float v[4] = {acc[q][i][0], acc[q][i][1], acc[q][i][2], acc[q][i][3]};
+                if (ACC) {
+                    if (inb) {
+                        const u32x2 o = *(const u32x2*)(p.dst + ((long)(co.n * p.H + ho) * p.W + wo) * 64 + 32 * kh +
+                                                        16 * i + 4 * fg);
+                        v[0] += __uint_as_float(o[0] << 16);
+                        v[1] += __uint_as_float(o[0] & 0xffff0000u);
+                        v[2] += __uint_as_float(o[1] << 16);
+                        v[3] += __uint_as_float(o[1] & 0xffff0000u);
+                    }
+                }
+                u32x2 o;
+                o[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                o[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                const int col = 8 * kh + 4 * i + fg;
+                *(u32x2*)(sout + obuf * OUTB + q * 8192 + opix * 128 + ((((col >> 1) ^ ((opix >> 1) & 7)) << 4) | ((col & 1) << 3))) = o;
+            }
+            advance(co);
+        }
+    };
+
+    // write-back of one stage's rows: 16 row groups (8 pixels x 128 B = 1 KiB contiguous in memory), 2 per wave
+    auto writeback = [&](int obuf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int g = wave;                       // patch row handled by this wave
+            const int px = lane >> 3, c16 = lane & 7;  // pixel of the row, 16-B chunk
+            const int opx2 = g * 8 + px;
+            const u32x4 v = *(const u32x4*)(sout + obuf * OUTB + q * 8192 + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
+            const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
+            if (cw.t < t1 && ho < p.H && wo < p.W && !((p.debug & 1) && v[0] != 12345u))
+                *(u32x4*)(p.dst + ((long)(cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8) = v;
+            advance(cw);
+        }
+    };
+
+    // STAGES-deep LDS ring, one raw barrier per stage, counted vmcnt.  vmcnt counts stores too; per iteration a
+    // wave issues, in this order, 2 row stores (write-back of the previous stage) and d DMA instructions
+    // (d = 4 for waves 0,1, else 3).  At the top of iteration s the operations newer than DMA(s) are the row
+    // stores of iteration s-1 (for s >= 2) and DMA(s+1): DMA(s) has landed once at most those remain in
+    // flight.  Ragged images (a row store may be fully masked), the accumulate form (its loads are waited
+    // for by the compiler, conservatively) and the last stage use vmcnt(0).
+    const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !(p.debug & 3) && !ACC;
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nstages) stage(s);
+    int cur = 0, nxt = STAGES - 1;
+    for (int s = 0; s < nstages; ++s) {
+        if (exact && s + 1 < nstages) {
+            if (wave < 2) {
+                if (s >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else {
+                if (s >= 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (s > 0) writeback((s - 1) & 1);
+        if (s + STAGES - 1 < nstages && !(p.debug & 2)) stage(nxt);
+        compute(cur, s & 1);
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+    }
+    __syncthreads();
+    writeback((nstages - 1) & 1);
+}
+
+// returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the implicit GEMM)
+int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
+                         hipStream_t st) {
+    if ((long)N * H * W * 64 >= (1L << 31)) return PRIMIA_ERR_UNSUPPORTED;
+    C64Params p;
+    p.src = src; p.wt = wt; p.dst = dst;
+    p.N = N; p.H = H; p.W = W; p.flip = flip; p.accumulate = accumulate;
+    p.PH = (H + 7) / 8; p.PW = (W + 7) / 8; p.PPI = p.PH * p.PW;
+    p.total = N * p.PPI;
+    static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 256;
+    long per = (p.total + target - 1) / target;
+    per = (per + 1) & ~1L;
+    if (per < 2) per = 2;
+    p.per_block = (int)per;
+    static const int dbg = getenv("PRIMIA_C64_DEBUG") ? atoi(getenv("PRIMIA_C64_DEBUG")) : 0;
+    p.debug = dbg;
+    const int grid = (int)((p.total + per - 1) / per);
+    const size_t lds = (size_t)3 * 2 * 13 * 1024 + 2 * 2 * 64 * 128;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    if (accumulate)
+        conv3x3_c64_kernel<true><<<grid, 512, lds, st>>>(p);
+    else
+        conv3x3_c64_kernel<false><<<grid, 512, lds, st>>>(p);
+    return launch_status();
+}
+
+}  // namespace primia

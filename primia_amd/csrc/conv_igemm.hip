@@ -517,6 +517,18 @@ static int dispatch_igemm(const IgemmParams& p, bool stem, hipStream_t st) {
 
 using namespace primia;
 
+namespace primia {
+int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
+                         hipStream_t st);
+}
+
+// layer1 shape (3x3, stride 1, pad 1, 64 -> 64 channels, bf16): weight-stationary halo kernel (conv3x3_c64.hip);
+// PRIMIA_C64=0 keeps the implicit GEMM (A/B measurements)
+static bool use_c64(const ConvGeom& g) {
+    static const bool off = getenv("PRIMIA_C64") && getenv("PRIMIA_C64")[0] == '0';
+    return !off && !g.stem && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.C == 64 && g.K == 64;
+}
+
 extern "C" {
 
 static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stat_sums,
@@ -540,6 +552,10 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
         p.nsteps = g.stem ? 7 : g.klen / 32;
         return dispatch_igemm<float, false>(p, g.stem, st);
     } else if (dtype == PRIMIA_BF16) {
+        if (!stat_sums && use_c64(g)) {
+            const int rc = conv3x3_c64_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, 0, 0, st);
+            if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+        }
         p.nsteps = g.klen / 64;
         return dispatch_igemm<bf16, false>(p, g.stem, st);
     }
@@ -582,6 +598,11 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
         p.nsteps = p.klen / 32;
         return dispatch_igemm<float, true>(p, false, st);
     } else if (dtype == PRIMIA_BF16) {
+        if (use_c64(g)) {
+            const int rc = conv3x3_c64_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, 1,
+                                                accumulate, st);
+            if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+        }
         p.nsteps = p.klen / 64;
         return dispatch_igemm<bf16, true>(p, false, st);
     }

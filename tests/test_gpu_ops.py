@@ -62,6 +62,8 @@ CONV_CASES = [
     (3, 14, 256, 256, 3, 1, 1),   # layer3.1 (16-wide sub-patches in the halo-patch wgrad)
     (2, 28, 128, 128, 3, 1, 1),   # layer2.1 (ragged right edge: 28 = 3.5 x 8)
     (1, 56, 64, 64, 3, 1, 1),     # layer1 (exact 4x8 tiling)
+    (3, 12, 64, 64, 3, 1, 1),     # layer1 shape, ragged 8x8 patches (12 = 1.5 x 8), odd patch count
+    (5, 8, 64, 64, 3, 1, 1),      # one patch per image, odd total
 ]
 
 
