@@ -139,6 +139,14 @@ int primia_bn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
                   const float* gamma, const float* save_mean, const float* save_invstd,
                   float* dgamma, float* dbeta, int64_t M, int C, int relu, void* workspace,
                   int64_t workspace_bytes, int dtype, primia_stream_t stream);
+/* Backward of z = relu(bn(y)) WITHOUT a residual (bn1 of every BasicBlock and the stem,
+ * torchlib/models.py:261-263, 469-470): the mask (z > 0) is recomputed from y with the forward pass's
+ * own fma, so z is not read — one tensor less in each of the two passes.  Same outputs as
+ * primia_bn_bwd(relu = 1, g_out = NULL). */
+int primia_bn_relu_bwd(const void* y, const void* dz, void* dy, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                       int64_t M, int C, void* workspace, int64_t workspace_bytes, int dtype,
+                       primia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ fused ReLU / residual) and the per-sample pieces of DP-SGD — BASELINE.json

@@ -13,6 +13,12 @@ namespace primia {
 
 constexpr int kMaxPartialBlocks = 1024;
 
+// z before activation: one explicit fma, so the backward pass can recompute the ReLU mask from y
+// bit-identically to what the forward pass stored (see primia_bn_relu_bwd).
+__device__ __forceinline__ float bn_affine(float y, float mean, float scale, float beta) {
+    return __builtin_fmaf(y - mean, scale, beta);
+}
+
 // ---- generic column reduction of two per-element quantities ------------------------------------
 // Threads are laid out [rows_per_pass][C/CH]; thread (rg, cc) owns channels cc*CH..+CH-1.
 template <typename T, typename F>
@@ -75,6 +81,8 @@ struct BwdFn {
     const T* dz;
     const float* mean;
     const float* invstd;
+    const float* gamma;  // with beta: no z, the mask (z > 0) is recomputed from y
+    const float* beta;
     __device__ __forceinline__ void operator()(long off, int c0, float* s1, float* s2) const {
         constexpr int CH = Chunk<T>::N;
         float vy[CH], vg[CH];
@@ -85,6 +93,12 @@ struct BwdFn {
             Chunk<T>::unpack(*(const u32x4*)(z + off), vz);
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        } else if (beta) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const float zz = bn_affine(vy[i], mean[c0 + i], invstd[c0 + i] * gamma[c0 + i], beta[c0 + i]);
+                vg[i] = zz > 0.f ? vg[i] : 0.f;
+            }
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -162,7 +176,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
         float v[CH];
         Chunk<T>::unpack(*(const u32x4*)(y + q * CH), v);
 #pragma unroll
-        for (int i = 0; i < CH; ++i) v[i] = (v[i] - sm[0][c0 + i]) * sm[1][c0 + i] + sm[2][c0 + i];
+        for (int i = 0; i < CH; ++i) v[i] = bn_affine(v[i], sm[0][c0 + i], sm[1][c0 + i], sm[2][c0 + i]);
         if (res) {
             float r[CH];
             Chunk<T>::unpack(*(const u32x4*)(res + q * CH), r);
@@ -186,15 +200,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ dbeta,
                                                            const float* __restrict__ dgamma, float inv_m,
-                                                           long nchunks, int C) {
+                                                           long nchunks, int C, const float* __restrict__ beta) {
     constexpr int CH = Chunk<T>::N;
-    __shared__ float sm[5][512];
+    __shared__ float sm[7][512];
     for (int c = threadIdx.x; c < C; c += 256) {
         sm[0][c] = mean[c];
         sm[1][c] = invstd[c];
         sm[2][c] = gamma[c] * invstd[c];
         sm[3][c] = dbeta[c] * inv_m;
         sm[4][c] = dgamma[c] * inv_m;
+        sm[5][c] = invstd[c] * gamma[c];   // the forward pass's scale (same operand order)
+        sm[6][c] = beta ? beta[c] : 0.f;
     }
     __syncthreads();
     const int cpr = C / CH;
@@ -209,6 +225,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             Chunk<T>::unpack(*(const u32x4*)(z + q * CH), vz);
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        } else if (beta) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const float zz = bn_affine(vy[i], sm[0][c0 + i], sm[5][c0 + i], sm[6][c0 + i]);
+                vg[i] = zz > 0.f ? vg[i] : 0.f;
+            }
         }
         if (g_out) *(u32x4*)(g_out + q * CH) = Chunk<T>::pack(vg);
 #pragma unroll
@@ -262,17 +284,17 @@ template <typename T>
 static int bn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, void* g_out,
                        const float* gamma, const float* save_mean, const float* save_invstd,
                        float* dgamma, float* dbeta, long M, int C, int relu, float* partials,
-                       hipStream_t st) {
+                       hipStream_t st, const float* beta = nullptr) {
     int nblk;
     long rpb;
     reduce_geometry(M, C, nblk, rpb);
-    BwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, save_mean, save_invstd};
+    BwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, save_mean, save_invstd, gamma, beta};
     colreduce2_kernel<T, BwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
     bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
     const long nchunks = M * C / Chunk<T>::N;
     bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
         (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean,
-        save_invstd, dbeta, dgamma, (float)(1.0 / (double)M), nchunks, C);
+        save_invstd, dbeta, dgamma, (float)(1.0 / (double)M), nchunks, C, beta);
     return launch_status();
 }
 
@@ -370,6 +392,23 @@ int primia_bn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
     if (dtype == PRIMIA_BF16)
         return bn_bwd_impl<bf16>(y, z, dz, dy, g_out, gamma, save_mean, save_invstd, dgamma, dbeta, M, C, relu,
                                  (float*)workspace, st);
+    return PRIMIA_ERR_ARG;
+}
+
+
+int primia_bn_relu_bwd(const void* y, const void* dz, void* dy, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int64_t M,
+                       int C, void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && dz && dy && gamma && beta && save_mean && save_invstd && dgamma && dbeta && workspace);
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype));
+    if (workspace_bytes < primia_bn_workspace_bytes(M, C)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return bn_bwd_impl<float>(y, nullptr, dz, dy, nullptr, gamma, save_mean, save_invstd, dgamma, dbeta, M, C, 0,
+                                  (float*)workspace, st, beta);
+    if (dtype == PRIMIA_BF16)
+        return bn_bwd_impl<bf16>(y, nullptr, dz, dy, nullptr, gamma, save_mean, save_invstd, dgamma, dbeta, M, C, 0,
+                                 (float*)workspace, st, beta);
     return PRIMIA_ERR_ARG;
 }
 

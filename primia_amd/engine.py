@@ -370,6 +370,12 @@ class ResNet18Engine:
                 call("primia_weighted_colsum", psg, self.ones_n, self.gviews[b + ".weight"], self.N, C)
                 call("primia_weighted_colsum", psb, self.ones_n, self.gviews[b + ".bias"], self.N, C)
             return
+        if relu and g_out is None:
+            # z = relu(bn(y)), no residual: the mask is recomputed from y, z is not read
+            call("primia_bn_relu_bwd", y, dz, dy, self.views[b + ".weight"], self.views[b + ".bias"], sm, si,
+                 self.gviews[b + ".weight"], self.gviews[b + ".bias"], y.shape[0], y.shape[1], self.bn_ws,
+                 self.bn_ws_bytes, self.dt)
+            return
         call("primia_bn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, self.gviews[b + ".weight"],
              self.gviews[b + ".bias"], y.shape[0], y.shape[1], int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
 

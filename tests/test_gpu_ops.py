@@ -201,6 +201,12 @@ def test_batchnorm_train(cuda, dtype, C, relu, res, N, H):
     assert relerr(dbet, br.grad) < (1e-5 if dtype == torch.float32 else 5e-3)
     if res:
         assert relerr(from_nhwc(g_out, N, H, H), rr.grad) < t
+    if relu and not res:
+        # recomputed-mask form: identical results without reading z
+        dy2, dgam2, dbet2 = torch.empty_like(yd), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+        call("primia_bn_relu_bwd", yd, dzd, dy2, gamma.to(cuda), beta.to(cuda), sm, si, dgam2, dbet2, M, C, ws,
+             ws_bytes, dt)
+        assert torch.equal(dy2, dy) and torch.equal(dgam2, dgam) and torch.equal(dbet2, dbet)
 
     # eval mode
     z2 = torch.empty_like(yd)
