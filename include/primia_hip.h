@@ -147,6 +147,23 @@ int primia_bn_relu_bwd(const void* y, const void* dz, void* dy, const float* gam
                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                        int64_t M, int C, void* workspace, int64_t workspace_bytes, int dtype,
                        primia_stream_t stream);
+/* The stem's tail fused: pooled, argmax = MaxPool2d(3, 2, 1)(relu(bn1(y))) straight from the conv
+ * output (torchlib/models.py:468-471), batch statistics included — z = relu(bn(y)), the largest
+ * activation of the network, is never written.  Same results as primia_bn_fwd_train(relu = 1)
+ * followed by primia_maxpool3x3s2_fwd (values are rounded to `dtype` before the window comparison). */
+int primia_bn_relu_maxpool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var,
+                               float* save_mean, float* save_invstd, int N, int H, int W, int C, float eps,
+                               float momentum, void* workspace, int64_t workspace_bytes, int dtype,
+                               primia_stream_t stream);
+/* Its backward: from dpooled and the argmax codes to dy / dgamma / dbeta; the pool's input gradient
+ * is gathered and ReLU-masked inside BatchNorm's reduction pass.  Same results as
+ * primia_maxpool3x3s2_bwd followed by primia_bn_bwd(relu = 1).  N*H*W < 2^24. */
+int primia_bn_relu_maxpool_bwd(const void* y, const void* dpooled, const uint8_t* argmax, void* dy,
+                               const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W,
+                               int C, void* workspace, int64_t workspace_bytes, int dtype,
+                               primia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ fused ReLU / residual) and the per-sample pieces of DP-SGD — BASELINE.json

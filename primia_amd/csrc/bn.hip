@@ -36,7 +36,15 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(F f, long M, int C, lon
 #pragma unroll
     for (int i = 0; i < CH; ++i) s1[i] = s2[i] = 0.f;
     if (rg < rpp) {
-        for (long r = r0 + rg; r < r1; r += rpp) f(r * C + cc * CH, cc * CH, s1, s2);
+        F lf = f;
+        lf.prepare(cc * CH);  // per-channel constants -> registers (the functor's stores must not force reloads)
+        long r = r0 + rg;
+        constexpr int U = F::kUnroll;  // rows per trip: independent loads overlap (measured per functor)
+        for (; r + (long)(U - 1) * rpp < r1; r += (long)U * rpp) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) lf(r + (long)u * rpp, (r + (long)u * rpp) * C + cc * CH, cc * CH, s1, s2);
+        }
+        for (; r < r1; r += rpp) lf(r, r * C + cc * CH, cc * CH, s1, s2);
     }
     // cross-row-group reduction through LDS: [rpp][C] floats x 2 (rpp*C <= 256*CH)
     __shared__ float red[2][256 * CH];
@@ -61,8 +69,10 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(F f, long M, int C, lon
 
 template <typename T>
 struct StatsFn {
+    static constexpr int kUnroll = 4;
     const T* y;
-    __device__ __forceinline__ void operator()(long off, int c0, float* s1, float* s2) const {
+    __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ void operator()(long, long off, int c0, float* s1, float* s2) const {
         constexpr int CH = Chunk<T>::N;
         float v[CH];
         Chunk<T>::unpack(*(const u32x4*)(y + off), v);
@@ -76,6 +86,7 @@ struct StatsFn {
 
 template <typename T>
 struct BwdFn {
+    static constexpr int kUnroll = 1;
     const T* y;
     const T* z;   // may be null (no relu)
     const T* dz;
@@ -83,7 +94,8 @@ struct BwdFn {
     const float* invstd;
     const float* gamma;  // with beta: no z, the mask (z > 0) is recomputed from y
     const float* beta;
-    __device__ __forceinline__ void operator()(long off, int c0, float* s1, float* s2) const {
+    __device__ __forceinline__ void prepare(int) {}
+    __device__ __forceinline__ void operator()(long, long off, int c0, float* s1, float* s2) const {
         constexpr int CH = Chunk<T>::N;
         float vy[CH], vg[CH];
         Chunk<T>::unpack(*(const u32x4*)(y + off), vy);
@@ -242,6 +254,185 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// =================================================================================================
+// BatchNorm + ReLU + MaxPool(3, 2, 1) fused (the stem: conv1 -> bn1 -> relu -> maxpool,
+// torchlib/models.py:466-471).  The unfused chain writes z = relu(bn(y)) (the largest activation of
+// the network), reads it back for the pool, and in the backward pass materialises the pool's input
+// gradient dz only for the two BatchNorm backward passes to read it again.  Fused:
+//   forward : pooled, argmax = maxpool(relu(bn(y)))   straight from y              (z never exists)
+//   backward: g(h, w) = [z(h, w) > 0] * sum over the <= 4 windows whose argmax is (h, w) of dpooled
+//             is gathered INSIDE BatchNorm's reduction pass (which also parks it in dy); the pool's
+//             own backward pass and the re-read of its output are gone.
+// Values are rounded to the storage type before the window comparison, so argmax / ties are exactly
+// those of the unfused kernels (first maximum in scan order, like torch's max_pool2d).
+// =================================================================================================
+template <typename T>
+__device__ __forceinline__ float round_to(float v) {
+    return v;
+}
+template <>
+__device__ __forceinline__ float round_to<bf16>(float v) {
+    return bf16_to_f32(f32_to_bf16(v));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, T* __restrict__ pooled,
+                                                               uint8_t* __restrict__ argmax,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ invstd, int N, int H, int W,
+                                                               int C, int Ho, int Wo) {
+    constexpr int CH = Chunk<T>::N;
+    __shared__ float sm[3][512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        sm[0][c] = mean[c];
+        sm[1][c] = invstd[c] * gamma[c];
+        sm[2][c] = beta[c];
+    }
+    __syncthreads();
+    const int cpr = C / CH;
+    const long total = (long)N * Ho * Wo * cpr;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int cc = (int)(q % cpr);
+    long t = q / cpr;
+    const int wo = (int)(t % Wo);
+    t /= Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const int c0 = cc * CH;
+    float best[CH];
+    int pos[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        best[i] = 0.f;
+        pos[i] = -1;
+    }
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int h = ho * 2 - 1 + r;
+        if (h < 0 || h >= H) continue;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int w = wo * 2 - 1 + s;
+            if (w < 0 || w >= W) continue;
+            float v[CH];
+            Chunk<T>::unpack(*(const u32x4*)(y + (((long)n * H + h) * W + w) * C + c0), v);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const float z = round_to<T>(fmaxf(bn_affine(v[i], sm[0][c0 + i], sm[1][c0 + i], sm[2][c0 + i]), 0.f));
+                if (pos[i] < 0 || z > best[i] || z != z) {
+                    best[i] = z;
+                    pos[i] = r * 3 + s;
+                }
+            }
+        }
+    }
+    const long o = (((long)n * Ho + ho) * Wo + wo) * C + c0;
+    *(u32x4*)(pooled + o) = Chunk<T>::pack(best);
+#pragma unroll
+    for (int i = 0; i < CH; ++i) argmax[o + i] = (uint8_t)pos[i];
+}
+
+// gradient w.r.t. z(n, h, w, c0..c0+CH-1) coming back through the pool.  A pixel lies in at most 2 x 2
+// windows: along each axis candidate A = ((h + 1) >> 1, tap h + 1 - 2*ho) always exists (if in range) and
+// candidate B = ((h - 1) >> 1, tap 2) only for odd h.  Branch-free: loads go to a clamped address and are
+// discarded by the validity flag, so the compiler can overlap the loads of several pixels.
+template <typename T>
+__device__ __forceinline__ void pool_gather(const T* __restrict__ dp, const uint8_t* __restrict__ argmax, int n, int h,
+                                            int w, int c0, int C, int Ho, int Wo, float* g) {
+    constexpr int CH = Chunk<T>::N;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) g[i] = 0.f;
+    int hoc[2], rc[2], woc[2], sc[2];
+    bool hv[2], wv[2];
+    hoc[0] = (h + 1) >> 1; rc[0] = h + 1 - 2 * hoc[0]; hv[0] = hoc[0] < Ho;
+    hoc[1] = (h - 1) >> 1; rc[1] = 2;                  hv[1] = (h & 1) != 0;
+    woc[0] = (w + 1) >> 1; sc[0] = w + 1 - 2 * woc[0]; wv[0] = woc[0] < Wo;
+    woc[1] = (w - 1) >> 1; sc[1] = 2;                  wv[1] = (w & 1) != 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const bool ok = hv[a] && wv[b];
+            const int ho = ok ? hoc[a] : 0, wo = ok ? woc[b] : 0;
+            const long o = (((long)n * Ho + ho) * Wo + wo) * C + c0;
+            float v[CH];
+            Chunk<T>::unpack(*(const u32x4*)(dp + o), v);
+            const unsigned code = ok ? (unsigned)(rc[a] * 3 + sc[b]) : 0xffu;  // 0xff never matches
+            if (CH == 8) {
+                const u32x2 m = *(const u32x2*)(argmax + o);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    g[i] += ((m[0] >> (8 * i)) & 0xffu) == code ? v[i] : 0.f;
+                    g[4 + i] += ((m[1] >> (8 * i)) & 0xffu) == code ? v[4 + i] : 0.f;
+                }
+            } else {
+                const uint32_t m = *(const uint32_t*)(argmax + o);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) g[i] += ((m >> (8 * i)) & 0xffu) == code ? v[i] : 0.f;
+            }
+        }
+}
+
+template <typename T>
+struct PoolBwdFn {
+    static constexpr int kUnroll = 4;
+    const T* y;
+    const T* dp;
+    const uint8_t* argmax;
+    T* g_out;     // masked pool-input gradient, written once here and read by the apply pass
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    int H, W, C, Ho, Wo;
+    float rcp_w, rcp_h;
+    float k_mean[Chunk<T>::N], k_invstd[Chunk<T>::N], k_scale[Chunk<T>::N], k_beta[Chunk<T>::N];
+    __device__ __forceinline__ void prepare(int c0) {
+#pragma unroll
+        for (int i = 0; i < Chunk<T>::N; ++i) {
+            k_mean[i] = mean[c0 + i];
+            k_invstd[i] = invstd[c0 + i];
+            k_scale[i] = invstd[c0 + i] * gamma[c0 + i];
+            k_beta[i] = beta[c0 + i];
+        }
+    }
+    // q = m / d for 0 <= m < 2^24 via one float multiply and a fix-up
+    static __device__ __forceinline__ int fdiv(int m, int d, float rcp, int& rem) {
+        int q = (int)((float)m * rcp);
+        rem = m - q * d;
+        if (rem >= d) {
+            ++q;
+            rem -= d;
+        } else if (rem < 0) {
+            --q;
+            rem += d;
+        }
+        return q;
+    }
+    __device__ __forceinline__ void operator()(long row, long off, int c0, float* s1, float* s2) const {
+        constexpr int CH = Chunk<T>::N;
+        const int m = (int)row;
+        int w, h;
+        const int t = fdiv(m, W, rcp_w, w);
+        const int n = fdiv(t, H, rcp_h, h);
+        float vy[CH], vg[CH];
+        Chunk<T>::unpack(*(const u32x4*)(y + off), vy);
+        pool_gather<T>(dp, argmax, n, h, w, c0, C, Ho, Wo, vg);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const float zz = bn_affine(vy[i], k_mean[i], k_scale[i], k_beta[i]);
+            vg[i] = zz > 0.f ? round_to<T>(vg[i]) : 0.f;   // dz as the unfused pool backward stores it, masked
+            const float xh = (vy[i] - k_mean[i]) * k_invstd[i];
+            s1[i] += vg[i];
+            s2[i] += vg[i] * xh;
+        }
+        *(u32x4*)(g_out + off) = Chunk<T>::pack(vg);
+    }
+};
+
 static inline void reduce_geometry(long M, int C, int& nblk, long& rows_per_block) {
     // >= 256 rows per block so the fp32 in-block accumulation stays short; <= 1024 blocks.
     long nb = (M + 255) / 256;
@@ -295,6 +486,48 @@ static int bn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
     bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
         (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean,
         save_invstd, dbeta, dgamma, (float)(1.0 / (double)M), nchunks, C, beta);
+    return launch_status();
+}
+
+template <typename T>
+static int bn_relu_pool_fwd_impl(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float* save_mean, float* save_invstd, int N,
+                                 int H, int W, int C, float eps, float momentum, float* partials, hipStream_t st) {
+    const long M = (long)N * H * W;
+    int nblk;
+    long rpb;
+    reduce_geometry(M, C, nblk, rpb);
+    StatsFn<T> f{(const T*)y};
+    colreduce2_kernel<T, StatsFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
+    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
+                                                       running_mean, running_var);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long total = (long)N * Ho * Wo * (C / Chunk<T>::N);
+    bn_relu_pool_fwd_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+        (const T*)y, (T*)pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, Ho, Wo);
+    return launch_status();
+}
+
+template <typename T>
+static int bn_relu_pool_bwd_impl(const void* y, const void* dpooled, const uint8_t* argmax, void* dy,
+                                 const float* gamma, const float* beta, const float* save_mean,
+                                 const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W, int C,
+                                 float* partials, hipStream_t st) {
+    const long M = (long)N * H * W;
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    int nblk;
+    long rpb;
+    reduce_geometry(M, C, nblk, rpb);
+    // pass 1: gather the pool gradient, mask it, reduce it; the masked gradient g is parked in dy
+    PoolBwdFn<T> f{(const T*)y, (const T*)dpooled, argmax, (T*)dy, save_mean, save_invstd, gamma, beta,
+                   H, W, C, Ho, Wo, 1.0f / (float)W, 1.0f / (float)H, {}, {}, {}, {}};
+    colreduce2_kernel<T, PoolBwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
+    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
+    // pass 2: the ordinary apply pass, in place over g
+    const long nchunks = M * C / Chunk<T>::N;
+    bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>((const T*)y, nullptr, (const T*)dy, (T*)dy, nullptr,
+                                                                   gamma, save_mean, save_invstd, dbeta, dgamma,
+                                                                   (float)(1.0 / (double)M), nchunks, C, nullptr);
     return launch_status();
 }
 
@@ -395,6 +628,43 @@ int primia_bn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
     return PRIMIA_ERR_ARG;
 }
 
+
+int primia_bn_relu_maxpool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float* save_mean, float* save_invstd, int N,
+                               int H, int W, int C, float eps, float momentum, void* workspace,
+                               int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && pooled && argmax && gamma && beta && save_mean && save_invstd && workspace);
+    PRIMIA_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    PRIMIA_REQUIRE(N > 0 && H > 0 && W > 0 && bn_shape_ok((long)N * H * W, C, dtype));
+    if (workspace_bytes < primia_bn_workspace_bytes((int64_t)N * H * W, C)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return bn_relu_pool_fwd_impl<float>(y, pooled, argmax, gamma, beta, running_mean, running_var, save_mean,
+                                            save_invstd, N, H, W, C, eps, momentum, (float*)workspace, st);
+    if (dtype == PRIMIA_BF16)
+        return bn_relu_pool_fwd_impl<bf16>(y, pooled, argmax, gamma, beta, running_mean, running_var, save_mean,
+                                           save_invstd, N, H, W, C, eps, momentum, (float*)workspace, st);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_bn_relu_maxpool_bwd(const void* y, const void* dpooled, const uint8_t* argmax, void* dy,
+                               const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W, int C,
+                               void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && dpooled && argmax && dy && gamma && beta && save_mean && save_invstd && dgamma && dbeta &&
+                   workspace);
+    PRIMIA_REQUIRE(N > 0 && H > 0 && W > 0 && bn_shape_ok((long)N * H * W, C, dtype));
+    PRIMIA_REQUIRE((long)N * H * W < (1L << 24));  // float-reciprocal index math
+    if (workspace_bytes < primia_bn_workspace_bytes((int64_t)N * H * W, C)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return bn_relu_pool_bwd_impl<float>(y, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, dgamma,
+                                            dbeta, N, H, W, C, (float*)workspace, st);
+    if (dtype == PRIMIA_BF16)
+        return bn_relu_pool_bwd_impl<bf16>(y, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, dgamma,
+                                           dbeta, N, H, W, C, (float*)workspace, st);
+    return PRIMIA_ERR_ARG;
+}
 
 int primia_bn_relu_bwd(const void* y, const void* dz, void* dy, const float* gamma, const float* beta,
                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta, int64_t M,

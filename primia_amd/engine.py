@@ -150,6 +150,9 @@ class ResNet18Engine:
         # Measured on MI355X at batch 256 it is a wash — the epilogue reduction costs the forward kernels
         # +0.38 ms/step, the separate statistics pass it removes costs 0.39 ms/step — so it stays off.
         self.fuse_stats = False
+        # stem tail bn1 -> relu -> maxpool as ONE fused op in training (z = relu(bn(y)) is never written)
+        self.fuse_stem = True
+        self._stem_fused = False
         self.stat_slots = query("primia_conv_stat_slots")
         per = lambda c: self.stat_slots * 2 * c.cout
         self.stat_sums = torch.zeros(sum(per(c) for c in self.spec.convs), dtype=torch.float32, device=dev)
@@ -310,9 +313,20 @@ class ResNet18Engine:
             self.stat_sums.zero_()
         call("primia_nchw_to_nhwc", x_nchw, self.x0, N, self.spec.in_channels, S, S, 4, self.dt)
         self._conv_fwd("conv1", self.x0, t["stem.y"])
-        self._bn("conv1", t["stem.y"], t["stem.z"], None, True)
         hw = self.stem_hw
-        if self.spec.pooling == "max":
+        self._stem_fused = (self.fuse_stem and self.training and self.norm == "batch" and self.spec.pooling == "max"
+                            and not self.fuse_stats and N * hw * hw < (1 << 24))
+        if self._stem_fused:
+            sm, si = self.save["bn1"]
+            call("primia_bn_relu_maxpool_fwd", t["stem.y"], t["pool.out"], self.pool_argmax, self.views["bn1.weight"],
+                 self.views["bn1.bias"], self.views["bn1.running_mean"], self.views["bn1.running_var"], sm, si, N, hw,
+                 hw, 64, BN_EPS, BN_MOMENTUM, self.bn_ws, self.bn_ws_bytes, self.dt)
+            self.num_batches_tracked["bn1"] += 1
+        else:
+            self._bn("conv1", t["stem.y"], t["stem.z"], None, True)
+        if self._stem_fused:
+            pass
+        elif self.spec.pooling == "max":
             call("primia_maxpool3x3s2_fwd", t["stem.z"], t["pool.out"], self.pool_argmax, N, hw, hw, 64, self.dt)
         else:
             call("primia_avgpool3x3s2_fwd", t["stem.z"], t["pool.out"], N, hw, hw, 64, self.dt)
@@ -423,11 +437,17 @@ class ResNet18Engine:
                 # identity skip: dx_in aliases dout, which now holds the masked gradient g
                 self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, True)
         hw = self.stem_hw
-        if self.spec.pooling == "max":
-            call("primia_maxpool3x3s2_bwd", t["pool.dout"], self.pool_argmax, t["stem.dz"], N, hw, hw, 64, self.dt)
+        if self._stem_fused:
+            sm, si = self.save["bn1"]
+            call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.dout"], self.pool_argmax, t["stem.dy"],
+                 self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self.gviews["bn1.weight"],
+                 self.gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
         else:
-            call("primia_avgpool3x3s2_bwd", t["pool.dout"], t["stem.dz"], N, hw, hw, 64, self.dt)
-        self._bn_bwd("conv1", t["stem.y"], t["stem.z"], t["stem.dz"], t["stem.dy"], None, True)
+            if self.spec.pooling == "max":
+                call("primia_maxpool3x3s2_bwd", t["pool.dout"], self.pool_argmax, t["stem.dz"], N, hw, hw, 64, self.dt)
+            else:
+                call("primia_avgpool3x3s2_bwd", t["pool.dout"], t["stem.dz"], N, hw, hw, 64, self.dt)
+            self._bn_bwd("conv1", t["stem.y"], t["stem.z"], t["stem.dz"], t["stem.dy"], None, True)
         self._wgrad("conv1", self.x0, t["stem.dy"])
         if self.dp is None:
             self._finalize_wgrads()

@@ -379,3 +379,47 @@ def test_conv_fwd_fused_bn_stats(cuda, dtype, case):
     z_ref = F.relu(F.batch_norm(y_st, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5))
     assert relerr(from_nhwc(z, N, desc.Ho, desc.Wo), z_ref) < (5e-5 if dtype == torch.float32 else 1e-2)
     assert relerr(rm, rm_ref) < 1e-4 and relerr(rv, rv_ref) < 1e-4
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,C", [(2, 16, 64), (1, 9, 64), (3, 14, 128)])
+def test_bn_relu_maxpool_fused_matches_unfused(cuda, dtype, N, H, C):
+    """The fused stem tail gives bit-identical results to bn_fwd_train -> maxpool (forward) and
+    maxpool_bwd -> bn_bwd (backward), odd sizes included."""
+    g = torch.Generator().manual_seed(77 + H)
+    dt = _lib.dtype_code(dtype)
+    M = N * H * H
+    Ho = (H - 1) // 2 + 1
+    yd = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * 2 + 0.3, dtype), dtype, cuda)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    beta = torch.randn(C, generator=g).to(cuda)
+    ws_bytes = query("primia_bn_workspace_bytes", M, C)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=cuda)
+    rm0, rv0 = torch.randn(C, generator=g).to(cuda), (torch.rand(C, generator=g) + 0.5).to(cuda)
+
+    # unfused
+    rm, rv = rm0.clone(), rv0.clone()
+    sm, si = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    z = torch.empty_like(yd)
+    call("primia_bn_fwd_train", yd, None, z, gamma, beta, rm, rv, sm, si, M, C, 1e-5, 0.1, 1, ws, ws_bytes, dt)
+    p = torch.empty(N * Ho * Ho, C, dtype=dtype, device=cuda)
+    am = torch.empty(N * Ho * Ho, C, dtype=torch.uint8, device=cuda)
+    call("primia_maxpool3x3s2_fwd", z, p, am, N, H, H, C, dt)
+    dp = to_nhwc(rnd(torch.randn(N, C, Ho, Ho, generator=g), dtype), dtype, cuda)
+    dz = torch.empty_like(yd)
+    call("primia_maxpool3x3s2_bwd", dp, am, dz, N, H, H, C, dt)
+    dy, dg, db = torch.empty_like(yd), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_bwd", yd, z, dz, dy, None, gamma, sm, si, dg, db, M, C, 1, ws, ws_bytes, dt)
+
+    # fused
+    rm2, rv2 = rm0.clone(), rv0.clone()
+    sm2, si2 = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    p2, am2 = torch.empty_like(p), torch.empty_like(am)
+    call("primia_bn_relu_maxpool_fwd", yd, p2, am2, gamma, beta, rm2, rv2, sm2, si2, N, H, H, C, 1e-5, 0.1, ws,
+         ws_bytes, dt)
+    assert torch.equal(p2, p) and torch.equal(am2, am)
+    assert torch.equal(sm2, sm) and torch.equal(si2, si) and torch.equal(rm2, rm) and torch.equal(rv2, rv)
+    dy2, dg2, db2 = torch.empty_like(yd), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_relu_maxpool_bwd", yd, dp, am, dy2, gamma, beta, sm, si, dg2, db2, N, H, H, C, ws, ws_bytes, dt)
+    assert torch.equal(dg2, dg) and torch.equal(db2, db)
+    assert torch.equal(dy2, dy)

@@ -53,14 +53,36 @@ def test_fp32_engine_matches_reference_golden(cuda, golden_dir, name):
             y = y / y.sum(1, keepdim=True)
         else:
             y = torch.randint(0, 3, (batch,), generator=g)
+        chaotic = optimizer != "SGD" and step > 0
+        sd_before = eng.state_dict() if chaotic else None
         logits = eng.forward(x.to(cuda))
         loss = eng.loss_backward(y.to(cuda), soft=soft)
-        # Adam's first update is lr * g / (|g| + 1e-8): discontinuous at g = 0, so gradient
-        # components that are zero up to rounding move by +-lr depending on the rounding of the
-        # platform (CPU vs GPU summation order).  After an Adam step the comparison therefore
-        # loosens to 5e-3; the SGD cases keep the 1e-5 bound on every step, and the Adam kernel
-        # itself is checked to 1e-5 on identical gradients in test_gpu_ops.py.
-        rtol = 1e-5 if (optimizer == "SGD" or step == 0) else 5e-3
+        if chaotic:
+            # Adam's update is lr * m / (sqrt(v) + 1e-8): at step 0 it is lr * g / (|g| + 1e-8), discontinuous
+            # at g = 0, so gradient components that are zero up to rounding move by +-lr depending on the
+            # platform's rounding, and the TRAJECTORY after an Adam step is not comparable with the
+            # reference's beyond ~1e-2 (observed 2e-3 .. 2e-2 on logits as kernels changed summation
+            # order).  From step 1 on, the Adam case therefore checks every step against the ORACLE run
+            # on the engine's own current weights and the same batch — the same bounds as step 0, without
+            # trajectory chaos.  (The Adam kernel is held to 1e-5 on identical gradients in test_gpu_ops.)
+            osd = {k: v.clone() for k, v in sd_before.items()}
+            keys = O.param_keys(osd)
+            for k in keys:
+                osd[k].requires_grad_(True)
+            ol = O.forward(osd, x, True, pooling, size)
+            cwt = torch.tensor(cw) if cw else None
+            oloss = O.cross_entropy_one_hot(ol, y, cwt) if soft else torch.nn.functional.cross_entropy(ol, y, cwt)
+            oloss.backward()
+            err = (logits.cpu().double() - ol.detach().double()).norm() / ol.detach().double().norm()
+            assert err < 1e-5, f"step {step} logits vs oracle on the same weights: {err}"
+            assert abs(loss.item() - oloss.item()) <= 1e-5 * abs(oloss.item())
+            for k, _ in eng.p_entries:
+                gg, go = eng.gviews[k].cpu().double().flatten(), osd[k].grad.double().flatten()
+                assert (gg - go).norm() <= 1e-2 * go.norm() + 1e-9, f"step {step} grad {k} vs oracle"
+            eng.adam_step(lr, (0.5, 0.99), 1e-8, wd)
+            continue
+        # Step 0 and every SGD step are pinned to the reference-derived golden vectors.
+        rtol = 1e-5
         want = gold[f"s{step}.logits"]
         err = np.linalg.norm(logits.double().cpu().numpy() - want) / np.linalg.norm(want)
         assert err < rtol, f"step {step} logits rel err {err}"
@@ -73,7 +95,7 @@ def test_fp32_engine_matches_reference_golden(cuda, golden_dir, name):
         # ~1/sqrt(pixels per channel) of one element (measured on this network at batch 4: a single
         # flip in layer3.1 -> 2e-3 on all earlier layers, while all forward tensors agree to 5e-6).
         # So the end-to-end bound on gradients is 1e-2; logits, loss and post-step weights keep 1e-5.
-        gtol = 1e-2 if (optimizer == "SGD" or step == 0) else 5e-2
+        gtol = 1e-2
         for k, _ in eng.p_entries:
             check_summary(summary(eng.gviews[k]), gold[f"s{step}.grad.{k}"], gtol, f"step {step} grad {k}")
         if optimizer == "SGD":
@@ -91,8 +113,8 @@ def test_fp32_engine_matches_reference_golden(cuda, golden_dir, name):
                 check_summary(summary(v), gold[f"s{step}.post.{k}"], 1e-5, f"step {step} post {k}",
                               abs_norm=lr * gtol * gn, abs_val=20 * lr * gtol * gv)
             else:
-                check_summary(summary(v), gold[f"s{step}.post.{k}"], 5e-3 if step == 0 else 2e-2,
-                              f"step {step} post {k}")
+                # first Adam update = +-lr per component: components with |g| ~ 1e-8 may land on either side
+                check_summary(summary(v), gold[f"s{step}.post.{k}"], 5e-3, f"step {step} post {k}")
 
 
 def test_bf16_engine_tracks_oracle(cuda):
