@@ -161,6 +161,93 @@ __global__ __launch_bounds__(256) void wgrad_finalize_many_kernel(ManyArgs a) {
     }
 }
 
+// ---- tiled forms for every regular conv (C % 64 == 0, c_real == C): one block moves a 32 out-chan x 64
+// in-chan x R*S tile through LDS, so both the OIHW side (contiguous in (c, r, s) per out-chan) and the
+// kernel-layout side (contiguous in c per tap, or in k for the dgrad copy) are accessed in whole rows.
+// The element-wise kernels above gather with a stride of R*S floats and spend ~100 instructions of index
+// arithmetic per element (193 us for the network's 11 M weights; this form: see profiles/).
+struct TileArgs {
+    ManyEntry e[kMaxConvs];
+    int tile_begin[kMaxConvs + 1];
+    int n;
+};
+
+template <typename T, int RS>
+__device__ __forceinline__ void prepare_tile(const ManyEntry& en, int tile, float* lds) {
+    constexpr int ROW = 64 * RS, PITCH = ROW + 1;
+    const int C = en.g.C, K = en.g.K, nct = C / 64;
+    const int kt = tile / nct, ct = tile - kt * nct;
+    const int k0 = kt * 32, c0 = ct * 64;
+    const float* src = en.src + ((long)k0 * C + c0) * RS;
+    for (int idx = threadIdx.x; idx < 32 * ROW; idx += 256) {
+        const int k = idx / ROW, j = idx - k * ROW;
+        lds[k * PITCH + j] = src[(long)k * C * RS + j];
+    }
+    __syncthreads();
+    T* dst = (T*)en.dst;
+    for (int idx = threadIdx.x; idx < 32 * ROW; idx += 256) {
+        const int k = idx / ROW, j = idx - k * ROW;
+        const int t = j >> 6, c = j & 63;
+        Elem<T>::store(dst + (long)(k0 + k) * en.g.klen + t * C + c0 + c, lds[k * PITCH + c * RS + t]);
+    }
+    if (en.dst2) {
+        T* d2 = (T*)en.dst2;  // [C][R][S][K]
+        for (int idx = threadIdx.x; idx < 32 * ROW; idx += 256) {
+            const int k = idx & 31, j = idx >> 5;  // j = c * RS + t
+            Elem<T>::store(d2 + ((long)c0 * RS + j) * K + k0 + k, lds[k * PITCH + j]);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void weight_prepare_tiled_kernel(TileArgs a) {
+    __shared__ float lds[32 * (64 * 9 + 1)];
+    int c = 0;
+    while (c + 1 < a.n && (int)blockIdx.x >= a.tile_begin[c + 1]) ++c;
+    const ManyEntry& en = a.e[c];
+    const int tile = blockIdx.x - a.tile_begin[c];
+    if (en.g.R * en.g.S == 9)
+        prepare_tile<T, 9>(en, tile, lds);
+    else
+        prepare_tile<T, 1>(en, tile, lds);
+}
+
+template <int RS>
+__device__ __forceinline__ void finalize_tile(const ManyEntry& en, int tile, float* lds) {
+    constexpr int ROW = 64 * RS, PITCH = ROW + 1;
+    const int C = en.g.C, nct = C / 64;
+    const int kt = tile / nct, ct = tile - kt * nct;
+    const int k0 = kt * 32, c0 = ct * 64;
+    for (int idx = threadIdx.x; idx < 32 * ROW; idx += 256) {
+        const int k = idx / ROW, j = idx - k * ROW;
+        const int t = j >> 6, c = j & 63;
+        lds[k * PITCH + c * RS + t] = en.src[(long)(k0 + k) * en.g.klen + t * C + c0 + c];
+    }
+    __syncthreads();
+    float* dst = (float*)en.dst + ((long)k0 * C + c0) * RS;
+    for (int idx = threadIdx.x; idx < 32 * ROW; idx += 256) {
+        const int k = idx / ROW, j = idx - k * ROW;
+        dst[(long)k * C * RS + j] = lds[k * PITCH + j];
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_finalize_tiled_kernel(TileArgs a) {
+    __shared__ float lds[32 * (64 * 9 + 1)];
+    int c = 0;
+    while (c + 1 < a.n && (int)blockIdx.x >= a.tile_begin[c + 1]) ++c;
+    const ManyEntry& en = a.e[c];
+    const int tile = blockIdx.x - a.tile_begin[c];
+    if (en.g.R * en.g.S == 9)
+        finalize_tile<9>(en, tile, lds);
+    else
+        finalize_tile<1>(en, tile, lds);
+}
+
+// regular conv that the tiled kernels cover
+static inline bool tiled_ok(const ConvGeom& g, int c_real) {
+    return !g.stem && c_real == g.C && g.C % 64 == 0 && g.K % 32 == 0 && (g.R * g.S == 9 || g.R * g.S == 1);
+}
+
 }  // namespace primia
 
 using namespace primia;
@@ -279,28 +366,49 @@ int primia_conv_weight_prepare_many(const primia_conv_desc* descs, const int* c_
                                     void* const* w_fwd, void* const* w_dgrad, int n, int dtype,
                                     primia_stream_t stream) {
     PRIMIA_REQUIRE(descs && c_real && w_oihw && w_fwd && w_dgrad && n > 0 && n <= kMaxConvs);
-    ManyArgs a;
-    a.n = n;
+    PRIMIA_REQUIRE(dtype == PRIMIA_F32 || dtype == PRIMIA_BF16);
+    ManyArgs a;    // element-wise path: the stem (c_real = 3, padded layout) and anything irregular
+    TileArgs ta;   // tiled path: every regular conv
+    a.n = 0;
+    ta.n = 0;
     long total = 0;
+    int tiles = 0;
     for (int i = 0; i < n; ++i) {
-        PRIMIA_REQUIRE(a.e[i].g.init(descs[i]) && w_oihw[i] && w_fwd[i] && c_real[i] > 0 && c_real[i] <= descs[i].C);
-        PRIMIA_REQUIRE(!w_dgrad[i] || (!a.e[i].g.stem && c_real[i] == descs[i].C));
-        a.e[i].c_real = c_real[i];
-        a.e[i].src = w_oihw[i];
-        a.e[i].dst = w_fwd[i];
-        a.e[i].dst2 = w_dgrad[i];
-        a.e[i].begin = total;
-        total += (long)descs[i].K * a.e[i].g.klen;
-        if (w_dgrad[i]) total += (long)descs[i].C * descs[i].R * descs[i].S * descs[i].K;
+        ManyEntry en;
+        PRIMIA_REQUIRE(en.g.init(descs[i]) && w_oihw[i] && w_fwd[i] && c_real[i] > 0 && c_real[i] <= descs[i].C);
+        PRIMIA_REQUIRE(!w_dgrad[i] || (!en.g.stem && c_real[i] == descs[i].C));
+        en.c_real = c_real[i];
+        en.src = w_oihw[i];
+        en.dst = w_fwd[i];
+        en.dst2 = w_dgrad[i];
+        en.begin = 0;
+        if (tiled_ok(en.g, c_real[i])) {
+            ta.tile_begin[ta.n] = tiles;
+            ta.e[ta.n++] = en;
+            tiles += (descs[i].K / 32) * (descs[i].C / 64);
+        } else {
+            en.begin = total;
+            a.e[a.n++] = en;
+            total += (long)descs[i].K * en.g.klen;
+            if (w_dgrad[i]) total += (long)descs[i].C * descs[i].R * descs[i].S * descs[i].K;
+        }
     }
-    a.total = total;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    if (dtype == PRIMIA_F32)
-        weight_prepare_many_kernel<float><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
-    else if (dtype == PRIMIA_BF16)
-        weight_prepare_many_kernel<bf16><<<blocks, 256, 0, (hipStream_t)stream>>>(a);
-    else
-        return PRIMIA_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (ta.n) {
+        ta.tile_begin[ta.n] = tiles;
+        if (dtype == PRIMIA_F32)
+            weight_prepare_tiled_kernel<float><<<tiles, 256, 0, st>>>(ta);
+        else
+            weight_prepare_tiled_kernel<bf16><<<tiles, 256, 0, st>>>(ta);
+    }
+    if (a.n) {
+        a.total = total;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        if (dtype == PRIMIA_F32)
+            weight_prepare_many_kernel<float><<<blocks, 256, 0, st>>>(a);
+        else
+            weight_prepare_many_kernel<bf16><<<blocks, 256, 0, st>>>(a);
+    }
     return launch_status();
 }
 
@@ -308,20 +416,39 @@ int primia_conv_wgrad_finalize_many(const primia_conv_desc* descs, const int* c_
                                     float* const* dw_oihw, int n, primia_stream_t stream) {
     PRIMIA_REQUIRE(descs && c_real && dw_acc && dw_oihw && n > 0 && n <= kMaxConvs);
     ManyArgs a;
-    a.n = n;
+    TileArgs ta;
+    a.n = 0;
+    ta.n = 0;
     long total = 0;
+    int tiles = 0;
     for (int i = 0; i < n; ++i) {
-        PRIMIA_REQUIRE(a.e[i].g.init(descs[i]) && dw_acc[i] && dw_oihw[i] && c_real[i] > 0 && c_real[i] <= descs[i].C);
-        a.e[i].c_real = c_real[i];
-        a.e[i].src = dw_acc[i];
-        a.e[i].dst = dw_oihw[i];
-        a.e[i].dst2 = nullptr;
-        a.e[i].begin = total;
-        total += (long)descs[i].K * c_real[i] * descs[i].R * descs[i].S;
+        ManyEntry en;
+        PRIMIA_REQUIRE(en.g.init(descs[i]) && dw_acc[i] && dw_oihw[i] && c_real[i] > 0 && c_real[i] <= descs[i].C);
+        en.c_real = c_real[i];
+        en.src = dw_acc[i];
+        en.dst = dw_oihw[i];
+        en.dst2 = nullptr;
+        en.begin = 0;
+        if (tiled_ok(en.g, c_real[i])) {
+            ta.tile_begin[ta.n] = tiles;
+            ta.e[ta.n++] = en;
+            tiles += (descs[i].K / 32) * (descs[i].C / 64);
+        } else {
+            en.begin = total;
+            a.e[a.n++] = en;
+            total += (long)descs[i].K * c_real[i] * descs[i].R * descs[i].S;
+        }
     }
-    a.total = total;
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    wgrad_finalize_many_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(a);
+    hipStream_t st = (hipStream_t)stream;
+    if (ta.n) {
+        ta.tile_begin[ta.n] = tiles;
+        wgrad_finalize_tiled_kernel<<<tiles, 256, 0, st>>>(ta);
+    }
+    if (a.n) {
+        a.total = total;
+        const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        wgrad_finalize_many_kernel<<<blocks, 256, 0, st>>>(a);
+    }
     return launch_status();
 }
 

@@ -423,3 +423,41 @@ def test_bn_relu_maxpool_fused_matches_unfused(cuda, dtype, N, H, C):
     call("primia_bn_relu_maxpool_bwd", yd, dp, am, dy2, gamma, beta, sm, si, dg2, db2, N, H, H, C, ws, ws_bytes, dt)
     assert torch.equal(dg2, dg) and torch.equal(db2, db)
     assert torch.equal(dy2, dy)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batched_weight_prepare_and_finalize_match_single_calls(cuda, dtype):
+    """primia_conv_weight_prepare_many / primia_conv_wgrad_finalize_many (tiled kernels for the regular
+    convs, element-wise for the stem) against the per-conv entry points, bit for bit."""
+    import ctypes
+
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(3)
+    shapes = [(4, 64, 7, 2, 3, 3), (64, 64, 3, 1, 1, 64), (64, 128, 3, 2, 1, 64), (64, 128, 1, 2, 0, 64),
+              (128, 256, 3, 1, 1, 128), (256, 512, 1, 2, 0, 256)]   # C(stored), K, R, stride, pad, c_real
+    descs, creal, w, wf, wd, wf1, wd1, acc, dw, dw1 = [], [], [], [], [], [], [], [], [], []
+    for C, K, R, s, p, cr in shapes:
+        d = ConvDesc.make(2, 16, 16, C, K, R, R, s, p)
+        descs.append(d)
+        creal.append(cr)
+        w.append((torch.randn(K, cr, R, R, generator=g) * 0.1).to(cuda))
+        nf, nd = query("primia_conv_wfwd_elems", d), query("primia_conv_wdgrad_elems", d)
+        wf.append(torch.zeros(nf, dtype=dtype, device=cuda)); wf1.append(torch.zeros(nf, dtype=dtype, device=cuda))
+        has_d = R != 7
+        wd.append(torch.zeros(nd, dtype=dtype, device=cuda) if has_d else None)
+        wd1.append(torch.zeros(nd, dtype=dtype, device=cuda) if has_d else None)
+        acc.append(torch.randn(nf, generator=g).to(cuda))
+        dw.append(torch.zeros(K, cr, R, R, device=cuda)); dw1.append(torch.zeros(K, cr, R, R, device=cuda))
+    n = len(shapes)
+    vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+    arr = lambda ts: (ctypes.c_void_p * n)(*[vp(t) for t in ts])
+    call("primia_conv_weight_prepare_many", (ConvDesc * n)(*descs), (ctypes.c_int * n)(*creal), arr(w), arr(wf),
+         arr(wd), n, dt)
+    call("primia_conv_wgrad_finalize_many", (ConvDesc * n)(*descs), (ctypes.c_int * n)(*creal), arr(acc), arr(dw), n)
+    for i in range(n):
+        call("primia_conv_weight_prepare", descs[i], creal[i], w[i], wf1[i], wd1[i], dt)
+        call("primia_conv_wgrad_finalize", descs[i], creal[i], acc[i], dw1[i])
+        assert torch.equal(wf[i], wf1[i]), f"w_fwd {shapes[i]}"
+        if wd[i] is not None:
+            assert torch.equal(wd[i], wd1[i]), f"w_dgrad {shapes[i]}"
+        assert torch.equal(dw[i], dw1[i]), f"dw {shapes[i]}"
