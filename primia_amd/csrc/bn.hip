@@ -86,7 +86,7 @@ struct StatsFn {
 
 template <typename T>
 struct BwdFn {
-    static constexpr int kUnroll = 1;
+    static constexpr int kUnroll = 2;
     const T* y;
     const T* z;   // may be null (no relu)
     const T* dz;

@@ -176,7 +176,7 @@ class ResNet18Engine:
                                                 torch.empty(N, c.cout, dtype=torch.float32, device=dev))
                               for c in self.spec.convs}
             self.ones_n = torch.ones(N, dtype=torch.float32, device=dev)
-        self.bn_ws = torch.empty(self.bn_ws_bytes, dtype=torch.uint8, device=dev)
+        self.bn_ws = torch.zeros(self.bn_ws_bytes, dtype=torch.uint8, device=dev)  # holds a completion counter
         self.dp = None  # set by dp_backward: {"wgrads": [...]} defers the weight gradients
         self.feat = torch.empty(N, 512, dtype=torch.float32, device=dev)
         self.dfeat = torch.empty(N, 512, dtype=torch.float32, device=dev)

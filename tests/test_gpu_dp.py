@@ -39,7 +39,7 @@ def test_groupnorm_kernels(cuda, dtype, C, relu, res):
     back = lambda t: t.float().cpu().view(N, H, H, C).permute(0, 3, 1, 2)
     dt = _lib.dtype_code(dtype)
     wsb = query("primia_gn_workspace_bytes", N, C, G)
-    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    ws = torch.zeros(wsb, dtype=torch.uint8, device=cuda)
     z = torch.empty(N * HW, C, dtype=dtype, device=cuda)
     sm, si = torch.empty(N * G, device=cuda), torch.empty(N * G, device=cuda)
     call("primia_gn_fwd", nhwc(y), nhwc(r) if res else None, z, gamma.to(cuda), beta.to(cuda), sm, si, N, HW, C, G, 1e-5,

@@ -175,7 +175,7 @@ def test_batchnorm_train(cuda, dtype, C, relu, res, N, H):
     z_ref.backward(dz)
 
     ws_bytes = query("primia_bn_workspace_bytes", M, C)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=cuda)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
     yd = to_nhwc(y, dtype, cuda)
     rd = to_nhwc(r, dtype, cuda) if res else None
     z = torch.empty_like(yd)
@@ -394,7 +394,7 @@ def test_bn_relu_maxpool_fused_matches_unfused(cuda, dtype, N, H, C):
     gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
     beta = torch.randn(C, generator=g).to(cuda)
     ws_bytes = query("primia_bn_workspace_bytes", M, C)
-    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=cuda)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
     rm0, rv0 = torch.randn(C, generator=g).to(cuda), (torch.rand(C, generator=g) + 0.5).to(cuda)
 
     # unfused
