@@ -254,8 +254,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(PatchParams p) {
     // ---- accumulate: lane holds out-chan rows 32*kh + 16*i + fg*4 + j, in-chan column 16*wid + fr ----
     if ((p.debug_skip_epilogue & 1) && acc[0][0][0] != 12345.f) return;
     float* out = p.dw + (long)split * p.split_stride;
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
+    // Blocks that share a (kt, ct) slab finish together and add into the same addresses: start each block at
+    // a different tap so that at any instant the blocks of a slab hit different cache lines.
+    auto flush = [&](int t) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -264,6 +265,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(PatchParams p) {
                 const int e = t * p.C + ct * 64 + 16 * wid + fr;
                 unsafeAtomicAdd(out + (long)k * p.klen + e, acc[t][i][j]);
             }
+    };
+    const int rot = p.debug_skip_epilogue & 8 ? 0 : split % 9;
+#define PRIMIA_FLUSH_FROM(R)                       \
+    case R:                                        \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) flush((t + R) % 9); \
+        break;
+    switch (rot) {
+        PRIMIA_FLUSH_FROM(0)
+        PRIMIA_FLUSH_FROM(1)
+        PRIMIA_FLUSH_FROM(2)
+        PRIMIA_FLUSH_FROM(3)
+        PRIMIA_FLUSH_FROM(4)
+        PRIMIA_FLUSH_FROM(5)
+        PRIMIA_FLUSH_FROM(6)
+        PRIMIA_FLUSH_FROM(7)
+        PRIMIA_FLUSH_FROM(8)
+    }
+#undef PRIMIA_FLUSH_FROM
 }
 
 template <int SW>
