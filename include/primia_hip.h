@@ -49,6 +49,11 @@ int primia_abi_version(void);
  * ------------------------------------------------------------------------------------------ */
 int primia_nchw_to_nhwc(const float* src_nchw, void* dst_nhwc, int N, int C, int H, int W,
                         int c_pad, int dtype, primia_stream_t stream);
+/* The same conversion into a spatially padded destination [N][Hp][Wp][c_pad], interior at
+ * (pad_top, pad_left).  The padding is NOT written: zero the buffer once after allocating it. */
+int primia_nchw_to_nhwc_padded(const float* src_nchw, void* dst, int N, int C, int H, int W, int c_pad,
+                               int pad_top, int pad_left, int Hp, int Wp, int dtype,
+                               primia_stream_t stream);
 int primia_nhwc_to_nchw(const void* src_nhwc, float* dst_nchw, int N, int C, int H, int W,
                         int c_pad, int dtype, primia_stream_t stream);
 /* dst[i] = (dtype) src[i] and back; n elements. */
@@ -87,6 +92,17 @@ int primia_conv_wgrad_finalize_many(const primia_conv_desc* descs_host, const in
 /* y[N,Ho,Wo,K] = conv(x[N,H,W,C], w). */
 int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
                       int dtype, primia_stream_t stream);
+/* conv1 = Conv2d(3, 64, 7, 2, 3) (torchlib/models.py:371-372) on the padded channels-last input
+ * [N][H + 6][W + 8][4] (primia_stem_pad_dims; interior at (3, 3), 4th channel and padding zero): the
+ * filter lives in registers, the input patch is staged once per 8 x 16 output patch and the MFMA
+ * operands are read straight from it.  Same result as primia_conv2d_fwd on the unpadded input.
+ * bf16 only, H and W multiples of 32 (PRIMIA_ERR_UNSUPPORTED otherwise: use primia_conv2d_fwd). */
+int primia_stem_pad_dims(int H, int W, int* Hp, int* Wp);
+int primia_stem_conv_fwd(const void* x_padded, const void* w_fwd, void* y, int N, int H, int W, int dtype,
+                         primia_stream_t stream);
+/* Weight gradient of conv1 from the same padded input (accumulates into dw_acc like primia_conv2d_wgrad). */
+int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, int N, int H, int W, int dtype,
+                           primia_stream_t stream);
 /* Same, and the per-channel sum / sum of squares of y (values as stored) — the batch statistics of the
  * BatchNorm that follows — are accumulated into stat_sums, laid out [slots][2][K] with
  * slots = primia_conv_stat_slots() partial sums (spread to keep atomics uncontended); caller zeroes it. */

@@ -18,6 +18,7 @@ struct WgradParams {
     long split_stride;  // 0: every split accumulates into dw; else split i writes dw + i*split_stride
                         // (per-sample gradients for DP-SGD: one split per image, stride K*klen)
     int persample;
+    int xpad;          // stem only: x is the padded NHWC4p input [N][H+6][W+8][4] (stem_conv.hip)
 };
 
 int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st);

@@ -99,6 +99,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                 // the padded accumulator slots stay exactly 0 (per-sample norms sum the whole slab).
                 const int e0 = b_chunk[j] * CH;
                 const int sx = e0 >> 2;
+                if (p.xpad) {
+                    // padded input: tap (tr, sx) of output pixel (ho, wo) is padded pixel (2*ho + tr, 2*wo + sx)
+                    const long base = (((long)b_n[j] * (p.H + 6) + b_ho[j] * 2 + tr) * (p.W + 8) + b_wo[j] * 2 + sx) * 4;
+                    if (ES == 4) {
+                        if (ok && sx < p.S) v = *(const u32x4*)(x + base);
+                    } else {
+                        u32x2 a = {0, 0}, b = {0, 0};
+                        if (ok && sx < p.S) a = *(const u32x2*)(x + base);
+                        if (ok && sx + 1 < p.S) b = *(const u32x2*)(x + base + 4);
+                        v = u32x4{a[0], a[1], b[0], b[1]};
+                    }
+                } else {
                 const int ws = b_wo[j] * 2 - 3 + sx;
                 const bool rowok = ok && hs >= 0 && hs < p.H;
                 const long base = (((long)b_n[j] * p.H + hs) * p.W + ws) * 4;
@@ -109,6 +121,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
                     if (rowok && sx < p.S && ws >= 0 && ws < p.W) a = *(const u32x2*)(x + base);
                     if (rowok && sx + 1 < p.S && ws + 1 >= 0 && ws + 1 < p.W) b = *(const u32x2*)(x + base + 4);
                     v = u32x4{a[0], a[1], b[0], b[1]};
+                }
                 }
             } else {
                 const int ws = b_wo[j] * p.stride - p.pad + ts;
@@ -264,6 +277,24 @@ using namespace primia;
 static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc, int persample,
                              int dtype, primia_stream_t stream);
 
+extern "C" int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, int N, int H, int W, int dtype,
+                                      primia_stream_t stream) {
+    PRIMIA_REQUIRE(x_padded && dy && dw_acc && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
+    WgradParams p;
+    p.x = x_padded; p.dy = dy; p.dw = dw_acc;
+    p.N = N; p.H = H; p.W = W; p.C = 4; p.K = 64; p.R = 7; p.S = 7; p.stride = 2; p.pad = 3;
+    p.Ho = H / 2; p.Wo = W / 2;
+    p.klen = 256;
+    p.Md = (long)N * p.Ho * p.Wo;
+    p.ntaps = 7;
+    p.persample = 0;
+    p.split_stride = 0;
+    p.xpad = 1;
+    if (dtype == PRIMIA_F32) return launch_wgrad<float, 64, 32, true>(p, (hipStream_t)stream);
+    if (dtype == PRIMIA_BF16) return launch_wgrad<bf16, 64, 32, true>(p, (hipStream_t)stream);
+    return PRIMIA_ERR_ARG;
+}
+
 extern "C" int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,
                                    int dtype, primia_stream_t stream) {
     return conv2d_wgrad_impl(d, x, dy, dw_acc, 0, dtype, stream);
@@ -288,6 +319,7 @@ static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const voi
     p.ntaps = g.stem ? g.R : g.R * g.S;
     p.persample = persample;
     p.split_stride = 0;
+    p.xpad = 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         if (g.stem) return launch_wgrad<float, 64, 32, true>(p, st);

@@ -20,6 +20,23 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     for (int c = 0; c < c_pad; ++c) Elem<T>::store(d + c, c < C ? s[(long)c * HW] : 0.f);
 }
 
+// Same, into a spatially padded destination [N][Hp][Wp][c_pad] (interior at (pad_top, pad_left)); the
+// padding itself is never written — the caller zeroes the buffer once.
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_padded_kernel(const float* __restrict__ src, T* __restrict__ dst,
+                                                                  int C, int H, int W, int c_pad, int pad_top,
+                                                                  int pad_left, int Hp, int Wp, long total) {
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int HW = H * W;
+    const long n = i / HW;
+    const int hw = (int)(i - n * HW);
+    const int h = hw / W, w = hw - h * W;
+    const float* s = src + n * (long)C * HW + hw;
+    T* d = dst + ((n * Hp + h + pad_top) * Wp + w + pad_left) * c_pad;
+    for (int c = 0; c < c_pad; ++c) Elem<T>::store(d + c, c < C ? s[(long)c * HW] : 0.f);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src,
                                                            float* __restrict__ dst, int C, int HW,
@@ -266,6 +283,24 @@ int primia_nchw_to_nhwc(const float* src, void* dst, int N, int C, int H, int W,
         nchw_to_nhwc_kernel<float><<<grid, block, 0, st>>>(src, (float*)dst, C, H * W, c_pad, total);
     else if (dtype == PRIMIA_BF16)
         nchw_to_nhwc_kernel<bf16><<<grid, block, 0, st>>>(src, (bf16*)dst, C, H * W, c_pad, total);
+    else
+        return PRIMIA_ERR_ARG;
+    return launch_status();
+}
+
+int primia_nchw_to_nhwc_padded(const float* src, void* dst, int N, int C, int H, int W, int c_pad, int pad_top,
+                               int pad_left, int Hp, int Wp, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(src && dst && N > 0 && C > 0 && H > 0 && W > 0 && c_pad >= C);
+    PRIMIA_REQUIRE(pad_top >= 0 && pad_left >= 0 && Hp >= H + pad_top && Wp >= W + pad_left);
+    long total = (long)N * H * W;
+    dim3 grid(ceil_div(total, 256)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        nchw_to_nhwc_padded_kernel<float><<<grid, block, 0, st>>>(src, (float*)dst, C, H, W, c_pad, pad_top, pad_left, Hp,
+                                                                  Wp, total);
+    else if (dtype == PRIMIA_BF16)
+        nchw_to_nhwc_padded_kernel<bf16><<<grid, block, 0, st>>>(src, (bf16*)dst, C, H, W, c_pad, pad_top, pad_left, Hp,
+                                                                 Wp, total);
     else
         return PRIMIA_ERR_ARG;
     return launch_status();

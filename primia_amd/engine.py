@@ -117,6 +117,12 @@ class ResNet18Engine:
             return torch.empty(N * hw * hw, ch, dtype=dtype, device=dev)
 
         self.x0 = torch.empty(N * input_size * input_size, 4, dtype=dtype, device=dev)
+        # bf16: the stem also keeps a spatially padded copy of the input for primia_stem_conv_fwd (3 zero rows
+        # above / below, 3 zero columns left, 5 right; zeroed once, only the interior is rewritten)
+        self.x0p = None
+        if dtype == torch.bfloat16 and input_size % 32 == 0:
+            self.x0p_dims = (input_size + 6, input_size + 8)
+            self.x0p = torch.zeros(N * self.x0p_dims[0] * self.x0p_dims[1], 4, dtype=dtype, device=dev)
         self.t = {}  # named tensors
         t = self.t
         t["stem.y"] = act(self.stem_hw, 64)
@@ -153,6 +159,7 @@ class ResNet18Engine:
         # stem tail bn1 -> relu -> maxpool as ONE fused op in training (z = relu(bn(y)) is never written)
         self.fuse_stem = True
         self._stem_fused = False
+        self._stem_padded = False
         self.stat_slots = query("primia_conv_stat_slots")
         per = lambda c: self.stat_slots * 2 * c.cout
         self.stat_sums = torch.zeros(sum(per(c) for c in self.spec.convs), dtype=torch.float32, device=dev)
@@ -311,8 +318,16 @@ class ResNet18Engine:
         x_nchw = x_nchw.contiguous()
         if self.training and self.fuse_stats:
             self.stat_sums.zero_()
-        call("primia_nchw_to_nhwc", x_nchw, self.x0, N, self.spec.in_channels, S, S, 4, self.dt)
-        self._conv_fwd("conv1", self.x0, t["stem.y"])
+        self._stem_padded = self.x0p is not None and not (self.training and self.fuse_stats)
+        if not self._stem_padded or self.norm == "group":  # (the DP path's per-sample stem wgrad reads x0)
+            call("primia_nchw_to_nhwc", x_nchw, self.x0, N, self.spec.in_channels, S, S, 4, self.dt)
+        if self._stem_padded:
+            call("primia_nchw_to_nhwc_padded", x_nchw, self.x0p, N, self.spec.in_channels, S, S, 4, 3, 3,
+                 self.x0p_dims[0], self.x0p_dims[1], self.dt)
+            c = self.convs["conv1"]
+            self._timed("fwd", c, lambda: call("primia_stem_conv_fwd", self.x0p, c.w_fwd, t["stem.y"], N, S, S, self.dt))
+        else:
+            self._conv_fwd("conv1", self.x0, t["stem.y"])
         hw = self.stem_hw
         self._stem_fused = (self.fuse_stem and self.training and self.norm == "batch" and self.spec.pooling == "max"
                             and not self.fuse_stats and N * hw * hw < (1 << 24))
@@ -448,7 +463,12 @@ class ResNet18Engine:
             else:
                 call("primia_avgpool3x3s2_bwd", t["pool.dout"], t["stem.dz"], N, hw, hw, 64, self.dt)
             self._bn_bwd("conv1", t["stem.y"], t["stem.z"], t["stem.dz"], t["stem.dy"], None, True)
-        self._wgrad("conv1", self.x0, t["stem.dy"])
+        if self._stem_padded and self.dp is None:
+            c = self.convs["conv1"]
+            S = self.spec.input_size
+            self._timed("wgrad", c, lambda: call("primia_stem_conv_wgrad", self.x0p, t["stem.dy"], c.acc, N, S, S, self.dt))
+        else:
+            self._wgrad("conv1", self.x0, t["stem.dy"])
         if self.dp is None:
             self._finalize_wgrads()
 

@@ -461,3 +461,51 @@ def test_batched_weight_prepare_and_finalize_match_single_calls(cuda, dtype):
         if wd[i] is not None:
             assert torch.equal(wd[i], wd1[i]), f"w_dgrad {shapes[i]}"
         assert torch.equal(dw[i], dw1[i]), f"dw {shapes[i]}"
+
+
+@pytest.mark.parametrize("N,S", [(2, 64), (3, 32), (1, 96)])
+def test_stem_conv_fwd_padded_matches_conv2d_fwd(cuda, N, S):
+    """primia_stem_conv_fwd on the padded input against torch (bf16 tolerance) and against the generic
+    implicit GEMM on the unpadded input (same accumulation order: bit-identical)."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(S)
+    x = rnd(torch.randn(N, 3, S, S, generator=g), dtype)
+    w = rnd(torch.randn(64, 3, 7, 7, generator=g) * 0.05, dtype)
+    desc = ConvDesc.make(N, S, S, 4, 64, 7, 7, 2, 3)
+    wf, _ = prep_weights(desc, w, dtype, cuda, 3, need_dgrad=False)
+    x4 = torch.empty(N * S * S, 4, dtype=dtype, device=cuda)
+    call("primia_nchw_to_nhwc", x.to(cuda), x4, N, 3, S, S, 4, dt)
+    y_ref = torch.empty(N * (S // 2) ** 2, 64, dtype=dtype, device=cuda)
+    call("primia_conv2d_fwd", desc, x4, wf, y_ref, dt)
+    Hp, Wp = S + 6, S + 8
+    xp = torch.zeros(N * Hp * Wp, 4, dtype=dtype, device=cuda)
+    call("primia_nchw_to_nhwc_padded", x.to(cuda), xp, N, 3, S, S, 4, 3, 3, Hp, Wp, dt)
+    y = torch.full_like(y_ref, float("nan"))
+    call("primia_stem_conv_fwd", xp, wf, y, N, S, S, dt)
+    t_ref = F.conv2d(x, w, None, 2, 3)
+    assert relerr(from_nhwc(y, N, S // 2, S // 2), t_ref) < tol(dtype)
+    assert torch.equal(y, y_ref)
+
+
+def test_stem_conv_wgrad_padded_matches_unpadded(cuda):
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    N, S = 2, 64
+    g = torch.Generator().manual_seed(9)
+    x = rnd(torch.randn(N, 3, S, S, generator=g), dtype)
+    dy = to_nhwc(rnd(torch.randn(N, 64, S // 2, S // 2, generator=g), dtype), dtype, cuda)
+    desc = ConvDesc.make(N, S, S, 4, 64, 7, 7, 2, 3)
+    x4 = torch.empty(N * S * S, 4, dtype=dtype, device=cuda)
+    call("primia_nchw_to_nhwc", x.to(cuda), x4, N, 3, S, S, 4, dt)
+    xp = torch.zeros(N * (S + 6) * (S + 8), 4, dtype=dtype, device=cuda)
+    call("primia_nchw_to_nhwc_padded", x.to(cuda), xp, N, 3, S, S, 4, 3, 3, S + 6, S + 8, dt)
+    n = query("primia_conv_wfwd_elems", desc)
+    a0, a1 = torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    call("primia_conv2d_wgrad", desc, x4, dy, a0, dt)
+    call("primia_stem_conv_wgrad", xp, dy, a1, N, S, S, dt)
+    d0, d1 = torch.empty(64, 3, 7, 7, device=cuda), torch.empty(64, 3, 7, 7, device=cuda)
+    call("primia_conv_wgrad_finalize", desc, 3, a0, d0)
+    call("primia_conv_wgrad_finalize", desc, 3, a1, d1)
+    assert relerr(d1, d0) < 1e-5   # fp32 atomics: order differs run to run
+    assert float(a1.view(64, 256)[:, 7 * 32:].abs().max()) == 0.0 and float(a1.view(64, 8, 8, 4)[:, :, 7].abs().max()) == 0.0
