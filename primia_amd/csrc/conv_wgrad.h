@@ -24,5 +24,7 @@ struct WgradParams {
 int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st);
 // halo-patch kernel (3x3, stride 1, bf16); returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered
 int wgrad_patch_dispatch(const WgradParams& p, hipStream_t st);
+// stem (7x7/2) halo kernel on the padded input (stem_conv.hip)
+int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st);
 
 }  // namespace primia

@@ -291,7 +291,11 @@ extern "C" int primia_stem_conv_wgrad(const void* x_padded, const void* dy, floa
     p.split_stride = 0;
     p.xpad = 1;
     if (dtype == PRIMIA_F32) return launch_wgrad<float, 64, 32, true>(p, (hipStream_t)stream);
-    if (dtype == PRIMIA_BF16) return launch_wgrad<bf16, 64, 32, true>(p, (hipStream_t)stream);
+    if (dtype == PRIMIA_BF16) {
+        const int rc = stem_wgrad_halo_dispatch((const bf16*)x_padded, (const bf16*)dy, dw_acc, N, H, W, (hipStream_t)stream);
+        if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+        return launch_wgrad<bf16, 64, 32, true>(p, (hipStream_t)stream);
+    }
     return PRIMIA_ERR_ARG;
 }
 

@@ -255,3 +255,195 @@ int primia_stem_conv_fwd(const void* x_padded, const void* w_fwd, void* y, int N
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// Weight gradient of conv1 from the padded input (bf16):
+//   dw[k, r*32 + s*4 + c] += sum over pixels dy[n, oy, ox, k] * xp[n, 2*oy + r, 2*ox + s, c]
+// One 8-wave block owns the whole 64 x 256 accumulator (wave (kh, rq): out-channels 32*kh..+31, kernel
+// rows 2*rq, 2*rq+1 = 32 VGPRs) and walks 8 x 16 output patches: the dy tile (128 pixels x 64 channels)
+// and the 21 x 40 input patch are staged once per patch by LDS-DMA; both MFMA operands are transposing
+// reads (ds_read_b64_tr_b16): A from the dy tile, B straight from the input patch, where consecutive
+// output pixels are 16 bytes apart and a kernel row's 32 elements are 64 contiguous bytes.
+// Kernel row 7 and tap s = 7 carry no weight: their accumulator slots are never written (stay zero).
+// =================================================================================================
+namespace primia {
+
+struct StemWgParams {
+    const bf16* xp;
+    const bf16* dy;
+    float* dw;
+    int N, Hp, Wp, Ho, Wo;
+    int PH, PW, PPI;
+    int total, per_block;
+};
+
+__device__ __forceinline__ int stem_key_lin(int slot) { return ((slot >> 1) & 1) | (((slot >> 3) & 1) << 1); }
+
+__global__ __launch_bounds__(512) void stem_conv_wgrad_kernel(StemWgParams p) {
+    constexpr int STAGES = 3;
+    constexpr int XB = 7 * 1024, DYB = 16 * 1024, STAGE = XB + DYB;
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, rq = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tp = fr >> 2, tc8 = (fr & 3) * 8;
+
+    const int t0 = blockIdx.x * p.per_block;
+    int t1 = t0 + p.per_block;
+    if (t1 > p.total) t1 = p.total;
+    const int nstages = t1 - t0;
+    if (nstages <= 0) return;
+
+    int sn = t0 / p.PPI, sph, spw;
+    {
+        const int rem = t0 - sn * p.PPI;
+        sph = rem / p.PW;
+        spw = rem - sph * p.PW;
+    }
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // 23 DMA instructions per stage: 7 input-patch + 16 dy; wave w issues w, w + 8, w + 16 (< 23)
+    auto stage = [&](int buf) {
+        const long xbase = ((long)(sn * p.Hp + sph * 16) * p.Wp + spw * 32) * 4;
+        const long ybase = ((long)(sn * p.Ho + sph * 8) * p.Wo + spw * 16) * 64;
+        if (++spw == p.PW) {
+            spw = 0;
+            if (++sph == p.PH) {
+                sph = 0;
+                ++sn;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 3; ++it) {
+            const int idx = wave + 8 * it;
+            if (idx >= 23) break;
+            const bf16* g;
+            if (idx < 7) {
+                const int G = idx * 64 + lane;
+                const int row = G / 20, c16 = G - row * 20;
+                g = G < 420 ? p.xp + xbase + ((long)row * p.Wp + 2 * c16) * 4 : (const bf16*)kStemZeroPage;
+            } else {
+                const int slot = (idx - 7) * 8 + (lane >> 3), sl = lane & 7;
+                const int chunk = ((((sl >> 1) ^ stem_key_lin(slot)) << 1) | (sl & 1));
+                g = p.dy + ybase + ((long)(slot >> 4) * p.Wo + (slot & 15)) * 64 + chunk * 8;
+            }
+            stem_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + idx * 1024));
+        }
+    };
+
+    f32x4 acc[2][2][2];  // [K fragment i][kernel row rr][element half h]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[i][rr][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // lane-constant parts of the read addresses
+    const int a_slot = 8 * fg + tp;                                      // + 32*ks (+4)
+    const int b_off = ((fg >> 1) * 2) * 320 + 16 * (8 * (fg & 1) + tp) + tc8;  // + (4*ks + r)*320 + 32*h (+64 for the hi read)
+
+    auto compute = [&](int buf) {
+        const char* lx = smem + buf * STAGE;
+        const char* la = lx + XB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t a[2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s0 = 32 * ks + a_slot, s1 = s0 + 4, cg = 2 * kh + i;
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(la + s0 * 128 + ((cg ^ stem_key_lin(s0)) << 5) + tc8));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(la + s1 * 128 + ((cg ^ stem_key_lin(s1)) << 5) + tc8));
+                a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * rq + rr;  // r == 7: no such kernel row (skipped below, wave-uniform)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const char* q = lx + b_off + (4 * ks + r) * 320 + 32 * h;
+                    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)q);
+                    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(q + 64));
+                    b[rr][h] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (2 * rq + rr == 7) continue;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][rr][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[rr][h], acc[i][rr][h], 0, 0, 0);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nstages) stage(s);
+    int cur = 0, nxt = STAGES - 1;
+    for (int s = 0; s < nstages; ++s) {
+        if (s + 1 < nstages) {
+            if (wave < 7)
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (s + STAGES - 1 < nstages) stage(nxt);
+        compute(cur);
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+    }
+
+    // ---- accumulate: lane holds out-chan rows 32*kh + 16*i + 4*fg + j, element r*32 + 16*h + fr ----
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * rq + rr;
+        if (r == 7) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (16 * h + fr >= 28) continue;  // tap s = 7: no weight
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    unsafeAtomicAdd(p.dw + (long)(32 * kh + 16 * i + 4 * fg + j) * 256 + r * 32 + 16 * h + fr, acc[i][rr][h][j]);
+        }
+    }
+}
+
+// PRIMIA_ERR_UNSUPPORTED -> caller uses the per-tap stem kernel of conv_wgrad.hip
+int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st) {
+    if (H % 32 != 0 || W % 32 != 0) return PRIMIA_ERR_UNSUPPORTED;
+    if ((long)N * (H + 6) * (W + 8) * 4 >= (1L << 31) || (long)N * (H / 2) * (W / 2) * 64 >= (1L << 31))
+        return PRIMIA_ERR_UNSUPPORTED;
+    static const bool off = getenv("PRIMIA_STEM_WGRAD") && getenv("PRIMIA_STEM_WGRAD")[0] == 'o';  // old kernel (A/B)
+    if (off) return PRIMIA_ERR_UNSUPPORTED;
+    StemWgParams p;
+    p.xp = xp; p.dy = dy; p.dw = dw;
+    p.N = N; p.Hp = H + 6; p.Wp = W + 8; p.Ho = H / 2; p.Wo = W / 2;
+    p.PH = p.Ho / 8; p.PW = p.Wo / 16; p.PPI = p.PH * p.PW;
+    p.total = N * p.PPI;
+    static const int target = getenv("PRIMIA_STEM_BLOCKS") ? atoi(getenv("PRIMIA_STEM_BLOCKS")) : 256;
+    long per = (p.total + target - 1) / target;
+    if (per < 1) per = 1;
+    p.per_block = (int)per;
+    const int grid = (int)((p.total + per - 1) / per);
+    const size_t lds = (size_t)3 * (7 + 16) * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)stem_conv_wgrad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    stem_conv_wgrad_kernel<<<grid, 512, lds, st>>>(p);
+    return launch_status();
+}
+
+}  // namespace primia

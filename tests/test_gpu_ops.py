@@ -488,10 +488,11 @@ def test_stem_conv_fwd_padded_matches_conv2d_fwd(cuda, N, S):
     assert torch.equal(y, y_ref)
 
 
-def test_stem_conv_wgrad_padded_matches_unpadded(cuda):
+@pytest.mark.parametrize("N,S", [(2, 64), (75, 64), (3, 96)])
+def test_stem_conv_wgrad_padded_matches_unpadded(cuda, N, S):
+    # (75, 64): 600 patches over 256 blocks -> 3 patches per block (multi-stage ring, ragged last block)
     dtype = torch.bfloat16
     dt = _lib.dtype_code(dtype)
-    N, S = 2, 64
     g = torch.Generator().manual_seed(9)
     x = rnd(torch.randn(N, 3, S, S, generator=g), dtype)
     dy = to_nhwc(rnd(torch.randn(N, 64, S // 2, S // 2, generator=g), dtype), dtype, cuda)
@@ -507,5 +508,5 @@ def test_stem_conv_wgrad_padded_matches_unpadded(cuda):
     d0, d1 = torch.empty(64, 3, 7, 7, device=cuda), torch.empty(64, 3, 7, 7, device=cuda)
     call("primia_conv_wgrad_finalize", desc, 3, a0, d0)
     call("primia_conv_wgrad_finalize", desc, 3, a1, d1)
-    assert relerr(d1, d0) < 1e-5   # fp32 atomics: order differs run to run
+    assert relerr(d1, d0) < 2e-5   # fp32 atomics: order differs run to run
     assert float(a1.view(64, 256)[:, 7 * 32:].abs().max()) == 0.0 and float(a1.view(64, 8, 8, 4)[:, :, 7].abs().max()) == 0.0
