@@ -167,35 +167,54 @@ def main():
     for i in range(nprof):
         step(i)
     torch.cuda.synchronize()
-    agg = {}
+    # Launches are grouped by the kernel that serves them (the library's dispatch rules: conv_igemm.hip,
+    # conv_wgrad.hip) so that every group's average duration can be checked against the rocprofv3
+    # per-kernel averages under profiles/.
+    def family(kind, name):
+        sp = eng.convs[name].spec
+        l1 = sp.k == 3 and sp.stride == 1 and sp.cin == 64 and sp.cout == 64
+        if kind == "wgrad":
+            if sp.k == 7:
+                return "stem_conv_wgrad_kernel"
+            return "conv_wgrad_patch_kernel" if (sp.k == 3 and sp.stride == 1) else "conv_wgrad_kernel (per-tap, stride 2 / 1x1)"
+        if sp.k == 7:
+            return "stem_conv_fwd_kernel"
+        if l1:
+            return "conv3x3_c64_kernel"
+        return "conv_igemm_kernel<%s>" % kind
+
+    agg, fam = {}, {}
     for kind, name, flops, e0, e1 in eng.prof:
-        d = agg.setdefault(kind, {"ms": 0.0, "flops": 0.0, "launches": 0})
-        d["ms"] += e0.elapsed_time(e1)
-        d["flops"] += flops
-        d["launches"] += 1
+        ms = e0.elapsed_time(e1)
+        for table, key in ((agg, kind), (fam, family(kind, name))):
+            d = table.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
+            d["ms"] += ms
+            d["flops"] += flops
+            d["launches"] += 1
     eng.prof = None
     peak = MFMA_PEAK_TFLOPS[a.dtype]
-    kernels = {}
-    for kind, d in agg.items():
-        kernels[kind] = {"tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2),
-                         "ms_per_step": round(d["ms"] / nprof, 4),
-                         "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2)}
-    dom = max(agg, key=lambda k: agg[k]["ms"])
+
+    def summarise(table):
+        return {k: {"tflops": round(d["flops"] / (d["ms"] * 1e-3) / 1e12, 2), "ms_per_step": round(d["ms"] / nprof, 4),
+                    "avg_launch_us": round(d["ms"] * 1e3 / d["launches"], 2),
+                    "launches_per_step": d["launches"] // nprof} for k, d in table.items()}
+
+    kernels, by_pass = summarise(fam), summarise(agg)
+    dom = max(fam, key=lambda k: fam[k]["ms"])
     conv_ms = sum(d["ms"] for d in agg.values()) / nprof
     conv_fl = sum(d["flops"] for d in agg.values()) / nprof
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_v2.json")
     if os.path.exists(tpath) and a.batch == 256 and a.size == 224 and a.dtype == "bf16":
         # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the
         # gfx950 correction, + WRITE_SIZE), collected offline on this exact workload: see the file's _note
-        traffic = json.load(open(tpath)).get(dom, {}).get("hbm_bytes_per_launch")
-    roof = {"bound": "mfma", "kernel": {"fwd": "conv_igemm_kernel<fwd>", "dgrad": "conv_igemm_kernel<dgrad>",
-                                        "wgrad": "conv_wgrad_kernel"}[dom],
+        traffic = json.load(open(tpath)).get(dom.split(" ")[0], {}).get("hbm_bytes_per_launch")
+    roof = {"bound": "mfma", "kernel": dom,
             "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic,
             "all_conv": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 3),
                          "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)},
-            "kernels": kernels}
+            "kernels": kernels, "by_pass": by_pass}
 
     ms_per_step = dt / a.steps * 1e3
     total_ips = a.batch * world * a.steps / dt
