@@ -7,6 +7,8 @@
 // Reference semantics: torch.nn.functional.batch_norm as called from nn.BatchNorm2d
 // (torchlib/models.py:261-264, 382): biased variance for normalisation, unbiased for the running
 // estimate, momentum 0.1, eps 1e-5.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace primia {
@@ -434,8 +436,10 @@ struct PoolBwdFn {
 };
 
 static inline void reduce_geometry(long M, int C, int& nblk, long& rows_per_block) {
-    // >= 256 rows per block so the fp32 in-block accumulation stays short; <= 1024 blocks.
-    long nb = (M + 255) / 256;
+    // <= 1024 blocks; at least `min_rows` rows per block (PRIMIA_BN_MINROWS, default 64: the small late
+    // layers are latency-bound with few blocks — 256 rows per block left layer4 with 49 blocks).
+    static const long min_rows = getenv("PRIMIA_BN_MINROWS") ? atol(getenv("PRIMIA_BN_MINROWS")) : 64;
+    long nb = (M + min_rows - 1) / min_rows;
     if (nb > kMaxPartialBlocks) nb = kMaxPartialBlocks;
     if (nb < 1) nb = 1;
     rows_per_block = (M + nb - 1) / nb;
