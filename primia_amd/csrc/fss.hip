@@ -14,7 +14,45 @@ namespace primia {
 typedef unsigned long long u64;
 typedef unsigned int u32;
 
-__device__ __forceinline__ u64 ror64(u64 x, int n) { return (x >> n) | (x << (64 - n)); }
+// 64-bit rotate / shift / 3-way xor on explicit 32-bit halves: v_alignbit_b32 and v_bitop3_b32 are full-rate
+// 32-bit ops, where the generic (x >> n) | (x << (64 - n)) compiles to two 64-bit shifts plus two ORs.
+// n is a compile-time constant after unrolling.
+__device__ __forceinline__ u64 ror64(u64 x, int n) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    u32 rl, rh;
+    if (n < 32) {
+        rl = __builtin_amdgcn_alignbit(hi, lo, n);
+        rh = __builtin_amdgcn_alignbit(lo, hi, n);
+    } else if (n == 32) {
+        rl = hi;
+        rh = lo;
+    } else {
+        rl = __builtin_amdgcn_alignbit(lo, hi, n - 32);
+        rh = __builtin_amdgcn_alignbit(hi, lo, n - 32);
+    }
+    return ((u64)rh << 32) | rl;
+}
+__device__ __forceinline__ u64 shr64(u64 x, int n) {  // 0 < n < 32
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    return ((u64)(hi >> n) << 32) | __builtin_amdgcn_alignbit(hi, lo, n);
+}
+__device__ __forceinline__ u64 xor3_64(u64 a, u64 b, u64 c) {
+    const u32 lo = __builtin_amdgcn_bitop3_b32((u32)a, (u32)b, (u32)c, 0x96);
+    const u32 hi = __builtin_amdgcn_bitop3_b32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32), 0x96);
+    return ((u64)hi << 32) | lo;
+}
+// Ch(e, f, g) = (e & f) ^ (~e & g) (truth table 0xCA) and Maj(a, b, c) (0xE8), one v_bitop3_b32 per half
+__device__ __forceinline__ u64 bitop64(u64 a, u64 b, u64 c, int tt) {
+    u32 lo, hi;
+    if (tt == 0xCA) {
+        lo = __builtin_amdgcn_bitop3_b32((u32)a, (u32)b, (u32)c, 0xCA);
+        hi = __builtin_amdgcn_bitop3_b32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32), 0xCA);
+    } else {
+        lo = __builtin_amdgcn_bitop3_b32((u32)a, (u32)b, (u32)c, 0xE8);
+        hi = __builtin_amdgcn_bitop3_b32((u32)(a >> 32), (u32)(b >> 32), (u32)(c >> 32), 0xE8);
+    }
+    return ((u64)hi << 32) | lo;
+}
 __device__ __forceinline__ u32 ror32(u32 x, int n) { return (x >> n) | (x << (32 - n)); }
 __device__ __forceinline__ u64 bswap64(u64 x) { return __builtin_bswap64(x); }
 __device__ __forceinline__ u32 bswap32(u32 x) { return __builtin_bswap32(x); }
@@ -59,20 +97,20 @@ __device__ __forceinline__ void sha512_seed(u64 s0, u64 s1, u64 out[8]) {
     w[15] = 128;
     u64 a = 0x6a09e667f3bcc908ULL, b = 0xbb67ae8584caa73bULL, c = 0x3c6ef372fe94f82bULL, d = 0xa54ff53a5f1d36f1ULL,
         e = 0x510e527fade682d1ULL, f = 0x9b05688c2b3e6c1fULL, g = 0x1f83d9abfb41bd6bULL, h = 0x5be0cd19137e2179ULL;
-#pragma unroll
+#pragma clang loop unroll(full)
     for (int i = 0; i < 80; ++i) {
         u64 wi;
         if (i < 16) {
             wi = w[i];
         } else {
             const u64 w15 = w[(i - 15) & 15], w2 = w[(i - 2) & 15];
-            const u64 g0 = ror64(w15, 1) ^ ror64(w15, 8) ^ (w15 >> 7);
-            const u64 g1 = ror64(w2, 19) ^ ror64(w2, 61) ^ (w2 >> 6);
+            const u64 g0 = xor3_64(ror64(w15, 1), ror64(w15, 8), shr64(w15, 7));
+            const u64 g1 = xor3_64(ror64(w2, 19), ror64(w2, 61), shr64(w2, 6));
             wi = w[i & 15] + g0 + w[(i - 7) & 15] + g1;
             w[i & 15] = wi;
         }
-        const u64 t1 = h + (ror64(e, 14) ^ ror64(e, 18) ^ ror64(e, 41)) + ((e & f) ^ (~e & g)) + K512[i] + wi;
-        const u64 t2 = (ror64(a, 28) ^ ror64(a, 34) ^ ror64(a, 39)) + ((a & b) ^ (a & c) ^ (b & c));
+        const u64 t1 = h + xor3_64(ror64(e, 14), ror64(e, 18), ror64(e, 41)) + bitop64(e, f, g, 0xCA) + K512[i] + wi;
+        const u64 t2 = xor3_64(ror64(a, 28), ror64(a, 34), ror64(a, 39)) + bitop64(a, b, c, 0xE8);
         h = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
     }
     out[0] = bswap64(a + 0x6a09e667f3bcc908ULL);
@@ -137,7 +175,7 @@ __device__ __forceinline__ HSide h_side(const u64 buf[8], int side) {
 __device__ __forceinline__ long conv31(u64 last_word) { return (long)(last_word & 0x7fffffffULL); }
 
 // ---- DIF.eval (fss.py:400-428) ------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void dif_eval_kernel(int b, const u32* __restrict__ x, const u64* __restrict__ s0,
+__global__ __launch_bounds__(256, 2) void dif_eval_kernel(int b, const u32* __restrict__ x, const u64* __restrict__ s0,
                                                        const uint8_t* __restrict__ cw_bits,
                                                        const u64* __restrict__ cw_sigma, const u64* __restrict__ cw_s,
                                                        const int32_t* __restrict__ cw_leaf, int64_t* __restrict__ out,
@@ -200,7 +238,7 @@ __global__ __launch_bounds__(256) void dpf_eval_kernel(int b, const u32* __restr
 }
 
 // ---- DIF.keygen (fss.py:344-398), one comparison per lane --------------------------------------------
-__global__ __launch_bounds__(256) void dif_keygen_kernel(const u64* __restrict__ alpha, const u64* __restrict__ s0p,
+__global__ __launch_bounds__(256, 2) void dif_keygen_kernel(const u64* __restrict__ alpha, const u64* __restrict__ s0p,
                                                          uint8_t* __restrict__ cw_bits, u64* __restrict__ cw_sigma,
                                                          u64* __restrict__ cw_s, int32_t* __restrict__ cw_leaf,
                                                          long n) {

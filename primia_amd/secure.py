@@ -222,7 +222,7 @@ class SecureContext:
     def sub_public_scalar(self, a, value):
         """AST - int (additive_shared.py:453-484, 506-524): the constant becomes a FRESH random
         sharing of shape [1] that is subtracted share-wise (broadcast)."""
-        c = torch.tensor([value], dtype=I64, device=a[0].device)
+        c = torch.full((1,), int(value), dtype=I64, device=a[0].device)  # device-side fill: graph-capturable
         return self.sub(a, self.share(c))
 
     # ---- Beaver -----------------------------------------------------------------------------------
