@@ -119,6 +119,12 @@ int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy
  * image n's gradient in slab n. */
 int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,
                                   float* dw_ps, int dtype, primia_stream_t stream);
+/* The DP-SGD norm pass without the per-sample gradients themselves: sqnorm[n] += ||dW_n||_F^2 (fp64,
+ * accumulated across calls, i.e. across layers).  Every kernel block of the per-sample form holds one
+ * sample's complete gradient tile in registers, so the squares are summed there and the N x |W| slab
+ * (11 GB per step for ResNet-18 at batch 256) is never written, zeroed or re-read. */
+int primia_conv2d_wgrad_persample_sqnorm(const primia_conv_desc* d, const void* x, const void* dy,
+                                         double* sqnorm, int dtype, primia_stream_t stream);
 /* dw_oihw[K][c_real][R][S] = transpose(dw_acc) (drops padding). */
 int primia_conv_wgrad_finalize(const primia_conv_desc* d, int c_real, const float* dw_acc,
                                float* dw_oihw, primia_stream_t stream);

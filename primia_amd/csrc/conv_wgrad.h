@@ -18,8 +18,17 @@ struct WgradParams {
     long split_stride;  // 0: every split accumulates into dw; else split i writes dw + i*split_stride
                         // (per-sample gradients for DP-SGD: one split per image, stride K*klen)
     int persample;
+    double* sqnorm;    // per-sample mode: if set, split i adds the squared L2 norm of ITS gradient tile to
+                       // sqnorm[i] instead of writing the tile (the DP-SGD norm pass needs nothing else)
     int xpad;          // stem only: x is the padded NHWC4p input [N][H+6][W+8][4] (stem_conv.hip)
 };
+
+// sum over the wave of the squares of `n` accumulator values per lane, added (fp64 atomic) to *dst
+__device__ __forceinline__ void wave_sqnorm_add(double s, double* dst) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(dst, s);
+}
 
 int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st);
 // halo-patch kernel (3x3, stride 1, bf16); returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered

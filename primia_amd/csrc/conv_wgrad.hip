@@ -227,6 +227,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     }
 
     // ---- accumulate: lane holds rows (out-chan) fg*4+reg, column (in-chan) fr ---------------------
+    if (p.sqnorm) {  // per-sample norm pass: this block's tile is the sample's complete gradient tile
+        double sq = 0.0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sq += (double)acc[i][j][r] * (double)acc[i][j][r];
+        wave_sqnorm_add(sq, p.sqnorm + split);
+        return;
+    }
     const int ebase = STEM ? tr * 32 : tap * p.C + ct * BNC;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -275,7 +286,7 @@ static int launch_wgrad(WgradParams p, hipStream_t st) {
 using namespace primia;
 
 static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc, int persample,
-                             int dtype, primia_stream_t stream);
+                             int dtype, primia_stream_t stream, double* sqnorm = nullptr);
 
 extern "C" int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, int N, int H, int W, int dtype,
                                       primia_stream_t stream) {
@@ -290,6 +301,7 @@ extern "C" int primia_stem_conv_wgrad(const void* x_padded, const void* dy, floa
     p.persample = 0;
     p.split_stride = 0;
     p.xpad = 1;
+    p.sqnorm = nullptr;
     if (dtype == PRIMIA_F32) return launch_wgrad<float, 64, 32, true>(p, (hipStream_t)stream);
     if (dtype == PRIMIA_BF16) {
         const int rc = stem_wgrad_halo_dispatch((const bf16*)x_padded, (const bf16*)dy, dw_acc, N, H, W, (hipStream_t)stream);
@@ -309,9 +321,15 @@ extern "C" int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const vo
     return conv2d_wgrad_impl(d, x, dy, dw_ps, 1, dtype, stream);
 }
 
+extern "C" int primia_conv2d_wgrad_persample_sqnorm(const primia_conv_desc* d, const void* x, const void* dy,
+                                                    double* sqnorm, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(sqnorm);
+    return conv2d_wgrad_impl(d, x, dy, nullptr, 1, dtype, stream, sqnorm);
+}
+
 static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc, int persample,
-                             int dtype, primia_stream_t stream) {
-    PRIMIA_REQUIRE(d && x && dy && dw_acc);
+                             int dtype, primia_stream_t stream, double* sqnorm) {
+    PRIMIA_REQUIRE(d && x && dy && (dw_acc || sqnorm));
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
     WgradParams p;
@@ -324,6 +342,7 @@ static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const voi
     p.persample = persample;
     p.split_stride = 0;
     p.xpad = 0;
+    p.sqnorm = sqnorm;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         if (g.stem) return launch_wgrad<float, 64, 32, true>(p, st);
@@ -498,6 +517,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradParams p) {
         }
     }
 
+    if (p.sqnorm) {
+        double sq = 0.0;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) sq += (double)acc[i][j][t] * (double)acc[i][j][t];
+        wave_sqnorm_add(sq, p.sqnorm + split);
+        return;
+    }
     const int ebase = tap * p.C + ct * BNC;
 #pragma unroll
     for (int i = 0; i < FM; ++i)

@@ -54,6 +54,7 @@ struct PatchParams {
     int total;                // sub-patches overall
     int per_block;            // sub-patches per block (even)
     long split_stride;
+    double* sqnorm;           // per-sample norm pass (see WgradParams::sqnorm)
     int debug_skip_epilogue;  // timing experiments only (PRIMIA_WGP_NOEPI=1)
 };
 
@@ -253,6 +254,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(PatchParams p) {
 
     // ---- accumulate: lane holds out-chan rows 32*kh + 16*i + fg*4 + j, in-chan column 16*wid + fr ----
     if ((p.debug_skip_epilogue & 1) && acc[0][0][0] != 12345.f) return;
+    if (p.sqnorm) {
+        double sq = 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sq += (double)acc[t][i][j] * (double)acc[t][i][j];
+        wave_sqnorm_add(sq, p.sqnorm + split);
+        return;
+    }
     float* out = p.dw + (long)split * p.split_stride;
     // Blocks that share a (kt, ct) slab finish together and add into the same addresses: start each block at
     // a different tap so that at any instant the blocks of a slab hit different cache lines.
@@ -307,6 +319,7 @@ static int launch_patch(const WgradParams& w, hipStream_t st) {
     p.per_block = (int)per;
     const long nsplit = (p.total + per - 1) / per;
     p.split_stride = w.persample ? (long)w.K * w.klen : 0;
+    p.sqnorm = w.persample ? w.sqnorm : nullptr;
     static const int noepi = getenv("PRIMIA_WGP_NOEPI") ? atoi(getenv("PRIMIA_WGP_NOEPI")) : 0;
     p.debug_skip_epilogue = noepi;
     constexpr int XS = (SH + 2) * (SW == 8 ? 12 : 18);

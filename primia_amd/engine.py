@@ -486,8 +486,9 @@ class ResNet18Engine:
         Needs norm="group".  `noise` (fp32 [P], standard normal) may be given for reproducibility.
 
         How: one ordinary backward pass yields every layer's activation gradient dy (samples are
-        independent under GroupNorm).  Pass 1 forms per-sample weight gradients layer by layer in a
-        scratch slab (one wgrad split per image) only to accumulate ||g_n||^2; then each sample's rows of
+        independent under GroupNorm).  Pass 1 runs the weight-gradient kernels with one pixel split per image
+        and has every block add the squares of ITS (complete) per-sample tile to ||g_n||^2 — the per-sample
+        gradients are never written; then each sample's rows of
         dy are scaled by its clip factor and the ordinary batched wgrad — linear in dy — produces
         sum_n clip_n * g_n directly."""
         if self.norm != "group":
@@ -515,15 +516,9 @@ class ResNet18Engine:
                 call("primia_persample_sqnorm", psg, N, psg.shape[1], sq)
                 call("primia_persample_sqnorm", psb, N, psb.shape[1], sq)
                 mark(b)
-            need = max(self.convs[n].wfwd_n for n, _, _ in self.dp["wgrads"]) * N
-            if getattr(self, "_ps_scratch", None) is None or self._ps_scratch.numel() < need:
-                self._ps_scratch = torch.empty(need, dtype=torch.float32, device=dev)
             for name, x, dy in self.dp["wgrads"]:
                 c = self.convs[name]
-                slab = self._ps_scratch[:N * c.wfwd_n]
-                slab.zero_()
-                call("primia_conv2d_wgrad_persample", c.desc, x, dy, slab, self.dt)
-                call("primia_persample_sqnorm", slab, N, c.wfwd_n, sq)  # zero padding adds nothing
+                call("primia_conv2d_wgrad_persample_sqnorm", c.desc, x, dy, sq, self.dt)
                 mark(name)
             clip = torch.empty(N, dtype=torch.float32, device=dev)
             call("primia_dp_clip_factors", sq, clip, N, float(max_grad_norm))

@@ -109,3 +109,31 @@ def test_dp_sgd_gradient_matches_oracle(cuda):
     eng.forward(x.to(cuda))
     eng.dp_loss_backward(y.to(cuda), 1.0, 0.0, noise=torch.zeros(eng.P, device=cuda))
     assert eng.grads.double().norm().item() <= 1.0 + 1e-4
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("case", [(3, 16, 64, 64, 3, 1, 1), (2, 16, 64, 128, 3, 2, 1), (3, 8, 256, 256, 3, 1, 1),
+                                  (2, 8, 256, 512, 1, 2, 0), (3, 32, 4, 64, 7, 2, 3), (5, 14, 128, 128, 3, 1, 1)])
+def test_persample_sqnorm_matches_slab_norms(cuda, dtype, case):
+    """primia_conv2d_wgrad_persample_sqnorm (norms summed inside the wgrad kernels) against the explicit
+    per-sample slabs of primia_conv2d_wgrad_persample + primia_persample_sqnorm, for every kernel family
+    (patch, per-tap, LDS-DMA, stem)."""
+    from primia_amd._lib import ConvDesc
+
+    N, H, C, K, R, s, p = case
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(H * C + K)
+    d = ConvDesc.make(N, H, H, C, K, R, R, s, p)
+    x = (torch.randn(N * H * H, C, generator=g)).to(dtype).to(cuda)
+    if R == 7:
+        x[:, 3] = 0  # 4th stem channel is padding
+    dy = torch.randn(N * d.Ho * d.Wo, K, generator=g).to(dtype).to(cuda)
+    n = query("primia_conv_wfwd_elems", d)
+    slab = torch.zeros(N, n, device=cuda)
+    call("primia_conv2d_wgrad_persample", d, x, dy, slab, dt)
+    sq_ref = torch.zeros(N, dtype=torch.float64, device=cuda)
+    call("primia_persample_sqnorm", slab, N, n, sq_ref)
+    sq = torch.full((N,), 0.5, dtype=torch.float64, device=cuda)   # accumulates on top of what is there
+    call("primia_conv2d_wgrad_persample_sqnorm", d, x, dy, sq, dt)
+    assert rel(sq - 0.5, sq_ref) < 1e-6
+    assert rel(sq_ref, (slab.double() ** 2).sum(1)) < 1e-10
