@@ -250,11 +250,20 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(T* x, const float* __re
 // out[c] = sum_n w[n] * x[n][c]
 __global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               float* __restrict__ out, int N, int C) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    // block = 16 columns x 16 row slices (a single thread per column walking all N rows took 95 us per call,
+    // 42 calls per DP-SGD step); slices are combined in a fixed order: deterministic
+    __shared__ double part[16][17];
+    const int cl = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     double s = 0.0;
-    for (int n = 0; n < N; ++n) s += (double)w[n] * (double)x[(long)n * C + c];
-    out[c] = (float)s;
+    if (c < C)
+        for (int n = rs; n < N; n += 16) s += (double)w[n] * (double)x[(long)n * C + c];
+    part[rs][cl] = s;
+    __syncthreads();
+    if (rs == 0 && c < C) {
+        for (int k = 1; k < 16; ++k) s += part[k][cl];
+        out[c] = (float)s;
+    }
 }
 
 // ps[n] = [ outer(dy[n], x[n]) (out_f x in_f) | dy[n] (out_f) ]: per-sample fc gradients
@@ -397,7 +406,7 @@ int primia_scale_rows(void* x, const float* s, int N, int64_t elems_per_sample, 
 
 int primia_weighted_colsum(const float* x, const float* w, float* out, int N, int C, primia_stream_t stream) {
     PRIMIA_REQUIRE(x && w && out && N > 0 && C > 0);
-    weighted_colsum_kernel<<<(C + 255) / 256, 256, 0, (hipStream_t)stream>>>(x, w, out, N, C);
+    weighted_colsum_kernel<<<(C + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, out, N, C);
     return launch_status();
 }
 
