@@ -23,6 +23,8 @@
 
 namespace primia {
 
+constexpr bool kUpfront = true;
+
 struct IgemmParams {
     const void* src;
     const void* wt;
@@ -285,21 +287,26 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
         const char* lp = smem + buf * (TILE_P + TILE_W);
         const char* lw = lp + TILE_P;
         if constexpr (sizeof(T) == 2) {
+            // all fragment reads of the k-step (both 32-element halves) are issued before the first MFMA: the
+            // LDS latency is paid once per k-step instead of once per half
+            bf16x8_t a[2][FM], b[2][FN];
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                bf16x8_t a[FM], b[FN];
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
-                    a[i] = *(const bf16x8_t*)(lw + lds_off(crow0 + 16 * i, kk * 4 + fg));
+                    a[kk][i] = *(const bf16x8_t*)(lw + lds_off(crow0 + 16 * i, kk * 4 + fg));
 #pragma unroll
                 for (int j = 0; j < FN; ++j)
-                    b[j] = *(const bf16x8_t*)(lp + lds_off(prow0 + 16 * j, kk * 4 + fg));
+                    b[kk][j] = *(const bf16x8_t*)(lp + lds_off(prow0 + 16 * j, kk * 4 + fg));
+            }
+            if (kUpfront) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
                     for (int j = 0; j < FN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
         } else {
             // lane's k-set = floats of chunk fg and chunk fg+4 (any k order works as long as
             // both operands agree); MFMA t consumes float t of every lane.
