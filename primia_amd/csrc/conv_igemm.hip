@@ -98,6 +98,9 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
         tm -= cls * p.ntm_class;
         cls_ph = cls >> 1;
         cls_pw = cls & 1;
+        // a class without taps (1x1 / stride 2: three of the four) adds nothing: when accumulating, leave its
+        // pixels alone instead of reading and rewriting them
+        if (p.accumulate && (cls_ph >= p.R || cls_pw >= p.S)) return;
     }
     const long m0 = (long)tm * BM;
     const int Hc = (DGRAD && p.s2_classes) ? p.Hd >> 1 : p.Hd, Wc = (DGRAD && p.s2_classes) ? p.Wd >> 1 : p.Wd;
