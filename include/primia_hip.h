@@ -130,6 +130,21 @@ int primia_conv_wgrad_finalize(const primia_conv_desc* d, int c_real, const floa
                                float* dw_oihw, primia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Data path in front of the step: MixUp pair mixing (torchlib/utils.py:337-400), one-hot
+ * targets (utils.py:449-466) and per-channel dataset statistics (torchlib/dataloader.py:220-247).
+ * ------------------------------------------------------------------------------------------ */
+/* out[i] = lam * x[i] + one_minus_lam * x[L/2 + i] for i < L/2 over rows of `per_sample` floats (three
+ * roundings, like the reference's expression); an odd trailing sample is copied to out[L/2].  The same call
+ * mixes the one-hot targets (per_sample = classes).  out has ceil(L/2) rows. */
+int primia_mixup(const float* x, float* out_x, int64_t L, int64_t per_sample, float lam, float one_minus_lam,
+                 primia_stream_t stream);
+int primia_to_one_hot(const int64_t* labels, float* out, int64_t n, int classes, primia_stream_t stream);
+/* mean[c], std[c] (unbiased) of an NCHW fp32 tensor over (N, H, W) = torch.std_mean(dim=(0,2,3)). */
+int64_t primia_channel_stats_workspace_bytes(int C);
+int primia_channel_mean_std(const float* x_nchw, int64_t N, int C, int64_t HW, float* mean, float* stdv,
+                            void* workspace, int64_t workspace_bytes, primia_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * BatchNorm2d (+ fused ReLU / residual add) — replaces F.batch_norm, F.relu and Tensor.__iadd__
  * (torchlib/models.py:261-264, 268-284, 382-383); torch defaults momentum 0.1, eps 1e-5.
  * Tensors are [M, C] with M = N*H*W.

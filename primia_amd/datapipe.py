@@ -1,0 +1,135 @@
+"""Device-side data path in front of the training step: MixUp, one-hot targets,
+dataset mean/std and the client split — the reference's torchlib classes with the arithmetic on the GPU.
+
+  MixUp(λ, p)            torchlib/utils.py:327-400   (same constructor, same use of random.random())
+  To_one_hot(classes)    torchlib/utils.py:444-466
+  calc_mean_std(data)    torchlib/dataloader.py:220-247
+  iid_round_robin_split  data/server_simulation/distribute_data.py:62-74 (seed 0, i::num_workers)
+  label_skew_split       the non-IID shards BASELINE.json configs[2] asks for (the reference only ships the
+                         IID split): each client draws its class proportions from Dirichlet(alpha).
+
+The HIP kernels are mandatory (primia_amd._lib raises when the library is missing); there is no CPU fallback.
+"""
+from random import random
+from typing import Optional
+
+import numpy as np
+import torch
+
+from ._lib import call, query
+
+_DEV = "cuda"
+
+
+def _dev(t):
+    return t if t.is_cuda else t.to(_DEV)
+
+
+class MixUp(torch.nn.Module):
+    def __init__(self, λ: Optional[float] = None, p: Optional[float] = None):
+        super().__init__()
+        assert 0.0 <= p <= 1.0, "probability needs to be in [0,1]"
+        self.p = p
+        if λ:
+            assert 0.0 <= λ <= 1.0, "mix factor needs to be in [0,1]"
+        self.λ = λ
+
+    def forward(self, x):
+        assert len(x) == 2, "need data and target"
+        x, y = x
+        if self.p:
+            if random() > self.p:
+                if torch.is_tensor(x):
+                    return x, y
+                return x[0], y[0]
+        if torch.is_tensor(x):
+            L = x.shape[0]
+        elif type(x) == tuple and all(x[i].shape == x[i - 1].shape for i in range(1, len(x))):
+            L = len(x)
+        else:
+            raise ValueError("images need to be either list of equally shaped tensors or batch of size 2")
+        if not ((torch.is_tensor(y) and y.shape[0] == L)
+                or (len(y) == L and all(y[i - 1].shape == y[i].shape for i in range(1, len(y))))):
+            raise ValueError("targets need to be tuple of equally shaped one hot encoded tensors")
+        if L == 1:
+            return x, y
+        λ = self.λ if self.λ else random()
+        if not torch.is_tensor(x):
+            x = torch.stack(x).squeeze(1)
+        if not torch.is_tensor(y):
+            y = torch.stack(y).squeeze(1)
+        return self._mix(x, λ), self._mix(y, λ)
+
+    @staticmethod
+    def _mix(t, lam):
+        t = _dev(t).to(torch.float32).contiguous()
+        L = t.shape[0]
+        out = torch.empty(((L + 1) // 2, *t.shape[1:]), dtype=torch.float32, device=t.device)
+        per = t[0].numel()
+        # the scalars as torch sees them: float32(λ) and float32(1.0 - λ), the latter formed in double
+        call("primia_mixup", t, out, L, per, float(np.float32(lam)), float(np.float32(1.0 - lam)))
+        return out
+
+
+class To_one_hot(torch.nn.Module):
+    def __init__(self, num_classes, device=_DEV):
+        super().__init__()
+        self.num_classes = num_classes
+        self.device = device
+
+    def forward(self, x):
+        if type(x) in (int, list):
+            x = torch.tensor(x)
+        scalar = x.dim() == 0
+        lab = _dev(x.reshape(-1).to(torch.int64)).contiguous()
+        out = torch.empty(lab.shape[0], self.num_classes, dtype=torch.float32, device=lab.device)
+        call("primia_to_one_hot", lab, out, lab.shape[0], self.num_classes)
+        return out[0] if scalar else out
+
+
+def calc_mean_std(data):
+    """`data`: the stacked dataset [N, C, ...] (or a list / dataset of equally shaped samples).  Per-channel
+    statistics when C is 1 or 3, over everything otherwise — exactly the reference's rule.  Returns (mean, std)."""
+    if not torch.is_tensor(data):
+        data = torch.stack([d[0] if isinstance(d, (tuple, list)) else d for d in data])
+    data = _dev(data).to(torch.float32).contiguous()
+    N, C = data.shape[0], data.shape[1]
+    if C in (1, 3):
+        n, c, hw = N, C, data[0, 0].numel()
+    else:
+        n, c, hw = 1, 1, data.numel()
+    mean = torch.empty(c, dtype=torch.float32, device=data.device)
+    std = torch.empty(c, dtype=torch.float32, device=data.device)
+    wsb = query("primia_channel_stats_workspace_bytes", c)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=data.device)
+    call("primia_channel_mean_std", data, n, c, hw, mean, std, ws, wsb)
+    return (mean, std) if C in (1, 3) else (mean[0], std[0])
+
+
+def iid_round_robin_split(n_items, num_workers, seed=0):
+    """The reference's split (distribute_data.py:62-74): shuffle with random.seed(0), deal i::num_workers."""
+    import random as _r
+
+    idx = list(range(n_items))
+    rng = _r.Random()
+    rng.seed(seed)
+    rng.shuffle(idx)
+    return [idx[i::num_workers] for i in range(num_workers)]
+
+
+def label_skew_split(labels, num_workers, alpha=0.5, seed=0):
+    """Non-IID client shards by label skew: for every class the samples are divided between the clients in
+    proportions drawn from Dirichlet(alpha) (small alpha = strong skew).  Every sample is assigned exactly
+    once; deterministic in `seed`.  Returns a list of index lists."""
+    labels = np.asarray(labels)
+    rng = np.random.default_rng(seed)
+    shards = [[] for _ in range(num_workers)]
+    for c in np.unique(labels):
+        idx = np.flatnonzero(labels == c)
+        rng.shuffle(idx)
+        cuts = (np.cumsum(rng.dirichlet([alpha] * num_workers)) * len(idx)).astype(int)[:-1]
+        for w, part in enumerate(np.split(idx, cuts)):
+            shards[w].extend(part.tolist())
+    for s in shards:
+        s.sort()
+    return shards

@@ -68,6 +68,26 @@ def fedavg_allreduce(flat, out, weight=None, secure=False, precision_fractional=
     return out
 
 
+def exchange_mean_std(mean, std, group=None, ops=None, precision_fractional=3, base=10):
+    """setup_pysyft's secure average of the clients' data statistics (torchlib/utils.py:764-794): each rank
+    holds its local (mean, std); they are fixed-point encoded (`fix_precision()` defaults: 10^3), summed in
+    the 2^64 ring across the ranks (one int64 all-reduce — additive sharing commutes with the ring sum),
+    decoded and divided by the number of clients.  Returns (mean, std) as the reference's `val_mean_std`."""
+    ops = ops or HipArenaOps()
+    K = dist.get_world_size(group) if dist.is_initialized() else 1
+    both = torch.cat([mean.reshape(-1), std.reshape(-1)]).to(torch.float32).contiguous()
+    q = torch.empty(both.numel(), dtype=torch.int64, device=both.device)
+    scale = float(base ** precision_fractional)
+    ops.encode(both, q, scale)
+    if K > 1:
+        dist.all_reduce(q, op=dist.ReduceOp.SUM, group=group)
+    out = torch.empty_like(both)
+    ops.decode(q, out, scale)
+    ops.divide(out, float(K))
+    n = mean.numel()
+    return out[:n].reshape(mean.shape), out[n:].reshape(std.shape)
+
+
 class SyncSchedule:
     """Which batches end with a FedAvg sync and who adopts the result — the control flow of
     secure_aggregation_epoch (utils.py:1159-1230), shared by every rank."""

@@ -307,11 +307,27 @@ def train_federated(args, model, device, train_loaders, optimizer, epoch, loss_f
 
 def train(args, model, device, train_loader, optimizer, epoch, loss_fn, num_classes=3, vis_params=None,
           verbose=True):
-    """torchlib/utils.py:1236-1292 — local (non-federated) epoch."""
+    """torchlib/utils.py:1236-1292 — local (non-federated) epoch, incl. the on-device MixUp of :1249-1267."""
     losses = []
+    if getattr(args, "mixup", False):
+        from ._lib import PrimiaError
+        from .datapipe import MixUp, To_one_hot
+
+        mixup = MixUp(λ=args.mixup_lambda, p=args.mixup_prob)
+        oh_converter = To_one_hot(num_classes)
     for batch_idx, (data, target) in enumerate(train_loader):
+        soft = False
+        if getattr(args, "mixup", False):
+            target = oh_converter(target)
+            data, target = mixup((data, target))
+            soft = True
+            if data.shape[0] != model.N:
+                raise PrimiaError(
+                    "MixUp produced a batch of {:d}, the engine is built for {:d}: with mixup_prob < 1 the batch "
+                    "size changes from step to step; use mixup_prob = 1.0 (batch_size is doubled, as the reference "
+                    "does) or build the engine for the mixed size".format(data.shape[0], model.N))
         model.forward(data)
-        loss = model.loss_backward(target)
+        loss = model.loss_backward(target, soft=soft)
         if args.optimizer == "SGD":
             model.sgd_step(optimizer["lr"], args.weight_decay)
         else:

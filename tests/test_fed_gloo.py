@@ -63,6 +63,13 @@ def _worker(rank, world, port, tmp):
     res["input_untouched"] = torch.equal(arenas[rank], sds[rank]["a"])
     counts = fed.all_gather_int(3 + rank)
     res["gather"] = counts == [3, 4]
+    # secure mean/std exchange of setup_pysyft (utils.py:764-794), fix_precision() = 10^3
+    from oracle import datapipe_oracle as D
+    means = [torch.tensor([0.48, 0.52, 0.4371]), torch.tensor([0.5125, 0.4999, 0.61])]
+    stds = [torch.tensor([0.2219, 0.25, 0.3]), torch.tensor([0.19, 0.2451, 0.2777])]
+    m, sd = fed.exchange_mean_std(means[rank], stds[rank], ops=ops)
+    om, osd = D.exchange_mean_std(means, stds)
+    res["mean_std_exchange"] = torch.equal(m, om) and torch.equal(sd, osd)
     torch.save(res, os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 
