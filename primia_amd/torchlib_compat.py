@@ -109,6 +109,9 @@ def _cfg_get(config, section, key, kind, fallback):
 
 
 class Arguments:
+    # pickles as torchlib.utils.Arguments, the path the reference's checkpoints use (utils.py:1489); the
+    # `torchlib` shim package at the repository root resolves it back to this class
+    __module__ = "torchlib.utils"
     """Same attributes, fallbacks and side effects as the reference's Arguments."""
 
     def __init__(self, cmd_args, config, mode: str = "train", verbose: bool = True):

@@ -79,3 +79,28 @@ def _opener_worker(rank, port, tmp):
 def test_dist_opener_two_parties(tmp_path):
     mp.spawn(_opener_worker, args=(29700 + os.getpid() % 1000, str(tmp_path)), nprocs=2, join=True)
     assert all(torch.load(os.path.join(str(tmp_path), f"o{r}.pt")) for r in range(2))
+
+
+def test_torchlib_shim_and_checkpoint_argument_pickle(tmp_path):
+    """A checkpoint's pickled `args` names torchlib.utils.Arguments (utils.py:1489): the shim package resolves
+    it to the HIP-backed class, both for files we write and for a reference-style pickle."""
+    import pickle
+
+    import torch
+
+    import torchlib.utils as tu
+    from primia_amd.torchlib_compat import Arguments
+
+    assert tu.Arguments is Arguments and Arguments.__module__ == "torchlib.utils"
+    a = Arguments.__new__(Arguments)
+    a.batch_size, a.lr, a.model = 8, 1e-3, "resnet-18"
+    blob = pickle.dumps(a)
+    assert b"torchlib.utils" in blob
+    b = pickle.loads(blob)
+    assert isinstance(b, Arguments) and b.batch_size == 8 and b.model == "resnet-18"
+    p = tmp_path / "ckpt.pt"
+    torch.save({"epoch": 3, "args": a, "val_mean_std": torch.zeros(2, 3)}, p)
+    st = torch.load(p, weights_only=False)
+    assert isinstance(st["args"], Arguments) and st["epoch"] == 3
+    from torchlib.run_websocket_server import read_websocket_config  # noqa: F401
+    from torchlib.utils import LearningRateScheduler, MixUp, To_one_hot, train_federated  # noqa: F401

@@ -1,0 +1,13 @@
+"""`torchlib.utils` names of the hot path, re-exported from primia_amd (see torchlib/__init__.py)."""
+from primia_amd.datapipe import MixUp, To_one_hot, calc_mean_std  # noqa: F401
+from primia_amd.torchlib_compat import (  # noqa: F401
+    Arguments,
+    LearningRateScheduler,
+    aggregation,
+    save_model,
+    secure_aggregation_epoch,
+    send_new_models,
+    test,
+    train,
+    train_federated,
+)
