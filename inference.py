@@ -52,6 +52,9 @@ if __name__ == "__main__":
     parser.add_argument("--cuda", action="store_true", help="Use GPU acceleration (always on here).")
     parser.add_argument("--http_protocol", action="store_true", help="accepted for compatibility")
     parser.add_argument("--num_images", type=int, default=4)
+    parser.add_argument("--hip_graph", action="store_true",
+                        help="encrypted inference: capture the online phase once as a hipGraph and replay it per image "
+                             "(the dealer refills the primitive buffers between images)")
     cmd_args = parser.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("primia_amd runs inference on the GPU only (HIP kernels); no GPU visible")
@@ -69,8 +72,13 @@ if __name__ == "__main__":
     total_pred = []
     if args.encrypted_inference:
         # inference.py:279-286: fix_precision(precision_fractional=16, dtype="long").share(..., protocol="fss")
-        ctx = SecureContext(Dealer(device, seed=0), base=10, precision_fractional=16)
-        model = SecureResNet18(ctx, sd, input_size=size)
+        if cmd_args.hip_graph:
+            from primia_amd.secure import GraphedSecureInference
+
+            model = GraphedSecureInference(sd, device, input_size=size, precision_fractional=16, seed=0)
+        else:
+            ctx = SecureContext(Dealer(device, seed=0), base=10, precision_fractional=16)
+            model = SecureResNet18(ctx, sd, input_size=size)
         for i in range(images.shape[0]):
             out = model(images[i:i + 1].to(device))
             total_pred.append(int(out.argmax(dim=1).item()))

@@ -47,6 +47,7 @@ class Dealer:
         self.gen.manual_seed(seed)
         self.log = None  # set to a list to record every primitive handed out (tests replay it)
         self.tape = None  # set to a list to keep every primitive ON THE DEVICE (offline phase, see PreloadedDealer)
+        self.requests = None  # set to a list to record (method, args) of every request (GraphedSecureInference)
 
     def rand64(self, *shape):
         return torch.randint(-2 ** 63, 2 ** 63 - 1, shape, dtype=I64, device=self.device, generator=self.gen)
@@ -58,6 +59,8 @@ class Dealer:
         return [r, s1]
 
     def triple(self, op, xshape, yshape):
+        if self.requests is not None:
+            self.requests.append(("triple", (op, tuple(xshape), tuple(yshape))))
         a, b = self.rand64(*xshape), self.rand64(*yshape)
         if op == "mul":
             # element-wise with the smaller operand broadcast over the leading dims
@@ -77,6 +80,8 @@ class Dealer:
         return t
 
     def dif_keys(self, n):
+        if self.requests is not None:
+            self.requests.append(("dif_keys", (n,)))
         dev = self.device
         alpha = torch.randint(0, 2 ** 32, (n,), dtype=I64, device=dev, generator=self.gen)
         s0 = self.rand64(2, 2, n)
@@ -97,6 +102,8 @@ class Dealer:
         return keys
 
     def const_mask(self, *shape):
+        if self.requests is not None:
+            self.requests.append(("const_mask", tuple(shape)))
         r = self.rand64(*shape)
         if self.log is not None:
             self.log.append(("mask", r.cpu().numpy()))
@@ -501,3 +508,59 @@ class SecureResNet18:
         xs = c.share(c.encode(image))
         out = self.forward_shares(xs)
         return c.decode(c.reconstruct(out))
+
+
+def _copy_primitive(dst, src):
+    """In-place refill of one tape entry (tensor, tuple/list of tensors, or key dicts) from a fresh one."""
+    if torch.is_tensor(dst):
+        dst.copy_(src)
+    elif isinstance(dst, dict):
+        for k in dst:
+            _copy_primitive(dst[k], src[k])
+    else:
+        for d, s_ in zip(dst, src):
+            _copy_primitive(d, s_)
+
+
+class GraphedSecureInference:
+    """Serving form of the encrypted forward: the online phase (about 6,500 small launches per image) is
+    captured ONCE as a hipGraph over static buffers — the input image and every correlated-randomness
+    primitive — and replayed per image; `refill()` has the dealer regenerate all per-image primitives into
+    the same buffers (the reference's pre-provisioned crypto store, mpc/primitives.py:161-235, refilled
+    between requests).  Results are bit-identical to the eager SecureResNet18 fed the same primitives."""
+
+    def __init__(self, state_dict, device, input_size=224, precision_fractional=16, base=10, seed=0, blocks=None):
+        self.device = torch.device(device)
+        self.image = torch.zeros(1, 3, input_size, input_size, dtype=torch.float32, device=self.device)
+        self.dealer = Dealer(self.device, seed)
+        self.dealer.tape, self.dealer.requests = [], []
+        ctx = SecureContext(self.dealer, base, precision_fractional)
+        model = SecureResNet18(ctx, state_dict, input_size, blocks)
+        self._n_model = len(self.dealer.tape)          # primitives consumed by sharing the model (kept)
+        model(self.image)                              # offline pass: fills the tape, warms every kernel
+        self.tape, self.requests = self.dealer.tape, self.dealer.requests
+        self.dealer.tape = self.dealer.requests = None
+        self.stats = dict(ctx.stats)
+        pre = PreloadedDealer(self.tape, self.device)
+        self._ctx = SecureContext(pre, base, precision_fractional)
+        self._model = SecureResNet18(self._ctx, state_dict, input_size, blocks)   # re-shares with the same masks
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.out = self._model(self.image)
+        torch.cuda.current_stream().wait_stream(side)
+
+    def refill(self):
+        """Fresh per-image primitives from the dealer, written into the captured buffers."""
+        for i in range(self._n_model, len(self.tape)):
+            kind, args = self.requests[i]
+            _copy_primitive(self.tape[i], getattr(self.dealer, kind)(*args))
+
+    def __call__(self, image, refill=True):
+        if refill:
+            self.refill()
+        self.image.copy_(image)
+        self.graph.replay()
+        return self.out

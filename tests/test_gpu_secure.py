@@ -233,3 +233,24 @@ def test_mini_resnet_encrypted_forward_bit_exact(cuda, pf):
     dec = ctx.decode(ctx.reconstruct(out)).cpu().numpy()
     assert np.array_equal(dec, S.fix_decode(S.reconstruct(*oout), 10, pf))
     assert ctx.stats["dif_evals"] > 10000
+
+
+def test_graphed_inference_matches_eager_and_refills(cuda):
+    """The captured online phase replays bit-identically to the eager forward on the same primitives, and a
+    refill (fresh dealer randomness, same buffers) decodes to the same logits up to fixed-point noise."""
+    from primia_amd.secure import GraphedSecureInference, PreloadedDealer
+
+    gen = torch.Generator().manual_seed(21)
+    sd = mini_state_dict(gen)
+    blocks = [("layer1.0", 1), ("layer2.0", 2)]
+    g = GraphedSecureInference(sd, cuda, input_size=16, precision_fractional=16, seed=5, blocks=blocks)
+    img = torch.randn(1, 3, 16, 16, generator=gen).to(cuda)
+    out_g = g(img, refill=False).clone()
+    ctx = SecureContext(PreloadedDealer(g.tape, cuda), 10, 16)
+    out_e = SecureResNet18(ctx, sd, 16, blocks)(img)
+    assert torch.equal(out_g, out_e)
+    before = g.tape[-1].clone() if torch.is_tensor(g.tape[-1]) else None
+    out_r = g(img).clone()          # new primitives, same image
+    assert torch.allclose(out_r, out_g, atol=1e-3)
+    if before is not None:
+        assert not torch.equal(before, g.tape[-1])
