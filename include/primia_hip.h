@@ -107,6 +107,11 @@ int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, 
  * BatchNorm that follows — are accumulated into stat_sums, laid out [slots][2][K] with
  * slots = primia_conv_stat_slots() partial sums (spread to keep atomics uncontended); caller zeroes it. */
 int primia_conv_stat_slots(void);
+/* Slots the kernel chosen for `d` writes: kernels that own whole output rows (layer1's 64->64 convolution)
+ * emit one deterministic partial per block, written rather than accumulated (no zeroing needed); the
+ * generic kernel accumulates into primia_conv_stat_slots() zeroed slots.  Size stat_sums for this count
+ * and pass it as `slots` to primia_bn_fwd_train_from_sums. */
+int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype);
 int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
                             float* stat_sums, int dtype, primia_stream_t stream);
 /* dx[N,H,W,C] = conv_transpose(dy[N,Ho,Wo,K], w).  If accumulate != 0, dx += (dx is read). */

@@ -50,6 +50,7 @@ struct C64Params {
     int PH, PW, PPI;  // 8x8 patches per image column / row / image
     int total;        // patches overall
     int per_block;    // patches per block (even)
+    float* stat_partials;  // if set: per-block BatchNorm partial sums [grid][2][64] of the values AS STORED
     int debug;        // timing experiments only (PRIMIA_C64_DEBUG): 1 no stores, 2 no staging, 4 no MFMA loop
 };
 
@@ -207,6 +208,13 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     };
 
     // write-back of one stage's rows: 16 row groups (8 pixels x 128 B = 1 KiB contiguous in memory), 2 per wave
+    // BatchNorm batch statistics of the NEXT layer, for free: the write-back lane holds 8 stored channels of one
+    // pixel; per-lane fp32 sums over the block's pixels, combined per block at the end (deterministic), replace
+    // a full read pass over the output (primia_bn_fwd_train_from_sums consumes the per-block partials).
+    float st1[8], st2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.f;
+
     auto writeback = [&](int obuf) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -215,8 +223,19 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
             const int opx2 = g * 8 + px;
             const u32x4 v = *(const u32x4*)(sout + obuf * OUTB + q * 8192 + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
             const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
-            if (cw.t < t1 && ho < p.H && wo < p.W && !((p.debug & 1) && v[0] != 12345u))
+            if (cw.t < t1 && ho < p.H && wo < p.W && !((p.debug & 1) && v[0] != 12345u)) {
                 *(u32x4*)(p.dst + ((long)(cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8) = v;
+                if (p.stat_partials) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float lo = __uint_as_float(v[k] << 16), hi = __uint_as_float(v[k] & 0xffff0000u);
+                        st1[2 * k] += lo;
+                        st2[2 * k] += lo * lo;
+                        st1[2 * k + 1] += hi;
+                        st2[2 * k + 1] += hi * hi;
+                    }
+                }
+            }
             advance(cw);
         }
     };
@@ -253,15 +272,52 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     }
     __syncthreads();
     writeback((nstages - 1) & 1);
+    if (p.stat_partials) {
+        // lanes with equal (lane & 7) hold the same 8 channels: fold the 8 pixel lanes, then the 8 waves
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                st1[k] += __shfl_xor(st1[k], o, 64);
+                st2[k] += __shfl_xor(st2[k], o, 64);
+            }
+        }
+        __syncthreads();
+        float* red = (float*)smem;  // [8 waves][2][64]
+        if (lane < 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                red[(wave * 2 + 0) * 64 + lane * 8 + k] = st1[k];
+                red[(wave * 2 + 1) * 64 + lane * 8 + k] = st2[k];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += red[w * 128 + tid];
+            p.stat_partials[(long)blockIdx.x * 128 + tid] = a;   // [block][2][64]
+        }
+    }
 }
 
 // returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the implicit GEMM)
+int conv3x3_c64_grid(int N, int H, int W) {
+    const long total = (long)N * ((H + 7) / 8) * ((W + 7) / 8);
+    static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 256;
+    long per = (total + target - 1) / target;
+    per = (per + 1) & ~1L;
+    if (per < 2) per = 2;
+    return (int)((total + per - 1) / per);
+}
+
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
-                         hipStream_t st) {
+                         hipStream_t st, float* stat_partials) {
     if ((long)N * H * W * 64 >= (1L << 31)) return PRIMIA_ERR_UNSUPPORTED;
     C64Params p;
     p.src = src; p.wt = wt; p.dst = dst;
     p.N = N; p.H = H; p.W = W; p.flip = flip; p.accumulate = accumulate;
+    p.stat_partials = stat_partials;
     p.PH = (H + 7) / 8; p.PW = (W + 7) / 8; p.PPI = p.PH * p.PW;
     p.total = N * p.PPI;
     static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 256;

@@ -529,7 +529,8 @@ using namespace primia;
 
 namespace primia {
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
-                         hipStream_t st);
+                         hipStream_t st, float* stat_partials = nullptr);
+int conv3x3_c64_grid(int N, int H, int W);
 }
 
 // layer1 shape (3x3, stride 1, pad 1, 64 -> 64 channels, bf16): weight-stationary halo kernel (conv3x3_c64.hip);
@@ -562,8 +563,9 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
         p.nsteps = g.stem ? 7 : g.klen / 32;
         return dispatch_igemm<float, false>(p, g.stem, st);
     } else if (dtype == PRIMIA_BF16) {
-        if (!stat_sums && use_c64(g)) {
-            const int rc = conv3x3_c64_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, 0, 0, st);
+        if (use_c64(g)) {  // (its statistics are per-block partials, see primia_conv_stat_slots_for)
+            const int rc = conv3x3_c64_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, 0, 0, st,
+                                                stat_sums);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         }
         p.nsteps = g.klen / 64;
@@ -578,6 +580,13 @@ int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fw
 }
 
 int primia_conv_stat_slots(void) { return kStatSlots; }
+
+int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
+    if (dtype == PRIMIA_BF16 && use_c64(g) && (long)g.N * g.H * g.W * 64 < (1L << 31)) return conv3x3_c64_grid(g.N, g.H, g.W);
+    return kStatSlots;
+}
 
 int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stat_sums,
                             int dtype, primia_stream_t stream) {

@@ -161,12 +161,21 @@ class ResNet18Engine:
         self._stem_fused = False
         self._stem_padded = False
         self.stat_slots = query("primia_conv_stat_slots")
-        per = lambda c: self.stat_slots * 2 * c.cout
+        for c in self.spec.convs:   # slots the kernel serving this conv writes (per-block partials for layer1's)
+            self.convs[c.name].stat_slots = (query("primia_conv_stat_slots_for", self.convs[c.name].desc, self.dt)
+                                             if c.name != "conv1" else self.stat_slots)
+        per = lambda c: self.convs[c.name].stat_slots * 2 * c.cout
         self.stat_sums = torch.zeros(sum(per(c) for c in self.spec.convs), dtype=torch.float32, device=dev)
         off = 0
         for c in self.spec.convs:
             self.convs[c.name].sums = self.stat_sums[off:off + per(c)]
             off += per(c)
+        # Layers whose conv kernel emits the BatchNorm partial sums for free (deterministic per-block partials out
+        # of the write-back phase): the statistics pass over their output is dropped.  Decided per layer,
+        # independent of the global `fuse_stats` experiment above.
+        self.free_stats = {c.name for c in self.spec.convs
+                           if dtype == torch.bfloat16 and norm == "batch" and c.name != "conv1"
+                           and self.convs[c.name].stat_slots != self.stat_slots}
         self.save = {}
         for c in self.spec.convs:
             b = bn_name(c.name)
@@ -278,9 +287,10 @@ class ResNet18Engine:
         rm, rv = self.views[b + ".running_mean"], self.views[b + ".running_var"]
         if self.training:
             sm, si = self.save[b]
-            if self.fuse_stats:
+            if self.fuse_stats or conv_name in self.free_stats:
                 call("primia_bn_fwd_train_from_sums", y, residual, z, g, be, rm, rv, sm, si,
-                     self.convs[conv_name].sums, self.stat_slots, M, C, BN_EPS, BN_MOMENTUM, int(relu), self.dt)
+                     self.convs[conv_name].sums, self.convs[conv_name].stat_slots, M, C, BN_EPS, BN_MOMENTUM,
+                     int(relu), self.dt)
             else:
                 call("primia_bn_fwd_train", y, residual, z, g, be, rm, rv, sm, si, M, C, BN_EPS, BN_MOMENTUM,
                      int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
@@ -305,7 +315,7 @@ class ResNet18Engine:
 
     def _conv_fwd(self, name, x, y):
         c = self.convs[name]
-        if self.training and self.fuse_stats:
+        if self.training and (self.fuse_stats or name in self.free_stats):
             self._timed("fwd", c, lambda: call("primia_conv2d_fwd_stats", c.desc, x, c.w_fwd, y, c.sums, self.dt))
         else:
             self._timed("fwd", c, lambda: call("primia_conv2d_fwd", c.desc, x, c.w_fwd, y, self.dt))

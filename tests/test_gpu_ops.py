@@ -510,3 +510,41 @@ def test_stem_conv_wgrad_padded_matches_unpadded(cuda, N, S):
     call("primia_conv_wgrad_finalize", desc, 3, a1, d1)
     assert relerr(d1, d0) < 2e-5   # fp32 atomics: order differs run to run
     assert float(a1.view(64, 256)[:, 7 * 32:].abs().max()) == 0.0 and float(a1.view(64, 8, 8, 4)[:, :, 7].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("N,H", [(3, 16), (2, 56), (5, 12)])
+def test_layer1_conv_emits_batchnorm_partials(cuda, N, H):
+    """The 64->64 kernel's per-block BatchNorm partials: summed over the slots they equal the column sums of
+    the output AS STORED, and bn_fwd_train_from_sums on them matches bn_fwd_train on the same output."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(H)
+    x = to_nhwc(rnd(torch.randn(N, 64, H, H, generator=g), dtype), dtype, cuda)
+    w = rnd(torch.randn(64, 64, 3, 3, generator=g) * 0.05, dtype)
+    desc = ConvDesc.make(N, H, H, 64, 64, 3, 3, 1, 1)
+    wf, _ = prep_weights(desc, w, dtype, cuda, 64)
+    slots = query("primia_conv_stat_slots_for", desc, dt)
+    assert 1 <= slots <= 256 and slots != query("primia_conv_stat_slots")
+    M = N * H * H
+    y = torch.empty(M, 64, dtype=dtype, device=cuda)
+    sums = torch.full((slots, 2, 64), float("nan"), device=cuda)   # written, not accumulated
+    call("primia_conv2d_fwd_stats", desc, x, wf, y, sums, dt)
+    y2 = torch.empty_like(y)
+    call("primia_conv2d_fwd", desc, x, wf, y2, dt)
+    assert torch.equal(y, y2)
+    yf = y.float()
+    assert relerr(sums[:, 0].sum(0), yf.sum(0)) < 1e-5 and relerr(sums[:, 1].sum(0), (yf * yf).sum(0)) < 1e-5
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(cuda), torch.randn(64, generator=g).to(cuda)
+    ws_bytes = query("primia_bn_workspace_bytes", M, 64)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
+    outs = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(64, device=cuda), torch.ones(64, device=cuda)
+        sm, si, z = torch.empty(64, device=cuda), torch.empty(64, device=cuda), torch.empty_like(y)
+        if fused:
+            call("primia_bn_fwd_train_from_sums", y, None, z, gamma, beta, rm, rv, sm, si, sums, slots, M, 64, 1e-5, 0.1, 1, dt)
+        else:
+            call("primia_bn_fwd_train", y, None, z, gamma, beta, rm, rv, sm, si, M, 64, 1e-5, 0.1, 1, ws, ws_bytes, dt)
+        outs.append((sm, si, rm, rv, z.float()))
+    for a, b in zip(*outs):
+        assert relerr(a, b) < 1e-5
