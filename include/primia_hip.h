@@ -100,6 +100,12 @@ int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fw
 int primia_stem_pad_dims(int H, int W, int* Hp, int* Wp);
 int primia_stem_conv_fwd(const void* x_padded, const void* w_fwd, void* y, int N, int H, int W, int dtype,
                          primia_stream_t stream);
+/* The same, also emitting bn1's per-block partial sums [slots][2][64] (slots = primia_stem_conv_stat_slots) for
+ * primia_bn_relu_maxpool_fwd_from_sums / primia_bn_fwd_train_from_sums: the statistics pass over the 411 MB
+ * stem output is dropped. */
+int primia_stem_conv_stat_slots(int N, int H, int W);
+int primia_stem_conv_fwd_stats(const void* x_padded, const void* w_fwd, void* y, float* stat_partials, int N, int H,
+                               int W, int dtype, primia_stream_t stream);
 /* Weight gradient of conv1 from the same padded input (accumulates into dw_acc like primia_conv2d_wgrad). */
 int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, int N, int H, int W, int dtype,
                            primia_stream_t stream);
@@ -198,6 +204,12 @@ int primia_bn_relu_maxpool_fwd(const void* y, void* pooled, uint8_t* argmax, con
                                float* save_mean, float* save_invstd, int N, int H, int W, int C, float eps,
                                float momentum, void* workspace, int64_t workspace_bytes, int dtype,
                                primia_stream_t stream);
+/* The same with the batch sums already available as [slots][2][C] partials (from the conv kernel). */
+int primia_bn_relu_maxpool_fwd_from_sums(const void* y, void* pooled, uint8_t* argmax, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var,
+                                         float* save_mean, float* save_invstd, const float* sums, int slots, int N,
+                                         int H, int W, int C, float eps, float momentum, int dtype,
+                                         primia_stream_t stream);
 /* Its backward: from dpooled and the argmax codes to dy / dgamma / dbeta; the pool's input gradient
  * is gathered and ReLU-masked inside BatchNorm's reduction pass.  Same results as
  * primia_maxpool3x3s2_bwd followed by primia_bn_bwd(relu = 1).  N*H*W < 2^24. */

@@ -651,6 +651,33 @@ int primia_bn_relu_maxpool_fwd(const void* y, void* pooled, uint8_t* argmax, con
     return PRIMIA_ERR_ARG;
 }
 
+int primia_bn_relu_maxpool_fwd_from_sums(const void* y, void* pooled, uint8_t* argmax, const float* gamma,
+                                         const float* beta, float* running_mean, float* running_var,
+                                         float* save_mean, float* save_invstd, const float* sums, int slots, int N,
+                                         int H, int W, int C, float eps, float momentum, int dtype,
+                                         primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && pooled && argmax && gamma && beta && save_mean && save_invstd && sums && slots >= 1);
+    PRIMIA_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    PRIMIA_REQUIRE(N > 0 && H > 0 && W > 0 && bn_shape_ok((long)N * H * W, C, dtype));
+    hipStream_t st = (hipStream_t)stream;
+    const long M = (long)N * H * W;
+    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(sums, slots, C, M, 0, eps, momentum, save_mean, save_invstd,
+                                                       running_mean, running_var);
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    if (dtype == PRIMIA_F32) {
+        const long total = (long)N * Ho * Wo * (C / 4);
+        bn_relu_pool_fwd_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            (const float*)y, (float*)pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, Ho, Wo);
+    } else if (dtype == PRIMIA_BF16) {
+        const long total = (long)N * Ho * Wo * (C / 8);
+        bn_relu_pool_fwd_kernel<bf16><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            (const bf16*)y, (bf16*)pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, Ho, Wo);
+    } else {
+        return PRIMIA_ERR_ARG;
+    }
+    return launch_status();
+}
+
 int primia_bn_relu_maxpool_bwd(const void* y, const void* dpooled, const uint8_t* argmax, void* dy,
                                const float* gamma, const float* beta, const float* save_mean,
                                const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W, int C,

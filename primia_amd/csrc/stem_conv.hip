@@ -36,6 +36,7 @@ struct StemFwdParams {
     int N, Hp, Wp, Ho, Wo;
     int PH, PW, PPI;  // 8 x 16 patches per image column / row / image
     int total, per_block;
+    float* stat_partials;  // if set: per-block BatchNorm partial sums [grid][2][64] of the values as stored
 };
 
 __global__ __launch_bounds__(512) void stem_conv_fwd_kernel(StemFwdParams p) {
@@ -163,6 +164,11 @@ __global__ __launch_bounds__(512) void stem_conv_fwd_kernel(StemFwdParams p) {
 
     // write-back of one stage: 2 patches x 8 output rows of 16 pixels x 128 B = 2 KiB contiguous each; wave w
     // stores row w of both patches (two 1-KiB instructions per row)
+    // bn1's batch statistics for free (see conv3x3_c64.hip): per-lane sums of the 8 stored channels it writes
+    float st1[8], st2[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.f;
+
     auto writeback = [&](int obuf) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
@@ -173,7 +179,19 @@ __global__ __launch_bounds__(512) void stem_conv_fwd_kernel(StemFwdParams p) {
                 const int px = hlf * 8 + (lane >> 3), c16 = lane & 7;
                 const int opix = wave * 16 + px;
                 const u32x4 v = *(const u32x4*)(sout + obuf * OUTB + q * 16384 + opix * 128 + ((c16 ^ ((opix >> 1) & 7)) << 4));
-                if (live) *(u32x4*)(rowp + px * 64 + c16 * 8) = v;
+                if (live) {
+                    *(u32x4*)(rowp + px * 64 + c16 * 8) = v;
+                    if (p.stat_partials) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float lo = __uint_as_float(v[k] << 16), hi = __uint_as_float(v[k] & 0xffff0000u);
+                            st1[2 * k] += lo;
+                            st2[2 * k] += lo * lo;
+                            st1[2 * k + 1] += hi;
+                            st2[2 * k + 1] += hi * hi;
+                        }
+                    }
+                }
             }
             advance(cw);
         }
@@ -208,6 +226,42 @@ __global__ __launch_bounds__(512) void stem_conv_fwd_kernel(StemFwdParams p) {
     }
     __syncthreads();
     writeback((nstages - 1) & 1);
+    if (p.stat_partials) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+#pragma unroll
+            for (int o = 8; o < 64; o <<= 1) {
+                st1[k] += __shfl_xor(st1[k], o, 64);
+                st2[k] += __shfl_xor(st2[k], o, 64);
+            }
+        }
+        __syncthreads();
+        float* red = (float*)smem;  // [8 waves][2][64]
+        if (lane < 8) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                red[(wave * 2 + 0) * 64 + lane * 8 + k] = st1[k];
+                red[(wave * 2 + 1) * 64 + lane * 8 + k] = st2[k];
+            }
+        }
+        __syncthreads();
+        if (tid < 128) {
+            float a = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) a += red[w * 128 + tid];
+            p.stat_partials[(long)blockIdx.x * 128 + tid] = a;
+        }
+    }
+}
+
+static int stem_fwd_grid(int N, int H, int W, int* per_block) {
+    const long total = (long)N * (H / 2 / 8) * (W / 2 / 16);
+    static const int target = getenv("PRIMIA_STEM_BLOCKS") ? atoi(getenv("PRIMIA_STEM_BLOCKS")) : 256;
+    long per = (total + target - 1) / target;
+    per = (per + 1) & ~1L;
+    if (per < 2) per = 2;
+    if (per_block) *per_block = (int)per;
+    return (int)((total + per - 1) / per);
 }
 
 }  // namespace primia
@@ -223,8 +277,8 @@ int primia_stem_pad_dims(int H, int W, int* Hp, int* Wp) {
     return PRIMIA_OK;
 }
 
-int primia_stem_conv_fwd(const void* x_padded, const void* w_fwd, void* y, int N, int H, int W, int dtype,
-                         primia_stream_t stream) {
+static int stem_conv_fwd_impl(const void* x_padded, const void* w_fwd, void* y, float* stat_partials, int N, int H,
+                              int W, int dtype, primia_stream_t stream) {
     PRIMIA_REQUIRE(x_padded && w_fwd && y && N > 0 && H > 0 && W > 0);
     if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
     // 8 x 16 output patches must tile the output exactly (every legal PriMIA input size is a multiple of 32)
@@ -236,12 +290,8 @@ int primia_stem_conv_fwd(const void* x_padded, const void* w_fwd, void* y, int N
     p.N = N; p.Hp = H + 6; p.Wp = W + 8; p.Ho = H / 2; p.Wo = W / 2;
     p.PH = p.Ho / 8; p.PW = p.Wo / 16; p.PPI = p.PH * p.PW;
     p.total = N * p.PPI;
-    static const int target = getenv("PRIMIA_STEM_BLOCKS") ? atoi(getenv("PRIMIA_STEM_BLOCKS")) : 256;
-    long per = (p.total + target - 1) / target;
-    per = (per + 1) & ~1L;
-    if (per < 2) per = 2;
-    p.per_block = (int)per;
-    const int grid = (int)((p.total + per - 1) / per);
+    const int grid = stem_fwd_grid(N, H, W, &p.per_block);
+    p.stat_partials = stat_partials;
     const size_t lds = (size_t)3 * 2 * 7 * 1024 + 2 * 2 * 128 * 128;
     static bool attr_set = false;
     if (!attr_set) {
@@ -252,6 +302,22 @@ int primia_stem_conv_fwd(const void* x_padded, const void* w_fwd, void* y, int N
     }
     stem_conv_fwd_kernel<<<grid, 512, lds, (hipStream_t)stream>>>(p);
     return launch_status();
+}
+
+int primia_stem_conv_fwd(const void* x_padded, const void* w_fwd, void* y, int N, int H, int W, int dtype,
+                         primia_stream_t stream) {
+    return stem_conv_fwd_impl(x_padded, w_fwd, y, nullptr, N, H, W, dtype, stream);
+}
+
+int primia_stem_conv_stat_slots(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) return PRIMIA_ERR_ARG;
+    return stem_fwd_grid(N, H, W, nullptr);
+}
+
+int primia_stem_conv_fwd_stats(const void* x_padded, const void* w_fwd, void* y, float* stat_partials, int N, int H,
+                               int W, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(stat_partials);
+    return stem_conv_fwd_impl(x_padded, w_fwd, y, stat_partials, N, H, W, dtype, stream);
 }
 
 }  // extern "C"

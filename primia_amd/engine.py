@@ -335,13 +335,30 @@ class ResNet18Engine:
             call("primia_nchw_to_nhwc_padded", x_nchw, self.x0p, N, self.spec.in_channels, S, S, 4, 3, 3,
                  self.x0p_dims[0], self.x0p_dims[1], self.dt)
             c = self.convs["conv1"]
-            self._timed("fwd", c, lambda: call("primia_stem_conv_fwd", self.x0p, c.w_fwd, t["stem.y"], N, S, S, self.dt))
+            if self.training and self.norm == "batch":   # + bn1's per-block partial sums, for free
+                if getattr(self, "_stem_sums", None) is None:
+                    self._stem_slots = query("primia_stem_conv_stat_slots", N, S, S)
+                    self._stem_sums = torch.zeros(self._stem_slots, 2, 64, dtype=torch.float32, device=self.device)
+                self._timed("fwd", c, lambda: call("primia_stem_conv_fwd_stats", self.x0p, c.w_fwd, t["stem.y"],
+                                                   self._stem_sums, N, S, S, self.dt))
+                self._stem_has_sums = True
+            else:
+                self._timed("fwd", c, lambda: call("primia_stem_conv_fwd", self.x0p, c.w_fwd, t["stem.y"], N, S, S,
+                                                   self.dt))
+                self._stem_has_sums = False
         else:
             self._conv_fwd("conv1", self.x0, t["stem.y"])
         hw = self.stem_hw
         self._stem_fused = (self.fuse_stem and self.training and self.norm == "batch" and self.spec.pooling == "max"
                             and not self.fuse_stats and N * hw * hw < (1 << 24))
-        if self._stem_fused:
+        if self._stem_fused and getattr(self, "_stem_has_sums", False) and self._stem_padded:
+            sm, si = self.save["bn1"]
+            call("primia_bn_relu_maxpool_fwd_from_sums", t["stem.y"], t["pool.out"], self.pool_argmax,
+                 self.views["bn1.weight"], self.views["bn1.bias"], self.views["bn1.running_mean"],
+                 self.views["bn1.running_var"], sm, si, self._stem_sums, self._stem_slots, N, hw, hw, 64, BN_EPS,
+                 BN_MOMENTUM, self.dt)
+            self.num_batches_tracked["bn1"] += 1
+        elif self._stem_fused:
             sm, si = self.save["bn1"]
             call("primia_bn_relu_maxpool_fwd", t["stem.y"], t["pool.out"], self.pool_argmax, self.views["bn1.weight"],
                  self.views["bn1.bias"], self.views["bn1.running_mean"], self.views["bn1.running_var"], sm, si, N, hw,

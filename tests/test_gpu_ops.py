@@ -548,3 +548,46 @@ def test_layer1_conv_emits_batchnorm_partials(cuda, N, H):
         outs.append((sm, si, rm, rv, z.float()))
     for a, b in zip(*outs):
         assert relerr(a, b) < 1e-5
+
+
+def test_stem_conv_emits_batchnorm_partials_and_fused_tail_from_sums(cuda):
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    N, S = 3, 64
+    g = torch.Generator().manual_seed(31)
+    x = rnd(torch.randn(N, 3, S, S, generator=g), dtype)
+    w = rnd(torch.randn(64, 3, 7, 7, generator=g) * 0.05, dtype)
+    desc = ConvDesc.make(N, S, S, 4, 64, 7, 7, 2, 3)
+    wf, _ = prep_weights(desc, w, dtype, cuda, 3, need_dgrad=False)
+    xp = torch.zeros(N * (S + 6) * (S + 8), 4, dtype=dtype, device=cuda)
+    call("primia_nchw_to_nhwc_padded", x.to(cuda), xp, N, 3, S, S, 4, 3, 3, S + 6, S + 8, dt)
+    Ho = S // 2
+    M = N * Ho * Ho
+    y0 = torch.empty(M, 64, dtype=dtype, device=cuda)
+    call("primia_stem_conv_fwd", xp, wf, y0, N, S, S, dt)
+    slots = query("primia_stem_conv_stat_slots", N, S, S)
+    sums = torch.full((slots, 2, 64), float("nan"), device=cuda)
+    y = torch.empty_like(y0)
+    call("primia_stem_conv_fwd_stats", xp, wf, y, sums, N, S, S, dt)
+    assert torch.equal(y, y0)
+    yf = y.float()
+    assert relerr(sums[:, 0].sum(0), yf.sum(0)) < 1e-5 and relerr(sums[:, 1].sum(0), (yf * yf).sum(0)) < 1e-5
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(cuda), torch.randn(64, generator=g).to(cuda)
+    ws_bytes = query("primia_bn_workspace_bytes", M, 64)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
+    Hp = (Ho - 1) // 2 + 1
+    res = []
+    for fused in (False, True):
+        rm, rv = torch.zeros(64, device=cuda), torch.ones(64, device=cuda)
+        sm, si = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+        p = torch.empty(N * Hp * Hp, 64, dtype=dtype, device=cuda)
+        am = torch.empty(N * Hp * Hp, 64, dtype=torch.uint8, device=cuda)
+        if fused:
+            call("primia_bn_relu_maxpool_fwd_from_sums", y, p, am, gamma, beta, rm, rv, sm, si, sums, slots, N, Ho, Ho, 64,
+                 1e-5, 0.1, dt)
+        else:
+            call("primia_bn_relu_maxpool_fwd", y, p, am, gamma, beta, rm, rv, sm, si, N, Ho, Ho, 64, 1e-5, 0.1, ws,
+                 ws_bytes, dt)
+        res.append((sm, si, rm, rv, p.float()))
+    for a, b in zip(*res):
+        assert relerr(a, b) < 1e-5
