@@ -187,6 +187,20 @@ int primia_bn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
                   const float* gamma, const float* save_mean, const float* save_invstd,
                   float* dgamma, float* dbeta, int64_t M, int C, int relu, void* workspace,
                   int64_t workspace_bytes, int dtype, primia_stream_t stream);
+/* Residual layers (bn2 of every BasicBlock, models.py:277-282): the forward pass also writes one mask byte per
+ * 16-byte chunk (bit i = stored z_i > 0; M*C*sizeof(elem)/16 bytes) and both backward passes read it instead
+ * of z — 1/16 of the bytes.  `sums` (with `slots`) as in primia_bn_fwd_train_from_sums, or NULL to compute the
+ * statistics here (then `workspace` is required).  Same results as primia_bn_fwd_train(relu = 1) /
+ * primia_bn_bwd(relu = 1). */
+int primia_bn_fwd_train_mask(const void* y, const void* residual, void* z, uint8_t* relu_mask, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float* save_mean,
+                             float* save_invstd, const float* sums, int slots, int64_t M, int C, float eps,
+                             float momentum, void* workspace, int64_t workspace_bytes, int dtype,
+                             primia_stream_t stream);
+int primia_bn_bwd_mask(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
+                       const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
+                       float* dbeta, int64_t M, int C, void* workspace, int64_t workspace_bytes, int dtype,
+                       primia_stream_t stream);
 /* Backward of z = relu(bn(y)) WITHOUT a residual (bn1 of every BasicBlock and the stem,
  * torchlib/models.py:261-263, 469-470): the mask (z > 0) is recomputed from y with the forward pass's
  * own fma, so z is not read — one tensor less in each of the two passes.  Same outputs as

@@ -96,6 +96,7 @@ struct BwdFn {
     const float* invstd;
     const float* gamma;  // with beta: no z, the mask (z > 0) is recomputed from y
     const float* beta;
+    const uint8_t* mask;  // or: one byte per chunk written by the forward pass (bit i = z_i > 0)
     __device__ __forceinline__ void prepare(int) {}
     __device__ __forceinline__ void operator()(long, long off, int c0, float* s1, float* s2) const {
         constexpr int CH = Chunk<T>::N;
@@ -107,6 +108,10 @@ struct BwdFn {
             Chunk<T>::unpack(*(const u32x4*)(z + off), vz);
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        } else if (mask) {
+            const unsigned m = mask[off / CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vg[i] = (m >> i) & 1u ? vg[i] : 0.f;
         } else if (beta) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
@@ -166,14 +171,25 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     }
 }
 
-// z = act((y - mean) * (invstd * gamma) + beta [+ residual])
+template <typename T>
+__device__ __forceinline__ float round_to(float v) {
+    return v;
+}
+template <>
+__device__ __forceinline__ float round_to<bf16>(float v) {
+    return bf16_to_f32(f32_to_bf16(v));
+}
+
+// z = act((y - mean) * (invstd * gamma) + beta [+ residual]); optionally one mask byte per 16-byte chunk with
+// bit i = (stored z_i > 0): the backward passes of a residual layer read it instead of z (1/16 of the bytes)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res,
                                                        T* __restrict__ z, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd_or_var, float eps,
-                                                       int eval_mode, long nchunks, int C, int relu) {
+                                                       int eval_mode, long nchunks, int C, int relu,
+                                                       uint8_t* __restrict__ mask_out = nullptr) {
     constexpr int CH = Chunk<T>::N;
     __shared__ float sm[3][512];
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -202,6 +218,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
             for (int i = 0; i < CH; ++i) v[i] = fmaxf(v[i], 0.f);
         }
         *(u32x4*)(z + q * CH) = Chunk<T>::pack(v);
+        if (mask_out) {
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) m |= (round_to<T>(v[i]) > 0.f ? 1u : 0u) << i;
+            mask_out[q] = (uint8_t)m;
+        }
     }
 }
 
@@ -214,7 +236,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ dbeta,
                                                            const float* __restrict__ dgamma, float inv_m,
-                                                           long nchunks, int C, const float* __restrict__ beta) {
+                                                           long nchunks, int C, const float* __restrict__ beta,
+                                                           const uint8_t* __restrict__ mask = nullptr) {
     constexpr int CH = Chunk<T>::N;
     __shared__ float sm[7][512];
     for (int c = threadIdx.x; c < C; c += 256) {
@@ -239,6 +262,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
             Chunk<T>::unpack(*(const u32x4*)(z + q * CH), vz);
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        } else if (mask) {
+            const unsigned m = mask[q];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vg[i] = (m >> i) & 1u ? vg[i] : 0.f;
         } else if (beta) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
@@ -268,14 +295,6 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // Values are rounded to the storage type before the window comparison, so argmax / ties are exactly
 // those of the unfused kernels (first maximum in scan order, like torch's max_pool2d).
 // =================================================================================================
-template <typename T>
-__device__ __forceinline__ float round_to(float v) {
-    return v;
-}
-template <>
-__device__ __forceinline__ float round_to<bf16>(float v) {
-    return bf16_to_f32(f32_to_bf16(v));
-}
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, T* __restrict__ pooled,
@@ -479,17 +498,17 @@ template <typename T>
 static int bn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, void* g_out,
                        const float* gamma, const float* save_mean, const float* save_invstd,
                        float* dgamma, float* dbeta, long M, int C, int relu, float* partials,
-                       hipStream_t st, const float* beta = nullptr) {
+                       hipStream_t st, const float* beta = nullptr, const uint8_t* mask = nullptr) {
     int nblk;
     long rpb;
     reduce_geometry(M, C, nblk, rpb);
-    BwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, save_mean, save_invstd, gamma, beta};
+    BwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, save_mean, save_invstd, gamma, beta, mask};
     colreduce2_kernel<T, BwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
     bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
     const long nchunks = M * C / Chunk<T>::N;
     bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
         (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean,
-        save_invstd, dbeta, dgamma, (float)(1.0 / (double)M), nchunks, C, beta);
+        save_invstd, dbeta, dgamma, (float)(1.0 / (double)M), nchunks, C, beta, mask);
     return launch_status();
 }
 
@@ -694,6 +713,63 @@ int primia_bn_relu_maxpool_bwd(const void* y, const void* dpooled, const uint8_t
     if (dtype == PRIMIA_BF16)
         return bn_relu_pool_bwd_impl<bf16>(y, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, dgamma,
                                            dbeta, N, H, W, C, (float*)workspace, st);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_bn_fwd_train_mask(const void* y, const void* residual, void* z, uint8_t* relu_mask, const float* gamma,
+                             const float* beta, float* running_mean, float* running_var, float* save_mean,
+                             float* save_invstd, const float* sums, int slots, int64_t M, int C, float eps,
+                             float momentum, void* workspace, int64_t workspace_bytes, int dtype,
+                             primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && z && relu_mask && gamma && beta && save_mean && save_invstd && (sums || workspace));
+    PRIMIA_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype) && (!sums || slots >= 1));
+    if (!sums && workspace_bytes < primia_bn_workspace_bytes(M, C)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const float* part = sums;
+    int nblk = slots;
+    if (!sums) {
+        long rpb;
+        reduce_geometry(M, C, nblk, rpb);
+        part = (const float*)workspace;
+        if (dtype == PRIMIA_F32) {
+            StatsFn<float> f{(const float*)y};
+            colreduce2_kernel<float, StatsFn<float>><<<nblk, 256, 0, st>>>(f, M, C, rpb, (float*)workspace);
+        } else {
+            StatsFn<bf16> f{(const bf16*)y};
+            colreduce2_kernel<bf16, StatsFn<bf16>><<<nblk, 256, 0, st>>>(f, M, C, rpb, (float*)workspace);
+        }
+    }
+    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(part, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
+                                                       running_mean, running_var);
+    if (dtype == PRIMIA_F32) {
+        const long nchunks = M * C / 4;
+        bn_apply_kernel<float><<<stream_blocks(nchunks), 256, 0, st>>>((const float*)y, (const float*)residual,
+                                                                       (float*)z, gamma, beta, save_mean, save_invstd,
+                                                                       eps, 0, nchunks, C, 1, relu_mask);
+    } else {
+        const long nchunks = M * C / 8;
+        bn_apply_kernel<bf16><<<stream_blocks(nchunks), 256, 0, st>>>((const bf16*)y, (const bf16*)residual, (bf16*)z,
+                                                                      gamma, beta, save_mean, save_invstd, eps, 0,
+                                                                      nchunks, C, 1, relu_mask);
+    }
+    return launch_status();
+}
+
+int primia_bn_bwd_mask(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
+                       const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
+                       float* dbeta, int64_t M, int C, void* workspace, int64_t workspace_bytes, int dtype,
+                       primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && relu_mask && dz && dy && gamma && save_mean && save_invstd && dgamma && dbeta && workspace);
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype));
+    if (workspace_bytes < primia_bn_workspace_bytes(M, C)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return bn_bwd_impl<float>(y, nullptr, dz, dy, g_out, gamma, save_mean, save_invstd, dgamma, dbeta, M, C, 0,
+                                  (float*)workspace, st, nullptr, relu_mask);
+    if (dtype == PRIMIA_BF16)
+        return bn_bwd_impl<bf16>(y, nullptr, dz, dy, g_out, gamma, save_mean, save_invstd, dgamma, dbeta, M, C, 0,
+                                 (float*)workspace, st, nullptr, relu_mask);
     return PRIMIA_ERR_ARG;
 }
 

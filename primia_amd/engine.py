@@ -159,6 +159,8 @@ class ResNet18Engine:
         # stem tail bn1 -> relu -> maxpool as ONE fused op in training (z = relu(bn(y)) is never written)
         self.fuse_stem = True
         self._stem_fused = False
+        self.use_relu_masks = True   # residual layers: 1-bit ReLU masks for the backward passes (see _bn)
+        self.relu_masks = {}
         self._stem_padded = False
         self.stat_slots = query("primia_conv_stat_slots")
         for c in self.spec.convs:   # slots the kernel serving this conv writes (per-block partials for layer1's)
@@ -285,7 +287,17 @@ class ResNet18Engine:
                  self.bn_ws, self.bn_ws_bytes, self.dt)
             return
         rm, rv = self.views[b + ".running_mean"], self.views[b + ".running_var"]
-        if self.training:
+        if self.training and residual is not None and relu and self.use_relu_masks:
+            # residual layer: also write the 1-bit ReLU mask the backward passes read instead of z
+            sm, si = self.save[b]
+            if b not in self.relu_masks:
+                self.relu_masks[b] = torch.empty(y.numel() * y.element_size() // 16, dtype=torch.uint8, device=y.device)
+            have_sums = self.fuse_stats or conv_name in self.free_stats
+            call("primia_bn_fwd_train_mask", y, residual, z, self.relu_masks[b], g, be, rm, rv, sm, si,
+                 self.convs[conv_name].sums if have_sums else None, self.convs[conv_name].stat_slots if have_sums else 0,
+                 M, C, BN_EPS, BN_MOMENTUM, self.bn_ws, self.bn_ws_bytes, self.dt)
+            self.num_batches_tracked[b] += 1
+        elif self.training:
             sm, si = self.save[b]
             if self.fuse_stats or conv_name in self.free_stats:
                 call("primia_bn_fwd_train_from_sums", y, residual, z, g, be, rm, rv, sm, si,
@@ -425,6 +437,11 @@ class ResNet18Engine:
             if self.dp is None:  # plain training: dgamma / dbeta = sum over samples
                 call("primia_weighted_colsum", psg, self.ones_n, self.gviews[b + ".weight"], self.N, C)
                 call("primia_weighted_colsum", psb, self.ones_n, self.gviews[b + ".bias"], self.N, C)
+            return
+        if relu and g_out is not None and b in self.relu_masks:
+            call("primia_bn_bwd_mask", y, self.relu_masks[b], dz, dy, g_out, self.views[b + ".weight"], sm, si,
+                 self.gviews[b + ".weight"], self.gviews[b + ".bias"], y.shape[0], y.shape[1], self.bn_ws,
+                 self.bn_ws_bytes, self.dt)
             return
         if relu and g_out is None:
             # z = relu(bn(y)), no residual: the mask is recomputed from y, z is not read

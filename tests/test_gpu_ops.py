@@ -591,3 +591,36 @@ def test_stem_conv_emits_batchnorm_partials_and_fused_tail_from_sums(cuda):
         res.append((sm, si, rm, rv, p.float()))
     for a, b in zip(*res):
         assert relerr(a, b) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_batchnorm_relu_mask_variant_is_bit_identical(cuda, dtype):
+    """primia_bn_fwd_train_mask / primia_bn_bwd_mask (1-bit ReLU mask for residual layers) against
+    primia_bn_fwd_train / primia_bn_bwd: identical z, statistics, dy, g_out, dgamma, dbeta."""
+    dt = _lib.dtype_code(dtype)
+    N, H, C = 3, 9, 128
+    M = N * H * H
+    g = torch.Generator().manual_seed(99)
+    yd = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * 2 + 0.5, dtype), dtype, cuda)
+    rd = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
+    dzd = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    ws_bytes = query("primia_bn_workspace_bytes", M, C)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
+    outs = []
+    for masked in (False, True):
+        rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+        sm, si, z = torch.empty(C, device=cuda), torch.empty(C, device=cuda), torch.empty_like(yd)
+        dy, go = torch.empty_like(yd), torch.empty_like(yd)
+        dg, db = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+        if masked:
+            mask = torch.empty(yd.numel() * yd.element_size() // 16, dtype=torch.uint8, device=cuda)
+            call("primia_bn_fwd_train_mask", yd, rd, z, mask, gamma, beta, rm, rv, sm, si, None, 0, M, C, 1e-5, 0.1, ws,
+                 ws_bytes, dt)
+            call("primia_bn_bwd_mask", yd, mask, dzd, dy, go, gamma, sm, si, dg, db, M, C, ws, ws_bytes, dt)
+        else:
+            call("primia_bn_fwd_train", yd, rd, z, gamma, beta, rm, rv, sm, si, M, C, 1e-5, 0.1, 1, ws, ws_bytes, dt)
+            call("primia_bn_bwd", yd, z, dzd, dy, go, gamma, sm, si, dg, db, M, C, 1, ws, ws_bytes, dt)
+        outs.append((z, sm, si, rm, rv, dy, go, dg, db))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
