@@ -37,6 +37,32 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_padded_kernel(const float* _
     for (int c = 0; c < c_pad; ++c) Elem<T>::store(d + c, c < C ? s[(long)c * HW] : 0.f);
 }
 
+// bf16, 4 channels, W % 4 == 0: one thread converts 4 consecutive pixels (a float4 per channel plane in, 32
+// contiguous bytes out) — 4x fewer threads and 16-byte loads for the same bytes
+__global__ __launch_bounds__(256) void nchw_to_nhwc4_padded_x4_kernel(const float* __restrict__ src,
+                                                                      bf16* __restrict__ dst, int C, int H, int W,
+                                                                      int pad_top, int pad_left, int Hp, int Wp,
+                                                                      long total4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total4) return;
+    const int W4 = W >> 2, HW = H * W;
+    const long n = i / ((long)H * W4);
+    const int r = (int)(i - n * (long)H * W4);
+    const int h = r / W4, w = (r - h * W4) * 4;
+    const float* s = src + n * (long)C * HW + (long)h * W + w;
+    f32x4 v[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) v[c] = c < C ? *(const f32x4*)(s + (long)c * HW) : f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x2* d = (u32x2*)(dst + ((n * Hp + h + pad_top) * Wp + w + pad_left) * 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        u32x2 o;
+        o[0] = (uint32_t)f32_to_bf16(v[0][k]) | ((uint32_t)f32_to_bf16(v[1][k]) << 16);
+        o[1] = (uint32_t)f32_to_bf16(v[2][k]);
+        d[k] = o;
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const T* __restrict__ src,
                                                            float* __restrict__ dst, int C, int HW,
@@ -298,7 +324,11 @@ int primia_nchw_to_nhwc_padded(const float* src, void* dst, int N, int C, int H,
     if (dtype == PRIMIA_F32)
         nchw_to_nhwc_padded_kernel<float><<<grid, block, 0, st>>>(src, (float*)dst, C, H, W, c_pad, pad_top, pad_left, Hp,
                                                                   Wp, total);
-    else if (dtype == PRIMIA_BF16)
+    else if (dtype == PRIMIA_BF16 && c_pad == 4 && C <= 3 && W % 4 == 0 && ((uintptr_t)src & 15) == 0) {
+        const long total4 = total / 4;
+        nchw_to_nhwc4_padded_x4_kernel<<<ceil_div(total4, 256), 256, 0, st>>>(src, (bf16*)dst, C, H, W, pad_top, pad_left,
+                                                                             Hp, Wp, total4);
+    } else if (dtype == PRIMIA_BF16)
         nchw_to_nhwc_padded_kernel<bf16><<<grid, block, 0, st>>>(src, (bf16*)dst, C, H, W, c_pad, pad_top, pad_left, Hp,
                                                                  Wp, total);
     else
