@@ -59,7 +59,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     constexpr int STAGES = 3;
     constexpr int HALO = 13 * 1024;        // 100 slots used, 104 staged (13 DMA instructions)
     constexpr int STAGE = 2 * HALO;        // two patches per stage
-    constexpr int OUTB = 2 * 64 * 128;     // output rows of one stage: 2 patches x 64 pixels x 128 B
+    // output rows of one stage: 2 patches x 64 pixels x 64 channels, bf16 — or fp32 in the accumulate form, which
+    // adds the old values in the write-back phase (coalesced row loads, fp32 add, ONE rounding)
+    constexpr int OPIX = ACC ? 256 : 128;  // bytes per staged pixel row
+    constexpr int OUTB = 2 * 64 * OPIX;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE + 2 * OUTB
     char* const sout = smem + STAGES * STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -106,7 +109,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
             }
         }
     };
-    Cursor cs = make_cursor(t0), co = make_cursor(t0), cw = make_cursor(t0);  // staging / compute / write-back
+    Cursor cs = make_cursor(t0), cw = make_cursor(t0);  // staging / write-back
 
     // ---- staging: 26 DMA instructions per stage (2 patches x 13), round-robin over the 8 waves -----------
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -149,7 +152,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     // output staging: pixel opix = 16*pq + fr of the patch, 8-byte column 8*kh + 4*i + fg of its 128-B row,
     // stored at 16-B chunk (col >> 1) ^ ((opix >> 1) & 7): conflict-free ds_write_b64 / ds_read_b128
     const int opix = 16 * pq + fr;
-    const int opy = opix >> 3, opx = opix & 7;
 
     auto compute = [&](int buf, int obuf) {
         const char* sb = smem + buf * STAGE;
@@ -179,31 +181,22 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- results -> LDS rows (bf16); the accumulate form adds the old values first (fp32, one rounding) --
+        // ---- results -> LDS rows (bf16; fp32 for the accumulate form) ---------------------------------------
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int ho = co.ph * 8 + opy, wo = co.pw * 8 + opx;
-            const bool inb = co.t < t1 && ho < p.H && wo < p.W;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                float v[4] = {acc[q][i][0], acc[q][i][1], acc[q][i][2], acc[q][i][3]};
-                if (ACC) {
-                    if (inb) {
-                        const u32x2 o = *(const u32x2*)(p.dst + ((long)(co.n * p.H + ho) * p.W + wo) * 64 + 32 * kh +
-                                                        16 * i + 4 * fg);
-                        v[0] += __uint_as_float(o[0] << 16);
-                        v[1] += __uint_as_float(o[0] & 0xffff0000u);
-                        v[2] += __uint_as_float(o[1] << 16);
-                        v[3] += __uint_as_float(o[1] & 0xffff0000u);
-                    }
+                const int col = 8 * kh + 4 * i + fg;   // 4-channel column of the pixel's row
+                if constexpr (ACC) {
+                    // 16-byte fp32 chunks, chunk index swizzled with the pixel: conflict-free ds_write_b128
+                    *(f32x4*)(sout + obuf * OUTB + q * 64 * OPIX + opix * OPIX + ((col ^ (opix & 15)) << 4)) = acc[q][i];
+                } else {
+                    u32x2 o;
+                    o[0] = (uint32_t)f32_to_bf16(acc[q][i][0]) | ((uint32_t)f32_to_bf16(acc[q][i][1]) << 16);
+                    o[1] = (uint32_t)f32_to_bf16(acc[q][i][2]) | ((uint32_t)f32_to_bf16(acc[q][i][3]) << 16);
+                    *(u32x2*)(sout + obuf * OUTB + q * 8192 + opix * 128 + ((((col >> 1) ^ ((opix >> 1) & 7)) << 4) | ((col & 1) << 3))) = o;
                 }
-                u32x2 o;
-                o[0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                o[1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                const int col = 8 * kh + 4 * i + fg;
-                *(u32x2*)(sout + obuf * OUTB + q * 8192 + opix * 128 + ((((col >> 1) ^ ((opix >> 1) & 7)) << 4) | ((col & 1) << 3))) = o;
             }
-            advance(co);
         }
     };
 
@@ -216,15 +209,42 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.f;
 
     auto writeback = [&](int obuf) {
+        const int g = wave;                        // patch row handled by this wave
+        const int px = lane >> 3, c16 = lane & 7;  // pixel of the row, 16-B chunk
+        const int opx2 = g * 8 + px;
+        bool live[2];
+        bf16* gp[2];
+        u32x4 old[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int g = wave;                       // patch row handled by this wave
-            const int px = lane >> 3, c16 = lane & 7;  // pixel of the row, 16-B chunk
-            const int opx2 = g * 8 + px;
-            const u32x4 v = *(const u32x4*)(sout + obuf * OUTB + q * 8192 + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
             const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
-            if (cw.t < t1 && ho < p.H && wo < p.W && !((p.debug & 1) && v[0] != 12345u)) {
-                *(u32x4*)(p.dst + ((long)(cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8) = v;
+            live[q] = cw.t < t1 && ho < p.H && wo < p.W;
+            gp[q] = p.dst + ((long)(cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8;
+            advance(cw);
+            // accumulate form: both old rows are requested before anything is stored — a load waited for AFTER a
+            // store would also wait for that store to complete (one vmcnt for both)
+            old[q] = u32x4{0, 0, 0, 0};
+            if (ACC && live[q]) old[q] = *(const u32x4*)gp[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            u32x4 v;
+            if constexpr (ACC) {
+                const char* row = sout + obuf * OUTB + q * 64 * OPIX + opx2 * OPIX;
+                const f32x4 lo = *(const f32x4*)(row + (((2 * c16) ^ (opx2 & 15)) << 4));
+                const f32x4 hi = *(const f32x4*)(row + (((2 * c16 + 1) ^ (opx2 & 15)) << 4));
+                float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    f[2 * k] += __uint_as_float(old[q][k] << 16);
+                    f[2 * k + 1] += __uint_as_float(old[q][k] & 0xffff0000u);
+                    v[k] = (uint32_t)f32_to_bf16(f[2 * k]) | ((uint32_t)f32_to_bf16(f[2 * k + 1]) << 16);
+                }
+            } else {
+                v = *(const u32x4*)(sout + obuf * OUTB + q * 8192 + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
+            }
+            if (live[q] && !((p.debug & 1) && v[0] != 12345u)) {
+                *(u32x4*)gp[q] = v;
                 if (p.stat_partials) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
@@ -236,7 +256,6 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
                     }
                 }
             }
-            advance(cw);
         }
     };
 
@@ -246,7 +265,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     // stores of iteration s-1 (for s >= 2) and DMA(s+1): DMA(s) has landed once at most those remain in
     // flight.  Ragged images (a row store may be fully masked), the accumulate form (its loads are waited
     // for by the compiler, conservatively) and the last stage use vmcnt(0).
-    const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !(p.debug & 3) && !ACC;
+    const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !(p.debug & 3);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nstages) stage(s);
@@ -328,13 +347,14 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     static const int dbg = getenv("PRIMIA_C64_DEBUG") ? atoi(getenv("PRIMIA_C64_DEBUG")) : 0;
     p.debug = dbg;
     const int grid = (int)((p.total + per - 1) / per);
-    const size_t lds = (size_t)3 * 2 * 13 * 1024 + 2 * 2 * 64 * 128;
+    const size_t lds = (size_t)3 * 2 * 13 * 1024 + 2 * 2 * 64 * (accumulate ? 256 : 128);
     static bool attr_set = false;
     if (!attr_set) {
+        const int lds_plain = 3 * 2 * 13 * 1024 + 2 * 2 * 64 * 128, lds_acc = 3 * 2 * 13 * 1024 + 2 * 2 * 64 * 256;
         if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess ||
+                                lds_plain) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
+                                lds_acc) != hipSuccess)
             return PRIMIA_ERR_LAUNCH;
         attr_set = true;
     }
