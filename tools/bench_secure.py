@@ -64,6 +64,39 @@ if not a.no_graph:
     except Exception as e:  # capture is an optimisation of the measurement, not of the result
         print("hipGraph capture of the online phase failed:", repr(e)[:300], file=sys.stderr)
 
+def cpu_sample():
+    """Bounded CPU sample of the same workload with the oracle (single thread): FSS keygen + 2-party
+    eval on 20k comparisons (C SHA-512 loop), and torch-CPU int64 matmuls of the 21 Beaver products'
+    shapes (the reference's own native op, 3 products x 2 parties each).  Extrapolated to one image."""
+    import numpy as np
+    from oracle import secure_oracle as S
+    n = 20000
+    rng = np.random.default_rng(0)
+    alpha = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64)
+    s0 = rng.integers(0, 2 ** 64, size=(2, 2, n), dtype=np.uint64); s0[:, 0] %= 2 ** 63
+    x = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64)
+    t0 = time.perf_counter(); _, keys = S.dif_keygen(alpha, s0); t_kg = time.perf_counter() - t0
+    t0 = time.perf_counter(); [S.dif_eval(b, x, keys[b]) for b in range(2)]; t_ev = time.perf_counter() - t0
+    n_cmp = ctx.stats["dif_evals"]
+    fss_ms = (t_kg + t_ev) / n * n_cmp * 1e3
+    shapes = [(12544, 147, 64)] + [(3136, 576, 64)] * 4 + [(784, 576, 128), (784, 64, 128)] + [(784, 1152, 128)] * 3 \
+        + [(196, 1152, 256), (196, 128, 256)] + [(196, 2304, 256)] * 3 + [(49, 2304, 512), (49, 256, 512)] \
+        + [(49, 4608, 512)] * 3 + [(1, 512, 3)]
+    torch.set_num_threads(1)
+    t_mm = 0.0
+    done = set()
+    per = {}
+    for sh in shapes:
+        if sh not in per:
+            A = torch.randint(-2 ** 62, 2 ** 62, (sh[0], sh[1])); B = torch.randint(-2 ** 62, 2 ** 62, (sh[1], sh[2]))
+            t0 = time.perf_counter(); torch.matmul(A, B); per[sh] = time.perf_counter() - t0
+        t_mm += per[sh] * 3 * 2
+    return {"value": round(fss_ms + t_mm * 1e3, 0), "unit": "ms/image", "cores": 1, "kind": "port",
+            "sample": f"oracle DIF keygen+2-party eval on {n} of {n_cmp} comparisons ({fss_ms:.0f} ms extrapolated) + "
+                      f"torch-CPU int64 matmul of all 21 Beaver shapes x3 products x2 parties ({t_mm * 1e3:.0f} ms); "
+                      "excludes the reference's Python im2col, Newton BN and RPC overhead"}
+
+
 extra = {"cpu_baseline": cpu_sample()} if a.cpu_sample else {}
 print(json.dumps({"metric": "encrypted_inference_ms_per_image", "online_ms": round(to * 1e3, 1),
                   "online_graph_ms": None if graph_ms is None else round(graph_ms, 1),

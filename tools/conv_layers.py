@@ -41,9 +41,15 @@ for name, H, C, K, R, s, p, cnt in layers:
     call("primia_conv_weight_prepare", d, creal, w, wf, wd, dt)
     acc = torch.zeros(query("primia_conv_wfwd_elems", d), dtype=torch.float32, device=dev)
     fl = 2.0 * N * d.Ho * d.Wo * K * creal * R * R
-    tf = timeit(lambda: call("primia_conv2d_fwd", d, x, wf, y, dt))
-    td = timeit(lambda: call("primia_conv2d_dgrad", d, dy, wd, dx, 0, dt)) if wd is not None else 0.0
-    tw = timeit(lambda: call("primia_conv2d_wgrad", d, x, dy, acc, dt))
+    if name == "stem" and dtype == torch.bfloat16:   # the padded-input stem kernels the engine uses
+        xp = torch.zeros(N * (H + 6) * (H + 8), 4, dtype=dtype, device=dev)
+        tf = timeit(lambda: call("primia_stem_conv_fwd", xp, wf, y, N, H, H, dt))
+        td = 0.0
+        tw = timeit(lambda: call("primia_stem_conv_wgrad", xp, dy, acc, N, H, H, dt))
+    else:
+        tf = timeit(lambda: call("primia_conv2d_fwd", d, x, wf, y, dt))
+        td = timeit(lambda: call("primia_conv2d_dgrad", d, dy, wd, dx, 0, dt)) if wd is not None else 0.0
+        tw = timeit(lambda: call("primia_conv2d_wgrad", d, x, dy, acc, dt))
     f = lambda t: fl / (t * 1e-3) / 1e12 if t > 0 else 0
     print(f"{name:9s} {cnt:3d} {fl/1e9:7.1f} | {tf*1e3:8.1f} {f(tf):6.0f} | {td*1e3:8.1f} {f(td):6.0f} | {tw*1e3:8.1f} {f(tw):6.0f}")
     tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt
