@@ -224,10 +224,12 @@ int primia_bn_relu_maxpool_fwd_from_sums(const void* y, void* pooled, uint8_t* a
                                          float* save_mean, float* save_invstd, const float* sums, int slots, int N,
                                          int H, int W, int C, float eps, float momentum, int dtype,
                                          primia_stream_t stream);
-/* Its backward: from dpooled and the argmax codes to dy / dgamma / dbeta; the pool's input gradient
- * is gathered and ReLU-masked inside BatchNorm's reduction pass.  Same results as
- * primia_maxpool3x3s2_bwd followed by primia_bn_bwd(relu = 1).  N*H*W < 2^24. */
-int primia_bn_relu_maxpool_bwd(const void* y, const void* dpooled, const uint8_t* argmax, void* dy,
+/* Its backward: from the pooled output, dpooled and the argmax codes to dy / dgamma / dbeta.  dgamma / dbeta
+ * are summed at pooled resolution (a window's gradient reaches exactly its argmax, whose activation is the
+ * pooled value), the per-element pool gradient is gathered only in the apply pass.  Equal to
+ * primia_maxpool3x3s2_bwd followed by primia_bn_bwd(relu = 1) up to rounding (that chain rounds the pool
+ * gradient to `dtype` in between and normalises with y rather than with the stored activation). */
+int primia_bn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax, void* dy,
                                const float* gamma, const float* beta, const float* save_mean,
                                const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W,
                                int C, void* workspace, int64_t workspace_bytes, int dtype,

@@ -289,9 +289,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // the network), reads it back for the pool, and in the backward pass materialises the pool's input
 // gradient dz only for the two BatchNorm backward passes to read it again.  Fused:
 //   forward : pooled, argmax = maxpool(relu(bn(y)))   straight from y              (z never exists)
-//   backward: g(h, w) = [z(h, w) > 0] * sum over the <= 4 windows whose argmax is (h, w) of dpooled
-//             is gathered INSIDE BatchNorm's reduction pass (which also parks it in dy); the pool's
-//             own backward pass and the re-read of its output are gone.
+//   backward: the BatchNorm sums are formed at POOLED resolution (a window's gradient reaches exactly its
+//             argmax, whose activation is the pooled value itself: PoolScatterFn); only the apply pass gathers
+//             g(h, w) = [z(h, w) > 0] * sum over the <= 4 windows whose argmax is (h, w) of dpooled.
+//             The pool's own backward pass, its 411 MB output and both re-reads of it are gone.
 // Values are rounded to the storage type before the window comparison, so argmax / ties are exactly
 // those of the unfused kernels (first maximum in scan order, like torch's max_pool2d).
 // =================================================================================================
@@ -397,62 +398,107 @@ __device__ __forceinline__ void pool_gather(const T* __restrict__ dp, const uint
         }
 }
 
+// Reduction pass of the fused stem backward, over the POOLED pixels (a quarter of the input pixels, no gather):
+// a window's gradient reaches exactly one input element, its argmax, whose activation IS the pooled value p, so
+//     sum g        = sum over windows [p > 0] * dp
+//     sum g * xhat = sum over windows [p > 0] * dp * xhat(argmax),   xhat = (p - beta) / gamma   (ReLU active)
+// — two tensors at pooled resolution instead of y plus a 4-window gather per input element (400 -> ~50 us at
+// batch 256).  (gamma == 0 makes z constant and xhat unrecoverable from p: those channels read y at the argmax.)
 template <typename T>
-struct PoolBwdFn {
+struct PoolScatterFn {
     static constexpr int kUnroll = 4;
-    const T* y;
+    const T* p;
     const T* dp;
     const uint8_t* argmax;
-    T* g_out;     // masked pool-input gradient, written once here and read by the apply pass
+    const T* y;
     const float* mean;
     const float* invstd;
     const float* gamma;
     const float* beta;
     int H, W, C, Ho, Wo;
-    float rcp_w, rcp_h;
-    float k_mean[Chunk<T>::N], k_invstd[Chunk<T>::N], k_scale[Chunk<T>::N], k_beta[Chunk<T>::N];
+    float k_beta[Chunk<T>::N], k_rgamma[Chunk<T>::N], k_mean[Chunk<T>::N], k_invstd[Chunk<T>::N];
+    bool any_zero_gamma;
     __device__ __forceinline__ void prepare(int c0) {
+        any_zero_gamma = false;
 #pragma unroll
         for (int i = 0; i < Chunk<T>::N; ++i) {
+            const float g = gamma[c0 + i];
+            k_beta[i] = beta[c0 + i];
+            k_rgamma[i] = g != 0.f ? 1.f / g : 0.f;
             k_mean[i] = mean[c0 + i];
             k_invstd[i] = invstd[c0 + i];
-            k_scale[i] = invstd[c0 + i] * gamma[c0 + i];
-            k_beta[i] = beta[c0 + i];
+            any_zero_gamma |= g == 0.f;
         }
-    }
-    // q = m / d for 0 <= m < 2^24 via one float multiply and a fix-up
-    static __device__ __forceinline__ int fdiv(int m, int d, float rcp, int& rem) {
-        int q = (int)((float)m * rcp);
-        rem = m - q * d;
-        if (rem >= d) {
-            ++q;
-            rem -= d;
-        } else if (rem < 0) {
-            --q;
-            rem += d;
-        }
-        return q;
     }
     __device__ __forceinline__ void operator()(long row, long off, int c0, float* s1, float* s2) const {
         constexpr int CH = Chunk<T>::N;
-        const int m = (int)row;
-        int w, h;
-        const int t = fdiv(m, W, rcp_w, w);
-        const int n = fdiv(t, H, rcp_h, h);
+        float vp[CH], vd[CH];
+        Chunk<T>::unpack(*(const u32x4*)(p + off), vp);
+        Chunk<T>::unpack(*(const u32x4*)(dp + off), vd);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const float g = vp[i] > 0.f ? vd[i] : 0.f;
+            s1[i] += g;
+            s2[i] += g * ((vp[i] - k_beta[i]) * k_rgamma[i]);
+        }
+        if (any_zero_gamma) {  // rare: xhat of a gamma == 0 channel from y at the argmax position
+            const int wo = (int)(row % Wo);
+            const long t = row / Wo;
+            const int ho = (int)(t % Ho), n = (int)(t / Ho);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (k_rgamma[i] != 0.f || !(vp[i] > 0.f)) continue;
+                const int code = argmax[off + i];
+                const int h = 2 * ho - 1 + code / 3, w = 2 * wo - 1 + code % 3;
+                const float yv = Elem<T>::load(y + (((long)n * H + h) * W + w) * C + c0 + i);
+                s2[i] += vd[i] * ((yv - k_mean[i]) * k_invstd[i]);
+            }
+        }
+    }
+};
+
+// Apply pass of the fused stem backward: the pool gradient of every input element is gathered here (it is
+// needed per element only now), masked with the ReLU mask recomputed from y, and turned into dy.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_kernel(
+    const T* __restrict__ y, const T* __restrict__ dp, const uint8_t* __restrict__ argmax, T* __restrict__ dy,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_m,
+    int N, int H, int W, int C, int Ho, int Wo, float rcp_w, float rcp_h) {
+    constexpr int CH = Chunk<T>::N;
+    __shared__ float sm[7][512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        sm[0][c] = mean[c];
+        sm[1][c] = invstd[c];
+        sm[2][c] = gamma[c] * invstd[c];
+        sm[3][c] = dbeta[c] * inv_m;
+        sm[4][c] = dgamma[c] * inv_m;
+        sm[5][c] = invstd[c] * gamma[c];
+        sm[6][c] = beta[c];
+    }
+    __syncthreads();
+    const int cpr = C / CH;
+    const long total = (long)N * H * W * cpr;
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += stride) {
+        const int m = (int)(q / cpr);
+        const int c0 = (int)(q - (long)m * cpr) * CH;
+        int w = m % W;
+        const int t = m / W;
+        const int h = t % H, n = t / H;
         float vy[CH], vg[CH];
-        Chunk<T>::unpack(*(const u32x4*)(y + off), vy);
+        Chunk<T>::unpack(*(const u32x4*)(y + q * CH), vy);
         pool_gather<T>(dp, argmax, n, h, w, c0, C, Ho, Wo, vg);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
-            const float zz = bn_affine(vy[i], k_mean[i], k_scale[i], k_beta[i]);
-            vg[i] = zz > 0.f ? round_to<T>(vg[i]) : 0.f;   // dz as the unfused pool backward stores it, masked
-            const float xh = (vy[i] - k_mean[i]) * k_invstd[i];
-            s1[i] += vg[i];
-            s2[i] += vg[i] * xh;
+            const float zz = bn_affine(vy[i], sm[0][c0 + i], sm[5][c0 + i], sm[6][c0 + i]);
+            const float gi = zz > 0.f ? vg[i] : 0.f;
+            const float xh = (vy[i] - sm[0][c0 + i]) * sm[1][c0 + i];
+            vy[i] = sm[2][c0 + i] * (gi - sm[3][c0 + i] - xh * sm[4][c0 + i]);
         }
-        *(u32x4*)(g_out + off) = Chunk<T>::pack(vg);
+        *(u32x4*)(dy + q * CH) = Chunk<T>::pack(vy);
     }
-};
+}
 
 static inline void reduce_geometry(long M, int C, int& nblk, long& rows_per_block) {
     // <= 1024 blocks; at least `min_rows` rows per block (PRIMIA_BN_MINROWS, default 64: the small late
@@ -532,25 +578,24 @@ static int bn_relu_pool_fwd_impl(const void* y, void* pooled, uint8_t* argmax, c
 }
 
 template <typename T>
-static int bn_relu_pool_bwd_impl(const void* y, const void* dpooled, const uint8_t* argmax, void* dy,
-                                 const float* gamma, const float* beta, const float* save_mean,
+static int bn_relu_pool_bwd_impl(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax,
+                                 void* dy, const float* gamma, const float* beta, const float* save_mean,
                                  const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W, int C,
                                  float* partials, hipStream_t st) {
     const long M = (long)N * H * W;
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    const long Mp = (long)N * Ho * Wo;
     int nblk;
     long rpb;
-    reduce_geometry(M, C, nblk, rpb);
-    // pass 1: gather the pool gradient, mask it, reduce it; the masked gradient g is parked in dy
-    PoolBwdFn<T> f{(const T*)y, (const T*)dpooled, argmax, (T*)dy, save_mean, save_invstd, gamma, beta,
-                   H, W, C, Ho, Wo, 1.0f / (float)W, 1.0f / (float)H, {}, {}, {}, {}};
-    colreduce2_kernel<T, PoolBwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
+    reduce_geometry(Mp, C, nblk, rpb);
+    PoolScatterFn<T> f{(const T*)pooled, (const T*)dpooled, argmax, (const T*)y, save_mean, save_invstd, gamma, beta,
+                       H, W, C, Ho, Wo, {}, {}, {}, {}, false};
+    colreduce2_kernel<T, PoolScatterFn<T>><<<nblk, 256, 0, st>>>(f, Mp, C, rpb, partials);
     bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
-    // pass 2: the ordinary apply pass, in place over g
     const long nchunks = M * C / Chunk<T>::N;
-    bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>((const T*)y, nullptr, (const T*)dy, (T*)dy, nullptr,
-                                                                   gamma, save_mean, save_invstd, dbeta, dgamma,
-                                                                   (float)(1.0 / (double)M), nchunks, C, nullptr);
+    bn_relu_pool_bwd_apply_kernel<T><<<stream_blocks(nchunks) * 2, 256, 0, st>>>(
+        (const T*)y, (const T*)dpooled, argmax, (T*)dy, gamma, beta, save_mean, save_invstd, dbeta, dgamma,
+        (float)(1.0 / (double)M), N, H, W, C, Ho, Wo, 1.0f / (float)W, 1.0f / (float)H);
     return launch_status();
 }
 
@@ -697,21 +742,21 @@ int primia_bn_relu_maxpool_fwd_from_sums(const void* y, void* pooled, uint8_t* a
     return launch_status();
 }
 
-int primia_bn_relu_maxpool_bwd(const void* y, const void* dpooled, const uint8_t* argmax, void* dy,
-                               const float* gamma, const float* beta, const float* save_mean,
+int primia_bn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax,
+                               void* dy, const float* gamma, const float* beta, const float* save_mean,
                                const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W, int C,
                                void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream) {
-    PRIMIA_REQUIRE(y && dpooled && argmax && dy && gamma && beta && save_mean && save_invstd && dgamma && dbeta &&
-                   workspace);
+    PRIMIA_REQUIRE(y && pooled && dpooled && argmax && dy && gamma && beta && save_mean && save_invstd && dgamma &&
+                   dbeta && workspace);
     PRIMIA_REQUIRE(N > 0 && H > 0 && W > 0 && bn_shape_ok((long)N * H * W, C, dtype));
-    PRIMIA_REQUIRE((long)N * H * W < (1L << 24));  // float-reciprocal index math
+    PRIMIA_REQUIRE((long)N * H * W < (1L << 31));
     if (workspace_bytes < primia_bn_workspace_bytes((int64_t)N * H * W, C)) return PRIMIA_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32)
-        return bn_relu_pool_bwd_impl<float>(y, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, dgamma,
+        return bn_relu_pool_bwd_impl<float>(y, pooled, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, dgamma,
                                             dbeta, N, H, W, C, (float*)workspace, st);
     if (dtype == PRIMIA_BF16)
-        return bn_relu_pool_bwd_impl<bf16>(y, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, dgamma,
+        return bn_relu_pool_bwd_impl<bf16>(y, pooled, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, dgamma,
                                            dbeta, N, H, W, C, (float*)workspace, st);
     return PRIMIA_ERR_ARG;
 }

@@ -362,7 +362,7 @@ class ResNet18Engine:
             self._conv_fwd("conv1", self.x0, t["stem.y"])
         hw = self.stem_hw
         self._stem_fused = (self.fuse_stem and self.training and self.norm == "batch" and self.spec.pooling == "max"
-                            and not self.fuse_stats and N * hw * hw < (1 << 24))
+                            and not self.fuse_stats)
         if self._stem_fused and getattr(self, "_stem_has_sums", False) and self._stem_padded:
             sm, si = self.save["bn1"]
             call("primia_bn_relu_maxpool_fwd_from_sums", t["stem.y"], t["pool.out"], self.pool_argmax,
@@ -521,7 +521,7 @@ class ResNet18Engine:
         hw = self.stem_hw
         if self._stem_fused:
             sm, si = self.save["bn1"]
-            call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.dout"], self.pool_argmax, t["stem.dy"],
+            call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, t["stem.dy"],
                  self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self.gviews["bn1.weight"],
                  self.gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
         else:

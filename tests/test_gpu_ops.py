@@ -384,8 +384,8 @@ def test_conv_fwd_fused_bn_stats(cuda, dtype, case):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("N,H,C", [(2, 16, 64), (1, 9, 64), (3, 14, 128)])
 def test_bn_relu_maxpool_fused_matches_unfused(cuda, dtype, N, H, C):
-    """The fused stem tail gives bit-identical results to bn_fwd_train -> maxpool (forward) and
-    maxpool_bwd -> bn_bwd (backward), odd sizes included."""
+    """The fused stem tail: forward bit-identical to bn_fwd_train -> maxpool; backward equal to
+    maxpool_bwd -> bn_bwd up to rounding (see primia_bn_relu_maxpool_bwd), odd sizes included."""
     g = torch.Generator().manual_seed(77 + H)
     dt = _lib.dtype_code(dtype)
     M = N * H * H
@@ -393,6 +393,7 @@ def test_bn_relu_maxpool_fused_matches_unfused(cuda, dtype, N, H, C):
     yd = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * 2 + 0.3, dtype), dtype, cuda)
     gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
     beta = torch.randn(C, generator=g).to(cuda)
+    gamma[5], beta[5] = 0.0, 0.7     # a dead scale: z is constant, xhat must come from y (fallback path)
     ws_bytes = query("primia_bn_workspace_bytes", M, C)
     ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
     rm0, rv0 = torch.randn(C, generator=g).to(cuda), (torch.rand(C, generator=g) + 0.5).to(cuda)
@@ -420,9 +421,12 @@ def test_bn_relu_maxpool_fused_matches_unfused(cuda, dtype, N, H, C):
     assert torch.equal(p2, p) and torch.equal(am2, am)
     assert torch.equal(sm2, sm) and torch.equal(si2, si) and torch.equal(rm2, rm) and torch.equal(rv2, rv)
     dy2, dg2, db2 = torch.empty_like(yd), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
-    call("primia_bn_relu_maxpool_bwd", yd, dp, am, dy2, gamma, beta, sm, si, dg2, db2, N, H, H, C, ws, ws_bytes, dt)
-    assert torch.equal(dg2, dg) and torch.equal(db2, db)
-    assert torch.equal(dy2, dy)
+    call("primia_bn_relu_maxpool_bwd", yd, p, dp, am, dy2, gamma, beta, sm, si, dg2, db2, N, H, H, C, ws, ws_bytes, dt)
+    # the fused backward sums dgamma / dbeta at pooled resolution (no intermediate rounding of the pool gradient,
+    # xhat from the stored activation): equal to the unfused chain up to rounding
+    f32 = dtype == torch.float32
+    assert relerr(db2, db) < (1e-6 if f32 else 2e-3) and relerr(dg2, dg) < (1e-5 if f32 else 5e-3)
+    assert relerr(dy2.float(), dy.float()) < (1e-5 if f32 else 2e-2)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
