@@ -577,6 +577,89 @@ static int bn_relu_pool_fwd_impl(const void* y, void* pooled, uint8_t* argmax, c
     return launch_status();
 }
 
+// The same apply pass for even H and W, one thread per 2 x 2 block of input pixels (x one 16-byte channel chunk).
+// Input pixel (2a + i, 2b + j) can only be the argmax of the windows (a + di, b + dj) with di <= i, dj <= j, at tap
+// (1 + i - 2 di, 1 + j - 2 dj): the block shares 4 windows, loaded once (8 loads instead of up to 32 for four
+// independent gathers), and needs 9 code comparisons instead of 16.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply2x2_kernel(
+    const T* __restrict__ y, const T* __restrict__ dp, const uint8_t* __restrict__ argmax, T* __restrict__ dy,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_m,
+    int N, int H, int W, int C, int Ho, int Wo) {
+    constexpr int CH = Chunk<T>::N;
+    __shared__ float sm[7][512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        sm[0][c] = mean[c];
+        sm[1][c] = invstd[c];
+        sm[2][c] = gamma[c] * invstd[c];
+        sm[3][c] = dbeta[c] * inv_m;
+        sm[4][c] = dgamma[c] * inv_m;
+        sm[5][c] = invstd[c] * gamma[c];
+        sm[6][c] = beta[c];
+    }
+    __syncthreads();
+    const int cpr = C / CH, H2 = H >> 1, W2 = W >> 1;
+    const long total = (long)N * H2 * W2 * cpr;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int c0 = (int)(q % cpr) * CH;
+    long t = q / cpr;
+    const int b = (int)(t % W2);
+    t /= W2;
+    const int a = (int)(t % H2), n = (int)(t / H2);
+    // the 4 windows (a + di, b + dj): gradient values and argmax codes (invalid windows: code 0xff never matches)
+    float wv[2][2][CH];
+    unsigned code[2][2][CH];
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+            const bool ok = a + di < Ho && b + dj < Wo;
+            const long o = (((long)n * Ho + (ok ? a + di : 0)) * Wo + (ok ? b + dj : 0)) * C + c0;
+            Chunk<T>::unpack(*(const u32x4*)(dp + o), wv[di][dj]);
+            if (CH == 8) {
+                const u32x2 m = *(const u32x2*)(argmax + o);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    code[di][dj][k] = ok ? (m[0] >> (8 * k)) & 0xffu : 0xffu;
+                    code[di][dj][4 + k] = ok ? (m[1] >> (8 * k)) & 0xffu : 0xffu;
+                }
+            } else {
+                const uint32_t m = *(const uint32_t*)(argmax + o);
+#pragma unroll
+                for (int k = 0; k < CH; ++k) code[di][dj][k] = ok ? (m >> (8 * k)) & 0xffu : 0xffu;
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long off = ((((long)n * H + 2 * a + i) * W) + 2 * b + j) * C + c0;
+            float vy[CH], g[CH];
+            Chunk<T>::unpack(*(const u32x4*)(y + off), vy);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) g[k] = 0.f;
+            // same summation order as the generic gather: window row a + i first ... i.e. candidates A then B per axis
+#pragma unroll
+            for (int di = i; di >= 0; --di)
+#pragma unroll
+                for (int dj = j; dj >= 0; --dj) {
+                    const unsigned want = (unsigned)((1 + i - 2 * di) * 3 + (1 + j - 2 * dj));
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) g[k] += code[di][dj][k] == want ? wv[di][dj][k] : 0.f;
+                }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const float zz = bn_affine(vy[k], sm[0][c0 + k], sm[5][c0 + k], sm[6][c0 + k]);
+                const float gi = zz > 0.f ? g[k] : 0.f;
+                const float xh = (vy[k] - sm[0][c0 + k]) * sm[1][c0 + k];
+                vy[k] = sm[2][c0 + k] * (gi - sm[3][c0 + k] - xh * sm[4][c0 + k]);
+            }
+            *(u32x4*)(dy + off) = Chunk<T>::pack(vy);
+        }
+}
+
 template <typename T>
 static int bn_relu_pool_bwd_impl(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax,
                                  void* dy, const float* gamma, const float* beta, const float* save_mean,
@@ -593,9 +676,16 @@ static int bn_relu_pool_bwd_impl(const void* y, const void* pooled, const void* 
     colreduce2_kernel<T, PoolScatterFn<T>><<<nblk, 256, 0, st>>>(f, Mp, C, rpb, partials);
     bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
     const long nchunks = M * C / Chunk<T>::N;
-    bn_relu_pool_bwd_apply_kernel<T><<<stream_blocks(nchunks) * 2, 256, 0, st>>>(
-        (const T*)y, (const T*)dpooled, argmax, (T*)dy, gamma, beta, save_mean, save_invstd, dbeta, dgamma,
-        (float)(1.0 / (double)M), N, H, W, C, Ho, Wo, 1.0f / (float)W, 1.0f / (float)H);
+    if (H % 2 == 0 && W % 2 == 0) {
+        const long total = nchunks / 4;
+        bn_relu_pool_bwd_apply2x2_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+            (const T*)y, (const T*)dpooled, argmax, (T*)dy, gamma, beta, save_mean, save_invstd, dbeta, dgamma,
+            (float)(1.0 / (double)M), N, H, W, C, Ho, Wo);
+    } else {
+        bn_relu_pool_bwd_apply_kernel<T><<<stream_blocks(nchunks) * 2, 256, 0, st>>>(
+            (const T*)y, (const T*)dpooled, argmax, (T*)dy, gamma, beta, save_mean, save_invstd, dbeta, dgamma,
+            (float)(1.0 / (double)M), N, H, W, C, Ho, Wo, 1.0f / (float)W, 1.0f / (float)H);
+    }
     return launch_status();
 }
 
