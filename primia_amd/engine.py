@@ -461,9 +461,11 @@ class ResNet18Engine:
                                                                              self.dt)))
 
     # Weight gradients are leaves of the backward graph (nothing reads them before the finalize) and every layer
-    # has its own dy buffer, so they CAN run on a second stream next to the BatchNorm / dgrad chain.  Measured
-    # (MI355X, batch 256, hipGraph): 7.70 ms serial -> 7.91 ms overlapped — the wgrad blocks (8 waves, 80 KB LDS)
-    # and the data-gradient tiles evict each other from the CUs.  Off by default.
+    # has its own dy buffer, so they can run on a second stream.  Overlapping them with EVERYTHING was slower
+    # (7.70 -> 7.91 ms: wgrad and dgrad tiles evict each other from the CUs).  With `wgrad_overlap` the schedule is
+    # narrower: a layer's wgrad starts after its sibling dgrad and runs beside the BatchNorm backward chain that
+    # follows (HBM-bound kernels and 7-us finalize launches); the next dgrad waits for it.  Also slower on
+    # MI355X (7.10 ms serial -> 7.30 ms): kept as an option for other shapes, off by default.
     wgrad_overlap = False
 
     def _on_wgrad_stream(self, fn):
@@ -484,6 +486,7 @@ class ResNet18Engine:
 
     def _dgrad(self, name, dy, dx, accumulate):
         c = self.convs[name]
+        self._join_wgrad_stream()   # (overlap mode) two MFMA-bound kernels never run side by side
         self._timed("dgrad", c,
                     lambda: call("primia_conv2d_dgrad", c.desc, dy, c.w_dgrad, dx, int(accumulate), self.dt))
 
@@ -506,18 +509,20 @@ class ResNet18Engine:
             dout = t[p + ".dout"]
             # bn2 (+residual, relu): dy2, and the masked gradient g written back over dout
             self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True)
-            self._wgrad(blk.conv2.name, t[p + ".a1"], t[p + ".dy2"])
+            # data gradient first: the weight gradient (a leaf) then runs beside the BatchNorm chain that follows
             self._dgrad(blk.conv2.name, t[p + ".dy2"], t[p + ".da1"], False)
+            self._wgrad(blk.conv2.name, t[p + ".a1"], t[p + ".dy2"])
             self._bn_bwd(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], t[p + ".da1"], t[p + ".dy1"], None, True)
-            self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
             if blk.down is not None:
                 self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, False)
+                self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
                 self._bn_bwd(blk.down.name, t[p + ".yd"], None, dout, t[p + ".dyd"], None, False)
-                self._wgrad(blk.down.name, x_in, t[p + ".dyd"])
                 self._dgrad(blk.down.name, t[p + ".dyd"], dx_in, True)
+                self._wgrad(blk.down.name, x_in, t[p + ".dyd"])
             else:
                 # identity skip: dx_in aliases dout, which now holds the masked gradient g
                 self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, True)
+                self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
         hw = self.stem_hw
         if self._stem_fused:
             sm, si = self.save["bn1"]
