@@ -355,27 +355,69 @@ def matthews_corrcoef(y_true, y_pred, num_classes):
     return float(num / den) if den > 0 else 0.0
 
 
+def stats_table(conf_matrix, report, roc_auc=0.0, matthews_coeff=0.0, class_names=None, epoch=0):
+    """The validation table of torchlib/utils.py:1295-1351: one row per class (recall, precision, F1, support,
+    confusion-matrix row), macro / weighted averages, then micro recall, MCC and ROC AUC; `fancy_grid`."""
+    from tabulate import tabulate
+
+    pct = lambda v: "{:.1f} %".format(v * 100.0)
+    n = conf_matrix.shape[0]
+    label = lambda i: class_names[i] if class_names else i
+    rows = []
+    for i in range(n):
+        e = report[str(i)]
+        rows.append([label(i), pct(e["recall"]), pct(e["precision"]), pct(e["f1-score"]), e["support"]]
+                    + [conf_matrix[i, j] for j in range(conf_matrix.shape[1])])
+    for title, key in (("Overall (macro)", "macro avg"), ("Overall (weighted)", "weighted avg")):
+        e = report[key]
+        rows.append([title, pct(e["recall"]), pct(e["precision"]), pct(e["f1-score"]), e["support"]])
+    rows.append(["Overall stats", "micro recall", "matthews coeff", "AUC ROC score"])
+    rows.append(["", pct(report["accuracy"]), "{:.3f}".format(matthews_coeff), "{:.3f}".format(roc_auc)])
+    headers = ["Epoch {:d}".format(epoch), "Recall", "Precision", "F1 score", "n total"] + [label(i) for i in range(n)]
+    return tabulate(rows, headers=headers, tablefmt="fancy_grid")
+
+
 def test(args, model, device, val_loader, epoch, loss_fn, num_classes, verbose=True, vis_params=None,
          class_names=None):
-    """torchlib/utils.py:1354-1467 reduced to what the training loop consumes: (loss, objective)."""
+    """torchlib/utils.py:1354-1467 (plaintext branch): mean batch loss, ROC AUC (one-vs-one on the min-shifted,
+    row-normalised logits), MCC; returns (loss, 100 * MCC) — the objective train.py maximises — and prints the
+    reference's table when verbose."""
+    from warnings import warn
+
     import numpy as np
     import torch
 
     model.eval()
-    losses, preds, tgts = [], [], []
+    losses, preds, tgts, scores = [], [], [], []
     for data, target in val_loader:
         logits = model.forward(data)
         ls = torch.log_softmax(logits, dim=1)
         losses.append(float(-ls.gather(1, target.view(-1, 1)).mean().item()))
+        scores.append(logits.detach().float().cpu().numpy().copy())
         preds += logits.argmax(1).tolist()
         tgts += target.tolist()
     model.train()
-    acc = float(np.mean(np.array(preds) == np.array(tgts)))
+    test_loss = float(np.mean(losses))
+    total_scores = np.concatenate(scores)
+    total_scores -= total_scores.min(axis=1)[:, np.newaxis]
+    total_scores = total_scores / total_scores.sum(axis=1)[:, np.newaxis]
+    try:
+        from sklearn import metrics as mt
+
+        roc_auc = mt.roc_auc_score(np.asarray(tgts), total_scores, multi_class="ovo")
+    except ValueError:
+        warn("ROC AUC score could not be calculated and was set to zero.", category=UserWarning)
+        roc_auc = 0.0
     mcc = matthews_corrcoef(tgts, preds, num_classes)
     if verbose:
-        print("Test set: Epoch: {:d} Average loss: {:.4f}, Accuracy: {:.1f}%\tMCC: {:.3f}".format(
-            epoch, float(np.mean(losses)), 100 * acc, mcc))
-    return float(np.mean(losses)), mcc
+        from sklearn import metrics as mt
+
+        cm = mt.confusion_matrix(tgts, preds, labels=list(range(num_classes)))
+        rep = mt.classification_report(tgts, preds, labels=list(range(num_classes)), output_dict=True, zero_division=0)
+        if "accuracy" not in rep:   # sklearn omits it when `labels` is a superset of the observed classes
+            rep["accuracy"] = float(np.mean(np.asarray(preds) == np.asarray(tgts)))
+        print(stats_table(cm, rep, roc_auc=roc_auc, matthews_coeff=mcc, class_names=class_names, epoch=epoch))
+    return test_loss, 100.0 * mcc
 
 
 def save_model(model, optim, path, args, epoch, val_mean_std):

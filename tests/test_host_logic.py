@@ -104,3 +104,23 @@ def test_torchlib_shim_and_checkpoint_argument_pickle(tmp_path):
     assert isinstance(st["args"], Arguments) and st["epoch"] == 3
     from torchlib.run_websocket_server import read_websocket_config  # noqa: F401
     from torchlib.utils import LearningRateScheduler, MixUp, To_one_hot, train_federated  # noqa: F401
+
+
+def test_stats_table_matches_reference_rendering():
+    """The validation table against the text rendered by the reference's own stats_table
+    (tests/golden/make_metrics_golden.py), and test()'s objective = 100 * MCC."""
+    import os
+
+    import numpy as np
+    from sklearn import metrics as mt
+
+    from primia_amd.torchlib_compat import matthews_corrcoef, stats_table
+
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "metrics.npz"))
+    for name, names in (("named", ["normal", "bacterial", "viral"]), ("numbered", None)):
+        t, p = gold[f"{name}.target"], gold[f"{name}.pred"]
+        cm = mt.confusion_matrix(t, p)
+        rep = mt.classification_report(t, p, output_dict=True, zero_division=0)
+        text = stats_table(cm, rep, roc_auc=0.8123, matthews_coeff=0.5678, class_names=names, epoch=7)
+        assert text == bytes(gold[f"{name}.table"]).decode("utf-8")
+        assert abs(matthews_corrcoef(t.tolist(), p.tolist(), 3) - mt.matthews_corrcoef(t, p)) < 1e-12

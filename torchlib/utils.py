@@ -7,6 +7,7 @@ from primia_amd.torchlib_compat import (  # noqa: F401
     save_model,
     secure_aggregation_epoch,
     send_new_models,
+    stats_table,
     test,
     train,
     train_federated,
