@@ -608,28 +608,24 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply2x2_kernel(
     const int b = (int)(t % W2);
     t /= W2;
     const int a = (int)(t % H2), n = (int)(t / H2);
-    // the 4 windows (a + di, b + dj): gradient values and argmax codes (invalid windows: code 0xff never matches)
-    float wv[2][2][CH];
-    unsigned code[2][2][CH];
+    // the 4 windows (a + di, b + dj), kept PACKED (24 registers; unpacked they would be 64 and the occupancy of this
+    // latency-bound gather halves): gradient chunk and argmax codes (invalid windows: code 0xff never matches)
+    u32x4 wraw[2][2];
+    u32x2 craw[2][2];
 #pragma unroll
     for (int di = 0; di < 2; ++di)
 #pragma unroll
         for (int dj = 0; dj < 2; ++dj) {
             const bool ok = a + di < Ho && b + dj < Wo;
             const long o = (((long)n * Ho + (ok ? a + di : 0)) * Wo + (ok ? b + dj : 0)) * C + c0;
-            Chunk<T>::unpack(*(const u32x4*)(dp + o), wv[di][dj]);
+            wraw[di][dj] = *(const u32x4*)(dp + o);
             if (CH == 8) {
-                const u32x2 m = *(const u32x2*)(argmax + o);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    code[di][dj][k] = ok ? (m[0] >> (8 * k)) & 0xffu : 0xffu;
-                    code[di][dj][4 + k] = ok ? (m[1] >> (8 * k)) & 0xffu : 0xffu;
-                }
+                craw[di][dj] = *(const u32x2*)(argmax + o);
             } else {
-                const uint32_t m = *(const uint32_t*)(argmax + o);
-#pragma unroll
-                for (int k = 0; k < CH; ++k) code[di][dj][k] = ok ? (m >> (8 * k)) & 0xffu : 0xffu;
+                craw[di][dj][0] = *(const uint32_t*)(argmax + o);
+                craw[di][dj][1] = 0xffffffffu;
             }
+            if (!ok) craw[di][dj] = u32x2{0xffffffffu, 0xffffffffu};
         }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -646,8 +642,13 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply2x2_kernel(
 #pragma unroll
                 for (int dj = j; dj >= 0; --dj) {
                     const unsigned want = (unsigned)((1 + i - 2 * di) * 3 + (1 + j - 2 * dj));
+                    float wv[CH];
+                    Chunk<T>::unpack(wraw[di][dj], wv);
 #pragma unroll
-                    for (int k = 0; k < CH; ++k) g[k] += code[di][dj][k] == want ? wv[di][dj][k] : 0.f;
+                    for (int k = 0; k < CH; ++k) {
+                        const unsigned code = (craw[di][dj][k >> 2] >> (8 * (k & 3))) & 0xffu;
+                        g[k] += code == want ? wv[k] : 0.f;
+                    }
                 }
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
@@ -657,6 +658,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply2x2_kernel(
                 vy[k] = sm[2][c0 + k] * (gi - sm[3][c0 + k] - xh * sm[4][c0 + k]);
             }
             *(u32x4*)(dy + off) = Chunk<T>::pack(vy);
+            // keep the four pixels' work apart: hoisting all of it to the top costs 174 VGPRs (occupancy 2) and
+            // this gather lives on waves in flight
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         }
 }
 
