@@ -55,6 +55,10 @@ if __name__ == "__main__":
     parser.add_argument("--hip_graph", action="store_true",
                         help="encrypted inference: capture the online phase once as a hipGraph and replay it per image "
                              "(the dealer refills the primitive buffers between images)")
+    parser.add_argument("--three_role", action="store_true",
+                        help="encrypted inference with model_owner, data_owner and crypto_provider as three ranks "
+                             "(launch with `python -m torch.distributed.run --nproc-per-node 3 inference.py ...`): "
+                             "one GPU each over RCCL when three are visible, else all on GPU 0 over gloo")
     cmd_args = parser.parse_args()
     if not torch.cuda.is_available():
         raise SystemExit("primia_amd runs inference on the GPU only (HIP kernels); no GPU visible")
@@ -72,16 +76,43 @@ if __name__ == "__main__":
     total_pred = []
     if args.encrypted_inference:
         # inference.py:279-286: fix_precision(precision_fractional=16, dtype="long").share(..., protocol="fss")
-        if cmd_args.hip_graph:
+        if cmd_args.three_role:
+            import torch.distributed as dist
+
+            from primia_amd.secure import PartyLink, architecture_of, run_three_role
+
+            multi = torch.cuda.device_count() >= 3
+            rank = int(os.environ["RANK"])
+            device = torch.device("cuda", rank if multi else 0)
+            torch.cuda.set_device(device)
+            dist.init_process_group(os.environ.get("PRIMIA_PARTY_BACKEND", "nccl" if multi else "gloo"))
+            link = PartyLink(device)
+            # one checkpoint file serves all three ranks of a single-node launch; each role is handed only what
+            # it owns: the weights (party 0), the images (party 1), the architecture (everyone)
+            logits = run_three_role(link, architecture_of(sd), size, images.shape[0],
+                                    state_dict=sd if link.role == 0 else None,
+                                    images=images.to(device) if link.role == 1 else None, seed=0)
+            dist.barrier()
+            dist.destroy_process_group()
+            if link.role != 1:
+                sys.exit(0)
+            total_pred = [int(o.argmax(dim=1).item()) for o in logits]
+            if os.environ.get("PRIMIA_DUMP_LOGITS"):
+                torch.save(torch.cat(logits).cpu(), os.environ["PRIMIA_DUMP_LOGITS"])
+        elif cmd_args.hip_graph:
             from primia_amd.secure import GraphedSecureInference
 
             model = GraphedSecureInference(sd, device, input_size=size, precision_fractional=16, seed=0)
         else:
             ctx = SecureContext(Dealer(device, seed=0), base=10, precision_fractional=16)
             model = SecureResNet18(ctx, sd, input_size=size)
-        for i in range(images.shape[0]):
+        logits = []
+        for i in range(0 if cmd_args.three_role else images.shape[0]):
             out = model(images[i:i + 1].to(device))
+            logits.append(out)
             total_pred.append(int(out.argmax(dim=1).item()))
+        if logits and os.environ.get("PRIMIA_DUMP_LOGITS"):
+            torch.save(torch.cat(logits).cpu(), os.environ["PRIMIA_DUMP_LOGITS"])
     else:
         eng = ResNet18Engine(1, sd["fc.weight"].shape[0], sd["conv1.weight"].shape[1], size,
                              getattr(args, "pooling_type", "max"), dtype=torch.float32, device=device)

@@ -60,7 +60,7 @@ class Dealer:
 
     def triple(self, op, xshape, yshape):
         if self.requests is not None:
-            self.requests.append(("triple", (op, tuple(xshape), tuple(yshape))))
+            self.requests.append(("triple", (op, tuple(xshape), tuple(yshape)), {}))
         a, b = self.rand64(*xshape), self.rand64(*yshape)
         if op == "mul":
             # element-wise with the smaller operand broadcast over the leading dims
@@ -81,7 +81,7 @@ class Dealer:
 
     def dif_keys(self, n):
         if self.requests is not None:
-            self.requests.append(("dif_keys", (n,)))
+            self.requests.append(("dif_keys", (n,), {}))
         dev = self.device
         alpha = torch.randint(0, 2 ** 32, (n,), dtype=I64, device=dev, generator=self.gen)
         s0 = self.rand64(2, 2, n)
@@ -101,9 +101,11 @@ class Dealer:
             self.tape.append(keys)
         return keys
 
-    def const_mask(self, *shape):
+    def const_mask(self, *shape, owner=None):
+        """The mask of a fresh sharing; `owner` (None = public value, else the party that holds the secret)
+        only matters to a distributed dealer, which sends the mask to the owner alone."""
         if self.requests is not None:
-            self.requests.append(("const_mask", tuple(shape)))
+            self.requests.append(("const_mask", tuple(shape), {"owner": owner}))
         r = self.rand64(*shape)
         if self.log is not None:
             self.log.append(("mask", r.cpu().numpy()))
@@ -131,44 +133,49 @@ class PreloadedDealer:
     def dif_keys(self, n):
         return self._next()
 
-    def const_mask(self, *shape):
+    def const_mask(self, *shape, owner=None):
         return self._next()
 
 
 class LocalOpener:
     """Both parties' shares live on this GPU: open = one ring add."""
 
-    def open(self, s0, s1):
-        out = _empty_like(s0)
-        call("primia_ring_add", s0, s1, out, s0.numel(), s0.numel())
+    def open(self, shares):
+        out = _empty_like(shares[0])
+        call("primia_ring_add", shares[0], shares[1], out, shares[0].numel(), shares[0].numel())
         return out
 
 
 class DistOpener:
-    """One party per rank (party j = rank j of a 2-rank group, e.g. two GPUs over xGMI): every rank
-    passes ITS share in slot `rank` and a dummy in the other; open = all_reduce(SUM) of the local
-    share — the 2-party exchange the reference routes through the orchestrator
-    (mpc/spdz.py:162-176, mpc/fss.py:158-170)."""
+    """One party per rank (party j = rank j of the 2-rank party group, e.g. two GPUs over xGMI): open = an
+    int64 all_reduce(SUM) of the local share, which wraps mod 2^64 — the 2-party exchange the reference routes
+    through the orchestrator (mpc/spdz.py:162-176, mpc/fss.py:158-170)."""
 
-    def __init__(self, group=None):
+    def __init__(self, group=None, party=None):
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
-        self.rank = dist.get_rank(group)
+        self.party = dist.get_rank(group) if party is None else party
 
-    def open(self, s0, s1):
-        mine = (s0, s1)[self.rank].clone()
-        self.dist.all_reduce(mine, op=self.dist.ReduceOp.SUM, group=self.group)  # int64 sum wraps mod 2^64
+    def open(self, shares):
+        mine = shares[self.party].clone()
+        self.dist.all_reduce(mine, op=self.dist.ReduceOp.SUM, group=self.group)
         return mine
 
 
 class SecureContext:
-    def __init__(self, dealer, base=10, precision_fractional=16, opener=None):
+    def __init__(self, dealer, base=10, precision_fractional=16, opener=None, party=None, link=None):
+        """party=None: both parties' shares live in this process (a share is a 2-list).  party=j: this process
+        is party j of a distributed run — every 2-list carries only entry j (the other is None), `opener` must
+        be a DistOpener and `link` a PartyLink for the owner-to-peer transfer of freshly shared secrets."""
         self.dealer = dealer
         self.base = base
         self.pf = precision_fractional
         self.scale = base ** precision_fractional
         self.opener = opener or LocalOpener()
+        self.party = party
+        self.parties = (0, 1) if party is None else (party,)
+        self.link = link
         self.stats = {"beaver_mul": 0, "beaver_matmul": 0, "dif_evals": 0}
 
     # ---- encode / share / reconstruct -----------------------------------------------------------
@@ -182,27 +189,55 @@ class SecureContext:
         call("primia_fx_decode", q, x, q.numel(), float(self.scale))
         return x
 
-    def share(self, q):
-        """share_secret (additive_shared.py:317-365): (r, q - r)."""
-        r = self.dealer.const_mask(*q.shape)
-        s1 = _empty_like(q)
-        call("primia_ring_sub", q, r, s1, q.numel(), q.numel())
-        return [r, s1]
+    def share(self, q, owner=None, shape=None):
+        """share_secret (additive_shared.py:317-365): (r, q - r) with r from the crypto provider.
+        `owner`: the party that knows q (0 = model owner, 1 = data owner) or None for a value both parties
+        know.  In a distributed run the mask goes to the owner only (to both for a public value); the owner
+        forms q - r and hands the peer ITS share; a non-owner passes q = None and `shape`."""
+        shape = tuple(q.shape) if q is not None else tuple(shape)
+        if self.party is None:
+            r = self.dealer.const_mask(*shape, owner=owner)
+            s1 = _empty_like(q)
+            call("primia_ring_sub", q, r, s1, q.numel(), q.numel())
+            return [r, s1]
+        me, out = self.party, [None, None]
+        if owner is None or owner == me:
+            r = self.dealer.const_mask(*shape, owner=owner)
+            s1 = _empty_like(r)
+            call("primia_ring_sub", q, r, s1, r.numel(), r.numel())
+            mine, theirs = (r, s1) if me == 0 else (s1, r)
+            out[me] = mine
+            if owner is not None:
+                self.link.send_to_peer(theirs)
+        else:
+            out[me] = self.link.recv_from_peer(shape)
+        return out
 
     def reconstruct(self, x):
-        return self.opener.open(x[0], x[1])
+        return self.opener.open(x)
+
+    def _ref(self, x):
+        """The share this process holds (shapes / devices are read from it)."""
+        return x[self.parties[0]]
+
+    def _each(self, fn):
+        """[fn(j) for the parties hosted here], as a 2-list."""
+        out = [None, None]
+        for j in self.parties:
+            out[j] = fn(j)
+        return out
 
     # ---- local (per-share) ops -------------------------------------------------------------------
     def _ew(self, fn, a, b):
-        out = []
-        for j in range(2):
+        def one(j):
             big, small = (a[j], b[j])
             if small.numel() > big.numel():
                 raise ValueError("second operand must not be larger")
             o = _empty_like(big)
             call(fn, big, small, o, big.numel(), small.numel())
-            out.append(o)
-        return out
+            return o
+
+        return self._each(one)
 
     def add(self, a, b):
         return self._ew("primia_ring_add", a, b)
@@ -211,69 +246,73 @@ class SecureContext:
         return self._ew("primia_ring_sub", a, b)
 
     def neg(self, a):
-        out = []
-        for j in range(2):
+        def one(j):
             o = _empty_like(a[j])
             call("primia_ring_scale", a[j], -1, o, a[j].numel())
-            out.append(o)
-        return out
+            return o
+
+        return self._each(one)
 
     def trunc(self, a, d):
-        out = []
-        for j in range(2):
+        def one(j):
             o = _empty_like(a[j])
             call("primia_trunc_div", a[j], int(d), o, a[j].numel())
-            out.append(o)
-        return out
+            return o
+
+        return self._each(one)
 
     def sub_public_scalar(self, a, value):
         """AST - int (additive_shared.py:453-484, 506-524): the constant becomes a FRESH random
         sharing of shape [1] that is subtracted share-wise (broadcast)."""
-        c = torch.full((1,), int(value), dtype=I64, device=a[0].device)  # device-side fill: graph-capturable
+        c = torch.full((1,), int(value), dtype=I64, device=self._ref(a).device)  # device-side fill: graph-capturable
         return self.sub(a, self.share(c))
 
     # ---- Beaver -----------------------------------------------------------------------------------
     def beaver_mul(self, x, y):
         """Element-wise private product (no truncation).  One operand may be a vector broadcast over
         the other's leading dims; the ring product is symmetric so the big one is taken first."""
-        swap = x[0].numel() < y[0].numel()
-        t = self.dealer.triple("mul", tuple(x[0].shape), tuple(y[0].shape))
+        xr, yr = self._ref(x), self._ref(y)
+        swap = xr.numel() < yr.numel()
+        t = self.dealer.triple("mul", tuple(xr.shape), tuple(yr.shape))
         if swap:
-            x, y = y, x
-            t = [(tj[1], tj[0], tj[2]) for tj in t]
-        n, nb = x[0].numel(), y[0].numel()
-        d = [_empty_like(x[0]) for _ in range(2)]
-        e = [_empty_like(y[0]) for _ in range(2)]
-        for j in range(2):  # spdz_mask
+            x, y, xr, yr = y, x, yr, xr
+            t = [None if tj is None else (tj[1], tj[0], tj[2]) for tj in t]
+        n, nb = xr.numel(), yr.numel()
+        d, e = [None, None], [None, None]
+        for j in self.parties:  # spdz_mask
+            d[j], e[j] = _empty_like(xr), _empty_like(yr)
             call("primia_ring_sub", x[j], t[j][0], d[j], n, n)
             call("primia_ring_sub", y[j], t[j][1], e[j], nb, nb)
-        delta, eps = self.opener.open(d[0], d[1]), self.opener.open(e[0], e[1])
-        z = []
-        for j in range(2):  # spdz_compute
-            o = _empty_like(x[0])
+        delta, eps = self.opener.open(d), self.opener.open(e)
+
+        def one(j):  # spdz_compute
+            o = _empty_like(xr)
             call("primia_beaver_combine_mul", j, delta, eps, t[j][0], t[j][1], t[j][2], o, n, nb)
-            z.append(o)
+            return o
+
         self.stats["beaver_mul"] += 1
-        return z
+        return self._each(one)
 
     def beaver_matmul(self, x, y):
-        M, K = x[0].shape[-2], x[0].shape[-1]
-        N = y[0].shape[-1]
-        t = self.dealer.triple("matmul", tuple(x[0].shape), tuple(y[0].shape))
-        d = [_empty_like(x[0]) for _ in range(2)]
-        e = [_empty_like(y[0]) for _ in range(2)]
-        for j in range(2):
-            call("primia_ring_sub", x[j], t[j][0], d[j], x[j].numel(), x[j].numel())
-            call("primia_ring_sub", y[j], t[j][1], e[j], y[j].numel(), y[j].numel())
-        delta, eps = self.opener.open(d[0], d[1]), self.opener.open(e[0], e[1])
-        z = []
-        scratch = torch.empty(K * N, dtype=I64, device=x[0].device)
-        for j in range(2):
-            o = torch.empty(*x[0].shape[:-1], N, dtype=I64, device=x[0].device)
+        xr, yr = self._ref(x), self._ref(y)
+        M, K = xr.shape[-2], xr.shape[-1]
+        N = yr.shape[-1]
+        t = self.dealer.triple("matmul", tuple(xr.shape), tuple(yr.shape))
+        d, e = [None, None], [None, None]
+        for j in self.parties:
+            d[j], e[j] = _empty_like(xr), _empty_like(yr)
+            call("primia_ring_sub", x[j], t[j][0], d[j], xr.numel(), xr.numel())
+            call("primia_ring_sub", y[j], t[j][1], e[j], yr.numel(), yr.numel())
+        delta, eps = self.opener.open(d), self.opener.open(e)
+        scratch = torch.empty(K * N, dtype=I64, device=xr.device)
+
+        def one(j):
+            o = torch.empty(*xr.shape[:-1], N, dtype=I64, device=xr.device)
             call("primia_beaver_combine_matmul", j, delta, eps, t[j][0], t[j][1], t[j][2], o, scratch, M, K, N)
-            z.append(o)
+            return o
+
         self.stats["beaver_matmul"] += 1
-        return z
+        return self._each(one)
 
     def fpt_mul(self, x, y):
         """FPT * FPT (precision.py:309-316, 356-358): Beaver mul, then per-share truncation."""
@@ -286,23 +325,28 @@ class SecureContext:
     # ---- FSS comparison ------------------------------------------------------------------------------
     def le(self, x1, x2):
         """fss.le(x1, x2) (mpc/fss.py:97-185, 279): int64 shares of the bit [x1 <= x2]."""
-        n = x1[0].numel()
+        xr = self._ref(x1)
+        n = xr.numel()
         keys = self.dealer.dif_keys(n)
-        r = []
-        for j in range(2):  # mask_builder
-            o = _empty_like(x1[j])
-            call("primia_fss_mask", x1[j], x2[j], keys[j]["alpha"], o, n)
-            r.append(o)
-        masked = torch.empty(n, dtype=torch.int32, device=x1[0].device)
-        call("primia_fss_open", r[0], r[1], masked, n)
-        out = []
-        for j in range(2):  # evaluate
-            o = _empty_like(x1[j])
+        r = [None, None]
+        for j in self.parties:  # mask_builder
+            r[j] = _empty_like(xr)
+            call("primia_fss_mask", x1[j], x2[j], keys[j]["alpha"], r[j], n)
+        masked = torch.empty(n, dtype=torch.int32, device=xr.device)
+        if self.party is None:
+            call("primia_fss_open", r[0], r[1], masked, n)
+        else:  # the parties exchange their masked shares; the sum is taken mod 2^32 (fss.py:158-170)
+            opened = self.opener.open(r)
+            call("primia_fss_open", opened, torch.zeros_like(opened), masked, n)
+
+        def one(j):  # evaluate
+            o = _empty_like(xr)
             k = keys[j]
             call("primia_dif_eval", j, masked, k["s0"], k["bits"], k["cw_sigma"], k["cw_s"], k["cw_leaf"], o, n)
-            out.append(o)
+            return o
+
         self.stats["dif_evals"] += n
-        return out
+        return self._each(one)
 
     def relu(self, x):
         """AST.relu under fss (additive_shared.py:922-925): x * (x >= 0), (x >= 0) = le(x - x, x)."""
@@ -315,37 +359,38 @@ class SecureContext:
         return self.add(left, self.beaver_mul(bit, self.sub(right, left)))
 
     def _cols(self, x, rows, w, start, length):
-        out = []
-        for j in range(2):
+        def one(j):
             o = torch.empty(rows, length, dtype=I64, device=x[j].device)
             call("primia_ring_slice_cols", x[j], o, rows, w, start, length)
-            out.append(o)
-        return out
+            return o
+
+        return self._each(one)
 
     # ---- layers (nn/functional.py) ------------------------------------------------------------------
     def conv2d(self, x, w, stride, padding):
         """conv2d (nn/functional.py:204-308): per-share im2col, Beaver matmul + truncation,
         per-share reshape.  x shares [1,C,H,W]; w shares [O,C,R,S]; no bias in ResNet convs."""
-        B, C, H, W = x[0].shape
-        O, _, R, S = w[0].shape
+        B, C, H, W = self._ref(x).shape
+        O, _, R, S = self._ref(w).shape
         Ho, Wo = (H + 2 * padding - R) // stride + 1, (W + 2 * padding - S) // stride + 1
         K = C * R * S
-        im, wt = [], []
-        for j in range(2):
+        im, wt = [None, None], [None, None]
+        for j in self.parties:
             a = torch.empty(B, Ho * Wo, K, dtype=I64, device=x[j].device)
             call("primia_im2col_syft", x[j], a, B, C, H, W, R, S, stride, padding)
-            im.append(a)
+            im[j] = a
             # weight.reshape(O, -1).t(): [K, O]
             t = torch.empty(K, O, dtype=I64, device=x[j].device)
             call("primia_col2out_syft", w[j], None, t, 1, O, K)
-            wt.append(t)
+            wt[j] = t
         res = self.fpt_matmul(im, wt)
-        out = []
-        for j in range(2):
-            o = torch.empty(B, O, Ho, Wo, dtype=I64, device=x[j].device)
+
+        def one(j):
+            o = torch.empty(B, O, Ho, Wo, dtype=I64, device=res[j].device)
             call("primia_col2out_syft", res[j], None, o, B, Ho * Wo, O)
-            out.append(o)
-        return out
+            return o
+
+        return self._each(one)
 
     def reciprocal_newton(self, v):
         """FPT.reciprocal(method="newton") (precision.py:507-518), C = 20, 80 iterations."""
@@ -365,69 +410,76 @@ class SecureContext:
         [H*W, C] rows — no explicit sqrt and no eps, exactly as the reference computes it (its
         "newton" iteration converges to var^-1/2).  `inv` may carry shares of newton(var) computed
         earlier (see SecureResNet18.precompute_inv)."""
-        B, C, H, W = x[0].shape
+        B, C, H, W = self._ref(x).shape
         if B != 1:
             raise ValueError("encrypted inference runs one image at a time (inference.py:292)")
-        rows = []
-        for j in range(2):  # permute(1,0,2,3).reshape(C,-1).t()  -> [B*H*W, C]  (B == 1)
+
+        def to_rows(j):  # permute(1,0,2,3).reshape(C,-1).t()  -> [B*H*W, C]  (B == 1)
             o = torch.empty(B * H * W, C, dtype=I64, device=x[j].device)
             call("primia_col2out_syft", x[j], None, o, 1, C, B * H * W)
-            rows.append(o)
+            return o
+
+        rows = self._each(to_rows)
         if inv is None:
             inv = self.reciprocal_newton(var)
         normalized = self.fpt_mul(inv, self.sub(rows, mean))
         result = self.add(self.fpt_mul(normalized, weight), bias)
-        out = []
-        for j in range(2):
-            o = torch.empty(B, C, H, W, dtype=I64, device=x[j].device)
+
+        def back(j):
+            o = torch.empty(B, C, H, W, dtype=I64, device=result[j].device)
             call("primia_col2out_syft", result[j], None, o, 1, B * H * W, C)
-            out.append(o)
-        return out
+            return o
+
+        return self._each(back)
 
     def max_pool2d_3x3s2(self, x):
         """_pool2d(mode="max") for a 3x3 window (nn/functional.py:460-508): unroll to 9 columns,
         binary tree on the first 8, then against the 9th."""
-        B, C, H, W = x[0].shape
+        B, C, H, W = self._ref(x).shape
         Ho, Wo = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
         rows = B * C * Ho * Wo
-        im = []
-        for j in range(2):
+
+        def unroll(j):
             o = torch.empty(rows, 9, dtype=I64, device=x[j].device)
             call("primia_pool_unroll_syft", x[j], o, B, C, H, W, 3, 2, 1)
-            im.append(o)
+            return o
+
+        im = self._each(unroll)
         res = self._max_pair(self._cols(im, rows, 9, 0, 4), self._cols(im, rows, 9, 4, 4))
         res = self._max_pair(self._cols(res, rows, 4, 0, 2), self._cols(res, rows, 4, 2, 2))
         left = self._max_pair(self._cols(res, rows, 2, 0, 1), self._cols(res, rows, 2, 1, 1))
         res = self._max_pair(left, self._cols(im, rows, 9, 8, 1))
-        return [r.view(B, C, Ho, Wo) for r in res]
+        return [None if r is None else r.view(B, C, Ho, Wo) for r in res]
 
     def avg_pool2d(self, x, k):
         """_pool2d(mode="avg"), stride = kernel (nn.AvgPool2d(k)): per-share window sum, then the
         per-share truncating division of AST.mean (additive_shared.py:719-729)."""
-        B, C, H, W = x[0].shape
+        B, C, H, W = self._ref(x).shape
         Ho, Wo = (H - k) // k + 1, (W - k) // k + 1
         rows = B * C * Ho * Wo
-        out = []
-        for j in range(2):
+
+        def one(j):
             im = torch.empty(rows, k * k, dtype=I64, device=x[j].device)
             call("primia_pool_unroll_syft", x[j], im, B, C, H, W, k, k, 0)
             s = torch.empty(rows, dtype=I64, device=x[j].device)
             call("primia_ring_rowsum", im, s, rows, k * k)
             o = _empty_like(s)
             call("primia_trunc_div", s, k * k, o, rows)
-            out.append(o.view(B, C, Ho, Wo))
-        return out
+            return o.view(B, C, Ho, Wo)
+
+        return self._each(one)
 
     def linear(self, x, w, b):
         """F.linear -> torch.addmm(bias, input, weight.t()) -> FPT.addmm (nn/functional.py:10-14,
         precision.py:822-827): matmul + truncation, then + bias."""
-        O, I = w[0].shape
-        wt = []
-        for j in range(2):
+        O, I = self._ref(w).shape
+
+        def tr(j):
             t = torch.empty(I, O, dtype=I64, device=w[j].device)
             call("primia_col2out_syft", w[j], None, t, 1, O, I)
-            wt.append(t)
-        return self.add(self.fpt_matmul(x, wt), b)
+            return t
+
+        return self.add(self.fpt_matmul(x, self._each(tr)), b)
 
 
 class SecureResNet18:
@@ -444,7 +496,10 @@ class SecureResNet18:
         for k, v in state_dict.items():
             if k.endswith("num_batches_tracked"):
                 continue
-            self.p[k] = ctx.share(ctx.encode(v.to(dev)))
+            if ctx.party in (None, 0):  # the model owner is party 0 (inference.py:279-283)
+                self.p[k] = ctx.share(ctx.encode(v.to(dev)), owner=0)
+            else:
+                self.p[k] = ctx.share(None, owner=0, shape=v.shape)
         self.blocks = blocks if blocks is not None else [
             (f"layer{li}.{bi}", (2 if (li > 1 and bi == 0) else 1)) for li in range(1, 5) for bi in range(2)]
 
@@ -466,12 +521,12 @@ class SecureResNet18:
         the batched triple that channel receives)."""
         c = self.ctx
         names = self.bn_prefixes()
-        var = [torch.cat([self.p[n + ".running_var"][j] for n in names]) for j in range(2)]
+        var = c._each(lambda j: torch.cat([self.p[n + ".running_var"][j] for n in names]))
         inv = c.reciprocal_newton(var)
         out, off = {}, 0
         for n in names:
-            k = self.p[n + ".running_var"][0].numel()
-            out[n] = [inv[j][off:off + k].contiguous() for j in range(2)]
+            k = c._ref(self.p[n + ".running_var"]).numel()
+            out[n] = c._each(lambda j: inv[j][off:off + k].contiguous())
             off += k
         return out
 
@@ -497,15 +552,19 @@ class SecureResNet18:
                 identity = c.conv2d(x, p[prefix + ".downsample.0.weight"], stride, 0)
                 identity = self._bn(identity, prefix + ".downsample.1")
             x = c.relu(c.add(out, identity))
-        k = x[0].shape[-1]
+        k = c._ref(x).shape[-1]
         x = c.avg_pool2d(x, k)
-        x = [t.reshape(1, -1) for t in x]
+        x = [None if t is None else t.reshape(1, -1) for t in x]
         return c.linear(x, p["fc.weight"], p["fc.bias"])
 
     def __call__(self, image):
-        """image: fp32 [1, C, S, S] on the GPU -> decoded fp32 logits [1, classes]."""
+        """image: fp32 [1, C, S, S] on the GPU -> decoded fp32 logits [1, classes].  The data owner is
+        party 1 (inference.py:292-300); in a distributed run party 0 passes image = None."""
         c = self.ctx
-        xs = c.share(c.encode(image))
+        if c.party in (None, 1):
+            xs = c.share(c.encode(image), owner=1)
+        else:
+            xs = c.share(None, owner=1, shape=(1, 3, self.input_size, self.input_size))
         out = self.forward_shares(xs)
         return c.decode(c.reconstruct(out))
 
@@ -555,8 +614,8 @@ class GraphedSecureInference:
     def refill(self):
         """Fresh per-image primitives from the dealer, written into the captured buffers."""
         for i in range(self._n_model, len(self.tape)):
-            kind, args = self.requests[i]
-            _copy_primitive(self.tape[i], getattr(self.dealer, kind)(*args))
+            kind, args, kw = self.requests[i]
+            _copy_primitive(self.tape[i], getattr(self.dealer, kind)(*args, **kw))
 
     def __call__(self, image, refill=True):
         if refill:
@@ -564,3 +623,168 @@ class GraphedSecureInference:
         self.image.copy_(image)
         self.graph.replay()
         return self.out
+
+
+# ---- three-role deployment: party 0 (model owner), party 1 (data owner), crypto provider --------------------
+# inference.py:262-321 runs the same three roles as websocket workers (configs/websetting/config_inference.csv);
+# here each role is one rank of a torch.distributed job — one GPU each over xGMI with the RCCL backend — and the
+# only traffic is what the protocol itself exchanges: dealer -> party primitives, owner -> peer fresh shares, and
+# the 2-party opens of DistOpener.
+
+DEALER_RANK = 2
+
+
+class PartyLink:
+    """Point-to-point transport between the three roles, expressed as broadcasts inside 2-rank groups so the
+    same code runs on RCCL (device buffers over xGMI) and on gloo (tests).  Every rank of the job constructs
+    it (group creation is collective)."""
+
+    def __init__(self, device, ranks=(0, 1, 2)):
+        import torch.distributed as dist
+
+        self.dist, self.device = dist, torch.device(device)
+        self.rank = dist.get_rank()
+        p0, p1, d = ranks
+        self.ranks, self.dealer_rank = (p0, p1), d
+        self.role = {p0: 0, p1: 1, d: "dealer"}[self.rank]
+        self.parties_group = dist.new_group([p0, p1])
+        self.dealer_groups = [dist.new_group(sorted([p0, d])), dist.new_group(sorted([p1, d]))]
+        self.all_group = dist.new_group(sorted(ranks))
+
+    # party <-> party
+    def send_to_peer(self, t):
+        self.dist.broadcast(t.contiguous(), src=self.rank, group=self.parties_group)
+
+    def recv_from_peer(self, shape, dtype=I64):
+        t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+        self.dist.broadcast(t, src=self.ranks[1 - self.role], group=self.parties_group)
+        return t
+
+    # dealer -> party (to = 0 / 1) or dealer -> both (to = None)
+    def _dealer_group(self, to):
+        return self.all_group if to is None else self.dealer_groups[to]
+
+    def dealer_send(self, t, to=None):
+        self.dist.broadcast(t.contiguous(), src=self.dealer_rank, group=self._dealer_group(to))
+
+    def from_dealer(self, shape, dtype=I64, private=True):
+        t = torch.empty(tuple(shape), dtype=dtype, device=self.device)
+        self.dist.broadcast(t, src=self.dealer_rank, group=self._dealer_group(self.role if private else None))
+        return t
+
+
+def _triple_c_shape(op, xshape, yshape):
+    if op == "mul":
+        nx = int(torch.Size(xshape).numel())
+        return tuple(xshape) if nx >= int(torch.Size(yshape).numel()) else tuple(yshape)
+    return tuple(xshape[:-1]) + (yshape[-1],)
+
+
+class PartyDealer:
+    """What party j sees of the crypto provider: it receives ITS half of each primitive, in protocol order
+    (mpc/primitives.py:161-235 keeps the same per-worker store; here nothing is requested — the provider
+    follows the public request schedule of the network, see request_schedule)."""
+
+    def __init__(self, link: PartyLink):
+        self.link, self.device, self.j = link, link.device, link.role
+        self.log = None
+
+    def _mine(self, v):
+        out = [None, None]
+        out[self.j] = v
+        return out
+
+    def triple(self, op, xshape, yshape):
+        f = self.link.from_dealer
+        return self._mine((f(xshape), f(yshape), f(_triple_c_shape(op, xshape, yshape))))
+
+    def dif_keys(self, n):
+        f = self.link.from_dealer
+        k = dict(alpha=f((n,)), s0=f((2, n)))
+        k["bits"] = f((32, n), torch.uint8, private=False)
+        k["cw_sigma"] = f((32, 2, n), I64, private=False)
+        k["cw_s"] = f((32, 2, n), I64, private=False)
+        k["cw_leaf"] = f((33, n), torch.int32, private=False)
+        return self._mine(k)
+
+    def const_mask(self, *shape, owner=None):
+        return self.link.from_dealer(shape, private=owner is not None)
+
+
+def architecture_of(state_dict):
+    """name -> shape of every shared tensor: all a non-owner needs to know about the model."""
+    return {k: tuple(v.shape) for k, v in state_dict.items() if not k.endswith("num_batches_tracked")}
+
+
+def request_schedule(arch, input_size, device, blocks=None, precision_fractional=16, base=10):
+    """The (public) sequence of primitives one model sharing + one encrypted forward consumes, as
+    (model_requests, image_requests): it depends on the architecture and the input size only, so the crypto
+    provider derives it from a dry run on a dummy model of that architecture."""
+    d = Dealer(device, seed=0)
+    d.requests = []
+    ctx = SecureContext(d, base, precision_fractional)
+    dummy = {k: torch.ones(shape, dtype=torch.float32) for k, shape in arch.items()}
+    model = SecureResNet18(ctx, dummy, input_size, blocks)
+    n_model = len(d.requests)
+    model(torch.zeros(1, 3, input_size, input_size, dtype=torch.float32, device=device))
+    return d.requests[:n_model], d.requests[n_model:]
+
+
+class DealerService:
+    """The crypto provider's rank: generate each scheduled primitive on its GPU and ship each half to its
+    party (build_triple / build_fss_keys, mpc/beaver.py:7-63, mpc/primitives.py:237-253)."""
+
+    def __init__(self, dealer: Dealer, link: PartyLink):
+        self.dealer, self.link = dealer, link
+
+    def serve(self, requests):
+        send = self.link.dealer_send
+        for kind, args, kw in requests:
+            v = getattr(self.dealer, kind)(*args, **kw)
+            if kind == "triple":
+                for j in range(2):
+                    for t in v[j]:
+                        send(t, j)
+            elif kind == "dif_keys":
+                for j in range(2):
+                    send(v[j]["alpha"], j)
+                    send(v[j]["s0"], j)
+                for name in ("bits", "cw_sigma", "cw_s", "cw_leaf"):
+                    send(v[0][name], None)
+            else:
+                send(v, kw.get("owner"))
+
+
+def party_context(link: PartyLink, precision_fractional=16, base=10):
+    """SecureContext of the party this rank plays."""
+    return SecureContext(PartyDealer(link), base, precision_fractional,
+                         opener=DistOpener(link.parties_group, link.role), party=link.role, link=link)
+
+
+def run_three_role(link: PartyLink, arch, input_size, n_images, state_dict=None, images=None, seed=0, blocks=None,
+                   precision_fractional=16, base=10):
+    """One rank's part of the three-role encrypted inference of inference.py:279-321.
+    Party 0 passes `state_dict`, party 1 passes `images` (fp32 [n,3,S,S] on its GPU), the dealer neither;
+    all know the architecture, the input size and how many images will be classified.  Parties return the
+    list of decoded logits (the reference `.get()`s the prediction to the orchestrator), the dealer None."""
+    if link.role == "dealer":
+        model_req, image_req = request_schedule(arch, input_size, link.device, blocks, precision_fractional, base)
+        svc = DealerService(Dealer(link.device, seed), link)
+        svc.serve(model_req)
+        for _ in range(n_images):
+            svc.serve(image_req)
+        return None
+    ctx = party_context(link, precision_fractional, base)
+    if link.role == 0:
+        if state_dict is None:
+            raise ValueError("party 0 is the model owner: it needs the state dict")
+        shapes = {k: v for k, v in state_dict.items()}
+    else:
+        if images is None:
+            raise ValueError("party 1 is the data owner: it needs the images")
+        shapes = {k: torch.empty(shape, device="meta") for k, shape in arch.items()}
+    model = SecureResNet18(ctx, shapes, input_size, blocks)
+    out = []
+    for i in range(n_images):
+        out.append(model(images[i:i + 1] if link.role == 1 else None))
+    return out

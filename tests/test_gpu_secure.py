@@ -254,3 +254,31 @@ def test_graphed_inference_matches_eager_and_refills(cuda):
     assert torch.allclose(out_r, out_g, atol=1e-3)
     if before is not None:
         assert not torch.equal(before, g.tape[-1])
+
+
+@pytest.mark.parametrize("pf", [16])
+def test_three_role_deployment_bit_identical_to_in_process(cuda, tmp_path, pf):
+    """model_owner / data_owner / crypto_provider as three ranks: party j holds only share j, the
+    dealer ships each half of every primitive to its party, opens are 2-party all_reduces.  With the same
+    dealer seed the decoded logits equal the in-process run bit for bit, on both parties."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    gen = torch.Generator().manual_seed(21)
+    sd = mini_state_dict(gen)
+    images = torch.randn(2, 3, 16, 16, generator=gen)
+    blocks = [("layer1.0", 1), ("layer2.0", 2)]
+    ctx = SecureContext(Dealer(cuda, seed=5), 10, pf)
+    model = SecureResNet18(ctx, sd, input_size=16, blocks=blocks)
+    want = torch.cat([model(images[i:i + 1].to(cuda)) for i in range(2)]).cpu()
+    out = str(tmp_path / "logits")
+    port = 29800 + os.getpid() % 1000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "party_worker.py"),
+           out, str(pf)]
+    r = subprocess.run(cmd, cwd=root, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    for j in range(2):
+        assert torch.equal(torch.load(f"{out}.{j}"), want), j
