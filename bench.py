@@ -162,8 +162,13 @@ def main():
     loss = eng.loss.item()
 
     # ---- roofline leg: per-launch HIP events around every convolution kernel ----------------------
+    # One untimed eager step first (the timed region replays graphs), then `nprof` profiled steps.  A launch's
+    # duration is the MEDIAN over the profiled steps: the events bracket the host-side call too, so a host hiccup
+    # between the two records (GC, a page fault) would otherwise be booked as kernel time.
+    step(0)
+    torch.cuda.synchronize()
     eng.prof = []
-    nprof = 3
+    nprof = 5
     for i in range(nprof):
         step(i)
     torch.cuda.synchronize()
@@ -183,14 +188,18 @@ def main():
             return "conv3x3_c64_kernel"
         return "conv_igemm_kernel<%s>" % kind
 
-    agg, fam = {}, {}
+    per_launch = {}
     for kind, name, flops, e0, e1 in eng.prof:
-        ms = e0.elapsed_time(e1)
+        per_launch.setdefault((kind, name), (flops, []))[1].append(e0.elapsed_time(e1))
+    agg, fam = {}, {}
+    for (kind, name), (flops, samples) in per_launch.items():
+        samples.sort()
+        ms = samples[len(samples) // 2] * nprof   # median launch, scaled so the tables below stay per-nprof sums
         for table, key in ((agg, kind), (fam, family(kind, name))):
             d = table.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
             d["ms"] += ms
-            d["flops"] += flops
-            d["launches"] += 1
+            d["flops"] += flops * nprof
+            d["launches"] += nprof
     eng.prof = None
     peak = MFMA_PEAK_TFLOPS[a.dtype]
 

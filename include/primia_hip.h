@@ -126,6 +126,15 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
 /* dw_acc (fp32, fwd layout [K][R][Sp][C']) += sum over pixels.  Caller zeroes dw_acc first. */
 int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,
                         int dtype, primia_stream_t stream);
+/* The same weight gradient without atomics, where a layer has such a path (bf16 3x3 / stride-1 layers: every
+ * kernel block stores its partial tile in `ws`, a second kernel adds the partials in a fixed order, so the
+ * result is deterministic and, for those layers, OVERWRITES dw_acc).  primia_conv_wgrad_ws_bytes() gives the
+ * workspace a layer needs (0: the layer takes the accumulate path of primia_conv2d_wgrad; < 0: bad
+ * descriptor); with ws == NULL or ws_bytes too small the call is primia_conv2d_wgrad.  The reference has no
+ * counterpart: torch's conv backward owns its workspace (torchlib/models.py:219-235 via autograd). */
+int64_t primia_conv_wgrad_ws_bytes(const primia_conv_desc* d, int dtype);
+int primia_conv2d_wgrad_ws(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,
+                           void* ws, int64_t ws_bytes, int dtype, primia_stream_t stream);
 /* Per-sample weight gradients for DP-SGD: dw_ps [N][K][klen] (fwd layout, fp32, zeroed by the caller),
  * image n's gradient in slab n. */
 int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,

@@ -128,20 +128,21 @@ struct BwdFn {
     }
 };
 
-// Combine the per-block partials in fp64.  Block = 16 channels x 16 partial-slices; the slices are
-// reduced through LDS.  mode 0: batch statistics -> mean / invstd / running stats.
+// Combine the per-block partials in fp64.  Block = 16 channels x 64 partial-slices (1024 threads: the
+// kernel is pure load latency, <= 16 dependent-free trips per thread); the slices are reduced through LDS.  mode 0: batch statistics -> mean / invstd / running stats.
 // mode 1: backward sums -> dbeta (sum g) / dgamma (sum g*xhat).
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partials, int nblk,
+constexpr int kFinSlices = 64;
+__global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_kernel(const float* __restrict__ partials, int nblk,
                                                           int C, long M, int mode, float eps,
                                                           float momentum, float* out1, float* out2,
                                                           float* running_mean, float* running_var) {
-    __shared__ double sa[16][17], sb[16][17];
+    __shared__ double sa[kFinSlices][17], sb[kFinSlices][17];
     const int cl = threadIdx.x & 15, ks = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
     double a = 0.0, b = 0.0;
     if (c < C) {
 #pragma unroll 4
-        for (int k = ks; k < nblk; k += 16) {
+        for (int k = ks; k < nblk; k += kFinSlices) {
             a += (double)partials[((long)k * 2 + 0) * C + c];
             b += (double)partials[((long)k * 2 + 1) * C + c];
         }
@@ -149,11 +150,18 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     sa[ks][cl] = a;
     sb[ks][cl] = b;
     __syncthreads();
-    if (ks != 0 || c >= C) return;
-    for (int k = 1; k < 16; ++k) {
+    if (ks >= 4) return;
+    // 64 -> 4 slices by 4 threads per channel (wave 0), then two shuffles
+    for (int k = ks + 4; k < kFinSlices; k += 4) {
         a += sa[k][cl];
         b += sb[k][cl];
     }
+    // the four survivors of a channel sit in one wave at lanes cl, cl + 16, cl + 32, cl + 48
+    a += __shfl_down(a, 32);
+    b += __shfl_down(b, 32);
+    a += __shfl_down(a, 16);
+    b += __shfl_down(b, 16);
+    if (ks != 0 || c >= C) return;
     if (mode == 0) {
         const double mean = a / (double)M;
         double var = b / (double)M - mean * mean;
@@ -531,7 +539,7 @@ static int bn_fwd_train_impl(const void* y, const void* residual, void* z, const
     reduce_geometry(M, C, nblk, rpb);
     StatsFn<T> f{(const T*)y};
     colreduce2_kernel<T, StatsFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
-    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partials, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
                                            running_mean, running_var);
     const long nchunks = M * C / Chunk<T>::N;
     bn_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>((const T*)y, (const T*)residual, (T*)z, gamma,
@@ -550,7 +558,7 @@ static int bn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
     reduce_geometry(M, C, nblk, rpb);
     BwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, save_mean, save_invstd, gamma, beta, mask};
     colreduce2_kernel<T, BwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
-    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
     const long nchunks = M * C / Chunk<T>::N;
     bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
         (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean,
@@ -568,7 +576,7 @@ static int bn_relu_pool_fwd_impl(const void* y, void* pooled, uint8_t* argmax, c
     reduce_geometry(M, C, nblk, rpb);
     StatsFn<T> f{(const T*)y};
     colreduce2_kernel<T, StatsFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
-    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partials, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
                                                        running_mean, running_var);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     const long total = (long)N * Ho * Wo * (C / Chunk<T>::N);
@@ -679,7 +687,7 @@ static int bn_relu_pool_bwd_impl(const void* y, const void* pooled, const void* 
     PoolScatterFn<T> f{(const T*)pooled, (const T*)dpooled, argmax, (const T*)y, save_mean, save_invstd, gamma, beta,
                        H, W, C, Ho, Wo, {}, {}, {}, {}, false};
     colreduce2_kernel<T, PoolScatterFn<T>><<<nblk, 256, 0, st>>>(f, Mp, C, rpb, partials);
-    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
     const long nchunks = M * C / Chunk<T>::N;
     if (H % 2 == 0 && W % 2 == 0) {
         const long total = nchunks / 4;
@@ -733,7 +741,7 @@ int primia_bn_fwd_train_from_sums(const void* y, const void* residual, void* z, 
     PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype));
     hipStream_t st = (hipStream_t)stream;
     // `sums` has the layout of the partial blocks: [slots][2][C]
-    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(sums, slots, C, M, 0, eps, momentum, save_mean, save_invstd,
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(sums, slots, C, M, 0, eps, momentum, save_mean, save_invstd,
                                                        running_mean, running_var);
     if (dtype == PRIMIA_F32) {
         const long nchunks = M * C / 4;
@@ -820,7 +828,7 @@ int primia_bn_relu_maxpool_fwd_from_sums(const void* y, void* pooled, uint8_t* a
     PRIMIA_REQUIRE(N > 0 && H > 0 && W > 0 && bn_shape_ok((long)N * H * W, C, dtype));
     hipStream_t st = (hipStream_t)stream;
     const long M = (long)N * H * W;
-    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(sums, slots, C, M, 0, eps, momentum, save_mean, save_invstd,
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(sums, slots, C, M, 0, eps, momentum, save_mean, save_invstd,
                                                        running_mean, running_var);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     if (dtype == PRIMIA_F32) {
@@ -880,7 +888,7 @@ int primia_bn_fwd_train_mask(const void* y, const void* residual, void* z, uint8
             colreduce2_kernel<bf16, StatsFn<bf16>><<<nblk, 256, 0, st>>>(f, M, C, rpb, (float*)workspace);
         }
     }
-    bn_finalize_kernel<<<(C + 15) / 16, 256, 0, st>>>(part, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(part, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
                                                        running_mean, running_var);
     if (dtype == PRIMIA_F32) {
         const long nchunks = M * C / 4;

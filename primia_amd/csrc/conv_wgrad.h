@@ -20,6 +20,8 @@ struct WgradParams {
     int persample;
     double* sqnorm;    // per-sample mode: if set, split i adds the squared L2 norm of ITS gradient tile to
                        // sqnorm[i] instead of writing the tile (the DP-SGD norm pass needs nothing else)
+    float* ws;         // optional workspace of the store-and-reduce path (conv_wgrad_patch.hip); null: atomics
+    size_t ws_bytes;
     int xpad;          // stem only: x is the padded NHWC4p input [N][H+6][W+8][4] (stem_conv.hip)
 };
 
@@ -33,6 +35,7 @@ __device__ __forceinline__ void wave_sqnorm_add(double s, double* dst) {
 int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st);
 // halo-patch kernel (3x3, stride 1, bf16); returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered
 int wgrad_patch_dispatch(const WgradParams& p, hipStream_t st);
+size_t wgrad_patch_ws_bytes(const WgradParams& p);
 // stem (7x7/2) halo kernel on the padded input (stem_conv.hip)
 int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st);
 

@@ -286,7 +286,8 @@ static int launch_wgrad(WgradParams p, hipStream_t st) {
 using namespace primia;
 
 static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc, int persample,
-                             int dtype, primia_stream_t stream, double* sqnorm = nullptr);
+                             int dtype, primia_stream_t stream, double* sqnorm = nullptr, float* ws = nullptr,
+                             size_t ws_bytes = 0);
 
 extern "C" int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, int N, int H, int W, int dtype,
                                       primia_stream_t stream) {
@@ -302,6 +303,7 @@ extern "C" int primia_stem_conv_wgrad(const void* x_padded, const void* dy, floa
     p.split_stride = 0;
     p.xpad = 1;
     p.sqnorm = nullptr;
+    p.ws = nullptr; p.ws_bytes = 0;
     if (dtype == PRIMIA_F32) return launch_wgrad<float, 64, 32, true>(p, (hipStream_t)stream);
     if (dtype == PRIMIA_BF16) {
         const int rc = stem_wgrad_halo_dispatch((const bf16*)x_padded, (const bf16*)dy, dw_acc, N, H, W, (hipStream_t)stream);
@@ -316,6 +318,34 @@ extern "C" int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, con
     return conv2d_wgrad_impl(d, x, dy, dw_acc, 0, dtype, stream);
 }
 
+static bool fill_wgrad_params(const primia_conv_desc* d, WgradParams& p, ConvGeom& g) {
+    if (!d || !g.init(*d)) return false;
+    p.N = g.N; p.H = g.H; p.W = g.W; p.C = g.C; p.K = g.K; p.R = g.R; p.S = g.S;
+    p.stride = g.stride; p.pad = g.pad; p.Ho = g.Ho; p.Wo = g.Wo;
+    p.klen = g.klen;
+    p.Md = (long)g.N * g.Ho * g.Wo;
+    p.ntaps = g.stem ? g.R : g.R * g.S;
+    p.persample = 0;
+    p.split_stride = 0;
+    p.xpad = 0;
+    p.sqnorm = nullptr;
+    p.ws = nullptr; p.ws_bytes = 0;
+    return true;
+}
+
+extern "C" int64_t primia_conv_wgrad_ws_bytes(const primia_conv_desc* d, int dtype) {
+    WgradParams p;
+    ConvGeom g;
+    if (!fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
+    if (dtype != PRIMIA_BF16 || g.stem) return 0;
+    return (int64_t)wgrad_patch_ws_bytes(p);
+}
+
+extern "C" int primia_conv2d_wgrad_ws(const primia_conv_desc* d, const void* x, const void* dy, float* dw,
+                                      void* ws, int64_t ws_bytes, int dtype, primia_stream_t stream) {
+    return conv2d_wgrad_impl(d, x, dy, dw, 0, dtype, stream, nullptr, (float*)ws, ws_bytes > 0 ? (size_t)ws_bytes : 0);
+}
+
 extern "C" int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,
                                              float* dw_ps, int dtype, primia_stream_t stream) {
     return conv2d_wgrad_impl(d, x, dy, dw_ps, 1, dtype, stream);
@@ -328,21 +358,15 @@ extern "C" int primia_conv2d_wgrad_persample_sqnorm(const primia_conv_desc* d, c
 }
 
 static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc, int persample,
-                             int dtype, primia_stream_t stream, double* sqnorm) {
+                             int dtype, primia_stream_t stream, double* sqnorm, float* ws, size_t ws_bytes) {
     PRIMIA_REQUIRE(d && x && dy && (dw_acc || sqnorm));
     ConvGeom g;
-    PRIMIA_REQUIRE(g.init(*d));
     WgradParams p;
+    PRIMIA_REQUIRE(fill_wgrad_params(d, p, g));
     p.x = x; p.dy = dy; p.dw = dw_acc;
-    p.N = g.N; p.H = g.H; p.W = g.W; p.C = g.C; p.K = g.K; p.R = g.R; p.S = g.S;
-    p.stride = g.stride; p.pad = g.pad; p.Ho = g.Ho; p.Wo = g.Wo;
-    p.klen = g.klen;
-    p.Md = (long)g.N * g.Ho * g.Wo;
-    p.ntaps = g.stem ? g.R : g.R * g.S;
     p.persample = persample;
-    p.split_stride = 0;
-    p.xpad = 0;
     p.sqnorm = sqnorm;
+    p.ws = ws; p.ws_bytes = ws ? ws_bytes : 0;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         if (g.stem) return launch_wgrad<float, 64, 32, true>(p, st);

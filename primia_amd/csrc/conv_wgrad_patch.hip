@@ -55,8 +55,12 @@ struct PatchParams {
     int per_block;            // sub-patches per block (even)
     long split_stride;
     double* sqnorm;           // per-sample norm pass (see WgradParams::sqnorm)
+    int nsplit, split_fastest;
+    float* ws;                // if set: every block stores its partial slab here (no atomics), see below
     int debug_skip_epilogue;  // timing experiments only (PRIMIA_WGP_NOEPI=1)
 };
+
+constexpr int kSlab = 64 * 9 * 64;   // accumulator values of one block
 
 template <int SW, int STAGES>
 __global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(PatchParams p) {
@@ -76,9 +80,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(PatchParams p) {
     const int kh = wave >> 2, wid = wave & 3;                   // out-chan half, in-chan quarter
 
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int split;
+    if (p.split_fastest) {   // the blocks that add into one slab are neighbours: same XCD
+        split = bid % p.nsplit;
+        bid /= p.nsplit;
+    }
     const int ct = bid % p.nct; bid /= p.nct;
     const int kt = bid % p.nkt;
-    const int split = bid / p.nkt;
+    if (!p.split_fastest) split = bid / p.nkt;
     const int t0 = split * p.per_block;
     int t1 = t0 + p.per_block;
     if (t1 > p.total) t1 = p.total;
@@ -265,6 +274,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(PatchParams p) {
         wave_sqnorm_add(sq, p.sqnorm + split);
         return;
     }
+    if (p.ws) {
+        // Deterministic path: this block's 64 x 576 partial goes to ITS OWN slab of the workspace as nine
+        // x two 1-KiB-per-wave stores (lane-major, exactly the accumulator registers); wgrad_patch_reduce_kernel
+        // adds the slabs of a (kt, ct) tile in split order.  9.4 M fp32 atomics per launch (~25 us) become
+        // 38 MB of streaming stores and a reduction that reads them back while they are still in the
+        // Infinity Cache.
+        float* o = p.ws + ((long)(kt * p.nct + ct) * p.nsplit + split) * kSlab + (wave * 64 + lane) * 4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *(f32x4*)(o + (t * 2 + i) * 2048) = acc[t][i];
+        return;
+    }
     float* out = p.dw + (long)split * p.split_stride;
     // Blocks that share a (kt, ct) slab finish together and add into the same addresses: start each block at
     // a different tap so that at any instant the blocks of a slab hit different cache lines.
@@ -297,31 +319,107 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(PatchParams p) {
 #undef PRIMIA_FLUSH_FROM
 }
 
+// dw[k][e] = sum over splits of the partial slabs, in split order (deterministic).  Block = CL float4
+// chunks x SL split lanes (CL * SL = 256); a chunk q = ((t*2 + i)*8 + wave)*64 + lane of the slab is the
+// accumulator acc[t][i] of that lane, i.e. out-channels 32*(wave>>2) + 16*i + 4*(lane>>4) + 0..3 at
+// in-channel 16*(wave&3) + (lane&15) of tap t.
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                 int nsplit, int nct, int C, int klen) {
+    constexpr int CL = 256 / SL;
+    constexpr int CPB = kSlab / 4 / CL;            // blocks per slab
+    __shared__ f32x4 red[SL][CL];
+    const int combo = blockIdx.x / CPB;
+    const int q = (blockIdx.x % CPB) * CL + (threadIdx.x % CL);
+    const int sl = threadIdx.x / CL;
+    const float* src = ws + (long)combo * nsplit * kSlab + q * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int s = sl;
+#pragma unroll 1
+    for (; s + 3 * SL < nsplit; s += 4 * SL) {       // four independent loads in flight
+        const f32x4 v0 = *(const f32x4*)(src + (long)s * kSlab);
+        const f32x4 v1 = *(const f32x4*)(src + (long)(s + SL) * kSlab);
+        const f32x4 v2 = *(const f32x4*)(src + (long)(s + 2 * SL) * kSlab);
+        const f32x4 v3 = *(const f32x4*)(src + (long)(s + 3 * SL) * kSlab);
+        a += v0; a += v1; a += v2; a += v3;
+    }
+    for (; s < nsplit; s += SL) a += *(const f32x4*)(src + (long)s * kSlab);
+    if (SL > 1) {
+        red[sl][threadIdx.x % CL] = a;
+        __syncthreads();
+        if (sl != 0) return;
+#pragma unroll
+        for (int k = 1; k < SL; ++k) a += red[k][threadIdx.x % CL];
+    }
+    const int lane = q & 63, wave = (q >> 6) & 7, ti = q >> 9;
+    const int t = ti >> 1, i = ti & 1;
+    const int kt = combo / nct, ct = combo - kt * nct;
+    const int k0 = kt * 64 + 32 * (wave >> 2) + 16 * i + (lane >> 4) * 4;
+    const int e = t * C + ct * 64 + 16 * (wave & 3) + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dw[(long)(k0 + j) * klen + e] = a[j];
+}
+
+struct PatchGeom {
+    bool ok, wide;
+    int PH, PW, PPI, total, per_block, nsplit, combos;
+};
+
+static PatchGeom patch_geom(const WgradParams& w) {
+    PatchGeom g{};
+    g.ok = !(w.R != 3 || w.S != 3 || w.stride != 1 || w.pad != 1 || w.C % 64 || w.K % 64) &&
+           (long)w.N * w.H * w.W * (w.C > w.K ? w.C : w.K) < (1L << 31);
+    if (!g.ok) return g;
+    // 16-wide sub-patches when they waste fewer slots on the ragged right edge (W = 14: 16 vs 2 x 8)
+    const int waste8 = (w.W + 7) / 8 * 8 - w.W, waste16 = (w.W + 15) / 16 * 16 - w.W;
+    const int rows8 = (w.H + 3) / 4 * 4 - w.H, rows16 = (w.H + 1) / 2 * 2 - w.H;
+    const long slots8 = (long)(w.W + waste8) * (w.H + rows8), slots16 = (long)(w.W + waste16) * (w.H + rows16);
+    static const char force = getenv("PRIMIA_WGP_SW") ? getenv("PRIMIA_WGP_SW")[0] : 0;  // '8' | '1'(6)
+    g.wide = force ? force == '1' : slots16 < slots8;
+    const int SW = g.wide ? 16 : 8, SH = 32 / SW;
+    g.PH = (w.H + SH - 1) / SH; g.PW = (w.W + SW - 1) / SW; g.PPI = g.PH * g.PW;
+    g.total = w.N * g.PPI;
+    g.combos = (w.C / 64) * (w.K / 64);
+    // one 8-wave block per CU
+    static const int target_blocks = getenv("PRIMIA_WGP_BLOCKS") ? atoi(getenv("PRIMIA_WGP_BLOCKS")) : 0;
+    const int target = target_blocks ? target_blocks : 256;
+    long want = (target + g.combos - 1) / g.combos;
+    if (want < 1) want = 1;
+    long per = (g.total + want - 1) / want;
+    per = (per + 1) & ~1L;
+    if (per < 2) per = 2;
+    if (w.persample) per = g.PPI;  // one split per image
+    g.per_block = (int)per;
+    g.nsplit = (int)((g.total + per - 1) / per);
+    return g;
+}
+
+// bytes of workspace the store-and-reduce path needs for this layer (0: layer not served by this kernel)
+size_t wgrad_patch_ws_bytes(const WgradParams& w) {
+    const PatchGeom g = patch_geom(w);
+    if (!g.ok || w.persample) return 0;
+    return (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
+}
+
 template <int SW>
-static int launch_patch(const WgradParams& w, hipStream_t st) {
+static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st) {
     constexpr int SH = 32 / SW;
     PatchParams p;
     p.x = (const bf16*)w.x; p.dy = (const bf16*)w.dy; p.dw = w.dw;
     p.H = w.H; p.W = w.W; p.C = w.C; p.K = w.K; p.klen = w.klen;
     p.nct = w.C / 64; p.nkt = w.K / 64;
-    p.PH = (w.H + SH - 1) / SH; p.PW = (w.W + SW - 1) / SW; p.PPI = p.PH * p.PW;
-    p.total = w.N * p.PPI;
-    const int combos = p.nct * p.nkt;
-    // one 8-wave block per CU
-    static const int target_blocks = getenv("PRIMIA_WGP_BLOCKS") ? atoi(getenv("PRIMIA_WGP_BLOCKS")) : 0;
-    const int target = target_blocks ? target_blocks : 256;
-    long want = (target + combos - 1) / combos;
-    if (want < 1) want = 1;
-    long per = (p.total + want - 1) / want;
-    per = (per + 1) & ~1L;
-    if (per < 2) per = 2;
-    if (w.persample) per = p.PPI;  // one split per image
-    p.per_block = (int)per;
-    const long nsplit = (p.total + per - 1) / per;
+    p.PH = g.PH; p.PW = g.PW; p.PPI = g.PPI;
+    p.total = g.total;
+    p.per_block = g.per_block;
+    p.nsplit = g.nsplit;
+    static const int order = getenv("PRIMIA_WGP_ORDER") ? atoi(getenv("PRIMIA_WGP_ORDER")) : 0;
+    p.split_fastest = order;
     p.split_stride = w.persample ? (long)w.K * w.klen : 0;
     p.sqnorm = w.persample ? w.sqnorm : nullptr;
     static const int noepi = getenv("PRIMIA_WGP_NOEPI") ? atoi(getenv("PRIMIA_WGP_NOEPI")) : 0;
     p.debug_skip_epilogue = noepi;
+    const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
+    p.ws = store ? w.ws : nullptr;
     constexpr int XS = (SH + 2) * (SW == 8 ? 12 : 18);
     static const int stages = getenv("PRIMIA_WGP_STAGES") ? atoi(getenv("PRIMIA_WGP_STAGES")) : 3;
     const size_t lds = (size_t)(stages == 4 ? 4 : 3) * (2 * XS * 128 + 64 * 128);
@@ -332,20 +430,23 @@ static int launch_patch(const WgradParams& w, hipStream_t st) {
             return PRIMIA_ERR_LAUNCH;
         attr_set = true;
     }
-    kern<<<(unsigned)(combos * nsplit), 512, lds, st>>>(p);
+    kern<<<(unsigned)(g.combos * g.nsplit), 512, lds, st>>>(p);
+    if (store) {
+        const int ns = g.nsplit;
+        if (ns >= 64)
+            wgrad_patch_reduce_kernel<16><<<g.combos * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+        else if (ns >= 8)
+            wgrad_patch_reduce_kernel<4><<<g.combos * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+        else
+            wgrad_patch_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+    }
     return launch_status();
 }
 
 int wgrad_patch_dispatch(const WgradParams& w, hipStream_t st) {
-    if (w.R != 3 || w.S != 3 || w.stride != 1 || w.pad != 1 || w.C % 64 || w.K % 64) return PRIMIA_ERR_UNSUPPORTED;
-    if ((long)w.N * w.H * w.W * (w.C > w.K ? w.C : w.K) >= (1L << 31)) return PRIMIA_ERR_UNSUPPORTED;
-    // 16-wide sub-patches when they waste fewer slots on the ragged right edge (W = 14: 16 vs 2 x 8)
-    const int waste8 = (w.W + 7) / 8 * 8 - w.W, waste16 = (w.W + 15) / 16 * 16 - w.W;
-    const int rows8 = (w.H + 3) / 4 * 4 - w.H, rows16 = (w.H + 1) / 2 * 2 - w.H;
-    const long slots8 = (long)(w.W + waste8) * (w.H + rows8), slots16 = (long)(w.W + waste16) * (w.H + rows16);
-    static const char force = getenv("PRIMIA_WGP_SW") ? getenv("PRIMIA_WGP_SW")[0] : 0;  // '8' | '1'(6)
-    const bool wide = force ? force == '1' : slots16 < slots8;
-    return wide ? launch_patch<16>(w, st) : launch_patch<8>(w, st);
+    const PatchGeom g = patch_geom(w);
+    if (!g.ok) return PRIMIA_ERR_UNSUPPORTED;
+    return g.wide ? launch_patch<16>(w, g, st) : launch_patch<8>(w, g, st);
 }
 
 }  // namespace primia

@@ -111,6 +111,11 @@ class ResNet18Engine:
             if c.spec.name != stem.name:
                 c.w_dgrad = torch.empty(query("primia_conv_wdgrad_elems", c.desc), dtype=dtype, device=dev)
             c.acc = self.dw_acc[c.acc_off:c.acc_off + c.wfwd_n]
+        # workspace of the atomic-free weight-gradient path (primia_conv2d_wgrad_ws): the layers run one after
+        # the other on one stream, so they share one buffer sized for the largest (38 MB at batch 256)
+        ws_bytes = max(query("primia_conv_wgrad_ws_bytes", c.desc, self.dt) for c in self.convs.values())
+        self.wgrad_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev) if ws_bytes > 0 else None
+        self.wgrad_ws_bytes = ws_bytes
 
         # ---- activations ------------------------------------------------------------------------
         def act(hw, ch):
@@ -456,6 +461,10 @@ class ResNet18Engine:
         c = self.convs[name]
         if self.dp is not None:  # DP-SGD: weight gradients wait for the per-sample clip factors
             self.dp["wgrads"].append((name, x, dy))
+            return
+        if self.wgrad_ws is not None and not self.wgrad_overlap:
+            self._timed("wgrad", c, lambda: call("primia_conv2d_wgrad_ws", c.desc, x, dy, c.acc, self.wgrad_ws,
+                                                 self.wgrad_ws_bytes, self.dt))
             return
         self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call("primia_conv2d_wgrad", c.desc, x, dy, c.acc,
                                                                              self.dt)))
