@@ -50,6 +50,8 @@ for name, H, C, K, R, s, p, cnt in layers:
         tf = timeit(lambda: call("primia_conv2d_fwd", d, x, wf, y, dt))
         td = timeit(lambda: call("primia_conv2d_dgrad", d, dy, wd, dx, 0, dt)) if wd is not None else 0.0
         tw = timeit(lambda: call("primia_conv2d_wgrad", d, x, dy, acc, dt))
+        if os.environ.get("CONV_LAYERS_ACC") and wd is not None:   # accumulate-form data gradient instead
+            td = timeit(lambda: call("primia_conv2d_dgrad", d, dy, wd, dx, 1, dt))
     f = lambda t: fl / (t * 1e-3) / 1e12 if t > 0 else 0
     print(f"{name:9s} {cnt:3d} {fl/1e9:7.1f} | {tf*1e3:8.1f} {f(tf):6.0f} | {td*1e3:8.1f} {f(td):6.0f} | {tw*1e3:8.1f} {f(tw):6.0f}")
     tot["fwd"] += tf * cnt; tot["dgrad"] += td * cnt; tot["wgrad"] += tw * cnt
