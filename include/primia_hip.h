@@ -123,6 +123,14 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
 /* dx[N,H,W,C] = conv_transpose(dy[N,Ho,Wo,K], w).  If accumulate != 0, dx += (dx is read). */
 int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                         int accumulate, int dtype, primia_stream_t stream);
+/* Transition block (torchlib/models.py:268-284 with a downsample, :232-235): dx = dgrad(conv1 3x3/2, dy) +
+ * dgrad(downsample 1x1/2, dy_ds) in ONE pass — both convolutions read the same x, the downsample's gradient lands
+ * on the even/even pixels, where conv1's only tap is the centre one at the same dy pixel, so it is folded into
+ * that pixel class's reduction axis.  Replaces primia_conv2d_dgrad(conv1, accumulate=0) followed by
+ * primia_conv2d_dgrad(downsample, accumulate=1) (one rounding instead of two).  H, W even. */
+int primia_conv2d_dgrad_pair(const primia_conv_desc* d, const void* dy, const void* w_dgrad,
+                             const primia_conv_desc* d_ds, const void* dy_ds, const void* w_dgrad_ds, void* dx,
+                             int dtype, primia_stream_t stream);
 /* dw_acc (fp32, fwd layout [K][R][Sp][C']) += sum over pixels.  Caller zeroes dw_acc first. */
 int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,
                         int dtype, primia_stream_t stream);

@@ -41,6 +41,11 @@ struct IgemmParams {
     float* stat_sums;  // optional [slots][2][Nd]: per-channel sum and sum of squares of the stored output
     int s2_classes;    // data-gradient of a stride-2 conv: dst pixels are processed in 4 parity classes
     int ntm_class;     // pixel tiles per class
+    // Transition block (3x3/2 conv1 beside a 1x1/2 downsample, both reading the same x): the downsample's data
+    // gradient lands on the even/even pixels only, where conv1's only tap is the centre one and reads the SAME dy
+    // pixel — so it is that class's reduction axis made longer: K more elements from dy2 against wt2 [C][K].
+    const void* src2;
+    const void* wt2;
 };
 
 template <typename T>
@@ -122,6 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
 
     const T* __restrict__ src = (const T*)p.src;
     const T* __restrict__ wt = (const T*)p.wt;
+    const bool pair = DGRAD && !STEM && p.s2_classes && p.src2 && cls_ph == 1 && cls_pw == 1;  // block-uniform
 
     // ---- per-thread staging coordinates -----------------------------------------------------
     // Register staging (stem): thread t owns rows t/8 + 32j, chunk t%8.
@@ -159,6 +165,13 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
         } else {
             wrow[j] = wt + (long)(n0 + srow + 32 * j) * p.klen + schunk * CH;
         }
+    }
+
+    const T* wrow2[WR];
+#pragma unroll
+    for (int j = 0; j < WR; ++j) {
+        const int row = (wid * WR + j) * 8 + (lane >> 3);
+        wrow2[j] = (const T*)p.wt2 + (long)(n0 + row) * p.Cs + ((lane & 7) ^ ((row >> 1) & 7)) * CH;
     }
 
     u32x4 rp[PR], rw[WR];
@@ -205,10 +218,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     int st_tap = st_r * p.S + st_s;
     int st_tapoff = DGRAD ? -(((p.stride == 2 ? st_r >> 1 : st_r) * p.Ws + (p.stride == 2 ? st_s >> 1 : st_s)) * p.Cs)
                           : (st_r * p.Ws + st_s) * p.Cs;
+    int st_regular = 0;  // regular steps left before the paired tensor's steps (set with nsteps below)
     auto stage_glds = [&](int step, int buf) {
         (void)step;  // stages are issued in order; the walk state below IS the step
         char* lp = smem + buf * (TILE_P + TILE_W);
         char* lw = lp + TILE_P;
+        if (DGRAD && pair && st_regular == 0) {
+            // paired 1x1/2 tensor: the centre tap's pixel (tap offset 0 for stride 2), rows of wt2
+            const T* __restrict__ s2p = (const T*)p.src2;
+            const unsigned cbit = 1u << (p.S + 1);
+#pragma unroll
+            for (int j = 0; j < PR; ++j) {
+                const T* g = (pmask[j] & cbit) ? s2p + (poff[j] + st_c0) : (const T*)kZeroPage;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(lp + (wid * PR + j) * 1024),
+                                                 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < WR; ++j)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wrow2[j] + st_c0),
+                                                 (__attribute__((address_space(3))) void*)(lw + (wid * WR + j) * 1024),
+                                                 16, 0, 0);
+            st_c0 += KE;
+            return;
+        }
+        --st_regular;
         const int uoff = st_tapoff + st_c0;
         const unsigned tbit = 1u << st_tap;
 #pragma unroll
@@ -339,6 +373,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
         const int nr = cls_ph < p.R ? (p.R - cls_ph + 1) / 2 : 0, ns = cls_pw < p.S ? (p.S - cls_pw + 1) / 2 : 0;
         nsteps = nr * ns * (p.Cs / KE);
     }
+    st_regular = nsteps;
+    if (pair) nsteps += p.Cs / KE;
     if constexpr (GLDS) {
         // STAGES-deep LDS ring fed by LDS-DMA.  Per k-step ONE raw barrier: a counted vmcnt leaves the
         // newer stages' DMA in flight across it (a plain __syncthreads() would drain them).
@@ -558,6 +594,7 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
     p.stat_sums = stat_sums;
     p.s2_classes = 0;
     p.ntm_class = 0;
+    p.src2 = nullptr; p.wt2 = nullptr;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         p.nsteps = g.stem ? 7 : g.klen / 32;
@@ -594,13 +631,14 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
     return conv2d_fwd_impl(d, x, w_fwd, y, stat_sums, dtype, stream);
 }
 
-int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                        int accumulate, int dtype, primia_stream_t stream) {
+static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                             int accumulate, const void* dy2, const void* w_dgrad2, int dtype, primia_stream_t stream) {
     PRIMIA_REQUIRE(d && dy && w_dgrad && dx);
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
     PRIMIA_REQUIRE(!g.stem && (g.stride == 1 || g.stride == 2));
     IgemmParams p;
+    p.src2 = dy2; p.wt2 = w_dgrad2;
     p.src = dy; p.wt = w_dgrad; p.dst = dx;
     p.Nb = g.N; p.Hd = g.H; p.Wd = g.W; p.Nd = g.C;
     p.Hs = g.Ho; p.Ws = g.Wo; p.Cs = g.K;
@@ -612,6 +650,7 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
     static const bool no_classes = getenv("PRIMIA_DGRAD_CLASSES") && getenv("PRIMIA_DGRAD_CLASSES")[0] == '0';
     p.s2_classes = (g.stride == 2 && g.H % 2 == 0 && g.W % 2 == 0 && !no_classes) ? 1 : 0;
     p.ntm_class = 0;
+    if (p.src2 && !p.s2_classes) return PRIMIA_ERR_UNSUPPORTED;   // the pairing lives in the parity-class walk
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32) {
         p.nsteps = p.klen / 32;
@@ -626,6 +665,23 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
         return dispatch_igemm<bf16, true>(p, false, st);
     }
     return PRIMIA_ERR_ARG;
+}
+
+int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                        int accumulate, int dtype, primia_stream_t stream) {
+    return conv2d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, dtype, stream);
+}
+
+int primia_conv2d_dgrad_pair(const primia_conv_desc* d, const void* dy, const void* w_dgrad,
+                             const primia_conv_desc* d_ds, const void* dy_ds, const void* w_dgrad_ds, void* dx,
+                             int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && d_ds && dy_ds && w_dgrad_ds);
+    // conv1 3x3 / stride 2 / pad 1 and downsample 1x1 / stride 2 / pad 0 on the same even-sized input
+    PRIMIA_REQUIRE(d->R == 3 && d->S == 3 && d->stride == 2 && d->pad == 1 && d->H % 2 == 0 && d->W % 2 == 0);
+    PRIMIA_REQUIRE(d_ds->R == 1 && d_ds->S == 1 && d_ds->stride == 2 && d_ds->pad == 0);
+    PRIMIA_REQUIRE(d_ds->N == d->N && d_ds->H == d->H && d_ds->W == d->W && d_ds->C == d->C && d_ds->K == d->K &&
+                   d_ds->Ho == d->Ho && d_ds->Wo == d->Wo);
+    return conv2d_dgrad_impl(d, dy, w_dgrad, dx, 0, dy_ds, w_dgrad_ds, dtype, stream);
 }
 
 }  // extern "C"

@@ -319,16 +319,22 @@ class ResNet18Engine:
     # `self.prof` is a list, every conv launch is bracketed by events on the launch stream.
     prof = None
 
-    def _timed(self, kind, c, fn):
+    # conv1 + downsample data gradients of a transition block in one pass (primia_conv2d_dgrad_pair)
+    pair_dgrad = True
+
+    @staticmethod
+    def _macs(c):
+        d = c.desc
+        return d.N * d.Ho * d.Wo * d.K * c.c_real * d.R * d.S
+
+    def _timed(self, kind, c, fn, extra_macs=0):
         if self.prof is None:
             return fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
         e1.record()
-        d = c.desc
-        macs = d.N * d.Ho * d.Wo * d.K * c.c_real * d.R * d.S
-        self.prof.append((kind, c.spec.name, 2.0 * macs, e0, e1))
+        self.prof.append((kind, c.spec.name, 2.0 * (self._macs(c) + extra_macs), e0, e1))
 
     def _conv_fwd(self, name, x, y):
         c = self.convs[name]
@@ -522,7 +528,17 @@ class ResNet18Engine:
             self._dgrad(blk.conv2.name, t[p + ".dy2"], t[p + ".da1"], False)
             self._wgrad(blk.conv2.name, t[p + ".a1"], t[p + ".dy2"])
             self._bn_bwd(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], t[p + ".da1"], t[p + ".dy1"], None, True)
-            if blk.down is not None:
+            if blk.down is not None and self.pair_dgrad:
+                # both BatchNorm backward passes first, then ONE data-gradient pass for conv1 + downsample
+                self._bn_bwd(blk.down.name, t[p + ".yd"], None, dout, t[p + ".dyd"], None, False)
+                c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
+                self._join_wgrad_stream()
+                self._timed("dgrad", c1, lambda: call("primia_conv2d_dgrad_pair", c1.desc, t[p + ".dy1"], c1.w_dgrad,
+                                                      cd.desc, t[p + ".dyd"], cd.w_dgrad, dx_in, self.dt),
+                            extra_macs=self._macs(cd))
+                self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
+                self._wgrad(blk.down.name, x_in, t[p + ".dyd"])
+            elif blk.down is not None:
                 self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, False)
                 self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
                 self._bn_bwd(blk.down.name, t[p + ".yd"], None, dout, t[p + ".dyd"], None, False)

@@ -651,3 +651,36 @@ def test_batchnorm_relu_mask_variant_is_bit_identical(cuda, dtype):
         outs.append((z, sm, si, rm, rv, dy, go, dg, db))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,C,K", [(2, 16, 64, 128), (3, 28, 128, 256), (4, 14, 256, 512), (1, 6, 64, 128)])
+def test_conv_dgrad_pair_matches_two_passes(cuda, dtype, N, H, C, K):
+    """Transition block: dgrad(conv1 3x3/2) + dgrad(downsample 1x1/2) in one pass vs torch autograd of the sum,
+    and vs the two-call form it replaces (same values up to ONE bf16 rounding instead of two)."""
+    g = torch.Generator().manual_seed(77 + H + C)
+    x = rnd(torch.randn(N, C, H, H, generator=g), dtype)
+    w1 = rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype)
+    wd_ = rnd(torch.randn(K, C, 1, 1, generator=g) * 0.1, dtype)
+    d1 = ConvDesc.make(N, H, H, C, K, 3, 3, 2, 1)
+    dd = ConvDesc.make(N, H, H, C, K, 1, 1, 2, 0)
+    dt = _lib.dtype_code(dtype)
+    _, w1d = prep_weights(d1, w1, dtype, cuda, C)
+    _, wdd = prep_weights(dd, wd_, dtype, cuda, C)
+    xr = x.clone().requires_grad_(True)
+    y1 = F.conv2d(xr, w1, None, 2, 1)
+    yd = F.conv2d(xr, wd_, None, 2, 0)
+    dy1 = rnd(torch.randn(y1.shape, generator=g), dtype)
+    dyd = rnd(torch.randn(yd.shape, generator=g), dtype)
+    (y1 * dy1).sum().add((yd * dyd).sum()).backward()
+    dy1d, dydd = to_nhwc(dy1, dtype, cuda), to_nhwc(dyd, dtype, cuda)
+    dx = torch.full((N * H * H, C), 3.0, dtype=dtype, device=cuda)   # dirty: the call overwrites
+    call("primia_conv2d_dgrad_pair", d1, dy1d, w1d, dd, dydd, wdd, dx, dt)
+    assert relerr(from_nhwc(dx, N, H, H), xr.grad) < tol(dtype)
+    dx2 = torch.empty_like(dx)
+    call("primia_conv2d_dgrad", d1, dy1d, w1d, dx2, 0, dt)
+    call("primia_conv2d_dgrad", dd, dydd, wdd, dx2, 1, dt)
+    assert relerr(dx, dx2) < tol(dtype)
+    # argument checks: the second descriptor must be the 1x1/2 sibling of the first
+    with pytest.raises(_lib.PrimiaError):
+        call("primia_conv2d_dgrad_pair", d1, dy1d, w1d, d1, dydd, wdd, dx, dt)
