@@ -306,6 +306,13 @@ int primia_global_avgpool_fwd(const void* x, float* feat, int N, int HW, int C, 
 int primia_global_avgpool_bwd(const float* dfeat, void* dx, int N, int HW, int C, int dtype,
                               primia_stream_t stream);
 
+/* The head in two launches (torchlib/models.py:400-404, 478-481, 495: AvgPool2d(7) -> flatten -> Linear):
+ * primia_head_fwd = primia_global_avgpool_fwd + primia_linear_fwd (feat [N][C] is kept for the weight gradient),
+ * primia_head_bwd = dx of primia_linear_bwd + primia_global_avgpool_bwd (C a multiple of the 16-byte chunk). */
+int primia_head_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int N, int HW, int C,
+                    int out_f, int dtype, primia_stream_t stream);
+int primia_head_bwd(const float* w, const float* dlogits, void* dx, int N, int HW, int C, int out_f, int dtype,
+                    primia_stream_t stream);
 /* ------------------------------------------------------------------------------------------
  * Classifier head and loss — replaces F.linear (models.py:479,495), nn.CrossEntropyLoss
  * (train.py:335-340) and Cross_entropy_one_hot (torchlib/utils.py:404-441).  All fp32.

@@ -305,7 +305,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // those of the unfused kernels (first maximum in scan order, like torch's max_pool2d).
 // =================================================================================================
 
-template <typename T>
+// PW = output pixels per thread along W (1, or 2 when Wo is even: the two windows share a column, 15 loads
+// instead of 18, all independent).
+template <typename T, int PW>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, T* __restrict__ pooled,
                                                                uint8_t* __restrict__ argmax,
                                                                const float* __restrict__ gamma,
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
                                                                const float* __restrict__ invstd, int N, int H, int W,
                                                                int C, int Ho, int Wo) {
     constexpr int CH = Chunk<T>::N;
+    constexpr int NCOL = 2 * PW + 1;
     __shared__ float sm[3][512];
     for (int c = threadIdx.x; c < C; c += 256) {
         sm[0][c] = mean[c];
@@ -322,47 +325,84 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
     }
     __syncthreads();
     const int cpr = C / CH;
-    const long total = (long)N * Ho * Wo * cpr;
+    const int Wq = Wo / PW;
+    const long total = (long)N * Ho * Wq * cpr;
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= total) return;
     const int cc = (int)(q % cpr);
     long t = q / cpr;
-    const int wo = (int)(t % Wo);
-    t /= Wo;
+    const int wq = (int)(t % Wq);
+    t /= Wq;
     const int ho = (int)(t % Ho);
     const int n = (int)(t / Ho);
     const int c0 = cc * CH;
-    float best[CH];
-    int pos[CH];
+    float best[PW][CH];
+    int pos[PW][CH];
+#pragma unroll
+    for (int k = 0; k < PW; ++k)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            best[k][i] = 0.f;
+            pos[k][i] = -1;
+        }
+    float mu[CH], sc[CH], be[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        best[i] = 0.f;
-        pos[i] = -1;
+        mu[i] = sm[0][c0 + i];
+        sc[i] = sm[1][c0 + i];
+        be[i] = sm[2][c0 + i];
     }
+    const int w0 = wq * PW * 2 - 1;   // leftmost input column of the first window
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
         const int h = ho * 2 - 1 + r;
         if (h < 0 || h >= H) continue;
+        const T* row = y + (((long)n * H + h) * W) * C + c0;
+        u32x4 raw[NCOL];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int w = wo * 2 - 1 + s;
+        for (int col = 0; col < NCOL; ++col) {
+            const int w = w0 + col;
+            raw[col] = u32x4{0, 0, 0, 0};
+            if (w >= 0 && w < W) raw[col] = *(const u32x4*)(row + (long)w * C);
+        }
+#pragma unroll
+        for (int col = 0; col < NCOL; ++col) {
+            const int w = w0 + col;
             if (w < 0 || w >= W) continue;
             float v[CH];
-            Chunk<T>::unpack(*(const u32x4*)(y + (((long)n * H + h) * W + w) * C + c0), v);
+            Chunk<T>::unpack(raw[col], v);
 #pragma unroll
-            for (int i = 0; i < CH; ++i) {
-                const float z = round_to<T>(fmaxf(bn_affine(v[i], sm[0][c0 + i], sm[1][c0 + i], sm[2][c0 + i]), 0.f));
-                if (pos[i] < 0 || z > best[i] || z != z) {
-                    best[i] = z;
-                    pos[i] = r * 3 + s;
+            for (int i = 0; i < CH; ++i) v[i] = round_to<T>(fmaxf(bn_affine(v[i], mu[i], sc[i], be[i]), 0.f));
+#pragma unroll
+            for (int k = 0; k < PW; ++k) {
+                const int s = col - 2 * k;       // tap column of window k (scan order r, s as before)
+                if (s < 0 || s > 2) continue;
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const float z = v[i];
+                    if (pos[k][i] < 0 || z > best[k][i] || z != z) {
+                        best[k][i] = z;
+                        pos[k][i] = r * 3 + s;
+                    }
                 }
             }
         }
     }
-    const long o = (((long)n * Ho + ho) * Wo + wo) * C + c0;
-    *(u32x4*)(pooled + o) = Chunk<T>::pack(best);
 #pragma unroll
-    for (int i = 0; i < CH; ++i) argmax[o + i] = (uint8_t)pos[i];
+    for (int k = 0; k < PW; ++k) {
+        const long o = (((long)n * Ho + ho) * Wo + wq * PW + k) * C + c0;
+        *(u32x4*)(pooled + o) = Chunk<T>::pack(best[k]);
+        // the chunk's CH argmax bytes leave as one 4- / 8-byte store (o is a multiple of CH)
+        uint32_t pk[CH / 4];
+#pragma unroll
+        for (int j = 0; j < CH / 4; ++j)
+            pk[j] = (uint32_t)pos[k][4 * j] | ((uint32_t)pos[k][4 * j + 1] << 8) | ((uint32_t)pos[k][4 * j + 2] << 16) |
+                    ((uint32_t)pos[k][4 * j + 3] << 24);
+        if constexpr (CH == 8)
+            *(u32x2*)(argmax + o) = u32x2{pk[0], pk[1]};
+        else
+            *(uint32_t*)(argmax + o) = pk[0];
+    }
 }
 
 // gradient w.r.t. z(n, h, w, c0..c0+CH-1) coming back through the pool.  A pixel lies in at most 2 x 2
@@ -509,9 +549,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_kernel(
 }
 
 static inline void reduce_geometry(long M, int C, int& nblk, long& rows_per_block) {
-    // <= 1024 blocks; at least `min_rows` rows per block (PRIMIA_BN_MINROWS, default 64: the small late
-    // layers are latency-bound with few blocks — 256 rows per block left layer4 with 49 blocks).
-    static const long min_rows = getenv("PRIMIA_BN_MINROWS") ? atol(getenv("PRIMIA_BN_MINROWS")) : 64;
+    // <= 1024 blocks; at least `min_rows` rows per block (PRIMIA_BN_MINROWS, default 32: the small late
+    // layers are latency-bound with few blocks — 256 rows per block left layer4 with 49 blocks; measured
+    // 6.518 / 6.492 / 6.508 ms per step at 64 / 32 / 16).
+    static const long min_rows = getenv("PRIMIA_BN_MINROWS") ? atol(getenv("PRIMIA_BN_MINROWS")) : 32;
     long nb = (M + min_rows - 1) / min_rows;
     if (nb > kMaxPartialBlocks) nb = kMaxPartialBlocks;
     if (nb < 1) nb = 1;
@@ -567,6 +608,22 @@ static int bn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
 }
 
 template <typename T>
+static void launch_bn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
+                                    const float* mean, const float* invstd, int N, int H, int W, int C, int Ho, int Wo,
+                                    hipStream_t st) {
+    static const bool one = getenv("PRIMIA_POOL_PW") && getenv("PRIMIA_POOL_PW")[0] == '1';
+    const int pw = (Wo % 2 == 0 && !one) ? 2 : 1;
+    const long total = (long)N * Ho * (Wo / pw) * (C / Chunk<T>::N);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    if (pw == 2)
+        bn_relu_pool_fwd_kernel<T, 2><<<grid, 256, 0, st>>>((const T*)y, (T*)pooled, argmax, gamma, beta, mean, invstd, N,
+                                                           H, W, C, Ho, Wo);
+    else
+        bn_relu_pool_fwd_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)y, (T*)pooled, argmax, gamma, beta, mean, invstd, N,
+                                                           H, W, C, Ho, Wo);
+}
+
+template <typename T>
 static int bn_relu_pool_fwd_impl(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float* save_mean, float* save_invstd, int N,
                                  int H, int W, int C, float eps, float momentum, float* partials, hipStream_t st) {
@@ -579,9 +636,7 @@ static int bn_relu_pool_fwd_impl(const void* y, void* pooled, uint8_t* argmax, c
     bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partials, nblk, C, M, 0, eps, momentum, save_mean, save_invstd,
                                                        running_mean, running_var);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-    const long total = (long)N * Ho * Wo * (C / Chunk<T>::N);
-    bn_relu_pool_fwd_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-        (const T*)y, (T*)pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, Ho, Wo);
+    launch_bn_relu_pool_fwd<T>(y, pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, Ho, Wo, st);
     return launch_status();
 }
 
@@ -832,13 +887,9 @@ int primia_bn_relu_maxpool_fwd_from_sums(const void* y, void* pooled, uint8_t* a
                                                        running_mean, running_var);
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     if (dtype == PRIMIA_F32) {
-        const long total = (long)N * Ho * Wo * (C / 4);
-        bn_relu_pool_fwd_kernel<float><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-            (const float*)y, (float*)pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, Ho, Wo);
+        launch_bn_relu_pool_fwd<float>(y, pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, Ho, Wo, st);
     } else if (dtype == PRIMIA_BF16) {
-        const long total = (long)N * Ho * Wo * (C / 8);
-        bn_relu_pool_fwd_kernel<bf16><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-            (const bf16*)y, (bf16*)pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, Ho, Wo);
+        launch_bn_relu_pool_fwd<bf16>(y, pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, Ho, Wo, st);
     } else {
         return PRIMIA_ERR_ARG;
     }

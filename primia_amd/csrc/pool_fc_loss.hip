@@ -197,6 +197,73 @@ __global__ __launch_bounds__(1024) void linear_bwd_dw_kernel(const float* __rest
     }
 }
 
+// ---- head in two launches: AvgPool2d(7) -> flatten -> Linear (torchlib/models.py:400-404, 478-481, 495) ----
+// forward : block per sample; 16-byte loads, the pixel rows spread over the block's row groups, per-channel sums
+//           combined through LDS -> feat (kept for the weight gradient), then the out_f dot products by the waves.
+template <typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ b, float* __restrict__ feat,
+                                                       float* __restrict__ y, int HW, int C, int out_f) {
+    constexpr int CH = Chunk<T>::N;
+    extern __shared__ float sh[];              // [rpp][C] partial sums, then [C] feat in row 0
+    const int tpr = C / CH, rpp = 256 / tpr;
+    const int rg = threadIdx.x / tpr, cc = threadIdx.x % tpr;
+    const int n = blockIdx.x;
+    float s[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) s[i] = 0.f;
+    if (rg < rpp)
+        for (int p = rg; p < HW; p += rpp) {
+            float v[CH];
+            Chunk<T>::unpack(*(const u32x4*)(x + ((long)n * HW + p) * C + cc * CH), v);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) s[i] += v[i];
+        }
+    if (rg < rpp) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) sh[rg * C + cc * CH + i] = s[i];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int g = 0; g < rpp; ++g) a += sh[g * C + c];
+        a /= (float)HW;
+        feat[(long)n * C + c] = a;
+        sh[rpp * C + c] = a;
+    }
+    __syncthreads();
+    const float* f = sh + rpp * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int j = wave; j < out_f; j += 4) {
+        float a = 0.f;
+        for (int i = lane; i < C; i += 64) a += f[i] * w[(long)j * C + i];
+        a = wave_sum(a);
+        if (lane == 0) y[(long)n * out_f + j] = a + (b ? b[j] : 0.f);
+    }
+}
+// backward: dx[n][p][c] = (sum_j dy[n][j] w[j][c]) / HW for every pixel p (linear dx + avg-pool backward)
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                       T* __restrict__ dx, int HW, int C, int out_f) {
+    constexpr int CH = Chunk<T>::N;
+    extern __shared__ float sh[];              // [C]
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < out_f; ++j) a += dy[(long)n * out_f + j] * w[(long)j * C + c];
+        sh[c] = a / (float)HW;
+    }
+    __syncthreads();
+    const int cpr = C / CH;
+    for (int q = threadIdx.x; q < HW * cpr; q += 256) {
+        const int c0 = (q % cpr) * CH;
+        float v[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] = sh[c0 + i];
+        *(u32x4*)(dx + (long)n * HW * C + (long)q * CH) = Chunk<T>::pack(v);
+    }
+}
+
 // ---- cross entropy (single block; N is a batch size) ---------------------------------------------
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     v = wave_sum(v);
@@ -347,6 +414,40 @@ int primia_global_avgpool_bwd(const float* dfeat, void* dx, int N, int HW, int C
         gap_bwd_kernel<bf16><<<ceil_div(total, 256), 256, 0, st>>>(dfeat, (bf16*)dx, HW, C, total);
     else
         return PRIMIA_ERR_ARG;
+    return launch_status();
+}
+
+static bool head_shape_ok(int C, int dtype) {
+    const int ch = dtype == PRIMIA_F32 ? 4 : 8;
+    return C % ch == 0 && C / ch <= 256 && 256 % (C / ch) == 0 && C <= 2048;
+}
+int primia_head_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int N, int HW, int C,
+                    int out_f, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(x && w && feat && logits && N > 0 && HW > 0 && C > 0 && out_f > 0);
+    PRIMIA_REQUIRE(dtype == PRIMIA_F32 || dtype == PRIMIA_BF16);
+    hipStream_t st = (hipStream_t)stream;
+    if (!head_shape_ok(C, dtype)) {   // odd channel counts: the two general kernels
+        const int rc = primia_global_avgpool_fwd(x, feat, N, HW, C, dtype, stream);
+        return rc ? rc : primia_linear_fwd(feat, w, b, logits, N, C, out_f, stream);
+    }
+    const int ch = dtype == PRIMIA_F32 ? 4 : 8;
+    const size_t lds = (size_t)(256 / (C / ch) + 1) * C * sizeof(float);
+    if (dtype == PRIMIA_F32)
+        head_fwd_kernel<float><<<N, 256, lds, st>>>((const float*)x, w, b, feat, logits, HW, C, out_f);
+    else
+        head_fwd_kernel<bf16><<<N, 256, lds, st>>>((const bf16*)x, w, b, feat, logits, HW, C, out_f);
+    return launch_status();
+}
+int primia_head_bwd(const float* w, const float* dlogits, void* dx, int N, int HW, int C, int out_f, int dtype,
+                    primia_stream_t stream) {
+    PRIMIA_REQUIRE(w && dlogits && dx && N > 0 && HW > 0 && C > 0 && out_f > 0);
+    PRIMIA_REQUIRE((dtype == PRIMIA_F32 || dtype == PRIMIA_BF16) && head_shape_ok(C, dtype));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)C * sizeof(float);
+    if (dtype == PRIMIA_F32)
+        head_bwd_kernel<float><<<N, 256, lds, st>>>(w, dlogits, (float*)dx, HW, C, out_f);
+    else
+        head_bwd_kernel<bf16><<<N, 256, lds, st>>>(w, dlogits, (bf16*)dx, HW, C, out_f);
     return launch_status();
 }
 

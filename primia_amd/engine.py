@@ -99,11 +99,20 @@ class ResNet18Engine:
         if self.final_hw != input_size // 32:
             raise _lib.PrimiaError("input_size must be a multiple of 32")
 
+        # fp32 weight-gradient accumulators (forward layout), one arena.  The layers served by the atomic-free
+        # path (primia_conv2d_wgrad_ws OVERWRITES its accumulator) sit behind the ones that accumulate with
+        # atomics, so that only the front part needs zeroing every step.
         acc_total = 0
-        for c in self.convs.values():
-            c.wfwd_n = query("primia_conv_wfwd_elems", c.desc)
-            c.acc_off = acc_total
-            acc_total += (c.wfwd_n + 3) // 4 * 4
+        ws_need = {c.spec.name: query("primia_conv_wgrad_ws_bytes", c.desc, self.dt) for c in self.convs.values()}
+        for overwriting in (False, True):
+            for c in self.convs.values():
+                if (ws_need[c.spec.name] > 0) != overwriting:
+                    continue
+                c.wfwd_n = query("primia_conv_wfwd_elems", c.desc)
+                c.acc_off = acc_total
+                acc_total += (c.wfwd_n + 3) // 4 * 4
+            if not overwriting:
+                self._acc_zero_n = acc_total
         self.dw_acc = torch.zeros(acc_total, dtype=torch.float32, device=dev)
         for c in self.convs.values():
             c.w_fwd = torch.empty(c.wfwd_n, dtype=dtype, device=dev)
@@ -113,7 +122,7 @@ class ResNet18Engine:
             c.acc = self.dw_acc[c.acc_off:c.acc_off + c.wfwd_n]
         # workspace of the atomic-free weight-gradient path (primia_conv2d_wgrad_ws): the layers run one after
         # the other on one stream, so they share one buffer sized for the largest (38 MB at batch 256)
-        ws_bytes = max(query("primia_conv_wgrad_ws_bytes", c.desc, self.dt) for c in self.convs.values())
+        ws_bytes = max(ws_need.values())
         self.wgrad_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev) if ws_bytes > 0 else None
         self.wgrad_ws_bytes = ws_bytes
 
@@ -409,9 +418,8 @@ class ResNet18Engine:
             self._bn(blk.conv2.name, t[p + ".y2"], t[p + ".out"], idn, True)
             x = t[p + ".out"]
         hw = self.final_hw
-        call("primia_global_avgpool_fwd", x, self.feat, N, hw * hw, 512, self.dt)
-        call("primia_linear_fwd", self.feat, self.views["fc.weight"], self.views["fc.bias"], self.logits, N, 512,
-             self.spec.num_classes)
+        call("primia_head_fwd", x, self.views["fc.weight"], self.views["fc.bias"], self.feat, self.logits, N, hw * hw,
+             512, self.spec.num_classes, self.dt)
         return self.logits
 
     __call__ = forward
@@ -508,13 +516,16 @@ class ResNet18Engine:
     def backward(self):
         N, t = self.N, self.t
         nc = self.spec.num_classes
-        self.dw_acc.zero_()
+        if self.wgrad_ws is not None and not self.wgrad_overlap and self.dp is None:
+            self.dw_acc[:self._acc_zero_n].zero_()      # the other layers' accumulators are overwritten
+        else:
+            self.dw_acc.zero_()
         # (under DP-SGD fc.weight / fc.bias gradients are overwritten later from the clipped dlogits)
-        call("primia_linear_bwd", self.feat, self.views["fc.weight"], self.dlogits, self.dfeat,
+        call("primia_linear_bwd", self.feat, self.views["fc.weight"], self.dlogits, None,
              self.gviews["fc.weight"], self.gviews["fc.bias"], N, 512, nc)
         last = self.spec.blocks[-1].prefix
         hw = self.final_hw
-        call("primia_global_avgpool_bwd", self.dfeat, t[last + ".dout"], N, hw * hw, 512, self.dt)
+        call("primia_head_bwd", self.views["fc.weight"], self.dlogits, t[last + ".dout"], N, hw * hw, 512, nc, self.dt)
         blocks = self.spec.blocks
         for i in range(len(blocks) - 1, -1, -1):
             blk = blocks[i]

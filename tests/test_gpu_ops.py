@@ -298,6 +298,34 @@ def test_head(cuda, dtype):
     dx = torch.empty_like(xd)
     call("primia_global_avgpool_bwd", dfeat, dx, N, HW, C, dt)
     assert relerr(from_nhwc(dx, N, 2, 2), xr.grad) < tol(dtype)
+    # the head in two launches (what the engine calls): same feat / logits / dx
+    feat2, logits2, dx2 = torch.empty_like(feat), torch.empty_like(logits), torch.empty_like(xd)
+    call("primia_head_fwd", xd, w.to(cuda), b.to(cuda), feat2, logits2, N, HW, C, NC, dt)
+    assert relerr(feat2, feat_ref.detach()) < 1e-5 and relerr(logits2, logits_ref.detach()) < 1e-5
+    call("primia_head_bwd", w.to(cuda), dl.to(cuda), dx2, N, HW, C, NC, dt)
+    assert relerr(from_nhwc(dx2, N, 2, 2), xr.grad) < tol(dtype)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_head_fused_resnet_shape(cuda, dtype):
+    """AvgPool2d(7) -> Linear(512, 3) at the ResNet-18 shape (49 pixels: ragged over the 4 / 2 row groups)."""
+    N, C, NC = 3, 512, 3
+    g = torch.Generator().manual_seed(12)
+    x = rnd(torch.randn(N, C, 7, 7, generator=g), dtype)
+    w = torch.randn(NC, C, generator=g) * 0.05
+    b = torch.randn(NC, generator=g)
+    xr = x.clone().requires_grad_(True)
+    feat_ref = torch.flatten(F.avg_pool2d(xr, 7), 1)
+    logits_ref = F.linear(feat_ref, w, b)
+    dl = torch.randn(N, NC, generator=g)
+    logits_ref.backward(dl)
+    dt = _lib.dtype_code(dtype)
+    xd = to_nhwc(x, dtype, cuda)
+    feat, logits, dx = torch.empty(N, C, device=cuda), torch.empty(N, NC, device=cuda), torch.empty_like(xd)
+    call("primia_head_fwd", xd, w.to(cuda), b.to(cuda), feat, logits, N, 49, C, NC, dt)
+    assert relerr(feat, feat_ref.detach()) < 1e-5 and relerr(logits, logits_ref.detach()) < 1e-5
+    call("primia_head_bwd", w.to(cuda), dl.to(cuda), dx, N, 49, C, NC, dt)
+    assert relerr(from_nhwc(dx, N, 7, 7), xr.grad) < tol(dtype)
 
 
 @pytest.mark.parametrize("weighted", [False, True])
