@@ -14,6 +14,7 @@ Memory layout (all on one GPU):
   per conv: compute-dtype weight copies in the implicit-GEMM layouts (+ fp32 wgrad accumulator)
   activations / gradients: NHWC tensors in the compute dtype (bf16 for throughput, fp32 for parity)
 """
+import os
 from collections import OrderedDict
 
 import torch
@@ -192,6 +193,21 @@ class ResNet18Engine:
         self.free_stats = {c.name for c in self.spec.convs
                            if dtype == torch.bfloat16 and norm == "batch" and c.name != "conv1"
                            and self.convs[c.name].stat_slots != self.stat_slots}
+        # Experiment (PRIMIA_ATOMIC_STATS=layer3,layer4): the implicit-GEMM epilogue accumulates the batch sums with
+        # atomics for the named stages only, whose separate statistics kernels are latency- rather than
+        # bandwidth-bound.  Their partial slabs are the tail of stat_sums and are zeroed once per forward.
+        self._atomic_stats_from = None
+        pref = tuple(p for p in os.environ.get("PRIMIA_ATOMIC_STATS", "").split(",") if p)
+        if pref and dtype == torch.bfloat16 and norm == "batch":
+            off = 0
+            for c in self.spec.convs:
+                if c.name.startswith(pref) and c.name not in self.free_stats:
+                    self.free_stats.add(c.name)
+                    if self._atomic_stats_from is None:
+                        self._atomic_stats_from = off
+                elif self._atomic_stats_from is not None:
+                    raise _lib.PrimiaError("PRIMIA_ATOMIC_STATS must name a suffix of the network's stages")
+                off += per(c)
         self.save = {}
         for c in self.spec.convs:
             b = bn_name(c.name)
@@ -360,6 +376,8 @@ class ResNet18Engine:
         x_nchw = x_nchw.contiguous()
         if self.training and self.fuse_stats:
             self.stat_sums.zero_()
+        elif self.training and self._atomic_stats_from is not None:
+            self.stat_sums[self._atomic_stats_from:].zero_()
         self._stem_padded = self.x0p is not None and not (self.training and self.fuse_stats)
         if not self._stem_padded or self.norm == "group":  # (the DP path's per-sample stem wgrad reads x0)
             call("primia_nchw_to_nhwc", x_nchw, self.x0, N, self.spec.in_channels, S, S, 4, self.dt)
