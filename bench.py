@@ -213,12 +213,14 @@ def main():
     conv_ms = sum(d["ms"] for d in agg.values()) / nprof
     conv_fl = sum(d["flops"] for d in agg.values()) / nprof
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_v2.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_v3.json")
     if os.path.exists(tpath) and a.batch == 256 and a.size == 224 and a.dtype == "bf16":
         # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the
         # gfx950 correction, + WRITE_SIZE), collected offline on this exact workload: see the file's _note
         traffic = json.load(open(tpath)).get(dom.split(" ")[0], {}).get("hbm_bytes_per_launch")
     roof = {"bound": "mfma", "kernel": dom,
+            "launch": "median over %d steps of the HIP-event bracket around one C-ABI call (conv_wgrad_patch_kernel: the "
+                      "kernel + its wgrad_patch_reduce_kernel)" % nprof,
             "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic,
             "all_conv": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 3),

@@ -327,6 +327,8 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
     const int cpr = C / CH;
     const int Wq = Wo / PW;
     const long total = (long)N * Ho * Wq * cpr;
+    // (an XCD-contiguous block order was measured slower, 161 -> 178 us: the eight L2s then stream eight distant
+    // regions instead of sharing one; the 1.47x fetch amplification of the window rows is mostly MALL hits)
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= total) return;
     const int cc = (int)(q % cpr);

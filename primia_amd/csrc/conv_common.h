@@ -49,13 +49,5 @@ struct ConvGeom {
     }
 };
 
-// XCD-aware, bijective remap of a 1-D block id: blocks b, b+8, b+16, ... share an XCD (observed
-// placement; speed only), so give each XCD a contiguous range of tiles.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int q = nblk >> 3, r = nblk & 7;
-    const int xcd = bid & 7, idx = bid >> 3;
-    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + idx;
-}
 
 }  // namespace primia
