@@ -186,6 +186,8 @@ def main():
             return "stem_conv_fwd_kernel"
         if l1:
             return "conv3x3_c64_kernel"
+        if sp.k == 3 and sp.stride == 1 and sp.cout % 128 == 0 and os.environ.get("PRIMIA_LH", "1") != "0":
+            return "conv3x3_lh_kernel<%s>" % kind       # wide 3x3 / stride-1 layers: linear-halo kernel
         return "conv_igemm_kernel<%s>" % kind
 
     per_launch = {}

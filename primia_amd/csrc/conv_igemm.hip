@@ -567,6 +567,13 @@ namespace primia {
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
                          hipStream_t st, float* stat_partials = nullptr);
 int conv3x3_c64_grid(int N, int H, int W);
+int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
+                        int accumulate, hipStream_t st);
+}
+
+// wide 3x3 / stride-1 layers (layer2-4): linear-halo kernel (conv3x3_lh.hip); PRIMIA_LH=0 keeps the implicit GEMM
+static bool lh_shape(const ConvGeom& g) {
+    return !g.stem && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1;
 }
 
 // layer1 shape (3x3, stride 1, pad 1, 64 -> 64 channels, bf16): weight-stationary halo kernel (conv3x3_c64.hip);
@@ -603,6 +610,10 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
         if (use_c64(g)) {  // (its statistics are per-block partials, see primia_conv_stat_slots_for)
             const int rc = conv3x3_c64_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, 0, 0, st,
                                                 stat_sums);
+            if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+        } else if (lh_shape(g) && !stat_sums) {
+            const int rc = conv3x3_lh_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, g.C, g.K, 0, 0,
+                                               st);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         }
         p.nsteps = g.klen / 64;
@@ -659,6 +670,10 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
         if (use_c64(g)) {
             const int rc = conv3x3_c64_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, 1,
                                                 accumulate, st);
+            if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+        } else if (lh_shape(g) && !p.src2) {
+            const int rc = conv3x3_lh_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C, 1,
+                                               accumulate, st);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         }
         p.nsteps = p.klen / 64;
