@@ -57,6 +57,7 @@ struct LhParams {
     int flip;          // 0 forward, 1 data gradient
     int accumulate;    // dst += result
     int ntile_n;
+    float* stat_partials;  // forward only: BatchNorm partial sums [tiles_m][2][Nd] of the values AS STORED (or null)
     int debug;         // timing experiments only (PRIMIA_LH_DEBUG): 1 no stores, 2 no staging, 4 no MFMA
 };
 
@@ -282,6 +283,9 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
         }
     }
     __syncthreads();
+    float st1[8], st2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) st1[e] = st2[e] = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int q = tid + 512 * k;            // 16-byte output chunk: pixel q / 16, channels 8 * (q % 16) ..
@@ -303,23 +307,64 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
             }
         } else {
             v = *(const u32x4*)(smem + px * OPIX + ((c8 ^ (px & 15)) << 4));
+            if (p.stat_partials) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                    st1[2 * e] += lo;
+                    st2[2 * e] += lo * lo;
+                    st1[2 * e + 1] += hi;
+                    st2[2 * e + 1] += hi * hi;
+                }
+            }
         }
         *(u32x4*)gq = v;
+    }
+    if (!ACC && p.stat_partials) {
+        // BatchNorm batch statistics of the NEXT layer for free (as conv3x3_c64.hip): a write-back thread holds the
+        // same 8 channels (tid % 16) of 8 pixels; the 32 threads of a channel group are folded through LDS in a
+        // fixed order -> one deterministic partial per block, consumed by primia_bn_fwd_train_from_sums.
+        __syncthreads();                       // the staged rows are dead
+        float* red = (float*)smem;             // [32][2][128]
+        const int grp = tid >> 4, c0 = (tid & 15) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            red[(grp * 2 + 0) * 128 + c0 + e] = st1[e];
+            red[(grp * 2 + 1) * 128 + c0 + e] = st2[e];
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int q = tid >> 7, c = tid & 127;
+            float a = 0.f;
+#pragma unroll 8
+            for (int g = 0; g < 32; ++g) a += red[(g * 2 + q) * 128 + c];
+            p.stat_partials[((long)tm * 2 + q) * p.Nd + n0 + c] = a;
+        }
     }
 }
 
 // returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the implicit GEMM)
-int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
-                        int accumulate, hipStream_t st) {
+// pixel tiles (= BatchNorm partial slots of the forward form) if the shape is served by this kernel, else
+// PRIMIA_ERR_UNSUPPORTED
+int conv3x3_lh_tiles_m(int N, int H, int W, int Cs, int Nd) {
     static const bool off = getenv("PRIMIA_LH") && getenv("PRIMIA_LH")[0] == '0';
     if (off || W > 30 || W < 2 || Cs % 64 || Nd % kLhBN) return PRIMIA_ERR_UNSUPPORTED;
     const long M = (long)N * H * W;
     if (M * (Cs > Nd ? Cs : Nd) >= (1L << 31)) return PRIMIA_ERR_UNSUPPORTED;
+    return (int)((M + kLhBM - 1) / kLhBM);
+}
+
+int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
+                        int accumulate, hipStream_t st, float* stat_partials) {
+    if (conv3x3_lh_tiles_m(N, H, W, Cs, Nd) < 0) return PRIMIA_ERR_UNSUPPORTED;
+    if (stat_partials && (flip || accumulate)) return PRIMIA_ERR_ARG;
+    const long M = (long)N * H * W;
     LhParams p;
     p.src = src; p.wt = wt; p.dst = dst;
     p.H = H; p.W = W; p.Cs = Cs; p.Nd = Nd; p.M = M;
     p.flip = flip; p.accumulate = accumulate;
     p.ntile_n = Nd / kLhBN;
+    p.stat_partials = stat_partials;
     static const int dbg = getenv("PRIMIA_LH_DEBUG") ? atoi(getenv("PRIMIA_LH_DEBUG")) : 0;
     p.debug = dbg;
     const int grid = (int)((M + kLhBM - 1) / kLhBM) * p.ntile_n;

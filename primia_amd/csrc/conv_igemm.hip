@@ -568,7 +568,8 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
                          hipStream_t st, float* stat_partials = nullptr);
 int conv3x3_c64_grid(int N, int H, int W);
 int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
-                        int accumulate, hipStream_t st);
+                        int accumulate, hipStream_t st, float* stat_partials = nullptr);
+int conv3x3_lh_tiles_m(int N, int H, int W, int Cs, int Nd);
 }
 
 // wide 3x3 / stride-1 layers (layer2-4): linear-halo kernel (conv3x3_lh.hip); PRIMIA_LH=0 keeps the implicit GEMM
@@ -611,9 +612,9 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
             const int rc = conv3x3_c64_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, 0, 0, st,
                                                 stat_sums);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
-        } else if (lh_shape(g) && !stat_sums) {
+        } else if (lh_shape(g)) {   // (statistics: per-block partials as well)
             const int rc = conv3x3_lh_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, g.C, g.K, 0, 0,
-                                               st);
+                                               st, stat_sums);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         }
         p.nsteps = g.klen / 64;
@@ -633,6 +634,10 @@ int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype) {
     ConvGeom g;
     if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
     if (dtype == PRIMIA_BF16 && use_c64(g) && (long)g.N * g.H * g.W * 64 < (1L << 31)) return conv3x3_c64_grid(g.N, g.H, g.W);
+    if (dtype == PRIMIA_BF16 && !use_c64(g) && lh_shape(g)) {
+        const int t = conv3x3_lh_tiles_m(g.N, g.H, g.W, g.C, g.K);
+        if (t > 0) return t;
+    }
     return kStatSlots;
 }
 

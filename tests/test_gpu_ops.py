@@ -605,6 +605,33 @@ def test_layer1_conv_emits_batchnorm_partials(cuda, N, H):
         assert relerr(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("N,H,C,K", [(2, 28, 128, 128), (4, 14, 256, 256), (5, 7, 512, 512), (3, 10, 128, 256)])
+def test_wide_conv_emits_batchnorm_partials(cuda, N, H, C, K):
+    """The linear-halo kernel (wide 3x3 / stride-1 layers) emits one deterministic BatchNorm partial per pixel tile:
+    summed over the slots they equal the column sums of the output AS STORED (ragged last tile included)."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(H + C)
+    x = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
+    w = rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype)
+    desc = ConvDesc.make(N, H, H, C, K, 3, 3, 1, 1)
+    wf, _ = prep_weights(desc, w, dtype, cuda, C)
+    slots = query("primia_conv_stat_slots_for", desc, dt)
+    M = N * H * H
+    assert slots == (M + 255) // 256
+    y = torch.empty(M, K, dtype=dtype, device=cuda)
+    sums = torch.full((slots, 2, K), float("nan"), device=cuda)   # written, not accumulated
+    call("primia_conv2d_fwd_stats", desc, x, wf, y, sums, dt)
+    y2 = torch.empty_like(y)
+    call("primia_conv2d_fwd", desc, x, wf, y2, dt)
+    assert torch.equal(y, y2)
+    yf = y.float()
+    assert relerr(sums[:, 0].sum(0), yf.sum(0)) < 1e-5 and relerr(sums[:, 1].sum(0), (yf * yf).sum(0)) < 1e-5
+    sums2 = torch.full_like(sums, float("nan"))
+    call("primia_conv2d_fwd_stats", desc, x, wf, y2, sums2, dt)
+    assert torch.equal(sums, sums2)
+
+
 def test_stem_conv_emits_batchnorm_partials_and_fused_tail_from_sums(cuda):
     dtype = torch.bfloat16
     dt = _lib.dtype_code(dtype)
