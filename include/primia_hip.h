@@ -123,6 +123,17 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
 /* dx[N,H,W,C] = conv_transpose(dy[N,Ho,Wo,K], w).  If accumulate != 0, dx += (dx is read). */
 int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                         int accumulate, int dtype, primia_stream_t stream);
+/* Data gradient that also forms the two reductions of the BatchNorm backward pass which consumes dx (the layer
+ * torchlib/models.py:261-264 / :277-282 in front of this conv): sums [slots][2][C] = per-tile partial
+ * (sum g, sum g*(y - mean)) with g = dx AS STORED where the ReLU passed — relu_mask bits (primia_bn_fwd_train_mask)
+ * if given, else recomputed from bn_y as fma(y - mean, invstd*gamma, beta) > 0.  primia_bn_bwd_from_sums then needs
+ * no reduction pass over y and dx.  slots = primia_conv_dgrad_bnsum_slots (0: this conv's data gradient cannot emit
+ * them — call primia_conv2d_dgrad and the ordinary BatchNorm backward); bf16 only. */
+int primia_conv_dgrad_bnsum_slots(const primia_conv_desc* d, int dtype);
+int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                               const void* bn_y, const uint8_t* relu_mask, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, float* sums, int dtype,
+                               primia_stream_t stream);
 /* Transition block (torchlib/models.py:268-284 with a downsample, :232-235): dx = dgrad(conv1 3x3/2, dy) +
  * dgrad(downsample 1x1/2, dy_ds) in ONE pass — both convolutions read the same x, the downsample's gradient lands
  * on the even/even pixels, where conv1's only tap is the centre one at the same dy pixel, so it is folded into
@@ -226,6 +237,12 @@ int primia_bn_relu_bwd(const void* y, const void* dz, void* dy, const float* gam
                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                        int64_t M, int C, void* workspace, int64_t workspace_bytes, int dtype,
                        primia_stream_t stream);
+/* BatchNorm backward from the partial sums a data-gradient kernel already formed (primia_conv2d_dgrad_bnsums):
+ * finalize + apply pass; relu_mask (bits) or, if NULL, the ReLU mask recomputed from y (beta required). */
+int primia_bn_bwd_from_sums(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
+                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                            float* dgamma, float* dbeta, const float* sums, int slots, int64_t M, int C, int dtype,
+                            primia_stream_t stream);
 /* The stem's tail fused: pooled, argmax = MaxPool2d(3, 2, 1)(relu(bn1(y))) straight from the conv
  * output (torchlib/models.py:468-471), batch statistics included — z = relu(bn(y)), the largest
  * activation of the network, is never written.  Same results as primia_bn_fwd_train(relu = 1)

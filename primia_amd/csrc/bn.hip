@@ -135,7 +135,8 @@ constexpr int kFinSlices = 64;
 __global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_kernel(const float* __restrict__ partials, int nblk,
                                                           int C, long M, int mode, float eps,
                                                           float momentum, float* out1, float* out2,
-                                                          float* running_mean, float* running_var) {
+                                                          float* running_mean, float* running_var,
+                                                          const float* scale2 = nullptr) {
     __shared__ double sa[kFinSlices][17], sb[kFinSlices][17];
     const int cl = threadIdx.x & 15, ks = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_kernel(const floa
         }
     } else {
         out1[c] = (float)a;  // dbeta
-        out2[c] = (float)b;  // dgamma
+        // dgamma; mode 1 with scale2: the second sum is sum g*(y - mean) and still lacks the factor invstd
+        out2[c] = scale2 ? (float)(b * (double)scale2[c]) : (float)b;
     }
 }
 
@@ -763,6 +765,21 @@ static int bn_relu_pool_bwd_impl(const void* y, const void* pooled, const void* 
 
 using namespace primia;
 
+// BatchNorm backward whose two reductions were already formed by the data-gradient kernel that produced dz
+// (primia_conv2d_dgrad_bnsums): sums [slots][2][C] = partial (sum g, sum g*(y - mean)); finalize + apply pass only.
+template <typename T>
+static int bn_bwd_from_sums_impl(const void* y, const uint8_t* mask, const void* dz, void* dy, void* g_out,
+                                 const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                                 float* dgamma, float* dbeta, const float* sums, int slots, long M, int C, hipStream_t st) {
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(sums, slots, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr,
+                                                                  nullptr, save_invstd);
+    const long nchunks = M * C / Chunk<T>::N;
+    bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
+        (const T*)y, nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean, save_invstd, dbeta, dgamma,
+        (float)(1.0 / (double)M), nchunks, C, mask ? nullptr : beta, mask);
+    return launch_status();
+}
+
 extern "C" {
 
 int64_t primia_bn_workspace_bytes(int64_t M, int C) {
@@ -971,6 +988,23 @@ int primia_bn_bwd_mask(const void* y, const uint8_t* relu_mask, const void* dz, 
     if (dtype == PRIMIA_BF16)
         return bn_bwd_impl<bf16>(y, nullptr, dz, dy, g_out, gamma, save_mean, save_invstd, dgamma, dbeta, M, C, 0,
                                  (float*)workspace, st, nullptr, relu_mask);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_bn_bwd_from_sums(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
+                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                            float* dgamma, float* dbeta, const float* sums, int slots, int64_t M, int C, int dtype,
+                            primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && dz && dy && gamma && save_mean && save_invstd && dgamma && dbeta && sums && slots >= 1);
+    PRIMIA_REQUIRE(relu_mask || beta);
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype));
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return bn_bwd_from_sums_impl<float>(y, relu_mask, dz, dy, g_out, gamma, beta, save_mean, save_invstd, dgamma, dbeta,
+                                            sums, slots, M, C, st);
+    if (dtype == PRIMIA_BF16)
+        return bn_bwd_from_sums_impl<bf16>(y, relu_mask, dz, dy, g_out, gamma, beta, save_mean, save_invstd, dgamma, dbeta,
+                                           sums, slots, M, C, st);
     return PRIMIA_ERR_ARG;
 }
 

@@ -25,7 +25,7 @@
 // Data gradient = the same kernel on (dy, w_dgrad [C][R][S][K]) with the tap direction flipped.
 #include <stdlib.h>
 
-#include "conv_common.h"
+#include "conv3x3_lh.h"
 
 namespace primia {
 
@@ -57,6 +57,15 @@ struct LhParams {
     int flip;          // 0 forward, 1 data gradient
     int accumulate;    // dst += result
     int ntile_n;
+    // data gradient only: backward sums of the BatchNorm that consumes dst (see primia_conv2d_dgrad_bnsums):
+    // bwd_partials [tiles_m][2][Nd] = per-tile (sum g, sum g * (y - mean)), g = dst AS STORED where the ReLU passed
+    const bf16* bn_y;
+    const uint8_t* bn_mask;      // one byte per 8 channels (bit i = z_i > 0), or null: mask = fma(y-mean, invstd*gamma, beta) > 0
+    const float* bn_gamma;
+    const float* bn_beta;
+    const float* bn_mean;
+    const float* bn_invstd;
+    float* bwd_partials;
     float* stat_partials;  // forward only: BatchNorm partial sums [tiles_m][2][Nd] of the values AS STORED (or null)
     int debug;         // timing experiments only (PRIMIA_LH_DEBUG): 1 no stores, 2 no staging, 4 no MFMA
 };
@@ -266,6 +275,24 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
     // pixel so that both the fragment writes and the row reads spread over the banks.
     if ((p.debug & 1) && acc[0][0][0] != 12345.f) return;
     constexpr int OPIX = ACC ? 512 : 256;
+    // backward-sum form: the BatchNorm input (and mask bytes) of this thread's 8 write-back chunks are requested
+    // NOW, so that their latency runs beside the LDS staging of the accumulators
+    u32x4 yraw[8];
+    unsigned mkb[8];
+    if (p.bwd_partials) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = tid + 512 * k;
+            const long m = m0 + (q >> 4);
+            yraw[k] = u32x4{0, 0, 0, 0};
+            mkb[k] = 0;
+            if (m < p.M) {
+                const long eo = m * p.Nd + n0 + (q & 15) * 8;
+                yraw[k] = *(const u32x4*)(p.bn_y + eo);
+                if (p.bn_mask) mkb[k] = p.bn_mask[eo >> 3];
+            }
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int px = wm * 64 + 16 * j + fr;
@@ -286,6 +313,16 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
     float st1[8], st2[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) st1[e] = st2[e] = 0.f;
+    float bmean[8], bscale[8], bbeta[8];     // this thread's 8 channels are the same in every trip
+    if (p.bwd_partials) {
+        const int cb = n0 + (tid & 15) * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            bmean[e] = p.bn_mean[cb + e];
+            bscale[e] = p.bn_invstd[cb + e] * p.bn_gamma[cb + e];   // the forward pass's operand order
+            bbeta[e] = p.bn_beta ? p.bn_beta[cb + e] : 0.f;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const int q = tid + 512 * k;            // 16-byte output chunk: pixel q / 16, channels 8 * (q % 16) ..
@@ -319,8 +356,28 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
             }
         }
         *(u32x4*)gq = v;
+        if (p.bwd_partials) {
+            float yv[8];
+            Chunk<bf16>::unpack(yraw[k], yv);
+            unsigned mk;
+            if (p.bn_mask) {
+                mk = mkb[k];
+            } else {
+                mk = 0;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    mk |= (__builtin_fmaf(yv[e] - bmean[e], bscale[e], bbeta[e]) > 0.f ? 1u : 0u) << e;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float raw = (e & 1) ? __uint_as_float(v[e >> 1] & 0xffff0000u) : __uint_as_float(v[e >> 1] << 16);
+                const float gv = (mk >> e) & 1u ? raw : 0.f;
+                st1[e] += gv;
+                st2[e] += gv * (yv[e] - bmean[e]);
+            }
+        }
     }
-    if (!ACC && p.stat_partials) {
+    if ((!ACC && p.stat_partials) || p.bwd_partials) {
         // BatchNorm batch statistics of the NEXT layer for free (as conv3x3_c64.hip): a write-back thread holds the
         // same 8 channels (tid % 16) of 8 pixels; the 32 threads of a channel group are folded through LDS in a
         // fixed order -> one deterministic partial per block, consumed by primia_bn_fwd_train_from_sums.
@@ -338,7 +395,7 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
             float a = 0.f;
 #pragma unroll 8
             for (int g = 0; g < 32; ++g) a += red[(g * 2 + q) * 128 + c];
-            p.stat_partials[((long)tm * 2 + q) * p.Nd + n0 + c] = a;
+            (p.bwd_partials ? p.bwd_partials : p.stat_partials)[((long)tm * 2 + q) * p.Nd + n0 + c] = a;
         }
     }
 }
@@ -355,9 +412,10 @@ int conv3x3_lh_tiles_m(int N, int H, int W, int Cs, int Nd) {
 }
 
 int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
-                        int accumulate, hipStream_t st, float* stat_partials) {
+                        int accumulate, hipStream_t st, float* stat_partials, const LhBnArgs* bn) {
     if (conv3x3_lh_tiles_m(N, H, W, Cs, Nd) < 0) return PRIMIA_ERR_UNSUPPORTED;
     if (stat_partials && (flip || accumulate)) return PRIMIA_ERR_ARG;
+    if (bn && (!flip || stat_partials)) return PRIMIA_ERR_ARG;
     const long M = (long)N * H * W;
     LhParams p;
     p.src = src; p.wt = wt; p.dst = dst;
@@ -365,6 +423,12 @@ int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H
     p.flip = flip; p.accumulate = accumulate;
     p.ntile_n = Nd / kLhBN;
     p.stat_partials = stat_partials;
+    p.bwd_partials = nullptr;
+    p.bn_y = nullptr; p.bn_mask = nullptr; p.bn_gamma = p.bn_beta = p.bn_mean = p.bn_invstd = nullptr;
+    if (bn) {
+        p.bn_y = (const bf16*)bn->y; p.bn_mask = bn->mask; p.bn_gamma = bn->gamma; p.bn_beta = bn->beta;
+        p.bn_mean = bn->mean; p.bn_invstd = bn->invstd; p.bwd_partials = bn->partials;
+    }
     static const int dbg = getenv("PRIMIA_LH_DEBUG") ? atoi(getenv("PRIMIA_LH_DEBUG")) : 0;
     p.debug = dbg;
     const int grid = (int)((M + kLhBM - 1) / kLhBM) * p.ntile_n;

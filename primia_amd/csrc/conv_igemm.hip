@@ -19,7 +19,7 @@
 // v_mfma_f32_16x16x32_bf16 with fp32 accumulation — the throughput path.
 #include <stdlib.h>
 
-#include "conv_common.h"
+#include "conv3x3_lh.h"
 
 namespace primia {
 
@@ -567,9 +567,6 @@ namespace primia {
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
                          hipStream_t st, float* stat_partials = nullptr);
 int conv3x3_c64_grid(int N, int H, int W);
-int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
-                        int accumulate, hipStream_t st, float* stat_partials = nullptr);
-int conv3x3_lh_tiles_m(int N, int H, int W, int Cs, int Nd);
 }
 
 // wide 3x3 / stride-1 layers (layer2-4): linear-halo kernel (conv3x3_lh.hip); PRIMIA_LH=0 keeps the implicit GEMM
@@ -648,7 +645,8 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
 }
 
 static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
-                             int accumulate, const void* dy2, const void* w_dgrad2, int dtype, primia_stream_t stream) {
+                             int accumulate, const void* dy2, const void* w_dgrad2, int dtype, primia_stream_t stream,
+                             const LhBnArgs* bn = nullptr) {
     PRIMIA_REQUIRE(d && dy && w_dgrad && dx);
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
@@ -678,9 +676,10 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         } else if (lh_shape(g) && !p.src2) {
             const int rc = conv3x3_lh_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C, 1,
-                                               accumulate, st);
+                                               accumulate, st, nullptr, bn);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         }
+        if (bn) return PRIMIA_ERR_UNSUPPORTED;   // only the linear-halo kernel emits the sums
         p.nsteps = p.klen / 64;
         return dispatch_igemm<bf16, true>(p, false, st);
     }
@@ -690,6 +689,24 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
 int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                         int accumulate, int dtype, primia_stream_t stream) {
     return conv2d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, dtype, stream);
+}
+
+int primia_conv_dgrad_bnsum_slots(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
+    if (dtype != PRIMIA_BF16 || use_c64(g) || !lh_shape(g)) return 0;
+    const int t = conv3x3_lh_tiles_m(g.N, g.H, g.W, g.K, g.C);
+    return t > 0 ? t : 0;
+}
+
+int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
+                               const void* bn_y, const uint8_t* relu_mask, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, float* sums, int dtype,
+                               primia_stream_t stream) {
+    PRIMIA_REQUIRE(bn_y && gamma && save_mean && save_invstd && sums && (relu_mask || beta));
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
+    LhBnArgs bn{bn_y, relu_mask, gamma, beta, save_mean, save_invstd, sums};
+    return conv2d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, dtype, stream, &bn);
 }
 
 int primia_conv2d_dgrad_pair(const primia_conv_desc* d, const void* dy, const void* w_dgrad,

@@ -208,6 +208,24 @@ class ResNet18Engine:
                 elif self._atomic_stats_from is not None:
                     raise _lib.PrimiaError("PRIMIA_ATOMIC_STATS must name a suffix of the network's stages")
                 off += per(c)
+        # BatchNorm backward sums formed by the data-gradient kernel that produces the BatchNorm's input gradient
+        # (primia_conv2d_dgrad_bnsums; layer2-4's 3x3 / stride-1 convs): bn1 of a block is fed by its conv2's data
+        # gradient, bn2 of a block by the (accumulating) conv1 data gradient of the identity block after it.
+        # Measured on MI355X at batch 256 it LOSES (6.375 -> 6.449 ms per step: the 9 write-backs get a dependent read
+        # of y and ~400 VALU per thread on a CU that holds one block, which costs more than the 9 streaming reduction
+        # passes it removes), so it is opt-in: PRIMIA_BWD_SUMS=1.
+        self.bwd_sums, self._bwd_sums_ready = {}, set()
+        if dtype == torch.bfloat16 and norm == "batch" and os.environ.get("PRIMIA_BWD_SUMS", "0") == "1":
+            blks = self.spec.blocks
+            for i, blk in enumerate(blks):
+                feeders = [(blk.conv1, blk.conv2)]
+                if i + 1 < len(blks) and blks[i + 1].down is None:
+                    feeders.append((blk.conv2, blks[i + 1].conv1))
+                for consumer, producer in feeders:
+                    slots = query("primia_conv_dgrad_bnsum_slots", self.convs[producer.name].desc, self.dt)
+                    if slots > 0:
+                        self.bwd_sums[bn_name(consumer.name)] = torch.zeros(slots, 2, consumer.cout, dtype=torch.float32,
+                                                                            device=dev)
         self.save = {}
         for c in self.spec.convs:
             b = bn_name(c.name)
@@ -475,6 +493,14 @@ class ResNet18Engine:
                 call("primia_weighted_colsum", psg, self.ones_n, self.gviews[b + ".weight"], self.N, C)
                 call("primia_weighted_colsum", psb, self.ones_n, self.gviews[b + ".bias"], self.N, C)
             return
+        if b in self._bwd_sums_ready:   # both reductions came out of the data-gradient kernel's write-back
+            self._bwd_sums_ready.discard(b)
+            mask = self.relu_masks[b] if g_out is not None else None
+            sums = self.bwd_sums[b]
+            call("primia_bn_bwd_from_sums", y, mask, dz, dy, g_out, self.views[b + ".weight"], self.views[b + ".bias"],
+                 sm, si, self.gviews[b + ".weight"], self.gviews[b + ".bias"], sums, sums.shape[0], y.shape[0],
+                 y.shape[1], self.dt)
+            return
         if relu and g_out is not None and b in self.relu_masks:
             call("primia_bn_bwd_mask", y, self.relu_masks[b], dz, dy, g_out, self.views[b + ".weight"], sm, si,
                  self.gviews[b + ".weight"], self.gviews[b + ".bias"], y.shape[0], y.shape[1], self.bn_ws,
@@ -525,9 +551,20 @@ class ResNet18Engine:
             torch.cuda.current_stream().wait_stream(self._wg_stream)
             self._wg_pending = False
 
-    def _dgrad(self, name, dy, dx, accumulate):
+    def _dgrad(self, name, dy, dx, accumulate, consumer=None, consumer_y=None):
+        """Data gradient of conv `name` into dx.  `consumer`: the conv whose BatchNorm (+ReLU) backward reads dx next;
+        where the kernel can, it also forms that BatchNorm's two reductions (see bwd_sums)."""
         c = self.convs[name]
         self._join_wgrad_stream()   # (overlap mode) two MFMA-bound kernels never run side by side
+        b = bn_name(consumer) if consumer is not None else None
+        if b is not None and b in self.bwd_sums and self.training and (not accumulate or b in self.relu_masks):
+            sm, si = self.save[b]
+            mask = self.relu_masks[b] if accumulate else None   # bn2 (residual, mask bits) / bn1 (mask from y)
+            self._timed("dgrad", c, lambda: call("primia_conv2d_dgrad_bnsums", c.desc, dy, c.w_dgrad, dx, int(accumulate),
+                                                 consumer_y, mask, self.views[b + ".weight"], self.views[b + ".bias"], sm,
+                                                 si, self.bwd_sums[b], self.dt))
+            self._bwd_sums_ready.add(b)
+            return
         self._timed("dgrad", c,
                     lambda: call("primia_conv2d_dgrad", c.desc, dy, c.w_dgrad, dx, int(accumulate), self.dt))
 
@@ -554,7 +591,7 @@ class ResNet18Engine:
             # bn2 (+residual, relu): dy2, and the masked gradient g written back over dout
             self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True)
             # data gradient first: the weight gradient (a leaf) then runs beside the BatchNorm chain that follows
-            self._dgrad(blk.conv2.name, t[p + ".dy2"], t[p + ".da1"], False)
+            self._dgrad(blk.conv2.name, t[p + ".dy2"], t[p + ".da1"], False, blk.conv1.name, t[p + ".y1"])
             self._wgrad(blk.conv2.name, t[p + ".a1"], t[p + ".dy2"])
             self._bn_bwd(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], t[p + ".da1"], t[p + ".dy1"], None, True)
             if blk.down is not None and self.pair_dgrad:
@@ -575,7 +612,11 @@ class ResNet18Engine:
                 self._wgrad(blk.down.name, x_in, t[p + ".dyd"])
             else:
                 # identity skip: dx_in aliases dout, which now holds the masked gradient g
-                self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, True)
+                if i > 0:
+                    self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, True, blocks[i - 1].conv2.name,
+                                t[blocks[i - 1].prefix + ".y2"])
+                else:
+                    self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, True)
                 self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
         hw = self.stem_hw
         if self._stem_fused:

@@ -739,3 +739,60 @@ def test_conv_dgrad_pair_matches_two_passes(cuda, dtype, N, H, C, K):
     # argument checks: the second descriptor must be the 1x1/2 sibling of the first
     with pytest.raises(_lib.PrimiaError):
         call("primia_conv2d_dgrad_pair", d1, dy1d, w1d, d1, dydd, wdd, dx, dt)
+
+
+@pytest.mark.parametrize("N,H,C,K,acc", [(2, 28, 128, 128, 0), (4, 14, 256, 256, 1), (5, 7, 512, 512, 0), (3, 10, 128, 256, 1)])
+def test_dgrad_emits_batchnorm_backward_sums(cuda, N, H, C, K, acc):
+    """primia_conv2d_dgrad_bnsums + primia_bn_bwd_from_sums == primia_conv2d_dgrad + the BatchNorm backward with its
+    own reduction pass: dx bit-identical, dy / dgamma / dbeta equal up to the summation order.  acc = 0: bn1 form
+    (ReLU mask recomputed from y); acc = 1: bn2 form (accumulating data gradient, 1-bit mask from the forward pass)."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(7 * H + C)
+    desc = ConvDesc.make(N, H, H, C, K, 3, 3, 1, 1)
+    slots = query("primia_conv_dgrad_bnsum_slots", desc, dt)
+    M = N * H * H
+    assert slots == (M + 255) // 256
+    w = rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype)
+    _, wd = prep_weights(desc, w, dtype, cuda, C)
+    dyc = to_nhwc(rnd(torch.randn(N, K, H, H, generator=g), dtype), dtype, cuda)          # gradient entering the conv
+    y = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * 1.5 + 0.3, dtype), dtype, cuda)  # the BatchNorm's input
+    base = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(cuda), (torch.randn(C, generator=g) * 0.3).to(cuda)
+    ws_bytes = query("primia_bn_workspace_bytes", M, C)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
+    rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+    sm, si, z = torch.empty(C, device=cuda), torch.empty(C, device=cuda), torch.empty_like(y)
+    mask = torch.empty(M * C // 8, dtype=torch.uint8, device=cuda)
+    if acc:   # residual form: z = relu(bn(y) + res), mask bits written by the forward pass
+        res = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
+        call("primia_bn_fwd_train_mask", y, res, z, mask, gamma, beta, rm, rv, sm, si, None, 0, M, C, 1e-5, 0.1, ws,
+             ws_bytes, dt)
+    else:
+        call("primia_bn_fwd_train", y, None, z, gamma, beta, rm, rv, sm, si, M, C, 1e-5, 0.1, 1, ws, ws_bytes, dt)
+
+    def run(fused):
+        dx = base.clone() if acc else torch.empty_like(base)
+        dyb, gout = torch.empty_like(y), (torch.empty_like(y) if acc else None)
+        dga, dbe = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+        if fused:
+            sums = torch.full((slots, 2, C), float("nan"), device=cuda)
+            call("primia_conv2d_dgrad_bnsums", desc, dyc, wd, dx, acc, y, mask if acc else None, gamma, beta, sm, si, sums, dt)
+            call("primia_bn_bwd_from_sums", y, mask if acc else None, dx, dyb, gout, gamma, beta, sm, si, dga, dbe, sums,
+                 slots, M, C, dt)
+        else:
+            call("primia_conv2d_dgrad", desc, dyc, wd, dx, acc, dt)
+            if acc:
+                call("primia_bn_bwd_mask", y, mask, dx, dyb, gout, gamma, sm, si, dga, dbe, M, C, ws, ws_bytes, dt)
+            else:
+                call("primia_bn_relu_bwd", y, dx, dyb, gamma, beta, sm, si, dga, dbe, M, C, ws, ws_bytes, dt)
+        return dx, dyb, gout, dga, dbe
+
+    a, b = run(False), run(True)
+    assert torch.equal(a[0], b[0])
+    if acc:
+        assert torch.equal(a[2], b[2])
+    assert relerr(b[3], a[3]) < 1e-4 and relerr(b[4], a[4]) < 1e-4
+    assert relerr(b[1], a[1]) < 1e-3   # bf16 outputs: a 1-ulp flip where the sums differ in the last bits
+    c = run(True)
+    assert all(torch.equal(u, v) for u, v in zip(b, c) if u is not None)
