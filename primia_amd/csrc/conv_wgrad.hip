@@ -258,7 +258,8 @@ static int launch_wgrad(WgradParams p, hipStream_t st) {
     p.nct = STEM ? 1 : p.C / BNC;
     const int combos = p.ntaps * p.nkt * p.nct;
     // enough blocks to fill 256 CUs a few times over, but at least 8 steps per block
-    long want = (4 * 256 + combos - 1) / combos;
+    static const int target_blocks = getenv("PRIMIA_WGT_BLOCKS") ? atoi(getenv("PRIMIA_WGT_BLOCKS")) : 4 * 256;
+    long want = (target_blocks + combos - 1) / combos;
     long max_split = (p.Md + 8 * KP - 1) / (8 * KP);
     if (want > max_split) want = max_split;
     if (want < 1) want = 1;
@@ -572,7 +573,9 @@ static int launch_wgrad_dma(WgradParams p, hipStream_t st) {
     p.nkt = p.K / BMK;
     p.nct = p.C / BNC;
     const int combos = p.ntaps * p.nkt * p.nct;
-    static const int target_blocks = getenv("PRIMIA_WG_BLOCKS") ? atoi(getenv("PRIMIA_WG_BLOCKS")) : 1024;
+    // Blocks of one launch: ONE round at two resident blocks per CU.  Every block ends with BMK x BNC fp32 atomics, so
+    // fewer, longer blocks halve that traffic too (1024 -> 504: layer3.0.conv1 100 -> 84 us, layer4.0.conv1 97 -> 83).
+    static const int target_blocks = getenv("PRIMIA_WG_BLOCKS") ? atoi(getenv("PRIMIA_WG_BLOCKS")) : 504;
     long want = (target_blocks + combos - 1) / combos;
     long max_split = (p.Md + 8 * KP - 1) / (8 * KP);
     if (want > max_split) want = max_split;
