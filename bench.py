@@ -113,14 +113,21 @@ def main():
     scratch = torch.empty(eng.flat.numel(), dtype=torch.int64, device=dev) if a.secure_aggregation else None
     lr, wd = 1e-4, 5e-4
 
-    def step(i):
+    def local_step(i):
         eng.forward(xs[i % nbuf])
         eng.loss_backward(ys[i % nbuf])
         eng.sgd_step(lr, wd)
+
+    def exchange(i):
+        """FedAvg over RCCL every `sync_every` batches (torchlib/utils.py:1175: batch_idx > 0 and batch_idx % s == 0)."""
         if world > 1 and i > 0 and i % a.sync_every == 0:
             fed.fedavg_allreduce(eng.flat, local_flat, None, a.secure_aggregation, 16, 10, None, None, scratch)
             eng.flat.copy_(local_flat)
             eng.refresh_weights()
+
+    def step(i):
+        local_step(i)
+        exchange(i)
 
     def barrier():
         if world > 1:
@@ -129,21 +136,37 @@ def main():
 
     if a.dp:
         a.no_graph = True  # the DP step draws its noise through torch's generator: launch it eagerly
-    # The step is ~190 kernel launches; replaying it as a hipGraph (one per input buffer) removes the
-    # host launch cost from the launch-bound stretches (BN finalize, weight refresh).  Single-GPU
-    # only: the FedAvg all-reduce stays outside graphs.
+    # The local step is ~190 kernel launches; replaying it as a hipGraph (one per input buffer) removes the host
+    # launch cost (7.5 -> 6.3 ms per step).  Only the client-local step is captured: the FedAvg exchange — the one
+    # collective of the path — is launched between replays, so every rank count runs the same graphs.
     graphs = None
-    if not a.no_graph and world == 1:
+    if not a.no_graph:
         for i in range(2):
-            step(i)
-        torch.cuda.synchronize()
+            local_step(i)
+        barrier()
         graphs = []
-        for b in range(nbuf):
-            gph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gph):
-                step(b)
-            graphs.append(gph)
-        run = lambda i: graphs[i % nbuf].replay()
+        try:
+            for b in range(nbuf):
+                gph = torch.cuda.CUDAGraph()
+                # thread_local: the process group's watchdog thread may touch the runtime while this thread captures
+                with torch.cuda.graph(gph, capture_error_mode="thread_local"):
+                    local_step(b)
+                graphs.append(gph)
+        except Exception as e:  # noqa: BLE001 - a rank that cannot capture still measures, launch by launch
+            print(f"[bench] rank {rank}: graph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr)
+            graphs = None
+            torch.cuda.synchronize()
+        if world > 1:
+            # every rank must run the same way (a graph rank would wait for an eager one at each exchange anyway)
+            ok = torch.tensor([1 if graphs is not None else 0], device=dev)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if ok.item() == 0:
+                graphs = None
+
+    if graphs is not None:
+        def run(i):
+            graphs[i % nbuf].replay()
+            exchange(i)
     else:
         run = step
 
@@ -165,12 +188,12 @@ def main():
     # One untimed eager step first (the timed region replays graphs), then `nprof` profiled steps.  A launch's
     # duration is the MEDIAN over the profiled steps: the events bracket the host-side call too, so a host hiccup
     # between the two records (GC, a page fault) would otherwise be booked as kernel time.
-    step(0)
+    local_step(0)
     torch.cuda.synchronize()
     eng.prof = []
     nprof = 5
     for i in range(nprof):
-        step(i)
+        local_step(i)
     torch.cuda.synchronize()
     # Launches are grouped by the kernel that serves them (the library's dispatch rules: conv_igemm.hip,
     # conv_wgrad.hip) so that every group's average duration can be checked against the rocprofv3

@@ -161,4 +161,5 @@ def test_bench_two_ranks_control_flow(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["clients"] == 2
+    assert d["hip_graph"] is True   # the local step is replayed as a graph at every rank count, the exchange is not
     assert d["value"] > 0 and abs(d["value"] - 2 * d["images_per_sec_per_client"]) < 1e-3 * d["value"]
