@@ -4,11 +4,11 @@
 // The generic implicit GEMM (conv_igemm.hip) re-stages a 128-pixel activation tile for every one
 // of the 9 taps: each activation travels L2 -> LDS nine times and the K = 64 tile leaves only 2x2
 // fragments per wave.  For C = K = 64 the whole filter (64 x 576 bf16 = 72 KiB) fits in the
-// REGISTERS of one 8-wave block:
-//     wave (kh, pq):  out-channels 32*kh .. +31  x  all 576 reduction elements  = 144 VGPRs
+// REGISTERS of one block (4 waves; two such blocks share a CU):
+//     wave (kh, ph):  out-channels 32*kh .. +31  x  all 576 reduction elements  = 144 VGPRs
 // so the block is persistent, loads its weights once, and then streams 8x8 output patches:
 //     stage  : the patch's 10x10 halo x 64 channels (12.5 KiB) by LDS-DMA, ONCE for all 9 taps
-//     compute: wave (kh, pq) owns patch rows 2*pq, 2*pq+1 (16 pixels = one MFMA column block);
+//     compute: wave (kh, ph) owns patch rows 4*ph .. 4*ph+3 (two 16-pixel MFMA column blocks);
 //              per tap and channel half ONE ds_read_b128 feeds two MFMAs (A = weights in registers)
 //     store  : 4 consecutive out-channels per lane, straight from the accumulators.
 // L2 -> LDS traffic is 1.56x the activation tensor instead of 9x, LDS reads are 1 per 2 MFMAs and
@@ -49,31 +49,36 @@ struct C64Params {
     int accumulate;   // dst += result
     int PH, PW, PPI;  // 8x8 patches per image column / row / image
     int total;        // patches overall
-    int per_block;    // patches per block (even)
+    int per_block;    // patches per block
     float* stat_partials;  // if set: per-block BatchNorm partial sums [grid][2][64] of the values AS STORED
     int debug;        // timing experiments only (PRIMIA_C64_DEBUG): 1 no stores, 2 no staging, 4 no MFMA loop
 };
 
+// Block = 4 waves (256 threads), TWO blocks per CU: the two waves of a SIMD belong to different blocks, so they are
+// never in the same phase — one block's barrier, write-back, DMA issue and first-fragment latency run beside the other
+// block's MFMAs.  (The 8-wave form ran every wave of the CU through those phases in lockstep: with staging and stores
+// switched off it still took 60 us for 32 us worth of MFMAs.)  Wave (kh, ph): out-channels 32*kh..+31, patch rows
+// 4*ph..4*ph+3 = two 16-pixel MFMA column blocks q = 0, 1; one 8x8 patch per stage.
 template <bool ACC>
-__global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(C64Params p) {
     constexpr int STAGES = 3;
     constexpr int HALO = 13 * 1024;        // 100 slots used, 104 staged (13 DMA instructions)
-    constexpr int STAGE = 2 * HALO;        // two patches per stage
-    // output rows of one stage: 2 patches x 64 pixels x 64 channels, bf16 — or fp32 in the accumulate form, which
-    // adds the old values in the write-back phase (coalesced row loads, fp32 add, ONE rounding)
+    constexpr int STAGE = HALO;            // one patch per stage
+    // output rows of one stage: 64 pixels x 64 channels, bf16 — or fp32 in the accumulate form, which adds the old
+    // values in the write-back phase (coalesced row loads, fp32 add, ONE rounding)
     constexpr int OPIX = ACC ? 256 : 128;  // bytes per staged pixel row
-    constexpr int OUTB = 2 * 64 * OPIX;
+    constexpr int OUTB = 64 * OPIX;
     extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE + 2 * OUTB
     char* const sout = smem + STAGES * STAGE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int kh = wave >> 2, pq = wave & 3;
+    const int kh = wave >> 1, ph = wave & 1;
     const int fr = lane & 15, fg = lane >> 4;
 
     const int t0 = blockIdx.x * p.per_block;
     int t1 = t0 + p.per_block;
     if (t1 > p.total) t1 = p.total;
-    const int nstages = (t1 - t0 + 1) >> 1;
+    const int nstages = t1 - t0;
     if (nstages <= 0) return;
 
     // ---- weights -> registers: A fragment (i, j): row 32*kh + 16*i + fr, elements j*32 + 8*fg .. +7 -------
@@ -111,47 +116,41 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     };
     Cursor cs = make_cursor(t0), cw = make_cursor(t0);  // staging / write-back
 
-    // ---- staging: 26 DMA instructions per stage (2 patches x 13), round-robin over the 8 waves -----------
+    // ---- staging: 13 DMA instructions per stage, round-robin over the 4 waves (wave 0 issues 4, the others 3) ----
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     auto stage = [&](int buf) {
-        int rb[2], cb[2], pixbase[2];
-        bool live[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            live[q] = cs.t < t1;
-            rb[q] = cs.ph * 8;
-            cb[q] = cs.pw * 8;
-            pixbase[q] = (cs.n * p.H + rb[q]) * p.W + cb[q];
-            advance(cs);
-        }
+        const bool live = cs.t < t1;
+        const int rb = cs.ph * 8, cb = cs.pw * 8;
+        const int pixbase = (cs.n * p.H + rb) * p.W + cb;
+        advance(cs);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int idx = wave + 8 * it;  // wave-uniform
-            if (idx >= 26) break;
-            const int q = idx >= 13;
-            const int slot = (idx - 13 * q) * 8 + (lane >> 3);
+            const int idx = wave + 4 * it;  // wave-uniform
+            if (idx >= 13) break;
+            const int slot = idx * 8 + (lane >> 3);
             const int hy = slot / 10, hx = slot - hy * 10;
             const int chunk = (lane & 7) ^ c64_key(slot);
-            const int row = rb[q] + hy - 1, col = cb[q] + hx - 1;
-            const bool ok = live[q] && slot < 100 && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
-            const bf16* g = ok ? p.src + ((pixbase[q] + (hy - 1) * p.W + (hx - 1)) * 64 + chunk * 8)
+            const int row = rb + hy - 1, col = cb + hx - 1;
+            const bool ok = live && slot < 100 && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
+            const bf16* g = ok ? p.src + ((pixbase + (hy - 1) * p.W + (hx - 1)) * 64 + chunk * 8)
                                : (const bf16*)kC64ZeroPage;
             c64_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + idx * 1024));
         }
     };
 
-    // ---- per-lane LDS offsets of the B fragments: pixel (2*pq + (fr >> 3), fr & 7), tap shift, chunk fg ----
+    // ---- per-lane LDS offsets of the B fragments: column block q: pixel (4*ph + 2*q + (fr >> 3), fr & 7) --------
+    // (column block 1 is two halo rows = 20 slots further: the key table has period 20 slots, so its offsets are
+    // those of block 0 + 2560 bytes — an immediate, not nine more registers)
     int offb[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
         const int r = t / 3, s = t - 3 * r;
         const int rr = p.flip ? 2 - r : r, ss = p.flip ? 2 - s : s;
-        const int slot = (2 * pq + (fr >> 3) + rr) * 10 + (fr & 7) + ss;
+        const int slot = (4 * ph + (fr >> 3) + rr) * 10 + (fr & 7) + ss;
         offb[t] = slot * 128 + ((fg ^ c64_key(slot)) << 4);   // channel half 1: offb ^ 64
     }
-    // output staging: pixel opix = 16*pq + fr of the patch, 8-byte column 8*kh + 4*i + fg of its 128-B row,
+    // output staging: pixel opix = 32*ph + 16*q + fr of the patch, 8-byte column 8*kh + 4*i + fg of its 128-B row,
     // stored at 16-B chunk (col >> 1) ^ ((opix >> 1) & 7): conflict-free ds_write_b64 / ds_read_b128
-    const int opix = 16 * pq + fr;
 
     auto compute = [&](int buf, int obuf) {
         const char* sb = smem + buf * STAGE;
@@ -163,9 +162,10 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
         // B fragments: 3-deep register ring, reads run two steps ahead of the MFMAs that consume them
         bf16x8_t bq[3][2];
         auto rd = [&](int step, int slot) {
-            const int o = offb[step >> 1] ^ ((step & 1) * 64);
-            bq[slot][0] = *(const bf16x8_t*)(sb + o);
-            bq[slot][1] = *(const bf16x8_t*)(sb + HALO + o);
+            const int x = (step & 1) * 64;
+            const char* q0 = sb + (offb[step >> 1] ^ x);
+            bq[slot][0] = *(const bf16x8_t*)q0;
+            bq[slot][1] = *(const bf16x8_t*)(q0 + 20 * 128);
         };
         if (!(p.debug & 4)) {
             rd(0, 0);
@@ -184,23 +184,24 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
         // ---- results -> LDS rows (bf16; fp32 for the accumulate form) ---------------------------------------
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            const int opix = 32 * ph + 16 * q + fr;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int col = 8 * kh + 4 * i + fg;   // 4-channel column of the pixel's row
                 if constexpr (ACC) {
                     // 16-byte fp32 chunks, chunk index swizzled with the pixel: conflict-free ds_write_b128
-                    *(f32x4*)(sout + obuf * OUTB + q * 64 * OPIX + opix * OPIX + ((col ^ (opix & 15)) << 4)) = acc[q][i];
+                    *(f32x4*)(sout + obuf * OUTB + opix * OPIX + ((col ^ (opix & 15)) << 4)) = acc[q][i];
                 } else {
                     u32x2 o;
                     o[0] = (uint32_t)f32_to_bf16(acc[q][i][0]) | ((uint32_t)f32_to_bf16(acc[q][i][1]) << 16);
                     o[1] = (uint32_t)f32_to_bf16(acc[q][i][2]) | ((uint32_t)f32_to_bf16(acc[q][i][3]) << 16);
-                    *(u32x2*)(sout + obuf * OUTB + q * 8192 + opix * 128 + ((((col >> 1) ^ ((opix >> 1) & 7)) << 4) | ((col & 1) << 3))) = o;
+                    *(u32x2*)(sout + obuf * OUTB + opix * 128 + ((((col >> 1) ^ ((opix >> 1) & 7)) << 4) | ((col & 1) << 3))) = o;
                 }
             }
         }
     };
 
-    // write-back of one stage's rows: 16 row groups (8 pixels x 128 B = 1 KiB contiguous in memory), 2 per wave
+    // write-back of one stage's rows: 8 row groups (8 pixels x 128 B = 1 KiB contiguous in memory), 2 per wave
     // BatchNorm batch statistics of the NEXT layer, for free: the write-back lane holds 8 stored channels of one
     // pixel; per-lane fp32 sums over the block's pixels, combined per block at the end (deterministic), replace
     // a full read pass over the output (primia_bn_fwd_train_from_sums consumes the per-block partials).
@@ -209,28 +210,28 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.f;
 
     auto writeback = [&](int obuf) {
-        const int g = wave;                        // patch row handled by this wave
         const int px = lane >> 3, c16 = lane & 7;  // pixel of the row, 16-B chunk
-        const int opx2 = g * 8 + px;
         bool live[2];
         bf16* gp[2];
         u32x4 old[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            const int g = 2 * wave + q;                // patch row handled by this wave
             const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
             live[q] = cw.t < t1 && ho < p.H && wo < p.W;
             gp[q] = p.dst + ((long)(cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8;
-            advance(cw);
             // accumulate form: both old rows are requested before anything is stored — a load waited for AFTER a
             // store would also wait for that store to complete (one vmcnt for both)
             old[q] = u32x4{0, 0, 0, 0};
             if (ACC && live[q]) old[q] = *(const u32x4*)gp[q];
         }
+        advance(cw);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
+            const int opx2 = (2 * wave + q) * 8 + px;
             u32x4 v;
             if constexpr (ACC) {
-                const char* row = sout + obuf * OUTB + q * 64 * OPIX + opx2 * OPIX;
+                const char* row = sout + obuf * OUTB + opx2 * OPIX;
                 const f32x4 lo = *(const f32x4*)(row + (((2 * c16) ^ (opx2 & 15)) << 4));
                 const f32x4 hi = *(const f32x4*)(row + (((2 * c16 + 1) ^ (opx2 & 15)) << 4));
                 float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
                     v[k] = (uint32_t)f32_to_bf16(f[2 * k]) | ((uint32_t)f32_to_bf16(f[2 * k + 1]) << 16);
                 }
             } else {
-                v = *(const u32x4*)(sout + obuf * OUTB + q * 8192 + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
+                v = *(const u32x4*)(sout + obuf * OUTB + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
             }
             if (live[q] && !((p.debug & 1) && v[0] != 12345u)) {
                 *(u32x4*)gp[q] = v;
@@ -261,7 +262,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
 
     // STAGES-deep LDS ring, one raw barrier per stage, counted vmcnt.  vmcnt counts stores too; per iteration a
     // wave issues, in this order, 2 row stores (write-back of the previous stage) and d DMA instructions
-    // (d = 4 for waves 0,1, else 3).  At the top of iteration s the operations newer than DMA(s) are the row
+    // (d = 4 for wave 0, else 3).  At the top of iteration s the operations newer than DMA(s) are the row
     // stores of iteration s-1 (for s >= 2) and DMA(s+1): DMA(s) has landed once at most those remain in
     // flight.  Ragged images (a row store may be fully masked), the accumulate form (its loads are waited
     // for by the compiler, conservatively) and the last stage use vmcnt(0).
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     int cur = 0, nxt = STAGES - 1;
     for (int s = 0; s < nstages; ++s) {
         if (exact && s + 1 < nstages) {
-            if (wave < 2) {
+            if (wave == 0) {
                 if (s >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             } else {
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
     __syncthreads();
     writeback((nstages - 1) & 1);
     if (p.stat_partials) {
-        // lanes with equal (lane & 7) hold the same 8 channels: fold the 8 pixel lanes, then the 8 waves
+        // lanes with equal (lane & 7) hold the same 8 channels: fold the 8 pixel lanes, then the 4 waves
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
 #pragma unroll
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
             }
         }
         __syncthreads();
-        float* red = (float*)smem;  // [8 waves][2][64]
+        float* red = (float*)smem;  // [4 waves][2][64]
         if (lane < 8) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) {
@@ -314,7 +315,7 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
         if (tid < 128) {
             float a = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; ++w) a += red[w * 128 + tid];
+            for (int w = 0; w < 4; ++w) a += red[w * 128 + tid];
             p.stat_partials[(long)blockIdx.x * 128 + tid] = a;   // [block][2][64]
         }
     }
@@ -323,10 +324,9 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(C64Params p) {
 // returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the implicit GEMM)
 int conv3x3_c64_grid(int N, int H, int W) {
     const long total = (long)N * ((H + 7) / 8) * ((W + 7) / 8);
-    static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 256;
+    static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 512;
     long per = (total + target - 1) / target;
-    per = (per + 1) & ~1L;
-    if (per < 2) per = 2;
+    if (per < 1) per = 1;
     return (int)((total + per - 1) / per);
 }
 
@@ -339,18 +339,17 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     p.stat_partials = stat_partials;
     p.PH = (H + 7) / 8; p.PW = (W + 7) / 8; p.PPI = p.PH * p.PW;
     p.total = N * p.PPI;
-    static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 256;
+    static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 512;   // 2 per CU
     long per = (p.total + target - 1) / target;
-    per = (per + 1) & ~1L;
-    if (per < 2) per = 2;
+    if (per < 1) per = 1;
     p.per_block = (int)per;
     static const int dbg = getenv("PRIMIA_C64_DEBUG") ? atoi(getenv("PRIMIA_C64_DEBUG")) : 0;
     p.debug = dbg;
     const int grid = (int)((p.total + per - 1) / per);
-    const size_t lds = (size_t)3 * 2 * 13 * 1024 + 2 * 2 * 64 * (accumulate ? 256 : 128);
+    const size_t lds = (size_t)3 * 13 * 1024 + 2 * 64 * (accumulate ? 256 : 128);
     static bool attr_set = false;
     if (!attr_set) {
-        const int lds_plain = 3 * 2 * 13 * 1024 + 2 * 2 * 64 * 128, lds_acc = 3 * 2 * 13 * 1024 + 2 * 2 * 64 * 256;
+        const int lds_plain = 3 * 13 * 1024 + 2 * 64 * 128, lds_acc = 3 * 13 * 1024 + 2 * 64 * 256;
         if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_plain) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -359,9 +358,9 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
         attr_set = true;
     }
     if (accumulate)
-        conv3x3_c64_kernel<true><<<grid, 512, lds, st>>>(p);
+        conv3x3_c64_kernel<true><<<grid, 256, lds, st>>>(p);
     else
-        conv3x3_c64_kernel<false><<<grid, 512, lds, st>>>(p);
+        conv3x3_c64_kernel<false><<<grid, 256, lds, st>>>(p);
     return launch_status();
 }
 
