@@ -118,6 +118,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- staging: 13 DMA instructions per stage, round-robin over the 4 waves (wave 0 issues 4, the others 3) ----
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // per-lane constants of this wave's (up to 4) DMA instructions, packed: halo row / column of the lane's slot (4 bits
+    // each) and its swizzled source chunk (3 bits) — the division by 10 and the key lookup happen once, not per stage
+    unsigned hyx = 0, chk = 0;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int slot = (wave + 4 * it) * 8 + (lane >> 3);
+        const int hy = slot / 10, hx = slot - hy * 10;       // hy >= 10: pad slot (never valid)
+        hyx |= (unsigned)((hy > 15 ? 15 : hy) | (hx << 4)) << (8 * it);
+        chk |= (unsigned)((lane & 7) ^ c64_key(slot)) << (4 * it);
+    }
     auto stage = [&](int buf) {
         const bool live = cs.t < t1;
         const int rb = cs.ph * 8, cb = cs.pw * 8;
@@ -127,11 +137,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int it = 0; it < 4; ++it) {
             const int idx = wave + 4 * it;  // wave-uniform
             if (idx >= 13) break;
-            const int slot = idx * 8 + (lane >> 3);
-            const int hy = slot / 10, hx = slot - hy * 10;
-            const int chunk = (lane & 7) ^ c64_key(slot);
+            const int hy = (hyx >> (8 * it)) & 15, hx = (hyx >> (8 * it + 4)) & 15;
+            const int chunk = (chk >> (4 * it)) & 7;
             const int row = rb + hy - 1, col = cb + hx - 1;
-            const bool ok = live && slot < 100 && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
+            const bool ok = live && hy < 10 && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
             const bf16* g = ok ? p.src + ((pixbase + (hy - 1) * p.W + (hx - 1)) * 64 + chunk * 8)
                                : (const bf16*)kC64ZeroPage;
             c64_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + idx * 1024));
