@@ -109,6 +109,11 @@ int primia_stem_conv_fwd_stats(const void* x_padded, const void* w_fwd, void* y,
 /* Weight gradient of conv1 from the same padded input (accumulates into dw_acc like primia_conv2d_wgrad). */
 int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, int N, int H, int W, int dtype,
                            primia_stream_t stream);
+/* ... without atomics (see primia_conv2d_wgrad_ws): workspace from primia_stem_conv_wgrad_ws_bytes (0: this shape
+ * takes the accumulate path, dw_acc must then be zeroed by the caller as for primia_stem_conv_wgrad). */
+int64_t primia_stem_conv_wgrad_ws_bytes(int N, int H, int W);
+int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_acc, void* ws, int64_t ws_bytes, int N,
+                              int H, int W, int dtype, primia_stream_t stream);
 /* Same, and the per-channel sum / sum of squares of y (values as stored) — the batch statistics of the
  * BatchNorm that follows — are accumulated into stat_sums, laid out [slots][2][K] with
  * slots = primia_conv_stat_slots() partial sums (spread to keep atomics uncontended); caller zeroes it. */
@@ -145,11 +150,10 @@ int primia_conv2d_dgrad_pair(const primia_conv_desc* d, const void* dy, const vo
 /* dw_acc (fp32, fwd layout [K][R][Sp][C']) += sum over pixels.  Caller zeroes dw_acc first. */
 int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,
                         int dtype, primia_stream_t stream);
-/* The same weight gradient without atomics, where a layer has such a path (bf16 3x3 / stride-1 layers: every
- * kernel block stores its partial tile in `ws`, a second kernel adds the partials in a fixed order, so the
- * result is deterministic and, for those layers, OVERWRITES dw_acc).  primia_conv_wgrad_ws_bytes() gives the
- * workspace a layer needs (0: the layer takes the accumulate path of primia_conv2d_wgrad; < 0: bad
- * descriptor); with ws == NULL or ws_bytes too small the call is primia_conv2d_wgrad.  The reference has no
+/* The same weight gradient without atomics: every kernel block stores its partial tile in `ws`, a second kernel adds
+ * the partials in a fixed order, so the result is deterministic and OVERWRITES dw_acc (no zeroing needed).
+ * primia_conv_wgrad_ws_bytes() gives the workspace the layer needs (< 0: bad descriptor); with ws == NULL or
+ * ws_bytes too small the call is primia_conv2d_wgrad (accumulate into a zeroed dw_acc).  The reference has no
  * counterpart: torch's conv backward owns its workspace (torchlib/models.py:219-235 via autograd). */
 int64_t primia_conv_wgrad_ws_bytes(const primia_conv_desc* d, int dtype);
 int primia_conv2d_wgrad_ws(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,

@@ -269,12 +269,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    // STAGES-deep LDS ring, one raw barrier per stage, counted vmcnt.  vmcnt counts stores too; per iteration a
-    // wave issues, in this order, 2 row stores (write-back of the previous stage) and d DMA instructions
-    // (d = 4 for wave 0, else 3).  At the top of iteration s the operations newer than DMA(s) are the row
-    // stores of iteration s-1 (for s >= 2) and DMA(s+1): DMA(s) has landed once at most those remain in
-    // flight.  Ragged images (a row store may be fully masked), the accumulate form (its loads are waited
-    // for by the compiler, conservatively) and the last stage use vmcnt(0).
+    // STAGES-deep LDS ring, one raw barrier per stage, counted vmcnt.  Per iteration a wave issues, in this order,
+    // 2 row stores (write-back of the previous stage) and d DMA instructions (d = 4 for wave 0, else 3).  At the top
+    // of iteration s, DMA(s) has landed once at most the d instructions of DMA(s+1) remain in flight.  Ragged
+    // images, the accumulate form (its loads are waited for by the compiler, conservatively) and the last stage use
+    // vmcnt(0).
     const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !(p.debug & 3);
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -282,16 +281,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int cur = 0, nxt = STAGES - 1;
     for (int s = 0; s < nstages; ++s) {
         if (exact && s + 1 < nstages) {
-            if (wave == 0) {
-                if (s >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            } else {
-                if (s >= 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            }
+            // only DMA(s+1) may stay in flight.  (Counting the row stores of iteration s-1 in as well — vmcnt(d + 2) —
+            // is WRONG: stores and loads retire out of order with respect to each other, so two early store
+            // completions let the wave through with two pieces of DMA(s) still in flight.  Seen as run-to-run
+            // differences of the training loss once every other source of nondeterminism was gone.)
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        // the result rows this wave wrote to LDS in the previous iteration must have LANDED before the barrier lets
+        // the other waves read them (a raw s_barrier does not wait for the wave's own outstanding ds_write; with two
+        // blocks per CU competing for the LDS the write-back occasionally read a stale 1-KiB row)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (s > 0) writeback((s - 1) & 1);
         if (s + STAGES - 1 < nstages && !(p.debug & 2)) stage(nxt);

@@ -238,6 +238,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         wave_sqnorm_add(sq, p.sqnorm + split);
         return;
     }
+    if (p.ws) {
+        // atomic-free path: this block's BMK x BNC partial tile goes to ITS slot of the workspace, row-major
+        // [k_local][c_local]; wgrad_tile_reduce_kernel adds the slots of a (tap, kt, ct) tile in split order
+        float* o = p.ws + ((long)(((tap * p.nkt + kt) * p.nct + ct)) * p.nsplit + split) * (BMK * BNC);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    o[(ca0 + 16 * i + fg * 4 + r) * BNC + cb0 + 16 * j + fr] = acc[i][j][r];
+        return;
+    }
     const int ebase = STEM ? tr * 32 : tap * p.C + ct * BNC;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -251,9 +264,70 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
             }
 }
 
-template <typename T, int BMK, int BNC, bool STEM>
-static int launch_wgrad(WgradParams p, hipStream_t st) {
-    constexpr int KP = (sizeof(T) == 2) ? 64 : 32;
+// dw[kt*BMK + k][ebase(tap, ct) + c] = sum over splits of the partial tiles, in split order (deterministic).
+// Block = CL float4 chunks x SL split lanes (CL * SL = 256), as wgrad_patch_reduce_kernel.
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_tile_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                int nsplit, int BMK, int BNC, int nkt, int nct, int C,
+                                                                int klen, int stem) {
+    constexpr int CL = 256 / SL;
+    __shared__ f32x4 red[SL][CL];
+    const int tile4 = BMK * BNC / 4;                // float4 chunks per tile
+    const int cpb = (tile4 + CL - 1) / CL;          // blocks per tile
+    const int combo = blockIdx.x / cpb;
+    const int q = (blockIdx.x % cpb) * CL + (threadIdx.x % CL);
+    const int sl = threadIdx.x / CL;
+    const bool live = q < tile4;
+    const float* src = ws + (long)combo * nsplit * (BMK * BNC) + (live ? q : 0) * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+        int s = sl;
+#pragma unroll 1
+        for (; s + 3 * SL < nsplit; s += 4 * SL) {
+            const f32x4 v0 = *(const f32x4*)(src + (long)s * (BMK * BNC));
+            const f32x4 v1 = *(const f32x4*)(src + (long)(s + SL) * (BMK * BNC));
+            const f32x4 v2 = *(const f32x4*)(src + (long)(s + 2 * SL) * (BMK * BNC));
+            const f32x4 v3 = *(const f32x4*)(src + (long)(s + 3 * SL) * (BMK * BNC));
+            a += v0; a += v1; a += v2; a += v3;
+        }
+        for (; s < nsplit; s += SL) a += *(const f32x4*)(src + (long)s * (BMK * BNC));
+    }
+    if (SL > 1) {
+        red[sl][threadIdx.x % CL] = a;
+        __syncthreads();
+        if (sl != 0) return;
+#pragma unroll
+        for (int k = 1; k < SL; ++k) a += red[k][threadIdx.x % CL];
+    }
+    if (!live) return;
+    const int ct = combo % nct, kt = (combo / nct) % nkt, tap = combo / (nct * nkt);
+    const int kl = (q * 4) / BNC, cl = (q * 4) % BNC;
+    const int ebase = stem ? tap * 32 : tap * C + ct * BNC;
+    *(f32x4*)(dw + (long)(kt * BMK + kl) * klen + ebase + cl) = a;
+}
+
+void wgrad_tile_reduce(const float* ws, float* dw, int nsplit, int combos, int BMK, int BNC, int nkt, int nct, int C,
+                       int klen, int stem, hipStream_t st) {
+    const int tile4 = BMK * BNC / 4;
+    if (nsplit >= 32)
+        wgrad_tile_reduce_kernel<16><<<combos * ((tile4 + 15) / 16), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C,
+                                                                                 klen, stem);
+    else if (nsplit >= 4)
+        wgrad_tile_reduce_kernel<4><<<combos * ((tile4 + 63) / 64), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C,
+                                                                                klen, stem);
+    else
+        wgrad_tile_reduce_kernel<1><<<combos * ((tile4 + 255) / 256), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C,
+                                                                                  klen, stem);
+}
+
+static void launch_tile_reduce(const WgradParams& p, int BMK, int BNC, int stem, hipStream_t st) {
+    wgrad_tile_reduce(p.ws, p.dw, p.nsplit, p.ntaps * p.nkt * p.nct, BMK, BNC, p.nkt, p.nct, p.C, p.klen, stem, st);
+}
+
+// split geometry of the per-tap kernel (shared by the launcher and the workspace query)
+template <int ES, int BMK, int BNC, bool STEM>
+static void wgrad_geometry(WgradParams& p) {
+    constexpr int KP = (ES == 2) ? 64 : 32;
     p.nkt = p.K / BMK;
     p.nct = STEM ? 1 : p.C / BNC;
     const int combos = p.ntaps * p.nkt * p.nct;
@@ -269,6 +343,21 @@ static int launch_wgrad(WgradParams p, hipStream_t st) {
     p.pix_per_split = pps;
     p.nsplit = (int)((p.Md + pps - 1) / pps);
     p.split_stride = p.persample ? (long)p.K * p.klen : 0;
+}
+
+template <typename T, int BMK, int BNC, bool STEM>
+static size_t wgrad_ws_need(WgradParams p) {
+    wgrad_geometry<sizeof(T), BMK, BNC, STEM>(p);
+    return (size_t)p.ntaps * p.nkt * p.nct * p.nsplit * BMK * BNC * sizeof(float);
+}
+
+template <typename T, int BMK, int BNC, bool STEM>
+static int launch_wgrad(WgradParams p, hipStream_t st) {
+    constexpr int KP = (sizeof(T) == 2) ? 64 : 32;
+    wgrad_geometry<sizeof(T), BMK, BNC, STEM>(p);
+    const int combos = p.ntaps * p.nkt * p.nct;
+    const bool store = !p.persample && p.ws && p.ws_bytes >= (size_t)combos * p.nsplit * BMK * BNC * sizeof(float);
+    if (!store) p.ws = nullptr;
     const int grid = combos * p.nsplit;
     const size_t lds = 2 * KP * ((BMK + BNC) * sizeof(T) + 32);
     auto kern = conv_wgrad_kernel<T, BMK, BNC, STEM>;
@@ -279,6 +368,7 @@ static int launch_wgrad(WgradParams p, hipStream_t st) {
         attr_set = true;
     }
     kern<<<grid, 256, lds, st>>>(p);
+    if (store) launch_tile_reduce(p, BMK, BNC, STEM ? 1 : 0, st);
     return launch_status();
 }
 
@@ -290,8 +380,27 @@ static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const voi
                              int dtype, primia_stream_t stream, double* sqnorm = nullptr, float* ws = nullptr,
                              size_t ws_bytes = 0);
 
+static int stem_conv_wgrad_impl(const void* x_padded, const void* dy, float* dw_acc, float* ws, size_t ws_bytes, int N,
+                                int H, int W, int dtype, primia_stream_t stream);
+
 extern "C" int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, int N, int H, int W, int dtype,
                                       primia_stream_t stream) {
+    return stem_conv_wgrad_impl(x_padded, dy, dw_acc, nullptr, 0, N, H, W, dtype, stream);
+}
+
+extern "C" int64_t primia_stem_conv_wgrad_ws_bytes(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return PRIMIA_ERR_ARG;
+    return (int64_t)stem_wgrad_halo_ws_bytes(N, H, W);
+}
+
+extern "C" int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_acc, void* ws, int64_t ws_bytes,
+                                         int N, int H, int W, int dtype, primia_stream_t stream) {
+    return stem_conv_wgrad_impl(x_padded, dy, dw_acc, (float*)ws, ws_bytes > 0 ? (size_t)ws_bytes : 0, N, H, W, dtype,
+                                stream);
+}
+
+static int stem_conv_wgrad_impl(const void* x_padded, const void* dy, float* dw_acc, float* ws, size_t ws_bytes, int N,
+                                int H, int W, int dtype, primia_stream_t stream) {
     PRIMIA_REQUIRE(x_padded && dy && dw_acc && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0);
     WgradParams p;
     p.x = x_padded; p.dy = dy; p.dw = dw_acc;
@@ -307,7 +416,8 @@ extern "C" int primia_stem_conv_wgrad(const void* x_padded, const void* dy, floa
     p.ws = nullptr; p.ws_bytes = 0;
     if (dtype == PRIMIA_F32) return launch_wgrad<float, 64, 32, true>(p, (hipStream_t)stream);
     if (dtype == PRIMIA_BF16) {
-        const int rc = stem_wgrad_halo_dispatch((const bf16*)x_padded, (const bf16*)dy, dw_acc, N, H, W, (hipStream_t)stream);
+        const int rc = stem_wgrad_halo_dispatch((const bf16*)x_padded, (const bf16*)dy, dw_acc, N, H, W, (hipStream_t)stream,
+                                                ws, ws_bytes);
         if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         return launch_wgrad<bf16, 64, 32, true>(p, (hipStream_t)stream);
     }
@@ -338,8 +448,23 @@ extern "C" int64_t primia_conv_wgrad_ws_bytes(const primia_conv_desc* d, int dty
     WgradParams p;
     ConvGeom g;
     if (!fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
-    if (dtype != PRIMIA_BF16 || g.stem) return 0;
-    return (int64_t)wgrad_patch_ws_bytes(p);
+    // mirrors the kernel choice of conv2d_wgrad_impl below
+    if (dtype == PRIMIA_F32) {
+        if (g.stem) return (int64_t)wgrad_ws_need<float, 64, 32, true>(p);
+        if (g.K % 128 == 0 && g.C % 128 == 0) return (int64_t)wgrad_ws_need<float, 128, 128, false>(p);
+        return (int64_t)wgrad_ws_need<float, 64, 64, false>(p);
+    }
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_ARG;
+    static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    const bool dma = force == 'd' || (force != 'o' && (g.C >= 256 || (g.K >= 256 && g.C >= 128)));
+    if (!force && !g.stem) {
+        const size_t n = wgrad_patch_ws_bytes(p);
+        if (n > 0) return (int64_t)n;
+    }
+    if (!g.stem && dma) return (int64_t)wgrad_dma_ws_bytes(p);
+    if (g.stem) return (int64_t)wgrad_ws_need<bf16, 64, 32, true>(p);
+    if (g.K % 128 == 0 && g.C % 128 == 0) return (int64_t)wgrad_ws_need<bf16, 128, 128, false>(p);
+    return (int64_t)wgrad_ws_need<bf16, 64, 64, false>(p);
 }
 
 extern "C" int primia_conv2d_wgrad_ws(const primia_conv_desc* d, const void* x, const void* dy, float* dw,
@@ -553,6 +678,17 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradParams p) {
         wave_sqnorm_add(sq, p.sqnorm + split);
         return;
     }
+    if (p.ws) {   // atomic-free path, as conv_wgrad_kernel
+        float* o = p.ws + ((long)(((tap * p.nkt + kt) * p.nct + ct)) * p.nsplit + split) * (BMK * BNC);
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    o[(ka0 + 16 * i + fg * 4 + t) * BNC + cb0 + 16 * j + fr] = acc[i][j][t];
+        return;
+    }
     const int ebase = tap * p.C + ct * BNC;
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -567,13 +703,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma_kernel(WgradParams p) {
 }
 
 template <int BMK, int BNC>
-static int launch_wgrad_dma(WgradParams p, hipStream_t st) {
+static bool wgrad_dma_geometry(WgradParams& p) {
     constexpr int KP = 64;
-    if (p.Md >= (1L << 24)) return PRIMIA_ERR_ARG;  // fast_div range
+    if (p.Md >= (1L << 24)) return false;  // fast_div range
     p.nkt = p.K / BMK;
     p.nct = p.C / BNC;
     const int combos = p.ntaps * p.nkt * p.nct;
-    // Blocks of one launch: ONE round at two resident blocks per CU.  Every block ends with BMK x BNC fp32 atomics, so
+    // Blocks of one launch: ONE round at two resident blocks per CU.  Every block ends with a BMK x BNC fp32 flush, so
     // fewer, longer blocks halve that traffic too (1024 -> 504: layer3.0.conv1 100 -> 84 us, layer4.0.conv1 97 -> 83).
     static const int target_blocks = getenv("PRIMIA_WG_BLOCKS") ? atoi(getenv("PRIMIA_WG_BLOCKS")) : 504;
     long want = (target_blocks + combos - 1) / combos;
@@ -586,6 +722,16 @@ static int launch_wgrad_dma(WgradParams p, hipStream_t st) {
     p.pix_per_split = pps;
     p.nsplit = (int)((p.Md + pps - 1) / pps);
     p.split_stride = p.persample ? (long)p.K * p.klen : 0;
+    return true;
+}
+
+template <int BMK, int BNC>
+static int launch_wgrad_dma(WgradParams p, hipStream_t st) {
+    constexpr int KP = 64;
+    if (!wgrad_dma_geometry<BMK, BNC>(p)) return PRIMIA_ERR_ARG;
+    const int combos = p.ntaps * p.nkt * p.nct;
+    const bool store = !p.persample && p.ws && p.ws_bytes >= (size_t)combos * p.nsplit * BMK * BNC * sizeof(float);
+    if (!store) p.ws = nullptr;
     const int grid = combos * p.nsplit;
     const size_t lds = 2 * (size_t)KP * (BMK + BNC) * 2;
     auto kern = conv_wgrad_dma_kernel<BMK, BNC>;
@@ -596,7 +742,18 @@ static int launch_wgrad_dma(WgradParams p, hipStream_t st) {
         attr_set = true;
     }
     kern<<<grid, 512, lds, st>>>(p);
+    if (store) launch_tile_reduce(p, BMK, BNC, 0, st);
     return launch_status();
+}
+
+size_t wgrad_dma_ws_bytes(const WgradParams& w) {
+    WgradParams p = w;
+    if (p.K % 128 == 0 && p.C % 128 == 0) {
+        if (!wgrad_dma_geometry<128, 128>(p)) return 0;
+        return (size_t)p.ntaps * p.nkt * p.nct * p.nsplit * 128 * 128 * sizeof(float);
+    }
+    if (!wgrad_dma_geometry<64, 64>(p)) return 0;
+    return (size_t)p.ntaps * p.nkt * p.nct * p.nsplit * 64 * 64 * sizeof(float);
 }
 
 int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st) {

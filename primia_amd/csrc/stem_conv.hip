@@ -19,7 +19,7 @@
 // The kernel is bound by the 411 MB it has to write at batch 256, not by the MFMAs.
 #include <stdlib.h>
 
-#include "conv_common.h"
+#include "conv_wgrad.h"
 
 namespace primia {
 
@@ -197,26 +197,27 @@ __global__ __launch_bounds__(512) void stem_conv_fwd_kernel(StemFwdParams p) {
         }
     };
 
-    // 3-deep LDS ring, one raw barrier per stage, counted vmcnt (stores count too).  Per iteration a wave issues,
-    // in this order, 4 row stores (write-back of the previous stage) and d DMA instructions (d = 2 for waves
-    // 0..5, 1 for waves 6, 7).  At the top of iteration s the operations newer than DMA(s) are the stores of
-    // iteration s-1 (s >= 2) and DMA(s+1).  The last stage (a patch may be dead) uses vmcnt(0).
+    // 3-deep LDS ring, one raw barrier per stage, counted vmcnt.  Per iteration a wave issues, in this order, 4 row
+    // stores (write-back of the previous stage) and d DMA instructions (d = 2 for waves 0..5, 1 for waves 6, 7).
+    // At the top of iteration s at most DMA(s+1) may remain in flight.  The last stage (a patch may be dead) uses
+    // vmcnt(0).
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nstages) stage(s);
     int cur = 0, nxt = STAGES - 1;
     for (int s = 0; s < nstages; ++s) {
         if (s + 1 < nstages) {
-            if (wave < 6) {
-                if (s >= 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            } else {
-                if (s >= 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-            }
+            // only DMA(s+1) may stay in flight (stores retire out of order with respect to loads: they must not be
+            // counted in, see conv3x3_c64.hip)
+            if (wave < 6) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        // the result rows this wave wrote to LDS in the previous iteration must have LANDED before the barrier lets
+        // the other waves read them (a raw s_barrier does not wait for the wave's own outstanding ds_write; with two
+        // blocks per CU competing for the LDS the write-back occasionally read a stale 1-KiB row)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (s > 0) writeback((s - 1) & 1);
         if (s + STAGES - 1 < nstages) stage(nxt);
@@ -338,6 +339,7 @@ struct StemWgParams {
     const bf16* xp;
     const bf16* dy;
     float* dw;
+    float* ws;      // atomic-free path: one [64][256] fp32 slab per block (or null: atomics into dw)
     int N, Hp, Wp, Ho, Wo;
     int PH, PW, PPI;
     int total, per_block;
@@ -467,6 +469,23 @@ __global__ __launch_bounds__(512) void stem_conv_wgrad_kernel(StemWgParams p) {
     }
 
     // ---- accumulate: lane holds out-chan rows 32*kh + 16*i + 4*fg + j, element r*32 + 16*h + fr ----
+    if (p.ws) {   // atomic-free path: the block's whole [64][256] slab (zeros in the padding) to ITS workspace slot
+        float* o = p.ws + (long)blockIdx.x * (64 * 256);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * rq + rr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool live = r < 7 && 16 * h + fr < 28;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[(32 * kh + 16 * i + 4 * fg + j) * 256 + r * 32 + 16 * h + fr] = live ? acc[i][rr][h][j] : 0.f;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int rr = 0; rr < 2; ++rr) {
         const int r = 2 * rq + rr;
@@ -483,25 +502,43 @@ __global__ __launch_bounds__(512) void stem_conv_wgrad_kernel(StemWgParams p) {
     }
 }
 
-// PRIMIA_ERR_UNSUPPORTED -> caller uses the per-tap stem kernel of conv_wgrad.hip
-int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st) {
-    if (H % 32 != 0 || W % 32 != 0) return PRIMIA_ERR_UNSUPPORTED;
-    if ((long)N * (H + 6) * (W + 8) * 4 >= (1L << 31) || (long)N * (H / 2) * (W / 2) * 64 >= (1L << 31))
-        return PRIMIA_ERR_UNSUPPORTED;
+static bool stem_wgrad_halo_ok(int N, int H, int W) {
+    if (H % 32 != 0 || W % 32 != 0) return false;
+    if ((long)N * (H + 6) * (W + 8) * 4 >= (1L << 31) || (long)N * (H / 2) * (W / 2) * 64 >= (1L << 31)) return false;
     static const bool off = getenv("PRIMIA_STEM_WGRAD") && getenv("PRIMIA_STEM_WGRAD")[0] == 'o';  // old kernel (A/B)
-    if (off) return PRIMIA_ERR_UNSUPPORTED;
+    return !off;
+}
+
+// two blocks per CU (76 VGPRs, 69 KiB of LDS each): independent blocks cover each other's barriers and DMA waits
+// (127 -> 113 us); every block flushes one [64][256] slab
+static void stem_wgrad_geometry(int N, int H, int W, int& total, int& per_block, int& grid) {
+    total = N * (H / 2 / 8) * (W / 2 / 16);
+    static const int target = getenv("PRIMIA_STEM_WG_BLOCKS") ? atoi(getenv("PRIMIA_STEM_WG_BLOCKS")) : 512;
+    long per = (total + target - 1) / target;
+    if (per < 1) per = 1;
+    per_block = (int)per;
+    grid = (int)((total + per - 1) / per);
+}
+
+size_t stem_wgrad_halo_ws_bytes(int N, int H, int W) {
+    if (!stem_wgrad_halo_ok(N, H, W)) return 0;
+    int total, per, grid;
+    stem_wgrad_geometry(N, H, W, total, per, grid);
+    return (size_t)grid * 64 * 256 * sizeof(float);
+}
+
+// PRIMIA_ERR_UNSUPPORTED -> caller uses the per-tap stem kernel of conv_wgrad.hip
+int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st, float* ws,
+                             size_t ws_bytes) {
+    if (!stem_wgrad_halo_ok(N, H, W)) return PRIMIA_ERR_UNSUPPORTED;
     StemWgParams p;
     p.xp = xp; p.dy = dy; p.dw = dw;
     p.N = N; p.Hp = H + 6; p.Wp = W + 8; p.Ho = H / 2; p.Wo = W / 2;
     p.PH = p.Ho / 8; p.PW = p.Wo / 16; p.PPI = p.PH * p.PW;
-    p.total = N * p.PPI;
-    // two blocks per CU (76 VGPRs, 69 KiB of LDS each): independent blocks cover each other's barriers and DMA
-    // waits (127 -> 113 us), at the price of twice the atomics of the slab flush
-    static const int target = getenv("PRIMIA_STEM_WG_BLOCKS") ? atoi(getenv("PRIMIA_STEM_WG_BLOCKS")) : 512;
-    long per = (p.total + target - 1) / target;
-    if (per < 1) per = 1;
-    p.per_block = (int)per;
-    const int grid = (int)((p.total + per - 1) / per);
+    int grid;
+    stem_wgrad_geometry(N, H, W, p.total, p.per_block, grid);
+    const bool store = ws && ws_bytes >= (size_t)grid * 64 * 256 * sizeof(float);
+    p.ws = store ? ws : nullptr;
     const size_t lds = (size_t)3 * (7 + 16) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
@@ -511,6 +548,8 @@ int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, i
         attr_set = true;
     }
     stem_conv_wgrad_kernel<<<grid, 512, lds, st>>>(p);
+    // the slabs are [k][e] tiles of the accumulator itself: one "tile" of 64 x 256, one tap, `grid` splits
+    if (store) wgrad_tile_reduce(ws, dw, grid, 1, 64, 256, 1, 1, 4, 256, 1, st);
     return launch_status();
 }
 

@@ -105,9 +105,11 @@ class ResNet18Engine:
         # atomics, so that only the front part needs zeroing every step.
         acc_total = 0
         ws_need = {c.spec.name: query("primia_conv_wgrad_ws_bytes", c.desc, self.dt) for c in self.convs.values()}
+        self._stem_ws_bytes = query("primia_stem_conv_wgrad_ws_bytes", N, input_size, input_size)
         for overwriting in (False, True):
             for c in self.convs.values():
-                if (ws_need[c.spec.name] > 0) != overwriting:
+                # (conv1's 64 KiB slab stays in the zeroed part: odd input sizes take its accumulate path)
+                if (ws_need[c.spec.name] > 0 and c.spec.name != "conv1") != overwriting:
                     continue
                 c.wfwd_n = query("primia_conv_wfwd_elems", c.desc)
                 c.acc_off = acc_total
@@ -123,7 +125,7 @@ class ResNet18Engine:
             c.acc = self.dw_acc[c.acc_off:c.acc_off + c.wfwd_n]
         # workspace of the atomic-free weight-gradient path (primia_conv2d_wgrad_ws): the layers run one after
         # the other on one stream, so they share one buffer sized for the largest (38 MB at batch 256)
-        ws_bytes = max(ws_need.values())
+        ws_bytes = max(max(ws_need.values()), self._stem_ws_bytes)
         self.wgrad_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev) if ws_bytes > 0 else None
         self.wgrad_ws_bytes = ws_bytes
 
@@ -633,8 +635,12 @@ class ResNet18Engine:
         if self._stem_padded and self.dp is None:
             c = self.convs["conv1"]
             S = self.spec.input_size
-            self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call("primia_stem_conv_wgrad", self.x0p,
-                                                                             t["stem.dy"], c.acc, N, S, S, self.dt)))
+            if self.wgrad_ws is not None and not self.wgrad_overlap:
+                self._timed("wgrad", c, lambda: call("primia_stem_conv_wgrad_ws", self.x0p, t["stem.dy"], c.acc,
+                                                     self.wgrad_ws, self.wgrad_ws_bytes, N, S, S, self.dt))
+            else:
+                self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call("primia_stem_conv_wgrad", self.x0p,
+                                                                                 t["stem.dy"], c.acc, N, S, S, self.dt)))
         else:
             self._wgrad("conv1", self.x0, t["stem.dy"])
         if self.dp is None:

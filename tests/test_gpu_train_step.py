@@ -165,3 +165,55 @@ def test_state_dict_roundtrip_and_eval(cuda):
     assert (a - ref).norm() / ref.norm() < 1e-5
     with pytest.raises(KeyError):
         eng.load_state_dict({"conv1.weight": sd["conv1.weight"]})
+
+
+@pytest.mark.parametrize("dtype,batch,size", [(torch.bfloat16, 16, 64), (torch.float32, 4, 64), (torch.bfloat16, 6, 96)])
+def test_training_step_is_bitwise_deterministic(cuda, dtype, batch, size):
+    """Every weight gradient leaves through per-block partial tiles added in a fixed order (primia_conv2d_wgrad_ws,
+    primia_stem_conv_wgrad_ws), every BatchNorm reduction is two-level in a fixed order: the same weights and batches
+    give bit-identical weights after several SGD steps, run after run (no floating-point atomics on the path)."""
+    spec = rs.resnet18_spec(3, 3, size, "max")
+    torch.manual_seed(7)
+    sd = rs.init_state_dict(spec)
+    g = torch.Generator().manual_seed(9)
+    xs = [torch.randn(batch, 3, size, size, generator=g).to(cuda) for _ in range(2)]
+    ys = [torch.randint(0, 3, (batch,), generator=g).to(cuda) for _ in range(2)]
+    outs = []
+    for _ in range(2):
+        eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=dtype, device=cuda)
+        eng.load_state_dict(sd)
+        for i in range(4):
+            eng.forward(xs[i % 2])
+            eng.loss_backward(ys[i % 2])
+            eng.sgd_step(1e-2, 5e-4)
+        torch.cuda.synchronize()
+        outs.append((eng.flat.clone(), eng.grads.clone(), eng.loss.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+def test_full_size_forward_and_step_are_repeatable(cuda):
+    """BASELINE configs[1] size (batch 256, 224x224, bf16): the same batch gives bit-identical activations forward
+    after forward, and the same gradients step after step.  (Small shapes never put two blocks of the 64->64 kernel on
+    one CU; at this size they compete for the LDS, which once let a write-back read a result row before the wave that
+    computes it had finished writing it.)"""
+    B, S = 256, 224
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(B, 3, S, S, generator=g).to(cuda)
+    y = torch.randint(0, 3, (B,), generator=g).to(cuda)
+    eng = ResNet18Engine(B, 3, 3, S, "max", dtype=torch.bfloat16, device=cuda)
+    torch.manual_seed(42)
+    eng.init_weights()
+    names = ["pool.out", "layer1.0.y1", "layer1.0.out", "layer1.1.y2", "layer1.1.out", "layer2.1.out", "layer4.1.out"]
+    ref = ref_g = None
+    for _ in range(10):
+        eng.forward(x)
+        eng.loss_backward(y)
+        torch.cuda.synchronize()
+        cur = {n: eng.t[n].clone() for n in names}
+        if ref is None:
+            ref, ref_g = cur, eng.grads.clone()
+            continue
+        for n in names:
+            assert torch.equal(ref[n], cur[n]), n
+        assert torch.equal(ref_g, eng.grads)
