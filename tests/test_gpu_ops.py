@@ -64,6 +64,12 @@ CONV_CASES = [
     (1, 56, 64, 64, 3, 1, 1),     # layer1 (exact 4x8 tiling)
     (3, 12, 64, 64, 3, 1, 1),     # layer1 shape, ragged 8x8 patches (12 = 1.5 x 8), odd patch count
     (5, 8, 64, 64, 3, 1, 1),      # one patch per image, odd total
+    # linear-halo kernel (conv3x3_lh.hip) corner cases
+    (1, 30, 64, 128, 3, 1, 1),    # widest image it serves (W = 30), ONE 64-channel chunk (9 steps in all)
+    (1, 31, 64, 128, 3, 1, 1),    # W = 31: falls back to the implicit GEMM
+    (3, 5, 128, 128, 3, 1, 1),    # M = 75: a single ragged 256-pixel tile, images narrower than the halo shift table
+    (7, 9, 192, 256, 3, 1, 1),    # 3 chunks, 2 channel tiles, ragged last pixel tile (M = 567)
+    (2, 2, 128, 128, 3, 1, 1),    # 2x2 images: every tap but the centre leaves the image somewhere
 ]
 
 
