@@ -418,6 +418,62 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     // accumulated for the BatchNorm that follows: 16-lane shuffle reduction over the pixels a wave owns,
     // then one atomic per channel per wave — this replaces a full read pass over the conv output.
     T* __restrict__ dst = (T*)p.dst;
+    if constexpr (sizeof(T) == 2 && GLDS) {
+        if (!p.stat_sums && !(p.Nd & 7) && BM * (p.accumulate ? BN * 4 : BN * 2) <= STAGES * (BM + BN) * 128) {
+            // bf16, no fused statistics: the tile leaves through LDS as whole 16-byte chunks of its pixel rows (the
+            // 8-byte-per-lane stores below are store-issue bound: T21 of the programming guide; the stride-2 classes
+            // scatter their rows two pixels apart, which makes it worse).  fp32 staging + ONE rounding when accumulating.
+            __syncthreads();                       // every wave is done reading the last stage
+            const int rb = p.accumulate ? BN * 4 : BN * 2;   // staged row bytes
+            constexpr int CPR = BN / 8;            // 16-byte bf16 output chunks per row
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int row = wm * (BM / WM) + 16 * j + fr;
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int ch = wn * (BN / WN) + 16 * i + fg * 4;
+                    if (p.accumulate) {
+                        *(f32x4*)(smem + row * rb + (((ch >> 2) ^ (row & (2 * CPR - 1))) << 4)) = acc[i][j];
+                    } else {
+                        u32x2 o;
+                        o[0] = (uint32_t)f32_to_bf16(acc[i][j][0]) | ((uint32_t)f32_to_bf16(acc[i][j][1]) << 16);
+                        o[1] = (uint32_t)f32_to_bf16(acc[i][j][2]) | ((uint32_t)f32_to_bf16(acc[i][j][3]) << 16);
+                        *(u32x2*)(smem + row * rb + (((ch >> 3) ^ (row & (CPR - 1))) << 4) + ((ch & 4) << 1)) = o;
+                    }
+                }
+            }
+            __syncthreads();
+            for (int q = tid; q < BM * CPR; q += NT) {
+                const int row = q / CPR, c8 = q - row * CPR;
+                const long mc = m0 + row;
+                if (mc >= Mc) continue;
+                long m = mc;
+                if (DGRAD && p.s2_classes) {
+                    int n, hd, wd;
+                    dst_pixel(mc, n, hd, wd);
+                    m = ((long)n * p.Hd + hd) * p.Wd + wd;
+                }
+                T* gq = dst + m * p.Nd + n0 + c8 * 8;
+                u32x4 v;
+                if (p.accumulate) {
+                    const u32x4 old = *(const u32x4*)gq;
+                    const f32x4 lo = *(const f32x4*)(smem + row * rb + (((2 * c8) ^ (row & (2 * CPR - 1))) << 4));
+                    const f32x4 hi = *(const f32x4*)(smem + row * rb + (((2 * c8 + 1) ^ (row & (2 * CPR - 1))) << 4));
+                    float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        f[2 * e] += __uint_as_float(old[e] << 16);
+                        f[2 * e + 1] += __uint_as_float(old[e] & 0xffff0000u);
+                        v[e] = (uint32_t)f32_to_bf16(f[2 * e]) | ((uint32_t)f32_to_bf16(f[2 * e + 1]) << 16);
+                    }
+                } else {
+                    v = *(const u32x4*)(smem + row * rb + ((c8 ^ (row & (CPR - 1))) << 4));
+                }
+                *(u32x4*)gq = v;
+            }
+            return;
+        }
+    }
     float s1[FM][4], s2[FM][4];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
