@@ -139,6 +139,14 @@ int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const 
                                const void* bn_y, const uint8_t* relu_mask, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, float* sums, int dtype,
                                primia_stream_t stream);
+/* Identity block (torchlib/models.py:268-284, `out += identity; out = relu(out)`): dx = mask(dx) + dgrad(dy), where dx
+ * holds the gradient of the block's OUTPUT and relu_mask the bits of that ReLU (primia_bn_fwd_train_mask).  The
+ * masked residual gradient is then never written by the BatchNorm backward pass (g_out = NULL there): one tensor
+ * write less per identity block.  primia_conv_dgrad_masked_acc_ok() says whether this conv's kernel has the form
+ * (else: g_out + primia_conv2d_dgrad(accumulate = 1)). */
+int primia_conv_dgrad_masked_acc_ok(const primia_conv_desc* d, int dtype);
+int primia_conv2d_dgrad_masked_acc(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                                   const uint8_t* relu_mask, int dtype, primia_stream_t stream);
 /* Transition block (torchlib/models.py:268-284 with a downsample, :232-235): dx = dgrad(conv1 3x3/2, dy) +
  * dgrad(downsample 1x1/2, dy_ds) in ONE pass — both convolutions read the same x, the downsample's gradient lands
  * on the even/even pixels, where conv1's only tap is the centre one at the same dy pixel, so it is folded into

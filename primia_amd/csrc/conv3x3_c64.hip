@@ -47,6 +47,7 @@ struct C64Params {
     int N, H, W;
     int flip;         // 0 forward, 1 data gradient
     int accumulate;   // dst += result
+    const uint8_t* acc_mask;  // accumulate form: bit i of byte (pixel*64 + 8*chunk)/8 keeps the old channel 8*chunk + i
     int PH, PW, PPI;  // 8x8 patches per image column / row / image
     int total;        // patches overall
     int per_block;    // patches per block
@@ -232,7 +233,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // accumulate form: both old rows are requested before anything is stored — a load waited for AFTER a
             // store would also wait for that store to complete (one vmcnt for both)
             old[q] = u32x4{0, 0, 0, 0};
-            if (ACC && live[q]) old[q] = *(const u32x4*)gp[q];
+            if (ACC && live[q]) {
+                old[q] = *(const u32x4*)gp[q];
+                if (p.acc_mask) {   // old value = gradient through a ReLU whose mask is applied here, not stored
+                    const unsigned m = p.acc_mask[(gp[q] - p.dst) >> 3];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        old[q][k] &= ((m >> (2 * k)) & 1u ? 0x0000ffffu : 0u) | ((m >> (2 * k + 1)) & 1u ? 0xffff0000u : 0u);
+                }
+            }
         }
         advance(cw);
 #pragma unroll
@@ -342,12 +351,13 @@ int conv3x3_c64_grid(int N, int H, int W) {
 }
 
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
-                         hipStream_t st, float* stat_partials) {
+                         hipStream_t st, float* stat_partials, const uint8_t* acc_mask) {
     if ((long)N * H * W * 64 >= (1L << 31)) return PRIMIA_ERR_UNSUPPORTED;
     C64Params p;
     p.src = src; p.wt = wt; p.dst = dst;
     p.N = N; p.H = H; p.W = W; p.flip = flip; p.accumulate = accumulate;
     p.stat_partials = stat_partials;
+    p.acc_mask = accumulate ? acc_mask : nullptr;
     p.PH = (H + 7) / 8; p.PW = (W + 7) / 8; p.PPI = p.PH * p.PW;
     p.total = N * p.PPI;
     static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 512;   // 2 per CU

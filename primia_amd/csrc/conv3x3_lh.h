@@ -18,6 +18,7 @@ struct LhBnArgs {
 // pixel tiles (= partial slots) if the shape is served by the kernel, else PRIMIA_ERR_UNSUPPORTED
 int conv3x3_lh_tiles_m(int N, int H, int W, int Cs, int Nd);
 int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
-                        int accumulate, hipStream_t st, float* stat_partials = nullptr, const LhBnArgs* bn = nullptr);
+                        int accumulate, hipStream_t st, float* stat_partials = nullptr, const LhBnArgs* bn = nullptr,
+                        const uint8_t* acc_mask = nullptr);
 
 }  // namespace primia

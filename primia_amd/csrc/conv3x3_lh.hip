@@ -56,6 +56,7 @@ struct LhParams {
     long M;            // N*H*W
     int flip;          // 0 forward, 1 data gradient
     int accumulate;    // dst += result
+    const uint8_t* acc_mask;   // accumulate form: ReLU mask bits applied to the OLD values (one byte per 8 channels)
     int ntile_n;
     // data gradient only: backward sums of the BatchNorm that consumes dst (see primia_conv2d_dgrad_bnsums):
     // bwd_partials [tiles_m][2][Nd] = per-tile (sum g, sum g * (y - mean)), g = dst AS STORED where the ReLU passed
@@ -332,7 +333,13 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
         bf16* gq = p.dst + m * p.Nd + n0 + c8 * 8;
         u32x4 v;
         if constexpr (ACC) {
-            const u32x4 old = *(const u32x4*)gq;
+            u32x4 old = *(const u32x4*)gq;
+            if (p.acc_mask) {
+                const unsigned mk = p.acc_mask[(gq - p.dst) >> 3];
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    old[e] &= ((mk >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((mk >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+            }
             const f32x4 lo = *(const f32x4*)(smem + px * OPIX + (((2 * c8) ^ (px & 31)) << 4));
             const f32x4 hi = *(const f32x4*)(smem + px * OPIX + (((2 * c8 + 1) ^ (px & 31)) << 4));
             float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -412,7 +419,8 @@ int conv3x3_lh_tiles_m(int N, int H, int W, int Cs, int Nd) {
 }
 
 int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
-                        int accumulate, hipStream_t st, float* stat_partials, const LhBnArgs* bn) {
+                        int accumulate, hipStream_t st, float* stat_partials, const LhBnArgs* bn,
+                        const uint8_t* acc_mask) {
     if (conv3x3_lh_tiles_m(N, H, W, Cs, Nd) < 0) return PRIMIA_ERR_UNSUPPORTED;
     if (stat_partials && (flip || accumulate)) return PRIMIA_ERR_ARG;
     if (bn && (!flip || stat_partials)) return PRIMIA_ERR_ARG;
@@ -421,6 +429,7 @@ int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H
     p.src = src; p.wt = wt; p.dst = dst;
     p.H = H; p.W = W; p.Cs = Cs; p.Nd = Nd; p.M = M;
     p.flip = flip; p.accumulate = accumulate;
+    p.acc_mask = accumulate ? acc_mask : nullptr;
     p.ntile_n = Nd / kLhBN;
     p.stat_partials = stat_partials;
     p.bwd_partials = nullptr;

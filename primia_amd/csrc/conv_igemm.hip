@@ -621,7 +621,7 @@ using namespace primia;
 
 namespace primia {
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
-                         hipStream_t st, float* stat_partials = nullptr);
+                         hipStream_t st, float* stat_partials = nullptr, const uint8_t* acc_mask = nullptr);
 int conv3x3_c64_grid(int N, int H, int W);
 }
 
@@ -702,7 +702,7 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
 
 static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                              int accumulate, const void* dy2, const void* w_dgrad2, int dtype, primia_stream_t stream,
-                             const LhBnArgs* bn = nullptr) {
+                             const LhBnArgs* bn = nullptr, const uint8_t* acc_mask = nullptr) {
     PRIMIA_REQUIRE(d && dy && w_dgrad && dx);
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
@@ -728,14 +728,15 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
     } else if (dtype == PRIMIA_BF16) {
         if (use_c64(g)) {
             const int rc = conv3x3_c64_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, 1,
-                                                accumulate, st);
+                                                accumulate, st, nullptr, acc_mask);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         } else if (lh_shape(g) && !p.src2) {
             const int rc = conv3x3_lh_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C, 1,
-                                               accumulate, st, nullptr, bn);
+                                               accumulate, st, nullptr, bn, acc_mask);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         }
         if (bn) return PRIMIA_ERR_UNSUPPORTED;   // only the linear-halo kernel emits the sums
+        if (acc_mask) return PRIMIA_ERR_UNSUPPORTED;   // only the 64->64 and linear-halo write-backs mask the old values
         p.nsteps = p.klen / 64;
         return dispatch_igemm<bf16, true>(p, false, st);
     }
@@ -763,6 +764,21 @@ int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const 
     if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
     LhBnArgs bn{bn_y, relu_mask, gamma, beta, save_mean, save_invstd, sums};
     return conv2d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, dtype, stream, &bn);
+}
+
+int primia_conv_dgrad_masked_acc_ok(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
+    if (dtype != PRIMIA_BF16) return 0;
+    if (use_c64(g)) return (long)g.N * g.H * g.W * 64 < (1L << 31) ? 1 : 0;
+    return lh_shape(g) && conv3x3_lh_tiles_m(g.N, g.H, g.W, g.K, g.C) > 0 ? 1 : 0;
+}
+
+int primia_conv2d_dgrad_masked_acc(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                                   const uint8_t* relu_mask, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(relu_mask);
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
+    return conv2d_dgrad_impl(d, dy, w_dgrad, dx, 1, nullptr, nullptr, dtype, stream, nullptr, relu_mask);
 }
 
 int primia_conv2d_dgrad_pair(const primia_conv_desc* d, const void* dy, const void* w_dgrad,

@@ -228,6 +228,13 @@ class ResNet18Engine:
                     if slots > 0:
                         self.bwd_sums[bn_name(consumer.name)] = torch.zeros(slots, 2, consumer.cout, dtype=torch.float32,
                                                                             device=dev)
+        # identity blocks: can conv1's accumulating data gradient apply bn2's ReLU mask to the old values itself?
+        self.masked_acc_ok = {}
+        if os.environ.get("PRIMIA_MASKED_ACC", "1") != "0":
+            for blk in self.spec.blocks:
+                if blk.down is None:
+                    self.masked_acc_ok[blk.conv1.name] = query("primia_conv_dgrad_masked_acc_ok",
+                                                               self.convs[blk.conv1.name].desc, self.dt) == 1
         self.save = {}
         for c in self.spec.convs:
             b = bn_name(c.name)
@@ -487,7 +494,9 @@ class ResNet18Engine:
         self.backward()
         return self.loss
 
-    def _bn_bwd(self, conv_name, y, z, dz, dy, g_out, relu):
+    def _bn_bwd(self, conv_name, y, z, dz, dy, g_out, relu, keep_g=True):
+        """keep_g=False (residual layers with a 1-bit mask only): the masked gradient g is NOT written back over dz —
+        the accumulating data gradient that consumes it applies the mask itself (primia_conv2d_dgrad_masked_acc)."""
         b = bn_name(conv_name)
         sm, si = self.save[b]
         if self.norm == "group":
@@ -508,7 +517,8 @@ class ResNet18Engine:
                  y.shape[1], self.dt)
             return
         if relu and g_out is not None and b in self.relu_masks:
-            call("primia_bn_bwd_mask", y, self.relu_masks[b], dz, dy, g_out, self.views[b + ".weight"], sm, si,
+            call("primia_bn_bwd_mask", y, self.relu_masks[b], dz, dy, g_out if keep_g else None,
+                 self.views[b + ".weight"], sm, si,
                  self.gviews[b + ".weight"], self.gviews[b + ".bias"], y.shape[0], y.shape[1], self.bn_ws,
                  self.bn_ws_bytes, self.dt)
             return
@@ -594,8 +604,13 @@ class ResNet18Engine:
             x_in = t[blocks[i - 1].prefix + ".out"] if i > 0 else t["pool.out"]
             dx_in = t[blocks[i - 1].prefix + ".dout"] if i > 0 else t["pool.dout"]
             dout = t[p + ".dout"]
-            # bn2 (+residual, relu): dy2, and the masked gradient g written back over dout
-            self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True)
+            # bn2 (+residual, relu): dy2, and the masked gradient g written back over dout — unless this is an identity
+            # block whose conv1 data gradient can mask the old values itself (one tensor write less)
+            b2 = bn_name(blk.conv2.name)
+            masked_acc = (blk.down is None and self.masked_acc_ok.get(blk.conv1.name, False) and self.norm == "batch"
+                          and b2 in self.relu_masks and not self.bwd_sums)
+            self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True,
+                         keep_g=not masked_acc)
             # data gradient first: the weight gradient (a leaf) then runs beside the BatchNorm chain that follows
             if self.wgrad_first:   # weight gradient, then data gradient, so that the BatchNorm backward pass which
                 # follows finds the data gradient it reads still in the Infinity Cache
@@ -629,7 +644,12 @@ class ResNet18Engine:
                 # identity skip: dx_in aliases dout, which now holds the masked gradient g
                 if self.wgrad_first:
                     self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
-                if i > 0:
+                if masked_acc:
+                    c1 = self.convs[blk.conv1.name]
+                    self._join_wgrad_stream()
+                    self._timed("dgrad", c1, lambda: call("primia_conv2d_dgrad_masked_acc", c1.desc, t[p + ".dy1"],
+                                                          c1.w_dgrad, dx_in, self.relu_masks[b2], self.dt))
+                elif i > 0:
                     self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, True, blocks[i - 1].conv2.name,
                                 t[blocks[i - 1].prefix + ".y2"])
                 else:

@@ -801,3 +801,31 @@ def test_dgrad_emits_batchnorm_backward_sums(cuda, N, H, C, K, acc):
     assert relerr(b[1], a[1]) < 1e-3   # bf16 outputs: a 1-ulp flip where the sums differ in the last bits
     c = run(True)
     assert all(torch.equal(u, v) for u, v in zip(b, c) if u is not None)
+
+
+@pytest.mark.parametrize("N,H,C", [(2, 16, 64), (1, 56, 64), (2, 28, 128), (4, 14, 256), (5, 7, 512)])
+def test_dgrad_masked_accumulate(cuda, N, H, C):
+    """primia_conv2d_dgrad_masked_acc: dx = relu_mask(dx) + dgrad(dy), bit-identical to masking dx first and then
+    calling primia_conv2d_dgrad(accumulate = 1) (identity blocks: the BatchNorm backward no longer writes the
+    masked residual gradient)."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    desc = ConvDesc.make(N, H, H, C, C, 3, 3, 1, 1)
+    assert query("primia_conv_dgrad_masked_acc_ok", desc, dt) == 1
+    g = torch.Generator().manual_seed(3 * H + C)
+    w = rnd(torch.randn(C, C, 3, 3, generator=g) * 0.05, dtype)
+    _, wd = prep_weights(desc, w, dtype, cuda, C)
+    dy = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
+    base = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
+    M = N * H * H
+    bits = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.int32).to(torch.uint8).to(cuda)
+    keep = ((bits.to(torch.int32).unsqueeze(1) >> torch.arange(8, device=cuda)) & 1).reshape(M, C).to(torch.bool)
+    ref = torch.where(keep, base, torch.zeros_like(base))
+    call("primia_conv2d_dgrad", desc, dy, wd, ref, 1, dt)
+    out = base.clone()
+    call("primia_conv2d_dgrad_masked_acc", desc, dy, wd, out, bits, dt)
+    assert torch.equal(out, ref)
+    # a shape no masking write-back serves
+    d2 = ConvDesc.make(2, 16, 16, 64, 128, 3, 3, 2, 1)
+    assert query("primia_conv_dgrad_masked_acc_ok", d2, dt) == 0
+    assert query("primia_conv_dgrad_masked_acc_ok", desc, _lib.dtype_code(torch.float32)) == 0
