@@ -249,6 +249,16 @@ int primia_bn_relu_bwd(const void* y, const void* dz, void* dy, const float* gam
                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                        int64_t M, int C, void* workspace, int64_t workspace_bytes, int dtype,
                        primia_stream_t stream);
+/* Transition block (torchlib/models.py:277-283 with a downsample): out = relu(bn2(y2) + bn_d(yd)).  Both BatchNorm
+ * backward passes in ONE reduction + ONE apply pass over (y2, yd, dz): dy2, dyd and the four parameter gradients; the
+ * masked gradient dz * relu_mask is never written (the block's input gradient is primia_conv2d_dgrad_pair(dy1, dyd)).
+ * Bit-identical to primia_bn_bwd_mask(y2, .., g_out = g) followed by primia_bn_bwd(yd, dz = g, relu = 0).
+ * workspace >= 1024 * 3 * C floats. */
+int primia_bn_bwd_pair(const void* y2, const void* yd, const void* dz, const uint8_t* relu_mask, void* dy2, void* dyd,
+                       const float* gamma2, const float* save_mean2, const float* save_invstd2, const float* gamma_d,
+                       const float* save_mean_d, const float* save_invstd_d, float* dgamma2, float* dbeta2,
+                       float* dgamma_d, float* dbeta_d, int64_t M, int C, void* workspace, int64_t workspace_bytes,
+                       int dtype, primia_stream_t stream);
 /* BatchNorm backward from the partial sums a data-gradient kernel already formed (primia_conv2d_dgrad_bnsums):
  * finalize + apply pass; relu_mask (bits) or, if NULL, the ReLU mask recomputed from y (beta required). */
 int primia_bn_bwd_from_sums(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,

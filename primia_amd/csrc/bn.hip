@@ -611,6 +611,175 @@ static int bn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
     return launch_status();
 }
 
+// =================================================================================================
+// Transition block (conv2 -> bn2, + downsample -> bn_d, ReLU): both BatchNorm backward passes read the SAME incoming
+// gradient g = dz * relu_mask.  Separately they cost: bn2 (reduce: y2, dz | apply: y2, dz -> dy2, g) and then bn_d
+// (reduce: yd, g | apply: yd, g -> dyd) = 7 tensor reads + 3 writes.  Together: one reduction with three sums (sum g,
+// sum g*xhat2, sum g*xhat_d) over y2, yd, dz and one apply pass y2, yd, dz -> dy2, dyd = 6 reads + 2 writes, and g is
+// never materialised (the block's input gradient comes from primia_conv2d_dgrad_pair(dy1, dyd)).  Same reduction
+// geometry and arithmetic as the separate kernels: bit-identical results.
+// =================================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_pair_reduce_kernel(const T* __restrict__ y2, const T* __restrict__ yd,
+                                                                 const T* __restrict__ dz,
+                                                                 const uint8_t* __restrict__ mask,
+                                                                 const float* __restrict__ mean2,
+                                                                 const float* __restrict__ invstd2,
+                                                                 const float* __restrict__ meand,
+                                                                 const float* __restrict__ invstdd, long M, int C,
+                                                                 long rows_per_block, float* __restrict__ partials) {
+    constexpr int CH = Chunk<T>::N;
+    const int tpr = C / CH, rpp = 256 / tpr;
+    const int rg = threadIdx.x / tpr, cc = threadIdx.x % tpr;
+    const long r0 = (long)blockIdx.x * rows_per_block;
+    long r1 = r0 + rows_per_block;
+    if (r1 > M) r1 = M;
+    float s1[CH], s2[CH], s3[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) s1[i] = s2[i] = s3[i] = 0.f;
+    const int c0 = cc * CH;
+    if (rg < rpp) {
+        for (long r = r0 + rg; r < r1; r += rpp) {
+            const long off = r * C + c0;
+            float v2[CH], vd[CH], vg[CH];
+            Chunk<T>::unpack(*(const u32x4*)(y2 + off), v2);
+            Chunk<T>::unpack(*(const u32x4*)(yd + off), vd);
+            Chunk<T>::unpack(*(const u32x4*)(dz + off), vg);
+            const unsigned m = mask[off / CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                vg[i] = (m >> i) & 1u ? vg[i] : 0.f;
+                const float xh2 = (v2[i] - mean2[c0 + i]) * invstd2[c0 + i];
+                const float xhd = (vd[i] - meand[c0 + i]) * invstdd[c0 + i];
+                s1[i] += vg[i];
+                s2[i] += vg[i] * xh2;
+                s3[i] += vg[i] * xhd;
+            }
+        }
+    }
+    __shared__ float red[3][256 * CH];
+    if (rg < rpp) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            red[0][rg * C + c0 + i] = s1[i];
+            red[1][rg * C + c0 + i] = s2[i];
+            red[2][rg * C + c0 + i] = s3[i];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f, b = 0.f, d = 0.f;
+        for (int g = 0; g < rpp; ++g) {
+            a += red[0][g * C + c];
+            b += red[1][g * C + c];
+            d += red[2][g * C + c];
+        }
+        partials[((long)blockIdx.x * 3 + 0) * C + c] = a;
+        partials[((long)blockIdx.x * 3 + 1) * C + c] = b;
+        partials[((long)blockIdx.x * 3 + 2) * C + c] = d;
+    }
+}
+
+// the fp64 combine of bn_finalize_kernel (same slicing, same order) for three sums
+__global__ __launch_bounds__(16 * kFinSlices) void bn_finalize3_kernel(const float* __restrict__ partials, int nblk, int C,
+                                                                      float* dbeta2, float* dgamma2, float* dbetad,
+                                                                      float* dgammad) {
+    __shared__ double sa[kFinSlices][17], sb[kFinSlices][17], sc[kFinSlices][17];
+    const int cl = threadIdx.x & 15, ks = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a = 0.0, b = 0.0, d = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int k = ks; k < nblk; k += kFinSlices) {
+            a += (double)partials[((long)k * 3 + 0) * C + c];
+            b += (double)partials[((long)k * 3 + 1) * C + c];
+            d += (double)partials[((long)k * 3 + 2) * C + c];
+        }
+    }
+    sa[ks][cl] = a;
+    sb[ks][cl] = b;
+    sc[ks][cl] = d;
+    __syncthreads();
+    if (ks >= 4) return;
+    for (int k = ks + 4; k < kFinSlices; k += 4) {
+        a += sa[k][cl];
+        b += sb[k][cl];
+        d += sc[k][cl];
+    }
+    a += __shfl_down(a, 32);
+    b += __shfl_down(b, 32);
+    d += __shfl_down(d, 32);
+    a += __shfl_down(a, 16);
+    b += __shfl_down(b, 16);
+    d += __shfl_down(d, 16);
+    if (ks != 0 || c >= C) return;
+    dbeta2[c] = (float)a;
+    dgamma2[c] = (float)b;
+    dbetad[c] = (float)a;
+    dgammad[c] = (float)d;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_pair_apply_kernel(
+    const T* __restrict__ y2, const T* __restrict__ yd, const T* __restrict__ dz, const uint8_t* __restrict__ mask,
+    T* __restrict__ dy2, T* __restrict__ dyd, const float* __restrict__ gamma2, const float* __restrict__ mean2,
+    const float* __restrict__ invstd2, const float* __restrict__ gammad, const float* __restrict__ meand,
+    const float* __restrict__ invstdd, const float* __restrict__ dbeta, const float* __restrict__ dgamma2,
+    const float* __restrict__ dgammad, float inv_m, long nchunks, int C) {
+    constexpr int CH = Chunk<T>::N;
+    __shared__ float sm[9][512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        sm[0][c] = mean2[c];
+        sm[1][c] = invstd2[c];
+        sm[2][c] = gamma2[c] * invstd2[c];
+        sm[3][c] = dbeta[c] * inv_m;
+        sm[4][c] = dgamma2[c] * inv_m;
+        sm[5][c] = meand[c];
+        sm[6][c] = invstdd[c];
+        sm[7][c] = gammad[c] * invstdd[c];
+        sm[8][c] = dgammad[c] * inv_m;
+    }
+    __syncthreads();
+    const int cpr = C / CH;
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nchunks; q += stride) {
+        const int c0 = (int)(q % cpr) * CH;
+        float v2[CH], vd[CH], vg[CH];
+        Chunk<T>::unpack(*(const u32x4*)(y2 + q * CH), v2);
+        Chunk<T>::unpack(*(const u32x4*)(yd + q * CH), vd);
+        Chunk<T>::unpack(*(const u32x4*)(dz + q * CH), vg);
+        const unsigned m = mask[q];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            vg[i] = (m >> i) & 1u ? vg[i] : 0.f;
+            const float xh2 = (v2[i] - sm[0][c0 + i]) * sm[1][c0 + i];
+            const float xhd = (vd[i] - sm[5][c0 + i]) * sm[6][c0 + i];
+            v2[i] = sm[2][c0 + i] * (vg[i] - sm[3][c0 + i] - xh2 * sm[4][c0 + i]);
+            vd[i] = sm[7][c0 + i] * (vg[i] - sm[3][c0 + i] - xhd * sm[8][c0 + i]);
+        }
+        *(u32x4*)(dy2 + q * CH) = Chunk<T>::pack(v2);
+        *(u32x4*)(dyd + q * CH) = Chunk<T>::pack(vd);
+    }
+}
+
+template <typename T>
+static int bn_bwd_pair_impl(const void* y2, const void* yd, const void* dz, const uint8_t* mask, void* dy2, void* dyd,
+                            const float* gamma2, const float* mean2, const float* invstd2, const float* gammad,
+                            const float* meand, const float* invstdd, float* dgamma2, float* dbeta2, float* dgammad,
+                            float* dbetad, long M, int C, float* partials, hipStream_t st) {
+    int nblk;
+    long rpb;
+    reduce_geometry(M, C, nblk, rpb);
+    bn_bwd_pair_reduce_kernel<T><<<nblk, 256, 0, st>>>((const T*)y2, (const T*)yd, (const T*)dz, mask, mean2, invstd2,
+                                                       meand, invstdd, M, C, rpb, partials);
+    bn_finalize3_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partials, nblk, C, dbeta2, dgamma2, dbetad, dgammad);
+    const long nchunks = M * C / Chunk<T>::N;
+    bn_bwd_pair_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
+        (const T*)y2, (const T*)yd, (const T*)dz, mask, (T*)dy2, (T*)dyd, gamma2, mean2, invstd2, gammad, meand,
+        invstdd, dbeta2, dgamma2, dgammad, (float)(1.0 / (double)M), nchunks, C);
+    return launch_status();
+}
+
 template <typename T>
 static void launch_bn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
                                     const float* mean, const float* invstd, int N, int H, int W, int C, int Ho, int Wo,
@@ -1005,6 +1174,27 @@ int primia_bn_bwd_from_sums(const void* y, const uint8_t* relu_mask, const void*
     if (dtype == PRIMIA_BF16)
         return bn_bwd_from_sums_impl<bf16>(y, relu_mask, dz, dy, g_out, gamma, beta, save_mean, save_invstd, dgamma, dbeta,
                                            sums, slots, M, C, st);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_bn_bwd_pair(const void* y2, const void* yd, const void* dz, const uint8_t* relu_mask, void* dy2, void* dyd,
+                       const float* gamma2, const float* save_mean2, const float* save_invstd2, const float* gamma_d,
+                       const float* save_mean_d, const float* save_invstd_d, float* dgamma2, float* dbeta2,
+                       float* dgamma_d, float* dbeta_d, int64_t M, int C, void* workspace, int64_t workspace_bytes,
+                       int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y2 && yd && dz && relu_mask && dy2 && dyd && gamma2 && save_mean2 && save_invstd2 && gamma_d &&
+                   save_mean_d && save_invstd_d && dgamma2 && dbeta2 && dgamma_d && dbeta_d && workspace);
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype));
+    if (workspace_bytes < (int64_t)kMaxPartialBlocks * 3 * C * (int64_t)sizeof(float)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return bn_bwd_pair_impl<float>(y2, yd, dz, relu_mask, dy2, dyd, gamma2, save_mean2, save_invstd2, gamma_d,
+                                       save_mean_d, save_invstd_d, dgamma2, dbeta2, dgamma_d, dbeta_d, M, C,
+                                       (float*)workspace, st);
+    if (dtype == PRIMIA_BF16)
+        return bn_bwd_pair_impl<bf16>(y2, yd, dz, relu_mask, dy2, dyd, gamma2, save_mean2, save_invstd2, gamma_d,
+                                      save_mean_d, save_invstd_d, dgamma2, dbeta2, dgamma_d, dbeta_d, M, C,
+                                      (float*)workspace, st);
     return PRIMIA_ERR_ARG;
 }
 

@@ -240,7 +240,7 @@ class ResNet18Engine:
             b = bn_name(c.name)
             self.save[b] = (torch.empty(c.cout, dtype=torch.float32, device=dev),
                             torch.empty(c.cout, dtype=torch.float32, device=dev))
-        self.bn_ws_bytes = query("primia_bn_workspace_bytes", 1, 512)
+        self.bn_ws_bytes = max(query("primia_bn_workspace_bytes", 1, 512), 1024 * 3 * 512 * 4)   # (pair backward: 3 sums)
         if norm == "group":
             self.bn_ws_bytes = max(self.bn_ws_bytes, query("primia_gn_workspace_bytes", N, 512, self.groups))
             # statistics are per (sample, group); per-sample affine gradients [N][C] per layer
@@ -373,6 +373,8 @@ class ResNet18Engine:
 
     # conv1 + downsample data gradients of a transition block in one pass (primia_conv2d_dgrad_pair)
     pair_dgrad = True
+    # transition blocks: bn2's and the downsample BatchNorm's backward passes as one (primia_bn_bwd_pair)
+    bn_pair = os.environ.get("PRIMIA_BN_PAIR", "1") != "0"
     # order of a layer's two gradient kernels: weight gradient first, so that the BatchNorm backward pass that follows
     # the data gradient reads it while it is still in the Infinity Cache (6.42 -> 6.39 ms per step; PRIMIA_WGRAD_FIRST=0
     # restores the other order)
@@ -609,8 +611,20 @@ class ResNet18Engine:
             b2 = bn_name(blk.conv2.name)
             masked_acc = (blk.down is None and self.masked_acc_ok.get(blk.conv1.name, False) and self.norm == "batch"
                           and b2 in self.relu_masks and not self.bwd_sums)
-            self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True,
-                         keep_g=not masked_acc)
+            # transition block: bn2 and the downsample BatchNorm share the incoming gradient -> ONE fused backward
+            bn_pair = (blk.down is not None and self.pair_dgrad and self.bn_pair and self.norm == "batch"
+                       and b2 in self.relu_masks and not self.bwd_sums)
+            if bn_pair:
+                bd = bn_name(blk.down.name)
+                (sm2, si2), (smd, sid) = self.save[b2], self.save[bd]
+                call("primia_bn_bwd_pair", t[p + ".y2"], t[p + ".yd"], dout, self.relu_masks[b2], t[p + ".dy2"],
+                     t[p + ".dyd"], self.views[b2 + ".weight"], sm2, si2, self.views[bd + ".weight"], smd, sid,
+                     self.gviews[b2 + ".weight"], self.gviews[b2 + ".bias"], self.gviews[bd + ".weight"],
+                     self.gviews[bd + ".bias"], t[p + ".y2"].shape[0], t[p + ".y2"].shape[1], self.bn_ws,
+                     self.bn_ws_bytes, self.dt)
+            else:
+                self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True,
+                             keep_g=not masked_acc)
             # data gradient first: the weight gradient (a leaf) then runs beside the BatchNorm chain that follows
             if self.wgrad_first:   # weight gradient, then data gradient, so that the BatchNorm backward pass which
                 # follows finds the data gradient it reads still in the Infinity Cache
@@ -622,7 +636,8 @@ class ResNet18Engine:
             self._bn_bwd(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], t[p + ".da1"], t[p + ".dy1"], None, True)
             if blk.down is not None and self.pair_dgrad:
                 # both BatchNorm backward passes first, then ONE data-gradient pass for conv1 + downsample
-                self._bn_bwd(blk.down.name, t[p + ".yd"], None, dout, t[p + ".dyd"], None, False)
+                if not bn_pair:
+                    self._bn_bwd(blk.down.name, t[p + ".yd"], None, dout, t[p + ".dyd"], None, False)
                 c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
                 self._join_wgrad_stream()
                 if self.wgrad_first:

@@ -829,3 +829,37 @@ def test_dgrad_masked_accumulate(cuda, N, H, C):
     d2 = ConvDesc.make(2, 16, 16, 64, 128, 3, 3, 2, 1)
     assert query("primia_conv_dgrad_masked_acc_ok", d2, dt) == 0
     assert query("primia_conv_dgrad_masked_acc_ok", desc, _lib.dtype_code(torch.float32)) == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,C", [(3, 9, 128), (2, 14, 256), (5, 7, 512), (4, 28, 128)])
+def test_batchnorm_backward_pair_is_bit_identical(cuda, dtype, N, H, C):
+    """primia_bn_bwd_pair == primia_bn_bwd_mask(y2, g_out = g) followed by primia_bn_bwd(yd, dz = g, relu = 0)."""
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(H + C)
+    M = N * H * H
+    mk = lambda s=1.0, b=0.0: to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * s + b, dtype), dtype, cuda)
+    y2, yd, res, dz = mk(1.3, 0.2), mk(0.7, -0.1), mk(), mk()
+    ws_bytes = 1024 * 3 * C * 4
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
+    gam2, bet2 = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    gamd, betd = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    sm2, si2, smd, sid = (torch.empty(C, device=cuda) for _ in range(4))
+    z, idn = torch.empty_like(y2), torch.empty_like(y2)
+    ch = 4 if dtype == torch.float32 else 8
+    mask = torch.empty(M * C // ch, dtype=torch.uint8, device=cuda)
+    rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+    call("primia_bn_fwd_train", yd, None, idn, gamd, betd, rm.clone(), rv.clone(), smd, sid, M, C, 1e-5, 0.1, 0, ws, ws_bytes, dt)
+    call("primia_bn_fwd_train_mask", y2, idn, z, mask, gam2, bet2, rm, rv, sm2, si2, None, 0, M, C, 1e-5, 0.1, ws, ws_bytes, dt)
+    # separate
+    dy2a, ga, dyda = torch.empty_like(y2), torch.empty_like(y2), torch.empty_like(y2)
+    d2a, b2a, dda, bda = (torch.empty(C, device=cuda) for _ in range(4))
+    call("primia_bn_bwd_mask", y2, mask, dz, dy2a, ga, gam2, sm2, si2, d2a, b2a, M, C, ws, ws_bytes, dt)
+    call("primia_bn_bwd", yd, None, ga, dyda, None, gamd, smd, sid, dda, bda, M, C, 0, ws, ws_bytes, dt)
+    # fused
+    dy2b, dydb = torch.empty_like(y2), torch.empty_like(y2)
+    d2b, b2b, ddb, bdb = (torch.empty(C, device=cuda) for _ in range(4))
+    call("primia_bn_bwd_pair", y2, yd, dz, mask, dy2b, dydb, gam2, sm2, si2, gamd, smd, sid, d2b, b2b, ddb, bdb, M, C, ws,
+         ws_bytes, dt)
+    for a, b in ((dy2a, dy2b), (dyda, dydb), (d2a, d2b), (b2a, b2b), (dda, ddb), (bda, bdb)):
+        assert torch.equal(a, b)
