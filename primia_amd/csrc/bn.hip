@@ -237,6 +237,51 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     }
 }
 
+// Transition block forward: z = relu(bn2(y2) + bn_d(yd)) with the downsample BatchNorm applied on the fly (its output,
+// rounded to the storage type exactly as if it had been stored, is never written or read back) + the 1-bit ReLU mask.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_pair_kernel(const T* __restrict__ y2, const T* __restrict__ yd,
+                                                            T* __restrict__ z, const float* __restrict__ gamma2,
+                                                            const float* __restrict__ beta2,
+                                                            const float* __restrict__ mean2,
+                                                            const float* __restrict__ invstd2,
+                                                            const float* __restrict__ gammad,
+                                                            const float* __restrict__ betad,
+                                                            const float* __restrict__ meand,
+                                                            const float* __restrict__ invstdd, long nchunks, int C,
+                                                            uint8_t* __restrict__ mask_out) {
+    constexpr int CH = Chunk<T>::N;
+    __shared__ float sm[6][512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        sm[0][c] = mean2[c];
+        sm[1][c] = invstd2[c] * gamma2[c];
+        sm[2][c] = beta2[c];
+        sm[3][c] = meand[c];
+        sm[4][c] = invstdd[c] * gammad[c];
+        sm[5][c] = betad[c];
+    }
+    __syncthreads();
+    const int cpr = C / CH;
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nchunks; q += stride) {
+        const int c0 = (int)(q % cpr) * CH;
+        float v[CH], r[CH];
+        Chunk<T>::unpack(*(const u32x4*)(y2 + q * CH), v);
+        Chunk<T>::unpack(*(const u32x4*)(yd + q * CH), r);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            v[i] = bn_affine(v[i], sm[0][c0 + i], sm[1][c0 + i], sm[2][c0 + i]);
+            v[i] += round_to<T>(bn_affine(r[i], sm[3][c0 + i], sm[4][c0 + i], sm[5][c0 + i]));
+            v[i] = fmaxf(v[i], 0.f);
+        }
+        *(u32x4*)(z + q * CH) = Chunk<T>::pack(v);
+        unsigned m = 0;
+#pragma unroll
+        for (int i = 0; i < CH; ++i) m |= (round_to<T>(v[i]) > 0.f ? 1u : 0u) << i;
+        mask_out[q] = (uint8_t)m;
+    }
+}
+
 // dy = gamma*invstd * (g - dbeta/M - xhat*dgamma/M); optionally g_out = g.
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ z,
@@ -949,6 +994,32 @@ static int bn_bwd_from_sums_impl(const void* y, const uint8_t* mask, const void*
     return launch_status();
 }
 
+template <typename T>
+static int bn_fwd_train_pair_impl(const void* y2, const void* yd, void* z, uint8_t* relu_mask, const float* gamma2,
+                                  const float* beta2, float* rm2, float* rv2, float* sm2, float* si2, const float* sums2,
+                                  int slots2, const float* gammad, const float* betad, float* rmd, float* rvd, float* smd,
+                                  float* sid, long M, int C, float eps, float momentum, float* ws, hipStream_t st) {
+    int nblk;
+    long rpb;
+    reduce_geometry(M, C, nblk, rpb);
+    StatsFn<T> fd{(const T*)yd};
+    colreduce2_kernel<T, StatsFn<T>><<<nblk, 256, 0, st>>>(fd, M, C, rpb, ws);
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(ws, nblk, C, M, 0, eps, momentum, smd, sid, rmd, rvd);
+    const float* part = sums2;
+    int n2 = slots2;
+    if (!sums2) {
+        StatsFn<T> f2{(const T*)y2};
+        colreduce2_kernel<T, StatsFn<T>><<<nblk, 256, 0, st>>>(f2, M, C, rpb, ws);
+        part = ws;
+        n2 = nblk;
+    }
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(part, n2, C, M, 0, eps, momentum, sm2, si2, rm2, rv2);
+    const long nchunks = M * C / Chunk<T>::N;
+    bn_apply_pair_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>((const T*)y2, (const T*)yd, (T*)z, gamma2, beta2, sm2,
+                                                                    si2, gammad, betad, smd, sid, nchunks, C, relu_mask);
+    return launch_status();
+}
+
 extern "C" {
 
 int64_t primia_bn_workspace_bytes(int64_t M, int C) {
@@ -1141,6 +1212,30 @@ int primia_bn_fwd_train_mask(const void* y, const void* residual, void* z, uint8
                                                                       nchunks, C, 1, relu_mask);
     }
     return launch_status();
+}
+
+int primia_bn_fwd_train_pair(const void* y2, const void* yd, void* z, uint8_t* relu_mask, const float* gamma2,
+                             const float* beta2, float* running_mean2, float* running_var2, float* save_mean2,
+                             float* save_invstd2, const float* sums2, int slots2, const float* gamma_d,
+                             const float* beta_d, float* running_mean_d, float* running_var_d, float* save_mean_d,
+                             float* save_invstd_d, int64_t M, int C, float eps, float momentum, void* workspace,
+                             int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y2 && yd && z && relu_mask && gamma2 && beta2 && save_mean2 && save_invstd2 && gamma_d && beta_d &&
+                   save_mean_d && save_invstd_d && workspace);
+    PRIMIA_REQUIRE((running_mean2 == nullptr) == (running_var2 == nullptr));
+    PRIMIA_REQUIRE((running_mean_d == nullptr) == (running_var_d == nullptr));
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype) && (!sums2 || slots2 >= 1));
+    if (workspace_bytes < primia_bn_workspace_bytes(M, C)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return bn_fwd_train_pair_impl<float>(y2, yd, z, relu_mask, gamma2, beta2, running_mean2, running_var2, save_mean2,
+                                             save_invstd2, sums2, slots2, gamma_d, beta_d, running_mean_d, running_var_d,
+                                             save_mean_d, save_invstd_d, M, C, eps, momentum, (float*)workspace, st);
+    if (dtype == PRIMIA_BF16)
+        return bn_fwd_train_pair_impl<bf16>(y2, yd, z, relu_mask, gamma2, beta2, running_mean2, running_var2, save_mean2,
+                                            save_invstd2, sums2, slots2, gamma_d, beta_d, running_mean_d, running_var_d,
+                                            save_mean_d, save_invstd_d, M, C, eps, momentum, (float*)workspace, st);
+    return PRIMIA_ERR_ARG;
 }
 
 int primia_bn_bwd_mask(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,

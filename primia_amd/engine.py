@@ -462,6 +462,27 @@ class ResNet18Engine:
             self._bn(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], None, True)
             self._conv_fwd(blk.conv2.name, t[p + ".a1"], t[p + ".y2"])
             idn = x
+            if blk.down is not None and self.training and self.norm == "batch" and self.use_relu_masks and self.bn_pair:
+                # transition block: both BatchNorms in one apply pass (the downsample branch's output is never stored)
+                self._conv_fwd(blk.down.name, x, t[p + ".yd"])
+                b2, bd = bn_name(blk.conv2.name), bn_name(blk.down.name)
+                y2 = t[p + ".y2"]
+                if b2 not in self.relu_masks:
+                    self.relu_masks[b2] = torch.empty(y2.numel() * y2.element_size() // 16, dtype=torch.uint8,
+                                                      device=y2.device)
+                c2 = self.convs[blk.conv2.name]
+                have = self.fuse_stats or blk.conv2.name in self.free_stats
+                (sm2, si2), (smd, sid) = self.save[b2], self.save[bd]
+                call("primia_bn_fwd_train_pair", y2, t[p + ".yd"], t[p + ".out"], self.relu_masks[b2],
+                     self.views[b2 + ".weight"], self.views[b2 + ".bias"], self.views[b2 + ".running_mean"],
+                     self.views[b2 + ".running_var"], sm2, si2, c2.sums if have else None, c2.stat_slots if have else 0,
+                     self.views[bd + ".weight"], self.views[bd + ".bias"], self.views[bd + ".running_mean"],
+                     self.views[bd + ".running_var"], smd, sid, y2.shape[0], y2.shape[1], BN_EPS, BN_MOMENTUM, self.bn_ws,
+                     self.bn_ws_bytes, self.dt)
+                self.num_batches_tracked[b2] += 1
+                self.num_batches_tracked[bd] += 1
+                x = t[p + ".out"]
+                continue
             if blk.down is not None:
                 self._conv_fwd(blk.down.name, x, t[p + ".yd"])
                 self._bn(blk.down.name, t[p + ".yd"], t[p + ".idn"], None, False)

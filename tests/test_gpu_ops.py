@@ -863,3 +863,36 @@ def test_batchnorm_backward_pair_is_bit_identical(cuda, dtype, N, H, C):
          ws_bytes, dt)
     for a, b in ((dy2a, dy2b), (dyda, dydb), (d2a, d2b), (b2a, b2b), (dda, ddb), (bda, bdb)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("N,H,C", [(3, 9, 128), (2, 14, 256), (4, 28, 128)])
+def test_batchnorm_forward_pair_is_bit_identical(cuda, dtype, N, H, C):
+    """primia_bn_fwd_train_pair == primia_bn_fwd_train(yd -> idn, relu = 0) + primia_bn_fwd_train_mask(y2, idn)."""
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(2 * H + C)
+    M = N * H * H
+    mk = lambda s=1.0, b=0.0: to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * s + b, dtype), dtype, cuda)
+    y2, yd = mk(1.3, 0.2), mk(0.7, -0.1)
+    ws_bytes = query("primia_bn_workspace_bytes", M, C)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
+    gam2, bet2 = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    gamd, betd = (torch.rand(C, generator=g) + 0.5).to(cuda), torch.randn(C, generator=g).to(cuda)
+    ch = 4 if dtype == torch.float32 else 8
+    outs = []
+    for fused in (False, True):
+        sm2, si2, smd, sid = (torch.empty(C, device=cuda) for _ in range(4))
+        rm2, rv2, rmd, rvd = torch.zeros(C, device=cuda), torch.ones(C, device=cuda), torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+        z = torch.empty_like(y2)
+        mask = torch.empty(M * C // ch, dtype=torch.uint8, device=cuda)
+        if fused:
+            call("primia_bn_fwd_train_pair", y2, yd, z, mask, gam2, bet2, rm2, rv2, sm2, si2, None, 0, gamd, betd, rmd, rvd,
+                 smd, sid, M, C, 1e-5, 0.1, ws, ws_bytes, dt)
+        else:
+            idn = torch.empty_like(y2)
+            call("primia_bn_fwd_train", yd, None, idn, gamd, betd, rmd, rvd, smd, sid, M, C, 1e-5, 0.1, 0, ws, ws_bytes, dt)
+            call("primia_bn_fwd_train_mask", y2, idn, z, mask, gam2, bet2, rm2, rv2, sm2, si2, None, 0, M, C, 1e-5, 0.1, ws,
+                 ws_bytes, dt)
+        outs.append((z, mask, sm2, si2, smd, sid, rm2, rv2, rmd, rvd))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
