@@ -252,14 +252,15 @@ int primia_bn_relu_bwd(const void* y, const void* dz, void* dy, const float* gam
 /* Transition block forward (torchlib/models.py:277-283): z = relu(bn2(y2) + bn_d(yd)) and its 1-bit mask, batch
  * statistics / running estimates of BOTH BatchNorms updated; the downsample BatchNorm's output is applied on the fly
  * (rounded to the storage type as if stored) and never written.  Bit-identical to primia_bn_fwd_train(yd -> idn,
- * relu = 0) followed by primia_bn_fwd_train_mask(y2, residual = idn).  sums2 / slots2: bn2's partial sums from the
- * conv (primia_conv2d_fwd_stats) or NULL. */
+ * relu = 0) followed by primia_bn_fwd_train_mask(y2, residual = idn).  sums2 / slots2, sums_d / slots_d: the partial
+ * sums the convolutions emitted (primia_conv2d_fwd_stats) or NULL (a statistics pass over that tensor is run). */
 int primia_bn_fwd_train_pair(const void* y2, const void* yd, void* z, uint8_t* relu_mask, const float* gamma2,
                              const float* beta2, float* running_mean2, float* running_var2, float* save_mean2,
                              float* save_invstd2, const float* sums2, int slots2, const float* gamma_d,
                              const float* beta_d, float* running_mean_d, float* running_var_d, float* save_mean_d,
-                             float* save_invstd_d, int64_t M, int C, float eps, float momentum, void* workspace,
-                             int64_t workspace_bytes, int dtype, primia_stream_t stream);
+                             float* save_invstd_d, const float* sums_d, int slots_d, int64_t M, int C, float eps,
+                             float momentum, void* workspace, int64_t workspace_bytes, int dtype,
+                             primia_stream_t stream);
 /* Transition block (torchlib/models.py:277-283 with a downsample): out = relu(bn2(y2) + bn_d(yd)).  Both BatchNorm
  * backward passes in ONE reduction + ONE apply pass over (y2, yd, dz): dy2, dyd and the four parameter gradients; the
  * masked gradient dz * relu_mask is never written (the block's input gradient is primia_conv2d_dgrad_pair(dy1, dyd)).

@@ -998,13 +998,20 @@ template <typename T>
 static int bn_fwd_train_pair_impl(const void* y2, const void* yd, void* z, uint8_t* relu_mask, const float* gamma2,
                                   const float* beta2, float* rm2, float* rv2, float* sm2, float* si2, const float* sums2,
                                   int slots2, const float* gammad, const float* betad, float* rmd, float* rvd, float* smd,
-                                  float* sid, long M, int C, float eps, float momentum, float* ws, hipStream_t st) {
+                                  float* sid, const float* sumsd, int slotsd, long M, int C, float eps, float momentum,
+                                  float* ws, hipStream_t st) {
     int nblk;
     long rpb;
     reduce_geometry(M, C, nblk, rpb);
-    StatsFn<T> fd{(const T*)yd};
-    colreduce2_kernel<T, StatsFn<T>><<<nblk, 256, 0, st>>>(fd, M, C, rpb, ws);
-    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(ws, nblk, C, M, 0, eps, momentum, smd, sid, rmd, rvd);
+    const float* partd = sumsd;
+    int nd = slotsd;
+    if (!sumsd) {
+        StatsFn<T> fd{(const T*)yd};
+        colreduce2_kernel<T, StatsFn<T>><<<nblk, 256, 0, st>>>(fd, M, C, rpb, ws);
+        partd = ws;
+        nd = nblk;
+    }
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partd, nd, C, M, 0, eps, momentum, smd, sid, rmd, rvd);
     const float* part = sums2;
     int n2 = slots2;
     if (!sums2) {
@@ -1218,23 +1225,26 @@ int primia_bn_fwd_train_pair(const void* y2, const void* yd, void* z, uint8_t* r
                              const float* beta2, float* running_mean2, float* running_var2, float* save_mean2,
                              float* save_invstd2, const float* sums2, int slots2, const float* gamma_d,
                              const float* beta_d, float* running_mean_d, float* running_var_d, float* save_mean_d,
-                             float* save_invstd_d, int64_t M, int C, float eps, float momentum, void* workspace,
-                             int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+                             float* save_invstd_d, const float* sums_d, int slots_d, int64_t M, int C, float eps,
+                             float momentum, void* workspace, int64_t workspace_bytes, int dtype,
+                             primia_stream_t stream) {
     PRIMIA_REQUIRE(y2 && yd && z && relu_mask && gamma2 && beta2 && save_mean2 && save_invstd2 && gamma_d && beta_d &&
                    save_mean_d && save_invstd_d && workspace);
     PRIMIA_REQUIRE((running_mean2 == nullptr) == (running_var2 == nullptr));
     PRIMIA_REQUIRE((running_mean_d == nullptr) == (running_var_d == nullptr));
-    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype) && (!sums2 || slots2 >= 1));
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype) && (!sums2 || slots2 >= 1) && (!sums_d || slots_d >= 1));
     if (workspace_bytes < primia_bn_workspace_bytes(M, C)) return PRIMIA_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_F32)
         return bn_fwd_train_pair_impl<float>(y2, yd, z, relu_mask, gamma2, beta2, running_mean2, running_var2, save_mean2,
                                              save_invstd2, sums2, slots2, gamma_d, beta_d, running_mean_d, running_var_d,
-                                             save_mean_d, save_invstd_d, M, C, eps, momentum, (float*)workspace, st);
+                                             save_mean_d, save_invstd_d, sums_d, slots_d, M, C, eps, momentum,
+                                             (float*)workspace, st);
     if (dtype == PRIMIA_BF16)
         return bn_fwd_train_pair_impl<bf16>(y2, yd, z, relu_mask, gamma2, beta2, running_mean2, running_var2, save_mean2,
                                             save_invstd2, sums2, slots2, gamma_d, beta_d, running_mean_d, running_var_d,
-                                            save_mean_d, save_invstd_d, M, C, eps, momentum, (float*)workspace, st);
+                                            save_mean_d, save_invstd_d, sums_d, slots_d, M, C, eps, momentum,
+                                            (float*)workspace, st);
     return PRIMIA_ERR_ARG;
 }
 

@@ -39,6 +39,7 @@ struct IgemmParams {
     int accumulate;
     int ntile_n;
     float* stat_sums;  // optional [slots][2][Nd]: per-channel sum and sum of squares of the stored output
+    int stat_tiles;    // 1: stat_sums holds one deterministic partial per pixel tile (written); 0: kStatSlots atomic slots
     int s2_classes;    // data-gradient of a stride-2 conv: dst pixels are processed in 4 parity classes
     int ntm_class;     // pixel tiles per class
     // Transition block (3x3/2 conv1 beside a 1x1/2 downsample, both reading the same x): the downsample's data
@@ -419,7 +420,8 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     // then one atomic per channel per wave — this replaces a full read pass over the conv output.
     T* __restrict__ dst = (T*)p.dst;
     if constexpr (sizeof(T) == 2 && GLDS) {
-        if (!p.stat_sums && !(p.Nd & 7) && BM * (p.accumulate ? BN * 4 : BN * 2) <= STAGES * (BM + BN) * 128) {
+        if ((!p.stat_sums || p.stat_tiles) && !(p.Nd & 7) &&
+            BM * (p.accumulate ? BN * 4 : BN * 2) <= STAGES * (BM + BN) * 128) {
             // bf16, no fused statistics: the tile leaves through LDS as whole 16-byte chunks of its pixel rows (the
             // 8-byte-per-lane stores below are store-issue bound: T21 of the programming guide; the stride-2 classes
             // scatter their rows two pixels apart, which makes it worse).  fp32 staging + ONE rounding when accumulating.
@@ -443,6 +445,12 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
                 }
             }
             __syncthreads();
+            // (forward, stat_tiles): BatchNorm partial sums of the values AS STORED, one deterministic partial per
+            // pixel tile [tm][2][Nd] as the linear-halo kernel emits them — NT is a multiple of CPR, so a thread's 8
+            // channels are the same in every trip
+            float st1[8], st2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) st1[e] = st2[e] = 0.f;
             for (int q = tid; q < BM * CPR; q += NT) {
                 const int row = q / CPR, c8 = q - row * CPR;
                 const long mc = m0 + row;
@@ -470,6 +478,33 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
                     v = *(const u32x4*)(smem + row * rb + ((c8 ^ (row & (CPR - 1))) << 4));
                 }
                 *(u32x4*)gq = v;
+                if (p.stat_sums) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
+                        st1[2 * e] += lo;
+                        st2[2 * e] += lo * lo;
+                        st1[2 * e + 1] += hi;
+                        st2[2 * e + 1] += hi * hi;
+                    }
+                }
+            }
+            if (p.stat_sums) {
+                __syncthreads();                   // the staged rows are dead
+                float* red = (float*)smem;         // [NT / CPR][2][BN]
+                const int grp = tid / CPR, cb = (tid % CPR) * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    red[(grp * 2 + 0) * BN + cb + e] = st1[e];
+                    red[(grp * 2 + 1) * BN + cb + e] = st2[e];
+                }
+                __syncthreads();
+                for (int c = tid; c < 2 * BN; c += NT) {
+                    const int qq = c / BN, cl = c - qq * BN;
+                    float a = 0.f;
+                    for (int g = 0; g < NT / CPR; ++g) a += red[(g * 2 + qq) * BN + cl];
+                    p.stat_sums[((long)tm * 2 + qq) * p.Nd + n0 + cl] = a;
+                }
             }
             return;
         }
@@ -594,7 +629,8 @@ static int dispatch_igemm(const IgemmParams& p, bool stem, hipStream_t st) {
         return launch_igemm<T, 128, 64, 2, 2, 2, false, true>(p, st);
     }
     if ((long)p.Nb * p.Hs * p.Ws * p.Cs >= (1L << 31)) return PRIMIA_ERR_ARG;  // 32-bit element offsets
-    static const char cfg = getenv("PRIMIA_CONV_CFG") ? getenv("PRIMIA_CONV_CFG")[0] : 'e';
+    static const char cfg_env = getenv("PRIMIA_CONV_CFG") ? getenv("PRIMIA_CONV_CFG")[0] : 'e';
+    const char cfg = p.stat_tiles ? 'e' : cfg_env;   // per-tile statistics assume the 128-pixel tile
     const bool wide = p.Nd % 128 == 0;
 #define PRIMIA_IGEMM_CASE(L, BM, WM_, WN_, ST)                                                   \
     case L:                                                                                      \
@@ -653,6 +689,7 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
     p.Md = (long)g.N * g.Ho * g.Wo;
     p.accumulate = 0;
     p.stat_sums = stat_sums;
+    p.stat_tiles = (stat_sums && dtype == PRIMIA_BF16 && !g.stem) ? 1 : 0;
     p.s2_classes = 0;
     p.ntm_class = 0;
     p.src2 = nullptr; p.wt2 = nullptr;
@@ -691,6 +728,8 @@ int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype) {
         const int t = conv3x3_lh_tiles_m(g.N, g.H, g.W, g.C, g.K);
         if (t > 0) return t;
     }
+    // bf16 implicit GEMM: one partial per 128-pixel tile out of its write-back (every tile config in use has BM = 128)
+    if (dtype == PRIMIA_BF16 && !g.stem && g.K % 8 == 0) return (int)(((long)g.N * g.Ho * g.Wo + 127) / 128);
     return kStatSlots;
 }
 
@@ -717,6 +756,7 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
     p.Md = (long)g.N * g.H * g.W;
     p.accumulate = accumulate;
     p.stat_sums = nullptr;
+    p.stat_tiles = 0;
     static const bool no_classes = getenv("PRIMIA_DGRAD_CLASSES") && getenv("PRIMIA_DGRAD_CLASSES")[0] == '0';
     p.s2_classes = (g.stride == 2 && g.H % 2 == 0 && g.W % 2 == 0 && !no_classes) ? 1 : 0;
     p.ntm_class = 0;

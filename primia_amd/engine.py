@@ -472,13 +472,15 @@ class ResNet18Engine:
                                                       device=y2.device)
                 c2 = self.convs[blk.conv2.name]
                 have = self.fuse_stats or blk.conv2.name in self.free_stats
+                cd = self.convs[blk.down.name]
+                have_d = self.fuse_stats or blk.down.name in self.free_stats
                 (sm2, si2), (smd, sid) = self.save[b2], self.save[bd]
                 call("primia_bn_fwd_train_pair", y2, t[p + ".yd"], t[p + ".out"], self.relu_masks[b2],
                      self.views[b2 + ".weight"], self.views[b2 + ".bias"], self.views[b2 + ".running_mean"],
                      self.views[b2 + ".running_var"], sm2, si2, c2.sums if have else None, c2.stat_slots if have else 0,
                      self.views[bd + ".weight"], self.views[bd + ".bias"], self.views[bd + ".running_mean"],
-                     self.views[bd + ".running_var"], smd, sid, y2.shape[0], y2.shape[1], BN_EPS, BN_MOMENTUM, self.bn_ws,
-                     self.bn_ws_bytes, self.dt)
+                     self.views[bd + ".running_var"], smd, sid, cd.sums if have_d else None, cd.stat_slots if have_d else 0,
+                     y2.shape[0], y2.shape[1], BN_EPS, BN_MOMENTUM, self.bn_ws, self.bn_ws_bytes, self.dt)
                 self.num_batches_tracked[b2] += 1
                 self.num_batches_tracked[bd] += 1
                 x = t[p + ".out"]

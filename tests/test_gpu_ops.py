@@ -416,7 +416,7 @@ def test_conv_fwd_fused_bn_stats(cuda, dtype, case):
     wf, _ = prep_weights(desc, w, dtype, cuda, C, need_dgrad=False)
     M = N * desc.Ho * desc.Wo
     y = torch.empty(M, K, dtype=dtype, device=cuda)
-    slots = query("primia_conv_stat_slots")
+    slots = query("primia_conv_stat_slots_for", desc, dt)   # 64 atomic slots (fp32) or one partial per kernel tile
     part = torch.zeros(slots, 2, K, device=cuda)
     call("primia_conv2d_fwd_stats", desc, to_nhwc(x, dtype, cuda), wf, y, part, dt)
     sums = part.double().sum(0).reshape(-1)
@@ -887,7 +887,7 @@ def test_batchnorm_forward_pair_is_bit_identical(cuda, dtype, N, H, C):
         mask = torch.empty(M * C // ch, dtype=torch.uint8, device=cuda)
         if fused:
             call("primia_bn_fwd_train_pair", y2, yd, z, mask, gam2, bet2, rm2, rv2, sm2, si2, None, 0, gamd, betd, rmd, rvd,
-                 smd, sid, M, C, 1e-5, 0.1, ws, ws_bytes, dt)
+                 smd, sid, None, 0, M, C, 1e-5, 0.1, ws, ws_bytes, dt)
         else:
             idn = torch.empty_like(y2)
             call("primia_bn_fwd_train", yd, None, idn, gamd, betd, rmd, rvd, smd, sid, M, C, 1e-5, 0.1, 0, ws, ws_bytes, dt)
