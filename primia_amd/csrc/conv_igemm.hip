@@ -662,6 +662,10 @@ int conv3x3_c64_grid(int N, int H, int W);
 }
 
 // wide 3x3 / stride-1 layers (layer2-4): linear-halo kernel (conv3x3_lh.hip); PRIMIA_LH=0 keeps the implicit GEMM
+static int lh_fwd_maxw() {   // forward only: widest image the linear-halo kernel takes (A/B: PRIMIA_LH_FWD_MAXW)
+    static const int v = getenv("PRIMIA_LH_FWD_MAXW") ? atoi(getenv("PRIMIA_LH_FWD_MAXW")) : 30;
+    return v;
+}
 static bool lh_shape(const ConvGeom& g) {
     return !g.stem && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1;
 }
@@ -702,7 +706,7 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
             const int rc = conv3x3_c64_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, 0, 0, st,
                                                 stat_sums);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
-        } else if (lh_shape(g)) {   // (statistics: per-block partials as well)
+        } else if (lh_shape(g) && g.W <= lh_fwd_maxw()) {   // (statistics: per-block partials as well)
             const int rc = conv3x3_lh_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, g.C, g.K, 0, 0,
                                                st, stat_sums);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
@@ -724,7 +728,7 @@ int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype) {
     ConvGeom g;
     if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
     if (dtype == PRIMIA_BF16 && use_c64(g) && (long)g.N * g.H * g.W * 64 < (1L << 31)) return conv3x3_c64_grid(g.N, g.H, g.W);
-    if (dtype == PRIMIA_BF16 && !use_c64(g) && lh_shape(g)) {
+    if (dtype == PRIMIA_BF16 && !use_c64(g) && lh_shape(g) && g.W <= lh_fwd_maxw()) {
         const int t = conv3x3_lh_tiles_m(g.N, g.H, g.W, g.C, g.K);
         if (t > 0) return t;
     }
