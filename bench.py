@@ -238,7 +238,7 @@ def main():
     conv_ms = sum(d["ms"] for d in agg.values()) / nprof
     conv_fl = sum(d["flops"] for d in agg.values()) / nprof
     traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_v6.json")
+    tpath = os.path.join(ROOT, "profiles", "r01_hbm_traffic_v7.json")
     if os.path.exists(tpath) and a.batch == 256 and a.size == 224 and a.dtype == "bf16":
         # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE x2 per the
         # gfx950 correction, + WRITE_SIZE), collected offline on this exact workload: see the file's _note
