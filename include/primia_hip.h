@@ -111,6 +111,8 @@ int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, 
                            primia_stream_t stream);
 /* ... without atomics (see primia_conv2d_wgrad_ws): workspace from primia_stem_conv_wgrad_ws_bytes (0: this shape
  * takes the accumulate path, dw_acc must then be zeroed by the caller as for primia_stem_conv_wgrad). */
+int primia_stem_conv_wgrad_persample_sqnorm(const void* x_padded, const void* dy, double* sqnorm, int N, int H, int W,
+                                            int dtype, primia_stream_t stream);   /* DP-SGD norm pass, padded input */
 int64_t primia_stem_conv_wgrad_ws_bytes(int N, int H, int W);
 int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_acc, void* ws, int64_t ws_bytes, int N,
                               int H, int W, int dtype, primia_stream_t stream);

@@ -39,7 +39,7 @@ int wgrad_patch_dispatch(const WgradParams& p, hipStream_t st);
 size_t wgrad_patch_ws_bytes(const WgradParams& p);
 // stem (7x7/2) halo kernel on the padded input (stem_conv.hip)
 int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st,
-                             float* ws = nullptr, size_t ws_bytes = 0);
+                             float* ws = nullptr, size_t ws_bytes = 0, double* sqnorm = nullptr);
 size_t stem_wgrad_halo_ws_bytes(int N, int H, int W);   // 0: shape not served by the halo kernel
 // dw tile (kt, tap, ct) = sum over nsplit partial tiles of ws [combo][split][BMK*BNC], in split order
 void wgrad_tile_reduce(const float* ws, float* dw, int nsplit, int combos, int BMK, int BNC, int nkt, int nct, int C,

@@ -388,6 +388,17 @@ extern "C" int primia_stem_conv_wgrad(const void* x_padded, const void* dy, floa
     return stem_conv_wgrad_impl(x_padded, dy, dw_acc, nullptr, 0, N, H, W, dtype, stream);
 }
 
+// DP-SGD norm pass for conv1 on the padded input: sqnorm[n] += ||dW_n||_F^2 (see primia_conv2d_wgrad_persample_sqnorm);
+// PRIMIA_ERR_UNSUPPORTED where the halo kernel does not serve the shape (caller uses the generic form on the
+// unpadded input)
+extern "C" int primia_stem_conv_wgrad_persample_sqnorm(const void* x_padded, const void* dy, double* sqnorm, int N, int H,
+                                                       int W, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(x_padded && dy && sqnorm && N > 0 && H > 0 && W > 0);
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
+    return stem_wgrad_halo_dispatch((const bf16*)x_padded, (const bf16*)dy, nullptr, N, H, W, (hipStream_t)stream, nullptr,
+                                    0, sqnorm);
+}
+
 extern "C" int64_t primia_stem_conv_wgrad_ws_bytes(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0) return PRIMIA_ERR_ARG;
     return (int64_t)stem_wgrad_halo_ws_bytes(N, H, W);

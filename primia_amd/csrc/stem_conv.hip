@@ -340,6 +340,7 @@ struct StemWgParams {
     const bf16* dy;
     float* dw;
     float* ws;      // atomic-free path: one [64][256] fp32 slab per block (or null: atomics into dw)
+    double* sqnorm; // DP-SGD norm pass: one block per image, adds ||dW_n||^2 to sqnorm[blockIdx.x] instead of writing
     int N, Hp, Wp, Ho, Wo;
     int PH, PW, PPI;
     int total, per_block;
@@ -469,6 +470,23 @@ __global__ __launch_bounds__(512) void stem_conv_wgrad_kernel(StemWgParams p) {
     }
 
     // ---- accumulate: lane holds out-chan rows 32*kh + 16*i + 4*fg + j, element r*32 + 16*h + fr ----
+    if (p.sqnorm) {   // per-sample norm pass: this block holds image blockIdx.x's complete gradient
+        double sq = 0.0;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * rq + rr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (r == 7 || 16 * h + fr >= 28) continue;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sq += (double)acc[i][rr][h][j] * (double)acc[i][rr][h][j];
+            }
+        }
+        wave_sqnorm_add(sq, p.sqnorm + blockIdx.x);
+        return;
+    }
     if (p.ws) {   // atomic-free path: the block's whole [64][256] slab (zeros in the padding) to ITS workspace slot
         float* o = p.ws + (long)blockIdx.x * (64 * 256);
 #pragma unroll
@@ -529,7 +547,7 @@ size_t stem_wgrad_halo_ws_bytes(int N, int H, int W) {
 
 // PRIMIA_ERR_UNSUPPORTED -> caller uses the per-tap stem kernel of conv_wgrad.hip
 int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st, float* ws,
-                             size_t ws_bytes) {
+                             size_t ws_bytes, double* sqnorm) {
     if (!stem_wgrad_halo_ok(N, H, W)) return PRIMIA_ERR_UNSUPPORTED;
     StemWgParams p;
     p.xp = xp; p.dy = dy; p.dw = dw;
@@ -537,7 +555,12 @@ int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, i
     p.PH = p.Ho / 8; p.PW = p.Wo / 16; p.PPI = p.PH * p.PW;
     int grid;
     stem_wgrad_geometry(N, H, W, p.total, p.per_block, grid);
-    const bool store = ws && ws_bytes >= (size_t)grid * 64 * 256 * sizeof(float);
+    p.sqnorm = sqnorm;
+    if (sqnorm) {          // one block per image
+        p.per_block = p.PPI;
+        grid = N;
+    }
+    const bool store = !sqnorm && ws && ws_bytes >= (size_t)grid * 64 * 256 * sizeof(float);
     p.ws = store ? ws : nullptr;
     const size_t lds = (size_t)3 * (7 + 16) * 1024;
     static bool attr_set = false;

@@ -767,7 +767,16 @@ class ResNet18Engine:
                 mark(b)
             for name, x, dy in self.dp["wgrads"]:
                 c = self.convs[name]
-                call("primia_conv2d_wgrad_persample_sqnorm", c.desc, x, dy, sq, self.dt)
+                done = False
+                if name == "conv1" and self._stem_padded:   # halo kernel on the padded input, one block per image
+                    S = self.spec.input_size
+                    try:
+                        call("primia_stem_conv_wgrad_persample_sqnorm", self.x0p, dy, sq, N, S, S, self.dt)
+                        done = True
+                    except _lib.PrimiaError:
+                        done = False
+                if not done:
+                    call("primia_conv2d_wgrad_persample_sqnorm", c.desc, x, dy, sq, self.dt)
                 mark(name)
             clip = torch.empty(N, dtype=torch.float32, device=dev)
             call("primia_dp_clip_factors", sq, clip, N, float(max_grad_norm))
@@ -775,7 +784,16 @@ class ResNet18Engine:
             for name, x, dy in self.dp["wgrads"]:
                 c = self.convs[name]
                 call("primia_scale_rows", dy, clip, N, dy.numel() // N, self.dt)
-                call("primia_conv2d_wgrad", c.desc, x, dy, c.acc, self.dt)
+                # the clipped SUM is an ordinary batched weight gradient: atomic-free kernels, and for the stem the
+                # halo kernel on the padded input (118 us instead of 444 us for the per-tap one)
+                if self.wgrad_ws is None:
+                    call("primia_conv2d_wgrad", c.desc, x, dy, c.acc, self.dt)
+                elif name == "conv1" and self._stem_padded:
+                    S = self.spec.input_size
+                    call("primia_stem_conv_wgrad_ws", self.x0p, dy, c.acc, self.wgrad_ws, self.wgrad_ws_bytes, N, S, S,
+                         self.dt)
+                else:
+                    call("primia_conv2d_wgrad_ws", c.desc, x, dy, c.acc, self.wgrad_ws, self.wgrad_ws_bytes, self.dt)
             self._finalize_wgrads()
             for b, (psg, psb) in self.ps_affine.items():
                 call("primia_weighted_colsum", psg, clip, self.gviews[b + ".weight"], N, psg.shape[1])
