@@ -334,6 +334,9 @@ int primia_scale_rows(void* x, const float* s, int N, int64_t elems_per_sample, 
 /* out[c] = sum_n w[n] * x[n][c]. */
 int primia_weighted_colsum(const float* x, const float* w, float* out, int N, int C,
                            primia_stream_t stream);
+/* `count` such sums in one launch: xs_dev / outs_dev are DEVICE arrays of `count` pointers, widths_dev of `count` ints */
+int primia_weighted_colsum_many(const void* xs_dev, const float* w, const void* outs_dev, const int* widths_dev, int count,
+                                int max_width, int N, primia_stream_t stream);
 /* ps[n] = [dy[n]^T x[n] flattened (out_f*in_f) | dy[n] (out_f)]: per-sample gradients of nn.Linear. */
 int primia_fc_persample_grads(const float* x, const float* dy, float* ps, int N, int in_f, int out_f,
                               primia_stream_t stream);

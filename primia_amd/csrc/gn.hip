@@ -275,6 +275,28 @@ __global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __res
     }
 }
 
+// the same for `count` (x, out, C) jobs in one launch (blockIdx.y = job): the 42 tiny launches of a DP-SGD step
+__global__ __launch_bounds__(256) void weighted_colsum_many_kernel(const float* const* __restrict__ xs,
+                                                                   const float* __restrict__ w,
+                                                                   float* const* __restrict__ outs,
+                                                                   const int* __restrict__ Cs, int N) {
+    __shared__ double part[16][17];
+    const int job = blockIdx.y, C = Cs[job];
+    if ((int)blockIdx.x * 16 >= C) return;
+    const float* __restrict__ x = xs[job];
+    const int cl = threadIdx.x & 15, rs = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0;
+    if (c < C)
+        for (int n = rs; n < N; n += 16) s += (double)w[n] * (double)x[(long)n * C + c];
+    part[rs][cl] = s;
+    __syncthreads();
+    if (rs == 0 && c < C) {
+        for (int k = 1; k < 16; ++k) s += part[k][cl];
+        outs[job][c] = (float)s;
+    }
+}
+
 // ps[n] = [ outer(dy[n], x[n]) (out_f x in_f) | dy[n] (out_f) ]: per-sample fc gradients
 __global__ __launch_bounds__(256) void fc_persample_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                            float* __restrict__ ps, int N, int in_f, int out_f) {
@@ -418,6 +440,15 @@ int primia_scale_rows(void* x, const float* s, int N, int64_t elems_per_sample, 
 int primia_weighted_colsum(const float* x, const float* w, float* out, int N, int C, primia_stream_t stream) {
     PRIMIA_REQUIRE(x && w && out && N > 0 && C > 0);
     weighted_colsum_kernel<<<(C + 15) / 16, 256, 0, (hipStream_t)stream>>>(x, w, out, N, C);
+    return launch_status();
+}
+
+int primia_weighted_colsum_many(const void* xs_dev, const float* w, const void* outs_dev, const int* widths_dev, int count,
+                                int max_width, int N, primia_stream_t stream) {
+    if (count == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(xs_dev && w && outs_dev && widths_dev && count > 0 && max_width > 0 && N > 0);
+    weighted_colsum_many_kernel<<<dim3((max_width + 15) / 16, count), 256, 0, (hipStream_t)stream>>>(
+        (const float* const*)xs_dev, w, (float* const*)outs_dev, widths_dev, N);
     return launch_status();
 }
 

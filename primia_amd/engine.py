@@ -795,9 +795,18 @@ class ResNet18Engine:
                 else:
                     call("primia_conv2d_wgrad_ws", c.desc, x, dy, c.acc, self.wgrad_ws, self.wgrad_ws_bytes, self.dt)
             self._finalize_wgrads()
-            for b, (psg, psb) in self.ps_affine.items():
-                call("primia_weighted_colsum", psg, clip, self.gviews[b + ".weight"], N, psg.shape[1])
-                call("primia_weighted_colsum", psb, clip, self.gviews[b + ".bias"], N, psb.shape[1])
+            # clipped sums of the per-sample affine gradients: all 40 (dgamma, dbeta) pairs in ONE launch
+            if getattr(self, "_colsum_many", None) is None:
+                xs, outs, ws_ = [], [], []
+                for b, (psg, psb) in self.ps_affine.items():
+                    xs += [psg.data_ptr(), psb.data_ptr()]
+                    outs += [self.gviews[b + ".weight"].data_ptr(), self.gviews[b + ".bias"].data_ptr()]
+                    ws_ += [psg.shape[1], psb.shape[1]]
+                self._colsum_many = (torch.tensor(xs, dtype=torch.int64, device=dev),
+                                     torch.tensor(outs, dtype=torch.int64, device=dev),
+                                     torch.tensor(ws_, dtype=torch.int32, device=dev), len(xs), max(ws_))
+            xs_d, outs_d, ws_d, cnt, mw = self._colsum_many
+            call("primia_weighted_colsum_many", xs_d, clip, outs_d, ws_d, cnt, mw, N)
             call("primia_weighted_colsum", ps_fc[:, :nc * 512].contiguous(), clip, self.gviews["fc.weight"].view(-1), N,
                  nc * 512)
             call("primia_weighted_colsum", ps_fc[:, nc * 512:].contiguous(), clip, self.gviews["fc.bias"], N, nc)
