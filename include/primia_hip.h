@@ -325,6 +325,9 @@ int primia_gn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
 /* sq_acc[n] += sum_j x[n][j]^2 (fp64): per-sample squared gradient norm, accumulated layer by layer. */
 int primia_persample_sqnorm(const float* x, int N, int64_t per_sample, double* sq_acc,
                             primia_stream_t stream);
+/* ... for `count` small tensors x_k [N][width_k] in one launch (DEVICE arrays of pointers / widths) */
+int primia_persample_sqnorm_many(const void* xs_dev, const int* widths_dev, int count, int N, double* sq_acc,
+                                 primia_stream_t stream);
 /* clip[n] = min(1, max_grad_norm / (sqrt(sq[n]) + 1e-6)). */
 int primia_dp_clip_factors(const double* sq, float* clip, int N, float max_grad_norm,
                            primia_stream_t stream);

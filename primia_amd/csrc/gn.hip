@@ -233,6 +233,23 @@ __global__ __launch_bounds__(256) void persample_sqnorm_kernel(const float* __re
     if (threadIdx.x == 0) atomicAdd(out + n, sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
+// the same for `count` small tensors x_k [N][per_k] in one launch (blockIdx.x = k)
+__global__ __launch_bounds__(256) void persample_sqnorm_many_kernel(const float* const* __restrict__ xs,
+                                                                    const int* __restrict__ pers, double* out) {
+    const int n = blockIdx.y, per = pers[blockIdx.x];
+    const float* p = xs[blockIdx.x] + (long)n * per;
+    double s = 0.0;
+    for (int j = threadIdx.x; j < per; j += 256) {
+        const double v = (double)p[j];
+        s += v * v;
+    }
+    s = wave_sum(s);
+    __shared__ double sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + n, sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
 // clip[n] = min(1, C / (sqrt(sq[n]) + 1e-6))   (pytorch-dp's per-sample clip factor)
 __global__ void dp_clip_factor_kernel(const double* __restrict__ sq, float* __restrict__ clip, int N, float max_norm) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -411,6 +428,15 @@ int primia_persample_sqnorm(const float* x, int N, int64_t per_sample, double* s
     long b = (per_sample + 255) / 256;
     if (b > 64) b = 64;
     persample_sqnorm_kernel<<<dim3((int)b, N), 256, 0, (hipStream_t)stream>>>(x, per_sample, sq_acc);
+    return launch_status();
+}
+
+int primia_persample_sqnorm_many(const void* xs_dev, const int* widths_dev, int count, int N, double* sq_acc,
+                                 primia_stream_t stream) {
+    if (count == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(xs_dev && widths_dev && sq_acc && count > 0 && N > 0);
+    persample_sqnorm_many_kernel<<<dim3(count, N), 256, 0, (hipStream_t)stream>>>((const float* const*)xs_dev, widths_dev,
+                                                                                 sq_acc);
     return launch_status();
 }
 

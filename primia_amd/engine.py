@@ -761,10 +761,18 @@ class ResNet18Engine:
 
             call("primia_persample_sqnorm", ps_fc, N, nc * 512 + nc, sq)
             mark("fc")
-            for b, (psg, psb) in self.ps_affine.items():
-                call("primia_persample_sqnorm", psg, N, psg.shape[1], sq)
-                call("primia_persample_sqnorm", psb, N, psb.shape[1], sq)
-                mark(b)
+            if trace is None:   # all 40 per-sample affine gradients in one launch
+                if getattr(self, "_sqnorm_many", None) is None:
+                    xs = [tt.data_ptr() for pair in self.ps_affine.values() for tt in pair]
+                    ws_ = [tt.shape[1] for pair in self.ps_affine.values() for tt in pair]
+                    self._sqnorm_many = (torch.tensor(xs, dtype=torch.int64, device=dev),
+                                         torch.tensor(ws_, dtype=torch.int32, device=dev), len(xs))
+                call("primia_persample_sqnorm_many", self._sqnorm_many[0], self._sqnorm_many[1], self._sqnorm_many[2], N, sq)
+            else:
+                for b, (psg, psb) in self.ps_affine.items():
+                    call("primia_persample_sqnorm", psg, N, psg.shape[1], sq)
+                    call("primia_persample_sqnorm", psb, N, psb.shape[1], sq)
+                    mark(b)
             for name, x, dy in self.dp["wgrads"]:
                 c = self.convs[name]
                 done = False
