@@ -134,8 +134,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if a.dp:
-        a.no_graph = True  # the DP step draws its noise through torch's generator: launch it eagerly
+    # (the DP step draws its Gaussian noise through torch's default generator, which CUDA-graph capture supports: the
+    # Philox offset advances per replay; if a torch build cannot capture it, the fallback below launches eagerly)
     # The local step is ~190 kernel launches; replaying it as a hipGraph (one per input buffer) removes the host
     # launch cost (7.5 -> 6.3 ms per step).  Only the client-local step is captured: the FedAvg exchange — the one
     # collective of the path — is launched between replays, so every rank count runs the same graphs.
