@@ -421,6 +421,13 @@ int primia_fx_decode(const int64_t* q, float* x, int64_t n, float scale, primia_
  * All tensors int64 unless stated; n = element count.
  * ========================================================================================== */
 
+/* The crypto provider's randomness: n int64 words of ChaCha20 keystream (key k0..k3 little-endian words, 64-bit
+ * nonce, starting at 64-byte block `block0`; 8 words per block).  Replaces the process-seeded Mersenne Twisters the
+ * reference's provider draws triples, masks and FSS seeds from (mpc/beaver.py:31-34,
+ * tensors/interpreters/additive_shared.py:336-365, mpc/fss.py:344-358,495-501).  `out` must be 16-byte aligned. */
+int primia_chacha20_fill(uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3, uint64_t nonce, uint64_t block0,
+                         int64_t* out, int64_t n, primia_stream_t stream);
+
 /* out[i] = a[i] (+|-|*) b[i % nb]  mod 2^64.  nb == n: plain element-wise; nb < n broadcasts b
  * over the leading dims ([HW, C] op [C], additive_shared.py:489-524, beaver.py:33-53). */
 int primia_ring_add(const int64_t* a, const int64_t* b, int64_t* out, int64_t n, int64_t nb,

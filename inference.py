@@ -59,7 +59,14 @@ if __name__ == "__main__":
                         help="encrypted inference with model_owner, data_owner and crypto_provider as three ranks "
                              "(launch with `python -m torch.distributed.run --nproc-per-node 3 inference.py ...`): "
                              "one GPU each over RCCL when three are visible, else all on GPU 0 over gloo")
+    parser.add_argument("--debug_dealer_seed", type=int, default=None,
+                        help="DEBUG ONLY: derive the crypto provider's key from this number (reproducible, hence "
+                             "NOT private); by default the key comes from the OS entropy pool and never leaves the "
+                             "provider")
     cmd_args = parser.parse_args()
+    if cmd_args.debug_dealer_seed is not None:
+        print("WARNING: --debug_dealer_seed makes every mask, triple and FSS key predictable: no confidentiality",
+              file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("primia_amd runs inference on the GPU only (HIP kernels); no GPU visible")
     device = torch.device("cuda:0")
@@ -91,7 +98,8 @@ if __name__ == "__main__":
             # it owns: the weights (party 0), the images (party 1), the architecture (everyone)
             logits = run_three_role(link, architecture_of(sd), size, images.shape[0],
                                     state_dict=sd if link.role == 0 else None,
-                                    images=images.to(device) if link.role == 1 else None, seed=0)
+                                    images=images.to(device) if link.role == 1 else None,
+                                    seed=cmd_args.debug_dealer_seed)
             dist.barrier()
             dist.destroy_process_group()
             if link.role != 1:
@@ -102,9 +110,10 @@ if __name__ == "__main__":
         elif cmd_args.hip_graph:
             from primia_amd.secure import GraphedSecureInference
 
-            model = GraphedSecureInference(sd, device, input_size=size, precision_fractional=16, seed=0)
+            model = GraphedSecureInference(sd, device, input_size=size, precision_fractional=16,
+                                           seed=cmd_args.debug_dealer_seed)
         else:
-            ctx = SecureContext(Dealer(device, seed=0), base=10, precision_fractional=16)
+            ctx = SecureContext(Dealer(device, seed=cmd_args.debug_dealer_seed), base=10, precision_fractional=16)
             model = SecureResNet18(ctx, sd, input_size=size)
         logits = []
         for i in range(0 if cmd_args.three_role else images.shape[0]):

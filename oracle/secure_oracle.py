@@ -395,9 +395,10 @@ def dpf_eval(b, x, key):
 
 
 def split_alpha(alpha, r):
-    """primitives.py:250-251 — alpha additively split mod 2^32: (r, alpha - r mod 2^32)."""
+    """primitives.py:249-251 — alpha additively split mod 2^32 with the mask r: party 0 receives
+    (alpha - r) mod 2^32, party 1 receives r."""
     r = np.asarray(r, U64) & U64(0xFFFFFFFF)
-    return r, (np.asarray(alpha, U64) - r) & U64(0xFFFFFFFF)
+    return (np.asarray(alpha, U64) - r) & U64(0xFFFFFFFF), r
 
 
 def fss_mask(x1_j, x2_j, alpha_j):
@@ -597,15 +598,24 @@ class OracleContext:
         return self.add(self.fpt_matmul(x, wt), b)
 
 
-def secure_resnet_forward(ctx, state_dict, image, blocks=None):
+def share_order(keys):
+    """Order in which model.fix_precision().share() walks a module: every parameter, THEN every buffer
+    (syft/frameworks/torch/hook/hook.py:624-632,738-765 — `parameters()` before `buffers()`).  The 0-dim
+    num_batches_tracked buffers draw nothing: generate_shares sizes its random share with
+    LongTensor(torch.Size([])), an empty tensor (additive_shared.py:352), and eval mode never reads them."""
+    keys = [k for k in keys if not k.endswith("num_batches_tracked")]
+    buf = [k for k in keys if k.endswith("running_mean") or k.endswith("running_var")]
+    return [k for k in keys if k not in buf] + buf
+
+
+def secure_resnet_forward(ctx, state_dict, image, blocks=None, batched_newton=True):
     """inference.py:279-321 on numpy: share every parameter/buffer, share the image, run the
     forward with the stem swap (:289), return the output shares.  state_dict values / image are
-    float32 numpy arrays."""
+    float32 numpy arrays.  batched_newton=False follows the reference's primitive order exactly
+    (newton(running_var) inside every batch_norm call, nn/functional.py:62-69)."""
     p = {}
-    for k, v in state_dict.items():
-        if k.endswith("num_batches_tracked"):
-            continue
-        p[k] = ctx.share(fix_encode(v, ctx.base, ctx.pf))
+    for k in share_order(list(state_dict.keys())):
+        p[k] = ctx.share(fix_encode(state_dict[k], ctx.base, ctx.pf))
     if blocks is None:
         blocks = [(f"layer{li}.{bi}", (2 if (li > 1 and bi == 0) else 1)) for li in range(1, 5) for bi in range(2)]
     x = ctx.share(fix_encode(image, ctx.base, ctx.pf))
@@ -617,12 +627,14 @@ def secure_resnet_forward(ctx, state_dict, image, blocks=None):
         names += [prefix + ".bn1", prefix + ".bn2"]
         if (prefix + ".downsample.0.weight") in p:
             names.append(prefix + ".downsample.1")
-    inv_all = ctx.reciprocal_newton([np.concatenate([p[n + ".running_var"][j] for n in names]) for j in range(2)])
-    inv, off = {}, 0
-    for n in names:
-        k = p[n + ".running_var"][0].size
-        inv[n] = [inv_all[j][off:off + k] for j in range(2)]
-        off += k
+    inv = {n: None for n in names}
+    if batched_newton:
+        inv_all = ctx.reciprocal_newton([np.concatenate([p[n + ".running_var"][j] for n in names]) for j in range(2)])
+        off = 0
+        for n in names:
+            k = p[n + ".running_var"][0].size
+            inv[n] = [inv_all[j][off:off + k] for j in range(2)]
+            off += k
 
     def bn(t, prefix):
         return ctx.batch_norm_eval(t, p[prefix + ".running_mean"], p[prefix + ".running_var"], p[prefix + ".weight"],

@@ -35,22 +35,41 @@ def _empty_like(t):
 
 
 class Dealer:
-    """The crypto provider: generates correlated randomness on the GPU from a seeded generator.
+    """The crypto provider: generates correlated randomness on the GPU.
 
     build_triple (mpc/beaver.py:7-63): a, b uniform int64, c = a∘b, each split into two shares.
     build_fss_keys (mpc/primitives.py:237-253): DIF keys + alpha additively split mod 2^32.
-    """
 
-    def __init__(self, device, seed=0):
+    Randomness is a ChaCha20 keystream (`primia_chacha20_fill`) under a 256-bit key taken from the operating
+    system's entropy pool (`os.urandom`) when the dealer is constructed — never shared, never derived from anything
+    public: the parties' privacy rests on not being able to predict these masks (the request schedule itself IS
+    public).  `seed` is for tests, benchmarks and oracle replay only: it derives the key from the seed
+    (SHA-256), making the whole stream reproducible — and therefore worthless as a secret."""
+
+    def __init__(self, device, seed=None):
+        import hashlib
+        import os
+
         self.device = torch.device(device)
-        self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(seed)
+        self.seeded = seed is not None
+        raw = os.urandom(40) if seed is None else hashlib.sha256(b"primia-dealer-debug-seed:%d" % int(seed)).digest() + bytes(8)
+        self._key = [int.from_bytes(raw[8 * i:8 * i + 8], "little") for i in range(4)]
+        self._nonce = int.from_bytes(raw[32:40], "little")
+        self._block = 0
         self.log = None  # set to a list to record every primitive handed out (tests replay it)
         self.tape = None  # set to a list to keep every primitive ON THE DEVICE (offline phase, see PreloadedDealer)
         self.requests = None  # set to a list to record (method, args) of every request (GraphedSecureInference)
 
     def rand64(self, *shape):
-        return torch.randint(-2 ** 63, 2 ** 63 - 1, shape, dtype=I64, device=self.device, generator=self.gen)
+        out = torch.empty(shape, dtype=I64, device=self.device)
+        n = out.numel()
+        call("primia_chacha20_fill", *self._key, self._nonce, self._block, out, n)
+        self._block += (n + 7) // 8
+        return out
+
+    def rand32(self, *shape):
+        """uniform in [0, 2^32) as int64 (alpha and its mask, mpc/fss.py:346, mpc/primitives.py:249)."""
+        return self.rand64(*shape) & 0xFFFFFFFF
 
     def _split(self, v):
         r = self.rand64(*v.shape)
@@ -83,7 +102,7 @@ class Dealer:
         if self.requests is not None:
             self.requests.append(("dif_keys", (n,), {}))
         dev = self.device
-        alpha = torch.randint(0, 2 ** 32, (n,), dtype=I64, device=dev, generator=self.gen)
+        alpha = self.rand32(n)
         s0 = self.rand64(2, 2, n)
         s0[:, 0] &= 0x7FFFFFFFFFFFFFFF  # randbit: word 0 carries 63 bits (fss.py:495-501)
         bits = torch.empty(32, n, dtype=torch.uint8, device=dev)
@@ -91,9 +110,10 @@ class Dealer:
         cw_s = torch.empty(32, 2, n, dtype=I64, device=dev)
         leaf = torch.empty(33, n, dtype=torch.int32, device=dev)
         call("primia_dif_keygen", alpha, s0, bits, cw_sigma, cw_s, leaf, n)
-        r = torch.randint(0, 2 ** 32, (n,), dtype=I64, device=dev, generator=self.gen)
-        a1 = (alpha - r) & 0xFFFFFFFF
-        keys = [dict(alpha=[r, a1][b], s0=s0[b].contiguous(), bits=bits, cw_sigma=cw_sigma, cw_s=cw_s, cw_leaf=leaf)
+        # primitives.py:249-251: party 0 receives (alpha - mask) mod 2^32, party 1 the mask
+        r = self.rand32(n)
+        a0 = (alpha - r) & 0xFFFFFFFF
+        keys = [dict(alpha=[a0, r][b], s0=s0[b].contiguous(), bits=bits, cw_sigma=cw_sigma, cw_s=cw_s, cw_leaf=leaf)
                 for b in range(2)]
         if self.log is not None:
             self.log.append(("dif", n, alpha.cpu().numpy(), s0.cpu().numpy(), r.cpu().numpy()))
@@ -482,20 +502,32 @@ class SecureContext:
         return self.add(self.fpt_matmul(x, self._each(tr)), b)
 
 
+def share_order(keys):
+    """model.fix_precision().share() walks `parameters()` and then `buffers()` (hook.py:624-632,738-765)."""
+    keys = [k for k in keys if not k.endswith("num_batches_tracked")]
+    buf = [k for k in keys if k.endswith("running_mean") or k.endswith("running_var")]
+    return [k for k in keys if k not in buf] + buf
+
+
 class SecureResNet18:
     """ResNet-18 forward on secret shares — `model.fix_precision().share()` followed by
     `model(data)` in inference.py:279-321, including the stem swap `model.pool, model.relu =
     model.relu, model.pool` (:289): conv1 -> bn1 -> MAXPOOL -> RELU."""
 
-    def __init__(self, ctx: SecureContext, state_dict, input_size=224, blocks=None):
+    def __init__(self, ctx: SecureContext, state_dict, input_size=224, blocks=None, batched_newton=True):
+        """batched_newton=False consumes the provider's primitives in exactly the reference's order (newton(running_var)
+        inside every batch_norm call, nn/functional.py:62-69) — the mode the reference-minted fixtures pin; the
+        default hoists the image-independent iterations of all BatchNorm layers into one batched vector."""
         self.ctx = ctx
         self.input_size = input_size
+        self.batched_newton = batched_newton
         dev = ctx.dealer.device
         self.p = {}
-        # hook.py:626-632,738-765: every parameter AND buffer is encoded and shared
-        for k, v in state_dict.items():
-            if k.endswith("num_batches_tracked"):
-                continue
+        # hook.py:624-632,738-765: every parameter is encoded and shared, THEN every buffer (`parameters()` before
+        # `buffers()`); the 0-dim num_batches_tracked buffers draw no randomness (generate_shares sizes its random
+        # share with LongTensor(torch.Size([])) = an empty tensor, additive_shared.py:352) and are never read.
+        for k in share_order(state_dict.keys()):
+            v = state_dict[k]
             if ctx.party in (None, 0):  # the model owner is party 0 (inference.py:279-283)
                 self.p[k] = ctx.share(ctx.encode(v.to(dev)), owner=0)
             else:
@@ -537,7 +569,7 @@ class SecureResNet18:
 
     def forward_shares(self, x):
         c, p = self.ctx, self.p
-        self._inv = self.precompute_inv()
+        self._inv = self.precompute_inv() if self.batched_newton else {n: None for n in self.bn_prefixes()}
         x = c.conv2d(x, p["conv1.weight"], 2, 3)
         x = self._bn(x, "bn1")
         x = c.max_pool2d_3x3s2(x)      # swapped stem (inference.py:289)
@@ -588,7 +620,7 @@ class GraphedSecureInference:
     the same buffers (the reference's pre-provisioned crypto store, mpc/primitives.py:161-235, refilled
     between requests).  Results are bit-identical to the eager SecureResNet18 fed the same primitives."""
 
-    def __init__(self, state_dict, device, input_size=224, precision_fractional=16, base=10, seed=0, blocks=None):
+    def __init__(self, state_dict, device, input_size=224, precision_fractional=16, base=10, seed=None, blocks=None):
         self.device = torch.device(device)
         self.image = torch.zeros(1, 3, input_size, input_size, dtype=torch.float32, device=self.device)
         self.dealer = Dealer(self.device, seed)
@@ -761,7 +793,7 @@ def party_context(link: PartyLink, precision_fractional=16, base=10):
                          opener=DistOpener(link.parties_group, link.role), party=link.role, link=link)
 
 
-def run_three_role(link: PartyLink, arch, input_size, n_images, state_dict=None, images=None, seed=0, blocks=None,
+def run_three_role(link: PartyLink, arch, input_size, n_images, state_dict=None, images=None, seed=None, blocks=None,
                    precision_fractional=16, base=10):
     """One rank's part of the three-role encrypted inference of inference.py:279-321.
     Party 0 passes `state_dict`, party 1 passes `images` (fp32 [n,3,S,S] on its GPU), the dealer neither;

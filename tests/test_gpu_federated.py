@@ -136,9 +136,10 @@ def test_cli_train_federated_then_inference(tmp_path):
         res = json.loads(out.strip().splitlines()[-1])["Inference Results"]
         assert sorted(res) == ["0", "1"] and all(v in (0, 1, 2) for v in res.values())
     # the same encrypted inference with the three roles as three ranks (all on GPU 0 over gloo here): logits
-    # bit-identical to the in-process run above's, since the dealer seed is the same
+    # bit-identical to the in-process run's under the same (debug) dealer seed
     local, dist3 = str(tmp_path / "local.pt"), str(tmp_path / "dist.pt")
-    base = ["--model_weights", ckpt, "--data_dir", "synthetic", "--num_images", "2", "--cuda", "--encrypted_inference"]
+    base = ["--model_weights", ckpt, "--data_dir", "synthetic", "--num_images", "2", "--cuda", "--encrypted_inference",
+            "--debug_dealer_seed", "0"]
     run(["inference.py"] + base, {"PRIMIA_DUMP_LOGITS": local})
     out = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
                "--master-port", str(29900 + os.getpid() % 90), "inference.py"] + base + ["--three_role"],
