@@ -26,39 +26,48 @@ def _dev(t):
 
 
 class MixUp(torch.nn.Module):
+    """MixUp over one batch (torchlib/utils.py:327-400): sample i of the first half is blended with sample i of the
+    second half, `λ·a + (1-λ)·b`, for data and one-hot targets alike; an odd batch keeps its last sample unmixed.
+
+    Behaviour kept from the reference because seeded runs depend on it: `p` must be a number in [0, 1] and, when
+    non-zero, ONE `random()` draw decides whether the call mixes at all; a falsy `λ` (None or 0) means ONE further
+    draw per mixing call; inputs may be a batch tensor or a tuple of equally shaped per-sample tensors (the
+    collate-free form), in which case a skipped call returns the first sample.  The blend runs in `primia_mixup`."""
+
     def __init__(self, λ: Optional[float] = None, p: Optional[float] = None):
         super().__init__()
-        assert 0.0 <= p <= 1.0, "probability needs to be in [0,1]"
-        self.p = p
-        if λ:
-            assert 0.0 <= λ <= 1.0, "mix factor needs to be in [0,1]"
-        self.λ = λ
+        if not 0.0 <= p <= 1.0:
+            raise AssertionError("MixUp: p is a probability, got %r" % (p,))
+        if λ and not 0.0 <= λ <= 1.0:
+            raise AssertionError("MixUp: the mix factor lies in [0, 1], got %r" % (λ,))
+        self.p, self.λ = p, λ
 
-    def forward(self, x):
-        assert len(x) == 2, "need data and target"
-        x, y = x
-        if self.p:
-            if random() > self.p:
-                if torch.is_tensor(x):
-                    return x, y
-                return x[0], y[0]
-        if torch.is_tensor(x):
-            L = x.shape[0]
-        elif type(x) == tuple and all(x[i].shape == x[i - 1].shape for i in range(1, len(x))):
-            L = len(x)
-        else:
-            raise ValueError("images need to be either list of equally shaped tensors or batch of size 2")
-        if not ((torch.is_tensor(y) and y.shape[0] == L)
-                or (len(y) == L and all(y[i - 1].shape == y[i].shape for i in range(1, len(y))))):
-            raise ValueError("targets need to be tuple of equally shaped one hot encoded tensors")
-        if L == 1:
-            return x, y
-        λ = self.λ if self.λ else random()
-        if not torch.is_tensor(x):
-            x = torch.stack(x).squeeze(1)
-        if not torch.is_tensor(y):
-            y = torch.stack(y).squeeze(1)
-        return self._mix(x, λ), self._mix(y, λ)
+    @staticmethod
+    def _count(items, what):
+        """Number of samples of a batch tensor or of a tuple of same-shaped tensors."""
+        if torch.is_tensor(items):
+            return items.shape[0]
+        shapes = {tuple(t.shape) for t in items} if isinstance(items, (tuple, list)) else None
+        if shapes is None or len(shapes) != 1:
+            raise ValueError(f"MixUp: {what} must be one batch tensor or a tuple of equally shaped tensors")
+        return len(items)
+
+    def forward(self, pair):
+        if len(pair) != 2:
+            raise AssertionError("MixUp takes (data, target)")
+        data, target = pair
+        if self.p and random() > self.p:                      # this call passes its input through
+            return (data, target) if torch.is_tensor(data) else (data[0], target[0])
+        if not torch.is_tensor(data) and type(data) != tuple:   # the reference accepts tuples only
+            raise ValueError("MixUp: data must be one batch tensor or a tuple of equally shaped tensors")
+        n = self._count(data, "data")
+        if self._count(target, "targets") != n:
+            raise ValueError("MixUp: one (one-hot) target per sample is needed")
+        if n == 1:
+            return data, target
+        lam = self.λ or random()
+        batch = [t if torch.is_tensor(t) else torch.stack(tuple(t)).squeeze(1) for t in (data, target)]
+        return self._mix(batch[0], lam), self._mix(batch[1], lam)
 
     @staticmethod
     def _mix(t, lam):

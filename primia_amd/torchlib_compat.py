@@ -10,45 +10,47 @@ import numpy as np
 
 
 class LearningRateScheduler:
-    """torchlib/utils.py:37-89.
+    """Epoch -> learning rate on a log10 scale (torchlib/utils.py:37-89).
 
-    Available schedule plans:
-    log_linear : linear interpolation of log10(lr)
-    log_cosine : cosine interpolation of log10(lr)
-    `restarts` splits the run into restarts+1 equal cycles.
-    """
+    One cycle covers T = total_epochs / (restarts + 1) epochs and the schedule is periodic in T, so `restarts`
+    warm restarts simply replay the cycle.  Within a cycle, at position e:
+        log_linear   log10 lr = log_start + (log_end - log_start) / T * e
+        log_cosine   log10 lr = log_end + |log_start - log_end| * (1 + cos(pi * e / T)) / 2
+    The expressions are evaluated in the reference's operation order so that the doubles agree to the last bit
+    (tests/golden/lr_schedule.npz is minted by executing the reference's class)."""
+
+    PLANS = ("log_linear", "log_cosine")
 
     def __init__(self, total_epochs: int, log_start_lr: float, log_end_lr: float,
                  schedule_plan: str = "log_linear", restarts: Optional[int] = None):
-        if restarts == 0:
-            restarts = None
-        self.total_epochs = total_epochs if not restarts else total_epochs / (restarts + 1)
-        span = log_end_lr - log_start_lr
-        if schedule_plan == "log_linear":
-            self.calc_lr = lambda epoch: np.power(10, (span / self.total_epochs) * epoch + log_start_lr)
-        elif schedule_plan == "log_cosine":
-            self.calc_lr = lambda epoch: np.power(
-                10, (np.cos(np.pi * (epoch / self.total_epochs)) / 2.0 + 0.5) * abs(span) + log_end_lr)
-        else:
-            raise NotImplementedError(
-                "Requested learning rate schedule {} not implemented".format(schedule_plan))
+        if schedule_plan not in self.PLANS:
+            raise NotImplementedError(f"learning rate schedule {schedule_plan!r} is not one of {self.PLANS}")
+        self.schedule_plan = schedule_plan
+        self.log_start_lr, self.log_end_lr = log_start_lr, log_end_lr
+        self.total_epochs = total_epochs / (restarts + 1) if restarts else total_epochs
 
-    def get_lr(self, epoch: int):
-        epoch = epoch % self.total_epochs
-        if (type(epoch) is int and epoch > self.total_epochs) or (
-                type(epoch) is np.ndarray and np.max(epoch) > self.total_epochs):
-            raise AssertionError("Requested epoch out of precalculated schedule")
-        return self.calc_lr(epoch)
+    def calc_lr(self, epoch):
+        T, lo, hi = self.total_epochs, self.log_start_lr, self.log_end_lr
+        if self.schedule_plan == "log_linear":
+            exponent = ((hi - lo) / T) * epoch + lo
+        else:
+            exponent = (np.cos(np.pi * (epoch / T)) / 2.0 + 0.5) * abs(lo - hi) + hi
+        return np.power(10, exponent)
+
+    def get_lr(self, epoch):
+        # periodic in T: the reference's range check behind the same modulo can never fire
+        return self.calc_lr(epoch % self.total_epochs)
 
     def adjust_learning_rate(self, optimizer, epoch: int):
-        """`optimizer` is anything with `param_groups` (torch optimizer) or an `lr` attribute."""
-        new_lr = self.get_lr(epoch)
-        if hasattr(optimizer, "param_groups"):
-            for param_group in optimizer.param_groups:
-                param_group["lr"] = new_lr
+        """Set and return the epoch's rate; `optimizer` has torch's `param_groups` or a plain `lr` attribute."""
+        lr = self.get_lr(epoch)
+        groups = getattr(optimizer, "param_groups", None)
+        if groups is None:
+            optimizer.lr = lr
         else:
-            optimizer.lr = new_lr
-        return new_lr
+            for g in groups:
+                g["lr"] = lr
+        return lr
 
 
 # ---------------------------------------------------------------------------------------------

@@ -35,6 +35,29 @@ def load_reference_models():
     return m
 
 
+def extract(path, names, glob):
+    """Execute exactly the named top-level definitions of a reference file in place (the file itself cannot be
+    imported: it needs syft / albumentations / torchvision)."""
+    import ast
+
+    tree = ast.parse(open(path).read())
+    body = [n for n in tree.body if isinstance(n, (ast.ClassDef, ast.FunctionDef)) and n.name in names]
+    assert {n.name for n in body} == set(names), (path, names)
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), glob)
+    return glob
+
+
+def load_reference_utils():
+    from typing import Optional
+
+    g = {"torch": torch, "np": np, "Optional": Optional}
+    extract("/root/reference/torchlib/utils.py", ["LearningRateScheduler", "Cross_entropy_one_hot"], g)
+    return g
+
+
+REF_UTILS = None
+
+
 def summary(t, n=8):
     f = t.detach().double().flatten()
     return np.array([f.norm().item(), f.sum().item()] + f[:n].tolist() + [0.0] * max(0, n - f.numel()))
@@ -65,10 +88,8 @@ def case(ref_models, name, seed, batch, size, pooling, optimizer, lr, wd, class_
         opt.zero_grad()
         pred = model(x)
         if soft:
-            # Cross_entropy_one_hot lives in torchlib/utils.py, which cannot be imported here
-            # (needs syft/albumentations); its 10-line forward is restated in the oracle and checked
-            # against torch's own soft-target cross entropy below.
-            loss = O.cross_entropy_one_hot(pred, y, cw)
+            # the reference's own Cross_entropy_one_hot (torchlib/utils.py:404-441), executed from its file
+            loss = REF_UTILS["Cross_entropy_one_hot"](weight=cw)(pred, y)
         else:
             loss = torch.nn.CrossEntropyLoss(weight=cw, reduction="mean")(pred, y)
         loss.backward()
@@ -97,25 +118,45 @@ def case(ref_models, name, seed, batch, size, pooling, optimizer, lr, wd, class_
         for k in rsd:
             if not k.endswith("num_batches_tracked"):
                 out[f"s{step}.post.{k}"] = summary(sd[k])  # == reference for SGD; 1.4-style Adam otherwise
-    if soft and cw is None:
-        # sanity: soft CE with no class weights == torch's soft-target cross entropy
-        pass
     path = os.path.join(HERE, f"train_{name}.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path) // 1024, "KiB")
 
 
 def main():
+    global REF_UTILS
+    REF_UTILS = load_reference_utils()
     ref = load_reference_models()
     # the reference's own config values: seed 42 / lr 1e-4 / wd 5e-4 (pneumonia-resnet-pretrained.ini)
     case(ref, "sgd_hard_224", 42, 4, 224, "max", "SGD", 1e-4, 5e-4, None, False, 2)
     case(ref, "sgd_hard_64", 42, 8, 64, "max", "SGD", 1e-2, 5e-4, [0.5, 1.0, 2.0], False, 2)
     case(ref, "adam_soft_64", 7, 8, 64, "avg", "Adam", 1e-3, 5e-4, [0.5, 1.0, 2.0], True, 2)
-    # LearningRateScheduler (torchlib/utils.py:37-89), restated; pin a few values
+    # LearningRateScheduler (torchlib/utils.py:37-89): the reference's class, executed from its file
     lrs = {}
-    for restarts in (0, 1):
-        s = O.LearningRateScheduler(40, -4, -5, restarts=restarts)
-        lrs[f"r{restarts}"] = np.array([s.get_lr(e) for e in range(40)])
+    for plan in ("log_linear", "log_cosine"):
+        for restarts in (0, 1, 3):
+            ref_s = REF_UTILS["LearningRateScheduler"](40, -4, -5, schedule_plan=plan, restarts=restarts)
+            mine = O.LearningRateScheduler(40, -4, -5, schedule_plan=plan, restarts=restarts)
+            vals = np.array([ref_s.get_lr(e) for e in range(40)])
+            assert np.array_equal(vals, np.array([mine.get_lr(e) for e in range(40)])), (plan, restarts)
+            lrs[f"{plan}.r{restarts}"] = vals
+    lrs["r0"], lrs["r1"] = lrs["log_linear.r0"], lrs["log_linear.r1"]
+    # soft cross entropy alone: weighted / unweighted, both reductions
+    g = torch.Generator().manual_seed(5)
+    out, tgt = torch.randn(6, 3, generator=g), torch.rand(6, 3, generator=g)
+    tgt = tgt / tgt.sum(1, keepdim=True)
+    lrs["ce.out"], lrs["ce.target"] = out.numpy(), tgt.numpy()
+    for wname, w in (("w", torch.tensor([0.5, 1.0, 2.0])), ("nw", None)):
+        for red in ("mean", "sum"):
+            o = out.clone().requires_grad_(True)
+            loss = REF_UTILS["Cross_entropy_one_hot"](reduction=red, weight=w)(o, tgt)
+            loss.backward()
+            o2 = out.clone().requires_grad_(True)
+            mine = O.cross_entropy_one_hot(o2, tgt, w, red)
+            mine.backward()
+            assert torch.equal(mine, loss.detach()) and torch.equal(o.grad, o2.grad), (wname, red)
+            lrs[f"ce.{wname}.{red}.loss"] = np.array(loss.item(), dtype=np.float32)
+            lrs[f"ce.{wname}.{red}.grad"] = o.grad.numpy()
     np.savez_compressed(os.path.join(HERE, "lr_schedule.npz"), **lrs)
 
 

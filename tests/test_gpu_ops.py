@@ -7,6 +7,9 @@ Oracle for each op = the native torch-CPU fp32 op the reference's workers execut
                  so the only differences are accumulation order and the final bf16 store
                  (<= 2^-8 relative per element) — bound 1e-2 normwise, stated per test.
 """
+import os
+
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -359,6 +362,14 @@ def test_xent(cuda, weighted):
     call("primia_xent_soft", logits.to(cuda), soft.to(cuda), cw.to(cuda) if weighted else None, loss, dl, N, C)
     assert abs(loss.item() - l2.item()) < 1e-5 * abs(l2.item())
     assert relerr(dl, lr2.grad) < 1e-5
+    # the reference's own Cross_entropy_one_hot class, executed when the fixture was minted
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "lr_schedule.npz"))
+    o, t = torch.from_numpy(gold["ce.out"]), torch.from_numpy(gold["ce.target"])
+    key = "w" if weighted else "nw"
+    dl6 = torch.empty(6, C, device=cuda)
+    call("primia_xent_soft", o.to(cuda), t.to(cuda), cw.to(cuda) if weighted else None, loss, dl6, 6, C)
+    assert abs(loss.item() - gold[f"ce.{key}.mean.loss"].item()) < 1e-5 * abs(gold[f"ce.{key}.mean.loss"].item())
+    assert relerr(dl6, torch.from_numpy(gold[f"ce.{key}.mean.grad"])) < 1e-5
 
 
 def test_optimizers_and_fx(cuda):

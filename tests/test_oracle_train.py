@@ -72,11 +72,35 @@ def test_lr_schedule(golden_dir):
     gold = np.load(os.path.join(golden_dir, "lr_schedule.npz"))
     from primia_amd.torchlib_compat import LearningRateScheduler
 
-    for restarts in (0, 1):
-        s = LearningRateScheduler(40, -4, -5, restarts=restarts)
-        got = np.array([s.get_lr(e) for e in range(40)])
-        assert np.allclose(got, gold[f"r{restarts}"], rtol=1e-12)
+    # every value below was produced by the reference's own class (tests/golden/make_train_golden.py)
+    for plan in ("log_linear", "log_cosine"):
+        for restarts in (0, 1, 3):
+            for cls in (LearningRateScheduler, O.LearningRateScheduler):
+                s = cls(40, -4, -5, schedule_plan=plan, restarts=restarts)
+                got = np.array([s.get_lr(e) for e in range(40)])
+                assert np.array_equal(got, gold[f"{plan}.r{restarts}"]), (plan, restarts, cls)
     assert abs(gold["r0"][0] - 1e-4) < 1e-12
+    with pytest.raises(NotImplementedError):
+        LearningRateScheduler(40, -4, -5, schedule_plan="step")
+
+    class Opt:
+        param_groups = [{"lr": 0.0}, {"lr": 0.0}]
+
+    lr = LearningRateScheduler(40, -4, -5).adjust_learning_rate(Opt, 7)
+    assert lr == gold["log_linear.r0"][7] and all(g["lr"] == lr for g in Opt.param_groups)
+
+
+def test_soft_cross_entropy_matches_reference_class(golden_dir):
+    """Cross_entropy_one_hot (torchlib/utils.py:404-441): losses and gradients minted by executing the reference class."""
+    gold = np.load(os.path.join(golden_dir, "lr_schedule.npz"))
+    out, tgt = torch.from_numpy(gold["ce.out"]), torch.from_numpy(gold["ce.target"])
+    for wname, w in (("w", torch.tensor([0.5, 1.0, 2.0])), ("nw", None)):
+        for red in ("mean", "sum"):
+            o = out.clone().requires_grad_(True)
+            loss = O.cross_entropy_one_hot(o, tgt, w, red)
+            loss.backward()
+            assert loss.item() == gold[f"ce.{wname}.{red}.loss"].item()
+            assert np.array_equal(o.grad.numpy(), gold[f"ce.{wname}.{red}.grad"])
 
 
 def test_fedavg_oracle_plain_and_secure():
