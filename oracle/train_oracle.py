@@ -43,9 +43,13 @@ def _bn(x, sd, prefix, training, momentum=0.1, eps=1e-5):
     return out
 
 
-def forward(sd, x, training=True, pooling="max", input_size=224, taps=None):
+def forward(sd, x, training=True, pooling="max", input_size=224, taps=None, relu_masks=None):
     """ResNet._forward_impl (models.py:466-482).  `sd` maps reference state-dict keys to tensors
-    (parameters may require grad).  `taps`, if a dict, receives named intermediates."""
+    (parameters may require grad).  `taps`, if a dict, receives named intermediates.
+    `relu_masks` (tests only): {site: bool NCHW mask} — at the named ReLU sites ("stem.z", "<block>.a1",
+    "<block>.out") the activation is `pre * mask` instead of relu(pre).  With the masks another implementation
+    produced, the backward pass follows that implementation's branch at pre-activations that are zero up to
+    rounding, which makes gradients comparable at fp32 accuracy (a ReLU gradient is discontinuous there)."""
 
     def tap(name, v):
         if taps is not None:
@@ -54,8 +58,13 @@ def forward(sd, x, training=True, pooling="max", input_size=224, taps=None):
             taps[name] = v
         return v
 
+    def relu(name, pre):
+        if relu_masks is not None and name in relu_masks:
+            return pre * relu_masks[name].to(pre.dtype)
+        return F.relu(pre)
+
     x = tap("stem.y", F.conv2d(x, sd["conv1.weight"], None, 2, 3))
-    x = tap("stem.z", F.relu(_bn(x, sd, "bn1", training)))
+    x = tap("stem.z", relu("stem.z", _bn(x, sd, "bn1", training)))
     if pooling == "max":
         x = F.max_pool2d(x, 3, 2, 1)
     else:
@@ -67,13 +76,13 @@ def forward(sd, x, training=True, pooling="max", input_size=224, taps=None):
             s = stride if bi == 0 else 1
             identity = x
             out = tap(p + ".y1", F.conv2d(x, sd[p + ".conv1.weight"], None, s, 1))
-            out = tap(p + ".a1", F.relu(_bn(out, sd, p + ".bn1", training)))
+            out = tap(p + ".a1", relu(p + ".a1", _bn(out, sd, p + ".bn1", training)))
             out = tap(p + ".y2", F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1))
             out = _bn(out, sd, p + ".bn2", training)
             if (p + ".downsample.0.weight") in sd:
                 identity = F.conv2d(x, sd[p + ".downsample.0.weight"], None, s, 0)
                 identity = _bn(identity, sd, p + ".downsample.1", training)
-            x = tap(p + ".out", F.relu(out + identity))
+            x = tap(p + ".out", relu(p + ".out", out + identity))
     x = F.avg_pool2d(x, int(input_size / 32))
     x = torch.flatten(x, 1)
     return F.linear(x, sd["fc.weight"], sd["fc.bias"])

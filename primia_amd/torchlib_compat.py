@@ -235,6 +235,11 @@ def aggregation(local_model, models, workers, crypto_provider, args, test_params
         out.copy_(tmp)
     if not weights:
         _lib.call("primia_divide", out, n, float(len(ids)))
+    # `fresh_state_dict` carries no num_batches_tracked (utils.py:1040) and is a plain dict, so load_state_dict takes
+    # BatchNorm's version-1 path, which under the reference's torch 1.4 (environment_torch.yml:98) re-creates the
+    # counter as 0; send_new_models then hands that 0 to every worker model with the rest of the state dict.
+    for b in local_model.num_batches_tracked:
+        local_model.num_batches_tracked[b] = 0
     local_model.refresh_weights()
     return local_model
 
@@ -245,6 +250,7 @@ def send_new_models(local_model, models):
         if worker == "local_model":
             continue
         m.flat.copy_(local_model.flat)
+        m.num_batches_tracked.update(local_model.num_batches_tracked)
         m.refresh_weights()
     return models
 

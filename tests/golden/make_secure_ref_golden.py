@@ -153,6 +153,81 @@ def mint_forward():
     print("secure_ref_forward.npz written")
 
 
+def fedavg_inputs(K=3):
+    """K tiny client state dicts with the key mix of a real model (weights, BN buffers, num_batches_tracked)."""
+    from collections import OrderedDict
+
+    g = torch.Generator().manual_seed(77)
+    sds = []
+    for k in range(K):
+        sds.append(OrderedDict([
+            ("conv.weight", torch.randn(4, 3, 3, 3, generator=g) * 0.2),
+            ("bn.weight", torch.rand(4, generator=g) + 0.5),
+            ("bn.bias", torch.randn(4, generator=g) * 0.1),
+            ("bn.running_mean", torch.randn(4, generator=g) * 0.1),
+            ("bn.running_var", torch.rand(4, generator=g) + 0.5),
+            ("bn.num_batches_tracked", torch.tensor(5 + k)),
+            ("fc.weight", torch.randn(3, 4, generator=g) * 5.0),       # larger magnitudes too
+            ("fc.bias", torch.tensor([0.0, -1e-4, 123.456])),
+        ]))
+    return sds
+
+
+class TinyNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(3, 4, 3, bias=False)
+        self.bn = torch.nn.BatchNorm2d(4)
+        self.fc = torch.nn.Linear(4, 3)
+
+
+def mint_fedavg():
+    """aggregation() of torchlib/utils.py:1000-1092, executed from its file: plain and secure (fix_prec -> share
+    between the K workers -> stack -> sum -> get -> float_prec), unweighted and weighted."""
+    from collections import Counter
+    from types import SimpleNamespace
+
+    from oracle import train_oracle as O
+
+    out = {}
+    ids = ["alice", "bob", "charlie"]
+    sds = fedavg_inputs(len(ids))
+    for k, sd in enumerate(sds):
+        for key, v in sd.items():
+            out[f"in{k}/{key}"] = v.numpy()
+    wts = {"alice": 0.2, "bob": 0.3, "charlie": 0.5}
+    for secure in (False, True):
+        for weighted in (False, True):
+            for pf in ((3, 16) if secure else (0,)):
+                rt = R.Runtime(parties=tuple(ids))
+                g = {"torch": R.torch_namespace(rt), "np": np, "Counter": Counter}
+                R._extract("/root/reference/torchlib/utils.py", ["aggregation"], g)
+                torch.manual_seed(1)
+                np.random.seed(1)
+                local = TinyNet()
+                local.bn.num_batches_tracked.fill_(9)
+                models = {i: R.RemoteModel(rt, sd) for i, sd in zip(ids, sds)}
+                args = SimpleNamespace(precision_fractional=pf)
+                res = g["aggregation"](local, models, ids, rt.local_worker, args, None,
+                                       weights=wts if weighted else None, secure=secure)
+                got = res.state_dict()
+                mine = (O.fedavg_secure(sds, [wts[i] for i in ids] if weighted else None, pf) if secure
+                        else O.fedavg_plain(sds, [wts[i] for i in ids] if weighted else None))
+                tag = f"{'secure' if secure else 'plain'}.{'w' if weighted else 'u'}.p{pf}"
+                for key, v in got.items():
+                    if key.endswith("num_batches_tracked"):
+                        # load_state_dict of a plain dict without the key: BatchNorm's version-1 path fills it in —
+                        # with 0 under the reference's torch 1.4, with the module's current value under torch 2
+                        assert int(v) in (0, 9)
+                        continue
+                    assert torch.equal(mine[key], v), (tag, key)
+                    out[f"{tag}/{key}"] = v.numpy()
+                print(f"  fedavg {tag}: oracle bit-identical")
+    np.savez_compressed(os.path.join(HERE, "fedavg_ref.npz"), **out)
+    print("fedavg_ref.npz written")
+
+
 if __name__ == "__main__":
+    mint_fedavg()
     mint_ops()
     mint_forward()

@@ -176,6 +176,13 @@ class AbstractTensor:
     def __neg__(self):
         return self * -1
 
+    def get(self):
+        # syft/generic/abstract/tensor.py: fetch the child and keep this tensor type on top
+        return type(self)(**self.get_class_attributes()).on(self.child.get(), wrap=False)
+
+    def float_prec(self):
+        return self.float_precision()
+
     def __getattr__(self, name):
         # TorchHook gives every syft tensor type the torch.Tensor methods it does not define itself: the
         # call is forwarded to .child (to every share of an AdditiveSharingTensor) and the result re-wrapped
@@ -553,6 +560,64 @@ class Runtime:
                 torch.flatten = saved_flatten
 
         return ctx()
+
+
+class RemoteTensor:
+    """A float tensor that lives on a training worker, as the orchestrator sees it (a PointerTensor wrapper): every
+    method runs "there"; `.get()` brings the value home."""
+
+    def __init__(self, rt, value):
+        self.rt, self.value = rt, value
+
+    @property
+    def shape(self):
+        return self.value.shape
+
+    @property
+    def data(self):
+        return self
+
+    def copy(self):
+        return RemoteTensor(self.rt, self.value.clone())
+
+    def __mul__(self, w):
+        return RemoteTensor(self.rt, self.value * w)
+
+    def get(self):
+        return self.value
+
+    def fix_prec(self, precision_fractional=3, **kw):
+        fpt = self.rt.FPT(owner=self.rt.local_worker, base=10, precision_fractional=precision_fractional, dtype="long")
+        return RemoteTensor(self.rt, fpt.on(self.value.clone(), wrap=False).fix_precision())
+
+    def share(self, *owners, crypto_provider=None, protocol="snn", **kw):
+        return RemoteTensor(self.rt, self.value.share(*owners, protocol=protocol, crypto_provider=crypto_provider))
+
+
+class RemoteModel:
+    def __init__(self, rt, state_dict):
+        from collections import OrderedDict
+
+        self._sd = OrderedDict((k, RemoteTensor(rt, v)) for k, v in state_dict.items())
+
+    def state_dict(self):
+        return self._sd
+
+
+def torch_namespace(rt):
+    """The `torch` the extracted aggregation() sees: stack / sum routed like TorchHook routes them for
+    FixedPrecisionTensor arguments (AdditiveSharingTensor.torch.stack, additive_shared.py:813-818; sum is the
+    per-share method)."""
+    def stack(tensors, **kw):
+        if isinstance(tensors[0], rt.FPT):
+            ast_ = rt.AST.torch.stack([t.child for t in tensors], **kw)
+            return rt.FPT(**tensors[0].get_class_attributes()).on(ast_, wrap=False)
+        return torch.stack(tensors, **kw)
+
+    def sum_(x, **kw):
+        return x.sum(**kw) if isinstance(x, rt.FPT) else torch.sum(x, **kw)
+
+    return types.SimpleNamespace(stack=stack, sum=sum_)
 
 
 def load_reference_models():

@@ -164,3 +164,43 @@ def test_bench_two_ranks_control_flow(tmp_path):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["clients"] == 2
     assert d["hip_graph"] is True   # the local step is replayed as a graph at every rank count, the exchange is not
     assert d["value"] > 0 and abs(d["value"] - 2 * d["images_per_sec_per_client"]) < 1e-3 * d["value"]
+
+
+def test_aggregation_kernels_match_reference_aggregation(cuda, golden_dir):
+    """torchlib_compat.aggregation (scale / fx_encode / ring_add / fx_decode / divide kernels on a flat arena) against
+    the outputs of the reference's own aggregation() (tests/golden/fedavg_ref.npz).  Secure path: bit-exact; plain
+    path: 1e-6 (the reference sums a stacked tensor, the arena accumulates client by client)."""
+    import numpy as np
+    from types import SimpleNamespace
+
+    from primia_amd.torchlib_compat import aggregation
+
+    z = np.load(os.path.join(golden_dir, "fedavg_ref.npz"))
+    keys = [k.split("/", 1)[1] for k in z.files if k.startswith("in0/") and not k.endswith("num_batches_tracked")]
+    ids = ["alice", "bob", "charlie"]
+
+    class Arena:
+        def __init__(self, flat):
+            self.flat, self.num_batches_tracked = flat, {"bn": 7}
+
+        def refresh_weights(self):
+            pass
+
+    def flat_of(c):
+        return torch.cat([torch.from_numpy(z[f"in{c}/{k}"]).reshape(-1) for k in keys]).to(cuda)
+
+    w = {"alice": 0.2, "bob": 0.3, "charlie": 0.5}
+    for tag, secure, weights, pf in (("plain.u.p0", False, None, 16), ("plain.w.p0", False, w, 16),
+                                     ("secure.u.p3", True, None, 3), ("secure.u.p16", True, None, 16),
+                                     ("secure.w.p3", True, w, 3), ("secure.w.p16", True, w, 16)):
+        models = {i: Arena(flat_of(c)) for c, i in enumerate(ids)}
+        local = Arena(torch.zeros_like(models["alice"].flat))
+        aggregation(local, models, ids, None, SimpleNamespace(precision_fractional=pf), None, weights=weights,
+                    secure=secure)
+        want = torch.cat([torch.from_numpy(z[f"{tag}/{k}"]).reshape(-1) for k in keys])
+        got = local.flat.cpu()
+        if secure:
+            assert torch.equal(got, want), tag
+        else:
+            assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), tag
+        assert local.num_batches_tracked == {"bn": 0}

@@ -117,3 +117,26 @@ def test_fedavg_oracle_plain_and_secure():
     for pf in (16, 3):
         sec = O.fedavg_secure(sds, None, pf)
         assert torch.allclose(sec["a"], plain["a"], atol=10.0 ** -pf * 3 + 1e-7)
+
+
+def _fedavg_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "fedavg_ref.npz"))
+    keys = [k.split("/", 1)[1] for k in z.files if k.startswith("in0/")]
+    sds = [OrderedDict((k, torch.from_numpy(z[f"in{c}/{k}"])) for k in keys) for c in range(3)]
+    return z, keys, sds
+
+
+def test_fedavg_oracle_matches_reference_aggregation(golden_dir):
+    """aggregation() of torchlib/utils.py:1000-1092 was EXECUTED (plain and secure, unweighted and weighted, K = 3
+    workers sharing between themselves) when tests/golden/fedavg_ref.npz was minted; the oracle must agree bit for bit."""
+    z, keys, sds = _fedavg_fixture(golden_dir)
+    w = [0.2, 0.3, 0.5]
+    for tag, fn in (("plain.u.p0", lambda: O.fedavg_plain(sds)), ("plain.w.p0", lambda: O.fedavg_plain(sds, w)),
+                    ("secure.u.p3", lambda: O.fedavg_secure(sds, None, 3)), ("secure.u.p16", lambda: O.fedavg_secure(sds, None, 16)),
+                    ("secure.w.p3", lambda: O.fedavg_secure(sds, w, 3)), ("secure.w.p16", lambda: O.fedavg_secure(sds, w, 16))):
+        got = fn()
+        for k in keys:
+            if k.endswith("num_batches_tracked"):
+                assert k not in got
+                continue
+            assert np.array_equal(got[k].numpy(), z[f"{tag}/{k}"]), (tag, k)
