@@ -43,9 +43,25 @@ def _bn(x, sd, prefix, training, momentum=0.1, eps=1e-5):
     return out
 
 
-def forward(sd, x, training=True, pooling="max", input_size=224, taps=None, relu_masks=None):
+class _StoreBF16(torch.autograd.Function):
+    """A tensor that is STORED in bf16: the value is rounded on the way forward and its gradient on the way back
+    (what a bf16 activation / activation-gradient buffer does to an fp32-accumulated result)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.bfloat16().to(x.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.bfloat16().to(g.dtype)
+
+
+def forward(sd, x, training=True, pooling="max", input_size=224, taps=None, relu_masks=None, bf16_storage=False):
     """ResNet._forward_impl (models.py:466-482).  `sd` maps reference state-dict keys to tensors
     (parameters may require grad).  `taps`, if a dict, receives named intermediates.
+    `bf16_storage` (tests only): model the bf16 engine's storage format — the input, every convolution output, every
+    block activation and the compute copies of the conv weights are rounded to bf16 where the engine keeps them in
+    bf16 buffers (fp32 accumulation, BatchNorm statistics and the master weights stay fp32).
     `relu_masks` (tests only): {site: bool NCHW mask} — at the named ReLU sites ("stem.z", "<block>.a1",
     "<block>.out") the activation is `pre * mask` instead of relu(pre).  With the masks another implementation
     produced, the backward pass follows that implementation's branch at pre-activations that are zero up to
@@ -63,26 +79,27 @@ def forward(sd, x, training=True, pooling="max", input_size=224, taps=None, relu
             return pre * relu_masks[name].to(pre.dtype)
         return F.relu(pre)
 
-    x = tap("stem.y", F.conv2d(x, sd["conv1.weight"], None, 2, 3))
+    q = _StoreBF16.apply if bf16_storage else (lambda t: t)
+    x = tap("stem.y", q(F.conv2d(q(x), q(sd["conv1.weight"]), None, 2, 3)))
     x = tap("stem.z", relu("stem.z", _bn(x, sd, "bn1", training)))
     if pooling == "max":
         x = F.max_pool2d(x, 3, 2, 1)
     else:
         x = F.avg_pool2d(x, 3, 2, 1)
-    x = tap("pool.out", x)
+    x = tap("pool.out", q(x))
     for lname, planes, stride in BLOCKS:
         for bi in range(2):
             p = f"{lname}.{bi}"
             s = stride if bi == 0 else 1
             identity = x
-            out = tap(p + ".y1", F.conv2d(x, sd[p + ".conv1.weight"], None, s, 1))
-            out = tap(p + ".a1", relu(p + ".a1", _bn(out, sd, p + ".bn1", training)))
-            out = tap(p + ".y2", F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1))
+            out = tap(p + ".y1", q(F.conv2d(x, q(sd[p + ".conv1.weight"]), None, s, 1)))
+            out = tap(p + ".a1", q(relu(p + ".a1", _bn(out, sd, p + ".bn1", training))))
+            out = tap(p + ".y2", q(F.conv2d(out, q(sd[p + ".conv2.weight"]), None, 1, 1)))
             out = _bn(out, sd, p + ".bn2", training)
             if (p + ".downsample.0.weight") in sd:
-                identity = F.conv2d(x, sd[p + ".downsample.0.weight"], None, s, 0)
+                identity = q(F.conv2d(x, q(sd[p + ".downsample.0.weight"]), None, s, 0))
                 identity = _bn(identity, sd, p + ".downsample.1", training)
-            x = tap(p + ".out", relu(p + ".out", out + identity))
+            x = tap(p + ".out", q(relu(p + ".out", out + identity)))
     x = F.avg_pool2d(x, int(input_size / 32))
     x = torch.flatten(x, 1)
     return F.linear(x, sd["fc.weight"], sd["fc.bias"])

@@ -117,6 +117,122 @@ def test_fp32_engine_matches_reference_golden(cuda, golden_dir, name):
                 check_summary(summary(v), gold[f"s{step}.post.{k}"], 5e-3, f"step {step} post {k}")
 
 
+def _nchw(t, N):
+    hw = int(round((t.shape[0] // N) ** 0.5))
+    return t.float().cpu().view(N, hw, hw, t.shape[1]).permute(0, 3, 1, 2).contiguous()
+
+
+def _engine_relu_masks(eng, N):
+    return {n: _nchw(v, N) > 0 for n, v in eng.t.items() if n == "stem.z" or n.endswith(".a1") or n.endswith(".out")
+            and n != "pool.out"}
+
+
+@pytest.mark.parametrize("batch,size,seed", [(4, 224, 42), (8, 64, 42), (8, 64, 7)])
+def test_fp32_gradients_hold_1e5_once_relu_branches_agree(cuda, batch, size, seed):
+    """The 1e-5 bar on GRADIENTS, demonstrated instead of argued.  A ReLU gradient is discontinuous where the
+    pre-activation is zero up to rounding, so two fp32 implementations may take different branches at a handful of
+    the ~10^7 ReLU sites (each flip moves every upstream gradient by ~1e-3).  The test
+      1. counts the sites where the engine's mask differs from the oracle's (= the reference's, bit for bit):
+         at most 8 of millions;
+      2. re-runs the oracle with the ENGINE's masks: all 62 gradient tensors then agree within 1e-5 of the exact
+         (float64) gradient of that network, and within 1.5e-5 of the torch-CPU fp32 oracle — which is itself
+         ~5e-6 away from the float64 gradient."""
+    torch.manual_seed(seed)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"))
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    y = torch.randint(0, 3, (batch,), generator=g)
+    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda)
+    eng.fuse_stem = False            # keep z = relu(bn1(y)) so that the stem's mask can be read back
+    eng.load_state_dict(sd)
+    logits = eng.forward(x.to(cuda)).cpu()
+    eng.loss_backward(y.to(cuda))
+    masks = _engine_relu_masks(eng, batch)
+    assert len(masks) == 17
+
+    def oracle(dtype, use_masks):
+        osd = {k: (v.clone().to(dtype) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        for k in O.param_keys(osd):
+            osd[k].requires_grad_(True)
+        taps = {}
+        ol = O.forward(osd, x.to(dtype), True, "max", size, taps=taps, relu_masks=masks if use_masks else None)
+        torch.nn.functional.cross_entropy(ol, y).backward()
+        return ol.detach(), osd, taps
+
+    ol, _, taps = oracle(torch.float32, False)
+    flips = sum(int((masks[n] != (taps[n].detach() > 0)).sum()) for n in masks)
+    assert flips <= 8, f"{flips} ReLU sites take the other branch"
+    assert (logits - ol).norm() / ol.norm() < 1e-5
+    _, osd32, _ = oracle(torch.float32, True)
+    _, osd64, _ = oracle(torch.float64, True)
+    for k, _ in eng.p_entries:
+        mine = eng.gviews[k].double().cpu().flatten()
+        exact, ref32 = osd64[k].grad.flatten(), osd32[k].grad.double().flatten()
+        assert (mine - exact).norm() <= 1e-5 * exact.norm(), f"{k}: {((mine - exact).norm() / exact.norm()).item():.2e}"
+        assert (mine - ref32).norm() <= 1.5e-5 * ref32.norm(), f"{k}: {((mine - ref32).norm() / ref32.norm()).item():.2e}"
+
+
+def test_bf16_full_size_step_against_oracle(cuda):
+    """BASELINE configs[1] exactly (batch 256, 3x224x224, bf16 storage / fp32 accumulate), the kernels the benchmark times:
+      1. logits within 3e-2 and loss within 2e-3 of the fp32 CPU oracle on the same batch;
+      2. every convolution at full size on the ENGINE'S OWN operands: forward output within 3e-3 of
+         conv2d(x, w) in fp32 (= one bf16 rounding of the result), weight gradient within 1e-4 of
+         conv2d_weight(x, dy), data gradient (where it lands in a buffer of its own) within 3e-3;
+      3. end-to-end gradients against the fp32 oracle: bf16 STORAGE makes them deviate by 25-50 % per tensor on this
+         randomly initialised network — the CPU oracle with nothing but bf16 rounding at the engine's storage points
+         (O.forward(bf16_storage=True)) is as far from the fp32 oracle as the engine is — so the bound is that band,
+         and the engine must not be further from the fp32 gradients than the bf16-storage oracle is, by more than 25 %."""
+    import torch.nn.functional as F
+
+    B, S = 256, 224
+    torch.manual_seed(42)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, S, "max"))
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(B, 3, S, S, generator=g)
+    y = torch.randint(0, 3, (B,), generator=g)
+    eng = ResNet18Engine(B, 3, 3, S, "max", dtype=torch.bfloat16, device=cuda)
+    eng.load_state_dict(sd)
+    logits = eng.forward(x.to(cuda)).float().cpu()
+    loss = eng.loss_backward(y.to(cuda)).item()
+    ologits, oloss, ograds = O.train_step(sd, x, y, 0.0, 0.0)
+    assert (logits - ologits).norm() / ologits.norm() < 3e-2
+    assert abs(loss - oloss.item()) < 2e-3 * abs(oloss.item())
+    # ---- 2. per layer, full size, the engine's own bf16 operands -------------------------------------------------
+    blocks = eng.spec.blocks
+    for i, blk in enumerate(blocks):
+        p = blk.prefix
+        xin = eng.t["pool.out"] if i == 0 else eng.t[blocks[i - 1].prefix + ".out"]
+        layers = [(blk.conv1, xin, "y1", "dy1", None), (blk.conv2, eng.t[p + ".a1"], "y2", "dy2", "da1")]
+        if blk.down is not None:
+            layers.append((blk.down, xin, "yd", "dyd", None))
+        for c, xt, yn, dyn, dxn in layers:
+            d = eng.convs[c.name].desc
+            xc, yc, dyc = _nchw(xt, B), _nchw(eng.t[f"{p}.{yn}"], B), _nchw(eng.t[f"{p}.{dyn}"], B)
+            w = sd[c.name + ".weight"].bfloat16().float()
+            yref = F.conv2d(xc, w, None, d.stride, d.pad)
+            assert (yc - yref).norm() <= 3e-3 * yref.norm(), f"{c.name} forward"
+            gref = torch.nn.grad.conv2d_weight(xc, w.shape, dyc, d.stride, d.pad)
+            got = eng.gviews[c.name + ".weight"].float().cpu()
+            assert (got - gref).norm() <= 1e-4 * gref.norm(), f"{c.name} wgrad {((got - gref).norm() / gref.norm()).item():.2e}"
+            if dxn is not None:
+                dxref = torch.nn.grad.conv2d_input(xc.shape, w, dyc, d.stride, d.pad)
+                dx = _nchw(eng.t[f"{p}.{dxn}"], B)
+                assert (dx - dxref).norm() <= 3e-3 * dxref.norm(), f"{c.name} dgrad"
+    # ---- 3. end to end ------------------------------------------------------------------------------------------------
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k in O.param_keys(osd):
+        osd[k].requires_grad_(True)
+    F.cross_entropy(O.forward(osd, x, True, "max", S, bf16_storage=True), y).backward()
+
+    def rel(a, b):
+        return ((a.double().flatten() - b.double().flatten()).norm() / b.double().norm()).item()
+
+    for k, _ in eng.p_entries:
+        e_engine, e_model = rel(eng.gviews[k].cpu(), ograds[k]), rel(osd[k].grad, ograds[k])
+        assert e_engine < 0.6, f"{k}: {e_engine:.2f}"
+        assert e_engine < 1.25 * e_model + 0.02, f"{k}: engine {e_engine:.3f} vs bf16-storage model {e_model:.3f}"
+
+
 def test_bf16_engine_tracks_oracle(cuda):
     """bf16 storage / fp32 accumulate: compare with the fp32 oracle on the same batch.
     Tolerance: logits 3e-2 of their norm, loss 2e-2, per-tensor gradient cosine > 0.9 (the

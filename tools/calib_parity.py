@@ -55,6 +55,19 @@ def fp32_case(batch, size, seed=42):
             a, b = eng.gviews[k].double().cpu().flatten(), osd[k].grad.double().flatten()
             e = ((a - b).norm() / b.norm()).item()
             worst = max(worst, e)
+        if use:
+            # the same masked network in float64: how far is each fp32 implementation from the exact gradient?
+            dsd = {k: v.clone().double() for k, v in sd.items()}
+            for k in O.param_keys(dsd):
+                dsd[k].requires_grad_(True)
+            dl = O.forward(dsd, x.double(), True, "max", size, relu_masks=masks)
+            torch.nn.functional.cross_entropy(dl, y).backward()
+            we = wo = 0.0
+            for k, _ in eng.p_entries:
+                t = dsd[k].grad.flatten()
+                we = max(we, ((eng.gviews[k].double().cpu().flatten() - t).norm() / t.norm()).item())
+                wo = max(wo, ((osd[k].grad.double().flatten() - t).norm() / t.norm()).item())
+            print(f"   vs float64 gradient: engine {we:.2e}, torch-CPU fp32 oracle {wo:.2e}")
         print(f"fp32 b{batch} s{size} masks={use}: logits {((logits.cpu() - ol.detach()).norm() / ol.detach().norm()).item():.2e} worst grad rel {worst:.2e}")
 
 
@@ -80,6 +93,39 @@ def bf16_full():
     for k, v in sorted(errs.items(), key=lambda kv: -kv[1])[:12]:
         print(f"   {k}: {v:.3e}")
     print("   median", sorted(errs.values())[len(errs) // 2])
+    # the oracle with the engine's storage format (bf16 buffers) on the same batch
+    osd = {k: v.clone() for k, v in sd.items()}
+    for k in O.param_keys(osd):
+        osd[k].requires_grad_(True)
+    ol = O.forward(osd, x, True, "max", S, bf16_storage=True)
+    torch.nn.functional.cross_entropy(ol, y).backward()
+    print(f"vs bf16-storage oracle: logits rel {((logits - ol.detach()).norm() / ol.detach().norm()).item():.3e}")
+    e2 = sorted(((eng.gviews[k].double().cpu().flatten() - osd[k].grad.double().flatten()).norm() / osd[k].grad.double().norm()).item()
+                for k, _ in eng.p_entries)
+    print("   grad rel: median", e2[len(e2) // 2], "max", e2[-1])
+    e3 = sorted(((ograds[k].double().flatten() - osd[k].grad.double().flatten()).norm() / ograds[k].double().norm()).item()
+                for k, _ in eng.p_entries)
+    print("   fp32 oracle vs bf16-storage oracle: median", e3[len(e3) // 2], "max", e3[-1])
+    # per-layer, full size: every conv's forward output and weight gradient from the ENGINE'S OWN operands
+    import torch.nn.functional as F
+    N = B
+    def nchw_(t, hw):
+        return t.float().cpu().view(N, hw, hw, -1).permute(0, 3, 1, 2).contiguous()
+    for blk in eng.spec.blocks[:3] + eng.spec.blocks[-1:]:
+        p = blk.prefix
+        for c, xin, yout, dyn in ((blk.conv1, None, "y1", "dy1"), (blk.conv2, "a1", "y2", "dy2")):
+            d = eng.convs[c.name].desc
+            if xin is None:
+                i = eng.spec.blocks.index(blk)
+                xin_t = eng.t["pool.out"] if i == 0 else eng.t[eng.spec.blocks[i - 1].prefix + ".out"]
+            else:
+                xin_t = eng.t[f"{p}.{xin}"]
+            xc, yc, dyc = nchw_(xin_t, d.H), nchw_(eng.t[f"{p}.{yout}"], d.Ho), nchw_(eng.t[f"{p}.{dyn}"], d.Ho)
+            w = sd[c.name + ".weight"].bfloat16().float()
+            yref = F.conv2d(xc, w, None, d.stride, d.pad)
+            gref = torch.nn.grad.conv2d_weight(xc, w.shape, dyc, d.stride, d.pad)
+            g = eng.gviews[c.name + ".weight"].float().cpu()
+            print(f"   {c.name}: fwd rel {((yc - yref).norm() / yref.norm()).item():.2e}  wgrad rel {((g - gref).norm() / gref.norm()).item():.2e}")
 
 
 if __name__ == "__main__":
