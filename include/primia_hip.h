@@ -186,6 +186,14 @@ int primia_conv_wgrad_finalize(const primia_conv_desc* d, int c_real, const floa
  * Data path in front of the step: MixUp pair mixing (torchlib/utils.py:337-400), one-hot
  * targets (utils.py:449-466) and per-channel dataset statistics (torchlib/dataloader.py:220-247).
  * ------------------------------------------------------------------------------------------ */
+/* The deterministic core of create_albu_transform (torchlib/dataloader.py:138-217) for ONE decoded image:
+ * a.Resize(R, R) -> a.RandomCrop(S, S) at (oy, ox) [-> a.VerticalFlip] -> a.ToFloat(255) ->
+ * a.Normalize(mean, std, max_pixel_value=1.0).  src: uint8 [Hin][Win][C] (C = 1 or 3, device memory);
+ * out: fp32 [C][S][S].  Bilinear, half-pixel centres, clamped (cv2.INTER_LINEAR), rounded to a uint8 level before
+ * ToFloat.  mean == std == NULL stops after ToFloat (the statistics pass of torchlib/utils.py:645-666). */
+int primia_image_prepare(const uint8_t* src, int Hin, int Win, int C, int R, int oy, int ox, int S, int flip_v,
+                         const float* mean, const float* std, float* out, primia_stream_t stream);
+
 /* out[i] = lam * x[i] + one_minus_lam * x[L/2 + i] for i < L/2 over rows of `per_sample` floats (three
  * roundings, like the reference's expression); an odd trailing sample is copied to out[L/2].  The same call
  * mixes the one-hot targets (per_sample = classes).  out has ceil(L/2) rows. */

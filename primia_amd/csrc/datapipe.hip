@@ -160,3 +160,58 @@ int primia_channel_mean_std(const float* x_nchw, int64_t N, int C, int64_t HW, f
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------
+// Image preparation in front of the stem: the deterministic core of create_albu_transform
+// (torchlib/dataloader.py:138-217) — a.Resize(R, R) -> a.RandomCrop(S, S) [-> a.VerticalFlip] -> a.ToFloat(255) ->
+// a.Normalize(mean, std, max_pixel_value=1.0) — on a decoded uint8 HWC image, one launch per image, writing one
+// fp32 [C, S, S] plane set of the client's device-resident dataset.
+//   resize: bilinear with half-pixel centres, source coordinates clamped to the image (cv2.INTER_LINEAR, what
+//           albumentations.Resize calls); the result is rounded to the nearest uint8 level like cv2's 8-bit
+//           path (cv2 evaluates the same weights in 11-bit fixed point: at most one level apart on ties);
+//   crop:   window (oy, ox) of the resized image, offsets drawn by the host exactly as albumentations draws them;
+//   normalise: (v / 255 - mean[c]) / std[c]; mean == nullptr stops after ToFloat (the statistics pass,
+//           torchlib/utils.py:645-666).
+// HBM-bound, trivially small: one thread per output pixel, coalesced fp32 stores per channel plane.
+// ---------------------------------------------------------------------------------------------------------------
+namespace primia {
+
+__global__ __launch_bounds__(256) void image_prepare_kernel(const uint8_t* __restrict__ src, int Hin, int Win, int C,
+                                                            int R, int oy, int ox, int S, int flip_v,
+                                                            const float* __restrict__ mean,
+                                                            const float* __restrict__ stdv, float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * S) return;
+    const int y = idx / S, x = idx - y * S;
+    const int ry = (flip_v ? S - 1 - y : y) + oy, rx = x + ox;       // pixel of the resized R x R image
+    const float sy = ((float)ry + 0.5f) * ((float)Hin / (float)R) - 0.5f;
+    const float sx = ((float)rx + 0.5f) * ((float)Win / (float)R) - 0.5f;
+    int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+    float fy = sy - (float)y0, fx = sx - (float)x0;
+    if (y0 < 0) { y0 = 0; fy = 0.f; }
+    if (x0 < 0) { x0 = 0; fx = 0.f; }
+    int y1 = y0 + 1, x1 = x0 + 1;
+    if (y1 >= Hin) { y1 = Hin - 1; if (y0 >= Hin - 1) { y0 = Hin - 1; fy = 0.f; } }
+    if (x1 >= Win) { x1 = Win - 1; if (x0 >= Win - 1) { x0 = Win - 1; fx = 0.f; } }
+    for (int c = 0; c < C; ++c) {
+        const float p00 = src[((long)y0 * Win + x0) * C + c], p01 = src[((long)y0 * Win + x1) * C + c];
+        const float p10 = src[((long)y1 * Win + x0) * C + c], p11 = src[((long)y1 * Win + x1) * C + c];
+        const float top = p00 + (p01 - p00) * fx, bot = p10 + (p11 - p10) * fx;
+        float v = floorf(top + (bot - top) * fy + 0.5f);
+        v = fminf(fmaxf(v, 0.f), 255.f) / 255.0f;
+        if (mean) v = (v - mean[c]) / stdv[c];
+        out[(long)c * S * S + idx] = v;
+    }
+}
+
+}  // namespace primia
+
+extern "C" int primia_image_prepare(const uint8_t* src, int Hin, int Win, int C, int R, int oy, int ox, int S,
+                                    int flip_v, const float* mean, const float* stdv, float* out,
+                                    primia_stream_t st) {
+    PRIMIA_REQUIRE(src && out && Hin > 0 && Win > 0 && (C == 1 || C == 3) && R > 0 && S > 0 && S <= R);
+    PRIMIA_REQUIRE(oy >= 0 && ox >= 0 && oy + S <= R && ox + S <= R && ((mean == nullptr) == (stdv == nullptr)));
+    primia::image_prepare_kernel<<<primia::ceil_div((long)S * S, 256), 256, 0, (hipStream_t)st>>>(
+        src, Hin, Win, C, R, oy, ox, S, flip_v, mean, stdv, out);
+    return primia::launch_status();
+}

@@ -40,14 +40,67 @@ class HipArenaOps:
         _lib.call("primia_fx_decode", q, x, x.numel(), float(scale))
 
 
+class PairwiseMasks:
+    """Masks m_k with sum_k m_k = 0 (mod 2^64) for the secure all-reduce: every pair of clients (i < j) shares a
+    256-bit ChaCha20 key; client i ADDS the pair's keystream to its encoded update, client j SUBTRACTS it.  What a
+    client puts on the wire is then uniformly random to everybody who lacks one of its pair keys, the masks cancel in
+    the ring sum, and the decoded average is bit-identical to the unmasked one — the role additive sharing between
+    the workers plays in the reference (`.fix_prec().share(*workers)`, torchlib/utils.py:1046-1060), without a hub.
+
+    Keys are drawn from `os.urandom` by the lower rank of each pair and handed to the higher rank point-to-point once
+    per run (`setup`); on one 8-GPU node that hop is an xGMI copy, across nodes it needs an authenticated channel —
+    the same trust the reference places in its websocket links.  Every sync consumes a fresh keystream segment."""
+
+    def __init__(self, keys, rank, n_words):
+        self.keys, self.rank = keys, rank          # {peer: (k0, k1, k2, k3, nonce)}
+        self.blocks_per_sync = (n_words + 7) // 8
+        self.syncs = 0
+        self._tmp = None
+
+    @classmethod
+    def setup(cls, n_words, device, group=None):
+        import os
+
+        K = dist.get_world_size(group)
+        rank = dist.get_rank(group)
+        keys = {}
+        for i in range(K):
+            for j in range(i + 1, K):
+                if rank == i:
+                    raw = os.urandom(40)
+                    words = [int.from_bytes(raw[8 * t:8 * t + 8], "little", signed=True) for t in range(5)]
+                    t = torch.tensor(words, dtype=torch.int64, device=device)
+                    dist.send(t, dist.get_global_rank(group, j) if group is not None else j, group=group)
+                    keys[j] = tuple(w & 0xFFFFFFFFFFFFFFFF for w in words)
+                elif rank == j:
+                    t = torch.empty(5, dtype=torch.int64, device=device)
+                    dist.recv(t, dist.get_global_rank(group, i) if group is not None else i, group=group)
+                    keys[i] = tuple(int(w) & 0xFFFFFFFFFFFFFFFF for w in t.tolist())
+        return cls(keys, rank, n_words)
+
+    def apply(self, q):
+        """q += sum_{j > rank} PRG(key_rank,j) - sum_{i < rank} PRG(key_i,rank)   (mod 2^64), in place."""
+        n = q.numel()
+        if self._tmp is None or self._tmp.numel() != n:
+            self._tmp = torch.empty(n, dtype=torch.int64, device=q.device)
+        block0 = self.syncs * self.blocks_per_sync
+        for peer, key in sorted(self.keys.items()):
+            _lib.call("primia_chacha20_fill", key[0], key[1], key[2], key[3], key[4], block0, self._tmp, n)
+            _lib.call("primia_ring_add" if peer > self.rank else "primia_ring_sub", q, self._tmp, q, n, n)
+        self.syncs += 1
+
+
 def fedavg_allreduce(flat, out, weight=None, secure=False, precision_fractional=16, base=10, group=None,
-                     ops=None, scratch=None):
+                     ops=None, scratch=None, masks=None):
     """Average the clients' arenas.
 
     flat   : this client's fp32 arena (not modified)
     out    : fp32 tensor of the same size receiving the average (may alias nothing else)
     weight : this client's w_k, or None for the unweighted mean (sum, then / K)
-    secure : reproduce the fixed-precision encode -> ring sum -> decode numerics
+    secure : fixed-precision encode -> ring sum -> decode (the numerics of the reference's secure aggregation);
+             with `masks` (a PairwiseMasks) every client's encoded update is hidden under pairwise one-time masks
+             that cancel in the sum.  Without `masks` the all-reduce carries the encoded updates in the clear: the
+             numbers are identical, the confidentiality is not — train.py always passes masks when K > 1.
     """
     ops = ops or HipArenaOps()
     K = dist.get_world_size(group) if dist.is_initialized() else 1
@@ -59,6 +112,8 @@ def fedavg_allreduce(flat, out, weight=None, secure=False, precision_fractional=
         q = scratch if scratch is not None else torch.empty(out.numel(), dtype=torch.int64, device=out.device)
         ops.encode(out, q, scale)
         if K > 1:
+            if masks is not None:
+                masks.apply(q)
             dist.all_reduce(q, op=dist.ReduceOp.SUM, group=group)
         ops.decode(q, out, scale)
     elif K > 1:
@@ -86,6 +141,27 @@ def exchange_mean_std(mean, std, group=None, ops=None, precision_fractional=3, b
     ops.divide(out, float(K))
     n = mean.numel()
     return out[:n].reshape(mean.shape), out[n:].reshape(std.shape)
+
+
+def secure_mean_of(stats, ops=None, precision_fractional=3, base=10):
+    """exchange_mean_std for clients that live in ONE process: `stats` = [(mean, std), ...]; same arithmetic
+    (encode each, ring sum, decode, / K)."""
+    ops = ops or HipArenaOps()
+    scale = float(base ** precision_fractional)
+    acc = None
+    for mean, std in stats:
+        both = torch.cat([mean.reshape(-1), std.reshape(-1)]).to(torch.float32).contiguous()
+        q = torch.empty(both.numel(), dtype=torch.int64, device=both.device)
+        ops.encode(both, q, scale)
+        if acc is None:
+            acc = q
+        else:
+            _lib.call("primia_ring_add", acc, q, acc, acc.numel(), acc.numel())
+    out = torch.empty(acc.numel(), dtype=torch.float32, device=acc.device)
+    ops.decode(acc, out, scale)
+    ops.divide(out, float(len(stats)))
+    n = stats[0][0].numel()
+    return out[:n].reshape(stats[0][0].shape), out[n:].reshape(stats[0][1].shape)
 
 
 class SyncSchedule:
@@ -117,47 +193,62 @@ def all_gather_int(value, group=None, device="cpu"):
     return [int(o.item()) for o in outs]
 
 
-def federated_epoch(engine, loader, lr, weight_decay, sync_every_n_batch, weighted_averaging=False,
-                    secure=False, precision_fractional=16, optimizer="SGD", betas=(0.9, 0.999),
-                    keep_optim_dict=False, soft_targets=False, group=None, ops=None, local_flat=None):
-    """One federated epoch for THIS rank's client (the body of secure_aggregation_epoch).
+def federated_epoch(engine, loader, args, optimizer=None, group=None, ops=None, local_flat=None, soft_targets=False,
+                    masks=None):
+    """One federated epoch for THIS rank's client — the body of secure_aggregation_epoch (torchlib/utils.py:1108-1233)
+    with one client per rank: the per-worker loop becomes "this rank trains if it still has batches", aggregation()
+    + send_new_models() become `fedavg_allreduce` + "adopt if batches are left" (always at the epoch end).
 
-    Returns (mean of this client's per-step losses, number of steps, local_flat) where local_flat
-    holds the last global average ("local_model" in the reference)."""
+    `args` carries the reference's settings (optimizer, lr, weight_decay, beta1/2, sync_every_n_batch,
+    keep_optim_dict, weighted_averaging, unencrypted_aggregation, precision_fractional).  Unless keep_optim_dict the
+    optimizer is re-created with lr = args.lr at the start of the epoch and after every mid-epoch sync
+    (utils.py:1131-1145,1208-1218).
+
+    Returns (mean loss over ALL clients' steps, as the reference's avg_loss; this client's step count; local_flat =
+    the last global average, the reference's "local_model"; the optimizer object now in use)."""
+    from .optim import EngineOptimizer
+
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     dev = engine.flat.device
     counts = all_gather_int(len(loader), group, dev)
-    sched = SyncSchedule(counts, sync_every_n_batch)
-    weight = None
-    if weighted_averaging:
-        weight = counts[rank] / float(sum(counts))
+    sched = SyncSchedule(counts, args.sync_every_n_batch)
+    weight = counts[rank] / float(sum(counts)) if args.weighted_averaging else None
+    secure = not args.unencrypted_aggregation
+    pf = int(getattr(args, "precision_fractional", 16))
     if local_flat is None:
         local_flat = torch.empty_like(engine.flat)
     scratch = torch.empty(engine.flat.numel(), dtype=torch.int64, device=dev) if secure else None
-    if not keep_optim_dict:
-        engine.reset_optimizer()
+    if not args.keep_optim_dict or optimizer is None:
+        optimizer = EngineOptimizer.from_args(engine, args)
     losses = []
     it = iter(loader)
 
     def sync(final, batch_idx):
-        fedavg_allreduce(engine.flat, local_flat, weight, secure, precision_fractional, 10, group, ops, scratch)
+        fedavg_allreduce(engine.flat, local_flat, weight, secure, pf, 10, group, ops, scratch, masks)
         if final or sched.adopts(rank, batch_idx):
             engine.flat.copy_(local_flat)
+            # the adopted state dict carries num_batches_tracked = 0 (see torchlib_compat.aggregation)
+            for b in engine.num_batches_tracked:
+                engine.num_batches_tracked[b] = 0
             engine.refresh_weights()
-        if not keep_optim_dict:
-            engine.reset_optimizer()
 
     for batch_idx in range(sched.max_batches):
         if sched.trains(rank, batch_idx):
             data, target = next(it)
+            optimizer.zero_grad()
             engine.forward(data)
             losses.append(engine.loss_backward(target, soft=soft_targets).clone())
-            if optimizer == "SGD":
-                engine.sgd_step(lr, weight_decay)
-            else:
-                engine.adam_step(lr, betas, 1e-8, weight_decay)
+            optimizer.step()
         if sched.sync_after(batch_idx):
             sync(False, batch_idx)
+            if not args.keep_optim_dict:
+                optimizer = EngineOptimizer.from_args(engine, args)
     sync(True, sched.max_batches)
-    mean_loss = float(torch.stack(losses).mean().item()) if losses else float("nan")
-    return mean_loss, len(losses), local_flat
+    tot = torch.zeros(2, dtype=torch.float64, device=dev)
+    if losses:
+        tot[0] = torch.stack(losses).double().sum()
+        tot[1] = len(losses)
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=group)
+    mean_loss = float((tot[0] / tot[1]).item()) if tot[1] > 0 else float("nan")
+    return mean_loss, len(losses), local_flat, optimizer

@@ -1,0 +1,130 @@
+"""Real image folders in front of the training step.
+
+The reference registers every client's COMPLETE dataset on its worker before training starts
+(torchlib/utils.py:612-739): an ImageFolder (`<root>/<class>/<image>`, classes sorted by name) is read once, a
+statistics pass (Resize -> RandomCrop -> ToFloat) yields the client's per-channel mean / std, every image then goes
+through create_albu_transform (torchlib/dataloader.py:138-217) with that mean / std, the stacked tensors are tagged
+#traindata / #traintargets and a FederatedDataLoader (batch_size, shuffle=True) iterates them.
+
+Here the decode (PIL, host) produces uint8 HWC arrays; everything after it runs on the GPU: `primia_image_prepare`
+(resize, crop, to-float, normalise — one launch per image into the client's device-resident dataset tensor) and
+`primia_mean_std`.  Of the transform chain the deterministic core is built (Resize, RandomCrop, ToFloat, Normalize);
+the stochastic augmentations (affine, gamma, blur, CLAHE, ...) are data preparation outside the hot path and are not
+applied — a config that enables them gets a warning, not silently different data.
+
+The engine runs a fixed batch size, so a ragged final batch is dropped (the reference's loader would yield it):
+`len(loader)` = floor(n / batch_size).
+"""
+import os
+import random
+from warnings import warn
+
+import numpy as np
+import torch
+
+from ._lib import call
+
+EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
+_AUGMENTATIONS = ("clahe", "randomgamma", "randombrightness", "blur", "elastic", "optical_distortion",
+                  "grid_distortion", "grid_shuffle", "hsv", "invert", "cutout", "shadow", "fog", "sun_flare",
+                  "solarize", "equalize", "grid_dropout")
+
+
+def scan(root):
+    """torchvision.datasets.ImageFolder's listing: classes = sorted sub-directory names, samples sorted per class."""
+    classes = sorted(d for d in os.listdir(root) if os.path.isdir(os.path.join(root, d)))
+    samples = []
+    for ci, c in enumerate(classes):
+        for dirpath, _, files in sorted(os.walk(os.path.join(root, c))):
+            for f in sorted(files):
+                if f.lower().endswith(EXTENSIONS) and not f.startswith("._"):
+                    samples.append((os.path.join(dirpath, f), ci))
+    return classes, samples
+
+
+def decode(filename, channels):
+    """default_loader (RGB) / single_channel_loader ('L', torchlib/dataloader.py:250-255) -> uint8 [H, W, C]."""
+    from PIL import Image
+
+    with open(filename, "rb") as f:
+        img = Image.open(f).convert("RGB" if channels == 3 else "L")
+        a = np.asarray(img, dtype=np.uint8)
+    return a if a.ndim == 3 else a[:, :, None]
+
+
+def crop_offsets(R, S, rng):
+    """albumentations.RandomCrop.get_params / functional.get_random_crop_coords: two uniform draws, h then w."""
+    h_start, w_start = rng.random(), rng.random()
+    return int((R - S) * h_start), int((R - S) * w_start)
+
+
+def prepare(samples, args, device, channels, rng, mean=None, std=None):
+    """All samples -> fp32 [n, C, S, S] on the device (one primia_image_prepare launch per image)."""
+    R, S = args.inference_resolution, args.train_resolution
+    out = torch.empty(len(samples), channels, S, S, dtype=torch.float32, device=device)
+    for i, (fn, _) in enumerate(samples):
+        img = torch.from_numpy(np.ascontiguousarray(decode(fn, channels))).to(device)
+        oy, ox = crop_offsets(R, S, rng)
+        call("primia_image_prepare", img, img.shape[0], img.shape[1], channels, R, oy, ox, S, 0, mean, std, out[i])
+    return out
+
+
+class DeviceLoader:
+    """FederatedDataLoader(batch_size, shuffle=True) over a device-resident (data, targets) pair."""
+
+    def __init__(self, data, targets, batch_size, shuffle, seed):
+        self.data, self.targets, self.batch_size, self.shuffle = data, targets, batch_size, shuffle
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        return self.data.shape[0] // self.batch_size
+
+    def __iter__(self):
+        n = self.data.shape[0]
+        order = torch.randperm(n, generator=self.gen) if self.shuffle else torch.arange(n)
+        order = order.to(self.data.device)
+        for b in range(len(self)):
+            idx = order[b * self.batch_size:(b + 1) * self.batch_size]
+            yield self.data.index_select(0, idx), self.targets.index_select(0, idx)
+
+
+def client_loader(root, args, device, channels, seed):
+    """One client's registration (torchlib/utils.py:643-739): returns (loader, (mean, std)) with mean / std on the
+    device (they take part in the secure mean/std exchange)."""
+    from .datapipe import calc_mean_std
+
+    classes, samples = scan(root)
+    assert len(classes) == 3, "We can only handle data that has 3 classes: normal, bacterial and viral"
+    if len(samples) < args.batch_size:
+        raise ValueError("{:s}: {:d} images, fewer than one batch of {:d}".format(root, len(samples), args.batch_size))
+    on = [a for a in _AUGMENTATIONS if getattr(args, a, False)]
+    if on or getattr(args, "albu_prob", 0) > 0 and (getattr(args, "rotation", 0) or getattr(args, "noise_prob", 0)):
+        warn("stochastic augmentations ({:s}) are not part of the accelerated path and are not applied".format(
+            ", ".join(on) or "affine / noise"))
+    rng = random.Random(seed)
+    raw = prepare(samples, args, device, channels, rng)                       # Resize, RandomCrop, ToFloat
+    mean, std = calc_mean_std(raw)
+    del raw
+    data = prepare(samples, args, device, channels, rng, mean.float().contiguous(), std.float().contiguous())
+    reps = int(getattr(args, "repetitions_dataset", 1) or 1)
+    targets = torch.tensor([t for _, t in samples], dtype=torch.int64, device=device)
+    if reps > 1:                                                               # utils.py:699-717
+        data, targets = data.repeat(reps, 1, 1, 1), targets.repeat(reps)
+    return DeviceLoader(data, targets, args.batch_size, True, seed), (mean, std)
+
+
+def validation_loader(root, args, device, channels, val_mean_std):
+    """The validation folder, normalised with the exchanged mean / std (torchlib/utils.py:815-860): Resize to the
+    inference resolution, centre crop to the train resolution when they differ, no shuffling."""
+    classes, samples = scan(root)
+    assert len(classes) == 3, "We can only handle data that has 3 classes: normal, bacterial and viral"
+    R, S = args.inference_resolution, args.train_resolution
+    mean = val_mean_std[0].to(device).float().contiguous()
+    std = val_mean_std[1].to(device).float().contiguous()
+    out = torch.empty(len(samples), channels, S, S, dtype=torch.float32, device=device)
+    off = (R - S) // 2
+    for i, (fn, _) in enumerate(samples):
+        img = torch.from_numpy(np.ascontiguousarray(decode(fn, channels))).to(device)
+        call("primia_image_prepare", img, img.shape[0], img.shape[1], channels, R, off, off, S, 0, mean, std, out[i])
+    targets = torch.tensor([t for _, t in samples], dtype=torch.int64, device=device)
+    return DeviceLoader(out, targets, args.batch_size, False, 0)

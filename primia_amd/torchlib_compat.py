@@ -173,8 +173,11 @@ class Arguments:
         self.websockets = getattr(cmd_args, "websockets", False)
 
     def incorporate_cmd_args(self, cmd_args):
-        for k, v in vars(cmd_args).items():
-            setattr(self, k, v)
+        """Only attributes this object already has are overridden (torchlib/utils.py:282-292); command-line flags
+        without a counterpart here are ignored."""
+        for attr in [a for a in dir(self) if not a.startswith("__") and not callable(getattr(self, a))]:
+            if hasattr(cmd_args, attr):
+                setattr(self, attr, getattr(cmd_args, attr))
 
     def __str__(self):
         width = max(len(k) for k in vars(self))
@@ -255,25 +258,36 @@ def send_new_models(local_model, models):
     return models
 
 
+def _as_optimizer(engine, opt, args):
+    """Host loops take the optimizer object of primia_amd.optim; a bare {"lr": ...} (older callers, tests) is wrapped
+    around the engine WITHOUT touching its state."""
+    from .optim import EngineOptimizer
+
+    if isinstance(opt, EngineOptimizer):
+        return opt
+    steps, state = engine.opt_steps, engine.opt_state
+    o = EngineOptimizer.from_args(engine, args, lr=opt["lr"])
+    engine.opt_steps, engine.opt_state = steps, state
+    return o
+
+
 def secure_aggregation_epoch(args, models, device, train_loaders, optimizers, epoch, loss_fns, crypto_provider,
                              weights=None, test_params=None, verbose=True, privacy_engines=None):
-    """torchlib/utils.py:1108-1233.  train_loaders: {worker: iterable of (data, target)};
-    optimizers: {worker_id: {"lr": ...}} (an optimizer here is just its hyper-parameters: the state
-    lives in the engine and is reset at every sync unless keep_optim_dict)."""
+    """torchlib/utils.py:1108-1233.  train_loaders: {worker: iterable of (data, target)}; optimizers: {worker_id:
+    EngineOptimizer}.  Unless `keep_optim_dict`, every worker's optimizer is RE-CREATED at the start of the epoch and
+    after every mid-epoch sync with `lr = args.lr` (utils.py:1131-1145,1208-1218) — the reference thereby discards both
+    the optimizer state and the rate its scheduler had just written into the old object (train.py:421-428); the new
+    objects are stored back into `optimizers`, as the reference does."""
     import numpy as np
+
+    from .optim import EngineOptimizer
 
     def wid(w):
         return w if isinstance(w, str) else w.id
 
-    def step(engine, opt):
-        if args.optimizer == "SGD":
-            engine.sgd_step(opt["lr"], args.weight_decay)
-        else:
-            engine.adam_step(opt["lr"], (args.beta1, args.beta2), 1e-8, args.weight_decay)
-
-    if not args.keep_optim_dict:
-        for w in optimizers:
-            models[w].reset_optimizer()
+    for w in list(optimizers):
+        optimizers[w] = (EngineOptimizer.from_args(models[w], args) if not args.keep_optim_dict
+                         else _as_optimizer(models[w], optimizers[w], args))
     avg_loss = []
     num_batches = {wid(w): len(tl) for w, tl in train_loaders.items()}
     loaders = {w: iter(tl) for w, tl in train_loaders.items()}
@@ -283,10 +297,11 @@ def secure_aggregation_epoch(args, models, device, train_loaders, optimizers, ep
             i = wid(w)
             if batch_idx >= num_batches[i]:
                 continue
+            optimizers[i].zero_grad()
             data, target = next(it)
             models[i].forward(data)
             loss = models[i].loss_backward(target, soft=getattr(loss_fns.get(i), "soft", False) if loss_fns else False)
-            step(models[i], optimizers[i])
+            optimizers[i].step()
             avg_loss.append(loss.item())
         if batch_idx > 0 and batch_idx % args.sync_every_n_batch == 0:
             models["local_model"] = aggregation(models["local_model"], models, train_loaders.keys(), crypto_provider,
@@ -294,8 +309,8 @@ def secure_aggregation_epoch(args, models, device, train_loaders, optimizers, ep
             send_new_models(models["local_model"],
                             {w: m for w, m in models.items() if w in num_batches and num_batches[w] > batch_idx})
             if not args.keep_optim_dict:
-                for w in optimizers:
-                    models[w].reset_optimizer()
+                for w in list(optimizers):
+                    optimizers[w] = EngineOptimizer.from_args(models[w], args)
     models["local_model"] = aggregation(models["local_model"], models, train_loaders.keys(), crypto_provider, args,
                                         test_params, weights=weights, secure=secure)
     models = send_new_models(models["local_model"], models)
@@ -320,6 +335,7 @@ def train(args, model, device, train_loader, optimizer, epoch, loss_fn, num_clas
           verbose=True):
     """torchlib/utils.py:1236-1292 — local (non-federated) epoch, incl. the on-device MixUp of :1249-1267."""
     losses = []
+    optimizer = _as_optimizer(model, optimizer, args)
     if getattr(args, "mixup", False):
         from ._lib import PrimiaError
         from .datapipe import MixUp, To_one_hot
@@ -337,12 +353,10 @@ def train(args, model, device, train_loader, optimizer, epoch, loss_fn, num_clas
                     "MixUp produced a batch of {:d}, the engine is built for {:d}: with mixup_prob < 1 the batch "
                     "size changes from step to step; use mixup_prob = 1.0 (batch_size is doubled, as the reference "
                     "does) or build the engine for the mixed size".format(data.shape[0], model.N))
+        optimizer.zero_grad()
         model.forward(data)
         loss = model.loss_backward(target, soft=soft)
-        if args.optimizer == "SGD":
-            model.sgd_step(optimizer["lr"], args.weight_decay)
-        else:
-            model.adam_step(optimizer["lr"], (args.beta1, args.beta2), 1e-8, args.weight_decay)
+        optimizer.step()
         if batch_idx % args.log_interval == 0:
             losses.append(loss.item())
             if verbose:
@@ -435,6 +449,10 @@ def save_model(model, optim, path, args, epoch, val_mean_std):
     import torch
 
     os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
-    opt_state_dict = {name: dict(o) for name, o in optim.items()} if args.train_federated else dict(optim)
+    def sd(o):
+        return o.state_dict() if hasattr(o, "state_dict") else dict(o)
+
+    opt_state_dict = {name: sd(o) for name, o in optim.items()} if args.train_federated else sd(optim)
+    model = model["local_model"] if isinstance(model, dict) else model
     torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optim_state_dict": opt_state_dict,
                 "args": args, "val_mean_std": val_mean_std}, path)

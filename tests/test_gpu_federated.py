@@ -204,3 +204,170 @@ def test_aggregation_kernels_match_reference_aggregation(cuda, golden_dir):
         else:
             assert torch.allclose(got, want, rtol=1e-6, atol=1e-7), tag
         assert local.num_batches_tracked == {"bn": 0}
+
+
+def _in_process_epochs(cuda, cfg):
+    """The same clients, shards and settings as tests/fed_rank_worker.py, all in this process
+    (torchlib_compat.train_federated, the reference's VirtualWorker layout)."""
+    from tests.fed_rank_worker import shard
+
+    args = SimpleNamespace(**cfg["args"])
+    batch, size = cfg["batch"], cfg["size"]
+    torch.manual_seed(11)
+    init = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"))
+    names = [f"w{k}" for k in range(len(cfg["shards"]))]
+    models = {"local_model": ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda)}
+    models["local_model"].load_state_dict(init)
+    loaders, opt = {}, {}
+    for k, w in enumerate(names):
+        models[w] = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda)
+        models[w].load_state_dict(init)
+        loaders[w] = [(x.to(cuda), y.to(cuda)) for x, y in shard(k, cfg["shards"][k], batch, size)]
+        opt[w] = {"lr": args.lr}
+    for epoch in range(cfg["epochs"]):
+        models = train_federated(args, models, cuda, loaders, opt, epoch + 1, {w: None for w in names}, None,
+                                 verbose=False)
+    return models, opt, names
+
+
+@pytest.mark.parametrize("case", ["secure_sgd", "plain_adam_keep", "weighted_secure_adam_reset"])
+def test_per_rank_federated_epoch_matches_in_process(cuda, tmp_path, case):
+    """one client per rank (here 2 ranks sharing GPU 0 over gloo; RCCL on a multi-GPU node) against the
+    in-process federated epoch on the same uneven shards — stragglers (3 vs 2 batches, a sync after every batch),
+    optimizer re-creation vs keep_optim_dict, weighted averaging, pairwise-masked secure aggregation.
+    Secure aggregation is integer arithmetic: the final arenas are BIT-identical.  Plain unweighted averaging of two
+    clients is too (a + b is commutative); weighted plain differs by the rounding of scale-then-add vs fused axpy."""
+    a = dict(optimizer="SGD", lr=1e-3, weight_decay=5e-4, sync_every_n_batch=1, keep_optim_dict=False,
+             weighted_averaging=False, unencrypted_aggregation=False, precision_fractional=16, beta1=0.5, beta2=0.99)
+    if case == "plain_adam_keep":
+        a.update(optimizer="Adam", keep_optim_dict=True, unencrypted_aggregation=True)
+    elif case == "weighted_secure_adam_reset":
+        a.update(optimizer="Adam", weighted_averaging=True, sync_every_n_batch=2)
+    cfg = {"args": a, "batch": 4, "size": 64, "shards": [3, 2], "epochs": 2}
+    out = str(tmp_path / "rank")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "tests", "fed_rank_worker.py"),
+           json.dumps(cfg), out]
+    r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    models, opt, names = _in_process_epochs(cuda, cfg)
+    want = models["local_model"].flat.cpu()
+    for k, w in enumerate(names):
+        got = torch.load(f"{out}.{k}", weights_only=False)
+        assert torch.equal(got["flat"], got["local"])            # every client ends the epoch on the average
+        assert torch.equal(got["flat"], want), (case, k, (got["flat"] - want).abs().max().item())
+        assert got["steps"] == models[w].opt_steps                # optimizer re-creation / keep_optim_dict
+        assert got["nbt"] == models[w].num_batches_tracked
+        mine = opt[w].state_dict()
+        assert got["opt"]["param_groups"] == mine["param_groups"]
+        assert set(got["opt"]["state"]) == set(mine["state"])
+        for i in mine["state"]:
+            assert torch.equal(got["opt"]["state"][i]["exp_avg"], mine["state"][i]["exp_avg"])
+
+
+def test_optimizer_state_dict_round_trips_with_torch_adam(cuda):
+    """8f.3: a checkpoint written with a stock torch.optim.Adam.state_dict() (index-keyed as torch >= 1.5 writes it, or
+    id()-keyed as the reference's torch 1.4 does) restores the engine's Adam moments: the next step equals torch's."""
+    from primia_amd.optim import EngineOptimizer
+
+    size, batch = 64, 2
+    torch.manual_seed(5)
+    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda)
+    eng.init_weights()
+    params = [torch.nn.Parameter(eng.views[k].detach().cpu().clone()) for k, _ in eng.p_entries]
+    topt = torch.optim.Adam(params, lr=1e-3, betas=(0.5, 0.99), weight_decay=5e-4)
+    g = torch.Generator().manual_seed(6)
+    grads = [[torch.randn(p.shape, generator=g) * 0.01 for p in params] for _ in range(3)]
+    for step in range(2):
+        for p, gr in zip(params, grads[step]):
+            p.grad = gr.clone()
+        topt.step()
+    sd = topt.state_dict()
+    for keyed in ("index", "id"):
+        saved = {"state": dict(sd["state"]), "param_groups": [dict(sd["param_groups"][0])]}
+        if keyed == "id":       # torch 1.4: keys are id(param)
+            remap = {i: 140000000000000 + 64 * i for i in saved["param_groups"][0]["params"]}
+            saved["state"] = {remap[i]: v for i, v in saved["state"].items()}
+            saved["param_groups"][0]["params"] = [remap[i] for i in saved["param_groups"][0]["params"]]
+        for k, _ in eng.p_entries:
+            eng.views[k].copy_(params[[n for n, _ in eng.p_entries].index(k)].detach().to(cuda))
+        opt = EngineOptimizer(eng, "Adam", lr=9.9, betas=(0.9, 0.999))
+        opt.load_state_dict(saved)
+        assert opt.param_groups[0]["lr"] == 1e-3 and tuple(opt.param_groups[0]["betas"]) == (0.5, 0.99)
+        assert eng.opt_steps == 2
+        again = opt.state_dict()
+        assert sorted(again["state"]) == list(range(len(params)))
+        assert torch.equal(again["state"][3]["exp_avg"], sd["state"][3]["exp_avg"])
+        for (k, _), gr in zip(eng.p_entries, grads[2]):
+            eng.gviews[k].copy_(gr.to(cuda))
+        opt.step()
+        ref = [p.detach().clone() for p in params]
+        ropt = torch.optim.Adam([torch.nn.Parameter(r) for r in ref], lr=1e-3, betas=(0.5, 0.99), weight_decay=5e-4)
+        ropt.load_state_dict(sd)
+        for p, gr in zip(ropt.param_groups[0]["params"], grads[2]):
+            p.grad = gr.clone()
+        ropt.step()
+        for (k, _), p in zip(eng.p_entries, ropt.param_groups[0]["params"]):
+            a, b = eng.views[k].cpu().double().flatten(), p.detach().double().flatten()
+            assert (a - b).norm() <= 1e-5 * b.norm() + 1e-9, k
+    # SGD: no per-parameter state; a checkpoint that carries some is refused loudly
+    sgd = EngineOptimizer(eng, "SGD", lr=1e-2, weight_decay=5e-4)
+    assert sgd.state_dict()["state"] == {}
+    with pytest.raises(ValueError):
+        sgd.load_state_dict(sd)
+
+
+def _write_tree(root, workers=2, per_class=4):
+    from tests.test_gpu_imagefolder import make_folder
+
+    for i in range(workers):
+        make_folder(os.path.join(root, f"worker{i + 1}"), per_class=per_class, seed=10 + i)
+    make_folder(os.path.join(root, "validation"), per_class=3, seed=99)
+
+
+def test_cli_per_rank_training_on_a_real_folder_and_resume(tmp_path):
+    """train.py under torch.distributed.run: rank k = client k of the CSV on its own process (2 ranks sharing GPU 0 over
+    gloo here), real image folders, secure aggregation under pairwise masks, Adam; then the resume matrix of
+    train.py:344-389: federated -> federated (per-worker optimizer state restored) and federated -> vanilla."""
+    data = str(tmp_path / "data")
+    _write_tree(data)
+    csv = tmp_path / "workers.csv"
+    csv.write_text("id,alice,bob,crypto_provider\nhost,127.0.0.1,127.0.0.1,127.0.0.1\nport,8777,8778,8780\n")
+    ini = tmp_path / "cfg.ini"
+    text = open(os.path.join(ROOT, "configs", "torch", "smoke-federated.ini")).read()
+    text = (text.replace("epochs = 10", "epochs = 2").replace("repetitions_dataset = 5", "repetitions_dataset = 1")
+            .replace("optimizer = SGD", "optimizer = Adam").replace("sync_every_n_batch = 3", "sync_every_n_batch = 1")
+            .replace("keep_optim_dict = no", "keep_optim_dict = yes"))
+    ini.write_text(text)
+    env = {"PRIMIA_BACKEND": "gloo", "PRIMIA_WEBSOCKETS_CONFIG": str(csv), "MASTER_ADDR": "127.0.0.1"}
+    torchrun = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", str(29500 + os.getpid() % 200)]
+    base = ["train.py", "--config", str(ini), "--cuda", "--data_dir", data]
+    out = run(torchrun + base + ["--train_federated", "--training_name", "rankcli"], env)
+    assert "Train Epoch: 2" in out and "matthews coeff" in out
+    assert out.count("Train Epoch: 1") == 1                     # only rank 0 reports
+    ckpt = os.path.join(ROOT, "model_weights", "final_federated_rankcli.pt")
+    state = torch.load(ckpt, map_location="cpu", weights_only=False)
+    assert set(state["optim_state_dict"]) == {"alice", "bob"}
+    for w in ("alice", "bob"):
+        o = state["optim_state_dict"][w]
+        assert set(o) == {"state", "param_groups"} and len(o["state"]) == 62 and o["state"][0]["step"] > 0
+        assert o["param_groups"][0]["betas"] == (0.5, 0.99)
+    m, s = state["val_mean_std"]
+    assert m.shape == (3,) and 0.3 < float(m.mean()) < 0.7 and 0.1 < float(s.mean()) < 0.5   # real statistics
+    assert state["args"].train_federated and len(state["model_state_dict"]) == 122
+    # federated -> federated, in process this time: starts AT the saved epoch with the saved optimizer state
+    out = run(base + ["--train_federated", "--training_name", "resumed", "--resume_checkpoint", ckpt],
+              {"PRIMIA_WEBSOCKETS_CONFIG": str(csv)})
+    assert "Resume training from a given checkpoint." in out
+    assert "Train Epoch: {:d}".format(state["epoch"]) in out and "Train Epoch: 1 " not in out
+    # federated -> vanilla
+    out = run(base[:4] + ["--data_dir", os.path.join(data, "worker1"), "--training_name", "vanilla",
+                          "--resume_checkpoint", ckpt])
+    assert "Resume training" in out
+    van = os.path.join(ROOT, "model_weights", "final_vanilla_vanilla.pt")
+    vs = torch.load(van, map_location="cpu", weights_only=False)
+    assert set(vs["optim_state_dict"]) == {"state", "param_groups"}
+    for f in (ckpt, van, os.path.join(ROOT, "model_weights", "final_federated_resumed.pt")):
+        os.remove(f)

@@ -7,14 +7,21 @@ Same command line, INI keys and worker CSV as the reference's train.py (train.py
         [--unencrypted_aggregation] [--data_dir DIR|synthetic] [--cuda] [--resume_checkpoint P] \
         [--save_file F] [--training_name N]
 
-Differences, all on the side of "more works":
-  * `--cuda` together with `--train_federated` is legal (the reference refuses it,
-    train.py:617-622): client i of configs/websetting/config.csv runs on the GPU;
-  * launched under `torch.distributed.run` (WORLD_SIZE = number of clients) every rank is one client
-    on its own GPU and FedAvg is an RCCL all-reduce; launched plainly, all clients live in this
-    process like the reference's VirtualWorkers and are visited sequentially;
-  * `--data_dir synthetic` (default when the folder does not exist) trains on seeded synthetic
-    3x224x224 batches — the data pipeline (albumentations, DICOM) is outside the hot path.
+Two deployments of the same federated epoch (torchlib/utils.py:936-1233):
+
+  * plain launch: every client of configs/websetting/config.csv lives in this process on GPU 0 and is visited
+    in turn, like the reference's VirtualWorkers (`torchlib_compat.train_federated`);
+  * `python -m torch.distributed.run --nproc-per-node K train.py ... --train_federated`: rank k IS client k of the CSV
+    (crypto_provider row excluded, utils.py:531-542) on GPU k; the process group is created before anything touches
+    the GPU's allocator, FedAvg is an RCCL all-reduce of the flat arena (`fed.federated_epoch`), secure aggregation
+    hides every client's encoded update under pairwise one-time masks, rank 0 validates and writes the checkpoints.
+    K must equal the number of clients in the CSV (PRIMIA_WEBSOCKETS_CONFIG selects another CSV, e.g.
+    configs/websetting/config_8gpu.csv).
+
+`--cuda` together with `--train_federated` is legal here (the reference refuses it, train.py:617-622).
+`--data_dir synthetic` trains on seeded synthetic batches; a folder is read as the reference lays it out
+(`<data_dir>/worker<i>/<class>/<image>` per client, `<data_dir>/validation/<class>/<image>`; vanilla training reads
+`<data_dir>/<class>/<image>`), resized / cropped / normalised on the GPU (primia_amd.imagefolder).
 
 `main(args, verbose, optuna_trial, cmd_args)` returns the best validation MCC like the reference's.
 """
@@ -22,22 +29,27 @@ import argparse
 import configparser
 import os
 import random
+import shutil
 from os import path
+from warnings import warn
 
 import numpy as np
 import torch
 
 from primia_amd.engine import ResNet18Engine
+from primia_amd.optim import EngineOptimizer
 from primia_amd.torchlib_compat import (Arguments, LearningRateScheduler, read_websocket_config, save_model, test,
                                         train, train_federated)
+
+WEBSOCKETS_CONFIG = os.environ.get("PRIMIA_WEBSOCKETS_CONFIG", "configs/websetting/config.csv")
 
 
 class SyntheticLoader:
     """Device-resident synthetic shard: yields (x fp32 NCHW on the GPU, int64 labels)."""
 
-    def __init__(self, n_batches, batch, size, num_classes, device, seed):
+    def __init__(self, n_batches, batch, size, num_classes, device, seed, channels=3):
         g = torch.Generator().manual_seed(seed)
-        self.data = [(torch.randn(batch, 3, size, size, generator=g).to(device),
+        self.data = [(torch.randn(batch, channels, size, size, generator=g).to(device),
                       torch.randint(0, num_classes, (batch,), generator=g).to(device)) for _ in range(n_batches)]
 
     def __len__(self):
@@ -49,7 +61,7 @@ class SyntheticLoader:
 
 def setup_workers(args):
     """setup_pysyft (torchlib/utils.py:516-542): worker list from the CSV, crypto_provider split off."""
-    worker_dict = read_websocket_config("configs/websetting/config.csv")
+    worker_dict = read_websocket_config(WEBSOCKETS_CONFIG)
     names = [w["id"] for w in worker_dict.values()]
     crypto_in_config = "crypto_provider" in names
     assert args.unencrypted_aggregation or crypto_in_config, "No crypto provider in configuration"
@@ -58,89 +70,226 @@ def setup_workers(args):
     return names, ("crypto_provider" if crypto_in_config else None)
 
 
-def main(args, verbose=True, optuna_trial=None, cmd_args=None):
-    use_cuda = torch.cuda.is_available()
-    if not use_cuda:
+def init_distributed():
+    """(rank, world, device).  Under torch.distributed.run the process group is created FIRST, bound to this rank's
+    GPU (backend "nccl" = RCCL; PRIMIA_BACKEND=gloo lets several ranks share one GPU in the tests)."""
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if not torch.cuda.is_available():
         raise SystemExit("primia_amd trains on the GPU only (HIP kernels); no GPU visible")
-    device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+    device = torch.device("cuda", local_rank % torch.cuda.device_count())
     torch.cuda.set_device(device)
+    if world == 1:
+        return 0, 1, device
+    import torch.distributed as dist
+
+    backend = os.environ.get("PRIMIA_BACKEND", "nccl")
+    if backend == "nccl":
+        dist.init_process_group("nccl", device_id=device)
+    else:
+        dist.init_process_group(backend)
+    return dist.get_rank(), world, device
+
+
+def resume(cmd_args, args, model, optimizer, worker_names):
+    """The four checkpoint / configuration combinations of train.py:344-389.  Returns the epoch to start at —
+    `state["epoch"]` itself, as the reference does (the saved epoch is run again)."""
+    state = torch.load(cmd_args.resume_checkpoint, map_location="cpu", weights_only=False)
+    ckpt_args = state["args"]
+    was_federated = bool(getattr(ckpt_args, "train_federated", False))
+    opt_sd = state["optim_state_dict"]
+    if args.train_federated and was_federated:
+        for w in worker_names:
+            if w not in opt_sd:
+                warn("The worker names of the checkpoint and the current configuration cannot be matched.")
+                raise SystemExit(1)
+            if w in optimizer:          # per-rank launch: each rank restores its own client's optimizer
+                optimizer[w].load_state_dict(opt_sd[w])
+        for m in model.values():
+            m.load_state_dict(state["model_state_dict"])
+    elif args.train_federated and not was_federated:
+        assert len(opt_sd) == 2 and "param_groups" in opt_sd and "state" in opt_sd  # no federated checkpoint
+        for w in worker_names:
+            if w in optimizer:
+                optimizer[w].load_state_dict(opt_sd)
+        for m in model.values():
+            m.load_state_dict(state["model_state_dict"])
+    elif not args.train_federated and was_federated:
+        # no optimizer is loaded.  (The reference indexes model_state_dict["local_model"] here although save_model
+        # stores the local model's state dict itself, utils.py:1484-1486 — both layouts are accepted.)
+        sd = state["model_state_dict"]
+        model.load_state_dict(sd["local_model"] if "local_model" in sd else sd)
+    else:
+        optimizer.load_state_dict(opt_sd)
+        model.load_state_dict(state["model_state_dict"])
+    return state["epoch"]
+
+
+def main(args, verbose=True, optuna_trial=None, cmd_args=None):
+    rank, world, device = init_distributed()
     torch.manual_seed(args.seed)
     random.seed(args.seed)
     np.random.seed(args.seed)
     num_classes = 3
     size = args.train_resolution
+    channels = 3 if args.pretrained else 1
     if args.model != "resnet-18":
         raise NotImplementedError("only resnet-18 is on the accelerated path")
+    if world > 1 and not args.train_federated:
+        raise SystemExit("several ranks are several federated clients: launch with --train_federated")
     dtype = torch.float32 if os.environ.get("PRIMIA_DTYPE", "bf16") == "f32" else torch.bfloat16
     n_batches = int(os.environ.get("PRIMIA_SYNTHETIC_BATCHES", 8))
+    synthetic = args.data_dir in (None, "synthetic") or not path.isdir(str(args.data_dir))
+    if not synthetic:
+        from primia_amd import imagefolder
+    elif args.data_dir not in (None, "synthetic"):
+        warn("data_dir {!r} does not exist: training on synthetic batches".format(args.data_dir))
 
     def make_engine():
         # differentially_private = yes (train.py:304-334 of the reference): BatchNorm is rejected by the
         # PrivacyEngine, so the network is built with GroupNorm and every step clips / noises per sample
-        eng = ResNet18Engine(args.batch_size, num_classes, 3 if args.pretrained else 1, size, args.pooling_type,
+        eng = ResNet18Engine(args.batch_size, num_classes, channels, size, args.pooling_type,
                              dtype=dtype, device=device, norm="group" if args.differentially_private else "batch")
         if args.differentially_private:
             eng.dp_params = {"max_grad_norm": 1.0, "noise_multiplier": 1.3}
         return eng
 
+    # `pretrained` only selects the three-channel stem here: there is no network to fetch ImageNet weights from
+    # (models.py:505-514 downloads them); start from a checkpoint with --resume_checkpoint instead.
     local = make_engine()
     local.init_weights()
-    start_at_epoch = 1
-    if cmd_args is not None and getattr(cmd_args, "resume_checkpoint", None):
-        state = torch.load(cmd_args.resume_checkpoint, map_location="cpu", weights_only=False)
-        local.load_state_dict(state["model_state_dict"])
-        start_at_epoch = state["epoch"] + 1
-    val_loader = SyntheticLoader(2, args.batch_size, size, num_classes, device, args.seed + 999)
-    scheduler = LearningRateScheduler(args.epochs, np.log10(args.lr), np.log10(args.end_lr), restarts=args.restarts)
+    val_mean_std = (torch.zeros(channels), torch.ones(channels))
     exp_name = "{:s}_{:s}".format("federated" if args.train_federated else "vanilla", args.name)
+    group = None
+    masks = None
 
     if args.train_federated:
         workers, crypto_provider = setup_workers(args)
+        if world > 1:
+            import torch.distributed as dist
+
+            from primia_amd import fed
+
+            if len(workers) != world:
+                raise SystemExit("{:d} ranks but {:d} clients in {:s}: one rank per client".format(
+                    world, len(workers), WEBSOCKETS_CONFIG))
+            mine = [workers[rank]]
+        else:
+            mine = list(workers)
         model = {"local_model": local}
-        for i, w in enumerate(workers):
+        for w in mine:
             model[w] = make_engine()
             model[w].load_state_dict(local.state_dict())
-        # synthetic, deliberately uneven shards (exercises weighted averaging and exhausted clients)
-        train_loader = {w: SyntheticLoader(n_batches - i, args.batch_size, size, num_classes, device, args.seed + i)
-                        for i, w in enumerate(workers)}
-        optimizer = {w: {"lr": args.lr} for w in workers}
-        loss_fn = {w: None for w in workers}
+        train_loader, stats = {}, {}
+        for w in mine:
+            i = workers.index(w)
+            if synthetic:
+                # deliberately uneven shards (exercises weighted averaging and exhausted clients)
+                train_loader[w] = SyntheticLoader(max(1, n_batches - i), args.batch_size, size, num_classes, device,
+                                                  args.seed + i, channels)
+                stats[w] = (torch.zeros(channels, device=device), torch.ones(channels, device=device))
+            else:
+                train_loader[w], stats[w] = imagefolder.client_loader(
+                    path.join(args.data_dir, "worker{:d}".format(i + 1)), args, device, channels, args.seed + i)
+        # setup_pysyft's secure average of the clients' (mean, std) (utils.py:764-794) -> val_mean_std
+        if world > 1:
+            m, s = fed.exchange_mean_std(*stats[mine[0]])
+        else:
+            from primia_amd import fed
+
+            m, s = fed.secure_mean_of([stats[w] for w in mine])
+        val_mean_std = (m.cpu(), s.cpu())
+        optimizer = {w: EngineOptimizer.from_args(model[w], args) for w in mine}
+        loss_fn = {w: None for w in mine}
+        if world > 1 and not args.unencrypted_aggregation:
+            masks = fed.PairwiseMasks.setup(local.flat.numel(), device, group)
     else:
+        workers, mine = [], []
         model = local
-        train_loader = SyntheticLoader(n_batches, args.batch_size, size, num_classes, device, args.seed)
-        optimizer = {"lr": args.lr}
+        if synthetic:
+            train_loader = SyntheticLoader(n_batches, args.batch_size, size, num_classes, device, args.seed, channels)
+        else:
+            train_loader, (m, s) = imagefolder.client_loader(args.data_dir, args, device, channels, args.seed)
+            val_mean_std = (m.cpu(), s.cpu())
+        optimizer = EngineOptimizer.from_args(model, args)
         loss_fn = None
+    if synthetic or not path.isdir(path.join(str(args.data_dir), "validation")):
+        val_loader = SyntheticLoader(2, args.batch_size, size, num_classes, device, args.seed + 999, channels)
+    else:
+        val_loader = imagefolder.validation_loader(path.join(args.data_dir, "validation"), args, device, channels,
+                                                   val_mean_std)
+
+    start_at_epoch = 1
+    if cmd_args is not None and getattr(cmd_args, "resume_checkpoint", None):
+        print("Resume training from a given checkpoint.")
+        start_at_epoch = resume(cmd_args, args, model, optimizer, workers)
+    scheduler = LearningRateScheduler(args.epochs, np.log10(args.lr), np.log10(args.end_lr), restarts=args.restarts)
+    reps = args.repetitions_dataset if "repetitions_dataset" in vars(args) else 1
 
     objectives, model_paths = [], []
+    local_flat = None
     for epoch in range(start_at_epoch, args.epochs + 1):
-        new_lr = float(scheduler.get_lr(epoch - 1))
-        if args.train_federated:
-            for w in optimizer:
-                optimizer[w]["lr"] = new_lr
-            model = train_federated(args, model, device, train_loader, optimizer, epoch, loss_fn, None,
+        for o in (optimizer.values() if args.train_federated else [optimizer]):
+            scheduler.adjust_learning_rate(o, epoch - 1)
+        if args.train_federated and world > 1:
+            w = mine[0]
+            avg_loss, _, local_flat, optimizer[w] = fed.federated_epoch(
+                model[w], train_loader[w], args, optimizer[w], group=group, local_flat=local_flat, masks=masks)
+            local.flat.copy_(local_flat)              # "local_model": the last global average
+            for b in local.num_batches_tracked:
+                local.num_batches_tracked[b] = 0
+            local.refresh_weights()
+            if verbose and rank == 0:
+                print("Train Epoch: {} \tLoss: {:.6f}".format(epoch, avg_loss))
+            eval_model = local
+        elif args.train_federated:
+            model = train_federated(args, model, device, train_loader, optimizer, epoch, loss_fn, crypto_provider,
                                     verbose=verbose)
             eval_model = model["local_model"]
         else:
-            optimizer["lr"] = new_lr
             model = train(args, model, device, train_loader, optimizer, epoch, loss_fn, num_classes, verbose=verbose)
             eval_model = model
         if epoch % args.test_interval == 0:
-            _, objective = test(args, eval_model, device, val_loader, epoch, loss_fn, num_classes, verbose=verbose)
-            objectives.append(objective)
-            p = "model_weights/{:s}_epoch_{:03d}.pt".format(exp_name, epoch)
-            save_model(eval_model, optimizer, p, args, epoch, val_mean_std=(torch.zeros(3), torch.ones(3)))
-            model_paths.append(p)
-    if not objectives:
-        return 0.0
-    best = int(np.argmax(objectives))
-    final = "model_weights/final_{:s}.pt".format(exp_name)
-    os.replace(model_paths[best], final)
-    for i, p in enumerate(model_paths):
-        if i != best and path.exists(p):
-            os.remove(p)
-    if verbose:
-        print("best epoch {:d} -> {:s}".format(best + 1, final))
-    return objectives[best]
+            opt_for_ckpt = optimizer
+            if world > 1:
+                # the checkpoint holds every worker's optimizer state (utils.py:1471-1472): collect them on rank 0
+                import torch.distributed as dist
+
+                gathered = [None] * world
+                dist.all_gather_object(gathered, (mine[0], optimizer[mine[0]].state_dict()))
+                opt_for_ckpt = dict(gathered)
+            if rank == 0:
+                _, objective = test(args, eval_model, device, val_loader, epoch, loss_fn, num_classes, verbose=verbose)
+                objectives.append(objective)
+                p = "model_weights/{:s}_epoch_{:03d}.pt".format(exp_name, epoch * reps)
+                save_model(eval_model, opt_for_ckpt, p, args, epoch, val_mean_std=val_mean_std)
+                model_paths.append(p)
+                if optuna_trial:
+                    optuna_trial.report(objective, epoch * reps)
+                    if optuna_trial.should_prune():
+                        raise RuntimeError("trial pruned")
+            if world > 1:
+                dist.barrier()
+    best_score = 0.0
+    if rank == 0 and objectives:
+        # the LAST occurrence of the highest score wins (train.py:514-521)
+        scores = np.array(objectives)[::-1]
+        best = len(scores) - int(np.argmax(scores)) - 1
+        final = "model_weights/final_{:s}.pt".format(exp_name)
+        shutil.copyfile(model_paths[best], final)
+        for p in model_paths:
+            if path.exists(p):
+                os.remove(p)
+        best_score = float(objectives[best])
+        if verbose:
+            print("Highest matthews coefficient was {:.1f}% in epoch {:d}".format(
+                best_score, (best + 1) * args.test_interval * (reps if args.train_federated else 1)))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+        dist.destroy_process_group()
+    return best_score
 
 
 if __name__ == "__main__":
@@ -161,9 +310,10 @@ if __name__ == "__main__":
     assert path.isfile(cmd_args.config), "Configuration file not found"
     config.read(cmd_args.config)
     cmd_args.websockets = False  # in-process / RCCL clients replace the websocket transport
-    args = Arguments(cmd_args, config, mode="train")
+    args = Arguments(cmd_args, config, mode="train", verbose=int(os.environ.get("RANK", 0)) == 0)
     if args.train_federated and (args.mixup or args.weight_classes):
         if args.mixup and args.mixup_lambda == 0.5:
             args.mixup_lambda = 0.499
-    print(str(args))
+    if int(os.environ.get("RANK", 0)) == 0:
+        print(str(args))
     main(args, cmd_args=cmd_args)
