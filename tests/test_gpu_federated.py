@@ -1,5 +1,6 @@
 """GPU: the in-process federated epoch (reference layout: all clients in one process) and the
 PriMIA-compatible CLIs."""
+import copy
 import json
 import os
 import subprocess
@@ -304,7 +305,7 @@ def test_optimizer_state_dict_round_trips_with_torch_adam(cuda):
         opt.step()
         ref = [p.detach().clone() for p in params]
         ropt = torch.optim.Adam([torch.nn.Parameter(r) for r in ref], lr=1e-3, betas=(0.5, 0.99), weight_decay=5e-4)
-        ropt.load_state_dict(sd)
+        ropt.load_state_dict(copy.deepcopy(sd))      # torch's loader keeps the `step` tensors it is given
         for p, gr in zip(ropt.param_groups[0]["params"], grads[2]):
             p.grad = gr.clone()
         ropt.step()
