@@ -360,6 +360,319 @@ __global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __
     for (int j = 0; j < 4; ++j) dw[(long)(k0 + j) * klen + e] = a[j];
 }
 
+
+// =====================================================================================================================
+// v2: the same halo-patch scheme on v_mfma_f32_32x32x16_bf16.
+//
+// What changed against the kernel above, and why (measured, profiles/r02_wgrad32_*.txt):
+//   * fragment traffic: a 32x32x16 MFMA does twice the MACs of a 16x16x32 per operand byte fetched from LDS, and the
+//     old stage body (all 44 transposing reads up front, then 36 dependent-issue MFMAs) ran at ~1.0 PFLOP/s with the
+//     staging switched off; the body below sustains 1.43 PFLOP/s alone (tools/micro/mfma_stage32.hip);
+//   * the two sub-patches of a stage go to the two HALVES of the block (waves 0-3 / 4-7) instead of every wave walking
+//     both: wave (half, kg, cg) owns out-channels 32*kg.., in-channels 32*cg.. of all nine taps for ITS sub-patch =
+//     nine f32x16 accumulators (144 registers, as before) and per 16-pixel k-step 1 dy + 9 x fragments for 9 MFMAs;
+//     the halves are added through LDS once, after the main loop;
+//   * LDS image: a pixel slot is 128 B = two 64-B channel groups; group g of slot s sits in half g ^ bit1(s), so the
+//     four consecutive slots one 32-lane phase of ds_read_b64_tr_b16 touches always cover all 64 banks, for any slot
+//     alignment (tap shifts!).  The halo row stride is a multiple of 4 slots (12 / 20) so that tap rows and k-steps
+//     are compile-time byte offsets from 3 x 2 + 2 address registers.
+// Staging (LDS-DMA pieces of 8 slots, source-side swizzle, zero page for padding), the split over pixel ranges, the
+// slab workspace and the three epilogues are those of the kernel above.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ int key32(int slot) { return (slot >> 1) & 1; }
+
+template <int SW, int STAGES>
+__global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) {
+    constexpr int SH = 32 / SW;
+    constexpr int HR = SH + 2;
+    constexpr int HS = SW == 8 ? 12 : 20;       // halo row stride in slots: a multiple of 4 (see above)
+    constexpr int XSLOTS = HR * HS;             // 72 | 80: whole 8-slot DMA pieces
+    constexpr int XP = XSLOTS / 8;              // pieces per sub-patch halo
+    constexpr int NPIECE = 2 * XP + 8;          // per stage: two halos + 64 dy slots
+    constexpr int X_BYTES = XSLOTS * 128;
+    constexpr int STAGE = 2 * X_BYTES + 64 * 128;
+    constexpr int NW4 = NPIECE - 24;            // waves that issue four pieces per stage (the others three)
+    static_assert(XSLOTS % 8 == 0 && NW4 >= 0 && NW4 <= 8, "piece bookkeeping");
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, kg = (wave >> 1) & 1, cg = wave & 1;
+
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int split;
+    if (p.split_fastest) {
+        split = bid % p.nsplit;
+        bid /= p.nsplit;
+    }
+    const int ct = bid % p.nct; bid /= p.nct;
+    const int kt = bid % p.nkt;
+    if (!p.split_fastest) split = bid / p.nkt;
+    const int t0 = split * p.per_block;
+    int t1 = t0 + p.per_block;
+    if (t1 > p.total) t1 = p.total;
+    const int nstages = (t1 - t0 + 1) >> 1;
+
+    const bf16* __restrict__ x = p.x + ct * 64;
+    const bf16* __restrict__ dy = p.dy + kt * 64;
+
+    // ---- staging constants (per DMA instruction `it` of this wave) ------------------------------------------------
+    int drow[4], dcol[4], rel[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = wave + 8 * it;
+        const int c16 = lane & 7;                       // 16-byte chunk of the 128-byte slot row
+        if (idx < 2 * XP) {
+            const int j = idx >= XP ? idx - XP : idx;
+            const int slot = j * 8 + (lane >> 3);
+            const int hy = slot / HS, hx = slot - hy * HS;
+            const int grp = (c16 >> 2) ^ key32(slot);   // the channel group that lives in this half of the row
+            drow[it] = hy - 1;
+            dcol[it] = hx < SW + 2 ? hx - 1 : (1 << 20);
+            rel[it] = ((hy - 1) * p.W + (hx - 1)) * p.C + (grp * 4 + (c16 & 3)) * 8;
+        } else {
+            const int slot = (idx - 2 * XP) * 8 + (lane >> 3);
+            const int k = slot & 31;
+            const int py = SW == 8 ? (k >> 3) : (k >> 4), px = SW == 8 ? (k & 7) : (k & 15);
+            const int grp = (c16 >> 2) ^ key32(slot);
+            drow[it] = py;
+            dcol[it] = px;
+            rel[it] = (py * p.W + px) * p.K + (grp * 4 + (c16 & 3)) * 8;
+        }
+    }
+    int sn, sph, spw;
+    {
+        sn = t0 / p.PPI;
+        const int rem = t0 - sn * p.PPI;
+        sph = rem / p.PW;
+        spw = rem - sph * p.PW;
+    }
+    int st = t0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    auto stage = [&](int buf) {
+        int rb[2], cb[2], pixbase[2];
+        bool live[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            live[q] = st < t1;
+            rb[q] = sph * SH;
+            cb[q] = spw * SW;
+            pixbase[q] = (sn * p.H + rb[q]) * p.W + cb[q];
+            ++st;
+            if (++spw == p.PW) {
+                spw = 0;
+                if (++sph == p.PH) {
+                    sph = 0;
+                    ++sn;
+                }
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = wave + 8 * it;
+            if (idx >= NPIECE) break;
+            const bool isx = idx < 2 * XP;
+            const int q = isx ? (idx >= XP) : (idx >= 2 * XP + 4);
+            const int dst = isx ? q * X_BYTES + (idx - XP * q) * 1024 : 2 * X_BYTES + (idx - 2 * XP) * 1024;
+            const int row = rb[q] + drow[it], col = cb[q] + dcol[it];
+            const bool ok = live[q] && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
+            const bf16* src = isx ? x : dy;
+            const int elem = pixbase[q] * (isx ? p.C : p.K) + rel[it];
+            const bf16* g = ok ? src + elem : (const bf16*)kWpZeroPage;
+            dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + dst));
+        }
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+    // ---- fragment addresses: lane (16-lane group g16, fr) reads pixel 8*(g16>>1) + (fr>>2) (+4) of the k-step,
+    //      channels 16*(g16&1) + 4*(fr&3) .. +3 of the wave's group --------------------------------------------------
+    const int fr = lane & 15, g16 = lane >> 4;
+    const int cbyte = (16 * (g16 & 1) + 4 * (fr & 3)) * 2;
+    int offa[2], offx[3][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int kk = 8 * (g16 >> 1) + (fr >> 2) + 4 * h;            // pixel of the FIRST k-step of the sub-patch
+        const int py = SW == 8 ? (kk >> 3) : 0, px = SW == 8 ? (kk & 7) : kk;
+        const int sa = half * 32 + kk;
+        offa[h] = 2 * X_BYTES + sa * 128 + ((kg ^ key32(sa)) << 6) + cbyte;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int slot = py * HS + px + s;
+            offx[s][h] = half * X_BYTES + slot * 128 + ((cg ^ key32(slot)) << 6) + cbyte;
+        }
+    }
+    constexpr int KSTEP_X = (SW == 8 ? 2 * HS : HS) * 128;   // second k-step: two rows (SW 8) / one row (SW 16) further
+    constexpr int KSTEP_A = 16 * 128;
+
+    auto compute = [&](int buf) {
+        const char* sb = smem + buf * STAGE;
+        bf16x8_t a[2], b[2][9];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            {
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sb + offa[0] + j * KSTEP_A));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sb + offa[1] + j * KSTEP_A));
+                a[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, s = t - 3 * r;
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds4_t)(sb + offx[s][0] + j * KSTEP_X + r * HS * 128));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+                    (lds4_t)(sb + offx[s][1] + j * KSTEP_X + r * HS * 128));
+                b[j][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[j][t], acc[t], 0, 0, 0);
+    };
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nstages) stage(s);
+    int cur = 0, nxt = STAGES - 1;
+    for (int s = 0; s < nstages; ++s) {
+        int ahead = nstages - 1 - s;
+        if (ahead > STAGES - 2) ahead = STAGES - 2;
+        if (ahead >= 2) {
+            if (wave < NW4)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (ahead == 1) {
+            if (wave < NW4)
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+        if (s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2)) stage(nxt);
+        if (!(p.debug_skip_epilogue & 4)) compute(cur);
+        cur = cur + 1 == STAGES ? 0 : cur + 1;
+        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+    }
+
+    // ---- the two halves meet in LDS: waves 4-7 park their accumulators, waves 0-3 add them ---------------------------
+    if ((p.debug_skip_epilogue & 1) && acc[0][0] != 12345.f) return;
+    __syncthreads();                                   // every wave is done reading the stage ring
+    {
+        f32x4* park = (f32x4*)smem + ((wave & 3) * 36) * 64 + lane;     // [wave & 3][t * 4 + m][lane] chunks of 16 B
+        if (half) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    park[(t * 4 + m) * 64] = f32x4{acc[t][4 * m], acc[t][4 * m + 1], acc[t][4 * m + 2], acc[t][4 * m + 3]};
+        }
+        __syncthreads();
+        if (half) return;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 v = park[(t * 4 + m) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][4 * m + j] += v[j];
+            }
+    }
+    // lane holds out-chan rows 32*kg + 8*m + 4*(lane>>5) + j (register 4*m + j), in-chan column 32*cg + (lane & 31)
+    if (p.sqnorm) {
+        double sq = 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sq += (double)acc[t][j] * (double)acc[t][j];
+        wave_sqnorm_add(sq, p.sqnorm + split);
+        return;
+    }
+    if (p.ws) {
+        // slab chunk ((t*4 + m)*4 + wave)*64 + lane = registers 4m..4m+3 of accumulator t (wgrad_patch32_reduce_kernel)
+        float* o = p.ws + ((long)(kt * p.nct + ct) * p.nsplit + split) * kSlab + (wave * 64 + lane) * 4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                *(f32x4*)(o + (t * 4 + m) * 1024) = f32x4{acc[t][4 * m], acc[t][4 * m + 1], acc[t][4 * m + 2], acc[t][4 * m + 3]};
+        return;
+    }
+    float* out = p.dw + (long)split * p.split_stride;
+    auto flush = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kt * 64 + 32 * kg + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            const int e = t * p.C + ct * 64 + 32 * cg + (lane & 31);
+            unsafeAtomicAdd(out + (long)k * p.klen + e, acc[t][r]);
+        }
+    };
+    // blocks of one slab start at different taps, so that at any instant they hit different cache lines
+#define PRIMIA_FLUSH32_FROM(R)                     \
+    case R:                                        \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) flush((t + R) % 9); \
+        break;
+    switch (split % 9) {
+        PRIMIA_FLUSH32_FROM(0)
+        PRIMIA_FLUSH32_FROM(1)
+        PRIMIA_FLUSH32_FROM(2)
+        PRIMIA_FLUSH32_FROM(3)
+        PRIMIA_FLUSH32_FROM(4)
+        PRIMIA_FLUSH32_FROM(5)
+        PRIMIA_FLUSH32_FROM(6)
+        PRIMIA_FLUSH32_FROM(7)
+        PRIMIA_FLUSH32_FROM(8)
+    }
+#undef PRIMIA_FLUSH32_FROM
+}
+
+// Ordered reduction of the v2 slabs (chunk q = ((t*4 + m)*4 + wave)*64 + lane, see the kernel's store).
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_patch32_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                   int nsplit, int nct, int C, int klen) {
+    constexpr int CL = 256 / SL;
+    constexpr int CPB = kSlab / 4 / CL;
+    __shared__ f32x4 red[SL][CL];
+    const int combo = blockIdx.x / CPB;
+    const int q = (blockIdx.x % CPB) * CL + (threadIdx.x % CL);
+    const int sl = threadIdx.x / CL;
+    const float* src = ws + (long)combo * nsplit * kSlab + q * 4;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    int s = sl;
+#pragma unroll 1
+    for (; s + 3 * SL < nsplit; s += 4 * SL) {
+        const f32x4 v0 = *(const f32x4*)(src + (long)s * kSlab);
+        const f32x4 v1 = *(const f32x4*)(src + (long)(s + SL) * kSlab);
+        const f32x4 v2 = *(const f32x4*)(src + (long)(s + 2 * SL) * kSlab);
+        const f32x4 v3 = *(const f32x4*)(src + (long)(s + 3 * SL) * kSlab);
+        a += v0; a += v1; a += v2; a += v3;
+    }
+    for (; s < nsplit; s += SL) a += *(const f32x4*)(src + (long)s * kSlab);
+    if (SL > 1) {
+        red[sl][threadIdx.x % CL] = a;
+        __syncthreads();
+        if (sl != 0) return;
+#pragma unroll
+        for (int k = 1; k < SL; ++k) a += red[k][threadIdx.x % CL];
+    }
+    const int lane = q & 63, wave = (q >> 6) & 3, m = (q >> 8) & 3, t = q >> 10;
+    const int kt = combo / nct, ct = combo - kt * nct;
+    const int k0 = kt * 64 + 32 * (wave >> 1) + 8 * m + 4 * (lane >> 5);
+    const int e = t * C + ct * 64 + 32 * (wave & 1) + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dw[(long)(k0 + j) * klen + e] = a[j];
+}
+
 struct PatchGeom {
     bool ok, wide;
     int PH, PW, PPI, total, per_block, nsplit, combos;
@@ -420,8 +733,33 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
     p.debug_skip_epilogue = noepi;
     const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
     p.ws = store ? w.ws : nullptr;
-    constexpr int XS = (SH + 2) * (SW == 8 ? 12 : 18);
+    static const int v2 = getenv("PRIMIA_WGP32") ? atoi(getenv("PRIMIA_WGP32")) : 1;
     static const int stages = getenv("PRIMIA_WGP_STAGES") ? atoi(getenv("PRIMIA_WGP_STAGES")) : 3;
+    if (v2) {
+        constexpr int XS2 = (SH + 2) * (SW == 8 ? 12 : 20);
+        // the stage ring, or the 144 KiB the two halves need to meet in after the main loop
+        size_t lds = (size_t)(stages == 4 ? 4 : 3) * (2 * XS2 * 128 + 64 * 128);
+        if (lds < (size_t)kSlab * 4) lds = (size_t)kSlab * 4;
+        auto kern = stages == 4 ? conv_wgrad_patch32_kernel<SW, 4> : conv_wgrad_patch32_kernel<SW, 3>;
+        static bool attr_set2 = false;
+        if (!attr_set2) {
+            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return PRIMIA_ERR_LAUNCH;
+            attr_set2 = true;
+        }
+        kern<<<(unsigned)(g.combos * g.nsplit), 512, lds, st>>>(p);
+        if (store) {
+            const int ns = g.nsplit;
+            if (ns >= 64)
+                wgrad_patch32_reduce_kernel<16><<<g.combos * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+            else if (ns >= 8)
+                wgrad_patch32_reduce_kernel<4><<<g.combos * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+            else
+                wgrad_patch32_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+        }
+        return launch_status();
+    }
+    constexpr int XS = (SH + 2) * (SW == 8 ? 12 : 18);
     const size_t lds = (size_t)(stages == 4 ? 4 : 3) * (2 * XS * 128 + 64 * 128);
     auto kern = stages == 4 ? conv_wgrad_patch_kernel<SW, 4> : conv_wgrad_patch_kernel<SW, 3>;
     static bool attr_set = false;
