@@ -379,6 +379,10 @@ __global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __
 // Staging (LDS-DMA pieces of 8 slots, source-side swizzle, zero page for padding), the split over pixel ranges, the
 // slab workspace and the three epilogues are those of the kernel above.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+template <bool V>
+struct OrderTag {
+    static constexpr bool value = V;
+};
 
 __device__ __forceinline__ int key32(int slot) { return (slot >> 1) & 1; }
 
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
             const int grp = (c16 >> 2) ^ key32(slot);   // the channel group that lives in this half of the row
             drow[it] = hy - 1;
             dcol[it] = hx < SW + 2 ? hx - 1 : (1 << 20);
-            rel[it] = ((hy - 1) * p.W + (hx - 1)) * p.C + (grp * 4 + (c16 & 3)) * 8;
+            rel[it] = (((hy - 1) * p.W + (hx - 1)) * p.C + (grp * 4 + (c16 & 3)) * 8) * 2;   // bytes
         } else {
             const int slot = (idx - 2 * XP) * 8 + (lane >> 3);
             const int k = slot & 31;
@@ -439,9 +443,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
             const int grp = (c16 >> 2) ^ key32(slot);
             drow[it] = py;
             dcol[it] = px;
-            rel[it] = (py * p.W + px) * p.K + (grp * 4 + (c16 & 3)) * 8;
+            rel[it] = ((py * p.W + px) * p.K + (grp * 4 + (c16 & 3)) * 8) * 2;
         }
     }
+    // Buffer resources over the two tensors (from this block's channel tile to the tensor's end).  A lane whose halo
+    // pixel lies outside the image (the convolution's zero padding), in a dead sub-patch or in the pad slots of a halo
+    // row gets an offset beyond num_records: the hardware returns zeros for it — no zero page, no pointer select.
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const long xbytes = ((long)p.total / p.PPI * p.H * p.W * p.C - ct * 64) * 2;
+    const long dybytes = ((long)p.total / p.PPI * p.H * p.W * p.K - kt * 64) * 2;
+    auto make_rsrc = [](const void* base, long bytes) {
+        const unsigned long long a = (unsigned long long)base;
+        i32x4 r;
+        r[0] = (int)(unsigned)a;
+        r[1] = (int)(unsigned)(a >> 32) & 0xffff;       // stride 0: raw buffer
+        r[2] = (int)(unsigned)(bytes > 0xfffffff0L ? 0xfffffff0L : bytes);
+        r[3] = 0x00020000;
+        return r;
+    };
+    i32x4 rsrc_x = make_rsrc(x, xbytes), rsrc_dy = make_rsrc(dy, dybytes);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rsrc_x[j] = __builtin_amdgcn_readfirstlane(rsrc_x[j]);
+        rsrc_dy[j] = __builtin_amdgcn_readfirstlane(rsrc_dy[j]);
+    }
+    constexpr unsigned kOob = 0xfffffff0u;
     int sn, sph, spw;
     {
         sn = t0 / p.PPI;
@@ -451,7 +477,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
     }
     int st = t0;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto stage = [&](int buf) {
+    unsigned voff[4];      // the stage being issued: per-lane byte offset of each of this wave's pieces (or kOob) ...
+    unsigned gdst[4];      // ... and its wave-uniform LDS destination
+    auto prep = [&](int buf) {
         int rb[2], cb[2], pixbase[2];
         bool live[2];
 #pragma unroll
@@ -476,13 +504,30 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
             const bool isx = idx < 2 * XP;
             const int q = isx ? (idx >= XP) : (idx >= 2 * XP + 4);
             const int dst = isx ? q * X_BYTES + (idx - XP * q) * 1024 : 2 * X_BYTES + (idx - 2 * XP) * 1024;
-            const int row = rb[q] + drow[it], col = cb[q] + dcol[it];
-            const bool ok = live[q] && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
-            const bf16* src = isx ? x : dy;
-            const int elem = pixbase[q] * (isx ? p.C : p.K) + rel[it];
-            const bf16* g = ok ? src + elem : (const bf16*)kWpZeroPage;
-            dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + dst));
+            // wave-uniform bounds of the valid (drow, dcol) rectangle of sub-patch q
+            const int r_lo = -rb[q], r_hi = live[q] ? p.H - rb[q] : r_lo, c_lo = -cb[q], c_hi = p.W - cb[q];
+            const bool ok = drow[it] >= r_lo && drow[it] < r_hi && dcol[it] >= c_lo && dcol[it] < c_hi;
+            // (the sub-patch origin goes into the per-lane offset, not into soffset: the range check must see it)
+            voff[it] = ok ? (unsigned)(rel[it] + pixbase[q] * (isx ? p.C : p.K) * 2) : kOob;
+            gdst[it] = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + dst);
         }
+    };
+    bool do_issue = true;               // false in the last STAGES - 1 intervals (nothing left to fetch)
+    auto issue = [&](int it) {          // one LDS-DMA piece (wave-uniform guards: waves >= NW4 have three)
+        if (do_issue && wave + 8 * it < NPIECE) {
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(gdst[it]);
+            if (wave + 8 * it < 2 * XP)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(voff[it]), "s"(rsrc_x), "s"(m0v) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(voff[it]), "s"(rsrc_dy), "s"(m0v) : "memory");
+        }
+    };
+    auto stage = [&](int buf) {
+        prep(buf);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) issue(it);
     };
 
     f32x16 acc[9];
@@ -511,6 +556,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
     constexpr int KSTEP_X = (SW == 8 ? 2 * HS : HS) * 128;   // second k-step: two rows (SW 8) / one row (SW 16) further
     constexpr int KSTEP_A = 16 * 128;
 
+    // One stage of this wave's sub-patch: 2 k-steps x (1 dy + 9 x fragments, 9 MFMAs); the scheduler is left free to
+    // place the 40 transposing reads among the 18 MFMAs (pinning groups with sched_barrier cost 20 %).
     auto compute = [&](int buf) {
         const char* sb = smem + buf * STAGE;
         bf16x8_t a[2], b[2][9];
@@ -541,29 +588,50 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nstages) stage(s);
-    int cur = 0, nxt = STAGES - 1;
-    for (int s = 0; s < nstages; ++s) {
-        int ahead = nstages - 1 - s;
-        if (ahead > STAGES - 2) ahead = STAGES - 2;
-        if (ahead >= 2) {
-            if (wave < NW4)
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else if (ahead == 1) {
-            if (wave < NW4)
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // The two waves of a SIMD belong to different halves.  Inside one barrier interval half 0 issues its DMA pieces
+    // (address arithmetic: VALU / SALU issue) and THEN multiplies, half 1 multiplies and THEN issues — so on every
+    // SIMD one wave feeds the matrix pipe while the other feeds the address pipe.  Legal because staging writes a ring
+    // slot nobody reads in that interval.  Two copies of the loop (one order each) keep one call site per lambda in
+    // each: both orders in ONE loop body made the register allocator spill 275 VGPRs.
+    // The two waves of a SIMD belong to different halves.  Inside one barrier interval half 0 issues its DMA pieces and
+    // THEN multiplies, half 1 multiplies and THEN issues: on every SIMD one wave feeds the matrix pipe while the other
+    // feeds the address pipe.  Legal because staging writes a ring slot nobody reads in that interval.  Two copies of
+    // the loop (one order each): both orders in ONE loop body made the register allocator spill 275 VGPRs.
+    auto main_loop = [&](auto stage_first) {
+        int cur = 0, nxt = STAGES - 1;
+        for (int s = 0; s < nstages; ++s) {
+            int ahead = nstages - 1 - s;
+            if (ahead > STAGES - 2) ahead = STAGES - 2;
+            if (ahead >= 2) {
+                if (wave < NW4)
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            } else if (ahead == 1) {
+                if (wave < NW4)
+                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            do_issue = s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2);
+            if constexpr (decltype(stage_first)::value) {
+                if (do_issue) stage(nxt);
+                if (!(p.debug_skip_epilogue & 4)) compute(cur);
+            } else {
+                if (!(p.debug_skip_epilogue & 4)) compute(cur);
+                if (do_issue) stage(nxt);
+            }
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
         }
-        __builtin_amdgcn_s_barrier();
-        if (s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2)) stage(nxt);
-        if (!(p.debug_skip_epilogue & 4)) compute(cur);
-        cur = cur + 1 == STAGES ? 0 : cur + 1;
-        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
-    }
+    };
+    if (half == 0 || (p.debug_skip_epilogue & 16))
+        main_loop(OrderTag<true>{});
+    else
+        main_loop(OrderTag<false>{});
 
     // ---- the two halves meet in LDS: waves 4-7 park their accumulators, waves 0-3 add them ---------------------------
     if ((p.debug_skip_epilogue & 1) && acc[0][0] != 12345.f) return;
@@ -731,6 +799,7 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
     p.sqnorm = w.persample ? w.sqnorm : nullptr;
     static const int noepi = getenv("PRIMIA_WGP_NOEPI") ? atoi(getenv("PRIMIA_WGP_NOEPI")) : 0;
     p.debug_skip_epilogue = noepi;
+
     const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
     p.ws = store ? w.ws : nullptr;
     static const int v2 = getenv("PRIMIA_WGP32") ? atoi(getenv("PRIMIA_WGP32")) : 1;

@@ -49,7 +49,12 @@ for name, H, C, K, R, s, p, cnt in layers:
     else:
         tf = timeit(lambda: call("primia_conv2d_fwd", d, x, wf, y, dt))
         td = timeit(lambda: call("primia_conv2d_dgrad", d, dy, wd, dx, 0, dt)) if wd is not None else 0.0
-        tw = timeit(lambda: call("primia_conv2d_wgrad", d, x, dy, acc, dt))
+        wsb = query("primia_conv_wgrad_ws_bytes", d, dt)
+        if wsb > 0 and not os.environ.get("CONV_LAYERS_ATOMIC_WGRAD"):   # the engine's path: slabs + ordered reduce
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+            tw = timeit(lambda: call("primia_conv2d_wgrad_ws", d, x, dy, acc, ws, wsb, dt))
+        else:
+            tw = timeit(lambda: call("primia_conv2d_wgrad", d, x, dy, acc, dt))
         if os.environ.get("CONV_LAYERS_ACC") and wd is not None:   # accumulate-form data gradient instead
             td = timeit(lambda: call("primia_conv2d_dgrad", d, dy, wd, dx, 1, dt))
     f = lambda t: fl / (t * 1e-3) / 1e12 if t > 0 else 0
