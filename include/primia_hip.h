@@ -388,7 +388,8 @@ int primia_linear_fwd(const float* x, const float* w, const float* b, float* y, 
                       int out_f, primia_stream_t stream);
 int primia_linear_bwd(const float* x, const float* w, const float* dy, float* dx, float* dw,
                       float* db, int N, int in_f, int out_f, primia_stream_t stream);
-/* Hard labels: loss = sum_n w[t_n] * nll_n / sum_n w[t_n]; class_weight may be NULL. */
+/* Hard labels: loss = sum_n w[t_n] * nll_n / sum_n w[t_n]; class_weight may be NULL.  A label outside [0, C)
+ * (torch raises IndexError there) turns the loss and that sample's dlogits row into NaN: nothing is read out of bounds. */
 int primia_xent_hard(const float* logits, const int64_t* target, const float* class_weight,
                      float* loss, float* dlogits, int N, int C, primia_stream_t stream);
 /* Soft labels: loss = mean_n[(sum_c w_c t_nc) * (-sum_c t_nc * logsoftmax(o)_nc)]. */

@@ -299,7 +299,12 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
             }
             num += a * l;
         } else {
-            const int t = (int)((const int64_t*)target)[n];
+            const int64_t t64 = ((const int64_t*)target)[n];
+            if (t64 < 0 || t64 >= C) {      // torch raises here; a kernel cannot: poison the loss instead of reading
+                num = __builtin_nanf("");   // out of bounds (and the sample's gradient row below)
+                continue;
+            }
+            const int t = (int)t64;
             const float wt = cw ? cw[t] : 1.f;
             num += wt * (lse - o[t]);
             den += wt;
@@ -326,8 +331,10 @@ __global__ __launch_bounds__(256) void xent_kernel(const float* __restrict__ log
             for (int c = 0; c < C; ++c)
                 dlogits[(long)n * C + c] = a / den * (expf(o[c] - mx) * inv * ts - t[c]);
         } else {
-            const int t = (int)((const int64_t*)target)[n];
-            const float wt = (cw ? cw[t] : 1.f) / den;
+            const int64_t t64 = ((const int64_t*)target)[n];
+            const bool bad = t64 < 0 || t64 >= C;
+            const int t = bad ? 0 : (int)t64;
+            const float wt = bad ? __builtin_nanf("") : (cw ? cw[t] : 1.f) / den;
             for (int c = 0; c < C; ++c)
                 dlogits[(long)n * C + c] = wt * (expf(o[c] - mx) * inv - (c == t ? 1.f : 0.f));
         }

@@ -87,3 +87,22 @@ def test_batch_one_training_step(cuda):
     loss = eng.loss_backward(torch.tensor([2], device=cuda))
     eng.sgd_step(1e-3, 0.0)
     assert torch.isfinite(loss).all() and torch.isfinite(eng.flat).all()
+
+
+def test_xent_out_of_range_label_poisons_instead_of_reading_out_of_bounds(cuda):
+    """torch raises for a label outside [0, C); the kernel cannot, so the loss and that sample's gradient row are NaN
+    (loud downstream) and no memory outside cw / logits is touched."""
+    import torch
+
+    from primia_amd._lib import call
+
+    N, C = 5, 3
+    logits = torch.randn(N, C, device=cuda)
+    cw = torch.tensor([0.5, 1.0, 2.0], device=cuda)
+    loss, dl = torch.zeros(1, device=cuda), torch.zeros(N, C, device=cuda)
+    for bad in (3, -1, 2 ** 40):
+        tgt = torch.tensor([0, 1, bad, 2, 1], device=cuda)
+        call("primia_xent_hard", logits, tgt, cw, loss, dl, N, C)
+        assert torch.isnan(loss).all() and torch.isnan(dl[2]).all()
+    call("primia_xent_hard", logits, torch.tensor([0, 1, 2, 2, 1], device=cuda), cw, loss, dl, N, C)
+    assert torch.isfinite(loss).all() and torch.isfinite(dl).all()
