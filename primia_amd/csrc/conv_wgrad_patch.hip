@@ -423,28 +423,43 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
     const bf16* __restrict__ dy = p.dy + kt * 64;
 
     // ---- staging constants (per DMA instruction `it` of this wave) ------------------------------------------------
-    int drow[4], dcol[4], rel[4];
+    // Everything that does not depend on the sub-patch is fixed here, per lane: the byte offset `rel` of the lane's
+    // 16 bytes from the sub-patch origin and `lbits` = one bit for its halo row and one for its halo column; per wave
+    // (scalars): which sub-patch q the piece belongs to, whether it carries x or dy, its LDS offset in the stage.
+    // Per stage a piece then costs four vector instructions (and, compare, add, select): the stage loop issues
+    // instructions at ~one per 4-5 cycles per wave, and the first version of this block — ~50 instructions per piece —
+    // took as long as the stage's MFMAs (profiles/r02_wgrad32_experiments.txt).
+    int rel[4];
+    unsigned lbits[4];
+    int pq[4], pisx[4], pdst[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int idx = wave + 8 * it;
         const int c16 = lane & 7;                       // 16-byte chunk of the 128-byte slot row
+        int drow, dcol;
         if (idx < 2 * XP) {
             const int j = idx >= XP ? idx - XP : idx;
             const int slot = j * 8 + (lane >> 3);
             const int hy = slot / HS, hx = slot - hy * HS;
             const int grp = (c16 >> 2) ^ key32(slot);   // the channel group that lives in this half of the row
-            drow[it] = hy - 1;
-            dcol[it] = hx < SW + 2 ? hx - 1 : (1 << 20);
+            drow = hy - 1;
+            dcol = hx < SW + 2 ? hx - 1 : -2;           // pad slots of the halo row: never valid
             rel[it] = (((hy - 1) * p.W + (hx - 1)) * p.C + (grp * 4 + (c16 & 3)) * 8) * 2;   // bytes
         } else {
             const int slot = (idx - 2 * XP) * 8 + (lane >> 3);
             const int k = slot & 31;
             const int py = SW == 8 ? (k >> 3) : (k >> 4), px = SW == 8 ? (k & 7) : (k & 15);
             const int grp = (c16 >> 2) ^ key32(slot);
-            drow[it] = py;
-            dcol[it] = px;
+            drow = py;
+            dcol = px;
             rel[it] = ((py * p.W + px) * p.K + (grp * 4 + (c16 & 3)) * 8) * 2;
         }
+        lbits[it] = dcol < -1 ? 0x80000000u : (1u << (drow + 1)) | (1u << (8 + dcol + 1));
+        const bool isx = idx < 2 * XP;
+        const int q = isx ? (idx >= XP) : (idx >= 2 * XP + 4);
+        pisx[it] = __builtin_amdgcn_readfirstlane((int)isx);
+        pq[it] = __builtin_amdgcn_readfirstlane(q);
+        pdst[it] = __builtin_amdgcn_readfirstlane(isx ? q * X_BYTES + (idx - XP * q) * 1024 : 2 * X_BYTES + (idx - 2 * XP) * 1024);
     }
     // Buffer resources over the two tensors (from this block's channel tile to the tensor's end).  A lane whose halo
     // pixel lies outside the image (the convolution's zero padding), in a dead sub-patch or in the pad slots of a halo
@@ -480,14 +495,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
     unsigned voff[4];      // the stage being issued: per-lane byte offset of each of this wave's pieces (or kOob) ...
     unsigned gdst[4];      // ... and its wave-uniform LDS destination
     auto prep = [&](int buf) {
-        int rb[2], cb[2], pixbase[2];
-        bool live[2];
+        unsigned smask[2];
+        int xo[2], dyo[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            live[q] = st < t1;
-            rb[q] = sph * SH;
-            cb[q] = spw * SW;
-            pixbase[q] = (sn * p.H + rb[q]) * p.W + cb[q];
+            const bool live = st < t1;
+            const int rb = sph * SH, cb = spw * SW;
+            const int pixbase = (sn * p.H + rb) * p.W + cb;
+            // valid halo rows: bit (drow + 1) for -rb <= drow < H - rb, columns likewise, shifted by 8
+            int rhi = p.H - rb + 1, chi = p.W - cb + 1;
+            rhi = rhi > SH + 2 ? SH + 2 : rhi;
+            chi = chi > SW + 2 ? SW + 2 : chi;
+            const unsigned rowm = ((1u << rhi) - 1u) & ~(rb == 0 ? 1u : 0u);
+            const unsigned colm = ((1u << chi) - 1u) & ~(cb == 0 ? 1u : 0u);
+            smask[q] = live ? rowm | (colm << 8) : 0u;
+            xo[q] = pixbase * p.C * 2;
+            dyo[q] = pixbase * p.K * 2;
             ++st;
             if (++spw == p.PW) {
                 spw = 0;
@@ -497,24 +520,20 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
                 }
             }
         }
+        const unsigned base = lds0 + buf * STAGE;
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int idx = wave + 8 * it;
-            if (idx >= NPIECE) break;
-            const bool isx = idx < 2 * XP;
-            const int q = isx ? (idx >= XP) : (idx >= 2 * XP + 4);
-            const int dst = isx ? q * X_BYTES + (idx - XP * q) * 1024 : 2 * X_BYTES + (idx - 2 * XP) * 1024;
-            // wave-uniform bounds of the valid (drow, dcol) rectangle of sub-patch q
-            const int r_lo = -rb[q], r_hi = live[q] ? p.H - rb[q] : r_lo, c_lo = -cb[q], c_hi = p.W - cb[q];
-            const bool ok = drow[it] >= r_lo && drow[it] < r_hi && dcol[it] >= c_lo && dcol[it] < c_hi;
+            if (wave + 8 * it >= NPIECE) break;
+            const unsigned m = pq[it] ? smask[1] : smask[0];
+            const int org = pisx[it] ? (pq[it] ? xo[1] : xo[0]) : (pq[it] ? dyo[1] : dyo[0]);
             // (the sub-patch origin goes into the per-lane offset, not into soffset: the range check must see it)
-            voff[it] = ok ? (unsigned)(rel[it] + pixbase[q] * (isx ? p.C : p.K) * 2) : kOob;
-            gdst[it] = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + dst);
+            voff[it] = (lbits[it] & m) == lbits[it] ? (unsigned)(rel[it] + org) : kOob;
+            gdst[it] = base + pdst[it];
         }
     };
     bool do_issue = true;               // false in the last STAGES - 1 intervals (nothing left to fetch)
     auto issue = [&](int it) {          // one LDS-DMA piece (wave-uniform guards: waves >= NW4 have three)
-        if (do_issue && wave + 8 * it < NPIECE) {
+        if (do_issue && wave + 8 * it < NPIECE && !(p.debug_skip_epilogue & 128)) {
             const unsigned m0v = __builtin_amdgcn_readfirstlane(gdst[it]);
             if (wave + 8 * it < 2 * XP)
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
@@ -559,22 +578,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
     // One stage of this wave's sub-patch: 2 k-steps x (1 dy + 9 x fragments, 9 MFMAs); the scheduler is left free to
     // place the 40 transposing reads among the 18 MFMAs (pinning groups with sched_barrier cost 20 %).
     auto compute = [&](int buf) {
-        const char* sb = smem + buf * STAGE;
+        // eight address registers per stage (3 tap columns x 2 halves + 2 for dy); tap rows and the second k-step are
+        // immediate offsets of the ds_read instructions — a wave issues one instruction per ~4-5 cycles, so every
+        // address add per fragment read would cost as much issue time as the MFMA it feeds
+        typedef __attribute__((address_space(3))) char* ldsp_t;
+        const ldsp_t sb = (ldsp_t)(size_t)(lds0 + buf * STAGE);
+        ldsp_t pa[2], px_[3][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            pa[h] = sb + offa[h];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) px_[s][h] = sb + offx[s][h];
+        }
         bf16x8_t a[2], b[2][9];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             {
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sb + offa[0] + j * KSTEP_A));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(sb + offa[1] + j * KSTEP_A));
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(pa[0] + j * KSTEP_A));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(pa[1] + j * KSTEP_A));
                 a[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int r = t / 3, s = t - 3 * r;
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (lds4_t)(sb + offx[s][0] + j * KSTEP_X + r * HS * 128));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (lds4_t)(sb + offx[s][1] + j * KSTEP_X + r * HS * 128));
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(px_[s][0] + (j * KSTEP_X + r * HS * 128)));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(px_[s][1] + (j * KSTEP_X + r * HS * 128)));
                 b[j][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
         }
@@ -617,11 +645,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
             }
             __builtin_amdgcn_s_barrier();
             do_issue = s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2);
+            // (no run-time switch around compute(): a conditional MFMA chain makes the compiler copy all 144
+            // accumulator registers every stage — 128 v_mov_b64 per iteration in the first version of this loop)
             if constexpr (decltype(stage_first)::value) {
                 if (do_issue) stage(nxt);
-                if (!(p.debug_skip_epilogue & 4)) compute(cur);
+                compute(cur);
             } else {
-                if (!(p.debug_skip_epilogue & 4)) compute(cur);
+                compute(cur);
                 if (do_issue) stage(nxt);
             }
             cur = cur + 1 == STAGES ? 0 : cur + 1;
