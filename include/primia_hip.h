@@ -421,6 +421,23 @@ int primia_fx_encode(const float* x, int64_t* q, int64_t n, float scale, primia_
 int primia_fx_decode(const int64_t* q, float* x, int64_t n, float scale, primia_stream_t stream);
 
 
+/* ------------------------------------------------------------------------------------------
+ * Exchange steps on an RCCL communicator of the CALLER (`comm` = its ncclComm_t; SURVEY.md §8b "comm").  RCCL is
+ * looked up in the running process (ncclAllReduce), not linked: PRIMIA_ERR_UNSUPPORTED when the process has none.
+ * ------------------------------------------------------------------------------------------ */
+int primia_comm_available(void);   /* 1 when ncclAllReduce resolves */
+/* aggregation() + send_new_models() (torchlib/utils.py:1000-1105) for one client per rank, in place on the client's
+ * flat fp32 arena of n elements (parameters + BatchNorm running statistics): weight >= 0: theta *= weight, sum over
+ * the communicator (weighted averaging, weights sum to 1); weight < 0: sum, then / nclients.  secure != 0 reproduces
+ * the secure aggregation's numerics: fix_prec(10^precision_fractional) -> int64 ring sum -> float_prec
+ * (utils.py:1046-1060,1079-1085); `scratch` holds n int64.  (Masking the encoded update before the sum, as
+ * primia_amd.fed.PairwiseMasks does, is the caller's: primia_chacha20_fill + primia_ring_add / primia_ring_sub.) */
+int primia_fedavg_allreduce(float* flat, int64_t n, float weight, int nclients, int secure, int precision_fractional,
+                            int64_t* scratch, void* comm, primia_stream_t stream);
+/* The two-party open of the SPDZ / FSS protocols (mpc/spdz.py:162-176: delta = sum(shares_delta); mpc/fss.py:158:
+ * sum(shares)): buf += the peer's buf (mod 2^64), in place, over a 2-rank communicator. */
+int primia_open2(int64_t* buf, int64_t n, void* comm, primia_stream_t stream);
+
 /* ==========================================================================================
  * Encrypted-inference path: fixed-precision additive secret sharing over Z_2^64 (int64 with
  * wrap-around), Beaver triples and Function Secret Sharing — the per-share functions PySyft

@@ -372,3 +372,48 @@ def test_cli_per_rank_training_on_a_real_folder_and_resume(tmp_path):
     assert set(vs["optim_state_dict"]) == {"state", "param_groups"}
     for f in (ckpt, van, os.path.join(ROOT, "model_weights", "final_federated_resumed.pt")):
         os.remove(f)
+
+
+def test_c_abi_comm_entry_points_on_an_rccl_communicator(cuda):
+    """§8b "comm": primia_fedavg_allreduce / primia_open2 take the CALLER's ncclComm_t.  A one-rank communicator made
+    with the RCCL that torch ships (ctypes: ncclGetUniqueId / ncclCommInitRank) exercises the whole call path on one
+    GPU: on one rank the sum is the rank's own buffer, so the results are exactly scale -> [encode -> decode] -> divide."""
+    import ctypes
+
+    from primia_amd import _lib
+    from primia_amd._lib import call, query
+
+    rccl = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"), mode=ctypes.RTLD_GLOBAL)
+
+    class UniqueId(ctypes.Structure):
+        _fields_ = [("internal", ctypes.c_char * 128)]
+
+    uid, comm = UniqueId(), ctypes.c_void_p()
+    assert rccl.ncclGetUniqueId(ctypes.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, UniqueId, ctypes.c_int]
+    torch.cuda.set_device(cuda)
+    assert rccl.ncclCommInitRank(ctypes.byref(comm), 1, uid, 0) == 0
+    assert query("primia_comm_available") == 1
+    g = torch.Generator().manual_seed(3)
+    x = (torch.randn(10001, generator=g) * 3).to(cuda)
+    for weight, secure, pf in ((-1.0, 0, 16), (0.25, 0, 16), (-1.0, 1, 16), (0.25, 1, 3)):
+        flat = x.clone()
+        scratch = torch.empty(flat.numel(), dtype=torch.int64, device=cuda)
+        call("primia_fedavg_allreduce", flat, flat.numel(), weight, 1, secure, pf, scratch, comm)
+        want = x.clone()
+        if weight >= 0:
+            call("primia_scale", want, want.numel(), weight)
+        if secure:
+            q = torch.empty(want.numel(), dtype=torch.int64, device=cuda)
+            call("primia_fx_encode", want, q, want.numel(), float(10 ** pf))
+            call("primia_fx_decode", q, want, want.numel(), float(10 ** pf))
+        if weight < 0:
+            call("primia_divide", want, want.numel(), 1.0)
+        torch.cuda.synchronize()
+        assert torch.equal(flat, want), (weight, secure, pf)
+    buf = torch.arange(-500, 500, dtype=torch.int64, device=cuda) * (2 ** 53)
+    keep = buf.clone()
+    call("primia_open2", buf, buf.numel(), comm)
+    torch.cuda.synchronize()
+    assert torch.equal(buf, keep)
+    rccl.ncclCommDestroy(comm)
