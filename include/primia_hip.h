@@ -492,6 +492,14 @@ int primia_col2out_syft(const int64_t* res, const int64_t* bias, int64_t* out, i
 int primia_pool_unroll_syft(const int64_t* x, int64_t* out, int B, int C, int H, int W, int k,
                             int stride, int pad, primia_stream_t stream);
 
+/* FixedPrecisionTensor.reciprocal(method="newton") (precision.py:507-518: C = 20, 80 steps — what eval-mode
+ * batch_norm calls on running_var, nn/functional.py:62) when BOTH parties' shares live in this process: the whole
+ * iteration for n elements in one launch, bit-identical to the chain of primia_ring_sub / primia_beaver_combine_mul /
+ * primia_trunc_div calls it replaces and consuming the provider's primitives in the same order.  `prim` is a DEVICE
+ * array of 1 + 79 * 19 pointers to int64 buffers: the mask of the first re-shared constant [1], then per iteration
+ * triple(x*x) as (a0, b0, c0, a1, b1, c1) [n each], triple(v*xx), the constant's mask [1], triple(y*x). */
+int primia_newton_reciprocal_local(const int64_t* v0, const int64_t* v1, const int64_t* const* prim, int64_t scale,
+                                   int64_t* x0, int64_t* x1, int64_t n, primia_stream_t stream);
 /* spdz_compute (mpc/spdz.py:63-122), party j in {0,1}:
  *   mul   : z = delta*b + a*eps + c (+ delta*eps if j == 0), element-wise; b / eps hold nb
  *           elements and broadcast over the leading dims when nb < n;

@@ -123,6 +123,64 @@ __global__ __launch_bounds__(256) void beaver_mul_kernel(int j, const u64* __res
     }
 }
 
+// ---- FixedPrecisionTensor.reciprocal(method="newton") for two parties hosted in ONE process -------------------------
+// precision.py:507-518:   x = (C + 1 - v) / C;  79 x { y = C + 1 - v * (x * x);  x = y * x / C },  C = 20,
+// every product a Beaver multiplication followed by each party's truncation of ITS share, every `C + 1 - t` the
+// re-sharing of the public constant with a fresh mask (additive_shared.py:453-527).  Unfused that is ~38 launches per
+// iteration on a few thousand elements (half of all launches of an encrypted forward); the iteration is element-wise,
+// and with both parties' shares on this GPU an "open" is an addition, so one thread can carry one element of BOTH
+// parties through all 80 steps.  The arithmetic, and the order in which the crypto provider's primitives are consumed,
+// are exactly those of the unfused chain (tests: bit-identical); the three-role deployment keeps the unfused form,
+// there the opens are messages.
+//   prim: device array of pointers, in consumption order:  mask0 | 79 x { T1 (a0,b0,c0,a1,b1,c1), T2 (..6..), mask, T3 (..6..) }
+__device__ __forceinline__ int64_t trunc_div1(int64_t v, u64 d) {
+    const u64 mag = v < 0 ? (u64)0 - (u64)v : (u64)v;
+    const u64 q = mag / d;
+    return v < 0 ? (int64_t)((u64)0 - q) : (int64_t)q;
+}
+
+__global__ __launch_bounds__(64) void newton_local_kernel(const u64* __restrict__ v0, const u64* __restrict__ v1,
+                                                          const u64* const* __restrict__ prim, u64 scale,
+                                                          u64* __restrict__ x0o, u64* __restrict__ x1o, long n) {
+    const long i = (long)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    constexpr u64 C = 20;
+    const u64 c21 = 21 * scale;                    // (C + 1) encoded
+    const u64 va = v0[i], vb = v1[i];
+    // Beaver product of (xa, xb) and (ya, yb) with triple t (6 pointers), then each party truncates by `scale`
+    auto fpt_mul = [&](u64 xa, u64 xb, u64 ya, u64 yb, const u64* const* t, u64& za, u64& zb) {
+        const u64 a0 = t[0][i], b0 = t[1][i], c0 = t[2][i], a1 = t[3][i], b1 = t[4][i], c1 = t[5][i];
+        const u64 delta = (xa - a0) + (xb - a1), eps = (ya - b0) + (yb - b1);      // spdz_mask + open
+        const u64 w0 = delta * b0 + a0 * eps + c0 + delta * eps;                   // spdz_compute, j = 0
+        const u64 w1 = delta * b1 + a1 * eps + c1;                                 // j = 1
+        za = (u64)trunc_div1((int64_t)w0, scale);
+        zb = (u64)trunc_div1((int64_t)w1, scale);
+    };
+    // -(t - [21*scale]) with the constant re-shared as (r, 21*scale - r)
+    auto c21_minus = [&](u64 ta, u64 tb, const u64* mask, u64& ya, u64& yb) {
+        const u64 r = mask[0];
+        ya = (u64)0 - (ta - r);
+        yb = (u64)0 - (tb - (c21 - r));
+    };
+    u64 ya, yb, xa, xb;
+    c21_minus(va, vb, prim[0], ya, yb);
+    xa = (u64)trunc_div1((int64_t)ya, C);
+    xb = (u64)trunc_div1((int64_t)yb, C);
+    const u64* const* pp = prim + 1;
+#pragma unroll 1
+    for (int it = 0; it < 79; ++it, pp += 19) {
+        u64 qa, qb, ta, tb;
+        fpt_mul(xa, xb, xa, xb, pp, qa, qb);            // x * x
+        fpt_mul(va, vb, qa, qb, pp + 6, ta, tb);        // v * (x * x)
+        c21_minus(ta, tb, pp[12], ya, yb);              // C + 1 - ...
+        fpt_mul(ya, yb, xa, xb, pp + 13, qa, qb);       // y * x
+        xa = (u64)trunc_div1((int64_t)qa, C);           // / C
+        xb = (u64)trunc_div1((int64_t)qb, C);
+    }
+    x0o[i] = xa;
+    x1o[i] = xb;
+}
+
 // ---- int64 ring GEMM: C = C0 + A1@B1 + A2@B2 ---------------------------------------------------------
 // 64x64 output tile per 256-thread block, 4x4 outputs per thread, k-step 16 staged through LDS.
 // There is no 64-bit integer MFMA; the products run on the vector ALU (v_mad_u64_u32 chains).
@@ -309,6 +367,16 @@ int primia_pool_unroll_syft(const int64_t* x, int64_t* out, int B, int C, int H,
     const long total = (long)B * C * Ho * Wo * k * k;
     pool_unroll_kernel<<<ceil_div(total, 256), 256, 0, (hipStream_t)st>>>((const u64*)x, (u64*)out, B, C, H, W, k,
                                                                            stride, pad, Ho, Wo);
+    return launch_status();
+}
+
+int primia_newton_reciprocal_local(const int64_t* v0, const int64_t* v1, const int64_t* const* prim, int64_t scale,
+                                   int64_t* x0, int64_t* x1, int64_t n, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(v0 && v1 && prim && x0 && x1 && n > 0 && scale > 0);
+    newton_local_kernel<<<ceil_div(n, 64), 64, 0, (hipStream_t)st>>>((const u64*)v0, (const u64*)v1,
+                                                                      (const u64* const*)prim, (u64)scale, (u64*)x0,
+                                                                      (u64*)x1, n);
     return launch_status();
 }
 

@@ -197,6 +197,8 @@ class SecureContext:
         self.parties = (0, 1) if party is None else (party,)
         self.link = link
         self.stats = {"beaver_mul": 0, "beaver_matmul": 0, "dif_evals": 0}
+        self.fuse_newton = True
+        self._newton_tables, self._newton_calls = [], 0     # see _reciprocal_newton_fused
 
     # ---- encode / share / reconstruct -----------------------------------------------------------
     def encode(self, x):
@@ -413,7 +415,15 @@ class SecureContext:
         return self._each(one)
 
     def reciprocal_newton(self, v):
-        """FPT.reciprocal(method="newton") (precision.py:507-518), C = 20, 80 iterations."""
+        """FPT.reciprocal(method="newton") (precision.py:507-518), C = 20, 80 iterations.
+
+        With both parties in this process (the default deployment) the whole iteration is ONE launch
+        (`primia_newton_reciprocal_local`): the primitives are requested from the dealer in exactly the order the
+        step-by-step chain below consumes them and handed to the kernel as a pointer table, so the two forms are
+        bit-identical — the chain is what a three-role run (opens = messages) executes, and `fuse_newton = False`
+        selects it here too."""
+        if self.party is None and isinstance(self.opener, LocalOpener) and self.fuse_newton:
+            return self._reciprocal_newton_fused(v)
         C = 20
         # x0 = (C + 1 - v) / C
         y = self.neg(self.sub_public_scalar(v, (C + 1) * self.scale))
@@ -424,6 +434,40 @@ class SecureContext:
             y = self.neg(self.sub_public_scalar(vxx, (C + 1) * self.scale))
             x = self.trunc(self.fpt_mul(y, x), C)
         return x
+
+    def _reciprocal_newton_fused(self, v):
+        shape = tuple(v[0].shape)
+        n = v[0].numel()
+        dev = v[0].device
+        prims = [self.dealer.const_mask(1, owner=None)]
+        keep = [prims[0]]
+        for _ in range(79):
+            for k in range(3):
+                if k == 2:
+                    m = self.dealer.const_mask(1, owner=None)
+                    prims.append(m)
+                    keep.append(m)
+                t = self.dealer.triple("mul", shape, shape)
+                keep.append(t)
+                prims += [t[0][0], t[0][1], t[0][2], t[1][0], t[1][1], t[1][2]]
+        # pointer table on the device; cached per call position so that a replayed / captured forward over the same
+        # (static) primitive buffers uploads nothing (a host-to-device copy cannot be captured into a hipGraph)
+        ptrs = [p.data_ptr() for p in prims]
+        idx = self._newton_calls
+        self._newton_calls += 1
+        if idx < len(self._newton_tables) and self._newton_tables[idx][0] == ptrs:
+            table = self._newton_tables[idx][1]
+        else:
+            table = torch.tensor(ptrs, dtype=I64).to(dev)
+            entry = (ptrs, table, keep)             # `keep`: the launch reads the primitives asynchronously
+            if idx < len(self._newton_tables):
+                self._newton_tables[idx] = entry
+            else:
+                self._newton_tables.append(entry)
+        out = [torch.empty(shape, dtype=I64, device=dev), torch.empty(shape, dtype=I64, device=dev)]
+        call("primia_newton_reciprocal_local", v[0].contiguous(), v[1].contiguous(), table, int(self.scale), out[0], out[1], n)
+        self.stats["beaver_mul"] += 3 * 79
+        return out
 
     def batch_norm_eval(self, x, mean, var, weight, bias, inv=None):
         """batch_norm in eval mode (nn/functional.py:44-75): ((x - mean) * newton(var)) * w + b on
@@ -635,6 +679,8 @@ class GraphedSecureInference:
         pre = PreloadedDealer(self.tape, self.device)
         self._ctx = SecureContext(pre, base, precision_fractional)
         self._model = SecureResNet18(self._ctx, state_dict, input_size, blocks)   # re-shares with the same masks
+        self._model(self.image)                        # eager pass over the static buffers: builds the pointer tables
+        pre.pos, self._ctx._newton_calls = self._n_model, 0
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):

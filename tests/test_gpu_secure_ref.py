@@ -202,3 +202,27 @@ def test_dealer_is_unpredictable_by_default(cuda):
     assert not torch.equal(a, b)
     assert torch.equal(Dealer(cuda, seed=3).rand64(64), Dealer(cuda, seed=3).rand64(64))
     assert not torch.equal(Dealer(cuda, seed=3).rand64(64), Dealer(cuda, seed=4).rand64(64))
+
+
+@pytest.mark.parametrize("pf", [3, 16])
+def test_fused_newton_is_bit_identical_to_the_step_by_step_chain(cuda, pf):
+    """primia_newton_reciprocal_local (one launch, both parties on this GPU) against the chain of ring / Beaver /
+    truncation launches a three-role run executes, on the same dealer stream; the reference fixtures above
+    (newton, bn_eval, the full forward) already run through the fused form."""
+    g = torch.Generator().manual_seed(4)
+    var = (torch.rand(1000, generator=g) * 1.5 + 0.5).to(cuda)
+    outs, logs = [], []
+    for fuse in (True, False):
+        dealer = Dealer(cuda, seed=21)
+        dealer.log = []
+        ctx = SecureContext(dealer, 10, pf)
+        ctx.fuse_newton = fuse
+        v = ctx.share(ctx.encode(var))
+        outs.append(ctx.reciprocal_newton(v))
+        logs.append(dealer.log)
+    assert len(logs[0]) == len(logs[1]) == 318 and all(a[0] == b[0] for a, b in zip(*logs))
+    for j in range(2):
+        assert torch.equal(outs[0][j], outs[1][j])
+    if pf == 3:
+        dec = ctx.decode(ctx.reconstruct(outs[0])).cpu()
+        assert torch.allclose(dec, var.cpu().rsqrt(), atol=5e-3)
