@@ -147,6 +147,8 @@ def main():
     ys = [torch.randint(0, 3, (a.batch,), generator=g).to(dev) for _ in range(nbuf)]
     local_flat = torch.empty_like(eng.flat)
     scratch = torch.empty(eng.flat.numel(), dtype=torch.int64, device=dev) if a.secure_aggregation else None
+    # secure aggregation across ranks goes onto the wire under pairwise one-time masks (fed.PairwiseMasks)
+    masks = fed.PairwiseMasks.setup(eng.flat.numel(), dev) if (a.secure_aggregation and world > 1) else None
     lr, wd = 1e-4, 5e-4
 
     def local_step(i):
@@ -157,7 +159,7 @@ def main():
     def exchange(i):
         """FedAvg over RCCL every `sync_every` batches (torchlib/utils.py:1175: batch_idx > 0 and batch_idx % s == 0)."""
         if world > 1 and i > 0 and i % a.sync_every == 0:
-            fed.fedavg_allreduce(eng.flat, local_flat, None, a.secure_aggregation, 16, 10, None, None, scratch)
+            fed.fedavg_allreduce(eng.flat, local_flat, None, a.secure_aggregation, 16, 10, None, None, scratch, masks)
             eng.flat.copy_(local_flat)
             eng.refresh_weights()
 

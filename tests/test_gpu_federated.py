@@ -150,19 +150,21 @@ def test_cli_train_federated_then_inference(tmp_path):
     os.remove(ckpt)
 
 
-def test_bench_two_ranks_control_flow(tmp_path):
+@pytest.mark.parametrize("secure", [False, True])
+def test_bench_two_ranks_control_flow(tmp_path, secure):
     """bench.py under torch.distributed.run with 2 ranks.  This box has ONE GPU, so both ranks share it
     and talk over gloo; what is exercised is the N > 1 path of the benchmark (barriers, FedAvg every 3
     steps, max-over-ranks timing, rank-0 JSON) that the driver runs on RCCL across 8 GPUs."""
     env = dict(os.environ, PRIMIA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), "bench.py", "--gpus", "2", "--steps", "7",
-           "--warmup", "1", "--batch", "8", "--size", "64", "--no-cpu-baseline"]
+           "--warmup", "1", "--batch", "8", "--size", "64", "--no-cpu-baseline"] + (["--secure-aggregation"] if secure else [])
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["clients"] == 2
+    assert d["config"]["secure_aggregation"] is secure
     assert d["hip_graph"] is True   # the local step is replayed as a graph at every rank count, the exchange is not
     assert d["value"] > 0 and abs(d["value"] - 2 * d["images_per_sec_per_client"]) < 1e-3 * d["value"]
 
