@@ -24,3 +24,13 @@ def cuda():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+def free_port():
+    """A TCP port nobody listens on right now (torchrun rendezvous of the multi-process tests): asking the kernel
+    beats deriving one from the pid — consecutive tests of one pytest process would otherwise share it."""
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]

@@ -20,6 +20,7 @@ from oracle import train_oracle as O  # noqa: E402
 from primia_amd import resnet_spec as rs  # noqa: E402
 from primia_amd.engine import ResNet18Engine  # noqa: E402
 from primia_amd.torchlib_compat import aggregation, send_new_models, train_federated  # noqa: E402
+from tests.conftest import free_port  # noqa: E402
 
 
 def make_args(**kw):
@@ -143,7 +144,7 @@ def test_cli_train_federated_then_inference(tmp_path):
             "--debug_dealer_seed", "0"]
     run(["inference.py"] + base, {"PRIMIA_DUMP_LOGITS": local})
     out = run(["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-               "--master-port", str(29900 + os.getpid() % 90), "inference.py"] + base + ["--three_role"],
+               "--master-port", str(free_port()), "inference.py"] + base + ["--three_role"],
               {"PRIMIA_DUMP_LOGITS": dist3, "MASTER_ADDR": "127.0.0.1"})
     assert "Inference Results" in out
     assert torch.equal(torch.load(local), torch.load(dist3))
@@ -157,7 +158,7 @@ def test_bench_two_ranks_control_flow(tmp_path, secure):
     steps, max-over-ranks timing, rank-0 JSON) that the driver runs on RCCL across 8 GPUs."""
     env = dict(os.environ, PRIMIA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(29900 + os.getpid() % 90), "bench.py", "--gpus", "2", "--steps", "7",
+           "127.0.0.1", "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--steps", "7",
            "--warmup", "1", "--batch", "8", "--size", "64", "--no-cpu-baseline"] + (["--secure-aggregation"] if secure else [])
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
@@ -249,7 +250,7 @@ def test_per_rank_federated_epoch_matches_in_process(cuda, tmp_path, case):
     cfg = {"args": a, "batch": 4, "size": 64, "shards": [3, 2], "epochs": 2}
     out = str(tmp_path / "rank")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(29700 + os.getpid() % 200), os.path.join(ROOT, "tests", "fed_rank_worker.py"),
+           "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "fed_rank_worker.py"),
            json.dumps(cfg), out]
     r = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True,
                        timeout=900)
@@ -345,7 +346,7 @@ def test_cli_per_rank_training_on_a_real_folder_and_resume(tmp_path):
     ini.write_text(text)
     env = {"PRIMIA_BACKEND": "gloo", "PRIMIA_WEBSOCKETS_CONFIG": str(csv), "MASTER_ADDR": "127.0.0.1"}
     torchrun = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", str(29500 + os.getpid() % 200)]
+                "--master-port", str(free_port())]
     base = ["train.py", "--config", str(ini), "--cuda", "--data_dir", data]
     out = run(torchrun + base + ["--train_federated", "--training_name", "rankcli"], env)
     assert "Train Epoch: 2" in out and "matthews coeff" in out

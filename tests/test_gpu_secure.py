@@ -273,7 +273,9 @@ def test_three_role_deployment_bit_identical_to_in_process(cuda, tmp_path, pf):
     model = SecureResNet18(ctx, sd, input_size=16, blocks=blocks)
     want = torch.cat([model(images[i:i + 1].to(cuda)) for i in range(2)]).cpu()
     out = str(tmp_path / "logits")
-    port = 29800 + os.getpid() % 1000
+    from tests.conftest import free_port
+
+    port = free_port()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(root, "tests", "party_worker.py"),
            out, str(pf)]

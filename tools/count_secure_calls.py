@@ -1,0 +1,22 @@
+import sys, os, collections
+sys.path.insert(0, "/root/repo")
+import torch
+from primia_amd import _lib, resnet_spec as rs
+from primia_amd.secure import Dealer, PreloadedDealer, SecureContext, SecureResNet18
+import primia_amd.secure as sec
+dev = torch.device("cuda:0")
+torch.manual_seed(42)
+sd = rs.init_state_dict(rs.resnet18_spec(3, 3, 224, "max"))
+img = torch.randn(1, 3, 224, 224).to(dev)
+d = Dealer(dev, seed=1); d.tape = []
+ctx = SecureContext(d, 10, 16); m = SecureResNet18(ctx, sd, 224); m(img)
+cnt = collections.Counter()
+orig = sec.call
+def counting(name, *a, **k):
+    cnt[name] += 1
+    return orig(name, *a, **k)
+sec.call = counting
+ctx2 = SecureContext(PreloadedDealer(d.tape, dev), 10, 16); m2 = SecureResNet18(ctx2, sd, 224)
+cnt.clear()
+m2(img)
+print(sum(cnt.values()), cnt.most_common())
