@@ -30,7 +30,11 @@ if __name__ == "__main__":
     batch, size = cfg["batch"], cfg["size"]
     torch.manual_seed(11)
     init = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"))
-    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=device)
+    norm = cfg.get("norm", "batch")
+    init = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"), norm) if norm != "batch" else init
+    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=device, norm=norm)
+    if cfg.get("dp"):
+        eng.dp_params = dict(cfg["dp"])
     eng.load_state_dict(init)
     loader = [(x.to(device), y.to(device)) for x, y in shard(rank, cfg["shards"][rank], batch, size)]
     masks = None

@@ -218,14 +218,23 @@ def _in_process_epochs(cuda, cfg):
     args = SimpleNamespace(**cfg["args"])
     batch, size = cfg["batch"], cfg["size"]
     torch.manual_seed(11)
+    norm = cfg.get("norm", "batch")
     init = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"))
+    if norm != "batch":
+        init = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"), norm)
+
+    def make():
+        e = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda, norm=norm)
+        if cfg.get("dp"):
+            e.dp_params = dict(cfg["dp"])
+        e.load_state_dict(init)
+        return e
+
     names = [f"w{k}" for k in range(len(cfg["shards"]))]
-    models = {"local_model": ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda)}
-    models["local_model"].load_state_dict(init)
+    models = {"local_model": make()}
     loaders, opt = {}, {}
     for k, w in enumerate(names):
-        models[w] = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.float32, device=cuda)
-        models[w].load_state_dict(init)
+        models[w] = make()
         loaders[w] = [(x.to(cuda), y.to(cuda)) for x, y in shard(k, cfg["shards"][k], batch, size)]
         opt[w] = {"lr": args.lr}
     for epoch in range(cfg["epochs"]):
@@ -234,7 +243,7 @@ def _in_process_epochs(cuda, cfg):
     return models, opt, names
 
 
-@pytest.mark.parametrize("case", ["secure_sgd", "plain_adam_keep", "weighted_secure_adam_reset"])
+@pytest.mark.parametrize("case", ["secure_sgd", "plain_adam_keep", "weighted_secure_adam_reset", "dp_clip_secure"])
 def test_per_rank_federated_epoch_matches_in_process(cuda, tmp_path, case):
     """one client per rank (here 2 ranks sharing GPU 0 over gloo; RCCL on a multi-GPU node) against the
     in-process federated epoch on the same uneven shards — stragglers (3 vs 2 batches, a sync after every batch),
@@ -248,6 +257,10 @@ def test_per_rank_federated_epoch_matches_in_process(cuda, tmp_path, case):
     elif case == "weighted_secure_adam_reset":
         a.update(optimizer="Adam", weighted_averaging=True, sync_every_n_batch=2)
     cfg = {"args": a, "batch": 4, "size": 64, "shards": [3, 2], "epochs": 2}
+    if case == "dp_clip_secure":
+        # BASELINE configs[3]'s control path: GroupNorm network, per-sample clipping (noise off: each deployment would
+        # draw its own), secure aggregation — clients of a DP run are engines like any other to the federated epoch
+        cfg.update(norm="group", dp={"max_grad_norm": 1.0, "noise_multiplier": 0.0})
     out = str(tmp_path / "rank")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "tests", "fed_rank_worker.py"),
