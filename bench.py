@@ -204,6 +204,7 @@ def main():
     if graphs is not None:
         def run(i):
             graphs[i % nbuf].replay()
+            eng.note_replayed_steps(1)
             exchange(i)
     else:
         run = step

@@ -70,6 +70,9 @@ class ResNet18Engine:
             n = int(torch.Size(s).numel())
             self.views[k] = self.flat[off:off + n].view(s)
             off += n
+        # BatchNorm's num_batches_tracked (only ever READ by torch when momentum is None, never by this network): a host
+        # counter advanced by forward(); a captured hipGraph replays kernels, not Python, so a caller that replays steps
+        # (bench.py) and then exports state_dict() must add its replay count itself (note_replayed_steps).
         self.num_batches_tracked = {bn_name(c.name): 0 for c in self.spec.convs}
         self.opt_state = None  # Adam moments, created lazily
         self.opt_steps = 0
@@ -831,6 +834,13 @@ class ResNet18Engine:
     # ------------------------------------------------------------------------------------------
     def zero_grad(self):
         self.grads.zero_()
+
+    def note_replayed_steps(self, n):
+        """Training steps that ran as hipGraph replays: advance the host-side counters forward() would have advanced."""
+        for b in self.num_batches_tracked:
+            self.num_batches_tracked[b] += int(n)
+        if self.opt_state is not None:
+            self.opt_steps += int(n)
 
     def reset_optimizer(self):
         """The reference re-creates its optimizers at every FedAvg sync (utils.py:1131-1145,1208-1218)."""
