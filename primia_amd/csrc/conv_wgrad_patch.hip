@@ -386,6 +386,81 @@ struct OrderTag {
 
 __device__ __forceinline__ int key32(int slot) { return (slot >> 1) & 1; }
 
+// Epilogue shared by the stride-1 and stride-2 kernels: the two halves of the block meet in LDS (waves 4-7 park their
+// accumulators, waves 0-3 add them), then one of the three outputs: per-sample squared norm, partial slab, atomics.
+__device__ __forceinline__ void wgrad32_epilogue(f32x16 (&acc)[9], const PatchParams& p, char* smem, int wave, int lane,
+                                                 int half, int kg, int cg, int kt, int ct, int split) {
+    // ---- the two halves meet in LDS: waves 4-7 park their accumulators, waves 0-3 add them ---------------------------
+    if ((p.debug_skip_epilogue & 1) && acc[0][0] != 12345.f) return;
+    __syncthreads();                                   // every wave is done reading the stage ring
+    {
+        f32x4* park = (f32x4*)smem + ((wave & 3) * 36) * 64 + lane;     // [wave & 3][t * 4 + m][lane] chunks of 16 B
+        if (half) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    park[(t * 4 + m) * 64] = f32x4{acc[t][4 * m], acc[t][4 * m + 1], acc[t][4 * m + 2], acc[t][4 * m + 3]};
+        }
+        __syncthreads();
+        if (half) return;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const f32x4 v = park[(t * 4 + m) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[t][4 * m + j] += v[j];
+            }
+    }
+    // lane holds out-chan rows 32*kg + 8*m + 4*(lane>>5) + j (register 4*m + j), in-chan column 32*cg + (lane & 31)
+    if (p.sqnorm) {
+        double sq = 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) sq += (double)acc[t][j] * (double)acc[t][j];
+        wave_sqnorm_add(sq, p.sqnorm + split);
+        return;
+    }
+    if (p.ws) {
+        // slab chunk ((t*4 + m)*4 + wave)*64 + lane = registers 4m..4m+3 of accumulator t (wgrad_patch32_reduce_kernel)
+        float* o = p.ws + ((long)(kt * p.nct + ct) * p.nsplit + split) * kSlab + (wave * 64 + lane) * 4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                *(f32x4*)(o + (t * 4 + m) * 1024) = f32x4{acc[t][4 * m], acc[t][4 * m + 1], acc[t][4 * m + 2], acc[t][4 * m + 3]};
+        return;
+    }
+    float* out = p.dw + (long)split * p.split_stride;
+    auto flush = [&](int t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int k = kt * 64 + 32 * kg + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
+            const int e = t * p.C + ct * 64 + 32 * cg + (lane & 31);
+            unsafeAtomicAdd(out + (long)k * p.klen + e, acc[t][r]);
+        }
+    };
+    // blocks of one slab start at different taps, so that at any instant they hit different cache lines
+#define PRIMIA_FLUSH32_FROM(R)                     \
+    case R:                                        \
+        _Pragma("unroll") for (int t = 0; t < 9; ++t) flush((t + R) % 9); \
+        break;
+    switch (split % 9) {
+        PRIMIA_FLUSH32_FROM(0)
+        PRIMIA_FLUSH32_FROM(1)
+        PRIMIA_FLUSH32_FROM(2)
+        PRIMIA_FLUSH32_FROM(3)
+        PRIMIA_FLUSH32_FROM(4)
+        PRIMIA_FLUSH32_FROM(5)
+        PRIMIA_FLUSH32_FROM(6)
+        PRIMIA_FLUSH32_FROM(7)
+        PRIMIA_FLUSH32_FROM(8)
+    }
+#undef PRIMIA_FLUSH32_FROM
+}
+
 template <int SW, int STAGES>
 __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) {
     constexpr int SH = 32 / SW;
@@ -663,75 +738,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
     else
         main_loop(OrderTag<false>{});
 
-    // ---- the two halves meet in LDS: waves 4-7 park their accumulators, waves 0-3 add them ---------------------------
-    if ((p.debug_skip_epilogue & 1) && acc[0][0] != 12345.f) return;
-    __syncthreads();                                   // every wave is done reading the stage ring
-    {
-        f32x4* park = (f32x4*)smem + ((wave & 3) * 36) * 64 + lane;     // [wave & 3][t * 4 + m][lane] chunks of 16 B
-        if (half) {
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    park[(t * 4 + m) * 64] = f32x4{acc[t][4 * m], acc[t][4 * m + 1], acc[t][4 * m + 2], acc[t][4 * m + 3]};
-        }
-        __syncthreads();
-        if (half) return;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const f32x4 v = park[(t * 4 + m) * 64];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[t][4 * m + j] += v[j];
-            }
-    }
-    // lane holds out-chan rows 32*kg + 8*m + 4*(lane>>5) + j (register 4*m + j), in-chan column 32*cg + (lane & 31)
-    if (p.sqnorm) {
-        double sq = 0.0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int j = 0; j < 16; ++j) sq += (double)acc[t][j] * (double)acc[t][j];
-        wave_sqnorm_add(sq, p.sqnorm + split);
-        return;
-    }
-    if (p.ws) {
-        // slab chunk ((t*4 + m)*4 + wave)*64 + lane = registers 4m..4m+3 of accumulator t (wgrad_patch32_reduce_kernel)
-        float* o = p.ws + ((long)(kt * p.nct + ct) * p.nsplit + split) * kSlab + (wave * 64 + lane) * 4;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int m = 0; m < 4; ++m)
-                *(f32x4*)(o + (t * 4 + m) * 1024) = f32x4{acc[t][4 * m], acc[t][4 * m + 1], acc[t][4 * m + 2], acc[t][4 * m + 3]};
-        return;
-    }
-    float* out = p.dw + (long)split * p.split_stride;
-    auto flush = [&](int t) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int k = kt * 64 + 32 * kg + 8 * (r >> 2) + 4 * (lane >> 5) + (r & 3);
-            const int e = t * p.C + ct * 64 + 32 * cg + (lane & 31);
-            unsafeAtomicAdd(out + (long)k * p.klen + e, acc[t][r]);
-        }
-    };
-    // blocks of one slab start at different taps, so that at any instant they hit different cache lines
-#define PRIMIA_FLUSH32_FROM(R)                     \
-    case R:                                        \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) flush((t + R) % 9); \
-        break;
-    switch (split % 9) {
-        PRIMIA_FLUSH32_FROM(0)
-        PRIMIA_FLUSH32_FROM(1)
-        PRIMIA_FLUSH32_FROM(2)
-        PRIMIA_FLUSH32_FROM(3)
-        PRIMIA_FLUSH32_FROM(4)
-        PRIMIA_FLUSH32_FROM(5)
-        PRIMIA_FLUSH32_FROM(6)
-        PRIMIA_FLUSH32_FROM(7)
-        PRIMIA_FLUSH32_FROM(8)
-    }
-#undef PRIMIA_FLUSH32_FROM
+    wgrad32_epilogue(acc, p, smem, wave, lane, half, kg, cg, kt, ct, split);
 }
 
 // Ordered reduction of the v2 slabs (chunk q = ((t*4 + m)*4 + wave)*64 + lane, see the kernel's store).
@@ -775,6 +782,11 @@ struct PatchGeom {
     bool ok, wide;
     int PH, PW, PPI, total, per_block, nsplit, combos;
 };
+
+static bool use_v2() {
+    static const int v2 = getenv("PRIMIA_WGP32") ? atoi(getenv("PRIMIA_WGP32")) : 1;
+    return v2 != 0;
+}
 
 static PatchGeom patch_geom(const WgradParams& w) {
     PatchGeom g{};
@@ -832,7 +844,7 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
 
     const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
     p.ws = store ? w.ws : nullptr;
-    static const int v2 = getenv("PRIMIA_WGP32") ? atoi(getenv("PRIMIA_WGP32")) : 1;
+    const bool v2 = use_v2();
     static const int stages = getenv("PRIMIA_WGP_STAGES") ? atoi(getenv("PRIMIA_WGP_STAGES")) : 3;
     if (v2) {
         constexpr int XS2 = (SH + 2) * (SW == 8 ? 12 : 20);
