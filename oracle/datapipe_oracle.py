@@ -14,8 +14,10 @@ What it restates (reference = /root/reference):
 Parity pin: tests/golden/make_datapipe_golden.py executes the reference's own MixUp / To_one_hot /
 calc_mean_std definitions (extracted from the files under /root/reference at mint time) on seeded
 inputs and checks this restatement bit for bit; the vectors are committed as tests/golden/datapipe.npz.
-The split and the exchange have no executable reference here (ImageFolder / PySyft workers): they are
-restated from the source and pinned only by construction ("parity unpinned" for those two).
+The split is pinned the same way (the dealing statements of distribute_data.py executed from the file, ImageFolder
+replaced by a length).  The exchange is pinned by tests/golden/make_secure_ref_golden.py (mint_mean_std): the
+reference's FixedPrecisionTensor / AdditiveSharingTensor classes run utils.py:764-794's chain and this restatement
+matches bit for bit (tests/golden/mean_std_ref.npz).
 """
 import random as _random
 

@@ -236,8 +236,11 @@ def dp_gradients(sd, x, target, max_grad_norm=1.0, noise_multiplier=1.3, noise=N
     """DP-SGD gradient as pytorch-dp 0.1b1's PrivacyEngine computes it for the optimizer
     (parameter values: train.py:325-334): per-sample gradients of each sample's own loss, flat L2
     clip to C with factor min(1, C / (norm + 1e-6)), sum, + N(0, (noise_multiplier*C)^2), / batch.
-    pytorch-dp is not in the reference tree (environment_torch.yml:136) — parity unpinned; the
-    GroupNorm network makes samples independent, so per-sample gradients are batch-of-1 gradients.
+    pytorch-dp is not in the reference tree (environment_torch.yml:136): the clip / noise rule is restated from its
+    published algorithm ("parity unpinned" for that rule).  The per-sample gradients under it ARE pinned: the
+    GroupNorm network makes samples independent, so they are batch-of-1 gradients, and
+    tests/golden/make_train_golden.py (mint_dp) checks them against the reference's model class
+    (norm_layer=GroupNorm) differentiated by torch.func.vmap(grad) — tests/golden/dp_ref.npz.
     `noise`: dict key -> standard-normal tensor (explicit randomness).  Returns (grads, norms, clip)."""
     keys = param_keys(sd)
     B = x.shape[0]

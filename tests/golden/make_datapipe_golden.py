@@ -34,6 +34,38 @@ def extract(path, names, glob):
     return glob
 
 
+def reference_split(n_items, num_workers):
+    """The statements of data/server_simulation/distribute_data.py that deal the images to the workers (from the
+    `worker_dirs = ...` assignment to the `for i in range(args.num_workers)` loop), executed from the file with
+    ImageFolder replaced by an object of the requested length.  Returns the per-worker index lists."""
+    import ast
+    from random import seed, shuffle
+    from types import SimpleNamespace
+
+    path = "/root/reference/data/server_simulation/distribute_data.py"
+    tree = ast.parse(open(path).read())
+    main_if = [n for n in tree.body if isinstance(n, ast.If)][-1]
+    names = [getattr(n.targets[0], "id", None) if isinstance(n, ast.Assign) else None for n in main_if.body]
+    start = names.index("worker_dirs")
+    stop = next(i for i in range(start, len(main_if.body))
+                if isinstance(main_if.body[i], ast.For) and getattr(main_if.body[i].target, "id", "") == "i")
+    body = main_if.body[start:stop + 1]
+
+    class Folder:
+        classes = ["a", "b", "c"]
+
+        def __init__(self, src):
+            pass
+
+        def __len__(self):
+            return n_items
+
+    g = {"args": SimpleNamespace(num_workers=num_workers, train_data_src="."), "ImageFolder": Folder,
+         "seed": seed, "shuffle": shuffle}
+    exec(compile(ast.Module(body=body, type_ignores=[]), path, "exec"), g)
+    return [g["worker_imgs"]["worker{:d}".format(i + 1)] for i in range(num_workers)]
+
+
 def main():
     from typing import List, Optional, Tuple, Union
 
@@ -84,6 +116,11 @@ def main():
         assert torch.equal(m, om) and torch.equal(s, os_), name
         out[f"meanstd.{name}.data"] = data.numpy()
         out[f"meanstd.{name}.mean"], out[f"meanstd.{name}.std"] = m.numpy(), s.numpy()
+    # the IID round-robin split (distribute_data.py:58-70), executed from the reference's script
+    for n_items, nw in ((5163, 3), (100, 8), (7, 2)):
+        ref_split = reference_split(n_items, nw)
+        assert ref_split == D.iid_round_robin_split(n_items, nw), (n_items, nw)
+        out[f"split.{n_items}.{nw}"] = np.array([len(s) for s in ref_split] + [v for s in ref_split for v in s[:8]])
     np.savez_compressed(os.path.join(HERE, "datapipe.npz"), **out)
     print("wrote", len(out), "arrays; the oracle reproduces the reference bit for bit")
 

@@ -227,7 +227,41 @@ def mint_fedavg():
     print("fedavg_ref.npz written")
 
 
+def mint_mean_std():
+    """The secure mean / std exchange of setup_pysyft (torchlib/utils.py:764-794), with the reference's own tensor
+    classes doing the work: every worker's statistic goes through FixedPrecisionTensor.fix_precision() (defaults:
+    base 10, 3 fractional digits), .share() between the workers, AdditiveSharingTensor `+=`, .get(),
+    .float_precision(), and is divided by the number of workers.  (Only grid.search and the pointer .get() that
+    fetches the shared tensor to the orchestrator are not executed — they move tensors, they do not change them.)"""
+    from oracle import datapipe_oracle as D
+
+    out = {}
+    g = torch.Generator().manual_seed(21)
+    for nw, ch in ((2, 1), (3, 3), (5, 3)):
+        ids = tuple("w%d" % i for i in range(nw))
+        rt = R.Runtime(parties=ids)
+        torch.manual_seed(2)
+        np.random.seed(2)
+        means = [torch.rand(ch, generator=g) * 0.6 + 0.2 for _ in range(nw)]
+        stds = [torch.rand(ch, generator=g) * 0.3 + 0.05 for _ in range(nw)]
+        mean = rt.fix_share(means[0], precision_fractional=3)
+        std = rt.fix_share(stds[0], precision_fractional=3)
+        for m, s_ in zip(means[1:], stds[1:]):
+            mean += rt.fix_share(m, precision_fractional=3)
+            std += rt.fix_share(s_, precision_fractional=3)
+        mean = rt.decode(mean) / len(stds)
+        std = rt.decode(std) / len(stds)
+        om, os_ = D.exchange_mean_std(means, stds)
+        assert torch.equal(om, mean) and torch.equal(os_, std), (nw, ch)
+        tag = f"w{nw}c{ch}"
+        out[tag + "/means"], out[tag + "/stds"] = torch.stack(means).numpy(), torch.stack(stds).numpy()
+        out[tag + "/mean"], out[tag + "/std"] = mean.numpy(), std.numpy()
+        print(f"  mean/std exchange {tag}: oracle bit-identical")
+    np.savez_compressed(os.path.join(HERE, "mean_std_ref.npz"), **out)
+    print("mean_std_ref.npz written")
+
+
 if __name__ == "__main__":
-    mint_fedavg()
-    mint_ops()
-    mint_forward()
+    todo = sys.argv[1:] or ["fedavg", "mean_std", "ops", "forward"]
+    for name in todo:
+        {"fedavg": mint_fedavg, "mean_std": mint_mean_std, "ops": mint_ops, "forward": mint_forward}[name]()

@@ -58,6 +58,46 @@ def load_reference_utils():
 REF_UTILS = None
 
 
+def mint_dp(ref_models):
+    """T10 (DP-SGD): the per-sample gradients are taken from the REFERENCE's model class with its norm_layer hook
+    (torchlib/models.py:355,362-364 -> GroupNorm(32, C)), differentiated per sample by torch.func.vmap(grad) — an
+    implementation independent of the oracle's batch-of-1 loop.  The clip / sum / divide rule on top of them is
+    pytorch-dp 0.1b1's (not in the tree: that part stays restated from its published algorithm)."""
+    from torch.func import functional_call, grad, vmap
+
+    seed, batch, size, C = 11, 6, 64, 1.0
+    torch.manual_seed(seed)
+    model = ref_models.resnet18(pretrained=False, num_classes=3, in_channels=3, adptpool=False, input_size=size,
+                                pooling="max", norm_layer=lambda c: torch.nn.GroupNorm(32, c))
+    model.train()
+    sd = OrderedDict((k, v.detach().clone()) for k, v in model.state_dict().items())
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    y = torch.randint(0, 3, (batch,), generator=g)
+    params = {k: v.detach() for k, v in model.named_parameters()}
+
+    def loss_fn(p, xi, yi):
+        return torch.nn.functional.cross_entropy(functional_call(model, p, (xi[None],)), yi[None])
+
+    per = vmap(grad(loss_fn), in_dims=(None, 0, 0))(params, x, y)
+    norms = torch.sqrt(sum((per[k].double().flatten(1) ** 2).sum(1) for k in per))
+    clip = torch.clamp(C / (norms + 1e-6), max=1.0)
+    clipped = {k: (per[k].double() * clip.view(-1, *[1] * (per[k].dim() - 1))).sum(0) / batch for k in per}
+    want, onorms, oclip = O.dp_gradients({k: v.clone() for k, v in sd.items()}, x, y, C, 0.0, None)
+    assert torch.allclose(onorms, norms, rtol=1e-5) and torch.allclose(oclip, clip, rtol=1e-5)
+    for k in clipped:
+        assert (clipped[k] - want[k].double()).norm() <= 1e-5 * clipped[k].norm(), k
+    out = {"meta": np.array([seed, batch, size]), "C": np.array(C), "norms": norms.numpy(), "clip": clip.numpy(),
+           "x_sum": np.array([x.double().sum().item(), x.double().abs().sum().item()]),
+           "init.conv1.weight": summary(sd["conv1.weight"]), "init.fc.weight": summary(sd["fc.weight"])}
+    for k in clipped:
+        out["grad." + k] = summary(clipped[k])
+        out["sample0." + k] = summary(per[k][0])
+    path = os.path.join(HERE, "dp_ref.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def summary(t, n=8):
     f = t.detach().double().flatten()
     return np.array([f.norm().item(), f.sum().item()] + f[:n].tolist() + [0.0] * max(0, n - f.numel()))
@@ -127,6 +167,7 @@ def main():
     global REF_UTILS
     REF_UTILS = load_reference_utils()
     ref = load_reference_models()
+    mint_dp(ref)
     # the reference's own config values: seed 42 / lr 1e-4 / wd 5e-4 (pneumonia-resnet-pretrained.ini)
     case(ref, "sgd_hard_224", 42, 4, 224, "max", "SGD", 1e-4, 5e-4, None, False, 2)
     case(ref, "sgd_hard_64", 42, 8, 64, "max", "SGD", 1e-2, 5e-4, [0.5, 1.0, 2.0], False, 2)

@@ -70,6 +70,13 @@ def _worker(rank, world, port, tmp):
     m, sd = fed.exchange_mean_std(means[rank], stds[rank], ops=ops)
     om, osd = D.exchange_mean_std(means, stds)
     res["mean_std_exchange"] = torch.equal(m, om) and torch.equal(sd, osd)
+    # ... and against the values the reference's own tensor classes produced (tests/golden/mean_std_ref.npz)
+    import numpy as np
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mean_std_ref.npz"))
+    m, sd = fed.exchange_mean_std(torch.from_numpy(gold["w2c1/means"][rank]), torch.from_numpy(gold["w2c1/stds"][rank]),
+                                  ops=ops)
+    res["mean_std_reference"] = (np.array_equal(m.numpy(), gold["w2c1/mean"])
+                                 and np.array_equal(sd.numpy(), gold["w2c1/std"]))
     torch.save(res, os.path.join(tmp, f"r{rank}.pt"))
     dist.destroy_process_group()
 

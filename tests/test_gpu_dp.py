@@ -1,6 +1,7 @@
 """GPU: GroupNorm network and the DP-SGD gradient (BASELINE configs[3]) against
-the oracle.  pytorch-dp is not in the reference tree, so this row is 'parity unpinned': the oracle
-restates the documented algorithm (per-sample clip to C = 1.0, noise multiplier 1.3)."""
+the oracle.  pytorch-dp is not in the reference tree, so the clip / noise rule is 'parity unpinned' (the oracle
+restates the documented algorithm: per-sample clip to C = 1.0, noise multiplier 1.3); the per-sample gradients under
+it are pinned to the reference's model class (tests/golden/dp_ref.npz, tests/test_oracle_train.py)."""
 import pytest
 import torch
 import torch.nn.functional as F

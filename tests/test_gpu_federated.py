@@ -243,6 +243,20 @@ def _in_process_epochs(cuda, cfg):
     return models, opt, names
 
 
+def test_mean_std_exchange_matches_reference_tensors(cuda, golden_dir):
+    """8f.1: fed.secure_mean_of (HIP encode -> ring add -> decode -> / K) against the values the reference's own
+    FixedPrecisionTensor / AdditiveSharingTensor classes produced for utils.py:764-794 (mean_std_ref.npz)."""
+    from primia_amd import fed
+
+    gold = np.load(os.path.join(golden_dir, "mean_std_ref.npz"))
+    for tag in ("w2c1", "w3c3", "w5c3"):
+        stats = [(torch.from_numpy(m).to(cuda), torch.from_numpy(s).to(cuda))
+                 for m, s in zip(gold[tag + "/means"], gold[tag + "/stds"])]
+        m, s = fed.secure_mean_of(stats)
+        assert np.array_equal(m.cpu().numpy(), gold[tag + "/mean"]), tag
+        assert np.array_equal(s.cpu().numpy(), gold[tag + "/std"]), tag
+
+
 @pytest.mark.parametrize("case", ["secure_sgd", "plain_adam_keep", "weighted_secure_adam_reset", "dp_clip_secure"])
 def test_per_rank_federated_epoch_matches_in_process(cuda, tmp_path, case):
     """one client per rank (here 2 ranks sharing GPU 0 over gloo; RCCL on a multi-GPU node) against the

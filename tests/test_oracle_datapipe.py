@@ -67,3 +67,31 @@ def test_exchange_mean_std_oracle():
     # fixed point with 3 fractional digits: every term is truncated to 1e-3 before the sum
     assert torch.allclose(m, torch.tensor([(0.5 + 0.7 + 0.1) / 3, (0.25 + 0.35 + 0.9) / 3]), atol=1e-6)
     assert torch.allclose(s, torch.tensor([0.25, 0.15]), atol=1e-6)
+
+
+def test_exchange_mean_std_against_reference_tensors(golden_dir):
+    """tests/golden/mean_std_ref.npz was produced by the reference's FixedPrecisionTensor / AdditiveSharingTensor
+    classes running utils.py:764-794's chain (make_secure_ref_golden.py mint_mean_std)."""
+    import os
+
+    gold = np.load(os.path.join(golden_dir, "mean_std_ref.npz"))
+    for tag in ("w2c1", "w3c3", "w5c3"):
+        means = [torch.from_numpy(v) for v in gold[tag + "/means"]]
+        stds = [torch.from_numpy(v) for v in gold[tag + "/stds"]]
+        m, s = D.exchange_mean_std(means, stds)
+        assert np.array_equal(m.numpy(), gold[tag + "/mean"]) and np.array_equal(s.numpy(), gold[tag + "/std"]), tag
+
+
+def test_iid_split_against_reference_script(golden_dir):
+    """The dealing statements of distribute_data.py, executed at mint time (make_datapipe_golden.reference_split)."""
+    import os
+
+    from primia_amd.datapipe import iid_round_robin_split
+
+    gold = np.load(os.path.join(golden_dir, "datapipe.npz"))
+    for n_items, nw in ((5163, 3), (100, 8), (7, 2)):
+        want = gold[f"split.{n_items}.{nw}"]
+        for fn in (D.iid_round_robin_split, iid_round_robin_split):
+            parts = fn(n_items, nw)
+            got = np.array([len(s) for s in parts] + [v for s in parts for v in s[:8]])
+            assert np.array_equal(got, want), (n_items, nw)

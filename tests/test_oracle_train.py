@@ -57,6 +57,27 @@ def test_oracle_matches_reference_golden(golden_dir, name):
                 assert np.allclose(_summary(v), gold[f"s{step}.post.{k}"], rtol=1e-6, atol=1e-9), k
 
 
+def test_dp_gradients_against_reference_model(golden_dir):
+    """T10: per-sample norms, clip factors and the clipped mean gradient of the oracle's batch-of-1 loop against
+    the fixture minted from the reference's model class (norm_layer=GroupNorm) differentiated by vmap(grad)."""
+    gold = np.load(os.path.join(golden_dir, "dp_ref.npz"))
+    seed, batch, size = [int(v) for v in gold["meta"]]
+    torch.manual_seed(seed)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"), "group")
+    assert np.allclose(_summary(sd["conv1.weight"]), gold["init.conv1.weight"], rtol=1e-6)
+    assert np.allclose(_summary(sd["fc.weight"]), gold["init.fc.weight"], rtol=1e-6)
+    g = torch.Generator().manual_seed(seed + 1)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    y = torch.randint(0, 3, (batch,), generator=g)
+    assert np.allclose(gold["x_sum"], [x.double().sum().item(), x.double().abs().sum().item()])
+    grads, norms, clip = O.dp_gradients(sd, x, y, float(gold["C"]), 0.0, None)
+    assert np.allclose(norms.numpy(), gold["norms"], rtol=1e-5)
+    assert np.allclose(clip.numpy(), gold["clip"], rtol=1e-5)
+    for k, gk in grads.items():
+        want = gold["grad." + k]
+        assert np.allclose(_summary(gk), want, rtol=1e-4, atol=1e-5 * want[0] + 1e-12), k
+
+
 def test_spec_matches_reference_inventory():
     spec = rs.resnet18_spec()
     keys = rs.state_dict_keys(spec)
