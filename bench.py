@@ -256,7 +256,7 @@ def main():
         if kind == "wgrad":
             if sp.k == 7:
                 return "stem_conv_wgrad_kernel"
-            return "conv_wgrad_patch_kernel" if (sp.k == 3 and sp.stride == 1) else "conv_wgrad_kernel (per-tap, stride 2 / 1x1)"
+            return "conv_wgrad_patch32_kernel" if (sp.k == 3 and sp.stride == 1) else "conv_wgrad_kernel (per-tap, stride 2 / 1x1)"
         if sp.k == 7:
             return "stem_conv_fwd_kernel"
         if l1:
@@ -302,8 +302,8 @@ def main():
             traffic_offline = {"hbm_bytes_per_launch": rec[key].get("hbm_bytes_per_launch"), "kernel": key,
                                "source": "profiles/" + TRAFFIC_FILE}
     roof = {"bound": "mfma", "kernel": dom,
-            "launch": "median over %d steps of the HIP-event bracket around one C-ABI call (conv_wgrad_patch_kernel: the "
-                      "kernel + its wgrad_patch_reduce_kernel)" % nprof,
+            "launch": "median over %d steps of the HIP-event bracket around one C-ABI call (conv_wgrad_patch32_kernel: the "
+                      "kernel + its wgrad_patch32_reduce_kernel)" % nprof,
             "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic, "traffic_offline": traffic_offline,
             "all_conv": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 3),
