@@ -123,11 +123,12 @@ def fedavg_allreduce(flat, out, weight=None, secure=False, precision_fractional=
     return out
 
 
-def exchange_mean_std(mean, std, group=None, ops=None, precision_fractional=3, base=10):
+def exchange_mean_std(mean, std, group=None, ops=None, precision_fractional=3, base=10, masks=None):
     """setup_pysyft's secure average of the clients' data statistics (torchlib/utils.py:764-794): each rank
     holds its local (mean, std); they are fixed-point encoded (`fix_precision()` defaults: 10^3), summed in
     the 2^64 ring across the ranks (one int64 all-reduce — additive sharing commutes with the ring sum),
-    decoded and divided by the number of clients.  Returns (mean, std) as the reference's `val_mean_std`."""
+    decoded and divided by the number of clients.  Returns (mean, std) as the reference's `val_mean_std`.
+    With `masks` (a PairwiseMasks) a client's statistics leave it under one-time masks, like the model updates."""
     ops = ops or HipArenaOps()
     K = dist.get_world_size(group) if dist.is_initialized() else 1
     both = torch.cat([mean.reshape(-1), std.reshape(-1)]).to(torch.float32).contiguous()
@@ -135,6 +136,8 @@ def exchange_mean_std(mean, std, group=None, ops=None, precision_fractional=3, b
     scale = float(base ** precision_fractional)
     ops.encode(both, q, scale)
     if K > 1:
+        if masks is not None:
+            masks.apply(q)
         dist.all_reduce(q, op=dist.ReduceOp.SUM, group=group)
     out = torch.empty_like(both)
     ops.decode(q, out, scale)

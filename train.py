@@ -192,8 +192,10 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
                 train_loader[w], stats[w] = imagefolder.client_loader(
                     path.join(args.data_dir, "worker{:d}".format(i + 1)), args, device, channels, args.seed + i)
         # setup_pysyft's secure average of the clients' (mean, std) (utils.py:764-794) -> val_mean_std
+        if world > 1 and not args.unencrypted_aggregation:
+            masks = fed.PairwiseMasks.setup(local.flat.numel(), device, group)
         if world > 1:
-            m, s = fed.exchange_mean_std(*stats[mine[0]])
+            m, s = fed.exchange_mean_std(*stats[mine[0]], masks=masks)
         else:
             from primia_amd import fed
 
@@ -201,8 +203,6 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
         val_mean_std = (m.cpu(), s.cpu())
         optimizer = {w: EngineOptimizer.from_args(model[w], args) for w in mine}
         loss_fn = {w: None for w in mine}
-        if world > 1 and not args.unencrypted_aggregation:
-            masks = fed.PairwiseMasks.setup(local.flat.numel(), device, group)
     else:
         workers, mine = [], []
         model = local
