@@ -3,9 +3,9 @@
 //
 // The generic implicit GEMM (conv_igemm.hip) stages a 128-pixel activation tile AND a weight tile for every one of
 // the 9 taps of every 64-channel chunk: 32 KiB of L2 -> LDS traffic per 2 MFLOP-pairs, and that fill rate (not the
-// MFMA or LDS pipes) is what bounds it.  Here a block owns 256 CONSECUTIVE output pixels (NHWC order, no spatial
-// patch, so 28-, 14- and 7-wide images tile without waste) x 128 output channels, and per 64-channel chunk stages
-//     the "linear halo":  pixels m0 - (W+1) .. m0 + 255 + (W+1)  (<= 320 slots of 128 B)   ONCE for all 9 taps
+// MFMA or LDS pipes) is what bounds it.  Here a block owns BM = 224 (or 256) CONSECUTIVE output pixels (NHWC order, no
+// spatial patch, so 28-, 14- and 7-wide images tile without waste) x 128 output channels, and per 64-channel chunk stages
+//     the "linear halo":  pixels m0 - (W+1) .. m0 + BM - 1 + (W+1)  (<= 320 slots of 128 B)   ONCE for all 9 taps
 //     one weight tile per tap: 128 rows x 128 B = 16 KiB
 // Tap (r, s) of output pixel m reads source pixel m + (r-1)*W + (s-1): the same LDS buffer at a tap-uniform slot
 // shift.  What the shifted slot holds when the tap falls outside the image (left / right border, first / last row,
@@ -14,8 +14,8 @@
 // 184 KiB for 4x the MFMA work of an implicit-GEMM tile step sequence that moves 9 x 32 = 288 KiB for 1x... i.e.
 // 0.32x the bytes per flop.
 //
-// 8 waves = 4 (pixels: 64 each) x 2 (channels: 64 each); per wave and 32-channel half 4 weight + 4 pixel fragment
-// reads (ds_read_b128) feed 16 MFMAs.  Weights are the MFMA A operand (a lane ends up with 4 consecutive output
+// 8 waves = 4 (pixels: 64 each; 64, 64, 48, 48 in the 224-pixel tile) x 2 (channels: 64 each); per wave and 32-channel
+// half 4 weight + 4 (3) pixel fragment reads (ds_read_b128) feed 16 (12) MFMAs.  Weights are the MFMA A operand (a lane ends up with 4 consecutive output
 // channels of one pixel).  LDS: 2 halo buffers (2 x 40 KiB) + a 4-deep weight ring (4 x 16 KiB) = 144 KiB, one block
 // per CU.  Ping-pong wave halves, two barriers per tap step; LDS-DMA issued as inline asm and ordered with counted vmcnt (see
 // conv_wgrad_patch.hip).  Both LDS images carry the XOR chunk swizzle (chunk ^ ((row >> 1) & 7)) applied on the DMA
@@ -71,16 +71,30 @@ struct LhParams {
     int debug;         // timing experiments only (PRIMIA_LH_DEBUG): 1 no stores, 2 no staging, 4 no MFMA
 };
 
-constexpr int kLhBM = 256, kLhBN = 128;
-constexpr int kLhSlots = 320;                  // 256 + 2*(W+1), W <= 31
+constexpr int kLhBN = 128;
+template <int J>
+struct LhJ {
+    static constexpr int value = J;
+};
+// pixels per tile: 224 (default) or 256 (PRIMIA_LH_BM=256)
+static int lh_bm() {
+    static const int bm = getenv("PRIMIA_LH_BM") && atoi(getenv("PRIMIA_LH_BM")) == 256 ? 256 : 224;
+    return bm;
+}
+constexpr int kLhSlots = 320;                  // BM + 2*(W+1) <= 256 + 62, W <= 30
 constexpr int kLhHalo = kLhSlots * 128;        // bytes per halo buffer
 constexpr int kLhWt = kLhBN * 128;             // bytes per weight tile
 constexpr int kLhWR = 4;                       // weight ring depth
 constexpr int kLhLds = 2 * kLhHalo + kLhWR * kLhWt;
 constexpr int kLhZeroSlot = kLhSlots - 1;      // never a live slot (W <= 30): staged as zeros in both buffers
 
-template <bool ACC>
+// JB = pixel fragments of the "B" waves (4-7).  JB = 4: 256-pixel tiles.  JB = 3: 224-pixel tiles (waves 0-3 own
+// 2 x 64 pixels, waves 4-7 2 x 48): 28x28, 14x14 and 7x7 images at batch 256 then give 896 / 448 / 224 tiles = 3.5 / 1.75 /
+// 0.875 rounds of 256 CUs where 256-pixel tiles give 784 / 392 / 196 = 4 / 2 / 1 rounds of which the last is 77 % empty;
+// on every SIMD an A segment (32 MFMAs) alternates with a B segment (24), so a step costs 7/8 of the 256-pixel step.
+template <bool ACC, int JB>
 __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
+    constexpr int BM = 128 + 32 * JB;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -89,11 +103,11 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
 
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = tile % p.ntile_n, tm = tile / p.ntile_n;
-    const long m0 = (long)tm * kLhBM;
+    const long m0 = (long)tm * BM;
     const int n0 = tn * kLhBN;
     const int W = p.W, H = p.H, Cs = p.Cs;
     const long hm0 = m0 - (W + 1);             // source pixel of halo slot 0
-    const int nslots = kLhBM + 2 * W + 2;      // live slots
+    const int nslots = BM + 2 * W + 2;         // live slots
     const int nchunks = Cs >> 6;
     const int klen = 9 * Cs;
 
@@ -133,13 +147,15 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
     // pixel fragments j: tile pixel wm*64 + 16j + fr; its halo slot at shift 0 is that + (W+1); 9-bit tap validity
     int sj[4];
     unsigned pmask[4];
+    const int wpix0 = wave < 4 ? wm * 64 : 128 + (wm - 2) * 16 * JB;   // first tile pixel of this wave
+    const int nj = wave < 4 ? 4 : JB;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int pl = wm * 64 + 16 * j + fr;
+        const int pl = wpix0 + 16 * j + fr;
         sj[j] = pl + W + 1;
         const long m = m0 + pl;
         unsigned mask = 0;
-        if (m < p.M) {
+        if (m < p.M && j < nj) {
             const int w = (int)(m % W);
             const int h = (int)((m / W) % H);
 #pragma unroll
@@ -202,7 +218,8 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
         __builtin_amdgcn_s_barrier();
     };
     // `tap` is a compile-time constant after unrolling, `chunk` is not
-    auto load_segment = [&](int chunk, int tap) {
+    auto load_segment = [&](int chunk, int tap, auto jtag) {
+        constexpr int J = decltype(jtag)::value;
         int issued = 0;
         if (staging) {
             if (tap < 5 && chunk + 1 < nchunks) {
@@ -225,7 +242,7 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) a[kk][i] = *(const bf16x8_t*)(wbp + (aoff[i] ^ (kk << 6)));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) b[kk][j] = *(const bf16x8_t*)(hb + (boffT[tap][j] ^ (kk << 6)));
+                for (int j = 0; j < J; ++j) b[kk][j] = *(const bf16x8_t*)(hb + (boffT[tap][j] ^ (kk << 6)));
             }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -233,14 +250,15 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
         wb = wb == kLhWR - 1 ? 0 : wb + 1;
         wb3 = wb3 == kLhWR - 1 ? 0 : wb3 + 1;
     };
-    auto mfma_segment = [&]() {
+    auto mfma_segment = [&](auto jtag) {
+        constexpr int J = decltype(jtag)::value;
         if (p.debug & 4) return;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < J; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[kk][i], b[kk][j], acc[i][j], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -249,9 +267,9 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 top();                                  // B_2t
-                load_segment(c, tap);
+                load_segment(c, tap, LhJ<4>{});
                 __builtin_amdgcn_s_barrier();           // B_2t+1
-                mfma_segment();
+                mfma_segment(LhJ<4>{});
             }
         }
         __builtin_amdgcn_s_barrier();                   // B_2n
@@ -260,13 +278,13 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
 #pragma unroll
             for (int tap = 0; tap < 9; ++tap) {
                 top();                                  // B_2t
-                if (tap != 0 || c != 0) mfma_segment(); // step t - 1
+                if (tap != 0 || c != 0) mfma_segment(LhJ<JB>{}); // step t - 1
                 __builtin_amdgcn_s_barrier();           // B_2t+1
-                load_segment(c, tap);
+                load_segment(c, tap, LhJ<JB>{});
             }
         }
         __builtin_amdgcn_s_barrier();                   // B_2n
-        mfma_segment();
+        mfma_segment(LhJ<JB>{});
     }
 
     // ---- epilogue: results leave through LDS as whole 256-byte pixel rows ------------------------------------
@@ -287,7 +305,7 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
             const long m = m0 + (q >> 4);
             yraw[k] = u32x4{0, 0, 0, 0};
             mkb[k] = 0;
-            if (m < p.M) {
+            if (m < p.M && (q >> 4) < BM) {
                 const long eo = m * p.Nd + n0 + (q & 15) * 8;
                 yraw[k] = *(const u32x4*)(p.bn_y + eo);
                 if (p.bn_mask) mkb[k] = p.bn_mask[eo >> 3];
@@ -296,7 +314,8 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int px = wm * 64 + 16 * j + fr;
+        if (j >= nj) break;                      // wave-uniform: the B waves of a 224-pixel tile own three fragments
+        const int px = wpix0 + 16 * j + fr;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int ch = wn * 64 + 16 * i + fg * 4;
@@ -329,7 +348,7 @@ __global__ __launch_bounds__(512) void conv3x3_lh_kernel(LhParams p) {
         const int q = tid + 512 * k;            // 16-byte output chunk: pixel q / 16, channels 8 * (q % 16) ..
         const int px = q >> 4, c8 = q & 15;
         const long m = m0 + px;
-        if (m >= p.M) continue;
+        if (m >= p.M || px >= BM) continue;
         bf16* gq = p.dst + m * p.Nd + n0 + c8 * 8;
         u32x4 v;
         if constexpr (ACC) {
@@ -415,7 +434,7 @@ int conv3x3_lh_tiles_m(int N, int H, int W, int Cs, int Nd) {
     if (off || W > 30 || W < 2 || Cs % 64 || Nd % kLhBN) return PRIMIA_ERR_UNSUPPORTED;
     const long M = (long)N * H * W;
     if (M * (Cs > Nd ? Cs : Nd) >= (1L << 31)) return PRIMIA_ERR_UNSUPPORTED;
-    return (int)((M + kLhBM - 1) / kLhBM);
+    return (int)((M + lh_bm() - 1) / lh_bm());
 }
 
 int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
@@ -440,20 +459,17 @@ int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H
     }
     static const int dbg = getenv("PRIMIA_LH_DEBUG") ? atoi(getenv("PRIMIA_LH_DEBUG")) : 0;
     p.debug = dbg;
-    const int grid = (int)((M + kLhBM - 1) / kLhBM) * p.ntile_n;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv3x3_lh_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kLhLds) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_lh_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                kLhLds) != hipSuccess)
+    const int bm = lh_bm();
+    const int grid = (int)((M + bm - 1) / bm) * p.ntile_n;
+    void (*kern)(LhParams) = bm == 256 ? (accumulate ? conv3x3_lh_kernel<true, 4> : conv3x3_lh_kernel<false, 4>)
+                                       : (accumulate ? conv3x3_lh_kernel<true, 3> : conv3x3_lh_kernel<false, 3>);
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[accumulate ? 1 : 0]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kLhLds) != hipSuccess)
             return PRIMIA_ERR_LAUNCH;
-        attr_set = true;
+        attr_set[accumulate ? 1 : 0] = true;
     }
-    if (accumulate)
-        conv3x3_lh_kernel<true><<<grid, 512, kLhLds, st>>>(p);
-    else
-        conv3x3_lh_kernel<false><<<grid, 512, kLhLds, st>>>(p);
+    kern<<<grid, 512, kLhLds, st>>>(p);
     return launch_status();
 }
 

@@ -634,7 +634,7 @@ def test_wide_conv_emits_batchnorm_partials(cuda, N, H, C, K):
     wf, _ = prep_weights(desc, w, dtype, cuda, C)
     slots = query("primia_conv_stat_slots_for", desc, dt)
     M = N * H * H
-    assert slots == (M + 255) // 256
+    assert slots == (M + 223) // 224      # 224-pixel tiles (conv3x3_lh.hip)
     y = torch.empty(M, K, dtype=dtype, device=cuda)
     sums = torch.full((slots, 2, K), float("nan"), device=cuda)   # written, not accumulated
     call("primia_conv2d_fwd_stats", desc, x, wf, y, sums, dt)
@@ -768,7 +768,7 @@ def test_dgrad_emits_batchnorm_backward_sums(cuda, N, H, C, K, acc):
     desc = ConvDesc.make(N, H, H, C, K, 3, 3, 1, 1)
     slots = query("primia_conv_dgrad_bnsum_slots", desc, dt)
     M = N * H * H
-    assert slots == (M + 255) // 256
+    assert slots == (M + 223) // 224      # 224-pixel tiles (conv3x3_lh.hip)
     w = rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype)
     _, wd = prep_weights(desc, w, dtype, cuda, C)
     dyc = to_nhwc(rnd(torch.randn(N, K, H, H, generator=g), dtype), dtype, cuda)          # gradient entering the conv
