@@ -373,9 +373,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // those of the unfused kernels (first maximum in scan order, like torch's max_pool2d).
 // =================================================================================================
 
-// PW = output pixels per thread along W (1, or 2 when Wo is even: the two windows share a column, 15 loads
-// instead of 18, all independent).
-template <typename T, int PW>
+// PW x PH = output pixels per thread (along W: 1, or 2 when Wo is even — the two windows share a column, 5 loads per
+// row instead of 6; along H: 1, or 2 when Ho is even — the two windows share input row 2*ho + 1, 5 rows instead of 6).
+// Default: PW = 2 (when Wo is even), PH = 1 — see launch_bn_relu_pool_fwd for the measurement behind it.
+template <typename T, int PW, int PH>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restrict__ y, T* __restrict__ pooled,
                                                                uint8_t* __restrict__ argmax,
                                                                const float* __restrict__ gamma,
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
                                                                const float* __restrict__ invstd, int N, int H, int W,
                                                                int C, int Ho, int Wo) {
     constexpr int CH = Chunk<T>::N;
-    constexpr int NCOL = 2 * PW + 1;
+    constexpr int NCOL = 2 * PW + 1, NROW = 2 * PH + 1;
     __shared__ float sm[3][512];
     for (int c = threadIdx.x; c < C; c += 256) {
         sm[0][c] = mean[c];
@@ -393,28 +394,30 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
     }
     __syncthreads();
     const int cpr = C / CH;
-    const int Wq = Wo / PW;
-    const long total = (long)N * Ho * Wq * cpr;
+    const int Wq = Wo / PW, Hq = Ho / PH;
+    const long total = (long)N * Hq * Wq * cpr;
     // (an XCD-contiguous block order was measured slower, 161 -> 178 us: the eight L2s then stream eight distant
-    // regions instead of sharing one; the 1.47x fetch amplification of the window rows is mostly MALL hits)
+    // regions instead of sharing one)
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= total) return;
     const int cc = (int)(q % cpr);
     long t = q / cpr;
     const int wq = (int)(t % Wq);
     t /= Wq;
-    const int ho = (int)(t % Ho);
-    const int n = (int)(t / Ho);
+    const int hq = (int)(t % Hq);
+    const int n = (int)(t / Hq);
     const int c0 = cc * CH;
-    float best[PW][CH];
-    int pos[PW][CH];
+    float best[PH][PW][CH];
+    int pos[PH][PW][CH];
 #pragma unroll
-    for (int k = 0; k < PW; ++k)
+    for (int kh = 0; kh < PH; ++kh)
 #pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            best[k][i] = 0.f;
-            pos[k][i] = -1;
-        }
+        for (int k = 0; k < PW; ++k)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                best[kh][k][i] = 0.f;
+                pos[kh][k][i] = -1;
+            }
     float mu[CH], sc[CH], be[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -423,9 +426,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
         be[i] = sm[2][c0 + i];
     }
     const int w0 = wq * PW * 2 - 1;   // leftmost input column of the first window
+    const int h0 = hq * PH * 2 - 1;   // topmost input row of the first window
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-        const int h = ho * 2 - 1 + r;
+    for (int rr = 0; rr < NROW; ++rr) {
+        const int h = h0 + rr;
         if (h < 0 || h >= H) continue;
         const T* row = y + (((long)n * H + h) * W) * C + c0;
         u32x4 raw[NCOL];
@@ -444,35 +448,42 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
 #pragma unroll
             for (int i = 0; i < CH; ++i) v[i] = round_to<T>(fmaxf(bn_affine(v[i], mu[i], sc[i], be[i]), 0.f));
 #pragma unroll
-            for (int k = 0; k < PW; ++k) {
-                const int s = col - 2 * k;       // tap column of window k (scan order r, s as before)
-                if (s < 0 || s > 2) continue;
+            for (int kh = 0; kh < PH; ++kh) {
+                const int r = rr - 2 * kh;       // tap row of window kh (a window sees its taps in scan order r, s)
+                if (r < 0 || r > 2) continue;
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const float z = v[i];
-                    if (pos[k][i] < 0 || z > best[k][i] || z != z) {
-                        best[k][i] = z;
-                        pos[k][i] = r * 3 + s;
+                for (int k = 0; k < PW; ++k) {
+                    const int s_ = col - 2 * k;  // tap column of window k
+                    if (s_ < 0 || s_ > 2) continue;
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        const float z = v[i];
+                        if (pos[kh][k][i] < 0 || z > best[kh][k][i] || z != z) {
+                            best[kh][k][i] = z;
+                            pos[kh][k][i] = r * 3 + s_;
+                        }
                     }
                 }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < PW; ++k) {
-        const long o = (((long)n * Ho + ho) * Wo + wq * PW + k) * C + c0;
-        *(u32x4*)(pooled + o) = Chunk<T>::pack(best[k]);
-        // the chunk's CH argmax bytes leave as one 4- / 8-byte store (o is a multiple of CH)
-        uint32_t pk[CH / 4];
+    for (int kh = 0; kh < PH; ++kh)
 #pragma unroll
-        for (int j = 0; j < CH / 4; ++j)
-            pk[j] = (uint32_t)pos[k][4 * j] | ((uint32_t)pos[k][4 * j + 1] << 8) | ((uint32_t)pos[k][4 * j + 2] << 16) |
-                    ((uint32_t)pos[k][4 * j + 3] << 24);
-        if constexpr (CH == 8)
-            *(u32x2*)(argmax + o) = u32x2{pk[0], pk[1]};
-        else
-            *(uint32_t*)(argmax + o) = pk[0];
-    }
+        for (int k = 0; k < PW; ++k) {
+            const long o = (((long)n * Ho + hq * PH + kh) * Wo + wq * PW + k) * C + c0;
+            *(u32x4*)(pooled + o) = Chunk<T>::pack(best[kh][k]);
+            // the chunk's CH argmax bytes leave as one 4- / 8-byte store (o is a multiple of CH)
+            uint32_t pk[CH / 4];
+#pragma unroll
+            for (int j = 0; j < CH / 4; ++j)
+                pk[j] = (uint32_t)pos[kh][k][4 * j] | ((uint32_t)pos[kh][k][4 * j + 1] << 8) |
+                        ((uint32_t)pos[kh][k][4 * j + 2] << 16) | ((uint32_t)pos[kh][k][4 * j + 3] << 24);
+            if constexpr (CH == 8)
+                *(u32x2*)(argmax + o) = u32x2{pk[0], pk[1]};
+            else
+                *(uint32_t*)(argmax + o) = pk[0];
+        }
 }
 
 // gradient w.r.t. z(n, h, w, c0..c0+CH-1) coming back through the pool.  A pixel lies in at most 2 x 2
@@ -845,15 +856,16 @@ static void launch_bn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax
                                     const float* mean, const float* invstd, int N, int H, int W, int C, int Ho, int Wo,
                                     hipStream_t st) {
     static const bool one = getenv("PRIMIA_POOL_PW") && getenv("PRIMIA_POOL_PW")[0] == '1';
+    // (two windows along H per thread — 25 loads for 4 windows — measured SLOWER: 265 vs 258 us for stats + pool at
+    // batch 256, 160 registers / occupancy 3, and the shared row is a MALL hit anyway; opt-in: PRIMIA_POOL_PH=2)
+    static const bool twoh = getenv("PRIMIA_POOL_PH") && getenv("PRIMIA_POOL_PH")[0] == '2';
     const int pw = (Wo % 2 == 0 && !one) ? 2 : 1;
-    const long total = (long)N * Ho * (Wo / pw) * (C / Chunk<T>::N);
+    const int ph = (Ho % 2 == 0 && twoh) ? 2 : 1;
+    const long total = (long)N * (Ho / ph) * (Wo / pw) * (C / Chunk<T>::N);
     const unsigned grid = (unsigned)((total + 255) / 256);
-    if (pw == 2)
-        bn_relu_pool_fwd_kernel<T, 2><<<grid, 256, 0, st>>>((const T*)y, (T*)pooled, argmax, gamma, beta, mean, invstd, N,
-                                                           H, W, C, Ho, Wo);
-    else
-        bn_relu_pool_fwd_kernel<T, 1><<<grid, 256, 0, st>>>((const T*)y, (T*)pooled, argmax, gamma, beta, mean, invstd, N,
-                                                           H, W, C, Ho, Wo);
+    auto kern = pw == 2 ? (ph == 2 ? bn_relu_pool_fwd_kernel<T, 2, 2> : bn_relu_pool_fwd_kernel<T, 2, 1>)
+                        : (ph == 2 ? bn_relu_pool_fwd_kernel<T, 1, 2> : bn_relu_pool_fwd_kernel<T, 1, 1>);
+    kern<<<grid, 256, 0, st>>>((const T*)y, (T*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo);
 }
 
 template <typename T>
