@@ -258,7 +258,56 @@ def _sel(pair, bit):
     return np.where(bit.astype(bool), pair[1], pair[0])
 
 
+# The reference fans FSS work above MULTI_LIMIT elements out over N_CORES processes, slicing the element axis
+# (fss.py:43-44, 47-95, 214-266).  Every element is independent, so the sliced result is the serial one; the
+# oracle does the same when a process pool is installed (full-size parity tests and the CPU baseline).
+MULTI_LIMIT = 50_000
+_POOL = None
+
+
+def use_pool(pool, n_slices=None):
+    """Install (or, with None, remove) a multiprocessing pool for dif_keygen / dif_eval above MULTI_LIMIT."""
+    global _POOL
+    _POOL = None if pool is None else (pool, int(n_slices or getattr(pool, "_processes", 8)))
+
+
+def _cuts(n, k):
+    step = -(-n // k)
+    return [(i, min(n, i + step)) for i in range(0, n, step)]
+
+
+def _keygen_job(args):
+    return _dif_keygen_serial(*args)[1]
+
+
+def _eval_job(args):
+    return _dif_eval_serial(*args)
+
+
 def dif_keygen(alpha, s0_pair):
+    """DIF.keygen; element slices in worker processes above MULTI_LIMIT (fss.py:47-95), else in place."""
+    n = alpha.shape[0]
+    if _POOL is None or n <= MULTI_LIMIT:
+        return _dif_keygen_serial(alpha, s0_pair)
+    pool, k = _POOL
+    s0_pair = np.asarray(s0_pair, U64)
+    parts = pool.map(_keygen_job, [(alpha[a:b], np.ascontiguousarray(s0_pair[:, :, a:b])) for a, b in _cuts(n, k)])
+    keys = [{name: np.concatenate([p[b][name] for p in parts], axis=-1) for name in parts[0][b]} for b in range(2)]
+    return alpha, keys
+
+
+def dif_eval(b, x, key):
+    """DIF.eval; element slices in worker processes above MULTI_LIMIT (fss.py:214-266), else in place."""
+    x = np.asarray(x)
+    n = x.shape[0]
+    if _POOL is None or n <= MULTI_LIMIT:
+        return _dif_eval_serial(b, x, key)
+    pool, k = _POOL
+    jobs = [(b, x[a:c], {name: np.ascontiguousarray(v[..., a:c]) for name, v in key.items()}) for a, c in _cuts(n, k)]
+    return np.concatenate(pool.map(_eval_job, jobs))
+
+
+def _dif_keygen_serial(alpha, s0_pair):
     """DIF.keygen (fss.py:344-398) with explicit randomness.
     alpha : uint64 [n] in [0, 2^32);  s0_pair : uint64 [2 parties, 2 words, n] (word 0 < 2^63).
     Returns (alpha, keys) with keys[b] = dict(s0 [2,n], bits [32,4,n] (τL,tL,τR,tR), cw_sigma
@@ -316,7 +365,7 @@ def dif_keygen(alpha, s0_pair):
     return alpha, keys
 
 
-def dif_eval(b, x, key):
+def _dif_eval_serial(b, x, key):
     """DIF.eval (fss.py:400-428): int64 share of [x <= alpha]... evaluated on the masked input x."""
     x_bits = bit_decomposition(x)
     n = x_bits.shape[1]

@@ -440,30 +440,33 @@ class SecureContext:
         n = v[0].numel()
         dev = v[0].device
         prims = [self.dealer.const_mask(1, owner=None)]
-        keep = [prims[0]]
         for _ in range(79):
             for k in range(3):
                 if k == 2:
                     m = self.dealer.const_mask(1, owner=None)
                     prims.append(m)
-                    keep.append(m)
                 t = self.dealer.triple("mul", shape, shape)
-                keep.append(t)
                 prims += [t[0][0], t[0][1], t[0][2], t[1][0], t[1][1], t[1][2]]
-        # pointer table on the device; cached per call position so that a replayed / captured forward over the same
-        # (static) primitive buffers uploads nothing (a host-to-device copy cannot be captured into a hipGraph)
         ptrs = [p.data_ptr() for p in prims]
-        idx = self._newton_calls
-        self._newton_calls += 1
-        if idx < len(self._newton_tables) and self._newton_tables[idx][0] == ptrs:
-            table = self._newton_tables[idx][1]
-        else:
-            table = torch.tensor(ptrs, dtype=I64).to(dev)
-            entry = (ptrs, table, keep)             # `keep`: the launch reads the primitives asynchronously
-            if idx < len(self._newton_tables):
-                self._newton_tables[idx] = entry
+        if isinstance(self.dealer, PreloadedDealer):
+            # static primitive buffers (pre-provisioned store, GraphedSecureInference): the device pointer table is
+            # cached per call position, so a replayed / captured forward uploads nothing (a host-to-device copy
+            # cannot be captured into a hipGraph).  Nothing is retained beyond the table: the tape owns the buffers.
+            idx = self._newton_calls
+            self._newton_calls += 1
+            if idx < len(self._newton_tables) and self._newton_tables[idx][0] == ptrs:
+                table = self._newton_tables[idx][1]
             else:
-                self._newton_tables.append(entry)
+                table = torch.tensor(ptrs, dtype=I64).to(dev)
+                if idx < len(self._newton_tables):
+                    self._newton_tables[idx] = (ptrs, table)
+                else:
+                    self._newton_tables.append((ptrs, table))
+        else:
+            # live dealer: fresh primitives every call — build the table, launch, drop every reference.  The launch
+            # is on the current stream and torch's allocator is stream-ordered, so the 237 triples may be recycled
+            # as soon as this function returns (round 2 pinned all of them per image: ~55 MB leaked per forward).
+            table = torch.tensor(ptrs, dtype=I64).to(dev)
         out = [torch.empty(shape, dtype=I64, device=dev), torch.empty(shape, dtype=I64, device=dev)]
         call("primia_newton_reciprocal_local", v[0].contiguous(), v[1].contiguous(), table, int(self.scale), out[0], out[1], n)
         self.stats["beaver_mul"] += 3 * 79

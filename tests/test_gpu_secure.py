@@ -284,3 +284,23 @@ def test_three_role_deployment_bit_identical_to_in_process(cuda, tmp_path, pf):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     for j in range(2):
         assert torch.equal(torch.load(f"{out}.{j}"), want), j
+
+
+def test_eager_forwards_do_not_retain_newton_primitives(cuda):
+    """inference.py's default path: one SecureContext with a live dealer, model(image) per image.  The fused Newton
+    launch must not pin its 237 triples (or cache a pointer table) per call: table list and device memory stay flat."""
+    gen = torch.Generator().manual_seed(21)
+    sd = mini_state_dict(gen)
+    blocks = [("layer1.0", 1), ("layer2.0", 2)]
+    ctx = SecureContext(Dealer(cuda, seed=5), 10, 16)
+    model = SecureResNet18(ctx, sd, input_size=16, blocks=blocks)
+    img = torch.randn(1, 3, 16, 16, generator=gen).to(cuda)
+    model(img)
+    torch.cuda.synchronize()
+    base = torch.cuda.memory_allocated()
+    for _ in range(5):
+        out = model(img)
+    torch.cuda.synchronize()
+    del out
+    assert len(ctx._newton_tables) == 0
+    assert torch.cuda.memory_allocated() <= base + (1 << 20)
