@@ -21,4 +21,10 @@ int conv3x3_lh_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H
                         int accumulate, hipStream_t st, float* stat_partials = nullptr, const LhBnArgs* bn = nullptr,
                         const uint8_t* acc_mask = nullptr);
 
+// second generation (conv3x3_lh2.hip): persistent 392- / 196-pixel tiles; no BatchNorm-backward sums
+int conv3x3_lh2_tiles_m(int N, int H, int W, int Cs, int Nd);
+int conv3x3_lh2_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
+                         int accumulate, hipStream_t st, float* stat_partials = nullptr,
+                         const uint8_t* acc_mask = nullptr);
+
 }  // namespace primia

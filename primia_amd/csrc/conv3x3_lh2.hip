@@ -1,0 +1,666 @@
+// 3x3 / stride-1 / pad-1 convolution, forward and data gradient, wide stages (ResNet-18 layer2-4), bf16, gfx950:
+// second generation of the "linear halo" implicit GEMM (conv3x3_lh.hip), rebuilt around what round 2 measured about it —
+// of a 67-84 us launch only 38-40 us was the MFMA phase; the rest was per-tile skeleton (launch, first-halo latency,
+// write-back) that nothing overlapped, a 77 %-full last round of tiles, and load segments longer than the MFMA
+// segments they alternate with.
+//
+//   * PERSISTENT: one 8-wave block per CU walks a contiguous range of tiles; the LDS rings (2 halo buffers, the weight
+//     rings) run straight through tile boundaries, so the next tile's first halo chunk and weights are already
+//     resident when the current tile's last step ends.  Results leave from the accumulator registers (no LDS
+//     staging: the rings never stop), as 16-byte stores after a v_permlane16_swap transpose.
+//   * BALANCED tiles: BM = 392 pixels (two per CU on 28x28, one per CU and channel half on 14x14 at batch 256) or
+//     196 pixels (7x7 images; small problems).  25 (13) pixel fragments of 16 are split 7 / 6 / 6 / 6 (4 / 3 / 3 / 3)
+//     over the four pixel groups; the ping-pong halves (waves 0-3 | 4-7) then carry 13 | 12 (7 | 6) fragments, and on
+//     every SIMD a matrix segment of one half runs beside the load segment of the other.
+//   * the tile is 1.75x the old one at the same weight traffic: 287 flop per L2 -> LDS byte instead of 176 (the
+//     matrix pipe needs 174 at its peak), and 22 fragment reads feed 56 MFMAs per wave and step (was 16 for 32).
+//   * registers: only the first 32-channel half of a step's fragments is read in the load segment; the second half
+//     is read INSIDE the matrix segment, each pixel fragment into the registers its first half has just released
+//     (112 accumulator + 60 fragment registers for 7 fragments instead of 112 + 88).
+//   * matrix segments hold nothing but MFMAs and those reads: every LDS-DMA piece is issued in a LOAD segment (its
+//     issue costs the wave 100-200 cycles, which must run beside the partner's MFMAs, not in front of its own).
+//
+// A block owns BM CONSECUTIVE NHWC pixels x 128 output channels.  Per 64-channel chunk the pixel run plus W + 1
+// pixels either side ("linear halo", <= 450 slots of 128 B) is staged ONCE for all 9 taps: tap (r, s) of output
+// pixel m reads source pixel m + (r-1) W + (s-1), i.e. the same buffer at a tap-uniform slot shift; a tap that leaves
+// the image reads an all-zero slot instead (9-bit validity per pixel fragment and lane, one select per fragment and
+// step).  Staging is buffer-addressed LDS-DMA, so out-of-range pixels and dead slots are zero-filled by the hardware
+// range check; the halo image carries the XOR chunk swizzle (chunk ^ ((slot >> 1) & 7)) on the DMA source side.
+//
+// Weights of a step (tap, chunk) = 128 rows x 64 channels, staged as two half tiles of 128 rows x 64 B (channels
+// 0-31 | 32-63), because the halves live differently: the first is read in the load segments of step t (ring of 2:
+// requested by the A waves in load(t-1)), the second in the matrix segments of step t, which end one segment later
+// (ring of 3: requested by the B waves in load(t-2)).  64-byte rows: four rows span the 64 banks; chunk c of row r
+// sits at c ^ key(r >> 2), key = {0, 2, 3, 1}, which keeps every 16-lane group of a ds_read_b128 conflict-free.
+//
+// Data gradient = the same kernel on (dy, w_dgrad [C][R][S][K]) with the tap direction flipped (FLIP).
+#include <stdlib.h>
+
+#include "conv3x3_lh.h"
+
+namespace primia {
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+struct Lh2Params {
+    const bf16* src;   // [M][Cs]
+    const bf16* wt;    // [Nd][9][Cs]
+    bf16* dst;         // [M][Nd]
+    int H, W, Cs, Nd;
+    int M;             // N*H*W
+    const uint8_t* acc_mask;   // accumulate form: ReLU mask bits applied to the OLD values (one byte per 8 channels)
+    float* stat_partials;      // forward only: BatchNorm partial sums [tiles_m][2][Nd] of the values AS STORED (or null)
+    int ntile_n, ntiles;
+    unsigned magicW, magicH;   // ceil(2^16 / W), ceil(2^16 / H)
+    unsigned long long* prof;  // LH2_PROF builds: [block][wave][4] cycles in load / matrix / barrier-wait / write-back
+};
+
+// compile-time experiment switches (tools/micro/lh2_bench.hip): 1 no write-back (accumulators kept alive), 2 no DMA
+// after the prologue, 4 no MFMA, 8 no fragment reads
+#ifndef LH2_DBG
+#define LH2_DBG 0
+#endif
+#ifndef LH2_PRIO
+#define LH2_PRIO 1
+#endif
+#ifdef LH2_PROF
+#define LH2_MARK(slot)                                 \
+    {                                                  \
+        const unsigned long long t_now = clock64();    \
+        prof_t[slot] += t_now - prof_prev;             \
+        prof_prev = t_now;                             \
+    }
+#else
+#define LH2_MARK(slot)
+#endif
+
+constexpr int kL2Slots = 456;                       // halo slots per buffer (57 DMA pieces of 8 slots)
+constexpr int kL2Pieces = kL2Slots / 8;
+constexpr int kL2Halo = kL2Slots * 128;             // 58,368 B
+constexpr int kL2Half = 128 * 64;                   // 8 KiB: one 32-channel half of a step's weight tile
+constexpr int kL2OffA0 = 2 * kL2Halo;               // ring of 2: first halves
+constexpr int kL2OffA1 = kL2OffA0 + 2 * kL2Half;    // ring of 3: second halves
+constexpr int kL2OffScr = kL2OffA1 + 3 * kL2Half;   // BatchNorm partials of the four pixel groups [4][2][128] fp32
+constexpr int kL2Lds = kL2OffScr + 4 * 2 * 128 * 4; // 161,792 B
+constexpr int kL2ZeroSlot = kL2Slots - 1;           // never live (live slots <= 450): zero-filled with every chunk
+constexpr unsigned kL2Oob = 0xfffffff0u;
+
+__device__ __forceinline__ void l2_dma(unsigned voff, i32x4_t rsrc, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
+}
+
+__device__ __forceinline__ i32x4_t l2_rsrc(const void* base, long bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4_t r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)(unsigned)(a >> 32) & 0xffff;       // stride 0: raw buffer
+    r[2] = (int)(unsigned)(bytes > 0x7ffffff0L ? 0x7ffffff0L : bytes);
+    r[3] = 0x00020000;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_readfirstlane(r[j]);
+    return r;
+}
+
+__device__ __forceinline__ void l2_wait_vmcnt(int n) {   // wave-uniform n
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
+}
+
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane, fixed order
+__device__ __forceinline__ float l2_row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+    return v;
+}
+
+// v_permlane16_swap: lanes 16-31 (48-63) of `a` trade places with lanes 0-15 (32-47) of `b`
+__device__ __forceinline__ void l2_swap16(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+template <int J>
+struct LhJ2 {
+    static constexpr int value = J;
+};
+
+// One wave's whole life.  JW = pixel fragments of this wave, F0 = its first fragment, ISA = first ping-pong half.
+template <int BM, int JW, int F0, bool ISA, bool FLIP, bool ACC>
+__device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile_first, int tile_count) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wh = wave & 3;           // channel half; index inside the ping-pong half
+    const int fr = lane & 15, fg = lane >> 4;
+    const int W = p.W, H = p.H, Cs = p.Cs, Nd = p.Nd;
+    const int nchunks = Cs >> 6;
+    const int klen = 9 * Cs;
+    const int nslots = BM + 2 * W + 2;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    constexpr bool staging = !(LH2_DBG & 2);
+#ifdef LH2_PROF
+    unsigned long long prof_t[5] = {0, 0, 0, 0, 0}, prof_prev = clock64();
+#endif
+
+    const i32x4_t rs_src = l2_rsrc(p.src, (long)p.M * Cs * 2);
+    const i32x4_t rs_wt = l2_rsrc(p.wt, (long)Nd * klen * 2);
+
+    // ---- staging addresses ------------------------------------------------------------------------------
+    // Halo piece q: slots 8q .. 8q+7, this lane: slot 8q + lane/8, LDS chunk lane%8 <- source chunk (lane%8) ^ key(slot).
+    // The pieces of a wave are q = qb + 4k (8k in the prologue): slot = hslot + 8 (q - qb), and the swizzle key
+    // (slot >> 1) & 7 is the same for all of them, so ONE per-lane byte offset serves every piece; the pixel part goes
+    // into the per-lane offset as well (not into soffset: the range check must see it).
+    int hslot = (lane >> 3) + 8 * wh;
+    const auto hvbase = [&]() { return (unsigned)((hslot * Cs + (((lane & 7) ^ ((hslot >> 1) & 7)) << 3)) * 2); };
+    auto halo_piece = [&](int q, int dq, int hm0, int c, int buf) {   // q = qb + dq (dq a multiple of 4)
+        unsigned voff = hvbase() + (unsigned)((hm0 + 8 * dq) * Cs * 2);
+        if (hslot + 8 * dq >= nslots) voff = kL2Oob;
+        l2_dma(voff, rs_src, __builtin_amdgcn_readfirstlane((unsigned)(c * 128)),
+               __builtin_amdgcn_readfirstlane(lds0 + buf * kL2Halo + q * 1024));
+    };
+    // Weight half-tile piece pc (0..7): rows 16pc .. 16pc+15, this lane: row 16pc + lane/4, LDS chunk lane%4 <- source
+    // chunk (lane%4) ^ key(row >> 2); (row >> 2) & 3 = lane >> 4 for every piece.
+    const unsigned wvoff = (unsigned)(((lane >> 2) * klen + (((lane & 3) ^ ((0x78 >> (2 * (lane >> 4))) & 3)) << 3)) * 2);
+    auto wt_piece = [&](int pc, int n0_, int tap, int c, int half, unsigned lds_base) {
+        const unsigned soff = (unsigned)((((long)(n0_ + 16 * pc)) * klen + tap * Cs + c * 64 + half * 32) * 2);
+        l2_dma(wvoff, rs_wt, __builtin_amdgcn_readfirstlane(soff), __builtin_amdgcn_readfirstlane(lds0 + lds_base + pc * 1024));
+    };
+
+    // ---- fragment read addresses ---------------------------------------------------------------------------
+    // weights: row wn*64 + 16i + fr of a half tile, 16-byte chunk fg; + i * 1024
+    const int aoff = (wn * 64 + fr) * 64 + ((fg ^ ((0x78 >> (2 * (fr >> 2))) & 3)) << 4);
+    // pixels: fragment j covers tile pixels 16 (F0 + j) + fr, halo slot at shift 0 = that + W + 1; + j * 2048
+    int sj0 = 16 * F0 + fr + W + 1;
+
+    f32x4 acc[4][JW];
+    bf16x8_t a0[4], a1[4], b[JW];      // 32-channel half 0 of the step; half 1 is read INSIDE the matrix segment, the
+    int bad[JW];                       // pixel fragments into the registers half 0 has just released
+    unsigned pmask[3] = {0u, 0u, 0u};  // bit 9 (j % 3) + t of word j / 3: tap t of fragment j stays inside the image
+
+    int m0 = 0, n0 = 0, tm = 0;
+    auto tile_coords = [&](int tile, int& tm_, int& m0_, int& n0_) {
+        tm_ = tile / p.ntile_n;
+        n0_ = (tile - tm_ * p.ntile_n) * 128;
+        m0_ = tm_ * BM;
+    };
+    // per-tile lane constants: 9-bit tap validity of every pixel fragment (forward tap numbering; FLIP mirrors it)
+    auto tile_setup = [&]() {
+        const int w0 = m0 % W, h0 = (m0 / W) % H;          // wave-uniform
+        unsigned pm[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            const int pl = 16 * (F0 + j) + fr;
+            const unsigned t = (unsigned)(w0 + pl);
+            const unsigned q = (t * p.magicW) >> 16;
+            const int w = (int)(t - q * W);
+            const unsigned hr = (unsigned)h0 + q;
+            const int h = (int)(hr - ((hr * p.magicH) >> 16) * H);
+            unsigned mask = 0;
+            if (pl < BM && m0 + pl < p.M) {
+                const unsigned cm = (w > 0 ? 1u : 0u) | 2u | (w < W - 1 ? 4u : 0u);
+                mask = (h > 0 ? cm : 0u) | (cm << 3) | (h < H - 1 ? cm << 6 : 0u);
+            }
+            if (FLIP) {   // tap t of the flipped direction = tap 8 - t of the forward one
+                unsigned rv = 0;
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) rv |= ((mask >> t9) & 1u) << (8 - t9);
+                mask = rv;
+            }
+            pm[j / 3] |= mask << (9 * (j % 3));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        pmask[0] = pm[0]; pmask[1] = pm[1]; pmask[2] = pm[2];
+    };
+
+    // ---- write-back from the accumulator registers -----------------------------------------------------------
+    // A lane (fr, fg) holds channels 16i + 4fg .. +3 (i = 0..3) of pixel 16 (F0 + j) + fr.  Per pair of fragments
+    // (i = 2b, 2b+1) a v_permlane16_swap between the lane rows fg = 2a and 2a+1 leaves an even row with channels
+    // 16 (2b) + 8a .. +7 and an odd row with channels 16 (2b+1) + 8a .. +7: 16 contiguous bytes per lane, the four
+    // rows of a pixel together 64 contiguous bytes per store instruction.
+    auto epilogue = [&]() {
+        if (LH2_DBG & 1) {
+#pragma unroll
+            for (int j = 0; j < JW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i][j]));
+            return;
+        }
+        float s1[4][4], s2[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
+        unsigned row0 = (unsigned)(m0 + 16 * F0 + fr);
+        // this lane's 16-byte piece after the swap: fragment 2b + (fg & 1), channels 8 (fg >> 1) .. +7 of it
+        const unsigned col0 = (unsigned)(n0 + wn * 64 + 16 * (fg & 1) + 8 * (fg >> 1));
+        // (m0 / n0 are known when the tile starts: without this the store addresses are computed there and stay in
+        // registers through the whole main loop)
+        asm volatile("" : "+v"(row0));
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            const int pl = 16 * (F0 + j) + fr;
+            const bool ok = pl < BM && m0 + pl < p.M;
+            u32x4 oldv[2];
+            unsigned mkb[2];
+            if constexpr (ACC) {
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) {
+                    const unsigned eo = (row0 + 16 * j) * (unsigned)Nd + col0 + 32 * bq;
+                    oldv[bq] = u32x4{0u, 0u, 0u, 0u};
+                    mkb[bq] = 0xffu;
+                    if (ok) {
+                        oldv[bq] = *(const u32x4*)((const char*)p.dst + (size_t)(eo * 2u));
+                        if (p.acc_mask) mkb[bq] = p.acc_mask[eo >> 3];
+                    }
+                }
+            }
+            u32x2 o[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                o[i][0] = (uint32_t)f32_to_bf16(acc[i][j][0]) | ((uint32_t)f32_to_bf16(acc[i][j][1]) << 16);
+                o[i][1] = (uint32_t)f32_to_bf16(acc[i][j][2]) | ((uint32_t)f32_to_bf16(acc[i][j][3]) << 16);
+            }
+            if constexpr (ACC) {
+                // bring the old values into the accumulators' lane layout (the inverse swap), add in fp32, round once
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) {
+                    u32x4 ov = oldv[bq];
+                    const unsigned mk = mkb[bq];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        ov[e] &= ((mk >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((mk >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+                    uint32_t x0 = ov[0], x1 = ov[1], y0 = ov[2], y1 = ov[3];   // (x | y) = quarters (2a | 2a+1) of a fragment
+                    l2_swap16(x0, y0);
+                    l2_swap16(x1, y1);
+                    // now x = fragment 2bq, y = fragment 2bq+1, both this lane's own quarter fg
+                    const uint32_t ox[2][2] = {{x0, x1}, {y0, y1}};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        const int i = 2 * bq + s;
+                        f32x4 v = acc[i][j];
+                        v[0] += __uint_as_float(ox[s][0] << 16);
+                        v[1] += __uint_as_float(ox[s][0] & 0xffff0000u);
+                        v[2] += __uint_as_float(ox[s][1] << 16);
+                        v[3] += __uint_as_float(ox[s][1] & 0xffff0000u);
+                        o[i][0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        o[i][1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    }
+                }
+            }
+            if (!ACC && p.stat_partials && ok) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float r0 = __uint_as_float(o[i][0] << 16), r1 = __uint_as_float(o[i][0] & 0xffff0000u);
+                    const float r2 = __uint_as_float(o[i][1] << 16), r3 = __uint_as_float(o[i][1] & 0xffff0000u);
+                    s1[i][0] += r0; s2[i][0] += r0 * r0;
+                    s1[i][1] += r1; s2[i][1] += r1 * r1;
+                    s1[i][2] += r2; s2[i][2] += r2 * r2;
+                    s1[i][3] += r3; s2[i][3] += r3 * r3;
+                }
+            }
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) {
+                uint32_t x0 = o[2 * bq][0], x1 = o[2 * bq][1], y0 = o[2 * bq + 1][0], y1 = o[2 * bq + 1][1];
+                l2_swap16(x0, y0);
+                l2_swap16(x1, y1);
+                const unsigned eo = (row0 + 16 * j) * (unsigned)Nd + col0 + 32 * bq;
+                if (ok) *(u32x4*)((char*)p.dst + (size_t)(eo * 2u)) = u32x4{x0, x1, y0, y1};
+            }
+        }
+        if (!ACC && p.stat_partials) {
+            // fold the 16 pixels of a row (same fg), then one lane per fg parks the pixel group's partial in LDS; the B
+            // half adds the four groups in a fixed order after the next barrier (stat_combine)
+            float* scr = (float*)(smem + kL2OffScr) + (wave >> 1) * 256;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t1 = l2_row_sum(s1[i][e]), t2 = l2_row_sum(s2[i][e]);
+                    if (fr == 0) {
+                        const int ch = wn * 64 + 16 * i + 4 * fg + e;
+                        scr[ch] = t1;
+                        scr[128 + ch] = t2;
+                    }
+                }
+        }
+    };
+    // B half, one segment after both halves' write-back: thread -> (q, channel); groups added in the order 0,1,2,3
+    auto stat_combine = [&](int tm_, int n0_) {
+        if (ACC || !p.stat_partials || ISA) return;
+        const int t = tid - 256;
+        const int q = t >> 7, ch = t & 127;
+        const float* scr = (const float*)(smem + kL2OffScr);
+        float s = scr[q * 128 + ch];
+#pragma unroll
+        for (int g = 1; g < 4; ++g) s += scr[g * 256 + q * 128 + ch];
+        p.stat_partials[((long)tm_ * 2 + q) * Nd + n0_ + ch] = s;
+    };
+
+    // ---- the two kinds of segment ---------------------------------------------------------------------------
+    int par = 0;        // first-half ring slot of the step being loaded (t & 1)
+    int tri = 0;        // second-half ring slot of the step being loaded (t % 3)
+    int tri_m = 0;      // ... of the step whose matrix segment runs next
+    int hbuf = 0;       // halo buffer of the chunk being loaded
+    auto load_segment = [&](auto tap_tag) {
+        constexpr int tap = decltype(tap_tag)::value;
+        if (!(LH2_DBG & 8)) {
+            const char* w0p = smem + kL2OffA0 + par * kL2Half;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a0[i] = *(const bf16x8_t*)(w0p + (aoff + i * 1024));
+            constexpr int tr = tap / 3, ts = tap - 3 * tr;
+            const int slot = sj0 + (FLIP ? (1 - tr) * W + (1 - ts) : (tr - 1) * W + (ts - 1));
+            const int offt = slot * 128 + ((fg ^ ((slot >> 1) & 7)) << 4) + hbuf * kL2Halo;
+            const int zoff = kL2ZeroSlot * 128 + hbuf * kL2Halo;
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                // an invalid tap reads the zero slot (minus the fragment's immediate offset)
+                bad[j] = ((pmask[j / 3] >> (9 * (j % 3) + tap)) & 1u) ? offt : zoff - j * 2048;
+                b[j] = *(const bf16x8_t*)(smem + (bad[j] + j * 2048));
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        par ^= 1;
+        tri_m = tri;
+        tri = tri == 2 ? 0 : tri + 1;
+    };
+    auto mfma_segment = [&]() {
+#if LH2_PRIO
+        __builtin_amdgcn_s_setprio(LH2_PRIO);   // the partner's load segment must not take issue slots from the MFMAs
+#endif
+        if (!(LH2_DBG & 8)) {
+            const char* w1p = smem + kL2OffA1 + tri_m * kL2Half;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a1[i] = *(const bf16x8_t*)(w1p + (aoff + i * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            if (!(LH2_DBG & 4)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(LH2_DBG & 8))
+                b[j] = *(const bf16x8_t*)(smem + ((bad[j] ^ 64) + j * 2048));  // half 1 of this fragment, same registers
+        }
+        if (!(LH2_DBG & 4)) {
+#pragma unroll
+            for (int j = 0; j < JW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#if LH2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+
+    // ---- prologue: first tile's chunk 0 (all waves), first half of step 0 (A), second halves of steps 0 and 1 (B) ----
+    tile_coords(tile_first, tm, m0, n0);
+    {
+        hslot = (lane >> 3) + 8 * wave;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = wave + 8 * k;
+            if (q < kL2Pieces) halo_piece(q, 8 * k, m0 - (W + 1), 0, 0);
+        }
+        hslot = (lane >> 3) + 8 * wh;
+        // second halves: pieces 0..3 belong to the A waves (requested one step ahead), 4..7 to the B waves (two ahead)
+        if (ISA) {
+            wt_piece(wh, n0, 0, 0, 0, kL2OffA0);
+            wt_piece(wh + 4, n0, 0, 0, 0, kL2OffA0);
+            wt_piece(wh, n0, 0, 0, 1, kL2OffA1);
+        } else {
+            wt_piece(wh + 4, n0, 0, 0, 1, kL2OffA1);
+            // step 1: tap 1 of chunk 0 (a tile has at least 9 steps)
+            wt_piece(wh + 4, n0, 1, 0, 1, kL2OffA1 + kL2Half);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // Segment numbering: segment 2t = { A: load(t) | B: mfma(t-1) }, segment 2t+1 = { A: mfma(t) | B: load(t) }, a barrier
+    // after each.  Requests (all in LOAD segments, drained by the same wave at the end of its NEXT matrix segment):
+    //   A, load(t): first half of step t+1 -> slot (t+1) & 1, last read by B's load(t-1) one segment earlier;
+    //   B, load(t): second half of step t+2 -> slot (t+2) % 3, last read by B's mfma(t-1) one segment earlier; needed
+    //               by A's mfma(t+2), four segments later;
+    //   B, load(t), taps 0..6 of chunk g: the halo pieces of chunk g+1 -> buffer (g+1) & 1, last read in chunk g-1.
+    int prev_tm = 0, prev_n0 = 0;
+    int issued = 0;                   // B: DMA pieces requested in the latest load segment
+    bool pending_combine = false;
+    for (int it = 0; it < tile_count; ++it) {
+        const bool more_tiles = it + 1 < tile_count;
+        int ntm = 0, nm0 = 0, nn0 = 0;
+        if (more_tiles) tile_coords(tile_first + it + 1, ntm, nm0, nn0);
+        if (ISA) tile_setup();
+        for (int c = 0; c < nchunks; ++c) {
+            // (the selects of the load segments are invariant over the chunks of a tile: left alone, the compiler hoists
+            // all 9 x JW of them out of this loop and keeps them in registers)
+            asm volatile("" : "+v"(pmask[0]), "+v"(pmask[1]), "+v"(pmask[2]), "+v"(sj0), "+v"(hslot));
+            const bool last_chunk = c + 1 == nchunks;
+            // the chunk after this one (same tile, or the next tile's first)
+            const bool has_next = !last_chunk || more_tiles;
+            const int nx_hm0 = (last_chunk ? nm0 : m0) - (W + 1), nx_c = last_chunk ? 0 : c + 1;
+            const int nx_n0 = last_chunk ? nn0 : n0;
+            auto step = [&](auto tap_tag) {
+                constexpr int tap = decltype(tap_tag)::value;
+                if constexpr (ISA) {
+                    if (staging) {      // first half of step t+1, and this half's share of its second half
+                        const int t1 = tri == 2 ? 0 : tri + 1;       // (t + 1) % 3
+                        if (tap < 8) {
+                            wt_piece(wh, n0, tap + 1, c, 0, kL2OffA0 + (par ^ 1) * kL2Half);
+                            wt_piece(wh + 4, n0, tap + 1, c, 0, kL2OffA0 + (par ^ 1) * kL2Half);
+                            wt_piece(wh, n0, tap + 1, c, 1, kL2OffA1 + t1 * kL2Half);
+                        } else if (has_next) {
+                            wt_piece(wh, nx_n0, 0, nx_c, 0, kL2OffA0 + (par ^ 1) * kL2Half);
+                            wt_piece(wh + 4, nx_n0, 0, nx_c, 0, kL2OffA0 + (par ^ 1) * kL2Half);
+                            wt_piece(wh, nx_n0, 0, nx_c, 1, kL2OffA1 + t1 * kL2Half);
+                        }
+                    }
+                    load_segment(tap_tag);
+                    LH2_MARK(0)
+                    __builtin_amdgcn_s_barrier();
+                    LH2_MARK(2)
+                    mfma_segment();
+                    LH2_MARK(1)
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    LH2_MARK(4)
+                    __builtin_amdgcn_s_barrier();
+                    LH2_MARK(2)
+                } else {
+                    // mfma of the previous step (tap - 1 of this chunk, or the last step of the previous chunk / tile)
+                    const bool first_step = it == 0 && c == 0 && tap == 0;
+                    if (!first_step) {
+                        mfma_segment();
+                        LH2_MARK(1)
+                        l2_wait_vmcnt(issued);       // everything but the pieces of the latest load segment has landed
+                        LH2_MARK(4)
+                    }
+                    if (tap == 0 && c == 0) {          // the previous step closed a tile (or nothing has run yet)
+                        if (!first_step) {
+                            const int km0 = m0, kn0 = n0;
+                            m0 = prev_tm * BM; n0 = prev_n0;       // write-back addresses of the tile just finished
+                            epilogue();
+                            m0 = km0; n0 = kn0;
+                            pending_combine = true;
+                        }
+                        tile_setup();
+                        LH2_MARK(3)
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    LH2_MARK(2)
+                    issued = 0;
+                    if (staging) {
+                        // this half's share of the second half of step t+2
+                        const int t2 = tri == 0 ? 2 : tri - 1;       // (t + 2) % 3
+                        if (tap < 7) {
+                            wt_piece(wh + 4, n0, tap + 2, c, 1, kL2OffA1 + t2 * kL2Half);
+                            ++issued;
+                        } else if (has_next) {
+                            wt_piece(wh + 4, nx_n0, tap - 7, nx_c, 1, kL2OffA1 + t2 * kL2Half);
+                            ++issued;
+                        }
+                        // halo pieces of the next chunk: 3, 2, 2, 2, 2, 2, 2 over the taps 0..6
+                        if (tap <= 6 && has_next) {
+                            constexpr int k0 = tap == 0 ? 0 : 2 * tap + 1, k1 = 2 * tap + 3;
+#pragma unroll
+                            for (int k = k0; k < k1; ++k) {
+                                const int q = wh + 4 * k;
+                                if (q < kL2Pieces) {
+                                    halo_piece(q, 4 * k, nx_hm0, nx_c, hbuf ^ 1);
+                                    ++issued;
+                                }
+                            }
+                        }
+                    }
+                    load_segment(tap_tag);
+                    if (tap == 0 && c == 0 && pending_combine) {
+                        stat_combine(prev_tm, prev_n0);
+                        pending_combine = false;
+                    }
+                    LH2_MARK(0)
+                    __builtin_amdgcn_s_barrier();
+                    LH2_MARK(2)
+                }
+            };
+            step(LhJ2<0>{}); step(LhJ2<1>{}); step(LhJ2<2>{}); step(LhJ2<3>{}); step(LhJ2<4>{});
+            step(LhJ2<5>{}); step(LhJ2<6>{}); step(LhJ2<7>{}); step(LhJ2<8>{});
+            hbuf ^= 1;
+        }
+        // tile boundary
+        if (ISA) {
+            epilogue();            // beside B's last matrix segment of this tile
+            LH2_MARK(3)
+        }
+        prev_tm = tm; prev_n0 = n0;
+        if (more_tiles) { tm = ntm; m0 = nm0; n0 = nn0; }
+    }
+    // drain: B's last matrix segment and write-back, then the statistics of the last tile
+    if (!ISA) {
+        mfma_segment();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        LH2_MARK(1)
+        const int km0 = m0, kn0 = n0;
+        m0 = prev_tm * BM; n0 = prev_n0;
+        epilogue();
+        m0 = km0; n0 = kn0;
+        LH2_MARK(3)
+    }
+    if (!ACC && p.stat_partials) {
+        __syncthreads();
+        stat_combine(prev_tm, prev_n0);
+    }
+#ifdef LH2_PROF
+    if (p.prof && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p.prof[((long)blockIdx.x * 8 + wave) * 5 + k] = prof_t[k];
+    }
+#endif
+}
+
+// BM = 392: fragments 7 | 6 | 6 | 6; BM = 196: 4 | 3 | 3 | 3
+template <int BM, bool FLIP, bool ACC>
+__global__ __launch_bounds__(512) void conv3x3_lh2_kernel(Lh2Params p) {
+    constexpr int J0 = BM == 392 ? 7 : 4, J = BM == 392 ? 6 : 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // contiguous tile range of this block, XCD-aware: blocks b, b+8, ... share an XCD and get neighbouring ranges
+    const int nb = gridDim.x;
+    const int lb = xcd_remap(blockIdx.x, nb);
+    const int first = (int)(((long)lb * p.ntiles) / nb), last = (int)(((long)(lb + 1) * p.ntiles) / nb);
+    const int count = last - first;
+    if (count <= 0) return;
+    const int wm = wave >> 1;
+    if (wm == 0) lh2_run<BM, J0, 0, true, FLIP, ACC>(p, smem, first, count);
+    else if (wm == 1) lh2_run<BM, J, J0, true, FLIP, ACC>(p, smem, first, count);
+    else if (wm == 2) lh2_run<BM, J, J0 + J, false, FLIP, ACC>(p, smem, first, count);
+    else lh2_run<BM, J, J0 + 2 * J, false, FLIP, ACC>(p, smem, first, count);
+}
+
+#ifdef LH2_PROF
+unsigned long long* lh2_prof_buffer = nullptr;
+#endif
+
+static int lh2_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// tile height in pixels for a shape (0: not served).  392 when that gives every CU at least one tile, else 196.
+static int lh2_bm(int N, int H, int W, int Cs, int Nd) {
+    static const int off = getenv("PRIMIA_LH2") ? (getenv("PRIMIA_LH2")[0] == '0') : 0;
+    static const int force = getenv("PRIMIA_LH2_BM") ? atoi(getenv("PRIMIA_LH2_BM")) : 0;
+    if (off || W > 28 || W < 2 || H < 2 || Cs % 64 || Nd % 128) return 0;
+    const long M = (long)N * H * W;
+    if (M * (Cs > Nd ? Cs : Nd) >= (1L << 30)) return 0;     // byte offsets stay below 2^31
+    if (force == 392 || force == 196) return force;
+    const long t392 = (M + 391) / 392 * (Nd / 128);
+    return t392 >= lh2_num_cus() ? 392 : 196;
+}
+
+int conv3x3_lh2_tiles_m(int N, int H, int W, int Cs, int Nd) {
+    const int bm = lh2_bm(N, H, W, Cs, Nd);
+    if (!bm) return PRIMIA_ERR_UNSUPPORTED;
+    return (int)(((long)N * H * W + bm - 1) / bm);
+}
+
+int conv3x3_lh2_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
+                         int accumulate, hipStream_t st, float* stat_partials, const uint8_t* acc_mask) {
+    const int bm = lh2_bm(N, H, W, Cs, Nd);
+    if (!bm) return PRIMIA_ERR_UNSUPPORTED;
+    if (stat_partials && (flip || accumulate)) return PRIMIA_ERR_ARG;
+    if (accumulate && !flip) return PRIMIA_ERR_UNSUPPORTED;
+    const long M = (long)N * H * W;
+    Lh2Params p;
+    p.src = src; p.wt = wt; p.dst = dst;
+    p.H = H; p.W = W; p.Cs = Cs; p.Nd = Nd; p.M = (int)M;
+    p.acc_mask = accumulate ? acc_mask : nullptr;
+    p.stat_partials = stat_partials;
+    p.ntile_n = Nd / 128;
+    p.ntiles = (int)((M + bm - 1) / bm) * p.ntile_n;
+    p.magicW = (65536u + W - 1) / W;
+    p.magicH = (65536u + H - 1) / H;
+#ifdef LH2_PROF
+    p.prof = lh2_prof_buffer;
+#else
+    p.prof = nullptr;
+#endif
+    const int ncu = lh2_num_cus();
+    const int grid = p.ntiles < ncu ? p.ntiles : ncu;
+    void (*kern)(Lh2Params);
+    int slot;
+    if (bm == 392) {
+        kern = !flip ? conv3x3_lh2_kernel<392, false, false> : (accumulate ? conv3x3_lh2_kernel<392, true, true> : conv3x3_lh2_kernel<392, true, false>);
+        slot = !flip ? 0 : (accumulate ? 2 : 1);
+    } else {
+        kern = !flip ? conv3x3_lh2_kernel<196, false, false> : (accumulate ? conv3x3_lh2_kernel<196, true, true> : conv3x3_lh2_kernel<196, true, false>);
+        slot = 3 + (!flip ? 0 : (accumulate ? 2 : 1));
+    }
+    static bool attr_set[6] = {false, false, false, false, false, false};
+    if (!attr_set[slot]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kL2Lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set[slot] = true;
+    }
+    kern<<<grid, 512, kL2Lds, st>>>(p);
+    return launch_status();
+}
+
+}  // namespace primia

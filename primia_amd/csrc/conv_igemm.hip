@@ -707,6 +707,9 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
                                                 stat_sums);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         } else if (lh_shape(g) && g.W <= lh_fwd_maxw()) {   // (statistics: per-block partials as well)
+            const int rc2 = conv3x3_lh2_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, g.C, g.K, 0,
+                                                 0, st, stat_sums);
+            if (rc2 != PRIMIA_ERR_UNSUPPORTED) return rc2;
             const int rc = conv3x3_lh_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, g.C, g.K, 0, 0,
                                                st, stat_sums);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
@@ -729,6 +732,8 @@ int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype) {
     if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
     if (dtype == PRIMIA_BF16 && use_c64(g) && (long)g.N * g.H * g.W * 64 < (1L << 31)) return conv3x3_c64_grid(g.N, g.H, g.W);
     if (dtype == PRIMIA_BF16 && !use_c64(g) && lh_shape(g) && g.W <= lh_fwd_maxw()) {
+        const int t2 = conv3x3_lh2_tiles_m(g.N, g.H, g.W, g.C, g.K);
+        if (t2 > 0) return t2;
         const int t = conv3x3_lh_tiles_m(g.N, g.H, g.W, g.C, g.K);
         if (t > 0) return t;
     }
@@ -775,6 +780,11 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
                                                 accumulate, st, nullptr, acc_mask);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         } else if (lh_shape(g) && !p.src2) {
+            if (!bn) {   // (the BatchNorm-backward sums are emitted by the first-generation kernel only)
+                const int rc2 = conv3x3_lh2_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K,
+                                                     g.C, 1, accumulate, st, nullptr, acc_mask);
+                if (rc2 != PRIMIA_ERR_UNSUPPORTED) return rc2;
+            }
             const int rc = conv3x3_lh_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C, 1,
                                                accumulate, st, nullptr, bn, acc_mask);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;

@@ -634,7 +634,7 @@ def test_wide_conv_emits_batchnorm_partials(cuda, N, H, C, K):
     wf, _ = prep_weights(desc, w, dtype, cuda, C)
     slots = query("primia_conv_stat_slots_for", desc, dt)
     M = N * H * H
-    assert slots == (M + 223) // 224      # 224-pixel tiles (conv3x3_lh.hip)
+    assert slots == (M + 195) // 196      # 196-pixel tiles (conv3x3_lh2.hip; 392 when every CU gets a tile)
     y = torch.empty(M, K, dtype=dtype, device=cuda)
     sums = torch.full((slots, 2, K), float("nan"), device=cuda)   # written, not accumulated
     call("primia_conv2d_fwd_stats", desc, x, wf, y, sums, dt)
@@ -646,6 +646,57 @@ def test_wide_conv_emits_batchnorm_partials(cuda, N, H, C, K):
     sums2 = torch.full_like(sums, float("nan"))
     call("primia_conv2d_fwd_stats", desc, x, wf, y2, sums2, dt)
     assert torch.equal(sums, sums2)
+
+
+@pytest.mark.parametrize("N,H,C,K,bm", [(160, 28, 128, 128, 392), (100, 28, 128, 128, 196), (300, 14, 128, 256, 392),
+                                        (37, 7, 256, 384, 196)])
+def test_wide_conv_persistent_tiles(cuda, N, H, C, K, bm):
+    """conv3x3_lh2.hip with MORE tiles than CUs (a block walks several tiles, rings running through the tile
+    boundaries, uneven tile counts per block): forward + per-tile BatchNorm partials, data gradient, masked
+    accumulating data gradient — against torch-CPU autograd on bf16-rounded operands."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(N + H)
+    x = rnd(torch.randn(N, C, H, H, generator=g), dtype)
+    w = rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype)
+    desc = ConvDesc.make(N, H, H, C, K, 3, 3, 1, 1)
+    wf, wd = prep_weights(desc, w, dtype, cuda, C)
+    M = N * H * H
+    slots = query("primia_conv_stat_slots_for", desc, dt)
+    assert slots == (M + bm - 1) // bm
+    xr = x.clone().requires_grad_(True)
+    y_ref = F.conv2d(xr, w, None, 1, 1)
+    dy = rnd(torch.randn(y_ref.shape, generator=g), dtype)
+    y_ref.backward(dy)
+    xd = to_nhwc(x, dtype, cuda)
+    y = torch.empty(M, K, dtype=dtype, device=cuda)
+    sums = torch.full((slots, 2, K), float("nan"), device=cuda)
+    call("primia_conv2d_fwd_stats", desc, xd, wf, y, sums, dt)
+    assert relerr(from_nhwc(y, N, H, H), y_ref.detach()) < tol(dtype)
+    yf = y.float()
+    assert relerr(sums[:, 0].sum(0), yf.sum(0)) < 1e-5 and relerr(sums[:, 1].sum(0), (yf * yf).sum(0)) < 1e-5
+    # every tile's partial on its own
+    pad = slots * bm - M
+    yt = torch.cat([yf, yf.new_zeros(pad, K)]).view(slots, bm, K)
+    assert relerr(sums[:, 0], yt.sum(1)) < 1e-5 and relerr(sums[:, 1], (yt * yt).sum(1)) < 1e-5
+    y2 = torch.empty_like(y)
+    call("primia_conv2d_fwd", desc, xd, wf, y2, dt)
+    assert torch.equal(y, y2)
+    dyd = to_nhwc(dy, dtype, cuda)
+    dx = torch.empty(M, C, dtype=dtype, device=cuda)
+    call("primia_conv2d_dgrad", desc, dyd, wd, dx, 0, dt)
+    assert relerr(from_nhwc(dx, N, H, H), xr.grad) < tol(dtype)
+    base = rnd(torch.randn(N, C, H, H, generator=g), dtype)
+    keep = torch.rand(N, C, H, H, generator=g) > 0.4
+    based = to_nhwc(base, dtype, cuda)
+    bits = to_nhwc(keep.float(), torch.float32, cuda).to(torch.uint8).view(M * C // 8, 8)
+    mask = (bits << torch.arange(8, device=cuda, dtype=torch.uint8)).sum(1).to(torch.uint8)
+    dx2 = based.clone()
+    call("primia_conv2d_dgrad_masked_acc", desc, dyd, wd, dx2, mask, dt)
+    assert relerr(from_nhwc(dx2, N, H, H), xr.grad + base * keep) < tol(dtype)
+    dx3 = based.clone()
+    call("primia_conv2d_dgrad", desc, dyd, wd, dx3, 1, dt)
+    assert relerr(from_nhwc(dx3, N, H, H), xr.grad + base) < tol(dtype)
 
 
 def test_stem_conv_emits_batchnorm_partials_and_fused_tail_from_sums(cuda):
