@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md
 GFLOP_PER_IMAGE = 10.881                            # SURVEY.md §8d (fwd 3.627 + bwd 7.254)
-TRAFFIC_FILE = "r02_hbm_traffic.json"               # rocprofv3 PMC passes over this command, see tools/hbm_traffic.py
+TRAFFIC_FILE = "r03_hbm_traffic.json"               # rocprofv3 PMC passes over this command, see tools/hbm_traffic.py
 
 
 def parse():
@@ -74,10 +74,11 @@ def host_cpu():
     return model, (len(phys) or logical), logical
 
 
-def cpu_baseline(batch, size, budget_s=25.0):
+def cpu_baseline(batch, size, budget_s=30.0):
     """the oracle train step (torch-CPU fp32 — what a PySyft VirtualWorker executes natively) at the
-    benchmark's own batch size on ALL physical cores of this host.  torch-CPU stops scaling long before a big node's
-    core count on this workload, so a second, 32-thread sample is reported beside it (`threads_32`)."""
+    benchmark's own batch size.  torch-CPU stops scaling long before a big node's core count on this workload, so the
+    thread count is chosen first (one step each at a quarter batch on 32 / 64 / all physical cores) and `value` is the
+    BEST count's rate over >= 5 full-batch steps; the probe's rates are reported beside it."""
     from oracle import train_oracle as O
     from primia_amd import resnet_spec as rs
 
@@ -87,27 +88,28 @@ def cpu_baseline(batch, size, budget_s=25.0):
     x = torch.randn(batch, 3, size, size)
     y = torch.randint(0, 3, (batch,))
 
-    def sample(threads, budget):
+    def sample(threads, nb, min_steps, budget):
         torch.set_num_threads(threads)
         sd = {k: v.clone() for k, v in sd0.items()}
-        O.train_step(sd, x, y, 1e-4, 5e-4)  # warm-up
+        O.train_step(sd, x[:nb], y[:nb], 1e-4, 5e-4)  # warm-up
         n, t0 = 0, time.perf_counter()
         while True:
-            O.train_step(sd, x, y, 1e-4, 5e-4)
+            O.train_step(sd, x[:nb], y[:nb], 1e-4, 5e-4)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget or n >= 10:
+            if n >= min_steps and (el > budget or n >= 10):
                 break
-        return round(batch * n / el, 2), n
+        return round(nb * n / el, 2), n
 
-    v_all, n_all = sample(phys, budget_s * 0.6)
-    out = {"value": v_all, "unit": "images/s", "cores": phys, "kind": "port", "cpu_model": model, "logical_cpus": logical,
-           "sample": f"{n_all} fp32 train steps of batch {batch} at {size}x{size} on {phys} threads = all physical cores "
-                     "(oracle/train_oracle.py, torch-CPU; BASELINE.md B1)"}
-    if phys > 32:
-        v32, n32 = sample(32, budget_s * 0.4)
-        out["threads_32"] = {"value": v32, "steps": n32}
-    return out
+    counts = sorted({c for c in (32, 64, phys) if c <= phys} or {phys})
+    probe = {c: sample(c, max(8, batch // 4), 1, 0.0)[0] for c in counts}
+    best = max(probe, key=probe.get)
+    v, n = sample(best, batch, 5, budget_s)
+    return {"value": v, "unit": "images/s", "cores": best, "kind": "port", "cpu_model": model, "physical_cores": phys,
+            "logical_cpus": logical,
+            "sample": f"{n} fp32 train steps of batch {batch} at {size}x{size} on {best} threads, the best of "
+                      f"{counts} (oracle/train_oracle.py, torch-CPU; BASELINE.md B1)",
+            "thread_probe": {str(c): r for c, r in probe.items()}}
 
 
 def main():
@@ -156,16 +158,24 @@ def main():
         eng.loss_backward(ys[i % nbuf])
         eng.sgd_step(lr, wd)
 
-    def exchange(i):
+    sync_events = []        # (start, end) HIP events around every timed exchange
+
+    def exchange(i, timed=False):
         """FedAvg over RCCL every `sync_every` batches (torchlib/utils.py:1175: batch_idx > 0 and batch_idx % s == 0)."""
         if world > 1 and i > 0 and i % a.sync_every == 0:
+            if timed:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             fed.fedavg_allreduce(eng.flat, local_flat, None, a.secure_aggregation, 16, 10, None, None, scratch, masks)
             eng.flat.copy_(local_flat)
             eng.refresh_weights()
+            if timed:
+                e1.record()
+                sync_events.append((e0, e1))
 
-    def step(i):
+    def step(i, timed=False):
         local_step(i)
-        exchange(i)
+        exchange(i, timed)
 
     def barrier():
         if world > 1:
@@ -202,10 +212,10 @@ def main():
                 graphs = None
 
     if graphs is not None:
-        def run(i):
+        def run(i, timed=False):
             graphs[i % nbuf].replay()
             eng.note_replayed_steps(1)
-            exchange(i)
+            exchange(i, timed)
     else:
         run = step
 
@@ -214,13 +224,17 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        run(i)
+        run(i, True)
     barrier()
     dt = time.perf_counter() - t0
+    fedavg_ms = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        # the exchange on its own (all-reduce of the 44.75 MB arena + copy back + weight refresh, stream time on this
+        # rank; the slowest rank counts) — so that a scaling run shows what the collective costs per sync
+        mine = sum(e0.elapsed_time(e1) for e0, e1 in sync_events) / max(1, len(sync_events))
+        t = torch.tensor([dt, mine], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
+        dt, fedavg_ms = t[0].item(), round(t[1].item(), 3)
     loss = eng.loss.item()
     # A second figure over >= 5 s of back-to-back steps: the 100-step region above lasts ~0.6 s, short enough for the
     # chip to ride its boost clock; this one shows what it sustains (same run() calls, own barriers).
@@ -250,20 +264,27 @@ def main():
     # Launches are grouped by the kernel that serves them (the library's dispatch rules: conv_igemm.hip,
     # conv_wgrad.hip) so that every group's average duration can be checked against the rocprofv3
     # per-kernel averages under profiles/.
+    # The library itself says which kernel its dispatch rules pick for a layer (primia_conv_kernel_id, include/primia_hip.h),
+    # so runs under PRIMIA_LH2=0 / PRIMIA_WGP32=0 / ... are labelled with what ran.  Forward and data gradient of the
+    # wide 3x3 layers are ONE kernel (same code, flipped taps) and therefore one family.
+    from primia_amd import _lib
+    from primia_amd._lib import query
+
+    KNAME = {1: "conv_igemm_kernel", 2: "conv3x3_c64_kernel (fwd + dgrad)", 3: "conv3x3_lh_kernel (fwd + dgrad)",
+             4: "conv3x3_lh2_kernel (fwd + dgrad)", 11: "conv_wgrad_patch32_kernel + wgrad_patch32_reduce_kernel",
+             12: "conv_wgrad_patch_kernel + wgrad_patch_reduce_kernel", 13: "conv_wgrad_dma_kernel (per-tap, stride 2 / 1x1)",
+             14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)"}
+    dtc = _lib.dtype_code(dtype)
+
     def family(kind, name):
         sp = eng.convs[name].spec
-        l1 = sp.k == 3 and sp.stride == 1 and sp.cin == 64 and sp.cout == 64
-        if kind == "wgrad":
-            if sp.k == 7:
-                return "stem_conv_wgrad_kernel"
-            return "conv_wgrad_patch32_kernel" if (sp.k == 3 and sp.stride == 1) else "conv_wgrad_kernel (per-tap, stride 2 / 1x1)"
         if sp.k == 7:
-            return "stem_conv_fwd_kernel"
-        if l1:
-            return "conv3x3_c64_kernel"
-        if sp.k == 3 and sp.stride == 1 and sp.cout % 128 == 0 and os.environ.get("PRIMIA_LH", "1") != "0":
-            return "conv3x3_lh_kernel<%s>" % kind       # wide 3x3 / stride-1 layers: linear-halo kernel
-        return "conv_igemm_kernel<%s>" % kind
+            return "stem_conv_wgrad_kernel" if kind == "wgrad" else "stem_conv_fwd_kernel"
+        d = eng.convs[name].desc
+        if kind == "wgrad":
+            return KNAME[query("primia_conv_wgrad_kernel_id", d, dtc)]
+        kid = query("primia_conv_kernel_id", d, 0 if kind == "fwd" else 1, dtc)
+        return KNAME[kid] + ("<%s>" % kind if kid == 1 else "")
 
     per_launch = {}
     for kind, name, flops, e0, e1 in eng.prof:
@@ -297,13 +318,13 @@ def main():
     tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if os.path.exists(tpath) and a.batch == 256 and a.size == 224 and a.dtype == "bf16":
         rec = json.load(open(tpath))
-        key = "conv_wgrad_patch32_kernel" if dom.startswith("conv_wgrad_patch") and "conv_wgrad_patch32_kernel" in rec else dom.split(" ")[0].split("<")[0]
+        key = dom.split(" ")[0].split("<")[0]     # the kernel that ran; no record for it -> traffic_offline stays null
         if key in rec:
             traffic_offline = {"hbm_bytes_per_launch": rec[key].get("hbm_bytes_per_launch"), "kernel": key,
                                "source": "profiles/" + TRAFFIC_FILE}
     roof = {"bound": "mfma", "kernel": dom,
-            "launch": "median over %d steps of the HIP-event bracket around one C-ABI call (conv_wgrad_patch32_kernel: the "
-                      "kernel + its wgrad_patch32_reduce_kernel)" % nprof,
+            "launch": "median over %d steps of the HIP-event bracket around one C-ABI call (a weight-gradient call = the "
+                      "kernel + its ordered reduce)" % nprof,
             "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic, "traffic_offline": traffic_offline,
             "all_conv": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 3),
@@ -325,6 +346,7 @@ def main():
         "step_tflops": round(GFLOP_PER_IMAGE * 1e9 * a.batch / (dt / a.steps) / 1e12, 2),
         "step_mfma_frac": round(GFLOP_PER_IMAGE * 1e9 * a.batch / (dt / a.steps) / 1e12 / peak, 4),
         "final_loss": round(loss, 5), "hip_graph": graphs is not None, "sustained": sustained,
+        "fedavg_ms_per_sync": fedavg_ms,
         "roofline": roof,
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

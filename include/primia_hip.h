@@ -119,6 +119,16 @@ int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_ac
 /* Same, and the per-channel sum / sum of squares of y (values as stored) — the batch statistics of the
  * BatchNorm that follows — are accumulated into stat_sums, laid out [slots][2][K] with
  * slots = primia_conv_stat_slots() partial sums (spread to keep atomics uncontended); caller zeroes it. */
+/* Which kernel the library's dispatch rules select for a convolution (measurement tooling: bench.py names its
+ * roofline families with it, so a run under PRIMIA_LH2=0 / PRIMIA_WGP32=0 / PRIMIA_WGRAD=... reports the kernel that
+ * actually ran).  pass 0 = forward, 1 = data gradient:
+ *   1 conv_igemm_kernel   2 conv3x3_c64_kernel   3 conv3x3_lh_kernel   4 conv3x3_lh2_kernel
+ * weight gradient:
+ *   11 conv_wgrad_patch32_kernel   12 conv_wgrad_patch_kernel   13 conv_wgrad_dma_kernel   14 conv_wgrad_kernel
+ *   15 the stem's (stem_conv_wgrad_kernel on the padded bf16 input, conv_wgrad_kernel<STEM> otherwise) */
+int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype);
+int primia_conv_wgrad_kernel_id(const primia_conv_desc* d, int dtype);
+
 int primia_conv_stat_slots(void);
 /* Slots the kernel chosen for `d` writes: kernels that own whole output rows (layer1's 64->64 convolution)
  * emit one deterministic partial per block, written rather than accumulated (no zeroing needed); the

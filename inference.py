@@ -22,24 +22,34 @@ from primia_amd.secure import Dealer, SecureContext, SecureResNet18
 from primia_amd.torchlib_compat import Arguments  # noqa: F401  (checkpoints pickle an Arguments instance)
 
 
-def load_images(data_dir, n, size, seed=0):
-    """Folder of images -> fp32 [n,3,S,S]; 'synthetic' (or a missing folder) -> seeded noise."""
-    if data_dir and os.path.isdir(data_dir):
-        try:
-            from PIL import Image
-            import numpy as np
+def load_images(data_dir, n, size, channels, device, mean, std, seed=0):
+    """The reference's inference transform (inference.py:176-196: a.Resize(R, R) -> a.CenterCrop(R, R) -> a.ToFloat ->
+    a.Normalize with the checkpoint's mean / std) for the first `n` images of `data_dir`, on the GPU through
+    primia_image_prepare; RGB or single channel as the checkpoint's stem says (CombinedLoader.change_channels).
+    `synthetic` (or no folder given) -> seeded noise; a folder that does not exist is an error."""
+    if data_dir in (None, "synthetic"):
+        g = torch.Generator().manual_seed(seed)
+        return torch.randn(n, channels, size, size, generator=g).to(device)
+    if not os.path.isdir(data_dir):
+        raise SystemExit("data_dir {!r} does not exist (pass 'synthetic' for seeded noise)".format(data_dir))
+    import numpy as np
 
-            files = sorted(f for f in os.listdir(data_dir) if f.lower().endswith((".png", ".jpg", ".jpeg")))[:n]
-            out = []
-            for f in files:
-                im = Image.open(os.path.join(data_dir, f)).convert("RGB").resize((size, size))
-                out.append(torch.from_numpy(np.asarray(im, dtype="float32") / 255.0).permute(2, 0, 1))
-            if out:
-                return torch.stack(out)
-        except ImportError:
-            pass
-    g = torch.Generator().manual_seed(seed)
-    return torch.randn(n, 3, size, size, generator=g)
+    from primia_amd import imagefolder
+    from primia_amd._lib import call
+
+    files = sorted(os.path.join(dp, f) for dp, _, fs in os.walk(data_dir) for f in fs
+                   if f.lower().endswith(imagefolder.EXTENSIONS) and not f.startswith("._"))[:n]
+    if not files:
+        raise SystemExit("no images under {!r}".format(data_dir))
+    out = torch.empty(len(files), channels, size, size, dtype=torch.float32, device=device)
+    m = mean.to(device).float().reshape(-1).contiguous()
+    s_ = std.to(device).float().reshape(-1).contiguous()
+    if m.numel() != channels:          # a one-element statistic applies to every channel
+        m, s_ = m[:1].repeat(channels), s_[:1].repeat(channels)
+    for i, fn in enumerate(files):
+        img = torch.from_numpy(np.ascontiguousarray(imagefolder.decode(fn, channels))).to(device)
+        call("primia_image_prepare", img, img.shape[0], img.shape[1], channels, size, 0, 0, size, 0, m, s_, out[i])
+    return out
 
 
 if __name__ == "__main__":
@@ -77,9 +87,10 @@ if __name__ == "__main__":
     args.from_previous_checkpoint(cmd_args)
     size = getattr(args, "inference_resolution", args.train_resolution)
     sd = state["model_state_dict"]
-    mean, std = state.get("val_mean_std", (torch.zeros(3), torch.ones(3)))
-    images = load_images(cmd_args.data_dir, cmd_args.num_images, size)
-    images = (images - mean.view(1, -1, 1, 1)) / std.view(1, -1, 1, 1)
+    channels = int(sd["conv1.weight"].shape[1])       # 3 for pretrained = yes, else 1 (train.py:262)
+    # inference.py:163-174: the checkpoint's statistics, else 0.5 / 0.2
+    mean, std = state.get("val_mean_std", (torch.full((channels,), 0.5), torch.full((channels,), 0.2)))
+    images = load_images(cmd_args.data_dir, cmd_args.num_images, size, channels, device, mean, std)
     total_pred = []
     if args.encrypted_inference:
         # inference.py:279-286: fix_precision(precision_fractional=16, dtype="long").share(..., protocol="fss")
@@ -98,7 +109,7 @@ if __name__ == "__main__":
             # it owns: the weights (party 0), the images (party 1), the architecture (everyone)
             logits = run_three_role(link, architecture_of(sd), size, images.shape[0],
                                     state_dict=sd if link.role == 0 else None,
-                                    images=images.to(device) if link.role == 1 else None,
+                                    images=images.to(device) if link.role == 1 else None,   # (this rank's GPU)
                                     seed=cmd_args.debug_dealer_seed)
             dist.barrier()
             dist.destroy_process_group()
@@ -117,7 +128,7 @@ if __name__ == "__main__":
             model = SecureResNet18(ctx, sd, input_size=size)
         logits = []
         for i in range(0 if cmd_args.three_role else images.shape[0]):
-            out = model(images[i:i + 1].to(device))
+            out = model(images[i:i + 1])
             logits.append(out)
             total_pred.append(int(out.argmax(dim=1).item()))
         if logits and os.environ.get("PRIMIA_DUMP_LOGITS"):
@@ -128,6 +139,6 @@ if __name__ == "__main__":
         eng.load_state_dict(sd)
         eng.eval()
         for i in range(images.shape[0]):
-            total_pred.append(int(eng.forward(images[i:i + 1].to(device)).argmax(dim=1).item()))
+            total_pred.append(int(eng.forward(images[i:i + 1]).argmax(dim=1).item()))
     print(json.dumps({"Inference Results": {i: p for i, p in enumerate(total_pred)}}))
     print("Took {:s} seconds.".format(str(datetime.now() - start_time)), file=sys.stderr)

@@ -725,6 +725,20 @@ int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fw
     return conv2d_fwd_impl(d, x, w_fwd, y, nullptr, dtype, stream);
 }
 
+int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype) {
+    ConvGeom g;
+    if (!d || !g.init(*d) || (pass != 0 && pass != 1)) return PRIMIA_ERR_ARG;
+    if (dtype != PRIMIA_BF16) return 1;
+    if (g.stem) return 1;     // (the engine's bf16 stem runs primia_stem_conv_fwd on the padded input: stem_conv_fwd_kernel)
+    if (use_c64(g) && (long)g.N * g.H * g.W * 64 < (1L << 31)) return 2;
+    if (lh_shape(g) && (pass == 1 || g.W <= lh_fwd_maxw())) {
+        const int cs = pass == 0 ? g.C : g.K, nd = pass == 0 ? g.K : g.C;
+        if (conv3x3_lh2_tiles_m(g.N, g.H, g.W, cs, nd) > 0) return 4;
+        if (conv3x3_lh_tiles_m(g.N, g.H, g.W, cs, nd) > 0) return 3;
+    }
+    return 1;
+}
+
 int primia_conv_stat_slots(void) { return kStatSlots; }
 
 int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype) {

@@ -36,6 +36,7 @@ int wgrad_dma_dispatch(const WgradParams& p, hipStream_t st);
 size_t wgrad_dma_ws_bytes(const WgradParams& p);
 // halo-patch kernel (3x3, stride 1, bf16); returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered
 int wgrad_patch_dispatch(const WgradParams& p, hipStream_t st);
+int wgrad_patch_kernel_id(const WgradParams& p);
 size_t wgrad_patch_ws_bytes(const WgradParams& p);
 // stem (7x7/2) halo kernel on the padded input (stem_conv.hip)
 int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st,

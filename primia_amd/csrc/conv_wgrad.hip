@@ -494,6 +494,21 @@ extern "C" int primia_conv2d_wgrad_persample_sqnorm(const primia_conv_desc* d, c
     return conv2d_wgrad_impl(d, x, dy, nullptr, 1, dtype, stream, sqnorm);
 }
 
+extern "C" int primia_conv_wgrad_kernel_id(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    WgradParams p;
+    if (!d || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
+    if (g.stem) return 15;
+    if (dtype != PRIMIA_BF16) return 14;
+    const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    if (!force) {
+        const int id = wgrad_patch_kernel_id(p);
+        if (id) return id;
+    }
+    const bool dma = force == 'd' || (force != 'o' && (g.C >= 256 || (g.K >= 256 && g.C >= 128)));
+    return dma ? 13 : 14;
+}
+
 static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc, int persample,
                              int dtype, primia_stream_t stream, double* sqnorm, float* ws, size_t ws_bytes) {
     PRIMIA_REQUIRE(d && x && dy && (dw_acc || sqnorm));

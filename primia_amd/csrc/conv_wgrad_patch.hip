@@ -790,8 +790,10 @@ static bool use_v2() {
 
 static PatchGeom patch_geom(const WgradParams& w) {
     PatchGeom g{};
+    // the v2 kernel addresses x and dy with 32-bit BYTE offsets through buffer resources (signed arithmetic, range
+    // check against num_records): elements < 2^30; the v1 kernel indexes elements with 32-bit ints: < 2^31
     g.ok = !(w.R != 3 || w.S != 3 || w.stride != 1 || w.pad != 1 || w.C % 64 || w.K % 64) &&
-           (long)w.N * w.H * w.W * (w.C > w.K ? w.C : w.K) < (1L << 31);
+           (long)w.N * w.H * w.W * (w.C > w.K ? w.C : w.K) < (use_v2() ? (1L << 30) : (1L << 31));
     if (!g.ok) return g;
     // 16-wide sub-patches when they waste fewer slots on the ragged right edge (W = 14: 16 vs 2 x 8)
     const int waste8 = (w.W + 7) / 8 * 8 - w.W, waste16 = (w.W + 15) / 16 * 16 - w.W;
@@ -890,6 +892,12 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
             wgrad_patch_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
     }
     return launch_status();
+}
+
+// 11 = conv_wgrad_patch32_kernel, 12 = conv_wgrad_patch_kernel (round 1), 0 = shape not served
+int wgrad_patch_kernel_id(const WgradParams& w) {
+    if (!patch_geom(w).ok) return 0;
+    return use_v2() ? 11 : 12;
 }
 
 int wgrad_patch_dispatch(const WgradParams& w, hipStream_t st) {

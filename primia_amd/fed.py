@@ -40,6 +40,16 @@ class HipArenaOps:
         _lib.call("primia_fx_decode", q, x, x.numel(), float(scale))
 
 
+class HipMaskOps:
+    """The two device operations of PairwiseMasks: ChaCha20 keystream and ring add / subtract (HIP kernels)."""
+
+    def keystream(self, key, block0, out):
+        _lib.call("primia_chacha20_fill", key[0], key[1], key[2], key[3], key[4], block0, out, out.numel())
+
+    def ring_accumulate(self, q, m, subtract):
+        _lib.call("primia_ring_sub" if subtract else "primia_ring_add", q, m, q, q.numel(), q.numel())
+
+
 class PairwiseMasks:
     """Masks m_k with sum_k m_k = 0 (mod 2^64) for the secure all-reduce: every pair of clients (i < j) shares a
     256-bit ChaCha20 key; client i ADDS the pair's keystream to its encoded update, client j SUBTRACTS it.  What a
@@ -47,36 +57,77 @@ class PairwiseMasks:
     the ring sum, and the decoded average is bit-identical to the unmasked one — the role additive sharing between
     the workers plays in the reference (`.fix_prec().share(*workers)`, torchlib/utils.py:1046-1060), without a hub.
 
-    Keys are drawn from `os.urandom` by the lower rank of each pair and handed to the higher rank point-to-point once
-    per run (`setup`); on one 8-GPU node that hop is an xGMI copy, across nodes it needs an authenticated channel —
-    the same trust the reference places in its websocket links.  Every sync consumes a fresh keystream segment."""
+    Pair keys come from an X25519 key agreement (RFC 7748) run once per training (`setup`): every client draws a
+    private scalar from `os.urandom`, only the PUBLIC points travel (one all_gather), and each pair derives its ChaCha20
+    key and nonce as SHA-256 of the shared point — nobody who merely observes the transport (the adversary the masks are
+    there for) learns a key, and key material never leaves host memory.  The exchange is not authenticated: an ACTIVE
+    man in the middle of a multi-node deployment still needs the authenticated channel the reference expects of its
+    websocket links.  Every sync consumes a fresh keystream segment."""
 
-    def __init__(self, keys, rank, n_words):
+    def __init__(self, keys, rank, n_words, ops=None):
         self.keys, self.rank = keys, rank          # {peer: (k0, k1, k2, k3, nonce)}
         self.blocks_per_sync = (n_words + 7) // 8
         self.syncs = 0
         self._tmp = None
+        self.ops = ops or HipMaskOps()
+
+    @staticmethod
+    def x25519(k: bytes, u: bytes) -> bytes:
+        """RFC 7748 section 5: scalar multiplication on Curve25519 (Montgomery ladder, Python integers)."""
+        P, A24 = 2 ** 255 - 19, 121665
+        kn = int.from_bytes(k, "little")
+        kn = (kn & ~7 & ~(128 << 8 * 31)) | (64 << 8 * 31)
+        x1 = int.from_bytes(u, "little") & ((1 << 255) - 1)
+        x2, z2, x3, z3, swap = 1, 0, x1, 1, 0
+        for t in reversed(range(255)):
+            kt = (kn >> t) & 1
+            if swap ^ kt:
+                x2, x3, z2, z3 = x3, x2, z3, z2
+            swap = kt
+            a, b = (x2 + z2) % P, (x2 - z2) % P
+            aa, bb = a * a % P, b * b % P
+            e = (aa - bb) % P
+            c, d = (x3 + z3) % P, (x3 - z3) % P
+            da, cb = d * a % P, c * b % P
+            x3 = (da + cb) ** 2 % P
+            z3 = x1 * (da - cb) ** 2 % P
+            x2 = aa * bb % P
+            z2 = e * (aa + A24 * e) % P
+        if swap:
+            x2, z2 = x3, z3
+        return (x2 * pow(z2, P - 2, P) % P).to_bytes(32, "little")
 
     @classmethod
-    def setup(cls, n_words, device, group=None):
+    def pair_key(cls, shared: bytes, i: int, j: int):
+        """(k0, k1, k2, k3, nonce) of the pair i < j from the X25519 shared point."""
+        import hashlib
+
+        tag = b"primia-pairwise-mask:%d:%d:" % (i, j)
+        key = hashlib.sha256(tag + b"key:" + shared).digest()
+        nonce = hashlib.sha256(tag + b"nonce:" + shared).digest()[:8]
+        return tuple(int.from_bytes(key[8 * t:8 * t + 8], "little") for t in range(4)) + (int.from_bytes(nonce, "little"),)
+
+    @classmethod
+    def setup(cls, n_words, device, group=None, ops=None):
         import os
 
         K = dist.get_world_size(group)
         rank = dist.get_rank(group)
+        secret = os.urandom(32)
+        public = cls.x25519(secret, (9).to_bytes(32, "little"))
+        # (public points only; RCCL moves device buffers, gloo host buffers)
+        mine = torch.tensor(list(public), dtype=torch.uint8, device=device if dist.get_backend(group) == "nccl" else "cpu")
+        everyone = [torch.empty_like(mine) for _ in range(K)]
+        dist.all_gather(everyone, mine, group=group)
         keys = {}
-        for i in range(K):
-            for j in range(i + 1, K):
-                if rank == i:
-                    raw = os.urandom(40)
-                    words = [int.from_bytes(raw[8 * t:8 * t + 8], "little", signed=True) for t in range(5)]
-                    t = torch.tensor(words, dtype=torch.int64, device=device)
-                    dist.send(t, dist.get_global_rank(group, j) if group is not None else j, group=group)
-                    keys[j] = tuple(w & 0xFFFFFFFFFFFFFFFF for w in words)
-                elif rank == j:
-                    t = torch.empty(5, dtype=torch.int64, device=device)
-                    dist.recv(t, dist.get_global_rank(group, i) if group is not None else i, group=group)
-                    keys[i] = tuple(int(w) & 0xFFFFFFFFFFFFFFFF for w in t.tolist())
-        return cls(keys, rank, n_words)
+        for peer in range(K):
+            if peer == rank:
+                continue
+            shared = cls.x25519(secret, bytes(everyone[peer].cpu().tolist()))
+            if shared == bytes(32):
+                raise RuntimeError("X25519: peer {:d} sent a low-order point".format(peer))
+            keys[peer] = cls.pair_key(shared, min(rank, peer), max(rank, peer))
+        return cls(keys, rank, n_words, ops)
 
     def apply(self, q):
         """q += sum_{j > rank} PRG(key_rank,j) - sum_{i < rank} PRG(key_i,rank)   (mod 2^64), in place."""
@@ -85,8 +136,8 @@ class PairwiseMasks:
             self._tmp = torch.empty(n, dtype=torch.int64, device=q.device)
         block0 = self.syncs * self.blocks_per_sync
         for peer, key in sorted(self.keys.items()):
-            _lib.call("primia_chacha20_fill", key[0], key[1], key[2], key[3], key[4], block0, self._tmp, n)
-            _lib.call("primia_ring_add" if peer > self.rank else "primia_ring_sub", q, self._tmp, q, n, n)
+            self.ops.keystream(key, block0, self._tmp)
+            self.ops.ring_accumulate(q, self._tmp, subtract=peer < self.rank)
         self.syncs += 1
 
 

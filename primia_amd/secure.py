@@ -643,7 +643,8 @@ class SecureResNet18:
         if c.party in (None, 1):
             xs = c.share(c.encode(image), owner=1)
         else:
-            xs = c.share(None, owner=1, shape=(1, 3, self.input_size, self.input_size))
+            cin = c._ref(self.p["conv1.weight"]).shape[1]        # 3 (pretrained) or 1 (train.py:262)
+            xs = c.share(None, owner=1, shape=(1, cin, self.input_size, self.input_size))
         out = self.forward_shares(xs)
         return c.decode(c.reconstruct(out))
 
@@ -669,7 +670,8 @@ class GraphedSecureInference:
 
     def __init__(self, state_dict, device, input_size=224, precision_fractional=16, base=10, seed=None, blocks=None):
         self.device = torch.device(device)
-        self.image = torch.zeros(1, 3, input_size, input_size, dtype=torch.float32, device=self.device)
+        self.image = torch.zeros(1, state_dict["conv1.weight"].shape[1], input_size, input_size, dtype=torch.float32,
+                                 device=self.device)
         self.dealer = Dealer(self.device, seed)
         self.dealer.tape, self.dealer.requests = [], []
         ctx = SecureContext(self.dealer, base, precision_fractional)
@@ -807,7 +809,7 @@ def request_schedule(arch, input_size, device, blocks=None, precision_fractional
     dummy = {k: torch.ones(shape, dtype=torch.float32) for k, shape in arch.items()}
     model = SecureResNet18(ctx, dummy, input_size, blocks)
     n_model = len(d.requests)
-    model(torch.zeros(1, 3, input_size, input_size, dtype=torch.float32, device=device))
+    model(torch.zeros(1, arch["conv1.weight"][1], input_size, input_size, dtype=torch.float32, device=device))
     return d.requests[:n_model], d.requests[n_model:]
 
 

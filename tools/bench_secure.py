@@ -7,161 +7,178 @@ import torch
 from primia_amd import resnet_spec as rs
 from primia_amd.secure import Dealer, PreloadedDealer, SecureContext, SecureResNet18
 
-ap = argparse.ArgumentParser()
-ap.add_argument("--size", type=int, default=224)
-ap.add_argument("--pf", type=int, default=16)
-ap.add_argument("--images", type=int, default=2)
-ap.add_argument("--cpu-sample", action="store_true", help="also time the CPU oracle on a bounded sample")
-ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the online phase")
-a = ap.parse_args()
-dev = torch.device("cuda:0")
-torch.manual_seed(42)
-sd = rs.init_state_dict(rs.resnet18_spec(3, 3, a.size, "max"))
-g = torch.Generator().manual_seed(1)
-img = torch.randn(1, 3, a.size, a.size, generator=g).to(dev)
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--size", type=int, default=224)
+    ap.add_argument("--pf", type=int, default=16)
+    ap.add_argument("--images", type=int, default=2)
+    ap.add_argument("--cpu-sample", action="store_true", help="also time the CPU oracle on a bounded sample")
+    ap.add_argument("--no-graph", action="store_true", help="skip the hipGraph replay of the online phase")
+    ap.add_argument("--only-fss-roofline", action="store_true",
+                    help="run the DIF keygen / eval kernels alone (the command the rocprofv3 --pmc passes of tools/pmc_secure.sh wrap)")
+    a = ap.parse_args()
 
-def run(dealer, share_model=True):
-    ctx = SecureContext(dealer, 10, a.pf)
-    model = SecureResNet18(ctx, sd, input_size=a.size)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    out = model(img)
-    torch.cuda.synchronize()
-    return time.perf_counter() - t0, out, ctx
 
-# warm-up (JIT-free, but first launches / allocator)
-run(Dealer(dev, seed=0))
-res = []
-for i in range(a.images):
-    d = Dealer(dev, seed=100 + i); d.tape = []
-    t_total, out_a, ctx = run(d)
-    t_online, out_b, _ = run(PreloadedDealer(d.tape, dev))
-    assert torch.equal(out_a, out_b), "replayed run must be bit-identical"
-    res.append((t_total, t_online))
-    del d
-tt = sum(r[0] for r in res) / len(res); to = sum(r[1] for r in res) / len(res)
+    def cpu_sample_timings():
+        """Bounded CPU sample of the same workload with the oracle, organised like the reference — run BEFORE this process
+        touches the GPU (the worker processes are spawned from a process without a HIP context):
+          * FSS evaluation above 50,000 elements fans out over N_CORES = max(4, cpu_count()) processes
+            (mpc/fss.py:43-44,214-236): a 400k-comparison tensor is evaluated that way (both parties), and on one core;
+          * FSS keygen (the crypto provider, mpc/fss.py:47-95) the same way;
+          * torch-CPU int64 matmuls of the 21 Beaver products' shapes (3 products x 2 parties each), torch's own threads.
+        Returns per-comparison / total-matmul seconds; cpu_sample_report() scales them to one image."""
+        import multiprocessing as mp
 
-# The online phase as ONE hipGraph (6,500 small launches per image): primitives sit in static buffers (a
-# deployment refills them from the dealer between images), the replay is checked bit for bit against the
-# eager run with the same primitives.
-graph_ms = refill_ms = None
-if not a.no_graph:
-    try:
-        from primia_amd.secure import GraphedSecureInference
+        import numpy as np
+        from oracle import secure_oracle as S
 
-        gi = GraphedSecureInference(sd, dev, input_size=a.size, precision_fractional=a.pf, seed=999)
-        ctx_e = SecureContext(PreloadedDealer(gi.tape, dev), 10, a.pf)
-        out_ref = SecureResNet18(ctx_e, sd, input_size=a.size)(img)
-        assert torch.equal(gi(img, refill=False), out_ref), "graph replay must be bit-identical"
+        ncores = max(4, os.cpu_count() or 1)
+        n = 400_000
+        rng = np.random.default_rng(0)
+        alpha = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64)
+        s0 = rng.integers(0, 2 ** 64, size=(2, 2, n), dtype=np.uint64); s0[:, 0] %= 2 ** 63
+        x = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64)
+        n1 = 20000
+        t0 = time.perf_counter(); S.dif_keygen(alpha[:n1], s0[:, :, :n1]); t_kg1 = (time.perf_counter() - t0) / n1
+        t0 = time.perf_counter(); _, keys = S.dif_keygen(alpha, s0); t_kg = (time.perf_counter() - t0) / n
+        t0 = time.perf_counter(); [S.dif_eval(b, x[:n1], {k: (v[..., :n1] if hasattr(v, "shape") else v) for k, v in keys[b].items()})
+                                   for b in range(2)]; t_ev1 = (time.perf_counter() - t0) / n1
+        with mp.get_context("spawn").Pool(ncores) as pool:
+            S.use_pool(pool, n_slices=ncores)               # the oracle slices the element axis over the pool (fss.py:214-266)
+            [S.dif_eval(b, x, keys[b]) for b in range(2)]   # warm every worker (import numpy, load the SHA loop)
+            t0 = time.perf_counter(); [S.dif_eval(b, x, keys[b]) for b in range(2)]; t_evp = (time.perf_counter() - t0) / n
+            S.use_pool(None)
+        shapes = [(12544, 147, 64)] + [(3136, 576, 64)] * 4 + [(784, 576, 128), (784, 64, 128)] + [(784, 1152, 128)] * 3 \
+            + [(196, 1152, 256), (196, 128, 256)] + [(196, 2304, 256)] * 3 + [(49, 2304, 512), (49, 256, 512)] \
+            + [(49, 4608, 512)] * 3 + [(1, 512, 3)]
+        t_mm = 0.0
+        per = {}
+        for sh in shapes:
+            if sh not in per:
+                A = torch.randint(-2 ** 62, 2 ** 62, (sh[0], sh[1])); B = torch.randint(-2 ** 62, 2 ** 62, (sh[1], sh[2]))
+                t0 = time.perf_counter(); torch.matmul(A, B); per[sh] = time.perf_counter() - t0
+            t_mm += per[sh] * 3 * 2
+        return dict(ncores=ncores, n=n, t_kg1=t_kg1, t_kg=t_kg, t_ev1=t_ev1, t_evp=t_evp, t_mm=t_mm)
+
+
+    cpu_t = cpu_sample_timings() if (a.cpu_sample and not a.only_fss_roofline) else None   # before the first GPU call
+    dev = torch.device("cuda:0")
+    torch.manual_seed(42)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, a.size, "max"))
+    g = torch.Generator().manual_seed(1)
+    img = torch.randn(1, 3, a.size, a.size, generator=g).to(dev)
+
+    def run(dealer, share_model=True):
+        ctx = SecureContext(dealer, 10, a.pf)
+        model = SecureResNet18(ctx, sd, input_size=a.size)
         torch.cuda.synchronize(); t0 = time.perf_counter()
+        out = model(img)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out, ctx
+
+    def valu_pmc():
+        """VALU-busy fraction of the DIF kernels from the committed rocprofv3 --pmc pass (tools/pmc_secure.sh): a
+        MEASURED utilisation beside the instruction-count model below."""
+        pth = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r03_secure_valu_pmc.json")
+        return json.load(open(pth)) if os.path.exists(pth) else None
+
+    def fss_roofline():
+        """The dominant secure kernel alone: DIF evaluation of 2^20 comparisons (one party).  32 SHA-512 compressions and
+        one 1,204-byte key per comparison.  VALU bound: a compression is 80 rounds of ~56 32-bit integer VALU operations
+        (rotations / sigma / Ch / Maj on 32-bit halves, 64-bit adds as add + add-with-carry, message schedule); the chip
+        issues 256 CUs x 128 lanes per clock at 2.4 GHz = 78.6 T op/s."""
+        n = 1 << 20
+        d = Dealer(dev, seed=7)
+        keys = d.dif_keys(n)
+        masked = (d.rand64(n) & 0xFFFFFFFF).to(torch.int32)
+        out = torch.empty(n, dtype=torch.int64, device=dev)
+        from primia_amd._lib import call
+        k = keys[0]
+        args = (0, masked, k["s0"], k["bits"], k["cw_sigma"], k["cw_s"], k["cw_leaf"], out, n)
+        for _ in range(2):
+            call("primia_dif_eval", *args)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        reps = 5
+        for _ in range(reps):
+            call("primia_dif_eval", *args)
+        e1.record(); torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) / reps * 1e-3
+        comp = n * 32 / t
+        peak = 256 * 128 * 2.4e9 / (80 * 56)
+        return {"bound": "valu", "kernel": "dif_eval_kernel", "achieved": round(comp / 1e9, 3), "peak": round(peak / 1e9, 3),
+                "unit": "G SHA-512 compressions/s", "frac": round(comp / peak, 4),
+                "key_read_GBps": round(n * 1204 / t / 1e9, 1), "key_read_frac_of_hbm": round(n * 1204 / t / 8e12, 4),
+                "launch_us": round(t * 1e6, 1), "comparisons": n, "valu_pmc": valu_pmc()}
+
+
+    if a.only_fss_roofline:
+        d = Dealer(dev, seed=3)
         for _ in range(3):
-            gi(img, refill=False)
-        torch.cuda.synchronize()
-        graph_ms = (time.perf_counter() - t0) / 3 * 1e3
-        t0 = time.perf_counter()
-        gi.refill()
-        torch.cuda.synchronize()
-        refill_ms = (time.perf_counter() - t0) * 1e3
-    except Exception as e:  # capture is an optimisation of the measurement, not of the result
-        print("hipGraph capture of the online phase failed:", repr(e)[:300], file=sys.stderr)
+            d.dif_keys(1 << 20)            # dif_keygen_kernel
+        print(json.dumps({"roofline": fss_roofline()}))
+        return
 
-def _eval_slice(args):
-    """One process of the reference's fan-out (comp_evaluate, mpc/fss.py:244-266): DIF.eval on a slice."""
-    b, x, key = args
-    from oracle import secure_oracle as S
-    return S.dif_eval(b, x, key)
+    # warm-up (JIT-free, but first launches / allocator)
+    run(Dealer(dev, seed=0))
+    res = []
+    for i in range(a.images):
+        d = Dealer(dev, seed=100 + i); d.tape = []
+        t_total, out_a, ctx = run(d)
+        t_online, out_b, _ = run(PreloadedDealer(d.tape, dev))
+        assert torch.equal(out_a, out_b), "replayed run must be bit-identical"
+        res.append((t_total, t_online))
+        del d
+    tt = sum(r[0] for r in res) / len(res); to = sum(r[1] for r in res) / len(res)
 
+    # The online phase as ONE hipGraph (6,500 small launches per image): primitives sit in static buffers (a
+    # deployment refills them from the dealer between images), the replay is checked bit for bit against the
+    # eager run with the same primitives.
+    graph_ms = refill_ms = None
+    if not a.no_graph:
+        try:
+            from primia_amd.secure import GraphedSecureInference
 
-def cpu_sample():
-    """Bounded CPU sample of the same workload with the oracle, organised like the reference:
-      * FSS evaluation above 50,000 elements fans out over N_CORES = max(4, cpu_count()) processes
-        (mpc/fss.py:43-44,214-236): a 400k-comparison tensor is evaluated that way (both parties), and on one core;
-      * FSS keygen (the crypto provider, mpc/fss.py:47-95) the same way;
-      * torch-CPU int64 matmuls of the 21 Beaver products' shapes (3 products x 2 parties each), torch's own threads.
-    Extrapolated to one image; online (eval + matmul) and dealer (keygen) are reported separately."""
-    import multiprocessing as mp
+            gi = GraphedSecureInference(sd, dev, input_size=a.size, precision_fractional=a.pf, seed=999)
+            ctx_e = SecureContext(PreloadedDealer(gi.tape, dev), 10, a.pf)
+            out_ref = SecureResNet18(ctx_e, sd, input_size=a.size)(img)
+            assert torch.equal(gi(img, refill=False), out_ref), "graph replay must be bit-identical"
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for _ in range(3):
+                gi(img, refill=False)
+            torch.cuda.synchronize()
+            graph_ms = (time.perf_counter() - t0) / 3 * 1e3
+            t0 = time.perf_counter()
+            gi.refill()
+            torch.cuda.synchronize()
+            refill_ms = (time.perf_counter() - t0) * 1e3
+        except Exception as e:  # capture is an optimisation of the measurement, not of the result
+            print("hipGraph capture of the online phase failed:", repr(e)[:300], file=sys.stderr)
 
-    import numpy as np
-    from oracle import secure_oracle as S
-
-    ncores = max(4, os.cpu_count() or 1)
-    n = 400_000
-    rng = np.random.default_rng(0)
-    alpha = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64)
-    s0 = rng.integers(0, 2 ** 64, size=(2, 2, n), dtype=np.uint64); s0[:, 0] %= 2 ** 63
-    x = rng.integers(0, 2 ** 32, size=n, dtype=np.uint64)
-    n1 = 20000
-    t0 = time.perf_counter(); S.dif_keygen(alpha[:n1], s0[:, :, :n1]); t_kg1 = (time.perf_counter() - t0) / n1
-    t0 = time.perf_counter(); _, keys = S.dif_keygen(alpha, s0); t_kg = (time.perf_counter() - t0) / n
-    t0 = time.perf_counter(); [S.dif_eval(b, x[:n1], {k: (v[..., :n1] if hasattr(v, "shape") else v) for k, v in keys[b].items()})
-                               for b in range(2)]; t_ev1 = (time.perf_counter() - t0) / n1
-    sl = -(-n // ncores)
-
-    def cut(key, i):
-        return {k: np.ascontiguousarray(v[..., i * sl:(i + 1) * sl]) for k, v in key.items()}
-
-    jobs = [(b, x[i * sl:(i + 1) * sl], cut(keys[b], i)) for b in range(2) for i in range(ncores) if i * sl < n]
-    with mp.get_context("fork").Pool(min(ncores, len(jobs))) as pool:
-        pool.map(_eval_slice, jobs[:2])                     # warm the workers
-        t0 = time.perf_counter(); pool.map(_eval_slice, jobs); t_evp = (time.perf_counter() - t0) / n
-    n_cmp = ctx.stats["dif_evals"]
-    shapes = [(12544, 147, 64)] + [(3136, 576, 64)] * 4 + [(784, 576, 128), (784, 64, 128)] + [(784, 1152, 128)] * 3 \
-        + [(196, 1152, 256), (196, 128, 256)] + [(196, 2304, 256)] * 3 + [(49, 2304, 512), (49, 256, 512)] \
-        + [(49, 4608, 512)] * 3 + [(1, 512, 3)]
-    t_mm = 0.0
-    per = {}
-    for sh in shapes:
-        if sh not in per:
-            A = torch.randint(-2 ** 62, 2 ** 62, (sh[0], sh[1])); B = torch.randint(-2 ** 62, 2 ** 62, (sh[1], sh[2]))
-            t0 = time.perf_counter(); torch.matmul(A, B); per[sh] = time.perf_counter() - t0
-        t_mm += per[sh] * 3 * 2
-    online = t_evp * n_cmp + t_mm
-    return {"value": round(online * 1e3, 0), "unit": "ms/image (online: FSS eval, both parties, + Beaver matmuls)",
-            "cores": ncores, "kind": "port",
-            "fss_eval_ms": round(t_evp * n_cmp * 1e3, 0), "fss_eval_one_core_ms": round(t_ev1 * n_cmp * 1e3, 0),
-            "beaver_matmul_ms": round(t_mm * 1e3, 0), "dealer_keygen_ms": round(t_kg * n_cmp * 1e3, 0),
-            "dealer_keygen_small_batch_ms": round(t_kg1 * n_cmp * 1e3, 0),
-            "sample": f"oracle DIF eval of {n} comparisons x 2 parties in {ncores} processes (the reference's fan-out, "
-                      f"mpc/fss.py:43-44,214-236), keygen of the same {n} on one core, extrapolated to the {n_cmp} "
-                      "comparisons of one image; torch-CPU int64 matmul of all 21 Beaver shapes x3 products x2 parties; "
-                      "excludes the reference's Python im2col, Newton BN and RPC overhead"}
+    def cpu_sample_report(t, n_cmp):
+        online = t["t_evp"] * n_cmp + t["t_mm"]
+        return {"value": round(online * 1e3, 0), "unit": "ms/image (online: FSS eval, both parties, + Beaver matmuls)",
+                "cores": t["ncores"], "kind": "port",
+                "fss_eval_ms": round(t["t_evp"] * n_cmp * 1e3, 0), "fss_eval_one_core_ms": round(t["t_ev1"] * n_cmp * 1e3, 0),
+                "beaver_matmul_ms": round(t["t_mm"] * 1e3, 0), "dealer_keygen_ms": round(t["t_kg"] * n_cmp * 1e3, 0),
+                "dealer_keygen_small_batch_ms": round(t["t_kg1"] * n_cmp * 1e3, 0),
+                "sample": f"oracle DIF eval of {t['n']} comparisons x 2 parties in {t['ncores']} spawned processes (the "
+                          f"reference's fan-out, mpc/fss.py:43-44,214-236), timed before this process touched the GPU; keygen of "
+                          f"the same {t['n']} on one core; extrapolated to the {n_cmp} comparisons of one image; torch-CPU int64 "
+                          "matmul of all 21 Beaver shapes x3 products x2 parties; excludes the reference's Python im2col, "
+                          "Newton BN and RPC overhead"}
 
 
-def fss_roofline():
-    """The dominant secure kernel alone: DIF evaluation of 2^20 comparisons (one party).  32 SHA-512 compressions and
-    one 1,204-byte key per comparison.  VALU bound: a compression is 80 rounds of ~56 32-bit integer VALU operations
-    (rotations / sigma / Ch / Maj on 32-bit halves, 64-bit adds as add + add-with-carry, message schedule); the chip
-    issues 256 CUs x 128 lanes per clock at 2.4 GHz = 78.6 T op/s."""
-    n = 1 << 20
-    d = Dealer(dev, seed=7)
-    keys = d.dif_keys(n)
-    masked = (d.rand64(n) & 0xFFFFFFFF).to(torch.int32)
-    out = torch.empty(n, dtype=torch.int64, device=dev)
-    from primia_amd._lib import call
-    k = keys[0]
-    args = (0, masked, k["s0"], k["bits"], k["cw_sigma"], k["cw_s"], k["cw_leaf"], out, n)
-    for _ in range(2):
-        call("primia_dif_eval", *args)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    reps = 5
-    for _ in range(reps):
-        call("primia_dif_eval", *args)
-    e1.record(); torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) / reps * 1e-3
-    comp = n * 32 / t
-    peak = 256 * 128 * 2.4e9 / (80 * 56)
-    return {"bound": "valu", "kernel": "dif_eval_kernel", "achieved": round(comp / 1e9, 3), "peak": round(peak / 1e9, 3),
-            "unit": "G SHA-512 compressions/s", "frac": round(comp / peak, 4),
-            "key_read_GBps": round(n * 1204 / t / 1e9, 1), "key_read_frac_of_hbm": round(n * 1204 / t / 8e12, 4),
-            "launch_us": round(t * 1e6, 1), "comparisons": n}
+    extra = {"cpu_baseline": cpu_sample_report(cpu_t, ctx.stats["dif_evals"])} if cpu_t else {}
+    extra["roofline"] = fss_roofline()
+    print(json.dumps({"metric": "encrypted_inference_ms_per_image", "online_ms": round(to * 1e3, 1),
+                      "online_graph_ms": None if graph_ms is None else round(graph_ms, 1),
+                      "dealer_refill_ms": None if refill_ms is None else round(refill_ms, 1),
+                      "with_dealer_ms": round(tt * 1e3, 1), "dealer_ms": round((tt - to) * 1e3, 1),
+                      "precision_fractional": a.pf, "size": a.size, "dif_evals": ctx.stats["dif_evals"],
+                      "beaver_matmul": ctx.stats["beaver_matmul"], "beaver_mul": ctx.stats["beaver_mul"],
+                      "topology": "party0 + party1 + dealer on one MI355X (LocalOpener)", **extra}))
 
 
-extra = {"cpu_baseline": cpu_sample()} if a.cpu_sample else {}
-extra["roofline"] = fss_roofline()
-print(json.dumps({"metric": "encrypted_inference_ms_per_image", "online_ms": round(to * 1e3, 1),
-                  "online_graph_ms": None if graph_ms is None else round(graph_ms, 1),
-                  "dealer_refill_ms": None if refill_ms is None else round(refill_ms, 1),
-                  "with_dealer_ms": round(tt * 1e3, 1), "dealer_ms": round((tt - to) * 1e3, 1),
-                  "precision_fractional": a.pf, "size": a.size, "dif_evals": ctx.stats["dif_evals"],
-                  "beaver_matmul": ctx.stats["beaver_matmul"], "beaver_mul": ctx.stats["beaver_mul"],
-                  "topology": "party0 + party1 + dealer on one MI355X (LocalOpener)", **extra}))
+if __name__ == "__main__":
+    main()

@@ -139,11 +139,13 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
         raise SystemExit("several ranks are several federated clients: launch with --train_federated")
     dtype = torch.float32 if os.environ.get("PRIMIA_DTYPE", "bf16") == "f32" else torch.bfloat16
     n_batches = int(os.environ.get("PRIMIA_SYNTHETIC_BATCHES", 8))
-    synthetic = args.data_dir in (None, "synthetic") or not path.isdir(str(args.data_dir))
+    synthetic = args.data_dir in (None, "synthetic")
     if not synthetic:
+        if not path.isdir(str(args.data_dir)):
+            # (round 2 silently trained on synthetic batches here)
+            raise SystemExit("data_dir {!r} does not exist; pass --data_dir synthetic for seeded synthetic batches".format(
+                args.data_dir))
         from primia_amd import imagefolder
-    elif args.data_dir not in (None, "synthetic"):
-        warn("data_dir {!r} does not exist: training on synthetic batches".format(args.data_dir))
 
     def make_engine():
         # differentially_private = yes (train.py:304-334 of the reference): BatchNorm is rejected by the
@@ -258,18 +260,38 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
                 gathered = [None] * world
                 dist.all_gather_object(gathered, (mine[0], optimizer[mine[0]].state_dict()))
                 opt_for_ckpt = dict(gathered)
+            # rank 0 validates; what it decides (pruned / failed) reaches every rank BEFORE anybody moves on, so a
+            # pruned trial or a validation error ends all ranks together instead of leaving them in a barrier until
+            # the RCCL timeout.  The pruning check precedes the checkpoint, as train.py:505-517 of the reference.
+            verdict = [None]        # None = go on, "pruned", or the exception rank 0 hit
             if rank == 0:
-                _, objective = test(args, eval_model, device, val_loader, epoch, loss_fn, num_classes, verbose=verbose)
-                objectives.append(objective)
-                p = "model_weights/{:s}_epoch_{:03d}.pt".format(exp_name, epoch * reps)
-                save_model(eval_model, opt_for_ckpt, p, args, epoch, val_mean_std=val_mean_std)
-                model_paths.append(p)
-                if optuna_trial:
-                    optuna_trial.report(objective, epoch * reps)
-                    if optuna_trial.should_prune():
-                        raise RuntimeError("trial pruned")
+                try:
+                    _, objective = test(args, eval_model, device, val_loader, epoch, loss_fn, num_classes,
+                                        verbose=verbose)
+                    objectives.append(objective)
+                    if optuna_trial:
+                        optuna_trial.report(objective, epoch * reps)
+                        if optuna_trial.should_prune():
+                            verdict[0] = "pruned"
+                    if verdict[0] is None:
+                        p = "model_weights/{:s}_epoch_{:03d}.pt".format(exp_name, epoch * reps)
+                        save_model(eval_model, opt_for_ckpt, p, args, epoch, val_mean_std=val_mean_std)
+                        model_paths.append(p)
+                except Exception as e:  # noqa: BLE001 - forwarded to every rank, re-raised below
+                    verdict[0] = e
             if world > 1:
-                dist.barrier()
+                dist.broadcast_object_list(verdict, src=0)
+            if verdict[0] is not None:
+                if world > 1:
+                    dist.destroy_process_group()
+                if isinstance(verdict[0], str):
+                    try:
+                        import optuna
+
+                        raise optuna.TrialPruned()
+                    except ImportError:
+                        raise RuntimeError("trial pruned") from None
+                raise verdict[0]
     best_score = 0.0
     if rank == 0 and objectives:
         # the LAST occurrence of the highest score wins (train.py:514-521)
