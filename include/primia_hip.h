@@ -204,6 +204,32 @@ int primia_conv_wgrad_finalize(const primia_conv_desc* d, int c_real, const floa
 int primia_image_prepare(const uint8_t* src, int Hin, int Win, int C, int R, int oy, int ox, int S, int flip_v,
                          const float* mean, const float* std, float* out, primia_stream_t stream);
 
+/* The augmentation chain of create_albu_transform (torchlib/dataloader.py:138-217) as separate steps on uint8 HWC
+ * images in device memory (C = 1 or 3); the host draws the random parameters (primia_amd/augment.py), every call is a
+ * deterministic function of image and parameters.  In the order the reference applies them:
+ *   primia_image_affine_u8       transforms.RandomAffine: PIL AFFINE / NEAREST with the INVERSE matrix (a b c; d e f),
+ *                                source index floor(a (x+.5) + b (y+.5) + c), fill 0.  out != src.
+ *   primia_image_resize_crop_u8  a.Resize(R, R) -> a.RandomCrop(S, S) at (oy, ox) [-> a.VerticalFlip], uint8 out
+ *                                (the sampling of primia_image_prepare).
+ *   primia_clahe_u8              a.CLAHE(clip_limit, tile grid 8 x 8): OpenCV's algorithm on the plane (C = 1) or on L of
+ *                                CIE L*a*b* (C = 3); workspace = primia_clahe_workspace_bytes.  in-place allowed.
+ *   primia_image_lut_u8          cv2.LUT with the 256-entry table albumentations builds (RandomGamma, RandomBrightness).
+ *   primia_image_box_blur_u8     a.Blur -> cv2.blur(k, k), BORDER_REFLECT_101.  out != in.
+ *   primia_image_add_noise_u8    a.GaussNoise: uint8(clip(img + noise, 0, 255)), noise fp32 per element.
+ *   primia_image_finish          a.ToFloat(255) -> a.Normalize(mean, std, 1.0): uint8 HWC -> fp32 [C][S][S]. */
+int primia_image_affine_u8(const uint8_t* src, int H, int W, int C, float a, float b, float c, float d, float e, float f,
+                           uint8_t* out, primia_stream_t stream);
+int primia_image_resize_crop_u8(const uint8_t* src, int Hin, int Win, int C, int R, int oy, int ox, int S, int flip_v,
+                                uint8_t* out, primia_stream_t stream);
+int64_t primia_clahe_workspace_bytes(int H, int W, int C);
+int primia_clahe_u8(const uint8_t* img, int H, int W, int C, float clip_limit, void* workspace, int64_t workspace_bytes,
+                    uint8_t* out, primia_stream_t stream);
+int primia_image_lut_u8(const uint8_t* in, int64_t n, const uint8_t* table256, uint8_t* out, primia_stream_t stream);
+int primia_image_box_blur_u8(const uint8_t* in, int H, int W, int C, int k, uint8_t* out, primia_stream_t stream);
+int primia_image_add_noise_u8(const uint8_t* in, const float* noise, int64_t n, uint8_t* out, primia_stream_t stream);
+int primia_image_finish(const uint8_t* in, int S, int C, const float* mean, const float* std, float* out,
+                        primia_stream_t stream);
+
 /* out[i] = lam * x[i] + one_minus_lam * x[L/2 + i] for i < L/2 over rows of `per_sample` floats (three
  * roundings, like the reference's expression); an odd trailing sample is copied to out[L/2].  The same call
  * mixes the one-hot targets (per_sample = classes).  out has ceil(L/2) rows. */

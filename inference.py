@@ -22,7 +22,7 @@ from primia_amd.secure import Dealer, SecureContext, SecureResNet18
 from primia_amd.torchlib_compat import Arguments  # noqa: F401  (checkpoints pickle an Arguments instance)
 
 
-def load_images(data_dir, n, size, channels, device, mean, std, seed=0):
+def load_images(data_dir, n, size, channels, device, mean, std, seed=0, clahe=False):
     """The reference's inference transform (inference.py:176-196: a.Resize(R, R) -> a.CenterCrop(R, R) -> a.ToFloat ->
     a.Normalize with the checkpoint's mean / std) for the first `n` images of `data_dir`, on the GPU through
     primia_image_prepare; RGB or single channel as the checkpoint's stem says (CombinedLoader.change_channels).
@@ -46,9 +46,20 @@ def load_images(data_dir, n, size, channels, device, mean, std, seed=0):
     s_ = std.to(device).float().reshape(-1).contiguous()
     if m.numel() != channels:          # a one-element statistic applies to every channel
         m, s_ = m[:1].repeat(channels), s_[:1].repeat(channels)
+    if clahe:        # inference.py:182-183: a.CLAHE(always_apply=True, clip_limit=(1, 1)) between the crop and ToFloat
+        from primia_amd._lib import query
+
+        wsb = query("primia_clahe_workspace_bytes", size, size, channels)
+        ws = torch.empty(wsb, dtype=torch.uint8, device=device)
+        u8 = torch.empty(size, size, channels, dtype=torch.uint8, device=device)
     for i, fn in enumerate(files):
         img = torch.from_numpy(np.ascontiguousarray(imagefolder.decode(fn, channels))).to(device)
-        call("primia_image_prepare", img, img.shape[0], img.shape[1], channels, size, 0, 0, size, 0, m, s_, out[i])
+        if clahe:
+            call("primia_image_resize_crop_u8", img, img.shape[0], img.shape[1], channels, size, 0, 0, size, 0, u8)
+            call("primia_clahe_u8", u8, size, size, channels, 1.0, ws, wsb, u8)
+            call("primia_image_finish", u8, size, channels, m, s_, out[i])
+        else:
+            call("primia_image_prepare", img, img.shape[0], img.shape[1], channels, size, 0, 0, size, 0, m, s_, out[i])
     return out
 
 
@@ -90,7 +101,8 @@ if __name__ == "__main__":
     channels = int(sd["conv1.weight"].shape[1])       # 3 for pretrained = yes, else 1 (train.py:262)
     # inference.py:163-174: the checkpoint's statistics, else 0.5 / 0.2
     mean, std = state.get("val_mean_std", (torch.full((channels,), 0.5), torch.full((channels,), 0.2)))
-    images = load_images(cmd_args.data_dir, cmd_args.num_images, size, channels, device, mean, std)
+    images = load_images(cmd_args.data_dir, cmd_args.num_images, size, channels, device, mean, std,
+                         clahe=bool(getattr(args, "clahe", False)))
     total_pred = []
     if args.encrypted_inference:
         # inference.py:279-286: fix_precision(precision_fractional=16, dtype="long").share(..., protocol="fss")

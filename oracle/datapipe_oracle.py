@@ -98,3 +98,52 @@ def exchange_mean_std(means, stds, precision_fractional=3, base=10):
         m = m + enc(a)
         s = s + enc(b)
     return m.float() / scale / len(stds), s.float() / scale / len(stds)
+
+
+def register_federated(samples, targets, orders, mix, lam=None, p=None, rng=_random):
+    """The registration loop of setup_pysyft (torchlib/utils.py:694-734) for one worker.
+
+    samples : per-sample tensors [C, H, W]; targets : per-sample one-hot rows [3] (mix or weight_classes) or ints.
+    orders  : one index sequence per dataset repetition — with `mixup` the reference wraps the dataset in a
+              DataLoader(batch_size=1, shuffle=True), so every repetition walks its own permutation; without it the
+              dataset order (the caller passes range(n) `repetitions_dataset` times).
+    mix     : args.mixup.  Sample k of the walk is blended with the UNMIXED sample k-1 of the walk (`last_set`
+              carries across repetitions): MixUp(((d, last_d), (t, last_t))) on [1, ...] tensors, i.e. one
+              `rng.random()` for p (a skipped call keeps d) and, when λ is unset, one more for λ.
+    Returns (data [n_total, C, H, W], targets [n_total, 3] or [n_total])."""
+    data, tgts = [], []
+    last = None
+    for order in orders:
+        for k in order:
+            d, t = samples[k], targets[k]
+            if mix:
+                d, t = d.unsqueeze(0), t.unsqueeze(0)           # the DataLoader's batch dimension
+                original = (d, t)
+                if last:
+                    d, t = mixup((d, last[0]), (t, last[1]), lam, p, rng=rng)
+                last = original
+            data.append(d)
+            tgts.append(t)
+    sel = torch.stack(data)
+    tt = torch.stack(tgts) if torch.is_tensor(tgts[0]) else torch.tensor(tgts)
+    if mix:
+        sel, tt = sel.squeeze(1), tt.squeeze(1)
+    return sel, tt
+
+
+def calc_class_weights(loaders, batch_size, num_classes, soft_targets):
+    """calc_class_weights (torchlib/utils.py:469-513): occurrences of every class over all loaders' batches (soft or
+    one-hot targets are reduced with max(dim=1) first — the first maximum wins), weights 1 / count normalised to
+    sum 1; all-zero counts give ones."""
+    occ = torch.zeros(num_classes)
+    for tl in loaders:
+        for _, target in tl:
+            if soft_targets:
+                target = target.max(dim=1)[1]
+            for i in range(num_classes):
+                occ[i] += float((target == i).sum().item())
+    if torch.sum(occ).item() == 0:
+        return torch.ones((num_classes,))
+    cw = 1.0 / occ
+    cw /= torch.sum(cw)
+    return cw

@@ -1,0 +1,293 @@
+// The augmentation chain of create_albu_transform (torchlib/dataloader.py:138-217) on the GPU, for the members the
+// reference's shipped presets switch on that are plain image arithmetic: RandomAffine (torchvision, nearest
+// neighbour), Resize + RandomCrop (to uint8), CLAHE (always applied when `clahe = yes`), VerticalFlip, RandomGamma,
+// RandomBrightness, Blur, GaussNoise, then ToFloat + Normalize.  Each is one launch on a decoded uint8 HWC image that
+// already lives in device memory; the random PARAMETERS are drawn by the host (primia_amd/augment.py) the way
+// torchvision / albumentations draw them, the kernels are deterministic functions of (image, parameters).
+//
+// cv2 / albumentations are not in this image, so these kernels follow the published algorithms (OpenCV's clahe.cpp,
+// box filter with BORDER_REFLECT_101, cv2.LUT tables as albumentations builds them) and are held bit-exact to
+// oracle/augment_oracle.py, which restates them in NumPy; parity with cv2's own binaries is unpinned.
+// Registration-time work, a few hundred kilobytes per image: nowhere near a roofline, written for clarity.
+#include "common.h"
+
+// every product below is rounded on its own, as the NumPy / OpenCV float arithmetic these kernels follow does: no
+// fused multiply-add contraction in this file
+#pragma clang fp contract(off)
+
+namespace primia {
+
+// ---- RandomAffine: PIL Image.transform(AFFINE, NEAREST): source index = floor(a (x + .5) + b (y + .5) + c) ----------
+__global__ __launch_bounds__(256) void affine_u8_kernel(const uint8_t* __restrict__ src, int H, int W, int C, float a,
+                                                        float b, float c, float d, float e, float f,
+                                                        uint8_t* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W;
+    const double xs = (double)a * (x + 0.5) + (double)b * (y + 0.5) + (double)c;
+    const double ys = (double)d * (x + 0.5) + (double)e * (y + 0.5) + (double)f;
+    const int xi = (int)floor(xs), yi = (int)floor(ys);
+    const bool in = xi >= 0 && xi < W && yi >= 0 && yi < H;
+    for (int ch = 0; ch < C; ++ch) out[(long)idx * C + ch] = in ? src[((long)yi * W + xi) * C + ch] : (uint8_t)0;
+}
+
+// ---- Resize(R, R) + crop (oy, ox, S) [+ vertical flip] to uint8 HWC: image_prepare_kernel's sampling ---------------
+__global__ __launch_bounds__(256) void resize_crop_u8_kernel(const uint8_t* __restrict__ src, int Hin, int Win, int C,
+                                                             int R, int oy, int ox, int S, int flip_v,
+                                                             uint8_t* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * S) return;
+    const int y = idx / S, x = idx - y * S;
+    const int ry = (flip_v ? S - 1 - y : y) + oy, rx = x + ox;
+    const float sy = ((float)ry + 0.5f) * ((float)Hin / (float)R) - 0.5f;
+    const float sx = ((float)rx + 0.5f) * ((float)Win / (float)R) - 0.5f;
+    int y0 = (int)floorf(sy), x0 = (int)floorf(sx);
+    float fy = sy - (float)y0, fx = sx - (float)x0;
+    if (y0 < 0) { y0 = 0; fy = 0.f; }
+    if (x0 < 0) { x0 = 0; fx = 0.f; }
+    int y1 = y0 + 1, x1 = x0 + 1;
+    if (y1 >= Hin) { y1 = Hin - 1; if (y0 >= Hin - 1) { y0 = Hin - 1; fy = 0.f; } }
+    if (x1 >= Win) { x1 = Win - 1; if (x0 >= Win - 1) { x0 = Win - 1; fx = 0.f; } }
+    for (int c = 0; c < C; ++c) {
+        const float p00 = src[((long)y0 * Win + x0) * C + c], p01 = src[((long)y0 * Win + x1) * C + c];
+        const float p10 = src[((long)y1 * Win + x0) * C + c], p11 = src[((long)y1 * Win + x1) * C + c];
+        const float top = p00 + (p01 - p00) * fx, bot = p10 + (p11 - p10) * fx;
+        const float v = fminf(fmaxf(floorf(top + (bot - top) * fy + 0.5f), 0.f), 255.f);
+        out[(long)idx * C + c] = (uint8_t)v;
+    }
+}
+
+// ---- CLAHE (OpenCV clahe.cpp), 8 x 8 tiles, on one uint8 plane with pixel stride `ps` ---------------------------
+__device__ __forceinline__ int reflect101(int p, int n) {   // BORDER_REFLECT_101: gfedcb|abcdefgh|gfedcba
+    if (n == 1) return 0;
+    while (p < 0 || p >= n) p = p < 0 ? -p : 2 * (n - 1) - p;
+    return p;
+}
+
+// one block per tile: histogram of the (reflect-padded) tile, clip, redistribute, cumulative LUT
+__global__ __launch_bounds__(256) void clahe_lut_kernel(const uint8_t* __restrict__ img, int H, int W, int ps, int tw,
+                                                        int th, int clip, uint8_t* __restrict__ lut) {
+    __shared__ int hist[256];
+    __shared__ int scan[256];
+    const int tx = blockIdx.x, ty = blockIdx.y, t = threadIdx.x;
+    hist[t] = 0;
+    __syncthreads();
+    for (int i = t; i < tw * th; i += 256) {
+        const int y = reflect101(ty * th + i / tw, H), x = reflect101(tx * tw + i % tw, W);
+        atomicAdd(&hist[img[((long)y * W + x) * ps]], 1);
+    }
+    __syncthreads();
+    if (clip > 0) {
+        // clipped = sum of the excesses; every bin gets clipped / 256, the residual goes to bins 0, step, 2 step, ...
+        int v = hist[t];
+        const int ex = v > clip ? v - clip : 0;
+        scan[t] = ex;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (t < o) scan[t] += scan[t + o];
+            __syncthreads();
+        }
+        const int clipped = scan[0];
+        __syncthreads();
+        const int batch = clipped / 256;
+        int residual = clipped - batch * 256;
+        v = (v > clip ? clip : v) + batch;
+        if (residual != 0) {
+            int step = 256 / residual;
+            if (step < 1) step = 1;
+            if (t % step == 0 && t / step < residual) ++v;
+        }
+        hist[t] = v;
+        __syncthreads();
+    }
+    // inclusive prefix sum (Hillis-Steele), then lut = saturate(round_half_even(sum * 255 / tile_area))
+    scan[t] = hist[t];
+    __syncthreads();
+    for (int o = 1; o < 256; o <<= 1) {
+        const int add = t >= o ? scan[t - o] : 0;
+        __syncthreads();
+        scan[t] += add;
+        __syncthreads();
+    }
+    const float scale = 255.0f / (float)(tw * th);
+    float r = rintf((float)scan[t] * scale);
+    r = fminf(fmaxf(r, 0.f), 255.f);
+    lut[((long)(ty * gridDim.x + tx)) * 256 + t] = (uint8_t)r;
+}
+
+__global__ __launch_bounds__(256) void clahe_apply_kernel(const uint8_t* __restrict__ img, int H, int W, int ps, int tw,
+                                                          int th, int tiles, const uint8_t* __restrict__ lut,
+                                                          uint8_t* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W;
+    const float txf = (float)x * (1.0f / (float)tw) - 0.5f, tyf = (float)y * (1.0f / (float)th) - 0.5f;
+    int tx1 = (int)floorf(txf), ty1 = (int)floorf(tyf);
+    const float xa = txf - (float)tx1, ya = tyf - (float)ty1;
+    int tx2 = tx1 + 1, ty2 = ty1 + 1;
+    tx1 = tx1 < 0 ? 0 : tx1;
+    ty1 = ty1 < 0 ? 0 : ty1;
+    tx2 = tx2 > tiles - 1 ? tiles - 1 : tx2;
+    ty2 = ty2 > tiles - 1 ? tiles - 1 : ty2;
+    const int v = img[(long)idx * ps];
+    const float l11 = lut[(ty1 * tiles + tx1) * 256 + v], l12 = lut[(ty1 * tiles + tx2) * 256 + v];
+    const float l21 = lut[(ty2 * tiles + tx1) * 256 + v], l22 = lut[(ty2 * tiles + tx2) * 256 + v];
+    const float res = (l11 * (1.0f - xa) + l12 * xa) * (1.0f - ya) + (l21 * (1.0f - xa) + l22 * xa) * ya;
+    out[(long)idx * ps] = (uint8_t)fminf(fmaxf(rintf(res), 0.f), 255.f);
+}
+
+// ---- RGB <-> CIE L*a*b* (D65, sRGB transfer), 8 bit: L * 255 / 100, a + 128, b + 128 ---------------------------
+__device__ __forceinline__ float srgb_to_linear(float c) { return c <= 0.04045f ? c / 12.92f : powf((c + 0.055f) / 1.055f, 2.4f); }
+__device__ __forceinline__ float linear_to_srgb(float c) { return c <= 0.0031308f ? 12.92f * c : 1.055f * powf(c, 1.0f / 2.4f) - 0.055f; }
+__device__ __forceinline__ float lab_f(float t) { return t > 0.008856f ? cbrtf(t) : 7.787f * t + 16.0f / 116.0f; }
+__device__ __forceinline__ uint8_t sat_u8(float v) { return (uint8_t)fminf(fmaxf(rintf(v), 0.f), 255.f); }
+
+__global__ __launch_bounds__(256) void rgb_lab_kernel(const uint8_t* __restrict__ in, long n, int inverse,
+                                                      uint8_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float p0 = in[3 * i], p1 = in[3 * i + 1], p2 = in[3 * i + 2];
+    if (!inverse) {
+        const float r = srgb_to_linear(p0 / 255.f), g = srgb_to_linear(p1 / 255.f), b = srgb_to_linear(p2 / 255.f);
+        const float X = (0.412453f * r + 0.357580f * g + 0.180423f * b) / 0.950456f;
+        const float Y = 0.212671f * r + 0.715160f * g + 0.072169f * b;
+        const float Z = (0.019334f * r + 0.119193f * g + 0.950227f * b) / 1.088754f;
+        const float fx = lab_f(X), fy = lab_f(Y), fz = lab_f(Z);
+        const float L = Y > 0.008856f ? 116.f * fy - 16.f : 903.3f * Y;
+        out[3 * i] = sat_u8(L * 255.f / 100.f);
+        out[3 * i + 1] = sat_u8(500.f * (fx - fy) + 128.f);
+        out[3 * i + 2] = sat_u8(200.f * (fy - fz) + 128.f);
+    } else {
+        const float L = p0 * 100.f / 255.f, a = p1 - 128.f, b = p2 - 128.f;
+        const float fy = (L + 16.f) / 116.f, fx = fy + a / 500.f, fz = fy - b / 200.f;
+        auto inv = [](float t) { return t > 0.206893f ? t * t * t : (t - 16.f / 116.f) / 7.787f; };
+        const float X = inv(fx) * 0.950456f, Y = L > 7.9996f ? inv(fy) : L / 903.3f, Z = inv(fz) * 1.088754f;
+        const float r = 3.240479f * X - 1.537150f * Y - 0.498535f * Z;
+        const float g = -0.969256f * X + 1.875991f * Y + 0.041556f * Z;
+        const float bl = 0.055648f * X - 0.204043f * Y + 1.057311f * Z;
+        out[3 * i] = sat_u8(linear_to_srgb(fminf(fmaxf(r, 0.f), 1.f)) * 255.f);
+        out[3 * i + 1] = sat_u8(linear_to_srgb(fminf(fmaxf(g, 0.f), 1.f)) * 255.f);
+        out[3 * i + 2] = sat_u8(linear_to_srgb(fminf(fmaxf(bl, 0.f), 1.f)) * 255.f);
+    }
+}
+
+// ---- cv2.LUT with a 256-entry table (RandomGamma, RandomBrightness) -------------------------------------------------
+__global__ __launch_bounds__(256) void lut_u8_kernel(const uint8_t* __restrict__ in, long n, const uint8_t* __restrict__ table,
+                                                     uint8_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = table[in[i]];
+}
+
+// ---- cv2.blur(img, (k, k)): normalised box filter, BORDER_REFLECT_101, rounded to nearest -------------------------
+__global__ __launch_bounds__(256) void box_blur_u8_kernel(const uint8_t* __restrict__ in, int H, int W, int C, int k,
+                                                          uint8_t* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W, r = k / 2;
+    for (int c = 0; c < C; ++c) {
+        int s = 0;
+        for (int dy = -r; dy <= r; ++dy)
+            for (int dx = -r; dx <= r; ++dx)
+                s += in[((long)reflect101(y + dy, H) * W + reflect101(x + dx, W)) * C + c];
+        out[(long)idx * C + c] = sat_u8((float)s / (float)(k * k));
+    }
+}
+
+// ---- GaussNoise: image + noise (fp32, given), clipped to [0, 255], cast to uint8 (truncation, as ndarray.astype) -----
+__global__ __launch_bounds__(256) void add_noise_u8_kernel(const uint8_t* __restrict__ in, const float* __restrict__ noise,
+                                                           long n, uint8_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (uint8_t)fminf(fmaxf((float)in[i] + noise[i], 0.f), 255.f);
+}
+
+// ---- ToFloat(255) + Normalize(mean, std, max_pixel_value = 1): uint8 HWC -> fp32 CHW ------------------------------
+__global__ __launch_bounds__(256) void finish_u8_kernel(const uint8_t* __restrict__ in, int S, int C,
+                                                        const float* __restrict__ mean, const float* __restrict__ stdv,
+                                                        float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= S * S) return;
+    for (int c = 0; c < C; ++c) {
+        float v = (float)in[(long)idx * C + c] / 255.0f;
+        if (mean) v = (v - mean[c]) / stdv[c];
+        out[(long)c * S * S + idx] = v;
+    }
+}
+
+}  // namespace primia
+
+using namespace primia;
+
+extern "C" {
+
+int primia_image_affine_u8(const uint8_t* src, int H, int W, int C, float a, float b, float c, float d, float e, float f,
+                           uint8_t* out, primia_stream_t st) {
+    PRIMIA_REQUIRE(src && out && src != out && H > 0 && W > 0 && (C == 1 || C == 3));
+    affine_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(src, H, W, C, a, b, c, d, e, f, out);
+    return launch_status();
+}
+
+int primia_image_resize_crop_u8(const uint8_t* src, int Hin, int Win, int C, int R, int oy, int ox, int S, int flip_v,
+                                uint8_t* out, primia_stream_t st) {
+    PRIMIA_REQUIRE(src && out && Hin > 0 && Win > 0 && (C == 1 || C == 3) && R > 0 && S > 0 && S <= R);
+    PRIMIA_REQUIRE(oy >= 0 && ox >= 0 && oy + S <= R && ox + S <= R);
+    resize_crop_u8_kernel<<<ceil_div((long)S * S, 256), 256, 0, (hipStream_t)st>>>(src, Hin, Win, C, R, oy, ox, S, flip_v, out);
+    return launch_status();
+}
+
+int64_t primia_clahe_workspace_bytes(int H, int W, int C) { return 64 * 256 + (C == 3 ? (int64_t)H * W * 3 : 0); }
+
+int primia_clahe_u8(const uint8_t* img, int H, int W, int C, float clip_limit, void* workspace, int64_t workspace_bytes,
+                    uint8_t* out, primia_stream_t stream) {
+    PRIMIA_REQUIRE(img && out && workspace && H >= 8 && W >= 8 && (C == 1 || C == 3) && clip_limit >= 0.f);
+    if (workspace_bytes < primia_clahe_workspace_bytes(H, W, C)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const int tiles = 8;
+    const int tw = (W + tiles - 1) / tiles, th = (H + tiles - 1) / tiles;      // tile size of the padded image
+    int clip = 0;
+    if (clip_limit > 0.f) {
+        clip = (int)(clip_limit * (float)(tw * th) / 256.0f);
+        if (clip < 1) clip = 1;
+    }
+    uint8_t* lut = (uint8_t*)workspace;
+    const long n = (long)H * W;
+    if (C == 1) {
+        clahe_lut_kernel<<<dim3(tiles, tiles), 256, 0, st>>>(img, H, W, 1, tw, th, clip, lut);
+        clahe_apply_kernel<<<ceil_div(n, 256), 256, 0, st>>>(img, H, W, 1, tw, th, tiles, lut, out);
+    } else {
+        uint8_t* lab = lut + 64 * 256;
+        rgb_lab_kernel<<<ceil_div(n, 256), 256, 0, st>>>(img, n, 0, lab);
+        clahe_lut_kernel<<<dim3(tiles, tiles), 256, 0, st>>>(lab, H, W, 3, tw, th, clip, lut);
+        clahe_apply_kernel<<<ceil_div(n, 256), 256, 0, st>>>(lab, H, W, 3, tw, th, tiles, lut, lab);   // L in place (pointwise)
+        rgb_lab_kernel<<<ceil_div(n, 256), 256, 0, st>>>(lab, n, 1, out);
+    }
+    return launch_status();
+}
+
+int primia_image_lut_u8(const uint8_t* in, int64_t n, const uint8_t* table256, uint8_t* out, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(in && out && table256 && n > 0);
+    lut_u8_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)st>>>(in, n, table256, out);
+    return launch_status();
+}
+
+int primia_image_box_blur_u8(const uint8_t* in, int H, int W, int C, int k, uint8_t* out, primia_stream_t st) {
+    PRIMIA_REQUIRE(in && out && in != out && H > 0 && W > 0 && (C == 1 || C == 3) && k >= 1 && (k & 1) && k <= 15);
+    box_blur_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(in, H, W, C, k, out);
+    return launch_status();
+}
+
+int primia_image_add_noise_u8(const uint8_t* in, const float* noise, int64_t n, uint8_t* out, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(in && noise && out && n > 0);
+    add_noise_u8_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)st>>>(in, noise, n, out);
+    return launch_status();
+}
+
+int primia_image_finish(const uint8_t* in, int S, int C, const float* mean, const float* stdv, float* out,
+                        primia_stream_t st) {
+    PRIMIA_REQUIRE(in && out && S > 0 && (C == 1 || C == 3) && ((mean == nullptr) == (stdv == nullptr)));
+    finish_u8_kernel<<<ceil_div((long)S * S, 256), 256, 0, (hipStream_t)st>>>(in, S, C, mean, stdv, out);
+    return launch_status();
+}
+
+}  // extern "C"

@@ -142,3 +142,51 @@ def label_skew_split(labels, num_workers, alpha=0.5, seed=0):
     for s in shards:
         s.sort()
     return shards
+
+
+def register_federated(samples, onehot, orders, mix: Optional[MixUp]):
+    """One worker's dataset registration (setup_pysyft, torchlib/utils.py:694-734) on device-resident data.
+
+    samples [n, C, H, W] fp32 and onehot [n, classes] fp32 live on the GPU; `orders` holds one index sequence per
+    dataset repetition (with MixUp the reference walks a freshly shuffled DataLoader every repetition; without it, the
+    dataset order).  With `mix`, sample k of the walk is blended with the UNMIXED sample k-1 of the walk through the
+    reference's own call `mixup(((d, last_d), (t, last_t)))` — same `random()` draws (one for p, one more for an unset
+    λ), the blend itself in `primia_mixup`.  Returns (data [n_total, C, H, W], targets [n_total, classes])."""
+    data = torch.empty((sum(len(o) for o in orders), *samples.shape[1:]), dtype=torch.float32, device=samples.device)
+    tgts = torch.empty((data.shape[0], onehot.shape[1]), dtype=torch.float32, device=samples.device)
+    pos, last = 0, None
+    for order in orders:
+        for k in order:
+            d, t = samples[k:k + 1], onehot[k:k + 1]
+            if mix is not None:
+                original = (d, t)
+                if last is not None:
+                    d, t = mix(((d, last[0]), (t, last[1])))
+                last = original
+            data[pos].copy_(d.reshape(samples.shape[1:]))
+            tgts[pos].copy_(t.reshape(-1))
+            pos += 1
+    return data, tgts
+
+
+def calc_class_weights(args, train_loader, num_classes):
+    """torchlib/utils.py:469-513: every class's share of 1 / (its number of training targets), normalised to sum 1.
+    `train_loader` is one loader, or {worker: loader} when federated; soft / one-hot targets (mixup or federated
+    weight_classes) count for their arg-max class.  No target at all -> ones (the reference warns the same way)."""
+    from warnings import warn
+
+    loaders = list(train_loader.values()) if isinstance(train_loader, dict) else [train_loader]
+    soft = bool(getattr(args, "train_federated", False) and (args.mixup or args.weight_classes))
+    occ = torch.zeros(num_classes, dtype=torch.float64)
+    for tl in loaders:
+        for _, target in tl:
+            if soft:
+                target = target.max(dim=1)[1]
+            occ += torch.bincount(target.reshape(-1).to(torch.int64), minlength=num_classes)[:num_classes].double().cpu()
+    occ = occ.to(torch.float32)
+    if torch.sum(occ).item() == 0:
+        warn("class weights could not be calculated - no weights are used")
+        return torch.ones((num_classes,))
+    cw = 1.0 / occ
+    cw /= torch.sum(cw)
+    return cw

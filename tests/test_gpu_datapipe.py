@@ -88,3 +88,64 @@ def test_train_with_mixup_matches_oracle_step(cuda):
     for k in ("fc.weight", "layer4.1.conv2.weight", "layer1.0.bn1.weight", "conv1.weight", "bn1.running_mean"):
         a, b = got[k].double(), osd[k].double()
         assert (a - b).norm() <= 1e-4 * b.norm() + 1e-7, k
+
+
+def test_federated_registration_matches_reference_loop(cuda):
+    """primia_amd.datapipe.register_federated (the blend in primia_mixup) against the output of the reference's own
+    registration loop (torchlib/utils.py:694-734, executed when tests/golden/datapipe.npz was minted): bit-exact."""
+    for name in sorted({k.split(".")[1] for k in GOLD.files if k.startswith("reg.")}):
+        n, reps, mix, lam, p, seed = GOLD[f"reg.{name}.meta"]
+        xs = torch.from_numpy(GOLD[f"reg.{name}.x"]).to(cuda)
+        ys = P.To_one_hot(3)(torch.from_numpy(GOLD[f"reg.{name}.labels"]))
+        orders = GOLD[f"reg.{name}.orders"].tolist()
+        mixer = P.MixUp(λ=None if lam < 0 else float(lam), p=float(p)) if mix else None
+        random.seed(int(seed))
+        d, t = P.register_federated(xs, ys, orders, mixer)
+        assert torch.equal(d.cpu(), torch.from_numpy(GOLD[f"reg.{name}.data"])), name
+        assert torch.equal(t.cpu(), torch.from_numpy(GOLD[f"reg.{name}.targets"])), name
+
+
+def test_class_weights_match_reference_function(cuda):
+    from types import SimpleNamespace
+
+    for name, fed in (("fed_soft", True), ("vanilla_hard", False), ("fed_empty", True)):
+        nw = int(GOLD[f"cw.{name}.n"][0])
+        loaders = {f"w{w}": [(None, torch.from_numpy(t).to(cuda)) for t in GOLD[f"cw.{name}.w{w}"]] for w in range(nw)}
+        args = SimpleNamespace(train_federated=fed, mixup=fed, weight_classes=True, batch_size=4)
+        arg = loaders if fed else (list(loaders.values())[0] if loaders else [])
+        with __import__("warnings").catch_warnings():
+            __import__("warnings").simplefilter("ignore")
+            cw = P.calc_class_weights(args, arg, 3)
+        assert torch.equal(cw.cpu(), torch.from_numpy(GOLD[f"cw.{name}.cw"])), name
+
+
+def test_registered_loader_feeds_soft_targets_and_class_weights_into_the_step(cuda):
+    """The reference's default INI in federated mode (mixup = yes): the loader a client trains on yields soft targets of
+    registered (blended) samples, and the engine's soft-label loss takes the class weights."""
+    from types import SimpleNamespace
+
+    from primia_amd.engine import ResNet18Engine
+    from primia_amd.imagefolder import DeviceLoader, register
+
+    args = SimpleNamespace(train_federated=True, mixup=True, weight_classes=True, mixup_lambda=None, mixup_prob=0.9,
+                           repetitions_dataset=2, batch_size=4)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(6, 3, 32, 32, generator=g).to(cuda)
+    y = torch.randint(0, 3, (6,), generator=g).to(cuda)
+    random.seed(5)
+    data, tg = register([x, x], y, args, 3, seed=1)        # two walks over the dataset (repetitions_dataset = 2)
+    assert data.shape == (12, 3, 32, 32) and tg.shape == (12, 3)
+    assert torch.allclose(tg.sum(1), torch.ones(12, device=cuda), atol=1e-6)
+    assert (tg.max(1)[0] < 1.0).any()                       # some targets are genuinely mixed
+    loader = DeviceLoader(data, tg, 4, True, 1)
+    cw = P.calc_class_weights(args, {"w": loader}, 3)
+    eng = ResNet18Engine(4, 3, 3, 32, "max", dtype=torch.float32, device=cuda)
+    torch.manual_seed(0)
+    eng.init_weights()
+    eng.class_weight = cw.to(cuda).float().contiguous()
+    xb, tb = next(iter(loader))
+    logits = eng.forward(xb)
+    loss = eng.loss_backward(tb, soft=True)
+    ls = torch.log_softmax(logits.float(), 1)
+    want = ((tb * eng.class_weight).sum(1) * (-(tb * ls).sum(1))).mean()       # Cross_entropy_one_hot (utils.py:404-441)
+    assert abs(loss.item() - want.item()) < 1e-5 * max(1.0, abs(want.item()))

@@ -73,7 +73,8 @@ def test_image_prepare_matches_bilinear_reference(cuda, tmp_path, channels):
 
 def test_client_loader_statistics_and_batches(cuda, tmp_path):
     make_folder(str(tmp_path), per_class=6)
-    args = SimpleNamespace(inference_resolution=64, train_resolution=64, batch_size=4, repetitions_dataset=2)
+    args = SimpleNamespace(inference_resolution=64, train_resolution=64, batch_size=4, repetitions_dataset=2,
+                           train_federated=True)       # a federated client registers its dataset repetitions_dataset times
     loader, (mean, std) = imagefolder.client_loader(str(tmp_path), args, cuda, 3, seed=1)
     assert len(loader) == (18 * 2) // 4
     # the dataset is normalised with its own statistics: per-channel mean 0 / std 1 (torch.std_mean, unbiased)
@@ -87,3 +88,13 @@ def test_client_loader_statistics_and_batches(cuda, tmp_path):
     with pytest.raises(ValueError):
         imagefolder.client_loader(str(tmp_path), SimpleNamespace(inference_resolution=64, train_resolution=64,
                                                                  batch_size=64, repetitions_dataset=1), cuda, 3, 1)
+    # vanilla training: a loader that re-augments every epoch; with CLAHE on, the data differ from the plain chain
+    van = SimpleNamespace(inference_resolution=64, train_resolution=64, batch_size=4, train_federated=False, clahe=True,
+                          rotation=10, scale=0.1, albu_prob=0.5, individual_albu_probs=0.5, noise_std=0.05, noise_prob=0.5,
+                          randomgamma=True, blur=True)
+    vl, _ = imagefolder.client_loader(str(tmp_path), van, cuda, 3, seed=1)
+    assert len(vl) == 18 // 4
+    e1 = [x.clone() for x, _ in vl]
+    e2 = [x.clone() for x, _ in vl]
+    assert all(x.shape == (4, 3, 64, 64) and torch.isfinite(x).all() for x in e1)
+    assert not all(torch.equal(a, b) for a, b in zip(e1, e2))

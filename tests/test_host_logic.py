@@ -123,3 +123,37 @@ def test_stats_table_matches_reference_rendering():
         text = stats_table(cm, rep, roc_auc=0.8123, matthews_coeff=0.5678, class_names=names, epoch=7)
         assert text == bytes(gold[f"{name}.table"]).decode("utf-8")
         assert abs(matthews_corrcoef(t.tolist(), p.tolist(), 3) - mt.matthews_corrcoef(t, p)) < 1e-12
+
+
+def test_distribute_data_tool_deals_like_the_reference_script(tmp_path):
+    """tools/distribute_data.py: the IID deal is the reference's (random.seed(0) shuffle, i::num_workers — pinned in
+    tests/golden/datapipe.npz against distribute_data.py itself), the label-skew deal assigns every image exactly once."""
+    import importlib.util
+    import os
+
+    from oracle import datapipe_oracle as D
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("distribute_data", os.path.join(root, "tools", "distribute_data.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    src, tst = tmp_path / "train", tmp_path / "test"
+    names = []
+    for ci, c in enumerate(("a_normal", "b_bact", "c_viral")):
+        for d in (src, tst):
+            (d / c).mkdir(parents=True)
+        for k in range(5 + 2 * ci):
+            (src / c / f"{c}_{k}.png").write_bytes(b"x")
+            names.append(f"{c}_{k}.png")
+        (tst / c / f"t_{c}.png").write_bytes(b"y")
+    out = tmp_path / "sim"
+    shards = mod.main(["--train_data_src", str(src), "--test_data_src", str(tst), "--num_workers", "3", "--out", str(out), "-s"])
+    assert shards == D.iid_round_robin_split(len(names), 3)
+    got = sorted(f for w in range(3) for _, _, fs in os.walk(out / f"worker{w + 1}") for f in fs)
+    assert got == sorted(names)
+    assert sorted(os.listdir(out / "validation")) == ["a_normal", "b_bact", "c_viral"]
+    out2 = tmp_path / "skew"
+    shards2 = mod.main(["--train_data_src", str(src), "--test_data_src", "", "--num_workers", "4", "--out", str(out2),
+                        "--label_skew", "0.3", "-s"])
+    assert sorted(i for s in shards2 for i in s) == list(range(len(names)))
+    assert len({len(s) for s in shards2}) > 1            # skewed shards are uneven

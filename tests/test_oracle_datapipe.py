@@ -95,3 +95,59 @@ def test_iid_split_against_reference_script(golden_dir):
             parts = fn(n_items, nw)
             got = np.array([len(s) for s in parts] + [v for s in parts for v in s[:8]])
             assert np.array_equal(got, want), (n_items, nw)
+
+
+def _reg_cases():
+    return sorted({k.split(".")[1] for k in GOLD.files if k.startswith("reg.")})
+
+
+def test_federated_registration_oracle_matches_reference_loop():
+    """setup_pysyft's registration loop (torchlib/utils.py:694-734), executed from the reference's file when the
+    fixture was minted: MixUp pairing with the previous unmixed sample, the random() draw order, repetitions."""
+    assert _reg_cases() == ["mix_always", "mix_fixed", "mix_rand_lambda", "onehot_only"]
+    for name in _reg_cases():
+        n, reps, mix, lam, p, seed = GOLD[f"reg.{name}.meta"]
+        xs = torch.from_numpy(GOLD[f"reg.{name}.x"])
+        ys = D.to_one_hot(torch.from_numpy(GOLD[f"reg.{name}.labels"]), 3)
+        orders = GOLD[f"reg.{name}.orders"].tolist()
+        d, t = D.register_federated(list(xs), list(ys), orders, bool(mix), None if lam < 0 else float(lam), float(p),
+                                    rng=random.Random(int(seed)))
+        assert torch.equal(d, torch.from_numpy(GOLD[f"reg.{name}.data"])), name
+        assert torch.equal(t, torch.from_numpy(GOLD[f"reg.{name}.targets"])), name
+        assert d.shape[0] == int(n) * int(reps)
+
+
+def test_class_weights_oracle_matches_reference_function():
+    for name, soft in (("fed_soft", True), ("vanilla_hard", False), ("fed_empty", True)):
+        nw = int(GOLD[f"cw.{name}.n"][0])
+        loaders = [[(None, torch.from_numpy(t)) for t in GOLD[f"cw.{name}.w{w}"]] for w in range(nw)]
+        cw = D.calc_class_weights(loaders, 4, 3, soft)
+        assert torch.equal(cw, torch.from_numpy(GOLD[f"cw.{name}.cw"])), name
+
+
+def test_augmentation_oracle_properties():
+    """oracle/augment_oracle.py: identities and invariants of the restated image arithmetic (its parity with cv2's
+    binaries is unpinned — this checks the restatement against the definitions it follows)."""
+    from oracle import augment_oracle as A
+
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, size=(40, 56, 3), dtype=np.uint8)
+    ident = A.inverse_affine_matrix((56 * 0.5 + 0.5, 40 * 0.5 + 0.5), 0, (0, 0), 1.0, 0)
+    assert np.array_equal(A.affine_nearest(img, ident), img)
+    sq = rng.integers(0, 256, size=(41, 41), dtype=np.uint8)
+    # (about the geometric centre W / 2; torchvision 0.5 passes W / 2 + 0.5, which shifts a rotation by one pixel)
+    rot = A.inverse_affine_matrix((20.5, 20.5), 90, (0, 0), 1.0, 0)
+    assert np.array_equal(A.affine_nearest(sq, rot), np.rot90(sq, 1)) or np.array_equal(A.affine_nearest(sq, rot), np.rot90(sq, -1))
+    assert np.array_equal(A.resize_crop(img, 40, 0, 0, 40)[:, :, 0].shape, (40, 40))
+    assert np.array_equal(A.resize_crop(sq, 41, 0, 0, 41), sq)                       # same size: identity
+    assert np.array_equal(A.box_blur(np.full((9, 9), 77, np.uint8), 5), np.full((9, 9), 77, np.uint8))
+    g1 = A.gamma_table(1.0).astype(int)       # (i / 255) * 255 truncated: within one level of the identity, monotone
+    assert np.abs(g1 - np.arange(256)).max() <= 1 and (np.diff(g1) >= 0).all()
+    assert (A.gamma_table(0.8).astype(int) >= A.gamma_table(1.2).astype(int)).all()
+    assert np.array_equal(A.brightness_table(1.0, 0.0), np.arange(256, dtype=np.uint8))
+    flat = np.full((64, 64), 90, np.uint8)
+    out = A.clahe_plane(flat, 1.0)
+    assert out.min() == out.max()                                                    # a flat image stays flat
+    ramp = np.tile(np.arange(64, dtype=np.uint8) * 2, (64, 1))
+    eq = A.clahe_plane(ramp, 40.0)
+    assert eq.max() > ramp.max() and eq.shape == ramp.shape                          # contrast stretched

@@ -33,6 +33,8 @@ import shutil
 from os import path
 from warnings import warn
 
+from types import SimpleNamespace
+
 import numpy as np
 import torch
 
@@ -45,18 +47,75 @@ WEBSOCKETS_CONFIG = os.environ.get("PRIMIA_WEBSOCKETS_CONFIG", "configs/websetti
 
 
 class SyntheticLoader:
-    """Device-resident synthetic shard: yields (x fp32 NCHW on the GPU, int64 labels)."""
+    """Device-resident synthetic shard: yields (x fp32 NCHW on the GPU, int64 labels) — or, with `args` of a federated
+    run that has mixup / weight_classes on, the registered form of the same samples (one-hot rows, each sample blended
+    with its predecessor: torchlib/utils.py:680-734 through primia_amd.imagefolder.register)."""
 
-    def __init__(self, n_batches, batch, size, num_classes, device, seed, channels=3):
+    def __init__(self, n_batches, batch, size, num_classes, device, seed, channels=3, args=None):
         g = torch.Generator().manual_seed(seed)
         self.data = [(torch.randn(batch, channels, size, size, generator=g).to(device),
                       torch.randint(0, num_classes, (batch,), generator=g).to(device)) for _ in range(n_batches)]
+        if args is not None and getattr(args, "train_federated", False) and (args.mixup or args.weight_classes):
+            from types import SimpleNamespace
+
+            from primia_amd.imagefolder import register
+
+            once = SimpleNamespace(**{**vars(args), "repetitions_dataset": 1})   # synthetic shards are not repeated
+            x, y = register([torch.cat([d for d, _ in self.data])], torch.cat([t for _, t in self.data]), once,
+                            num_classes, seed)
+            self.data = [(x[i * batch:(i + 1) * batch], y[i * batch:(i + 1) * batch]) for i in range(n_batches)]
 
     def __len__(self):
         return len(self.data)
 
     def __iter__(self):
         return iter(self.data)
+
+
+def class_counts(train_loader, num_classes, soft_targets):
+    """Occurrences of every class over this process's training targets (the counting loop of calc_class_weights)."""
+    loaders = list(train_loader.values()) if isinstance(train_loader, dict) else [train_loader]
+    occ = torch.zeros(num_classes, dtype=torch.float32)
+    for tl in loaders:
+        for _, target in tl:
+            if soft_targets and target.dim() == 2:
+                target = target.max(dim=1)[1]
+            occ += torch.bincount(target.reshape(-1).to(torch.int64), minlength=num_classes)[:num_classes].float().cpu()
+    return occ
+
+
+PRETRAINED_FILES = ("resnet18-5c106cde.pth", "resnet18-f37072fd.pth")      # torchvision's ImageNet ResNet-18 files
+
+
+def load_pretrained(engine, num_classes):
+    """`pretrained = yes` (torchlib/models.py:488-496): the ImageNet state dict goes into the freshly constructed
+    network, then `fc` is REPLACED by a new Linear(512, num_classes) with torch's default initialisation.  The
+    reference downloads the file; here it is read from PRIMIA_PRETRAINED_RESNET18 or torch's hub cache
+    (~/.cache/torch/hub/checkpoints/) — there is no network on the training box.  Without the file the run continues
+    from the random initialisation with a warning (it still has the three-channel stem `pretrained` selects)."""
+    cands = [os.environ.get("PRIMIA_PRETRAINED_RESNET18")] + [
+        path.join(path.expanduser("~"), ".cache", "torch", "hub", "checkpoints", f) for f in PRETRAINED_FILES]
+    src = next((c for c in cands if c and path.isfile(c)), None)
+    if src is None:
+        warn("pretrained = yes, but no ImageNet ResNet-18 state dict was found (set PRIMIA_PRETRAINED_RESNET18 to a "
+             "torchvision resnet18 .pth): training starts from the random initialisation")
+        return False
+    sd = torch.load(src, map_location="cpu", weights_only=True)
+    own = engine.state_dict()
+    if engine.norm != "batch":
+        raise SystemExit("pretrained ImageNet weights carry BatchNorm statistics; differentially_private = yes builds "
+                         "a GroupNorm network (train.py:304-334)")
+    for k, v in sd.items():
+        if k.startswith("fc."):
+            continue
+        if k not in own or tuple(own[k].shape) != tuple(v.shape):
+            raise SystemExit("{:s}: {:s} does not fit this network ({} vs {})".format(
+                src, k, tuple(v.shape), tuple(own[k].shape) if k in own else None))
+        own[k] = v.to(torch.float32)
+    fc = torch.nn.Linear(512, num_classes)            # model.fc = nn.Linear(512 * block.expansion, num_classes)
+    own["fc.weight"], own["fc.bias"] = fc.weight.detach().clone(), fc.bias.detach().clone()
+    engine.load_state_dict(own)
+    return True
 
 
 def setup_workers(args):
@@ -156,10 +215,10 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
             eng.dp_params = {"max_grad_norm": 1.0, "noise_multiplier": 1.3}
         return eng
 
-    # `pretrained` only selects the three-channel stem here: there is no network to fetch ImageNet weights from
-    # (models.py:505-514 downloads them); start from a checkpoint with --resume_checkpoint instead.
     local = make_engine()
     local.init_weights()
+    if args.pretrained:
+        load_pretrained(local, num_classes)
     val_mean_std = (torch.zeros(channels), torch.ones(channels))
     exp_name = "{:s}_{:s}".format("federated" if args.train_federated else "vanilla", args.name)
     group = None
@@ -188,7 +247,7 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
             if synthetic:
                 # deliberately uneven shards (exercises weighted averaging and exhausted clients)
                 train_loader[w] = SyntheticLoader(max(1, n_batches - i), args.batch_size, size, num_classes, device,
-                                                  args.seed + i, channels)
+                                                  args.seed + i, channels, args)
                 stats[w] = (torch.zeros(channels, device=device), torch.ones(channels, device=device))
             else:
                 train_loader[w], stats[w] = imagefolder.client_loader(
@@ -204,7 +263,9 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
             m, s = fed.secure_mean_of([stats[w] for w in mine])
         val_mean_std = (m.cpu(), s.cpu())
         optimizer = {w: EngineOptimizer.from_args(model[w], args) for w in mine}
-        loss_fn = {w: None for w in mine}
+        # train.py:335-342: Cross_entropy_one_hot (soft targets) with mixup or federated weight_classes
+        soft = bool(args.mixup or args.weight_classes)
+        loss_fn = {w: SimpleNamespace(soft=soft) for w in mine}
     else:
         workers, mine = [], []
         model = local
@@ -221,6 +282,23 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
         val_loader = imagefolder.validation_loader(path.join(args.data_dir, "validation"), args, device, channels,
                                                    val_mean_std)
 
+    # class weights (train.py:192-195, utils.py:469-513): counted over the training targets of every client — across
+    # ranks the per-class counts are summed — and handed to every engine's loss
+    if args.weight_classes:
+        from primia_amd.datapipe import calc_class_weights
+
+        cw = calc_class_weights(args, train_loader, num_classes)
+        if world > 1:
+            import torch.distributed as dist
+
+            # (the weights are not additive across clients: the counts are what is exchanged)
+            occ = class_counts(train_loader, num_classes, soft_targets=bool(args.train_federated)).to(device)
+            dist.all_reduce(occ)
+            cw = torch.ones(num_classes) if occ.sum().item() == 0 else ((1.0 / occ) / (1.0 / occ).sum()).float().cpu()
+        engines = [m for m in model.values()] if isinstance(model, dict) else [model]
+        for m in engines:
+            m.class_weight = cw.to(device).float().contiguous()
+
     start_at_epoch = 1
     if cmd_args is not None and getattr(cmd_args, "resume_checkpoint", None):
         print("Resume training from a given checkpoint.")
@@ -236,7 +314,8 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
         if args.train_federated and world > 1:
             w = mine[0]
             avg_loss, _, local_flat, optimizer[w] = fed.federated_epoch(
-                model[w], train_loader[w], args, optimizer[w], group=group, local_flat=local_flat, masks=masks)
+                model[w], train_loader[w], args, optimizer[w], group=group, local_flat=local_flat, masks=masks,
+                soft_targets=bool(args.mixup or args.weight_classes))
             local.flat.copy_(local_flat)              # "local_model": the last global average
             for b in local.num_batches_tracked:
                 local.num_batches_tracked[b] = 0
