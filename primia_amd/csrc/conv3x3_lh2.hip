@@ -63,6 +63,9 @@ struct Lh2Params {
 #ifndef LH2_PRIO
 #define LH2_PRIO 1
 #endif
+#ifndef LH2_SWAP
+#define LH2_SWAP 0
+#endif
 #ifdef LH2_PROF
 #define LH2_MARK(slot)                                 \
     {                                                  \
@@ -74,15 +77,16 @@ struct Lh2Params {
 #define LH2_MARK(slot)
 #endif
 
-constexpr int kL2Slots = 456;                       // halo slots per buffer (57 DMA pieces of 8 slots)
-constexpr int kL2Pieces = kL2Slots / 8;
-constexpr int kL2Halo = kL2Slots * 128;             // 58,368 B
+constexpr int kL2Slots = 464;                       // halo slots per buffer
+constexpr int kL2Plane = kL2Slots * 64;             // 29,696 B: one 32-channel half of every slot (29 DMA pieces of 16 slots)
+constexpr int kL2Halo = 2 * kL2Plane;               // 59,392 B
 constexpr int kL2Half = 128 * 64;                   // 8 KiB: one 32-channel half of a step's weight tile
 constexpr int kL2OffA0 = 2 * kL2Halo;               // ring of 2: first halves
 constexpr int kL2OffA1 = kL2OffA0 + 2 * kL2Half;    // ring of 3: second halves
 constexpr int kL2OffScr = kL2OffA1 + 3 * kL2Half;   // BatchNorm partials of the four pixel groups [4][2][128] fp32
-constexpr int kL2Lds = kL2OffScr + 4 * 2 * 128 * 4; // 161,792 B
+constexpr int kL2Lds = kL2OffScr + 4 * 2 * 128 * 4; // 163,840 B = all of a CU's LDS
 constexpr int kL2ZeroSlot = kL2Slots - 1;           // never live (live slots <= 450): zero-filled with every chunk
+static_assert(kL2Lds <= 163840, "LDS budget");
 constexpr unsigned kL2Oob = 0xfffffff0u;
 
 __device__ __forceinline__ void l2_dma(unsigned voff, i32x4_t rsrc, unsigned soff, unsigned lds_addr) {
@@ -154,17 +158,22 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
     const i32x4_t rs_wt = l2_rsrc(p.wt, (long)Nd * klen * 2);
 
     // ---- staging addresses ------------------------------------------------------------------------------
-    // Halo piece q: slots 8q .. 8q+7, this lane: slot 8q + lane/8, LDS chunk lane%8 <- source chunk (lane%8) ^ key(slot).
-    // The pieces of a wave are q = qb + 4k (8k in the prologue): slot = hslot + 8 (q - qb), and the swizzle key
-    // (slot >> 1) & 7 is the same for all of them, so ONE per-lane byte offset serves every piece; the pixel part goes
-    // into the per-lane offset as well (not into soffset: the range check must see it).
-    int hslot = (lane >> 3) + 8 * wh;
-    const auto hvbase = [&]() { return (unsigned)((hslot * Cs + (((lane & 7) ^ ((hslot >> 1) & 7)) << 3)) * 2); };
-    auto halo_piece = [&](int q, int dq, int hm0, int c, int buf) {   // q = qb + dq (dq a multiple of 4)
-        unsigned voff = hvbase() + (unsigned)((hm0 + 8 * dq) * Cs * 2);
-        if (hslot + 8 * dq >= nslots) voff = kL2Oob;
-        l2_dma(voff, rs_src, __builtin_amdgcn_readfirstlane((unsigned)(c * 128)),
-               __builtin_amdgcn_readfirstlane(lds0 + buf * kL2Halo + q * 1024));
+    // Halo image of a chunk = two planes (channels 0-31 | 32-63 of every slot, 64 B each): the second half of a pixel
+    // fragment then sits at a CONSTANT distance from the first (an immediate offset of its ds_read, no address
+    // arithmetic inside the matrix segment).  Piece q (0..57): plane q / 29, slots 16 (q % 29) .. +15; this lane: slot
+    // + lane / 4, LDS chunk lane % 4 <- source chunk (lane % 4) ^ key(slot >> 2), and (slot >> 2) & 3 = lane >> 4 for
+    // every piece, so ONE per-lane byte offset serves all pieces; the pixel part goes into the per-lane offset as well
+    // (not into soffset: the range check must see it).
+    // A wave stages ONE plane (wave & 1) and every second (prologue: fourth) piece of it: piece r = r0 + step * k.
+    const int hplane = wave & 1;
+    int hr0 = wh >> 1;                                   // main loop (B waves): r = (wh >> 1) + 2k; prologue: (wave >> 1) + 4k
+    auto halo_piece = [&](int k, int step, int hm0, int c, int buf) {
+        const int hslot = (lane >> 2) + 16 * hr0;        // slot of piece r0 (per-lane, loop-invariant)
+        const unsigned hvbase = (unsigned)((hslot * Cs + (((lane & 3) ^ ((0x78 >> (2 * (lane >> 4))) & 3)) << 3)) * 2);
+        unsigned voff = hvbase + (unsigned)((hm0 + 16 * step * k) * Cs * 2);
+        if (hslot + 16 * step * k >= nslots) voff = kL2Oob;
+        l2_dma(voff, rs_src, __builtin_amdgcn_readfirstlane((unsigned)(c * 128 + hplane * 64)),
+               __builtin_amdgcn_readfirstlane(lds0 + buf * kL2Halo + hplane * kL2Plane + (hr0 + step * k) * 1024));
     };
     // Weight half-tile piece pc (0..7): rows 16pc .. 16pc+15, this lane: row 16pc + lane/4, LDS chunk lane%4 <- source
     // chunk (lane%4) ^ key(row >> 2); (row >> 2) & 3 = lane >> 4 for every piece.
@@ -177,7 +186,7 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
     // ---- fragment read addresses ---------------------------------------------------------------------------
     // weights: row wn*64 + 16i + fr of a half tile, 16-byte chunk fg; + i * 1024
     const int aoff = (wn * 64 + fr) * 64 + ((fg ^ ((0x78 >> (2 * (fr >> 2))) & 3)) << 4);
-    // pixels: fragment j covers tile pixels 16 (F0 + j) + fr, halo slot at shift 0 = that + W + 1; + j * 2048
+    // pixels: fragment j covers tile pixels 16 (F0 + j) + fr, halo slot at shift 0 = that + W + 1; + j * 1024
     int sj0 = 16 * F0 + fr + W + 1;
 
     f32x4 acc[4][JW];
@@ -222,10 +231,15 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
     };
 
     // ---- write-back from the accumulator registers -----------------------------------------------------------
-    // A lane (fr, fg) holds channels 16i + 4fg .. +3 (i = 0..3) of pixel 16 (F0 + j) + fr.  Per pair of fragments
-    // (i = 2b, 2b+1) a v_permlane16_swap between the lane rows fg = 2a and 2a+1 leaves an even row with channels
-    // 16 (2b) + 8a .. +7 and an odd row with channels 16 (2b+1) + 8a .. +7: 16 contiguous bytes per lane, the four
-    // rows of a pixel together 64 contiguous bytes per store instruction.
+    // A lane (fr, fg) holds channels 16i + 4fg .. +3 (i = 0..3) of pixel 16 (F0 + j) + fr.
+    //  (1) per pair of fragments (i = 2b, 2b+1) a v_permlane16_swap between the lane rows fg = 2a and 2a+1 leaves an
+    //      even row with channels 16 (2b) + 8a .. +7 and an odd row with channels 16 (2b+1) + 8a .. +7: 16 contiguous
+    //      bytes per lane, i.e. pieces P0 (channels 0-31 of the wave's 64) and P1 (32-63) of the lane's pixel;
+    //  (2) the two 8-lane halves of every row trade pieces (DPP row_ror:8), so that ONE store instruction carries
+    //      complete 128-byte lines: pixels fr & 7 in the first, 8 + (fr & 7) in the second (lanes fr < 8 hold P0, lanes
+    //      fr >= 8 hold P1).  The CU's store path takes ~16 B/clk whatever the pattern (tools/micro/store_burst.hip:
+    //      16.1 B/clk for whole lines, 13.8 for half lines, 7.9 for 8-byte stores): a 100-KB tile is ~6,500 cycles of
+    //      store issue, which is why the stores go FIRST and the BatchNorm sums are formed while they drain.
     auto epilogue = [&]() {
         if (LH2_DBG & 1) {
 #pragma unroll
@@ -234,97 +248,128 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
                 for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i][j]));
             return;
         }
-        float s1[4][4], s2[4][4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s1[i][e] = s2[i][e] = 0.f;
-        unsigned row0 = (unsigned)(m0 + 16 * F0 + fr);
-        // this lane's 16-byte piece after the swap: fragment 2b + (fg & 1), channels 8 (fg >> 1) .. +7 of it
-        const unsigned col0 = (unsigned)(n0 + wn * 64 + 16 * (fg & 1) + 8 * (fg >> 1));
+        unsigned row0 = (unsigned)(m0 + 16 * F0 + (fr & 7));
+        const int hi8 = fr >> 3;                            // 0: this lane stores P0 pieces, 1: P1 pieces
+        // this lane's 16-byte piece: fragment 2 hi8 + (fg & 1), channels 8 (fg >> 1) .. +7 of it
+        const unsigned col0 = (unsigned)(n0 + wn * 64 + 32 * hi8 + 16 * (fg & 1) + 8 * (fg >> 1));
         // (m0 / n0 are known when the tile starts: without this the store addresses are computed there and stay in
         // registers through the whole main loop)
         asm volatile("" : "+v"(row0));
+        auto ror8 = [](uint32_t v) {
+            return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);   // row_ror:8
+        };
 #pragma unroll
         for (int j = 0; j < JW; ++j) {
-            const int pl = 16 * (F0 + j) + fr;
-            const bool ok = pl < BM && m0 + pl < p.M;
-            u32x4 oldv[2];
-            unsigned mkb[2];
+            // rows of this lane in the two stores of fragment j: pixels (fr & 7) and 8 + (fr & 7)
+            const int plA = 16 * (F0 + j) + (fr & 7), plB = plA + 8;
+            const bool okA = plA < BM && m0 + plA < p.M, okB = plB < BM && m0 + plB < p.M;
+            const unsigned eoA = (row0 + 16 * j) * (unsigned)Nd + col0, eoB = eoA + 8u * (unsigned)Nd;
+            u32x4 oldA = {0u, 0u, 0u, 0u}, oldB = {0u, 0u, 0u, 0u};
+            unsigned mkA = 0xffu, mkB = 0xffu;
             if constexpr (ACC) {
-#pragma unroll
-                for (int bq = 0; bq < 2; ++bq) {
-                    const unsigned eo = (row0 + 16 * j) * (unsigned)Nd + col0 + 32 * bq;
-                    oldv[bq] = u32x4{0u, 0u, 0u, 0u};
-                    mkb[bq] = 0xffu;
-                    if (ok) {
-                        oldv[bq] = *(const u32x4*)((const char*)p.dst + (size_t)(eo * 2u));
-                        if (p.acc_mask) mkb[bq] = p.acc_mask[eo >> 3];
-                    }
+                if (okA) {
+                    oldA = *(const u32x4*)((const char*)p.dst + (size_t)(eoA * 2u));
+                    if (p.acc_mask) mkA = p.acc_mask[eoA >> 3];
+                }
+                if (okB) {
+                    oldB = *(const u32x4*)((const char*)p.dst + (size_t)(eoB * 2u));
+                    if (p.acc_mask) mkB = p.acc_mask[eoB >> 3];
                 }
             }
-            u32x2 o[4];
+            f32x4 v[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                o[i][0] = (uint32_t)f32_to_bf16(acc[i][j][0]) | ((uint32_t)f32_to_bf16(acc[i][j][1]) << 16);
-                o[i][1] = (uint32_t)f32_to_bf16(acc[i][j][2]) | ((uint32_t)f32_to_bf16(acc[i][j][3]) << 16);
-            }
+            for (int i = 0; i < 4; ++i) v[i] = acc[i][j];
             if constexpr (ACC) {
-                // bring the old values into the accumulators' lane layout (the inverse swap), add in fp32, round once
-#pragma unroll
-                for (int bq = 0; bq < 2; ++bq) {
-                    u32x4 ov = oldv[bq];
-                    const unsigned mk = mkb[bq];
+                // the old values travel the two exchanges backwards into the accumulators' lane layout, are added in
+                // fp32 and the sum is rounded once
+                auto masked = [](u32x4 o, unsigned mk) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        ov[e] &= ((mk >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((mk >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+                        o[e] &= ((mk >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((mk >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+                    return o;
+                };
+                const u32x4 a_ = masked(oldA, mkA), b_ = masked(oldB, mkB);
+                // lanes fr < 8 hold (own P0 of pixel fr in A, P0 of pixel fr + 8 in B); lanes fr >= 8 hold (P1 of pixel
+                // fr - 8 in A, own P1 in B): what is not the lane's own pixel goes back across the row halves
+                u32x4 p0, p1;       // this lane's pixel: pieces P0 and P1 (post-swap layout)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t give = hi8 ? a_[e] : b_[e];
+                    const uint32_t got = ror8(give);
+                    p0[e] = hi8 ? got : a_[e];
+                    p1[e] = hi8 ? b_[e] : got;
+                }
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) {
+                    const u32x4 ov = bq ? p1 : p0;
                     uint32_t x0 = ov[0], x1 = ov[1], y0 = ov[2], y1 = ov[3];   // (x | y) = quarters (2a | 2a+1) of a fragment
                     l2_swap16(x0, y0);
                     l2_swap16(x1, y1);
                     // now x = fragment 2bq, y = fragment 2bq+1, both this lane's own quarter fg
                     const uint32_t ox[2][2] = {{x0, x1}, {y0, y1}};
 #pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        const int i = 2 * bq + s;
-                        f32x4 v = acc[i][j];
-                        v[0] += __uint_as_float(ox[s][0] << 16);
-                        v[1] += __uint_as_float(ox[s][0] & 0xffff0000u);
-                        v[2] += __uint_as_float(ox[s][1] << 16);
-                        v[3] += __uint_as_float(ox[s][1] & 0xffff0000u);
-                        o[i][0] = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        o[i][1] = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    for (int s_ = 0; s_ < 2; ++s_) {
+                        const int i = 2 * bq + s_;
+                        v[i][0] += __uint_as_float(ox[s_][0] << 16);
+                        v[i][1] += __uint_as_float(ox[s_][0] & 0xffff0000u);
+                        v[i][2] += __uint_as_float(ox[s_][1] << 16);
+                        v[i][3] += __uint_as_float(ox[s_][1] & 0xffff0000u);
                     }
                 }
             }
-            if (!ACC && p.stat_partials && ok) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float r0 = __uint_as_float(o[i][0] << 16), r1 = __uint_as_float(o[i][0] & 0xffff0000u);
-                    const float r2 = __uint_as_float(o[i][1] << 16), r3 = __uint_as_float(o[i][1] & 0xffff0000u);
-                    s1[i][0] += r0; s2[i][0] += r0 * r0;
-                    s1[i][1] += r1; s2[i][1] += r1 * r1;
-                    s1[i][2] += r2; s2[i][2] += r2 * r2;
-                    s1[i][3] += r3; s2[i][3] += r3 * r3;
-                }
-            }
+            u32x4 pc[2];        // P0, P1 of this lane's pixel
 #pragma unroll
             for (int bq = 0; bq < 2; ++bq) {
-                uint32_t x0 = o[2 * bq][0], x1 = o[2 * bq][1], y0 = o[2 * bq + 1][0], y1 = o[2 * bq + 1][1];
+                uint32_t x0 = (uint32_t)f32_to_bf16(v[2 * bq][0]) | ((uint32_t)f32_to_bf16(v[2 * bq][1]) << 16);
+                uint32_t x1 = (uint32_t)f32_to_bf16(v[2 * bq][2]) | ((uint32_t)f32_to_bf16(v[2 * bq][3]) << 16);
+                uint32_t y0 = (uint32_t)f32_to_bf16(v[2 * bq + 1][0]) | ((uint32_t)f32_to_bf16(v[2 * bq + 1][1]) << 16);
+                uint32_t y1 = (uint32_t)f32_to_bf16(v[2 * bq + 1][2]) | ((uint32_t)f32_to_bf16(v[2 * bq + 1][3]) << 16);
                 l2_swap16(x0, y0);
                 l2_swap16(x1, y1);
-                const unsigned eo = (row0 + 16 * j) * (unsigned)Nd + col0 + 32 * bq;
-                if (ok) *(u32x4*)((char*)p.dst + (size_t)(eo * 2u)) = u32x4{x0, x1, y0, y1};
+                pc[bq] = u32x4{x0, x1, y0, y1};
             }
+            u32x4 stA, stB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t give = hi8 ? pc[0][e] : pc[1][e];       // the piece the other half of the row stores
+                const uint32_t got = ror8(give);
+                stA[e] = hi8 ? got : pc[0][e];                         // pixel fr & 7:       P0 from lanes < 8, P1 via lanes >= 8
+                stB[e] = hi8 ? pc[1][e] : got;                         // pixel 8 + (fr & 7)
+            }
+            if (okA) *(u32x4*)((char*)p.dst + (size_t)(eoA * 2u)) = stA;
+            if (okB) *(u32x4*)((char*)p.dst + (size_t)(eoB * 2u)) = stB;
         }
         if (!ACC && p.stat_partials) {
-            // fold the 16 pixels of a row (same fg), then one lane per fg parks the pixel group's partial in LDS; the B
-            // half adds the four groups in a fixed order after the next barrier (stat_combine)
-            float* scr = (float*)(smem + kL2OffScr) + (wave >> 1) * 256;
+            // BatchNorm partial sums of the values AS STORED, formed while the stores drain: the accumulators are still
+            // intact, rounding them again gives the stored bits.  Fold the 16 pixels of a row (same fg), then one lane per
+            // fg parks the pixel group's partial in LDS; the B half adds the four groups in a fixed order after the next
+            // barrier (stat_combine).
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 s1[4][2], s2[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) s1[i][h] = s2[i][h] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                const int pl = 16 * (F0 + j) + fr;
+                const bool ok = pl < BM && m0 + pl < p.M;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x2 r = {bf16_to_f32(f32_to_bf16(acc[i][j][2 * h])), bf16_to_f32(f32_to_bf16(acc[i][j][2 * h + 1]))};
+                        if (!ok) r = f32x2{0.f, 0.f};
+                        s1[i][h] += r;
+                        s2[i][h] += r * r;
+                    }
+            }
+            float* scr = (float*)(smem + kL2OffScr) + (F0 == 0 ? 0 : (F0 - 1) / (BM == 392 ? 6 : 3)) * 256;   // pixel group 0..3
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t1 = l2_row_sum(s1[i][e]), t2 = l2_row_sum(s2[i][e]);
+                    const float t1 = l2_row_sum(s1[i][e >> 1][e & 1]), t2 = l2_row_sum(s2[i][e >> 1][e & 1]);
                     if (fr == 0) {
                         const int ch = wn * 64 + 16 * i + 4 * fg + e;
                         scr[ch] = t1;
@@ -336,7 +381,7 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
     // B half, one segment after both halves' write-back: thread -> (q, channel); groups added in the order 0,1,2,3
     auto stat_combine = [&](int tm_, int n0_) {
         if (ACC || !p.stat_partials || ISA) return;
-        const int t = tid - 256;
+        const int t = tid & 255;
         const int q = t >> 7, ch = t & 127;
         const float* scr = (const float*)(smem + kL2OffScr);
         float s = scr[q * 128 + ch];
@@ -358,16 +403,18 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
             for (int i = 0; i < 4; ++i) a0[i] = *(const bf16x8_t*)(w0p + (aoff + i * 1024));
             constexpr int tr = tap / 3, ts = tap - 3 * tr;
             const int slot = sj0 + (FLIP ? (1 - tr) * W + (1 - ts) : (tr - 1) * W + (ts - 1));
-            const int offt = slot * 128 + ((fg ^ ((slot >> 1) & 7)) << 4) + hbuf * kL2Halo;
-            const int zoff = kL2ZeroSlot * 128 + hbuf * kL2Halo;
+            const int offt = slot * 64 + ((fg ^ ((0x78 >> (2 * ((slot >> 2) & 3))) & 3)) << 4) + hbuf * kL2Halo;
+            const int zoff = kL2ZeroSlot * 64 + hbuf * kL2Halo;
 #pragma unroll
             for (int j = 0; j < JW; ++j) {
                 // an invalid tap reads the zero slot (minus the fragment's immediate offset)
-                bad[j] = ((pmask[j / 3] >> (9 * (j % 3) + tap)) & 1u) ? offt : zoff - j * 2048;
-                b[j] = *(const bf16x8_t*)(smem + (bad[j] + j * 2048));
+                bad[j] = ((pmask[j / 3] >> (9 * (j % 3) + tap)) & 1u) ? offt : zoff - j * 1024;
+                b[j] = *(const bf16x8_t*)(smem + (bad[j] + j * 1024));
             }
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // (the builtin, not inline asm: the compiler's own wait-count bookkeeping then knows these reads have landed and
+        // puts no further waits for them between the MFMAs of the matrix segment)
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
         __builtin_amdgcn_sched_barrier(0);
         par ^= 1;
         tri_m = tri;
@@ -391,14 +438,19 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
             }
             __builtin_amdgcn_sched_barrier(0);
             if (!(LH2_DBG & 8))
-                b[j] = *(const bf16x8_t*)(smem + ((bad[j] ^ 64) + j * 2048));  // half 1 of this fragment, same registers
+                b[j] = *(const bf16x8_t*)(smem + (bad[j] + (j * 1024 + kL2Plane)));  // half 1 of this fragment, same registers
         }
         if (!(LH2_DBG & 4)) {
+            // fragment order pinned: the second half of fragment 0 was requested first and has long landed when this
+            // phase starts, that of fragment JW-1 arrives while the earlier groups multiply (left to itself the
+            // scheduler starts with a late fragment and waits for ALL reads: lgkmcnt(0), ~150-300 exposed cycles)
 #pragma unroll
-            for (int j = 0; j < JW; ++j)
+            for (int j = 0; j < JW; ++j) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #if LH2_PRIO
@@ -409,13 +461,11 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
     // ---- prologue: first tile's chunk 0 (all waves), first half of step 0 (A), second halves of steps 0 and 1 (B) ----
     tile_coords(tile_first, tm, m0, n0);
     {
-        hslot = (lane >> 3) + 8 * wave;
+        hr0 = wave >> 1;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int q = wave + 8 * k;
-            if (q < kL2Pieces) halo_piece(q, 8 * k, m0 - (W + 1), 0, 0);
-        }
-        hslot = (lane >> 3) + 8 * wh;
+        for (int k = 0; k < 8; ++k)
+            if (hr0 + 4 * k < kL2Slots / 16) halo_piece(k, 4, m0 - (W + 1), 0, 0);
+        hr0 = wh >> 1;
         // second halves: pieces 0..3 belong to the A waves (requested one step ahead), 4..7 to the B waves (two ahead)
         if (ISA) {
             wt_piece(wh, n0, 0, 0, 0, kL2OffA0);
@@ -447,7 +497,7 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
         for (int c = 0; c < nchunks; ++c) {
             // (the selects of the load segments are invariant over the chunks of a tile: left alone, the compiler hoists
             // all 9 x JW of them out of this loop and keeps them in registers)
-            asm volatile("" : "+v"(pmask[0]), "+v"(pmask[1]), "+v"(pmask[2]), "+v"(sj0), "+v"(hslot));
+            asm volatile("" : "+v"(pmask[0]), "+v"(pmask[1]), "+v"(pmask[2]), "+v"(sj0), "+s"(hr0));
             const bool last_chunk = c + 1 == nchunks;
             // the chunk after this one (same tile, or the next tile's first)
             const bool has_next = !last_chunk || more_tiles;
@@ -516,9 +566,8 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
                             constexpr int k0 = tap == 0 ? 0 : 2 * tap + 1, k1 = 2 * tap + 3;
 #pragma unroll
                             for (int k = k0; k < k1; ++k) {
-                                const int q = wh + 4 * k;
-                                if (q < kL2Pieces) {
-                                    halo_piece(q, 4 * k, nx_hm0, nx_c, hbuf ^ 1);
+                                if (hr0 + 2 * k < kL2Slots / 16) {
+                                    halo_piece(k, 2, nx_hm0, nx_c, hbuf ^ 1);
                                     ++issued;
                                 }
                             }
@@ -581,7 +630,11 @@ __global__ __launch_bounds__(512) void conv3x3_lh2_kernel(Lh2Params p) {
     const int first = (int)(((long)lb * p.ntiles) / nb), last = (int)(((long)(lb + 1) * p.ntiles) / nb);
     const int count = last - first;
     if (count <= 0) return;
+#if LH2_SWAP
+    const int wm = (wave >> 1) ^ 2;      // experiment: the YOUNGER waves (4-7) play the A role
+#else
     const int wm = wave >> 1;
+#endif
     if (wm == 0) lh2_run<BM, J0, 0, true, FLIP, ACC>(p, smem, first, count);
     else if (wm == 1) lh2_run<BM, J, J0, true, FLIP, ACC>(p, smem, first, count);
     else if (wm == 2) lh2_run<BM, J, J0 + J, false, FLIP, ACC>(p, smem, first, count);
