@@ -279,7 +279,10 @@ def main():
     def family(kind, name):
         sp = eng.convs[name].spec
         if sp.k == 7:
-            return "stem_conv_wgrad_kernel" if kind == "wgrad" else "stem_conv_fwd_kernel"
+            if kind != "wgrad":
+                return "stem_conv_fwd_kernel"
+            # (fused: the kernel also forms its dy tiles from y / dpooled / argmax — bn1, relu and maxpool backward)
+            return "stem_conv_wgrad_kernel<fused>" if getattr(eng, "stem_bwd_fused_active", False) else "stem_conv_wgrad_kernel"
         d = eng.convs[name].desc
         if kind == "wgrad":
             return KNAME[query("primia_conv_wgrad_kernel_id", d, dtc)]

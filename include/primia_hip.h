@@ -348,6 +348,16 @@ int primia_bn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dp
                                const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W,
                                int C, void* workspace, int64_t workspace_bytes, int dtype,
                                primia_stream_t stream);
+/* The stem's backward tail without the 411 MB dy (batch 256, 224 x 224): primia_bn_relu_maxpool_bwd with dy = NULL
+ * forms dgamma / dbeta only, and this call is conv1's weight gradient (primia_stem_conv_wgrad_ws) whose dy tiles are
+ * produced on the fly, per 8 x 16 output patch, from y, dpooled, the argmax codes and bn1's statistics — the apply
+ * pass of primia_bn_relu_maxpool_bwd moved into the operand staging of the weight-gradient kernel (the reference's
+ * loss.backward() through conv1 <- bn1 <- relu <- maxpool, torchlib/models.py:466-471).  dw_acc is bit-identical to
+ * the two-call chain.  bf16, H and W multiples of 32; PRIMIA_ERR_UNSUPPORTED otherwise (use the chain). */
+int primia_stem_bwd_fused(const void* x_padded, const void* y, const void* dpooled, const uint8_t* argmax,
+                          const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                          const float* dgamma, const float* dbeta, float* dw_acc, void* ws, int64_t ws_bytes, int N,
+                          int H, int W, int dtype, primia_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * GroupNorm (+ fused ReLU / residual) and the per-sample pieces of DP-SGD — BASELINE.json

@@ -988,6 +988,7 @@ static int bn_relu_pool_bwd_impl(const void* y, const void* pooled, const void* 
                        H, W, C, Ho, Wo, {}, {}, {}, {}, false};
     colreduce2_kernel<T, PoolScatterFn<T>><<<nblk, 256, 0, st>>>(f, Mp, C, rpb, partials);
     bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
+    if (!dy) return launch_status();   // sums only: the apply pass runs inside the consumer (primia_stem_bwd_fused)
     const long nchunks = M * C / Chunk<T>::N;
     if (H % 2 == 0 && W % 2 == 0) {
         const long total = nchunks / 4;
@@ -1193,8 +1194,8 @@ int primia_bn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dp
                                void* dy, const float* gamma, const float* beta, const float* save_mean,
                                const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W, int C,
                                void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream) {
-    PRIMIA_REQUIRE(y && pooled && dpooled && argmax && dy && gamma && beta && save_mean && save_invstd && dgamma &&
-                   dbeta && workspace);
+    PRIMIA_REQUIRE(y && pooled && dpooled && argmax && gamma && beta && save_mean && save_invstd && dgamma &&
+                   dbeta && workspace);   // dy may be null: dgamma / dbeta only (see primia_stem_bwd_fused)
     PRIMIA_REQUIRE(N > 0 && H > 0 && W > 0 && bn_shape_ok((long)N * H * W, C, dtype));
     PRIMIA_REQUIRE((long)N * H * W < (1L << 31));
     if (workspace_bytes < primia_bn_workspace_bytes((int64_t)N * H * W, C)) return PRIMIA_ERR_WORKSPACE;

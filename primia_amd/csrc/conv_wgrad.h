@@ -42,6 +42,7 @@ size_t wgrad_patch_ws_bytes(const WgradParams& p);
 int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st,
                              float* ws = nullptr, size_t ws_bytes = 0, double* sqnorm = nullptr);
 size_t stem_wgrad_halo_ws_bytes(int N, int H, int W);   // 0: shape not served by the halo kernel
+bool stem_wgrad_halo_blocks(int N, int H, int W, int* total, int* per_block, int* grid);
 // dw tile (kt, tap, ct) = sum over nsplit partial tiles of ws [combo][split][BMK*BNC], in split order
 void wgrad_tile_reduce(const float* ws, float* dw, int nsplit, int combos, int BMK, int BNC, int nkt, int nct, int C,
                        int klen, int stem, hipStream_t st);

@@ -1,0 +1,377 @@
+// The stem's backward tail as ONE kernel: conv1's weight gradient (7x7/2 on the padded input, stem_conv.hip) whose dy
+// operand is never stored — torchlib/models.py:466-471 backwards: conv1 <- bn1 <- relu <- maxpool.
+//
+// The unfused chain (primia_bn_relu_maxpool_bwd -> primia_stem_conv_wgrad_ws) writes dy = 411 MB at batch 256 in its
+// apply pass only for the weight-gradient kernel to read it straight back.  Here a 16-wave block walks the same 8 x 16
+// output patches in two roles:
+//   * waves 8-15 ("T") turn the patch's y tile into its dy tile IN PLACE in LDS: the tile (128 pixels x 64 channels)
+//     lands by LDS-DMA exactly where the dy tile of stem_conv_wgrad_kernel lands, next to the 5 x 9 pool windows
+//     (incoming gradient + argmax codes) that can route a gradient into the patch, and every thread applies the
+//     arithmetic of bn_relu_pool_bwd_apply2x2_kernel (bn.hip) to two pixels x 8 channels — the same operations in the
+//     same order, so the weight gradient has the SAME BITS as the chain's;
+//   * waves 0-7 ("M") are stem_conv_wgrad_kernel's waves: wave (kh, rq) owns out-channels 32 kh..+31 x kernel rows
+//     2 rq, 2 rq + 1 of the [64][256] accumulator and multiplies tile k while the T waves prepare tile k + 1.
+// One barrier per stage.  Ring of FIVE raw / dy buffers: during stage k tile k is multiplied, k + 1 transformed and
+// k + 2 .. k + 4 are in flight (75 KB per CU — with less the HBM latency shows: two 8-wave blocks per CU, one stage in
+// flight each and the transformation behind a second barrier, ran at 3.3 TB/s and 267 us; the VALU work of the
+// transformation alone is ~85 us, the MFMAs ~40 us).  vmcnt is counted: LDS-DMA pieces return in order.
+// LDS: [3 x input patch 7 KiB][5 x (y/dy tile 16 KiB + window gradients 6 KiB + window codes 3 KiB)] = 146 KiB.
+#include <stdlib.h>
+
+#include "conv_wgrad.h"
+
+namespace primia {
+
+__device__ __attribute__((aligned(16))) const unsigned char kStemFusedZeroPage[16] = {0};
+
+__device__ __forceinline__ void sbf_dma16(const void* g, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
+}
+
+// chunk-pair swizzle of the dy tile (stem_conv.hip: stem_key_lin)
+__device__ __forceinline__ int sbf_key(int slot) { return ((slot >> 1) & 1) | (((slot >> 3) & 1) << 1); }
+
+__device__ __forceinline__ void sbf_wait_vmcnt(int n) {   // wave-uniform n
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    }
+}
+
+struct StemFusedParams {
+    const bf16* xp;         // [N][Hp][Wp][4]
+    const bf16* y;          // [N][Ho][Wo][64]
+    const bf16* dpool;      // [N][Hq][Wq][64]
+    const uint8_t* argmax;  // [N][Hq][Wq][64]
+    const float *gamma, *beta, *mean, *invstd, *dbeta, *dgamma;
+    float inv_m;
+    float* dw;
+    float* ws;              // one [64][256] fp32 slab per block (or null: atomics into dw)
+    int N, Hp, Wp, Ho, Wo, Hq, Wq;
+    int PH, PW, PPI;
+    int total, per_block;
+    int debug;              // timing experiments only (PRIMIA_STEM_FUSED_DEBUG): 1 no transform, 2 no MFMAs, 4 no raw staging
+};
+
+constexpr int kSbfXB = 7 * 1024;                 // one input patch: 21 rows x 320 B by 7 DMA pieces
+constexpr int kSbfTile = 16 * 1024;              // y / dy tile: 128 slots x 128 B
+constexpr int kSbfRaw = kSbfTile + 9 * 1024;     // + 45 windows x 128 B of gradient (6 pieces) + x 64 B of codes (3)
+constexpr int kSbfRing = 5;
+constexpr int kSbfRaw0 = 3 * kSbfXB;
+constexpr int kSbfLds = kSbfRaw0 + kSbfRing * kSbfRaw;   // 149,504 B
+
+__global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p) {
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+
+    const int t0 = blockIdx.x * p.per_block;
+    int t1 = t0 + p.per_block;
+    if (t1 > p.total) t1 = p.total;
+    const int n = t1 - t0;       // stages
+    if (n <= 0) return;
+    int cn = t0 / p.PPI, cph, cpw;   // patch cursor of this wave's staging (input patches: M waves, raw data: T waves)
+    {
+        const int rem = t0 - cn * p.PPI;
+        cph = rem / p.PW;
+        cpw = rem - cph * p.PW;
+    }
+    auto advance = [&](int& an, int& aph, int& apw) {
+        if (++apw == p.PW) {
+            apw = 0;
+            if (++aph == p.PH) {
+                aph = 0;
+                ++an;
+            }
+        }
+    };
+
+    if (wave >= 8) {
+        // =============================== T waves: raw staging + transformation ===============================
+        const int tw = wave - 8;
+        // 25 DMA pieces per stage: 16 y, 6 window gradients, 3 window codes; T wave w issues w, w + 8, w + 16 and, w = 0, 24
+        const int npc = tw == 0 ? 4 : 3;
+        auto stage_raw = [&](int rbuf) {
+            const long ybase = ((long)(cn * p.Ho + cph * 8) * p.Wo + cpw * 16) * 64;
+            const int A0 = cph * 4, B0 = cpw * 8;
+            const long wbase = (long)cn * p.Hq * p.Wq;
+            advance(cn, cph, cpw);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = tw + 8 * it;
+                if (idx >= 25) break;
+                const void* g;
+                if (idx < 16) {
+                    const int slot = idx * 8 + (lane >> 3), sl = lane & 7;
+                    const int chunk = ((((sl >> 1) ^ sbf_key(slot)) << 1) | (sl & 1));
+                    g = p.y + ybase + ((long)(slot >> 4) * p.Wo + (slot & 15)) * 64 + chunk * 8;
+                } else {
+                    // window slot = 9 * row + col of the 5 x 9 windows (A0 + row, B0 + col); a window beyond the
+                    // pooled image is never selected (its codes are overridden below): any mapped address will do
+                    const bool grad = idx < 22;
+                    const int G = (grad ? idx - 16 : idx - 22) * 64 + lane;
+                    const int slot = grad ? G >> 3 : G >> 2, sub = grad ? G & 7 : G & 3;
+                    const int row = slot / 9, col = slot - 9 * row;
+                    const bool ok = slot < 45 && A0 + row < p.Hq && B0 + col < p.Wq;
+                    const long pix = wbase + (ok ? (long)(A0 + row) * p.Wq + B0 + col : 0);
+                    g = grad ? (const void*)(p.dpool + pix * 64 + sub * 8) : (const void*)(p.argmax + pix * 64 + sub * 16);
+                }
+                sbf_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + kSbfRaw0 + rbuf * kSbfRaw + idx * 1024));
+            }
+        };
+        // thread -> (chunk c8 = 8 channels, 2-column block bcol, 2-row block brow, diagonal dg of the block); its two
+        // pixels are (2 brow + r, 2 bcol + (r ^ dg)), r = 0, 1.  Pixel (r, j) of a 2 x 2 block can only be the argmax
+        // of the windows (brow + di, bcol + dj) of the tile, di <= r, dj <= j, at tap (1 + r - 2 di, 1 + j - 2 dj) —
+        // see bn_relu_pool_bwd_apply2x2_kernel — i.e. of (r + 1)(j + 1) windows: the diagonal pair looks at 1 + 4, the
+        // anti-diagonal pair at 2 + 2 of them (rows as the unit would be 3 against 6).
+        const int tt = tid - 512;
+        const int c8 = tt & 7, bcol = (tt >> 3) & 7, brow = tw & 3, dg = tw >> 2;   // dg: wave-uniform
+        // per-channel constants of this thread's 8 channels, resident: mean, invstd, scale, dbeta/M, dgamma/M, beta
+        float k0[8], k1[8], k2[8], k3[8], k4[8], k5[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c8 * 8 + k;
+            const float is = p.invstd[c];
+            k0[k] = p.mean[c];
+            k1[k] = is;
+            k2[k] = p.gamma[c] * is;
+            k3[k] = p.dbeta[c] * p.inv_m;
+            k4[k] = p.dgamma[c] * p.inv_m;
+            k5[k] = p.beta[c];
+        }
+        // The constants must have ARRIVED, to the compiler's knowledge, before the loop: left pending, its wait-count
+        // pass puts a vmcnt(0) in front of their first use INSIDE the loop body — and that drains every LDS-DMA piece
+        // the wave has just requested, every stage (the builtin, not inline asm: it updates the pass's bookkeeping).
+        __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
+        int tph = cph, tpw = cpw;               // cursor of the transformation (window validity at the image border)
+        auto transform = [&](int rbuf) {
+            char* const tile = smem + kSbfRaw0 + rbuf * kSbfRaw;
+            const char* const wg = tile + kSbfTile;
+            const char* const wc = wg + 6 * 1024;
+            const bool rok = tph * 4 + brow + 1 < p.Hq, cok = tpw * 8 + bcol + 1 < p.Wq;   // windows di = 1 / dj = 1 exist
+            if (++tpw == p.PW) {
+                tpw = 0;
+                if (++tph == p.PH) tph = 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int j = r ^ dg;
+                const int slot = (2 * brow + r) * 16 + 2 * bcol + j;
+                char* const yp = tile + slot * 128 + ((((c8 >> 1) ^ sbf_key(slot)) << 5) | ((c8 & 1) << 4));
+                float vy[8], g[8];
+                Chunk<bf16>::unpack(*(const u32x4*)yp, vy);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) g[k] = 0.f;
+                // the summation order of the unfused kernels: window row a + i first, within it column b + j first
+#pragma unroll
+                for (int di = 1; di >= 0; --di) {
+                    if (di > r) continue;
+#pragma unroll
+                    for (int dj = 1; dj >= 0; --dj) {
+                        if (dj > j) continue;
+                        const unsigned want = (unsigned)((1 + r - 2 * di) * 3 + (1 + j - 2 * dj));
+                        const int ws_ = (brow + di) * 9 + bcol + dj;
+                        const bool ok = (di == 0 || rok) && (dj == 0 || cok);
+                        float wv[8];
+                        Chunk<bf16>::unpack(*(const u32x4*)(wg + ws_ * 128 + c8 * 16), wv);
+                        u32x2 codes = *(const u32x2*)(wc + ws_ * 64 + c8 * 8);
+                        if (!ok) codes = u32x2{0xffffffffu, 0xffffffffu};
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            g[k] += ((codes[k >> 2] >> (8 * (k & 3))) & 0xffu) == want ? wv[k] : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const float zz = __builtin_fmaf(vy[k] - k0[k], k2[k], k5[k]);
+                    const float gi = zz > 0.f ? g[k] : 0.f;
+                    const float xh = (vy[k] - k0[k]) * k1[k];
+                    vy[k] = k2[k] * (gi - k3[k] - xh * k4[k]);
+                }
+                *(u32x4*)yp = Chunk<bf16>::pack(vy);
+            }
+        };
+
+        // stage k = -1 .. n-1: [tile k+1 landed] barrier | request tile k+4 | transform tile k+1
+        const bool raw_on = !(p.debug & 4);
+        for (int s = 0; s < 3; ++s)
+            if (s < n && raw_on) stage_raw(s);
+        for (int k = -1; k < n; ++k) {
+            // issued so far: tiles 0 .. k+3; tile k+1 must have landed, k+2 and k+3 may still be in flight
+            const int inflight = (k + 2 < n ? npc : 0) + (k + 3 < n ? npc : 0);
+            sbf_wait_vmcnt(raw_on ? inflight : 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the dy tile written in the previous stage
+            __builtin_amdgcn_s_barrier();
+            if (k + 4 < n && raw_on) stage_raw((k + 4) % kSbfRing);
+            if (k + 1 < n && !(p.debug & 1)) transform((k + 1) % kSbfRing);
+        }
+        return;
+    }
+
+    // =================================== M waves: input patches + MFMAs ===================================
+    const int kh = wave >> 2, rq = wave & 3;
+    const int fr = lane & 15, fg = lane >> 4;
+    const int tp = fr >> 2, tc8 = (fr & 3) * 8;
+    auto stage_x = [&](int buf) {
+        const long xbase = ((long)(cn * p.Hp + cph * 16) * p.Wp + cpw * 32) * 4;
+        advance(cn, cph, cpw);
+        if (wave < 7) {
+            const int G = wave * 64 + lane;
+            const int row = G / 20, c16 = G - row * 20;
+            const bf16* g = G < 420 ? p.xp + xbase + ((long)row * p.Wp + 2 * c16) * 4 : (const bf16*)kStemFusedZeroPage;
+            sbf_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * kSbfXB + wave * 1024));
+        }
+    };
+
+    f32x4 acc[2][2][2];  // [K fragment i][kernel row rr][element half h]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[i][rr][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // lane-constant parts of the read addresses (stem_conv_wgrad_kernel)
+    const int a_slot = 8 * fg + tp;                                      // + 32*ks (+4)
+    const int b_off = ((fg >> 1) * 2) * 320 + 16 * (8 * (fg & 1) + tp) + tc8;  // + (4*ks + r)*320 + 32*h (+64 for the hi read)
+
+    auto compute = [&](int xbuf, int rbuf) {
+        const char* lx = smem + xbuf * kSbfXB;
+        const char* la = smem + kSbfRaw0 + rbuf * kSbfRaw;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8_t a[2], b[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s0 = 32 * ks + a_slot, s1 = s0 + 4, cg = 2 * kh + i;
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(la + s0 * 128 + ((cg ^ sbf_key(s0)) << 5) + tc8));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(la + s1 * 128 + ((cg ^ sbf_key(s1)) << 5) + tc8));
+                a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = 2 * rq + rr;  // r == 7: no such kernel row (skipped below, wave-uniform)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const char* q = lx + b_off + (4 * ks + r) * 320 + 32 * h;
+                    bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)q);
+                    bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(q + 64));
+                    b[rr][h] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if (2 * rq + rr == 7) continue;
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        acc[i][rr][h] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[rr][h], acc[i][rr][h], 0, 0, 0);
+            }
+        }
+    };
+
+    // stage k = -1 .. n-1: [input patch k landed, tile k transformed] barrier | request patch k+2 | multiply tile k
+    stage_x(0);
+    if (n > 1) stage_x(1);
+    for (int k = -1; k < n; ++k) {
+        // issued so far: patches 0 .. k+1; patch k must have landed
+        if (k + 1 < n && wave < 7)
+            asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (k < 0) continue;
+        if (k + 2 < n) stage_x((k + 2) % 3);
+        if (!(p.debug & 2)) compute(k % 3, k % kSbfRing);
+    }
+
+    // ---- the block's [64][256] slab: lane holds out-chan rows 32*kh + 16*i + 4*fg + j, element r*32 + 16*h + fr ----
+    if (p.ws) {   // atomic-free path (zeros in the padding) to ITS workspace slot
+        float* o = p.ws + (long)blockIdx.x * (64 * 256);
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int r = 2 * rq + rr;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bool live = r < 7 && 16 * h + fr < 28;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        o[(32 * kh + 16 * i + 4 * fg + j) * 256 + r * 32 + 16 * h + fr] = live ? acc[i][rr][h][j] : 0.f;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        const int r = 2 * rq + rr;
+        if (r == 7) continue;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (16 * h + fr >= 28) continue;  // tap s = 7: no weight
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    unsafeAtomicAdd(p.dw + (long)(32 * kh + 16 * i + 4 * fg + j) * 256 + r * 32 + 16 * h + fr, acc[i][rr][h][j]);
+        }
+    }
+}
+
+}  // namespace primia
+
+using namespace primia;
+
+extern "C" int primia_stem_bwd_fused(const void* x_padded, const void* y, const void* dpooled, const uint8_t* argmax,
+                                     const float* gamma, const float* beta, const float* save_mean,
+                                     const float* save_invstd, const float* dgamma, const float* dbeta, float* dw_acc,
+                                     void* ws, int64_t ws_bytes, int N, int H, int W, int dtype,
+                                     primia_stream_t stream) {
+    PRIMIA_REQUIRE(x_padded && y && dpooled && argmax && gamma && beta && save_mean && save_invstd && dgamma && dbeta &&
+                   dw_acc && N > 0 && H > 0 && W > 0);
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
+    // 8 x 16 output patches tile the stem output; the 2 x 2 pixel blocks of the gather coincide with the pool's windows
+    if (H % 32 != 0 || W % 32 != 0) return PRIMIA_ERR_UNSUPPORTED;
+    if ((long)N * (H + 6) * (W + 8) * 4 >= (1L << 31) || (long)N * (H / 2) * (W / 2) * 64 >= (1L << 31))
+        return PRIMIA_ERR_UNSUPPORTED;
+    StemFusedParams p;
+    p.xp = (const bf16*)x_padded; p.y = (const bf16*)y; p.dpool = (const bf16*)dpooled; p.argmax = argmax;
+    p.gamma = gamma; p.beta = beta; p.mean = save_mean; p.invstd = save_invstd; p.dbeta = dbeta; p.dgamma = dgamma;
+    p.dw = dw_acc;
+    p.N = N; p.Hp = H + 6; p.Wp = W + 8; p.Ho = H / 2; p.Wo = W / 2;
+    p.Hq = (p.Ho + 2 - 3) / 2 + 1; p.Wq = (p.Wo + 2 - 3) / 2 + 1;
+    p.inv_m = (float)(1.0 / ((double)N * p.Ho * p.Wo));
+    p.PH = p.Ho / 8; p.PW = p.Wo / 16; p.PPI = p.PH * p.PW;
+    // the same split over blocks as the unfused kernel: its slabs — and therefore the ordered sum over them — are the
+    // same, the result is bit-identical to the chain's
+    int grid = 0;
+    if (!stem_wgrad_halo_blocks(N, H, W, &p.total, &p.per_block, &grid)) return PRIMIA_ERR_UNSUPPORTED;
+    const int64_t slab_bytes = (int64_t)grid * 64 * 256 * (int64_t)sizeof(float);
+    const bool store = ws && ws_bytes >= slab_bytes;
+    p.ws = store ? (float*)ws : nullptr;
+    static const int dbg = getenv("PRIMIA_STEM_FUSED_DEBUG") ? atoi(getenv("PRIMIA_STEM_FUSED_DEBUG")) : 0;
+    p.debug = dbg;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)stem_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSbfLds) !=
+            hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    stem_bwd_fused_kernel<<<grid, 1024, kSbfLds, st>>>(p);
+    // the slabs are [k][e] tiles of the accumulator itself: one "tile" of 64 x 256, one tap, `grid` splits
+    if (store) wgrad_tile_reduce(p.ws, dw_acc, grid, 1, 64, 256, 1, 1, 4, 256, 1, st);
+    return launch_status();
+}

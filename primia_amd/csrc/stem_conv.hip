@@ -538,6 +538,14 @@ static void stem_wgrad_geometry(int N, int H, int W, int& total, int& per_block,
     grid = (int)((total + per - 1) / per);
 }
 
+// the split of the 8 x 16 patches over blocks, for the fused backward kernel (stem_bwd_fused.hip), which must use the
+// same one to produce the same slabs; false: shape not served
+bool stem_wgrad_halo_blocks(int N, int H, int W, int* total, int* per_block, int* grid) {
+    if (!stem_wgrad_halo_ok(N, H, W)) return false;
+    stem_wgrad_geometry(N, H, W, *total, *per_block, *grid);
+    return true;
+}
+
 size_t stem_wgrad_halo_ws_bytes(int N, int H, int W) {
     if (!stem_wgrad_halo_ok(N, H, W)) return 0;
     int total, per, grid;

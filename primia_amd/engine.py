@@ -578,6 +578,7 @@ class ResNet18Engine:
     # follows (HBM-bound kernels and 7-us finalize launches); the next dgrad waits for it.  Also slower on
     # MI355X (7.10 ms serial -> 7.30 ms): kept as an option for other shapes, off by default.
     wgrad_overlap = False
+    stem_bwd_fused = os.environ.get("PRIMIA_STEM_BWD_FUSED", "1") != "0"
 
     def _on_wgrad_stream(self, fn):
         if not self.wgrad_overlap or self.prof is not None:
@@ -698,6 +699,26 @@ class ResNet18Engine:
                 if not self.wgrad_first:
                     self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
         hw = self.stem_hw
+        # the stem's tail in two launches less and without the dy tensor (411 MB at batch 256): bn1's backward sums at
+        # pooled resolution, then conv1's weight gradient forming its dy tiles on the fly (primia_stem_bwd_fused)
+        stem_bwd_fused = (self._stem_fused and self._stem_padded and self.dp is None and self.stem_bwd_fused
+                          and self.wgrad_ws is not None and not self.wgrad_overlap and self.dtype == torch.bfloat16
+                          and self.spec.input_size % 32 == 0)
+        self.stem_bwd_fused_active = stem_bwd_fused
+        if stem_bwd_fused:
+            sm, si = self.save["bn1"]
+            c = self.convs["conv1"]
+            S = self.spec.input_size
+            call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, None,
+                 self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self.gviews["bn1.weight"],
+                 self.gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
+            self._timed("wgrad", c, lambda: call("primia_stem_bwd_fused", self.x0p, t["stem.y"], t["pool.dout"],
+                                                 self.pool_argmax, self.views["bn1.weight"], self.views["bn1.bias"], sm,
+                                                 si, self.gviews["bn1.weight"], self.gviews["bn1.bias"], c.acc,
+                                                 self.wgrad_ws, self.wgrad_ws_bytes, N, S, S, self.dt))
+            if self.dp is None:
+                self._finalize_wgrads()
+            return
         if self._stem_fused:
             sm, si = self.save["bn1"]
             call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, t["stem.dy"],

@@ -742,6 +742,58 @@ def test_stem_conv_emits_batchnorm_partials_and_fused_tail_from_sums(cuda):
         assert relerr(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("N,S", [(2, 64), (75, 64), (3, 96), (5, 32)])
+def test_stem_backward_fused_is_bit_identical_to_the_chain(cuda, N, S):
+    """primia_stem_bwd_fused (bn1 <- relu <- maxpool backward apply inside conv1's weight-gradient kernel, dy never
+    stored) against primia_bn_relu_maxpool_bwd -> primia_stem_conv_wgrad_ws: same dgamma / dbeta (the same reduction
+    kernels run), and the SAME BITS in the weight gradient.  (75, 64): several patches per block, ragged last block;
+    (5, 32): one patch per image, every window column / row at the pooled image's border."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(1000 + N + S)
+    x = rnd(torch.randn(N, 3, S, S, generator=g), dtype)
+    w = rnd(torch.randn(64, 3, 7, 7, generator=g) * 0.05, dtype)
+    desc = ConvDesc.make(N, S, S, 4, 64, 7, 7, 2, 3)
+    wf, _ = prep_weights(desc, w, dtype, cuda, 3, need_dgrad=False)
+    xp = torch.zeros(N * (S + 6) * (S + 8), 4, dtype=dtype, device=cuda)
+    call("primia_nchw_to_nhwc_padded", x.to(cuda), xp, N, 3, S, S, 4, 3, 3, S + 6, S + 8, dt)
+    Ho = S // 2
+    Hq = (Ho - 1) // 2 + 1
+    M = N * Ho * Ho
+    y = torch.empty(M, 64, dtype=dtype, device=cuda)
+    call("primia_stem_conv_fwd", xp, wf, y, N, S, S, dt)
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(cuda), (torch.randn(64, generator=g) * 0.3).to(cuda)
+    ws_bytes = query("primia_bn_workspace_bytes", M, 64)
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
+    rm, rv = torch.zeros(64, device=cuda), torch.ones(64, device=cuda)
+    sm, si = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+    p = torch.empty(N * Hq * Hq, 64, dtype=dtype, device=cuda)
+    am = torch.empty(N * Hq * Hq, 64, dtype=torch.uint8, device=cuda)
+    call("primia_bn_relu_maxpool_fwd", y, p, am, gamma, beta, rm, rv, sm, si, N, Ho, Ho, 64, 1e-5, 0.1, ws, ws_bytes, dt)
+    dp = to_nhwc(rnd(torch.randn(N, 64, Hq, Hq, generator=g), dtype), dtype, cuda)
+    wws_bytes = query("primia_stem_conv_wgrad_ws_bytes", N, S, S)
+    assert wws_bytes > 0
+    wws = torch.empty(wws_bytes // 4, device=cuda)
+    n = query("primia_conv_wfwd_elems", desc)
+
+    # the chain
+    dy = torch.empty_like(y)
+    dg, db = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+    call("primia_bn_relu_maxpool_bwd", y, p, dp, am, dy, gamma, beta, sm, si, dg, db, N, Ho, Ho, 64, ws, ws_bytes, dt)
+    a0 = torch.full((n,), float("nan"), device=cuda)
+    call("primia_stem_conv_wgrad_ws", xp, dy, a0, wws, wws_bytes, N, S, S, dt)
+    # fused: sums only, then the weight gradient straight from y / dpooled / argmax
+    dg2, db2 = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+    call("primia_bn_relu_maxpool_bwd", y, p, dp, am, None, gamma, beta, sm, si, dg2, db2, N, Ho, Ho, 64, ws, ws_bytes, dt)
+    assert torch.equal(dg2, dg) and torch.equal(db2, db)
+    wws.fill_(float("nan"))
+    a1 = torch.full((n,), float("nan"), device=cuda)
+    call("primia_stem_bwd_fused", xp, y, dp, am, gamma, beta, sm, si, dg2, db2, a1, wws, wws_bytes, N, S, S, dt)
+    assert torch.isfinite(a1).all()
+    assert float(a0.abs().max()) > 0
+    assert torch.equal(a1, a0), f"max diff {float((a1 - a0).abs().max())} of {float(a0.abs().max())}"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_batchnorm_relu_mask_variant_is_bit_identical(cuda, dtype):
     """primia_bn_fwd_train_mask / primia_bn_bwd_mask (1-bit ReLU mask for residual layers) against
