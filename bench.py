@@ -273,7 +273,8 @@ def main():
     KNAME = {1: "conv_igemm_kernel", 2: "conv3x3_c64_kernel (fwd + dgrad)", 3: "conv3x3_lh_kernel (fwd + dgrad)",
              4: "conv3x3_lh2_kernel (fwd + dgrad)", 11: "conv_wgrad_patch32_kernel + wgrad_patch32_reduce_kernel",
              12: "conv_wgrad_patch_kernel + wgrad_patch_reduce_kernel", 13: "conv_wgrad_dma_kernel (per-tap, stride 2 / 1x1)",
-             14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)"}
+             14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)",
+             16: "conv_wgrad_patch33_kernel + wgrad_patch32_reduce_kernel"}
     dtc = _lib.dtype_code(dtype)
 
     def family(kind, name):

@@ -125,6 +125,7 @@ int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_ac
  *   1 conv_igemm_kernel   2 conv3x3_c64_kernel   3 conv3x3_lh_kernel   4 conv3x3_lh2_kernel
  * weight gradient:
  *   11 conv_wgrad_patch32_kernel   12 conv_wgrad_patch_kernel   13 conv_wgrad_dma_kernel   14 conv_wgrad_kernel
+ *   16 conv_wgrad_patch33_kernel (3 + 3 fragments per k-step; the default)
  *   15 the stem's (stem_conv_wgrad_kernel on the padded bf16 input, conv_wgrad_kernel<STEM> otherwise) */
 int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype);
 int primia_conv_wgrad_kernel_id(const primia_conv_desc* d, int dtype);

@@ -778,30 +778,357 @@ __global__ __launch_bounds__(256) void wgrad_patch32_reduce_kernel(const float* 
     for (int j = 0; j < 4; ++j) dw[(long)(k0 + j) * klen + e] = a[j];
 }
 
+// =====================================================================================================================
+// v3 ("3 + 3"): the nine taps of a k-step from THREE row-shifted dy fragments and THREE column-shifted x fragments.
+//
+//   dw[k, (r, s), c] = sum over x pixels (h', w')  dy[h' - r + 1, w', k] * x[h', w' + s - 1, c]
+//
+// i.e. tap (r, s) = MFMA(Y_r, X_s) with Y_r = the k-step's pixels moved r - 1 rows UP in dy and X_s = the same pixels
+// moved s - 1 columns in x: the row shift sits on one operand and the column shift on the other, so a k-step needs
+// 3 + 3 fragments instead of v2's 1 + 9 — and for two-row fragments Y_2 of k-step j + 1 IS Y_0 of k-step j (kept in
+// registers).  What that buys (the stage body of v2 was bound by its 40 transposing reads and by staging):
+//   * fragment reads per 36 MFMAs: 80 (v2) -> 42 (8-row sub-patches of two-row fragments) / 48-56 (others);
+//   * staging: x needs only its column halo and dy only its row halo, and a sub-patch may be TALL: 8 x 8 pixels stage
+//     80 + 80 slots for 64 pixels (20 DMA pieces) where two 4 x 8 sub-patches staged 2 x 72 + 64 (26);
+//   * one barrier per 64 pixels and half where H allows 8-row sub-patches;
+//   * 24 fragment registers instead of 80.
+// Sub-patch shapes <SW, SH>: 8 x 8 (H % 8 == 0, and 7 x 7 images: one sub-patch each), 8 x 4, 16 x 2.  The k-step
+// fragment is 2 rows x 8 columns (SW = 8) or 1 row x 16 columns (SW = 16), as in v2; LDS slots, the g ^ bit1(slot)
+// channel-group swizzle, buffer-addressed LDS-DMA with hardware zero fill, the staggered halves, the slab epilogue
+// and the ordered reduce are v2's.  Images: x [SH rows][HSX slots] (column halo; HSX = 10 | 20, so that a k-step is a
+// multiple of 4 slots = an immediate offset), dy [SH + 2 rows][SW slots] (row halo).
+#ifndef PRIMIA_WGP33_PIN
+#define PRIMIA_WGP33_PIN 1
+#endif
+template <int SW, int SH, int STAGES>
+__global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) {
+    constexpr int FR = SW == 8 ? 2 : 1;         // rows of a k-step fragment
+    constexpr int NK = SH / FR;                 // k-steps per sub-patch
+    constexpr int HSX = SW == 8 ? 10 : 20;      // x row stride in slots
+    constexpr int XSLOTS = (SH * HSX + 7) / 8 * 8;
+    constexpr int DSLOTS = (SH + 2) * SW;
+    static_assert(DSLOTS % 8 == 0 && SH % FR == 0, "whole DMA pieces");
+    constexpr int XP = XSLOTS / 8, DP = DSLOTS / 8;
+    constexpr int HALF = (XSLOTS + DSLOTS) * 128;   // one sub-patch: [x image][dy image]
+    constexpr int STAGE = 2 * HALF;
+    constexpr int NPIECE = 2 * (XP + DP);
+    constexpr int MAXIT = (NPIECE + 7) / 8;
+    static_assert(MAXIT <= 5, "piece bookkeeping");
+    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2, kg = (wave >> 1) & 1, cg = wave & 1;
+
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int split;
+    if (p.split_fastest) {
+        split = bid % p.nsplit;
+        bid /= p.nsplit;
+    }
+    const int ct = bid % p.nct; bid /= p.nct;
+    const int kt = bid % p.nkt;
+    if (!p.split_fastest) split = bid / p.nkt;
+    const int t0 = split * p.per_block;
+    int t1 = t0 + p.per_block;
+    if (t1 > p.total) t1 = p.total;
+    const int nstages = (t1 - t0 + 1) >> 1;
+
+    const bf16* __restrict__ x = p.x + ct * 64;
+    const bf16* __restrict__ dy = p.dy + kt * 64;
+
+    // ---- staging constants (per DMA piece `it` of this wave): piece idx = wave + 8 it; pieces [q][x: XP | dy: DP] ----
+    // row bit i = image row (sub-patch origin) + i - 1, column bit 12 + i = image column origin + i - 1
+    int rel[MAXIT];
+    unsigned lbits[MAXIT];
+    int pq[MAXIT], pisx[MAXIT], pdst[MAXIT];
+    const int npc = (NPIECE - wave + 7) / 8;            // pieces of this wave (wave-uniform)
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        int idx = wave + 8 * it;
+        if (idx >= NPIECE) idx = NPIECE - 1;            // (never issued)
+        const int q = idx >= XP + DP;
+        const int j = idx - q * (XP + DP);
+        const bool isx = j < XP;
+        const int c16 = lane & 7;
+        int ri, ci;
+        if (isx) {
+            const int slot = j * 8 + (lane >> 3);
+            const int hy = slot / HSX, hx = slot - hy * HSX;
+            const int grp = (c16 >> 2) ^ key32(slot);
+            ri = hy + 1;                                 // rows 0 .. SH-1 of the sub-patch
+            ci = hx < SW + 2 && hy < SH ? hx : -1;       // columns -1 .. SW; pad slots: never valid
+            rel[it] = ((hy * p.W + (hx - 1)) * p.C + (grp * 4 + (c16 & 3)) * 8) * 2;
+        } else {
+            const int slot = (j - XP) * 8 + (lane >> 3);
+            const int py = slot / SW, px = slot - py * SW;
+            const int grp = (c16 >> 2) ^ key32(slot);
+            ri = py;                                     // rows -1 .. SH
+            ci = px + 1;
+            rel[it] = (((py - 1) * p.W + px) * p.K + (grp * 4 + (c16 & 3)) * 8) * 2;
+        }
+        lbits[it] = ci < 0 ? 0x80000000u : (1u << ri) | (1u << (12 + ci));
+        pisx[it] = __builtin_amdgcn_readfirstlane((int)isx);
+        pq[it] = __builtin_amdgcn_readfirstlane(q);
+        pdst[it] = __builtin_amdgcn_readfirstlane(q * HALF + (isx ? j * 1024 : XSLOTS * 128 + (j - XP) * 1024));
+    }
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    const long xbytes = ((long)p.total / p.PPI * p.H * p.W * p.C - ct * 64) * 2;
+    const long dybytes = ((long)p.total / p.PPI * p.H * p.W * p.K - kt * 64) * 2;
+    auto make_rsrc = [](const void* base, long bytes) {
+        const unsigned long long a = (unsigned long long)base;
+        i32x4 r;
+        r[0] = (int)(unsigned)a;
+        r[1] = (int)(unsigned)(a >> 32) & 0xffff;       // stride 0: raw buffer
+        r[2] = (int)(unsigned)(bytes > 0xfffffff0L ? 0xfffffff0L : bytes);
+        r[3] = 0x00020000;
+        return r;
+    };
+    i32x4 rsrc_x = make_rsrc(x, xbytes), rsrc_dy = make_rsrc(dy, dybytes);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rsrc_x[j] = __builtin_amdgcn_readfirstlane(rsrc_x[j]);
+        rsrc_dy[j] = __builtin_amdgcn_readfirstlane(rsrc_dy[j]);
+    }
+    constexpr unsigned kOob = 0xfffffff0u;
+    int sn, sph, spw;
+    {
+        sn = t0 / p.PPI;
+        const int rem = t0 - sn * p.PPI;
+        sph = rem / p.PW;
+        spw = rem - sph * p.PW;
+    }
+    int st = t0;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned voff[MAXIT], gdst[MAXIT];
+    auto prep = [&](int buf) {
+        unsigned smask[2];
+        int xo[2], dyo[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const bool live = st < t1;
+            const int rb = sph * SH, cb = spw * SW;
+            const int pixbase = (sn * p.H + rb) * p.W + cb;
+            // valid row bits: image row rb + i - 1 in [0, H); columns likewise from bit 12
+            int rhi = p.H - rb + 1, chi = p.W - cb + 1;
+            rhi = rhi > SH + 2 ? SH + 2 : rhi;
+            chi = chi > SW + 2 ? SW + 2 : chi;
+            const unsigned rowm = ((1u << rhi) - 1u) & ~(rb == 0 ? 1u : 0u);
+            const unsigned colm = ((1u << chi) - 1u) & ~(cb == 0 ? 1u : 0u);
+            smask[q] = live ? rowm | (colm << 12) : 0u;
+            xo[q] = pixbase * p.C * 2;
+            dyo[q] = pixbase * p.K * 2;
+            ++st;
+            if (++spw == p.PW) {
+                spw = 0;
+                if (++sph == p.PH) {
+                    sph = 0;
+                    ++sn;
+                }
+            }
+        }
+        const unsigned base = lds0 + buf * STAGE;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            if (it >= npc) break;
+            const unsigned m = pq[it] ? smask[1] : smask[0];
+            const int org = pisx[it] ? (pq[it] ? xo[1] : xo[0]) : (pq[it] ? dyo[1] : dyo[0]);
+            voff[it] = (lbits[it] & m) == lbits[it] ? (unsigned)(rel[it] + org) : kOob;
+            gdst[it] = base + pdst[it];
+        }
+    };
+    bool do_issue = true;
+    auto issue = [&](int it) {
+        if (do_issue && it < npc && !(p.debug_skip_epilogue & 128)) {
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(gdst[it]);
+            if (pisx[it])
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(voff[it]), "s"(rsrc_x), "s"(m0v) : "memory");
+            else
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(voff[it]), "s"(rsrc_dy), "s"(m0v) : "memory");
+        }
+    };
+    auto stage = [&](int buf) {
+        prep(buf);
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) issue(it);
+    };
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+    // ---- fragment addresses: lane (16-lane group g16, fr) reads pixel kk = 8*(g16>>1) + (fr>>2) (+4) of the k-step,
+    //      channels 16*(g16&1) + 4*(fr&3) .. +3 of the wave's group; k-steps and row shifts are immediate offsets --------
+    const int fr = lane & 15, g16 = lane >> 4;
+    const int cbyte = (16 * (g16 & 1) + 4 * (fr & 3)) * 2;
+    int offy[2], offx[3][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int kk = 8 * (g16 >> 1) + (fr >> 2) + 4 * h;
+        const int py = SW == 8 ? (kk >> 3) : 0, px = SW == 8 ? (kk & 7) : kk;
+        const int sy = py * SW + px;                       // dy image, row offset y = 0
+        offy[h] = half * HALF + XSLOTS * 128 + sy * 128 + ((kg ^ key32(sy)) << 6) + cbyte;
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            const int sx = py * HSX + px + s;              // x image, k-step 0
+            offx[s][h] = half * HALF + sx * 128 + ((cg ^ key32(sx)) << 6) + cbyte;
+        }
+    }
+    constexpr int KSTEP_X = FR * HSX * 128;    // next k-step: FR rows further in both images
+    constexpr int YROW = SW * 128;             // one dy row
+
+    // One stage of this wave's sub-patch: NK k-steps x 9 MFMAs.  Y[y] = dy fragment whose first row is image row y - 1
+    // of the sub-patch; tap row r of k-step j needs Y[FR j + 2 - r].
+    auto compute = [&](int buf) {
+        typedef __attribute__((address_space(3))) char* ldsp_t;
+        const ldsp_t sb = (ldsp_t)(size_t)(lds0 + buf * STAGE);
+        ldsp_t py_[2], px_[3][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            py_[h] = sb + offy[h];
+#pragma unroll
+            for (int s = 0; s < 3; ++s) px_[s][h] = sb + offx[s][h];
+        }
+        constexpr int NY = FR * (NK - 1) + 3;
+        bf16x8_t Y[NY], X[2][3];
+        auto read_y = [&](int y) {
+            bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(py_[0] + y * YROW));
+            bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(py_[1] + y * YROW));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+        auto read_x = [&](int j, int s) {
+            bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(px_[s][0] + j * KSTEP_X));
+            bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(px_[s][1] + j * KSTEP_X));
+            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+        };
+#pragma unroll
+        for (int y = 0; y < 3; ++y) Y[y] = read_y(y);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) X[0][s] = read_x(0, s);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            // the fragments of k-step j + 1 are requested BEFORE the MFMAs of k-step j (left to itself the scheduler
+            // issues them right in front of their first use: ~100-200 cycles of LDS latency per k-step in the open)
+            if (j + 1 < NK) {
+#pragma unroll
+                for (int s = 0; s < 3; ++s) X[(j + 1) & 1][s] = read_x(j + 1, s);
+#pragma unroll
+                for (int y = FR * j + 3; y < FR * (j + 1) + 3; ++y) Y[y] = read_y(y);
+            }
+            if (PRIMIA_WGP33_PIN) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int s = 0; s < 3; ++s)
+                    acc[3 * r + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[FR * j + 2 - r], X[j & 1][s], acc[3 * r + s], 0, 0, 0);
+            if (PRIMIA_WGP33_PIN) __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    auto wait_inflight = [&](int stages_ahead) {   // this wave's pieces of the newest `stages_ahead` stages may stay in flight
+        const int n = stages_ahead * npc;
+        switch (n) {
+            case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+            case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+            case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+            case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+            case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;   // n == 1 (npc >= 1 always)
+        }
+    };
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+        if (s < nstages) stage(s);
+    // the two waves of a SIMD belong to different halves: half 0 issues its DMA pieces and THEN multiplies, half 1
+    // multiplies and THEN issues (see v2); two copies of the loop, one order each
+    auto main_loop = [&](auto stage_first) {
+        int cur = 0, nxt = STAGES - 1;
+        for (int s = 0; s < nstages; ++s) {
+            int ahead = nstages - 1 - s;
+            if (ahead > STAGES - 2) ahead = STAGES - 2;
+            wait_inflight(ahead);
+            __builtin_amdgcn_s_barrier();
+            do_issue = s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2);
+            if constexpr (decltype(stage_first)::value) {
+                if (do_issue) stage(nxt);
+                compute(cur);
+            } else {
+                compute(cur);
+                if (do_issue) stage(nxt);
+            }
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+            nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+        }
+    };
+    if (half == 0 || (p.debug_skip_epilogue & 16))
+        main_loop(OrderTag<true>{});
+    else
+        main_loop(OrderTag<false>{});
+
+    wgrad32_epilogue(acc, p, smem, wave, lane, half, kg, cg, kt, ct, split);
+}
+
 struct PatchGeom {
     bool ok, wide;
+    int SW, SH;        // v3: sub-patch shape
     int PH, PW, PPI, total, per_block, nsplit, combos;
 };
 
-static bool use_v2() {
-    static const int v2 = getenv("PRIMIA_WGP32") ? atoi(getenv("PRIMIA_WGP32")) : 1;
-    return v2 != 0;
+// PRIMIA_WGP32: 0 = round 1's kernel (16x16x32), 1 = v2 (32x32x16, 1 + 9 fragments), 3 = v3 (3 + 3 fragments, default)
+static int wgp_version() {
+    static const int v = getenv("PRIMIA_WGP32") ? atoi(getenv("PRIMIA_WGP32")) : 3;
+    return v;
 }
+static bool use_v2() { return wgp_version() != 0; }    // v2 and v3 share the byte-offset addressing and the slab format
+static bool use_v3() { return wgp_version() >= 3; }
 
 static PatchGeom patch_geom(const WgradParams& w) {
     PatchGeom g{};
-    // the v2 kernel addresses x and dy with 32-bit BYTE offsets through buffer resources (signed arithmetic, range
+    // the v2 / v3 kernels address x and dy with 32-bit BYTE offsets through buffer resources (signed arithmetic, range
     // check against num_records): elements < 2^30; the v1 kernel indexes elements with 32-bit ints: < 2^31
     g.ok = !(w.R != 3 || w.S != 3 || w.stride != 1 || w.pad != 1 || w.C % 64 || w.K % 64) &&
            (long)w.N * w.H * w.W * (w.C > w.K ? w.C : w.K) < (use_v2() ? (1L << 30) : (1L << 31));
     if (!g.ok) return g;
-    // 16-wide sub-patches when they waste fewer slots on the ragged right edge (W = 14: 16 vs 2 x 8)
-    const int waste8 = (w.W + 7) / 8 * 8 - w.W, waste16 = (w.W + 15) / 16 * 16 - w.W;
-    const int rows8 = (w.H + 3) / 4 * 4 - w.H, rows16 = (w.H + 1) / 2 * 2 - w.H;
-    const long slots8 = (long)(w.W + waste8) * (w.H + rows8), slots16 = (long)(w.W + waste16) * (w.H + rows16);
-    static const char force = getenv("PRIMIA_WGP_SW") ? getenv("PRIMIA_WGP_SW")[0] : 0;  // '8' | '1'(6)
-    g.wide = force ? force == '1' : slots16 < slots8;
-    const int SW = g.wide ? 16 : 8, SH = 32 / SW;
+    int SW, SH;
+    if (use_v3()) {
+        // 8 x 8 unless it pads the image more than 35 % beyond the best shape: measured at batch 256, us per call incl.
+        // the reduce, 8 x 8 | best-fitting shape: 28 x 28 images (pads to 32 x 32, +14 %) 77 | 81 (8 x 4), 14 x 14 (16 x 16,
+        // +14 %) 75 | 83 (16 x 2) — a stage of 64 pixels per half with one barrier beats 32 pixels without padding
+        static const int cand[3][2] = {{8, 8}, {8, 4}, {16, 2}};
+        static const int force = getenv("PRIMIA_WGP_SHAPE") ? atoi(getenv("PRIMIA_WGP_SHAPE")) : -1;   // 0 | 1 | 2
+        long slots[3], best = -1;
+        for (int i = 0; i < 3; ++i) {
+            slots[i] = (long)((w.W + cand[i][0] - 1) / cand[i][0] * cand[i][0]) * ((w.H + cand[i][1] - 1) / cand[i][1] * cand[i][1]);
+            if (best < 0 || slots[i] < best) best = slots[i];
+        }
+        int pick = 0;
+        if (force >= 0 && force < 3) {
+            pick = force;
+        } else if (slots[0] * 100 > best * 135) {
+            pick = slots[1] <= slots[2] ? 1 : 2;
+        }
+        SW = cand[pick][0]; SH = cand[pick][1];
+        g.wide = SW == 16;
+    } else {
+        // 16-wide sub-patches when they waste fewer slots on the ragged right edge (W = 14: 16 vs 2 x 8)
+        const int waste8 = (w.W + 7) / 8 * 8 - w.W, waste16 = (w.W + 15) / 16 * 16 - w.W;
+        const int rows8 = (w.H + 3) / 4 * 4 - w.H, rows16 = (w.H + 1) / 2 * 2 - w.H;
+        const long slots8 = (long)(w.W + waste8) * (w.H + rows8), slots16 = (long)(w.W + waste16) * (w.H + rows16);
+        static const char force = getenv("PRIMIA_WGP_SW") ? getenv("PRIMIA_WGP_SW")[0] : 0;  // '8' | '1'(6)
+        g.wide = force ? force == '1' : slots16 < slots8;
+        SW = g.wide ? 16 : 8;
+        SH = 32 / SW;
+    }
+    g.SW = SW; g.SH = SH;
     g.PH = (w.H + SH - 1) / SH; g.PW = (w.W + SW - 1) / SW; g.PPI = g.PH * g.PW;
     g.total = w.N * g.PPI;
     g.combos = (w.C / 64) * (w.K / 64);
@@ -824,6 +1151,50 @@ size_t wgrad_patch_ws_bytes(const WgradParams& w) {
     const PatchGeom g = patch_geom(w);
     if (!g.ok || w.persample) return 0;
     return (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
+}
+
+static void fill_patch_params(PatchParams& p, const WgradParams& w, const PatchGeom& g) {
+    p.x = (const bf16*)w.x; p.dy = (const bf16*)w.dy; p.dw = w.dw;
+    p.H = w.H; p.W = w.W; p.C = w.C; p.K = w.K; p.klen = w.klen;
+    p.nct = w.C / 64; p.nkt = w.K / 64;
+    p.PH = g.PH; p.PW = g.PW; p.PPI = g.PPI;
+    p.total = g.total;
+    p.per_block = g.per_block;
+    p.nsplit = g.nsplit;
+    static const int order = getenv("PRIMIA_WGP_ORDER") ? atoi(getenv("PRIMIA_WGP_ORDER")) : 0;
+    p.split_fastest = order;
+    p.split_stride = w.persample ? (long)w.K * w.klen : 0;
+    p.sqnorm = w.persample ? w.sqnorm : nullptr;
+    static const int noepi = getenv("PRIMIA_WGP_NOEPI") ? atoi(getenv("PRIMIA_WGP_NOEPI")) : 0;
+    p.debug_skip_epilogue = noepi;
+    const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
+    p.ws = store ? w.ws : nullptr;
+}
+
+template <int SW, int SH>
+static int launch_patch33(const WgradParams& w, const PatchGeom& g, hipStream_t st) {
+    PatchParams p;
+    fill_patch_params(p, w, g);
+    // the stage ring (at most 120 KiB), or the 144 KiB the two halves need to meet in after the main loop
+    const size_t lds = (size_t)kSlab * 4;
+    auto kern = conv_wgrad_patch33_kernel<SW, SH, 3>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    kern<<<(unsigned)(g.combos * g.nsplit), 512, lds, st>>>(p);
+    if (p.ws) {
+        const int ns = g.nsplit;
+        if (ns >= 64)
+            wgrad_patch32_reduce_kernel<16><<<g.combos * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+        else if (ns >= 8)
+            wgrad_patch32_reduce_kernel<4><<<g.combos * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+        else
+            wgrad_patch32_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+    }
+    return launch_status();
 }
 
 template <int SW>
@@ -894,15 +1265,19 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
     return launch_status();
 }
 
-// 11 = conv_wgrad_patch32_kernel, 12 = conv_wgrad_patch_kernel (round 1), 0 = shape not served
+// 16 = conv_wgrad_patch33_kernel, 11 = conv_wgrad_patch32_kernel, 12 = conv_wgrad_patch_kernel (round 1), 0 = shape not served
 int wgrad_patch_kernel_id(const WgradParams& w) {
     if (!patch_geom(w).ok) return 0;
-    return use_v2() ? 11 : 12;
+    return use_v3() ? 16 : (use_v2() ? 11 : 12);
 }
 
 int wgrad_patch_dispatch(const WgradParams& w, hipStream_t st) {
     const PatchGeom g = patch_geom(w);
     if (!g.ok) return PRIMIA_ERR_UNSUPPORTED;
+    if (use_v3()) {
+        if (g.SW == 16) return launch_patch33<16, 2>(w, g, st);
+        return g.SH == 8 ? launch_patch33<8, 8>(w, g, st) : launch_patch33<8, 4>(w, g, st);
+    }
     return g.wide ? launch_patch<16>(w, g, st) : launch_patch<8>(w, g, st);
 }
 
