@@ -813,7 +813,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
     constexpr int STAGE = 2 * HALF;
     constexpr int NPIECE = 2 * (XP + DP);
     constexpr int MAXIT = (NPIECE + 7) / 8;
-    static_assert(MAXIT <= 5, "piece bookkeeping");
+    static_assert(MAXIT <= 9, "piece bookkeeping");
     typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1039,7 +1039,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
             case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
             case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
             case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+            case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
             case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+            case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
             case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
             default: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;   // n == 1 (npc >= 1 always)
         }
@@ -1090,6 +1092,10 @@ static int wgp_version() {
 }
 static bool use_v2() { return wgp_version() != 0; }    // v2 and v3 share the byte-offset addressing and the slab format
 static bool use_v3() { return wgp_version() >= 3; }
+static bool wgp_tall7() {
+    static const int t = getenv("PRIMIA_WGP_TALL7") ? atoi(getenv("PRIMIA_WGP_TALL7")) : 0;   // measured: no gain (2-stage ring, 9 spilled registers)
+    return t != 0;
+}
 
 static PatchGeom patch_geom(const WgradParams& w) {
     PatchGeom g{};
@@ -1103,16 +1109,18 @@ static PatchGeom patch_geom(const WgradParams& w) {
         // 8 x 8 unless it pads the image more than 35 % beyond the best shape: measured at batch 256, us per call incl.
         // the reduce, 8 x 8 | best-fitting shape: 28 x 28 images (pads to 32 x 32, +14 %) 77 | 81 (8 x 4), 14 x 14 (16 x 16,
         // +14 %) 75 | 83 (16 x 2) — a stage of 64 pixels per half with one barrier beats 32 pixels without padding
-        static const int cand[3][2] = {{8, 8}, {8, 4}, {16, 2}};
-        static const int force = getenv("PRIMIA_WGP_SHAPE") ? atoi(getenv("PRIMIA_WGP_SHAPE")) : -1;   // 0 | 1 | 2
-        long slots[3], best = -1;
-        for (int i = 0; i < 3; ++i) {
+        static const int cand[4][2] = {{8, 8}, {8, 4}, {16, 2}, {16, 7}};
+        static const int force = getenv("PRIMIA_WGP_SHAPE") ? atoi(getenv("PRIMIA_WGP_SHAPE")) : -1;   // 0 .. 3
+        long slots[4], best = -1;
+        for (int i = 0; i < 4; ++i) {
             slots[i] = (long)((w.W + cand[i][0] - 1) / cand[i][0] * cand[i][0]) * ((w.H + cand[i][1] - 1) / cand[i][1] * cand[i][1]);
-            if (best < 0 || slots[i] < best) best = slots[i];
+            if (i < 3 && (best < 0 || slots[i] < best)) best = slots[i];
         }
         int pick = 0;
-        if (force >= 0 && force < 3) {
+        if (force >= 0 && force < 4) {
             pick = force;
+        } else if (wgp_tall7() && w.H % 7 == 0 && slots[3] * 100 <= slots[0] * 90) {
+            pick = 3;        // 7-row bands of 16-column strips (a 2-stage ring of 72 KiB stages): H = 28, 14
         } else if (slots[0] * 100 > best * 135) {
             pick = slots[1] <= slots[2] ? 1 : 2;
         }
@@ -1171,13 +1179,13 @@ static void fill_patch_params(PatchParams& p, const WgradParams& w, const PatchG
     p.ws = store ? w.ws : nullptr;
 }
 
-template <int SW, int SH>
+template <int SW, int SH, int STAGES = 3>
 static int launch_patch33(const WgradParams& w, const PatchGeom& g, hipStream_t st) {
     PatchParams p;
     fill_patch_params(p, w, g);
-    // the stage ring (at most 120 KiB), or the 144 KiB the two halves need to meet in after the main loop
+    // the stage ring (at most 144 KiB), or the 144 KiB the two halves need to meet in after the main loop
     const size_t lds = (size_t)kSlab * 4;
-    auto kern = conv_wgrad_patch33_kernel<SW, SH, 3>;
+    auto kern = conv_wgrad_patch33_kernel<SW, SH, STAGES>;
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -1275,7 +1283,7 @@ int wgrad_patch_dispatch(const WgradParams& w, hipStream_t st) {
     const PatchGeom g = patch_geom(w);
     if (!g.ok) return PRIMIA_ERR_UNSUPPORTED;
     if (use_v3()) {
-        if (g.SW == 16) return launch_patch33<16, 2>(w, g, st);
+        if (g.SW == 16) return g.SH == 7 ? launch_patch33<16, 7, 2>(w, g, st) : launch_patch33<16, 2>(w, g, st);
         return g.SH == 8 ? launch_patch33<8, 8>(w, g, st) : launch_patch33<8, 4>(w, g, st);
     }
     return g.wide ? launch_patch<16>(w, g, st) : launch_patch<8>(w, g, st);
