@@ -60,9 +60,8 @@ struct C64Params {
 // block's MFMAs.  (The 8-wave form ran every wave of the CU through those phases in lockstep: with staging and stores
 // switched off it still took 60 us for 32 us worth of MFMAs.)  Wave (kh, ph): out-channels 32*kh..+31, patch rows
 // 4*ph..4*ph+3 = two 16-pixel MFMA column blocks q = 0, 1; one 8x8 patch per stage.
-template <bool ACC>
+template <bool ACC, int STAGES = 3>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(C64Params p) {
-    constexpr int STAGES = 3;
     constexpr int HALO = 13 * 1024;        // 100 slots used, 104 staged (13 DMA instructions)
     constexpr int STAGE = HALO;            // one patch per stage
     // output rows of one stage: 64 pixels x 64 channels, bf16 — or fp32 in the accumulate form, which adds the old
@@ -289,7 +288,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (s < nstages) stage(s);
     int cur = 0, nxt = STAGES - 1;
     for (int s = 0; s < nstages; ++s) {
-        if (exact && s + 1 < nstages) {
+        if (exact && STAGES == 4 && s + 2 < nstages) {
+            // 4-deep ring: DMA(s+1) and DMA(s+2) may stay in flight
+            if (wave == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else if (exact && s + 1 < nstages) {
             // only DMA(s+1) may stay in flight.  (Counting the row stores of iteration s-1 in as well — vmcnt(d + 2) —
             // is WRONG: stores and loads retire out of order with respect to each other, so two early store
             // completions let the wave through with two pieces of DMA(s) still in flight.  Seen as run-to-run
@@ -367,21 +370,29 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     static const int dbg = getenv("PRIMIA_C64_DEBUG") ? atoi(getenv("PRIMIA_C64_DEBUG")) : 0;
     p.debug = dbg;
     const int grid = (int)((p.total + per - 1) / per);
-    const size_t lds = (size_t)3 * 13 * 1024 + 2 * 64 * (accumulate ? 256 : 128);
+    // plain form: a 4-deep ring (68 KiB per block, two blocks per CU) keeps 78 KB per CU in flight instead of 52
+    static const int deep = getenv("PRIMIA_C64_STAGES") ? atoi(getenv("PRIMIA_C64_STAGES")) : 4;
+    const int stages = (!accumulate && deep == 4) ? 4 : 3;
+    const size_t lds = (size_t)stages * 13 * 1024 + 2 * 64 * (accumulate ? 256 : 128);
     static bool attr_set = false;
     if (!attr_set) {
         const int lds_plain = 3 * 13 * 1024 + 2 * 64 * 128, lds_acc = 3 * 13 * 1024 + 2 * 64 * 256;
-        if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        const int lds_plain4 = 4 * 13 * 1024 + 2 * 64 * 128;
+        if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_plain) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_plain4) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_acc) != hipSuccess)
             return PRIMIA_ERR_LAUNCH;
         attr_set = true;
     }
     if (accumulate)
-        conv3x3_c64_kernel<true><<<grid, 256, lds, st>>>(p);
+        conv3x3_c64_kernel<true, 3><<<grid, 256, lds, st>>>(p);
+    else if (stages == 4)
+        conv3x3_c64_kernel<false, 4><<<grid, 256, lds, st>>>(p);
     else
-        conv3x3_c64_kernel<false><<<grid, 256, lds, st>>>(p);
+        conv3x3_c64_kernel<false, 3><<<grid, 256, lds, st>>>(p);
     return launch_status();
 }
 

@@ -984,6 +984,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
 
     // One stage of this wave's sub-patch: NK k-steps x 9 MFMAs.  Y[y] = dy fragment whose first row is image row y - 1
     // of the sub-patch; tap row r of k-step j needs Y[FR j + 2 - r].
+    const bool prio = (p.debug_skip_epilogue & 64) != 0;
     auto compute = [&](int buf) {
         typedef __attribute__((address_space(3))) char* ldsp_t;
         const ldsp_t sb = (ldsp_t)(size_t)(lds0 + buf * STAGE);
@@ -1021,11 +1022,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
                 for (int y = FR * j + 3; y < FR * (j + 1) + 3; ++y) Y[y] = read_y(y);
             }
             if (PRIMIA_WGP33_PIN) __builtin_amdgcn_sched_barrier(0);
+            if (prio) __builtin_amdgcn_s_setprio(1);   // the partner wave's reads / DMA issue must not take slots from the MFMAs
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
                     acc[3 * r + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[FR * j + 2 - r], X[j & 1][s], acc[3 * r + s], 0, 0, 0);
+            if (prio) __builtin_amdgcn_s_setprio(0);
             if (PRIMIA_WGP33_PIN) __builtin_amdgcn_sched_barrier(0);
         }
     };
