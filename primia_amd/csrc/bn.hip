@@ -23,7 +23,7 @@ __device__ __forceinline__ float bn_affine(float y, float mean, float scale, flo
 
 // ---- generic column reduction of two per-element quantities ------------------------------------
 // Threads are laid out [rows_per_pass][C/CH]; thread (rg, cc) owns channels cc*CH..+CH-1.
-template <typename T, typename F>
+template <typename T, typename F, int UNROLL = 0>
 __global__ __launch_bounds__(256) void colreduce2_kernel(F f, long M, int C, long rows_per_block,
                                                          float* __restrict__ partials) {
     constexpr int CH = Chunk<T>::N;
@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void colreduce2_kernel(F f, long M, int C, lon
         F lf = f;
         lf.prepare(cc * CH);  // per-channel constants -> registers (the functor's stores must not force reloads)
         long r = r0 + rg;
-        constexpr int U = F::kUnroll;  // rows per trip: independent loads overlap (measured per functor)
+        constexpr int U = UNROLL ? UNROLL : F::kUnroll;  // rows per trip: independent loads overlap (measured per functor)
         for (; r + (long)(U - 1) * rpp < r1; r += (long)U * rpp) {
 #pragma unroll
             for (int u = 0; u < U; ++u) lf(r + (long)u * rpp, (r + (long)u * rpp) * C + cc * CH, cc * CH, s1, s2);
@@ -304,7 +304,8 @@ __global__ __launch_bounds__(256) void bn_apply_pair_kernel(const T* __restrict_
 }
 
 // dy = gamma*invstd * (g - dbeta/M - xhat*dgamma/M); optionally g_out = g.
-template <typename T>
+// U chunks per thread and trip: their loads are requested together (U = 2: twice the bytes in flight per CU).
+template <typename T, int U = 1>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ z,
                                                            const T* dz, T* __restrict__ dy, T* g_out,
                                                            const float* __restrict__ gamma,
@@ -328,34 +329,50 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     __syncthreads();
     const int cpr = C / CH;
     const long stride = (long)gridDim.x * 256;
-    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < nchunks; q += stride) {
-        const int c0 = (int)(q % cpr) * CH;
-        float vy[CH], vg[CH];
-        Chunk<T>::unpack(*(const u32x4*)(y + q * CH), vy);
-        Chunk<T>::unpack(*(const u32x4*)(dz + q * CH), vg);
-        if (z) {
-            float vz[CH];
-            Chunk<T>::unpack(*(const u32x4*)(z + q * CH), vz);
+    for (long q0 = (long)blockIdx.x * 256 + threadIdx.x; q0 < nchunks; q0 += stride * U) {
+        u32x4 ry[U], rg[U], rz[U];
+        unsigned rm[U];
 #pragma unroll
-            for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
-        } else if (mask) {
-            const unsigned m = mask[q];
+        for (int u = 0; u < U; ++u) {
+            const long q = q0 + u * stride;
+            const long qc = q < nchunks ? q : q0;          // clamped: the loads of all U chunks go out unconditionally
+            ry[u] = *(const u32x4*)(y + qc * CH);
+            rg[u] = *(const u32x4*)(dz + qc * CH);
+            if (z) rz[u] = *(const u32x4*)(z + qc * CH);
+            else if (mask) rm[u] = mask[qc];
+        }
 #pragma unroll
-            for (int i = 0; i < CH; ++i) vg[i] = (m >> i) & 1u ? vg[i] : 0.f;
-        } else if (beta) {
+        for (int u = 0; u < U; ++u) {
+            const long q = q0 + u * stride;
+            if (q >= nchunks) break;
+            const int c0 = (int)(q % cpr) * CH;
+            float vy[CH], vg[CH];
+            Chunk<T>::unpack(ry[u], vy);
+            Chunk<T>::unpack(rg[u], vg);
+            if (z) {
+                float vz[CH];
+                Chunk<T>::unpack(rz[u], vz);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+            } else if (mask) {
+                const unsigned m = rm[u];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) vg[i] = (m >> i) & 1u ? vg[i] : 0.f;
+            } else if (beta) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const float zz = bn_affine(vy[i], sm[0][c0 + i], sm[5][c0 + i], sm[6][c0 + i]);
+                    vg[i] = zz > 0.f ? vg[i] : 0.f;
+                }
+            }
+            if (g_out) *(u32x4*)(g_out + q * CH) = Chunk<T>::pack(vg);
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const float zz = bn_affine(vy[i], sm[0][c0 + i], sm[5][c0 + i], sm[6][c0 + i]);
-                vg[i] = zz > 0.f ? vg[i] : 0.f;
+                const float xh = (vy[i] - sm[0][c0 + i]) * sm[1][c0 + i];
+                vy[i] = sm[2][c0 + i] * (vg[i] - sm[3][c0 + i] - xh * sm[4][c0 + i]);
             }
+            *(u32x4*)(dy + q * CH) = Chunk<T>::pack(vy);
         }
-        if (g_out) *(u32x4*)(g_out + q * CH) = Chunk<T>::pack(vg);
-#pragma unroll
-        for (int i = 0; i < CH; ++i) {
-            const float xh = (vy[i] - sm[0][c0 + i]) * sm[1][c0 + i];
-            vy[i] = sm[2][c0 + i] * (vg[i] - sm[3][c0 + i] - xh * sm[4][c0 + i]);
-        }
-        *(u32x4*)(dy + q * CH) = Chunk<T>::pack(vy);
     }
 }
 
@@ -679,12 +696,22 @@ static int bn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
     long rpb;
     reduce_geometry(M, C, nblk, rpb);
     BwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, save_mean, save_invstd, gamma, beta, mask};
-    colreduce2_kernel<T, BwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
+    static const int runroll = getenv("PRIMIA_BN_RUNROLL") ? atoi(getenv("PRIMIA_BN_RUNROLL")) : 0;
+    if (runroll == 4)
+        colreduce2_kernel<T, BwdFn<T>, 4><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
+    else
+        colreduce2_kernel<T, BwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
     bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
     const long nchunks = M * C / Chunk<T>::N;
-    bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
-        (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean,
-        save_invstd, dbeta, dgamma, (float)(1.0 / (double)M), nchunks, C, beta, mask);
+    static const int unroll = getenv("PRIMIA_BN_UNROLL") ? atoi(getenv("PRIMIA_BN_UNROLL")) : 2;
+    if (unroll == 2 && nchunks >= 4L * 2048 * 256)
+        bn_bwd_apply_kernel<T, 2><<<stream_blocks(nchunks), 256, 0, st>>>(
+            (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean,
+            save_invstd, dbeta, dgamma, (float)(1.0 / (double)M), nchunks, C, beta, mask);
+    else
+        bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
+            (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean,
+            save_invstd, dbeta, dgamma, (float)(1.0 / (double)M), nchunks, C, beta, mask);
     return launch_status();
 }
 
