@@ -28,6 +28,28 @@ __device__ __forceinline__ void sbf_dma16(const void* g, unsigned lds_addr) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(g), "s"(lds_addr) : "memory");
 }
 
+typedef int sbf_i32x4 __attribute__((ext_vector_type(4)));
+
+// buffer-addressed LDS-DMA: 32-bit per-lane byte offset (one v_add per piece and stage instead of 64-bit pointer
+// arithmetic — the kernel is bound by VALU issue), offsets beyond num_records are zero-filled by the range check
+__device__ __forceinline__ void sbf_bdma16(unsigned voff, sbf_i32x4 rsrc, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+
+__device__ __forceinline__ sbf_i32x4 sbf_rsrc(const void* base, long bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    sbf_i32x4 r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)(unsigned)(a >> 32) & 0xffff;       // stride 0: raw buffer
+    r[2] = (int)(unsigned)(bytes > 0xfffffff0L ? 0xfffffff0L : bytes);
+    r[3] = 0x00020000;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_readfirstlane(r[j]);
+    return r;
+}
+constexpr unsigned kSbfOob = 0xfffffff0u;
+
 // chunk-pair swizzle of the dy tile (stem_conv.hip: stem_key_lin)
 __device__ __forceinline__ int sbf_key(int slot) { return ((slot >> 1) & 1) | (((slot >> 3) & 1) << 1); }
 
@@ -100,32 +122,54 @@ __global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p)
         const int tw = wave - 8;
         // 25 DMA pieces per stage: 16 y, 6 window gradients, 3 window codes; T wave w issues w, w + 8, w + 16 and, w = 0, 24
         const int npc = tw == 0 ? 4 : 3;
+        // per piece, lane constants: its byte offset from the patch's / window block's origin and, for the window
+        // pieces, the window's row and column in the 5 x 9 block (validity at the pooled image's border)
+        const sbf_i32x4 rs_y = sbf_rsrc(p.y, (long)p.N * p.Ho * p.Wo * 128);
+        const sbf_i32x4 rs_g = sbf_rsrc(p.dpool, (long)p.N * p.Hq * p.Wq * 128);
+        const sbf_i32x4 rs_c = sbf_rsrc(p.argmax, (long)p.N * p.Hq * p.Wq * 64);
+        unsigned prel[4];
+        int prow[4], pcol[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int idx = tw + 8 * it;
+            prow[it] = pcol[it] = 0;
+            if (idx < 16) {
+                const int slot = idx * 8 + (lane >> 3), sl = lane & 7;
+                const int chunk = ((((sl >> 1) ^ sbf_key(slot)) << 1) | (sl & 1));
+                prel[it] = (unsigned)((((slot >> 4) * p.Wo + (slot & 15)) * 64 + chunk * 8) * 2);
+            } else {
+                // window slot = 9 * row + col of the 5 x 9 windows (A0 + row, B0 + col)
+                const bool grad = idx < 22;
+                const int G = (grad ? idx - 16 : idx - 22) * 64 + lane;
+                const int slot = grad ? G >> 3 : G >> 2, sub = grad ? G & 7 : G & 3;
+                const int row = slot / 9, col = slot - 9 * row;
+                prow[it] = slot < 45 ? row : 1 << 20;       // (dead lanes of the last piece: never valid)
+                pcol[it] = col;
+                prel[it] = (unsigned)(grad ? (row * p.Wq + col) * 128 + sub * 16 : (row * p.Wq + col) * 64 + sub * 16);
+            }
+        }
         auto stage_raw = [&](int rbuf) {
-            const long ybase = ((long)(cn * p.Ho + cph * 8) * p.Wo + cpw * 16) * 64;
+            const unsigned ybase = (unsigned)(((cn * p.Ho + cph * 8) * p.Wo + cpw * 16) * 128);
             const int A0 = cph * 4, B0 = cpw * 8;
-            const long wbase = (long)cn * p.Hq * p.Wq;
+            const unsigned wpix = (unsigned)((cn * p.Hq + A0) * p.Wq + B0);
+            const int rmax = p.Hq - A0, cmax = p.Wq - B0;      // valid: row < rmax, col < cmax
             advance(cn, cph, cpw);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
-                const int idx = tw + 8 * it;
+                const int idx = tw + 8 * it;       // wave-uniform
                 if (idx >= 25) break;
-                const void* g;
+                const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + kSbfRaw0 + rbuf * kSbfRaw + idx * 1024);
                 if (idx < 16) {
-                    const int slot = idx * 8 + (lane >> 3), sl = lane & 7;
-                    const int chunk = ((((sl >> 1) ^ sbf_key(slot)) << 1) | (sl & 1));
-                    g = p.y + ybase + ((long)(slot >> 4) * p.Wo + (slot & 15)) * 64 + chunk * 8;
+                    sbf_bdma16(prel[it] + ybase, rs_y, dst);
                 } else {
-                    // window slot = 9 * row + col of the 5 x 9 windows (A0 + row, B0 + col); a window beyond the
-                    // pooled image is never selected (its codes are overridden below): any mapped address will do
-                    const bool grad = idx < 22;
-                    const int G = (grad ? idx - 16 : idx - 22) * 64 + lane;
-                    const int slot = grad ? G >> 3 : G >> 2, sub = grad ? G & 7 : G & 3;
-                    const int row = slot / 9, col = slot - 9 * row;
-                    const bool ok = slot < 45 && A0 + row < p.Hq && B0 + col < p.Wq;
-                    const long pix = wbase + (ok ? (long)(A0 + row) * p.Wq + B0 + col : 0);
-                    g = grad ? (const void*)(p.dpool + pix * 64 + sub * 8) : (const void*)(p.argmax + pix * 64 + sub * 16);
+                    // a window beyond the pooled image is never selected (the transformation overrides its codes):
+                    // it is left to the range check (zero fill)
+                    const bool ok = prow[it] < rmax && pcol[it] < cmax;
+                    if (idx < 22)
+                        sbf_bdma16(ok ? prel[it] + wpix * 128u : kSbfOob, rs_g, dst);
+                    else
+                        sbf_bdma16(ok ? prel[it] + wpix * 64u : kSbfOob, rs_c, dst);
                 }
-                sbf_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + kSbfRaw0 + rbuf * kSbfRaw + idx * 1024));
             }
         };
         // thread -> (chunk c8 = 8 channels, 2-column block bcol, 2-row block brow, diagonal dg of the block); its two
@@ -153,10 +197,20 @@ __global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p)
         // the wave has just requested, every stage (the builtin, not inline asm: it updates the pass's bookkeeping).
         __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
         int tph = cph, tpw = cpw;               // cursor of the transformation (window validity at the image border)
+        // lane-constant LDS offsets inside a raw buffer: the two y / dy chunks, window (0, 0) of the block (the other
+        // three are immediates: + dj slots, + 9 di slots)
+        typedef __attribute__((address_space(3))) char* ldsp_t;
+        int offy[2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int slot = (2 * brow + r) * 16 + 2 * bcol + (r ^ dg);
+            offy[r] = slot * 128 + ((((c8 >> 1) ^ sbf_key(slot)) << 5) | ((c8 & 1) << 4));
+        }
+        const int offg = kSbfTile + (brow * 9 + bcol) * 128 + c8 * 16;
+        const int offc = kSbfTile + 6 * 1024 + (brow * 9 + bcol) * 64 + c8 * 8;
         auto transform = [&](int rbuf) {
-            char* const tile = smem + kSbfRaw0 + rbuf * kSbfRaw;
-            const char* const wg = tile + kSbfTile;
-            const char* const wc = wg + 6 * 1024;
+            const ldsp_t tile = (ldsp_t)(size_t)(lds0 + kSbfRaw0 + rbuf * kSbfRaw);
+            const ldsp_t wg = tile + offg, wc = tile + offc;
             const bool rok = tph * 4 + brow + 1 < p.Hq, cok = tpw * 8 + bcol + 1 < p.Wq;   // windows di = 1 / dj = 1 exist
             if (++tpw == p.PW) {
                 tpw = 0;
@@ -165,10 +219,10 @@ __global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p)
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const int j = r ^ dg;
-                const int slot = (2 * brow + r) * 16 + 2 * bcol + j;
-                char* const yp = tile + slot * 128 + ((((c8 >> 1) ^ sbf_key(slot)) << 5) | ((c8 & 1) << 4));
+                const ldsp_t yp = tile + offy[r];
                 float vy[8], g[8];
-                Chunk<bf16>::unpack(*(const u32x4*)yp, vy);
+                const u32x4 yraw = *(const __attribute__((address_space(3))) u32x4*)yp;
+                Chunk<bf16>::unpack(yraw, vy);
 #pragma unroll
                 for (int k = 0; k < 8; ++k) g[k] = 0.f;
                 // the summation order of the unfused kernels: window row a + i first, within it column b + j first
@@ -179,11 +233,11 @@ __global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p)
                     for (int dj = 1; dj >= 0; --dj) {
                         if (dj > j) continue;
                         const unsigned want = (unsigned)((1 + r - 2 * di) * 3 + (1 + j - 2 * dj));
-                        const int ws_ = (brow + di) * 9 + bcol + dj;
                         const bool ok = (di == 0 || rok) && (dj == 0 || cok);
                         float wv[8];
-                        Chunk<bf16>::unpack(*(const u32x4*)(wg + ws_ * 128 + c8 * 16), wv);
-                        u32x2 codes = *(const u32x2*)(wc + ws_ * 64 + c8 * 8);
+                        const u32x4 wraw = *(const __attribute__((address_space(3))) u32x4*)(wg + (di * 9 + dj) * 128);
+                        Chunk<bf16>::unpack(wraw, wv);
+                        u32x2 codes = *(const __attribute__((address_space(3))) u32x2*)(wc + (di * 9 + dj) * 64);
                         if (!ok) codes = u32x2{0xffffffffu, 0xffffffffu};
 #pragma unroll
                         for (int k = 0; k < 8; ++k)
@@ -197,7 +251,7 @@ __global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p)
                     const float xh = (vy[k] - k0[k]) * k1[k];
                     vy[k] = k2[k] * (gi - k3[k] - xh * k4[k]);
                 }
-                *(u32x4*)yp = Chunk<bf16>::pack(vy);
+                *(__attribute__((address_space(3))) u32x4*)yp = Chunk<bf16>::pack(vy);
             }
         };
 
@@ -221,15 +275,19 @@ __global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p)
     const int kh = wave >> 2, rq = wave & 3;
     const int fr = lane & 15, fg = lane >> 4;
     const int tp = fr >> 2, tc8 = (fr & 3) * 8;
+    const sbf_i32x4 rs_x = sbf_rsrc(p.xp, (long)p.N * p.Hp * p.Wp * 8);
+    unsigned xrel;      // this lane's 16 bytes of input-patch piece `wave`: row G / 20, 16-byte column G % 20
+    {
+        const int G = wave * 64 + lane;
+        const int row = G / 20, c16 = G - row * 20;
+        xrel = G < 420 ? (unsigned)((row * p.Wp + 2 * c16) * 8) : kSbfOob;
+    }
     auto stage_x = [&](int buf) {
-        const long xbase = ((long)(cn * p.Hp + cph * 16) * p.Wp + cpw * 32) * 4;
+        const unsigned xbase = (unsigned)(((cn * p.Hp + cph * 16) * p.Wp + cpw * 32) * 8);
         advance(cn, cph, cpw);
-        if (wave < 7) {
-            const int G = wave * 64 + lane;
-            const int row = G / 20, c16 = G - row * 20;
-            const bf16* g = G < 420 ? p.xp + xbase + ((long)row * p.Wp + 2 * c16) * 4 : (const bf16*)kStemFusedZeroPage;
-            sbf_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * kSbfXB + wave * 1024));
-        }
+        if (wave < 7)
+            sbf_bdma16(xrel == kSbfOob ? kSbfOob : xrel + xbase, rs_x,
+                       __builtin_amdgcn_readfirstlane(lds0 + buf * kSbfXB + wave * 1024));
     };
 
     f32x4 acc[2][2][2];  // [K fragment i][kernel row rr][element half h]
@@ -240,29 +298,43 @@ __global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p)
 #pragma unroll
             for (int h = 0; h < 2; ++h) acc[i][rr][h] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // lane-constant parts of the read addresses (stem_conv_wgrad_kernel)
+    // lane-constant parts of the read addresses (stem_conv_wgrad_kernel); k-steps, kernel rows and element halves are
+    // immediate offsets of five address registers per stage — the first version computed every one of the 48 read
+    // addresses of a stage with vector instructions (~130 per stage), and this kernel is bound by VALU issue
+    typedef __attribute__((address_space(3))) char* ldsp_t;
     const int a_slot = 8 * fg + tp;                                      // + 32*ks (+4)
-    const int b_off = ((fg >> 1) * 2) * 320 + 16 * (8 * (fg & 1) + tp) + tc8;  // + (4*ks + r)*320 + 32*h (+64 for the hi read)
+    int offa[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int s0 = a_slot + 4 * h;       // (+ 32 ks: bits 1 and 3, the swizzle key, do not change)
+            offa[i][h] = s0 * 128 + (((2 * kh + i) ^ sbf_key(s0)) << 5) + tc8;
+        }
+    const int offb = ((fg >> 1) * 2) * 320 + 16 * (8 * (fg & 1) + tp) + tc8 + 2 * rq * 320;  // + (4*ks + rr)*320 + 32*h (+64)
 
     auto compute = [&](int xbuf, int rbuf) {
-        const char* lx = smem + xbuf * kSbfXB;
-        const char* la = smem + kSbfRaw0 + rbuf * kSbfRaw;
+        const ldsp_t lb = (ldsp_t)(size_t)(lds0 + xbuf * kSbfXB) + offb;
+        const ldsp_t la = (ldsp_t)(size_t)(lds0 + kSbfRaw0 + rbuf * kSbfRaw);
+        ldsp_t pa[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) pa[i][h] = la + offa[i][h];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8_t a[2], b[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const int s0 = 32 * ks + a_slot, s1 = s0 + 4, cg = 2 * kh + i;
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(la + s0 * 128 + ((cg ^ sbf_key(s0)) << 5) + tc8));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(la + s1 * 128 + ((cg ^ sbf_key(s1)) << 5) + tc8));
+                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(pa[i][0] + ks * 4096));
+                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(pa[i][1] + ks * 4096));
                 a[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const int r = 2 * rq + rr;  // r == 7: no such kernel row (skipped below, wave-uniform)
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const char* q = lx + b_off + (4 * ks + r) * 320 + 32 * h;
+                    const ldsp_t q = lb + ((4 * ks + rr) * 320 + 32 * h);
                     bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)q);
                     bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(q + 64));
                     b[rr][h] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
@@ -270,7 +342,7 @@ __global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p)
             }
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                if (2 * rq + rr == 7) continue;
+                if (2 * rq + rr == 7) continue;     // no such kernel row (wave-uniform)
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
