@@ -274,7 +274,8 @@ def main():
              4: "conv3x3_lh2_kernel (fwd + dgrad)", 11: "conv_wgrad_patch32_kernel + wgrad_patch32_reduce_kernel",
              12: "conv_wgrad_patch_kernel + wgrad_patch_reduce_kernel", 13: "conv_wgrad_dma_kernel (per-tap, stride 2 / 1x1)",
              14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)",
-             16: "conv_wgrad_patch33_kernel + wgrad_patch32_reduce_kernel"}
+             16: "conv_wgrad_patch33_kernel + wgrad_patch32_reduce_kernel",
+             17: "conv_wgrad_tap_kernel + wgrad_tile_reduce_kernel (per-tap, stride 2 / 1x1)"}
     dtc = _lib.dtype_code(dtype)
 
     def family(kind, name):

@@ -125,7 +125,7 @@ int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_ac
  *   1 conv_igemm_kernel   2 conv3x3_c64_kernel   3 conv3x3_lh_kernel   4 conv3x3_lh2_kernel
  * weight gradient:
  *   11 conv_wgrad_patch32_kernel   12 conv_wgrad_patch_kernel   13 conv_wgrad_dma_kernel   14 conv_wgrad_kernel
- *   16 conv_wgrad_patch33_kernel (3 + 3 fragments per k-step; the default)
+ *   16 conv_wgrad_patch33_kernel (3 + 3 fragments per k-step; the default)   17 conv_wgrad_tap_kernel
  *   15 the stem's (stem_conv_wgrad_kernel on the padded bf16 input, conv_wgrad_kernel<STEM> otherwise) */
 int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype);
 int primia_conv_wgrad_kernel_id(const primia_conv_desc* d, int dtype);
@@ -179,6 +179,16 @@ int primia_conv2d_wgrad(const primia_conv_desc* d, const void* x, const void* dy
 int64_t primia_conv_wgrad_ws_bytes(const primia_conv_desc* d, int dtype);
 int primia_conv2d_wgrad_ws(const primia_conv_desc* d, const void* x, const void* dy, float* dw_acc,
                            void* ws, int64_t ws_bytes, int dtype, primia_stream_t stream);
+/* A transition block's two weight gradients in ONE launch: conv1 (3x3 / stride 2, desc d) and the downsample (1x1 /
+ * stride 2, desc d2) read the same x — the downsample's input pixel is the 3x3's centre tap — so the downsample runs as a
+ * tenth tap with its own dy (torchlib/models.py:272-281 BasicBlock.conv1 / downsample[0], backwards).  dw and dw2
+ * differ from their single calls only in the grouping of the ordered fp32 sums (the pixel split is chosen so that all
+ * ten taps fit one round of blocks).  Workspace from primia_conv_wgrad_pair_ws_bytes (0: this pair is not
+ * served — PRIMIA_ERR_UNSUPPORTED from the call — use the two single calls). */
+int64_t primia_conv_wgrad_pair_ws_bytes(const primia_conv_desc* d, const primia_conv_desc* d2, int dtype);
+int primia_conv2d_wgrad_pair_ws(const primia_conv_desc* d, const void* x, const void* dy, float* dw,
+                                const primia_conv_desc* d2, const void* dy2, float* dw2, void* ws, int64_t ws_bytes,
+                                int dtype, primia_stream_t stream);
 /* Per-sample weight gradients for DP-SGD: dw_ps [N][K][klen] (fwd layout, fp32, zeroed by the caller),
  * image n's gradient in slab n. */
 int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,

@@ -47,6 +47,10 @@ struct IgemmParams {
     // pixel — so it is that class's reduction axis made longer: K more elements from dy2 against wt2 [C][K].
     const void* src2;
     const void* wt2;
+    // pixel index -> (n, h, w) without 64-bit division (set by launch_igemm): q = umulhi(m, magic), exact for
+    // m * d < 2^32; fastdiv = 0 falls back to the long division
+    unsigned magicW, magicH;
+    int fastdiv;
 };
 
 template <typename T>
@@ -112,11 +116,24 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     const int Hc = (DGRAD && p.s2_classes) ? p.Hd >> 1 : p.Hd, Wc = (DGRAD && p.s2_classes) ? p.Wd >> 1 : p.Wd;
     const long Mc = (DGRAD && p.s2_classes) ? (long)p.Nb * Hc * Wc : p.Md;
     // row index inside the (class) pixel set -> dst pixel (n, hd, wd)
+    // (the 64-bit division this replaces cost ~100 vector instructions a piece; with 2 + 2..4 calls per thread it was
+    // most of the 900 vector instructions per wave and tile of the short-reduction launches — the stride-2 data-gradient
+    // classes, the 1x1 layers — next to 64 MFMAs: profiles/r03_inst_mix.txt)
     auto dst_pixel = [&](long m, int& n, int& hd, int& wd) {
-        const int w2 = (int)(m % Wc);
-        const long t = m / Wc;
-        const int h2 = (int)(t % Hc);
-        n = (int)(t / Hc);
+        int w2, h2;
+        if (p.fastdiv) {
+            const unsigned mu = (unsigned)m;
+            const unsigned t = __umulhi(mu, p.magicW);
+            w2 = (int)(mu - t * (unsigned)Wc);
+            const unsigned nn = __umulhi(t, p.magicH);
+            h2 = (int)(t - nn * (unsigned)Hc);
+            n = (int)nn;
+        } else {
+            w2 = (int)(m % Wc);
+            const long t = m / Wc;
+            h2 = (int)(t % Hc);
+            n = (int)(t / Hc);
+        }
         if (DGRAD && p.s2_classes) {
             hd = 2 * h2 + ((cls_ph + p.pad) & 1);
             wd = 2 * w2 + ((cls_pw + p.pad) & 1);
@@ -191,22 +208,31 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
         for (int j = 0; j < PR; ++j) {
             const int row = (wid * PR + j) * 8 + (lane >> 3);
             const int chunk = (lane & 7) ^ ((row >> 1) & 7);
-            unsigned mask = 0;
-            for (int r = 0; r < p.R; ++r)
-                for (int s2 = 0; s2 < p.S; ++s2) {
-                    bool ok = mval[j];
-                    if (DGRAD) {
-                        const int th = hb[j] - r, tw = wb[j] - s2;
-                        ok = ok && th >= 0 && tw >= 0;
-                        if (p.stride == 2) ok = ok && ((th | tw) & 1) == 0;
-                        const int hs = p.stride == 2 ? th >> 1 : th, ws = p.stride == 2 ? tw >> 1 : tw;
-                        ok = ok && hs < p.Hs && ws < p.Ws;
-                    } else {
-                        const int hs = hb[j] + r, ws = wb[j] + s2;
-                        ok = ok && hs >= 0 && hs < p.Hs && ws >= 0 && ws < p.Ws;
-                    }
-                    if (ok) mask |= 1u << (r * p.S + s2);
+            // tap (r, s) is valid iff its row is and its column is: R + S tests instead of R * S compound ones
+            unsigned colm = 0, mask = 0;
+            for (int s2 = 0; s2 < p.S; ++s2) {
+                bool ok;
+                if (DGRAD) {
+                    const int tw = wb[j] - s2;
+                    ok = tw >= 0 && (p.stride != 2 || (tw & 1) == 0) && (p.stride == 2 ? tw >> 1 : tw) < p.Ws;
+                } else {
+                    const int ws = wb[j] + s2;
+                    ok = ws >= 0 && ws < p.Ws;
                 }
+                colm |= (ok ? 1u : 0u) << s2;
+            }
+            if (!mval[j]) colm = 0;
+            for (int r = 0; r < p.R; ++r) {
+                bool ok;
+                if (DGRAD) {
+                    const int th = hb[j] - r;
+                    ok = th >= 0 && (p.stride != 2 || (th & 1) == 0) && (p.stride == 2 ? th >> 1 : th) < p.Hs;
+                } else {
+                    const int hs = hb[j] + r;
+                    ok = hs >= 0 && hs < p.Hs;
+                }
+                if (ok) mask |= colm << (r * p.S);
+            }
             pmask[j] = mask;
             const int h0 = (DGRAD && p.stride == 2) ? hb[j] >> 1 : hb[j];
             const int w0 = (DGRAD && p.stride == 2) ? wb[j] >> 1 : wb[j];
@@ -602,6 +628,14 @@ static int launch_igemm(const IgemmParams& p, hipStream_t st) {
     if (DGRAD && p.s2_classes) {
         q.ntm_class = ceil_div((long)p.Nb * (p.Hd / 2) * (p.Wd / 2), BM);
         ntm = 4 * q.ntm_class;
+    }
+    {
+        const int Hc = (DGRAD && p.s2_classes) ? p.Hd >> 1 : p.Hd, Wc = (DGRAD && p.s2_classes) ? p.Wd >> 1 : p.Wd;
+        const long Mc = (DGRAD && p.s2_classes) ? (long)p.Nb * Hc * Wc : p.Md;
+        const long dmax = Hc > Wc ? Hc : Wc;
+        q.fastdiv = (Hc > 1 && Wc > 1 && (Mc + BM) * dmax < (1L << 32)) ? 1 : 0;
+        q.magicW = q.fastdiv ? (unsigned)(((1ULL << 32) + Wc - 1) / Wc) : 0u;
+        q.magicH = q.fastdiv ? (unsigned)(((1ULL << 32) + Hc - 1) / Hc) : 0u;
     }
     const int grid = ntm * q.ntile_n;
     const size_t lds = (size_t)STAGES * (BM + BN) * 128;

@@ -38,6 +38,13 @@ size_t wgrad_dma_ws_bytes(const WgradParams& p);
 int wgrad_patch_dispatch(const WgradParams& p, hipStream_t st);
 int wgrad_patch_kernel_id(const WgradParams& p);
 size_t wgrad_patch_ws_bytes(const WgradParams& p);
+// per-tap kernel of the stride-2 / 1x1 layers, second generation (conv_wgrad_tap.hip); needs the workspace
+int wgrad_tap_dispatch(const WgradParams& p, hipStream_t st);
+int wgrad_tap_kernel_id(const WgradParams& p);
+size_t wgrad_tap_ws_bytes(const WgradParams& p);
+// conv1 + downsample of a transition block in one launch (the downsample = a tenth tap with its own dy)
+int wgrad_tap_pair_dispatch(const WgradParams& p, const WgradParams& p2, hipStream_t st);
+size_t wgrad_tap_pair_ws_bytes(const WgradParams& p, const WgradParams& p2);
 // stem (7x7/2) halo kernel on the padded input (stem_conv.hip)
 int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, int H, int W, hipStream_t st,
                              float* ws = nullptr, size_t ws_bytes = 0, double* sqnorm = nullptr);

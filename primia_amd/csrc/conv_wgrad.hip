@@ -471,6 +471,8 @@ extern "C" int64_t primia_conv_wgrad_ws_bytes(const primia_conv_desc* d, int dty
     if (!force && !g.stem) {
         const size_t n = wgrad_patch_ws_bytes(p);
         if (n > 0) return (int64_t)n;
+        const size_t nt = wgrad_tap_ws_bytes(p);
+        if (nt > 0) return (int64_t)nt;
     }
     if (!g.stem && dma) return (int64_t)wgrad_dma_ws_bytes(p);
     if (g.stem) return (int64_t)wgrad_ws_need<bf16, 64, 32, true>(p);
@@ -481,6 +483,27 @@ extern "C" int64_t primia_conv_wgrad_ws_bytes(const primia_conv_desc* d, int dty
 extern "C" int primia_conv2d_wgrad_ws(const primia_conv_desc* d, const void* x, const void* dy, float* dw,
                                       void* ws, int64_t ws_bytes, int dtype, primia_stream_t stream) {
     return conv2d_wgrad_impl(d, x, dy, dw, 0, dtype, stream, nullptr, (float*)ws, ws_bytes > 0 ? (size_t)ws_bytes : 0);
+}
+
+extern "C" int64_t primia_conv_wgrad_pair_ws_bytes(const primia_conv_desc* d, const primia_conv_desc* d2, int dtype) {
+    WgradParams p, p2;
+    ConvGeom g, g2;
+    if (!fill_wgrad_params(d, p, g) || !fill_wgrad_params(d2, p2, g2)) return PRIMIA_ERR_ARG;
+    if (dtype != PRIMIA_BF16 || getenv("PRIMIA_WGRAD")) return 0;
+    return (int64_t)wgrad_tap_pair_ws_bytes(p, p2);
+}
+
+extern "C" int primia_conv2d_wgrad_pair_ws(const primia_conv_desc* d, const void* x, const void* dy, float* dw,
+                                           const primia_conv_desc* d2, const void* dy2, float* dw2, void* ws,
+                                           int64_t ws_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && d2 && x && dy && dy2 && dw && dw2);
+    WgradParams p, p2;
+    ConvGeom g, g2;
+    PRIMIA_REQUIRE(fill_wgrad_params(d, p, g) && fill_wgrad_params(d2, p2, g2));
+    if (dtype != PRIMIA_BF16 || getenv("PRIMIA_WGRAD")) return PRIMIA_ERR_UNSUPPORTED;
+    p.x = x; p.dy = dy; p.dw = dw; p.ws = (float*)ws; p.ws_bytes = ws && ws_bytes > 0 ? (size_t)ws_bytes : 0;
+    p2.x = x; p2.dy = dy2; p2.dw = dw2;
+    return wgrad_tap_pair_dispatch(p, p2, (hipStream_t)stream);
 }
 
 extern "C" int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,
@@ -504,6 +527,8 @@ extern "C" int primia_conv_wgrad_kernel_id(const primia_conv_desc* d, int dtype)
     if (!force) {
         const int id = wgrad_patch_kernel_id(p);
         if (id) return id;
+        const int idt = wgrad_tap_kernel_id(p);
+        if (idt) return idt;
     }
     const bool dma = force == 'd' || (force != 'o' && (g.C >= 256 || (g.K >= 256 && g.C >= 128)));
     return dma ? 13 : 14;
@@ -534,6 +559,8 @@ static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const voi
         if (!force && !g.stem) {
             const int rc = wgrad_patch_dispatch(p, st);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+            const int rt = wgrad_tap_dispatch(p, st);     // stride-2 / 1x1 layers with a workspace
+            if (rt != PRIMIA_ERR_UNSUPPORTED) return rt;
         }
         if (!g.stem && dma) return wgrad_dma_dispatch(p, st);
         if (g.stem) return launch_wgrad<bf16, 64, 32, true>(p, st);

@@ -126,9 +126,15 @@ class ResNet18Engine:
             if c.spec.name != stem.name:
                 c.w_dgrad = torch.empty(query("primia_conv_wdgrad_elems", c.desc), dtype=dtype, device=dev)
             c.acc = self.dw_acc[c.acc_off:c.acc_off + c.wfwd_n]
+        # a transition block's conv1 + downsample weight gradients as one launch (primia_conv2d_wgrad_pair_ws)
+        self._pair_ws = {}
+        for blk in self.spec.blocks:
+            if blk.down is not None:
+                self._pair_ws[blk.conv1.name] = query("primia_conv_wgrad_pair_ws_bytes", self.convs[blk.conv1.name].desc,
+                                                      self.convs[blk.down.name].desc, self.dt)
         # workspace of the atomic-free weight-gradient path (primia_conv2d_wgrad_ws): the layers run one after
         # the other on one stream, so they share one buffer sized for the largest (38 MB at batch 256)
-        ws_bytes = max(max(ws_need.values()), self._stem_ws_bytes)
+        ws_bytes = max(max(ws_need.values()), self._stem_ws_bytes, max(list(self._pair_ws.values()) + [0]))
         self.wgrad_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev) if ws_bytes > 0 else None
         self.wgrad_ws_bytes = ws_bytes
 
@@ -559,6 +565,20 @@ class ResNet18Engine:
         call("primia_bn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, self.gviews[b + ".weight"],
              self.gviews[b + ".bias"], y.shape[0], y.shape[1], int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
 
+    wgrad_pair = os.environ.get("PRIMIA_WGRAD_PAIR", "1") != "0"
+
+    def _wgrad_transition(self, blk, x, dy1, dyd):
+        """conv1 and the downsample of a transition block: one launch where the library serves the pair."""
+        c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
+        if (self.wgrad_pair and self.dp is None and self.wgrad_ws is not None and not self.wgrad_overlap
+                and self._pair_ws.get(blk.conv1.name, 0) > 0):
+            self._timed("wgrad", c1, lambda: call("primia_conv2d_wgrad_pair_ws", c1.desc, x, dy1, c1.acc, cd.desc, dyd,
+                                                  cd.acc, self.wgrad_ws, self.wgrad_ws_bytes, self.dt),
+                        extra_macs=self._macs(cd))
+            return
+        self._wgrad(blk.conv1.name, x, dy1)
+        self._wgrad(blk.down.name, x, dyd)
+
     def _wgrad(self, name, x, dy):
         c = self.convs[name]
         if self.dp is not None:  # DP-SGD: weight gradients wait for the per-sample clip factors
@@ -668,14 +688,12 @@ class ResNet18Engine:
                 c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
                 self._join_wgrad_stream()
                 if self.wgrad_first:
-                    self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
-                    self._wgrad(blk.down.name, x_in, t[p + ".dyd"])
+                    self._wgrad_transition(blk, x_in, t[p + ".dy1"], t[p + ".dyd"])
                 self._timed("dgrad", c1, lambda: call("primia_conv2d_dgrad_pair", c1.desc, t[p + ".dy1"], c1.w_dgrad,
                                                       cd.desc, t[p + ".dyd"], cd.w_dgrad, dx_in, self.dt),
                             extra_macs=self._macs(cd))
                 if not self.wgrad_first:
-                    self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
-                    self._wgrad(blk.down.name, x_in, t[p + ".dyd"])
+                    self._wgrad_transition(blk, x_in, t[p + ".dy1"], t[p + ".dyd"])
             elif blk.down is not None:
                 self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, False)
                 self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])

@@ -742,6 +742,45 @@ def test_stem_conv_emits_batchnorm_partials_and_fused_tail_from_sums(cuda):
         assert relerr(a, b) < 1e-5
 
 
+@pytest.mark.parametrize("N,H,C,K", [(4, 28, 128, 256), (2, 56, 64, 128), (3, 14, 256, 512), (2, 6, 64, 128)])
+def test_transition_block_weight_gradients_in_one_launch(cuda, N, H, C, K):
+    """primia_conv2d_wgrad_pair_ws (conv1 3x3/2 + downsample 1x1/2 of a transition block, the downsample as a tenth tap of
+    the per-tap kernel) against the two single calls and against the fp32 oracle on the rounded operands."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(5 + H)
+    x = rnd(torch.randn(N, C, H, H, generator=g), dtype)
+    Ho = H // 2
+    dy1 = rnd(torch.randn(N, K, Ho, Ho, generator=g), dtype)
+    dyd = rnd(torch.randn(N, K, Ho, Ho, generator=g), dtype)
+    d1, dd = ConvDesc.make(N, H, H, C, K, 3, 3, 2, 1), ConvDesc.make(N, H, H, C, K, 1, 1, 2, 0)
+    need = query("primia_conv_wgrad_pair_ws_bytes", d1, dd, dt)
+    assert need > 0
+    xd, dy1d, dydd = to_nhwc(x, dtype, cuda), to_nhwc(dy1, dtype, cuda), to_nhwc(dyd, dtype, cuda)
+    ws = torch.full((need // 4,), float("nan"), device=cuda)
+    n1, nd = query("primia_conv_wfwd_elems", d1), query("primia_conv_wfwd_elems", dd)
+    a1, ad = torch.full((n1,), float("nan"), device=cuda), torch.full((nd,), float("nan"), device=cuda)
+    call("primia_conv2d_wgrad_pair_ws", d1, xd, dy1d, a1, dd, dydd, ad, ws, need, dt)
+    # single calls
+    s1 = query("primia_conv_wgrad_ws_bytes", d1, dt)
+    sd = query("primia_conv_wgrad_ws_bytes", dd, dt)
+    w1, wd = torch.empty(max(s1, 16) // 4, device=cuda), torch.empty(max(sd, 16) // 4, device=cuda)
+    b1, bd = torch.zeros(n1, device=cuda), torch.zeros(nd, device=cuda)
+    call("primia_conv2d_wgrad_ws", d1, xd, dy1d, b1, w1, s1, dt)
+    call("primia_conv2d_wgrad_ws", dd, xd, dydd, bd, wd, sd, dt)
+    assert relerr(a1, b1) < 2e-6 and relerr(ad, bd) < 2e-6      # same products, another grouping of the ordered sums
+    # oracle
+    g1, gd = torch.empty(K, C, 3, 3, device=cuda), torch.empty(K, C, 1, 1, device=cuda)
+    call("primia_conv_wgrad_finalize", d1, C, a1, g1)
+    call("primia_conv_wgrad_finalize", dd, C, ad, gd)
+    xr = x.clone().requires_grad_(False)
+    w1r = torch.zeros(K, C, 3, 3, requires_grad=True)
+    wdr = torch.zeros(K, C, 1, 1, requires_grad=True)
+    (F.conv2d(xr, w1r, None, 2, 1) * dy1).sum().backward()
+    (F.conv2d(xr, wdr, None, 2, 0) * dyd).sum().backward()
+    assert relerr(g1, w1r.grad) < 1e-4 and relerr(gd, wdr.grad) < 1e-4
+
+
 @pytest.mark.parametrize("N,S", [(2, 64), (75, 64), (3, 96), (5, 32)])
 def test_stem_backward_fused_is_bit_identical_to_the_chain(cuda, N, S):
     """primia_stem_bwd_fused (bn1 <- relu <- maxpool backward apply inside conv1's weight-gradient kernel, dy never
