@@ -503,6 +503,107 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
         }
 }
 
+// The same kernel for bf16, PH = 1, on PACKED KEYS.  The instruction counters of round 3 showed the generic form bound
+// by vector-instruction issue, not by memory (87 M instructions per launch at batch 256 = ~140 us of issue in a 170-us
+// kernel): per window tap and channel it spends two compares, an or and two selects on the (best, argmax) pair.  A
+// stored activation is a non-negative bf16 (or NaN), whose 16 bits order like the value, so
+//     key = bits(z) << 4 | (15 - tap)            (tap = 3 r + s in scan order)
+// orders first by value, then by EARLIER tap: max over the window's keys = (maximum, first position attaining it) — two
+// instructions per tap (v_lshl_or_b32, v_max_u32), and the same result as the generic kernel bit for bit (a NaN, the
+// largest pattern, wins as it does there).
+template <int PW>
+__global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* __restrict__ y, bf16* __restrict__ pooled,
+                                                                   uint8_t* __restrict__ argmax,
+                                                                   const float* __restrict__ gamma,
+                                                                   const float* __restrict__ beta,
+                                                                   const float* __restrict__ mean,
+                                                                   const float* __restrict__ invstd, int N, int H, int W,
+                                                                   int C, int Ho, int Wo) {
+    constexpr int CH = 8, NCOL = 2 * PW + 1;
+    __shared__ float sm[3][512];
+    for (int c = threadIdx.x; c < C; c += 256) {
+        sm[0][c] = mean[c];
+        sm[1][c] = invstd[c] * gamma[c];
+        sm[2][c] = beta[c];
+    }
+    __syncthreads();
+    const int cpr = C / CH;
+    const int Wq = Wo / PW;
+    const long total = (long)N * Ho * Wq * cpr;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int cc = (int)(q % cpr);
+    long t = q / cpr;
+    const int wq = (int)(t % Wq);
+    t /= Wq;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const int c0 = cc * CH;
+    unsigned key[PW][CH];
+#pragma unroll
+    for (int k = 0; k < PW; ++k)
+#pragma unroll
+        for (int i = 0; i < CH; ++i) key[k][i] = 0u;     // below every real key (15 - tap >= 7)
+    float mu[CH], sc[CH], be[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        mu[i] = sm[0][c0 + i];
+        sc[i] = sm[1][c0 + i];
+        be[i] = sm[2][c0 + i];
+    }
+    const int w0 = wq * PW * 2 - 1;   // leftmost input column of the first window
+    const int h0 = ho * 2 - 1;        // topmost input row
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr) {
+        const int h = h0 + rr;
+        if (h < 0 || h >= H) continue;
+        const bf16* row = y + (((long)n * H + h) * W) * C + c0;
+        u32x4 raw[NCOL];
+#pragma unroll
+        for (int col = 0; col < NCOL; ++col) {
+            const int w = w0 + col;
+            raw[col] = u32x4{0, 0, 0, 0};
+            if (w >= 0 && w < W) raw[col] = *(const u32x4*)(row + (long)w * C);
+        }
+#pragma unroll
+        for (int col = 0; col < NCOL; ++col) {
+            const int w = w0 + col;
+            if (w < 0 || w >= W) continue;
+            float v[CH];
+            Chunk<bf16>::unpack(raw[col], v);
+            unsigned zb[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i)   // the stored activation's bits (sign cleared: -0 orders like +0, NaN stays NaN)
+                zb[i] = (unsigned)f32_to_bf16(fmaxf(bn_affine(v[i], mu[i], sc[i], be[i]), 0.f)) & 0x7fffu;
+#pragma unroll
+            for (int k = 0; k < PW; ++k) {
+                const int s_ = col - 2 * k;  // tap column of window k
+                if (s_ < 0 || s_ > 2) continue;
+                const unsigned tail = 15u - (unsigned)(rr * 3 + s_);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const unsigned cand = (zb[i] << 4) | tail;
+                    key[k][i] = cand > key[k][i] ? cand : key[k][i];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PW; ++k) {
+        const long o = (((long)n * Ho + ho) * Wo + wq * PW + k) * C + c0;
+        u32x4 pv;
+        uint32_t pk[2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) pv[j] = (key[k][2 * j] >> 4) | ((key[k][2 * j + 1] >> 4) << 16);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            pk[j] = (15u - (key[k][4 * j] & 15u)) | ((15u - (key[k][4 * j + 1] & 15u)) << 8) |
+                    ((15u - (key[k][4 * j + 2] & 15u)) << 16) | ((15u - (key[k][4 * j + 3] & 15u)) << 24);
+        *(u32x4*)(pooled + o) = pv;
+        *(u32x2*)(argmax + o) = u32x2{pk[0], pk[1]};
+    }
+}
+
 // gradient w.r.t. z(n, h, w, c0..c0+CH-1) coming back through the pool.  A pixel lies in at most 2 x 2
 // windows: along each axis candidate A = ((h + 1) >> 1, tap h + 1 - 2*ho) always exists (if in range) and
 // candidate B = ((h - 1) >> 1, tap 2) only for odd h.  Branch-free: loads go to a clamped address and are
@@ -890,6 +991,14 @@ static void launch_bn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax
     const int ph = (Ho % 2 == 0 && twoh) ? 2 : 1;
     const long total = (long)N * (Ho / ph) * (Wo / pw) * (C / Chunk<T>::N);
     const unsigned grid = (unsigned)((total + 255) / 256);
+    static const bool key_off = getenv("PRIMIA_POOL_KEY") && getenv("PRIMIA_POOL_KEY")[0] == '0';
+    if constexpr (sizeof(T) == 2) {
+        if (!key_off && ph == 1) {       // packed (value, first position) keys: half the vector instructions
+            auto kk = pw == 2 ? bn_relu_pool_fwd_key_kernel<2> : bn_relu_pool_fwd_key_kernel<1>;
+            kk<<<grid, 256, 0, st>>>((const bf16*)y, (bf16*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo);
+            return;
+        }
+    }
     auto kern = pw == 2 ? (ph == 2 ? bn_relu_pool_fwd_kernel<T, 2, 2> : bn_relu_pool_fwd_kernel<T, 2, 1>)
                         : (ph == 2 ? bn_relu_pool_fwd_kernel<T, 1, 2> : bn_relu_pool_fwd_kernel<T, 1, 1>);
     kern<<<grid, 256, 0, st>>>((const T*)y, (T*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo);
