@@ -511,7 +511,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
 // orders first by value, then by EARLIER tap: max over the window's keys = (maximum, first position attaining it) — two
 // instructions per tap (v_lshl_or_b32, v_max_u32), and the same result as the generic kernel bit for bit (a NaN, the
 // largest pattern, wins as it does there).
-template <int PW>
+template <int PW, int PH>
 __global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* __restrict__ y, bf16* __restrict__ pooled,
                                                                    uint8_t* __restrict__ argmax,
                                                                    const float* __restrict__ gamma,
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* _
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, int N, int H, int W,
                                                                    int C, int Ho, int Wo) {
-    constexpr int CH = 8, NCOL = 2 * PW + 1;
+    constexpr int CH = 8, NCOL = 2 * PW + 1, NROW = 2 * PH + 1;
     __shared__ float sm[3][512];
     for (int c = threadIdx.x; c < C; c += 256) {
         sm[0][c] = mean[c];
@@ -528,22 +528,24 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* _
     }
     __syncthreads();
     const int cpr = C / CH;
-    const int Wq = Wo / PW;
-    const long total = (long)N * Ho * Wq * cpr;
+    const int Wq = Wo / PW, Hq = Ho / PH;
+    const long total = (long)N * Hq * Wq * cpr;
     const long q = (long)blockIdx.x * 256 + threadIdx.x;
     if (q >= total) return;
     const int cc = (int)(q % cpr);
     long t = q / cpr;
     const int wq = (int)(t % Wq);
     t /= Wq;
-    const int ho = (int)(t % Ho);
-    const int n = (int)(t / Ho);
+    const int hq = (int)(t % Hq);
+    const int n = (int)(t / Hq);
     const int c0 = cc * CH;
-    unsigned key[PW][CH];
+    unsigned key[PH][PW][CH];
 #pragma unroll
-    for (int k = 0; k < PW; ++k)
+    for (int kh = 0; kh < PH; ++kh)
 #pragma unroll
-        for (int i = 0; i < CH; ++i) key[k][i] = 0u;     // below every real key (15 - tap >= 7)
+        for (int k = 0; k < PW; ++k)
+#pragma unroll
+            for (int i = 0; i < CH; ++i) key[kh][k][i] = 0u;     // below every real key (15 - tap >= 7)
     float mu[CH], sc[CH], be[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
@@ -552,9 +554,9 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* _
         be[i] = sm[2][c0 + i];
     }
     const int w0 = wq * PW * 2 - 1;   // leftmost input column of the first window
-    const int h0 = ho * 2 - 1;        // topmost input row
+    const int h0 = hq * PH * 2 - 1;   // topmost input row of the first window
 #pragma unroll
-    for (int rr = 0; rr < 3; ++rr) {
+    for (int rr = 0; rr < NROW; ++rr) {
         const int h = h0 + rr;
         if (h < 0 || h >= H) continue;
         const bf16* row = y + (((long)n * H + h) * W) * C + c0;
@@ -576,32 +578,39 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* _
             for (int i = 0; i < CH; ++i)   // the stored activation's bits (sign cleared: -0 orders like +0, NaN stays NaN)
                 zb[i] = (unsigned)f32_to_bf16(fmaxf(bn_affine(v[i], mu[i], sc[i], be[i]), 0.f)) & 0x7fffu;
 #pragma unroll
-            for (int k = 0; k < PW; ++k) {
-                const int s_ = col - 2 * k;  // tap column of window k
-                if (s_ < 0 || s_ > 2) continue;
-                const unsigned tail = 15u - (unsigned)(rr * 3 + s_);
+            for (int kh = 0; kh < PH; ++kh) {
+                const int r = rr - 2 * kh;       // tap row of window kh
+                if (r < 0 || r > 2) continue;
 #pragma unroll
-                for (int i = 0; i < CH; ++i) {
-                    const unsigned cand = (zb[i] << 4) | tail;
-                    key[k][i] = cand > key[k][i] ? cand : key[k][i];
+                for (int k = 0; k < PW; ++k) {
+                    const int s_ = col - 2 * k;  // tap column of window k
+                    if (s_ < 0 || s_ > 2) continue;
+                    const unsigned tail = 15u - (unsigned)(r * 3 + s_);
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        const unsigned cand = (zb[i] << 4) | tail;
+                        key[kh][k][i] = cand > key[kh][k][i] ? cand : key[kh][k][i];
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int k = 0; k < PW; ++k) {
-        const long o = (((long)n * Ho + ho) * Wo + wq * PW + k) * C + c0;
-        u32x4 pv;
-        uint32_t pk[2];
+    for (int kh = 0; kh < PH; ++kh)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) pv[j] = (key[k][2 * j] >> 4) | ((key[k][2 * j + 1] >> 4) << 16);
+        for (int k = 0; k < PW; ++k) {
+            const long o = (((long)n * Ho + hq * PH + kh) * Wo + wq * PW + k) * C + c0;
+            u32x4 pv;
+            uint32_t pk[2];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-            pk[j] = (15u - (key[k][4 * j] & 15u)) | ((15u - (key[k][4 * j + 1] & 15u)) << 8) |
-                    ((15u - (key[k][4 * j + 2] & 15u)) << 16) | ((15u - (key[k][4 * j + 3] & 15u)) << 24);
-        *(u32x4*)(pooled + o) = pv;
-        *(u32x2*)(argmax + o) = u32x2{pk[0], pk[1]};
-    }
+            for (int j = 0; j < 4; ++j) pv[j] = (key[kh][k][2 * j] >> 4) | ((key[kh][k][2 * j + 1] >> 4) << 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                pk[j] = (15u - (key[kh][k][4 * j] & 15u)) | ((15u - (key[kh][k][4 * j + 1] & 15u)) << 8) |
+                        ((15u - (key[kh][k][4 * j + 2] & 15u)) << 16) | ((15u - (key[kh][k][4 * j + 3] & 15u)) << 24);
+            *(u32x4*)(pooled + o) = pv;
+            *(u32x2*)(argmax + o) = u32x2{pk[0], pk[1]};
+        }
 }
 
 // gradient w.r.t. z(n, h, w, c0..c0+CH-1) coming back through the pool.  A pixel lies in at most 2 x 2
@@ -993,9 +1002,16 @@ static void launch_bn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax
     const unsigned grid = (unsigned)((total + 255) / 256);
     static const bool key_off = getenv("PRIMIA_POOL_KEY") && getenv("PRIMIA_POOL_KEY")[0] == '0';
     if constexpr (sizeof(T) == 2) {
-        if (!key_off && ph == 1) {       // packed (value, first position) keys: half the vector instructions
-            auto kk = pw == 2 ? bn_relu_pool_fwd_key_kernel<2> : bn_relu_pool_fwd_key_kernel<1>;
-            kk<<<grid, 256, 0, st>>>((const bf16*)y, (bf16*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo);
+        if (!key_off) {       // packed (value, first position) keys: half the vector instructions
+            // (two windows along H per thread as well — 25 loads and evaluations for 4 windows instead of 30 — measured
+            // slower again: 236 vs 225 us for statistics + pool at batch 256; opt-in: PRIMIA_POOL_KEYPH=2)
+            static const bool keyph2 = getenv("PRIMIA_POOL_KEYPH") && getenv("PRIMIA_POOL_KEYPH")[0] == '2';
+            const int kph = (Ho % 2 == 0 && keyph2) ? 2 : 1;
+            const long ktotal = (long)N * (Ho / kph) * (Wo / pw) * (C / 8);
+            const unsigned kgrid = (unsigned)((ktotal + 255) / 256);
+            auto kk = pw == 2 ? (kph == 2 ? bn_relu_pool_fwd_key_kernel<2, 2> : bn_relu_pool_fwd_key_kernel<2, 1>)
+                              : (kph == 2 ? bn_relu_pool_fwd_key_kernel<1, 2> : bn_relu_pool_fwd_key_kernel<1, 1>);
+            kk<<<kgrid, 256, 0, st>>>((const bf16*)y, (bf16*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo);
             return;
         }
     }
