@@ -74,6 +74,27 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+typedef int ig_i32x4 __attribute__((ext_vector_type(4)));
+
+// buffer-addressed LDS-DMA (bf16 launches): a 32-bit lane offset instead of a 64-bit pointer — one add and one select
+// per staged row and k-step instead of seven vector instructions; an offset beyond num_records reads zeros
+__device__ __forceinline__ void ig_bdma16(unsigned voff, ig_i32x4 rsrc, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 ::"v"(voff), "s"(rsrc), "s"(lds_addr) : "memory");
+}
+
+__device__ __forceinline__ ig_i32x4 ig_rsrc(const void* base, long bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    ig_i32x4 r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)(unsigned)(a >> 32) & 0xffff;       // stride 0: raw buffer
+    r[2] = (int)(unsigned)(bytes > 0xfffffff0L ? 0xfffffff0L : bytes);
+    r[3] = 0x00020000;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_readfirstlane(r[j]);
+    return r;
+}
+
 // WM x WN waves per block (pixels x channels); STAGES LDS buffers (STAGES-1 k-steps of DMA in flight).
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool DGRAD, bool STEM>
 __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p) {
@@ -246,8 +267,71 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     int st_tapoff = DGRAD ? -(((p.stride == 2 ? st_r >> 1 : st_r) * p.Ws + (p.stride == 2 ? st_s >> 1 : st_s)) * p.Cs)
                           : (st_r * p.Ws + st_s) * p.Cs;
     int st_regular = 0;  // regular steps left before the paired tensor's steps (set with nsteps below)
+    // bf16: buffer resources + lane-constant weight-row offsets (bytes)
+    constexpr bool BUFDMA = GLDS && sizeof(T) == 2;
+    constexpr unsigned kOob = 0xfffffff0u;
+    ig_i32x4 rs_src = {0, 0, 0, 0}, rs_wt = {0, 0, 0, 0}, rs_src2 = {0, 0, 0, 0}, rs_wt2 = {0, 0, 0, 0};
+    unsigned wbyte[WR], wbyte2[WR];
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    if constexpr (BUFDMA) {
+        rs_src = ig_rsrc(p.src, (long)p.Nb * p.Hs * p.Ws * p.Cs * 2);
+        rs_wt = ig_rsrc(p.wt, (long)p.Nd * p.klen * 2);
+        if (p.src2) {
+            rs_src2 = ig_rsrc(p.src2, (long)p.Nb * p.Hs * p.Ws * p.Cs * 2);
+            rs_wt2 = ig_rsrc(p.wt2, (long)p.Nd * p.Cs * 2);
+        }
+#pragma unroll
+        for (int j = 0; j < WR; ++j) {
+            const int row = (wid * WR + j) * 8 + (lane >> 3);
+            wbyte[j] = (unsigned)(((n0 + row) * p.klen + ((lane & 7) ^ ((row >> 1) & 7)) * CH) * 2);
+            wbyte2[j] = (unsigned)(((n0 + row) * p.Cs + ((lane & 7) ^ ((row >> 1) & 7)) * CH) * 2);
+        }
+    }
     auto stage_glds = [&](int step, int buf) {
         (void)step;  // stages are issued in order; the walk state below IS the step
+        if constexpr (BUFDMA) {
+            const unsigned lpa = lds0 + buf * (TILE_P + TILE_W), lwa = lpa + TILE_P;
+            if (DGRAD && pair && st_regular == 0) {
+                const unsigned cbit = 1u << (p.S + 1);
+#pragma unroll
+                for (int j = 0; j < PR; ++j)
+                    ig_bdma16((pmask[j] & cbit) ? (unsigned)((poff[j] + st_c0) * 2) : kOob, rs_src2,
+                              __builtin_amdgcn_readfirstlane(lpa + (wid * PR + j) * 1024));
+#pragma unroll
+                for (int j = 0; j < WR; ++j)
+                    ig_bdma16(wbyte2[j] + (unsigned)(st_c0 * 2), rs_wt2,
+                              __builtin_amdgcn_readfirstlane(lwa + (wid * WR + j) * 1024));
+                st_c0 += KE;
+                return;
+            }
+            --st_regular;
+            const int uoff = st_tapoff + st_c0;
+            const unsigned tbit = 1u << st_tap;
+#pragma unroll
+            for (int j = 0; j < PR; ++j)
+                ig_bdma16((pmask[j] & tbit) ? (unsigned)((poff[j] + uoff) * 2) : kOob, rs_src,
+                          __builtin_amdgcn_readfirstlane(lpa + (wid * PR + j) * 1024));
+            const unsigned woffb = (unsigned)((st_tap * p.Cs + st_c0) * 2);
+#pragma unroll
+            for (int j = 0; j < WR; ++j)
+                ig_bdma16(wbyte[j] + woffb, rs_wt, __builtin_amdgcn_readfirstlane(lwa + (wid * WR + j) * 1024));
+            // advance
+            st_c0 += KE;
+            if (st_c0 == p.Cs) {
+                st_c0 = 0;
+                st_s += tstep;
+                if (st_s >= p.S) {
+                    st_s = cls_pw;
+                    st_r += tstep;
+                }
+                st_tap = st_r * p.S + st_s;
+                if (DGRAD)
+                    st_tapoff = -(((p.stride == 2 ? st_r >> 1 : st_r) * p.Ws + (p.stride == 2 ? st_s >> 1 : st_s)) * p.Cs);
+                else
+                    st_tapoff = (st_r * p.Ws + st_s) * p.Cs;
+            }
+            return;
+        }
         char* lp = smem + buf * (TILE_P + TILE_W);
         char* lw = lp + TILE_P;
         if (DGRAD && pair && st_regular == 0) {
