@@ -118,32 +118,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 
     // ---- staging: 13 DMA instructions per stage, round-robin over the 4 waves (wave 0 issues 4, the others 3) ----
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    // per-lane constants of this wave's (up to 4) DMA instructions, packed: halo row / column of the lane's slot (4 bits
-    // each) and its swizzled source chunk (3 bits) — the division by 10 and the key lookup happen once, not per stage
-    unsigned hyx = 0, chk = 0;
+    // Buffer-addressed LDS-DMA: per piece the lane's byte offset from the patch origin (rel) and one validity bit for
+    // its halo row and one for its halo column are lane constants; per stage a piece costs and + compare + add +
+    // select — the first version unpacked (hy, hx), compared both against the image, built a 64-bit pointer and
+    // selected a zero page (~15 vector instructions per piece; the kernel issues ~400 instructions per wave and stage
+    // for 72 MFMAs).  Out-of-image / dead lanes get an offset beyond num_records: the hardware returns zeros.
+    typedef int c64_i32x4 __attribute__((ext_vector_type(4)));
+    c64_i32x4 rsrc;
+    {
+        const unsigned long long a = (unsigned long long)p.src;
+        const long bytes = (long)p.N * p.H * p.W * 128;
+        rsrc[0] = (int)(unsigned)a;
+        rsrc[1] = (int)(unsigned)(a >> 32) & 0xffff;
+        rsrc[2] = (int)(unsigned)(bytes > 0xfffffff0L ? 0xfffffff0L : bytes);
+        rsrc[3] = 0x00020000;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) rsrc[j] = __builtin_amdgcn_readfirstlane(rsrc[j]);
+    }
+    constexpr unsigned kOob = 0xfffffff0u;
+    int rel[4];
+    unsigned lbits[4];      // bit hy: halo row hy (image row rb + hy - 1), bit 16 + hx: halo column hx; pad slots: bit 31
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
         const int slot = (wave + 4 * it) * 8 + (lane >> 3);
         const int hy = slot / 10, hx = slot - hy * 10;       // hy >= 10: pad slot (never valid)
-        hyx |= (unsigned)((hy > 15 ? 15 : hy) | (hx << 4)) << (8 * it);
-        chk |= (unsigned)((lane & 7) ^ c64_key(slot)) << (4 * it);
+        const int chunk = (lane & 7) ^ c64_key(slot);
+        rel[it] = (((hy - 1) * p.W + (hx - 1)) * 64 + chunk * 8) * 2;
+        lbits[it] = hy < 10 ? (1u << hy) | (1u << (16 + hx)) : 0x80000000u;
     }
     auto stage = [&](int buf) {
         const bool live = cs.t < t1;
         const int rb = cs.ph * 8, cb = cs.pw * 8;
-        const int pixbase = (cs.n * p.H + rb) * p.W + cb;
+        const int org = ((cs.n * p.H + rb) * p.W + cb) * 128;
+        // valid halo rows hy: 0 <= rb + hy - 1 < H, columns likewise
+        int rhi = p.H - rb + 1, chi = p.W - cb + 1;
+        rhi = rhi > 10 ? 10 : rhi;
+        chi = chi > 10 ? 10 : chi;
+        const unsigned rowm = ((1u << rhi) - 1u) & ~(rb == 0 ? 1u : 0u);
+        const unsigned colm = ((1u << chi) - 1u) & ~(cb == 0 ? 1u : 0u);
+        const unsigned m = live ? rowm | (colm << 16) : 0u;
         advance(cs);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const int idx = wave + 4 * it;  // wave-uniform
             if (idx >= 13) break;
-            const int hy = (hyx >> (8 * it)) & 15, hx = (hyx >> (8 * it + 4)) & 15;
-            const int chunk = (chk >> (4 * it)) & 7;
-            const int row = rb + hy - 1, col = cb + hx - 1;
-            const bool ok = live && hy < 10 && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
-            const bf16* g = ok ? p.src + ((pixbase + (hy - 1) * p.W + (hx - 1)) * 64 + chunk * 8)
-                               : (const bf16*)kC64ZeroPage;
-            c64_dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + idx * 1024));
+            const unsigned voff = (lbits[it] & m) == lbits[it] ? (unsigned)(rel[it] + org) : kOob;
+            const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + idx * 1024);
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                         ::"v"(voff), "s"(rsrc), "s"(m0v) : "memory");
         }
     };
 
