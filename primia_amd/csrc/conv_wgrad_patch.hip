@@ -58,6 +58,7 @@ struct PatchParams {
     int nsplit, split_fastest;
     float* ws;                // if set: every block stores its partial slab here (no atomics), see below
     int debug_skip_epilogue;  // timing experiments only (PRIMIA_WGP_NOEPI=1)
+    int pairimg;              // v3, DP-SGD norm pass of one-sub-patch images (7x7): see conv_wgrad_patch33_kernel
 };
 
 constexpr int kSlab = 64 * 9 * 64;   // accumulator values of one block
@@ -1070,6 +1071,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
                 compute(cur);
                 if (do_issue) stage(nxt);
             }
+            if (p.pairimg) {
+                // DP-SGD norm pass, one sub-patch per image: this half's sub-patch of the stage IS a whole image and the
+                // wave's accumulators its complete share of that image's gradient tile — add its squared norm and start
+                // over.  (One block per (image, slab) — 16,384 blocks of a single stage for layer4 at batch 256, each with
+                // the prologue and the 144-KiB meeting of the halves — took 530 us per layer; this form ~40.)
+                const int img = t0 + 2 * s + half;
+                double sq = 0.0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        sq += (double)acc[t][j] * (double)acc[t][j];
+                        acc[t][j] = 0.f;
+                    }
+                if (img < t1) wave_sqnorm_add(sq, p.sqnorm + img);
+            }
             cur = cur + 1 == STAGES ? 0 : cur + 1;
             nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
         }
@@ -1079,6 +1096,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
     else
         main_loop(OrderTag<false>{});
 
+    if (p.pairimg) return;
     wgrad32_epilogue(acc, p, smem, wave, lane, half, kg, cg, kt, ct, split);
 }
 
@@ -1095,6 +1113,10 @@ static int wgp_version() {
 }
 static bool use_v2() { return wgp_version() != 0; }    // v2 and v3 share the byte-offset addressing and the slab format
 static bool use_v3() { return wgp_version() >= 3; }
+static bool wgp_pairimg() {
+    static const int t = getenv("PRIMIA_WGP_PAIRIMG") ? atoi(getenv("PRIMIA_WGP_PAIRIMG")) : 1;
+    return t != 0;
+}
 static bool wgp_tall7() {
     static const int t = getenv("PRIMIA_WGP_TALL7") ? atoi(getenv("PRIMIA_WGP_TALL7")) : 0;   // measured: no gain (2-stage ring, 9 spilled registers)
     return t != 0;
@@ -1152,6 +1174,12 @@ static PatchGeom patch_geom(const WgradParams& w) {
     per = (per + 1) & ~1L;
     if (per < 2) per = 2;
     if (w.persample) per = g.PPI;  // one split per image
+    if (w.persample && w.sqnorm && use_v3() && g.PPI == 1 && wgp_pairimg()) {
+        // norm pass of one-sub-patch images: a block walks many images, two per stage (see the kernel)
+        per = (g.total + want - 1) / want;
+        per = (per + 1) & ~1L;
+        if (per < 2) per = 2;
+    }
     g.per_block = (int)per;
     g.nsplit = (int)((g.total + per - 1) / per);
     return g;
@@ -1180,6 +1208,7 @@ static void fill_patch_params(PatchParams& p, const WgradParams& w, const PatchG
     p.debug_skip_epilogue = noepi;
     const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
     p.ws = store ? w.ws : nullptr;
+    p.pairimg = (w.persample && w.sqnorm && use_v3() && g.PPI == 1 && wgp_pairimg()) ? 1 : 0;
 }
 
 template <int SW, int SH, int STAGES = 3>
@@ -1225,6 +1254,7 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
     p.sqnorm = w.persample ? w.sqnorm : nullptr;
     static const int noepi = getenv("PRIMIA_WGP_NOEPI") ? atoi(getenv("PRIMIA_WGP_NOEPI")) : 0;
     p.debug_skip_epilogue = noepi;
+    p.pairimg = 0;
 
     const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
     p.ws = store ? w.ws : nullptr;
