@@ -58,7 +58,8 @@ struct PatchParams {
     int nsplit, split_fastest;
     float* ws;                // if set: every block stores its partial slab here (no atomics), see below
     int debug_skip_epilogue;  // timing experiments only (PRIMIA_WGP_NOEPI=1)
-    int pairimg;              // v3, DP-SGD norm pass of one-sub-patch images (7x7): see conv_wgrad_patch33_kernel
+    int pairimg;              // v3, DP-SGD norm pass: a half owns whole images (units of t0 / per_block / total: images)
+    int nimg;                 // batch size
 };
 
 constexpr int kSlab = 64 * 9 * 64;   // accumulator values of one block
@@ -834,7 +835,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
     const int t0 = split * p.per_block;
     int t1 = t0 + p.per_block;
     if (t1 > p.total) t1 = p.total;
-    const int nstages = (t1 - t0 + 1) >> 1;
+    // (pairimg: t0 / t1 count IMAGES; the two halves of a stage work on the same sub-patch position of two images)
+    const int nstages = p.pairimg ? ((t1 - t0 + 1) >> 1) * p.PPI : (t1 - t0 + 1) >> 1;
 
     const bf16* __restrict__ x = p.x + ct * 64;
     const bf16* __restrict__ dy = p.dy + kt * 64;
@@ -875,8 +877,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
         pdst[it] = __builtin_amdgcn_readfirstlane(q * HALF + (isx ? j * 1024 : XSLOTS * 128 + (j - XP) * 1024));
     }
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const long xbytes = ((long)p.total / p.PPI * p.H * p.W * p.C - ct * 64) * 2;
-    const long dybytes = ((long)p.total / p.PPI * p.H * p.W * p.K - kt * 64) * 2;
+    const long xbytes = ((long)p.nimg * p.H * p.W * p.C - ct * 64) * 2;
+    const long dybytes = ((long)p.nimg * p.H * p.W * p.K - kt * 64) * 2;
     auto make_rsrc = [](const void* base, long bytes) {
         const unsigned long long a = (unsigned long long)base;
         i32x4 r;
@@ -894,7 +896,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
     }
     constexpr unsigned kOob = 0xfffffff0u;
     int sn, sph, spw;
-    {
+    if (p.pairimg) {
+        sn = t0; sph = 0; spw = 0;
+    } else {
         sn = t0 / p.PPI;
         const int rem = t0 - sn * p.PPI;
         sph = rem / p.PW;
@@ -908,9 +912,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
         int xo[2], dyo[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const bool live = st < t1;
+            const bool live = p.pairimg ? sn + q < t1 : st < t1;
             const int rb = sph * SH, cb = spw * SW;
-            const int pixbase = (sn * p.H + rb) * p.W + cb;
+            const int pixbase = ((p.pairimg ? sn + q : sn) * p.H + rb) * p.W + cb;
             // valid row bits: image row rb + i - 1 in [0, H); columns likewise from bit 12
             int rhi = p.H - rb + 1, chi = p.W - cb + 1;
             rhi = rhi > SH + 2 ? SH + 2 : rhi;
@@ -920,12 +924,13 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
             smask[q] = live ? rowm | (colm << 12) : 0u;
             xo[q] = pixbase * p.C * 2;
             dyo[q] = pixbase * p.K * 2;
+            if (p.pairimg && q == 0) continue;     // both halves: the same sub-patch position, images sn and sn + 1
             ++st;
             if (++spw == p.PW) {
                 spw = 0;
                 if (++sph == p.PH) {
                     sph = 0;
-                    ++sn;
+                    sn += p.pairimg ? 2 : 1;
                 }
             }
         }
@@ -1056,6 +1061,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
         if (s < nstages) stage(s);
     // the two waves of a SIMD belong to different halves: half 0 issues its DMA pieces and THEN multiplies, half 1
     // multiplies and THEN issues (see v2); two copies of the loop, one order each
+    int sp_done = 0, img_pair = 0;     // pairimg: stages done of the current image pair; pairs done
     auto main_loop = [&](auto stage_first) {
         int cur = 0, nxt = STAGES - 1;
         for (int s = 0; s < nstages; ++s) {
@@ -1071,12 +1077,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
                 compute(cur);
                 if (do_issue) stage(nxt);
             }
-            if (p.pairimg) {
-                // DP-SGD norm pass, one sub-patch per image: this half's sub-patch of the stage IS a whole image and the
-                // wave's accumulators its complete share of that image's gradient tile — add its squared norm and start
-                // over.  (One block per (image, slab) — 16,384 blocks of a single stage for layer4 at batch 256, each with
-                // the prologue and the 144-KiB meeting of the halves — took 530 us per layer; this form ~40.)
-                const int img = t0 + 2 * s + half;
+            if (p.pairimg && ++sp_done == p.PPI) {
+                // DP-SGD norm pass: each half has just finished a whole image of its own, and the wave's accumulators are
+                // its complete share of that image's gradient tile — add its squared norm and start over.  (One block per
+                // (image, slab) — 16,384 blocks of a single stage for layer4 at batch 256, each with the prologue and the
+                // 144-KiB meeting of the halves — took 530 us per layer; this form ~40.)
+                sp_done = 0;
+                const int img = t0 + 2 * img_pair + half;
+                ++img_pair;
                 double sq = 0.0;
 #pragma unroll
                 for (int t = 0; t < 9; ++t)
@@ -1116,6 +1124,10 @@ static bool use_v3() { return wgp_version() >= 3; }
 static bool wgp_pairimg() {
     static const int t = getenv("PRIMIA_WGP_PAIRIMG") ? atoi(getenv("PRIMIA_WGP_PAIRIMG")) : 1;
     return t != 0;
+}
+// DP-SGD norm pass with whole images per half: needs at least two images per block for every slab
+static bool pairimg_mode(const WgradParams& w, const PatchGeom& g) {
+    return w.persample && w.sqnorm && use_v3() && wgp_pairimg() && w.N >= 2 && (long)g.combos * ((w.N + 1) / 2) >= 256;   // (else: one block per image, as before)
 }
 static bool wgp_tall7() {
     static const int t = getenv("PRIMIA_WGP_TALL7") ? atoi(getenv("PRIMIA_WGP_TALL7")) : 0;   // measured: no gain (2-stage ring, 9 spilled registers)
@@ -1174,9 +1186,10 @@ static PatchGeom patch_geom(const WgradParams& w) {
     per = (per + 1) & ~1L;
     if (per < 2) per = 2;
     if (w.persample) per = g.PPI;  // one split per image
-    if (w.persample && w.sqnorm && use_v3() && g.PPI == 1 && wgp_pairimg()) {
-        // norm pass of one-sub-patch images: a block walks many images, two per stage (see the kernel)
-        per = (g.total + want - 1) / want;
+    if (pairimg_mode(w, g)) {
+        // norm pass: a block walks many images, each half whole images of its own (see the kernel); units: images
+        g.total = w.N;
+        per = (w.N + want - 1) / want;
         per = (per + 1) & ~1L;
         if (per < 2) per = 2;
     }
@@ -1208,7 +1221,8 @@ static void fill_patch_params(PatchParams& p, const WgradParams& w, const PatchG
     p.debug_skip_epilogue = noepi;
     const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
     p.ws = store ? w.ws : nullptr;
-    p.pairimg = (w.persample && w.sqnorm && use_v3() && g.PPI == 1 && wgp_pairimg()) ? 1 : 0;
+    p.pairimg = pairimg_mode(w, g) ? 1 : 0;
+    p.nimg = w.N;
 }
 
 template <int SW, int SH, int STAGES = 3>
@@ -1255,6 +1269,7 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
     static const int noepi = getenv("PRIMIA_WGP_NOEPI") ? atoi(getenv("PRIMIA_WGP_NOEPI")) : 0;
     p.debug_skip_epilogue = noepi;
     p.pairimg = 0;
+    p.nimg = w.N;
 
     const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
     p.ws = store ? w.ws : nullptr;
