@@ -258,6 +258,30 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
         auto ror8 = [](uint32_t v) {
             return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);   // row_ror:8
         };
+        // accumulate form: EVERY old row (and mask byte) of the tile is requested before the first store — a load that
+        // is waited for after a store also waits for that store (one vmcnt for both), and the compiler cannot move a
+        // load of dst above a store to dst: fragment by fragment, the tile paid seven store -> load round trips (the
+        // fragment registers of the main loop are dead here: 70 registers are free)
+        u32x4 oldA_[JW], oldB_[JW];
+        unsigned mkA_[JW], mkB_[JW];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                const int plA = 16 * (F0 + j) + (fr & 7), plB = plA + 8;
+                const bool okA = plA < BM && m0 + plA < p.M, okB = plB < BM && m0 + plB < p.M;
+                const unsigned eoA = (row0 + 16 * j) * (unsigned)Nd + col0, eoB = eoA + 8u * (unsigned)Nd;
+                oldA_[j] = oldB_[j] = u32x4{0u, 0u, 0u, 0u};
+                mkA_[j] = mkB_[j] = 0xffu;
+                if (okA) {
+                    oldA_[j] = *(const u32x4*)((const char*)p.dst + (size_t)(eoA * 2u));
+                    if (p.acc_mask) mkA_[j] = p.acc_mask[eoA >> 3];
+                }
+                if (okB) {
+                    oldB_[j] = *(const u32x4*)((const char*)p.dst + (size_t)(eoB * 2u));
+                    if (p.acc_mask) mkB_[j] = p.acc_mask[eoB >> 3];
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < JW; ++j) {
             // rows of this lane in the two stores of fragment j: pixels (fr & 7) and 8 + (fr & 7)
@@ -267,14 +291,8 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
             u32x4 oldA = {0u, 0u, 0u, 0u}, oldB = {0u, 0u, 0u, 0u};
             unsigned mkA = 0xffu, mkB = 0xffu;
             if constexpr (ACC) {
-                if (okA) {
-                    oldA = *(const u32x4*)((const char*)p.dst + (size_t)(eoA * 2u));
-                    if (p.acc_mask) mkA = p.acc_mask[eoA >> 3];
-                }
-                if (okB) {
-                    oldB = *(const u32x4*)((const char*)p.dst + (size_t)(eoB * 2u));
-                    if (p.acc_mask) mkB = p.acc_mask[eoB >> 3];
-                }
+                oldA = oldA_[j]; oldB = oldB_[j];
+                mkA = mkA_[j]; mkB = mkB_[j];
             }
             f32x4 v[4];
 #pragma unroll
