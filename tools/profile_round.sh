@@ -14,5 +14,8 @@ python3 tools/mfma_util.py $(find $O/mfma -name "*.db" | head -1) > profiles/${R
 rocprofv3 --pmc FETCH_SIZE -d $O/fetch --output-format rocpd -- $B > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $O/write --output-format rocpd -- $B > $O/write.log 2>&1
 python3 tools/hbm_traffic.py $(find $O/fetch -name "*.db" | head -1) $(find $O/write -name "*.db" | head -1) > profiles/${R}_hbm_traffic.json
+# instruction mix per kernel (vector / matrix / scalar / LDS instructions issued, wave cycles): which kernels are bound by ISSUE
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/insts --output-format rocpd -- $B > $O/insts.log 2>&1
+python3 tools/rocpd_pmc.py $(find $O/insts -name "*.db" | head -1) kernel | cut -c1-250 > profiles/${R}_inst_mix_latest.txt
 head -12 profiles/${R}_bench_kernel_stats.csv
 cp profiles/${R}_* gpurun_out/ 2>/dev/null
