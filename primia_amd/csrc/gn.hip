@@ -8,6 +8,8 @@
 //
 // Layout: x [N, HW, C]; group g owns channels g*cpg .. g*cpg+cpg-1.  All kernels are HBM streaming
 // passes; reductions are two-level (per-slab fp32 partials -> fp64 combine), like csrc/bn.hip.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace primia {
@@ -159,6 +161,82 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
     if (c % cpg == 0) {
         gA[n * G + c / cpg] = (float)A;
         gB[n * G + c / cpg] = (float)B;
+    }
+}
+
+// The same two reductions with ONE 1024-thread block per sample and the finalize folded in (batches that fill the chip
+// with one block per sample: N >= kGnSampleBlockMinN).  The statistics of GroupNorm never leave a sample, so nothing
+// has to cross blocks: the slab partials, their table in HBM and the finalize launch (10-12 us each, 40 per DP-SGD
+// step) all go.  Row groups are added in a fixed order in fp64, like the slab path's second level.
+//   MODE 0: (sum, sumsq) -> mean / invstd [N][G]
+//   MODE 1: (sum g, sum g*xhat) -> ps_dbeta / ps_dgamma [N][C] and the group sums gA / gB [N][G]
+constexpr int kGnSampleBlockMinN = 128;
+
+template <typename T, typename F, int MODE>
+__global__ __launch_bounds__(1024) void gn_sample_reduce_kernel(F f, int HW, int C, int G, double count, float eps,
+                                                                const float* __restrict__ gamma, float* __restrict__ o0,
+                                                                float* __restrict__ o1, float* __restrict__ o2,
+                                                                float* __restrict__ o3) {
+    constexpr int CH = Chunk<T>::N;
+    const int tpr = C / CH, rpp = 1024 / tpr;
+    const int rg = threadIdx.x / tpr, cc = threadIdx.x % tpr;
+    const int n = blockIdx.x;
+    float s1[CH], s2[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) s1[i] = s2[i] = 0.f;
+    F lf = f;
+    lf.prepare(n, cc * CH);
+    const long base = (long)n * HW * C + cc * CH;
+#pragma unroll 4
+    for (int r = rg; r < HW; r += rpp) lf(base + (long)r * C, n, cc * CH, s1, s2);
+    __shared__ float red[2][1024 * CH];       // [q][row group][channel]
+    __shared__ double chs[2][512];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        red[0][rg * C + cc * CH + i] = s1[i];
+        red[1][rg * C + cc * CH + i] = s2[i];
+    }
+    __syncthreads();
+    // 2C (quantity, channel) columns over the 1024 threads: thread -> (column, part of the row groups)
+    const int parts = 1024 / (2 * C);                       // 1 (C = 512) .. 8 (C = 64)
+    const int col = threadIdx.x % (2 * C), part = threadIdx.x / (2 * C);
+    const int q = col / C, c = col - q * C;
+    double a = 0.0;
+    if (part < parts) {
+        const int per = rpp / parts;                       // rpp and parts are powers of two, rpp >= parts
+        for (int g = part * per; g < (part + 1) * per; ++g) a += (double)red[q][g * C + c];
+    }
+    __syncthreads();
+    double* dred = (double*)&red[0][0];                     // [part][2C]
+    if (part < parts) dred[part * 2 * C + col] = a;
+    __syncthreads();
+    if (threadIdx.x < 2 * C) {
+        double t = 0.0;
+        for (int k = 0; k < parts; ++k) t += dred[k * 2 * C + threadIdx.x];
+        if (MODE == 1) {
+            (q == 0 ? o0 : o1)[(long)n * C + c] = (float)t;   // ps_dbeta | ps_dgamma
+            t *= (double)gamma[c];
+        }
+        chs[q][c] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        const int cpg = C / G;
+        double A = 0.0, B = 0.0;
+        for (int k = 0; k < cpg; ++k) {
+            A += chs[0][threadIdx.x * cpg + k];
+            B += chs[1][threadIdx.x * cpg + k];
+        }
+        if (MODE == 0) {
+            const double m = A / count;
+            double var = B / count - m * m;
+            if (var < 0.0) var = 0.0;
+            o0[n * G + threadIdx.x] = (float)m;
+            o1[n * G + threadIdx.x] = (float)(1.0 / sqrt(var + (double)eps));
+        } else {
+            o2[n * G + threadIdx.x] = (float)A;
+            o3[n * G + threadIdx.x] = (float)B;
+        }
     }
 }
 
@@ -397,15 +475,27 @@ static inline bool gn_shape_ok(int N, int HW, int C, int G, int dtype) {
            256 % (C / ch) == 0;
 }
 
+// one block per sample (gn_sample_reduce_kernel): the batch fills the chip that way and 2C columns fit the block
+static inline bool gn_sample_blocks(int N, int C, int ch) {
+    static const int sw = getenv("PRIMIA_GN_SAMPLE") ? atoi(getenv("PRIMIA_GN_SAMPLE")) : 1;
+    const int tpr = C / ch;
+    return sw && N >= kGnSampleBlockMinN && 2 * C <= 1024 && 1024 % tpr == 0 && 1024 / tpr >= 1024 / (2 * C);
+}
+
 template <typename T>
 static int gn_fwd_impl(const void* y, const void* res, void* z, const float* gamma, const float* beta, float* mean,
                        float* invstd, int N, int HW, int C, int G, float eps, int relu, float* partials, hipStream_t st) {
     const int rps = (HW + kGnSlabs - 1) / kGnSlabs;
     const int nslab = (HW + rps - 1) / rps;
     GnStatsFn<T> f{(const T*)y};
-    gn_colreduce2_kernel<T, GnStatsFn<T>><<<dim3(nslab, N), 256, 0, st>>>(f, HW, C, rps, partials);
-    gn_stats_finalize_kernel<<<(N * C + 255) / 256, 256, 0, st>>>(partials, nslab, C, G, (long)HW * (C / G), eps, mean,
-                                                                  invstd, N * C);
+    if (gn_sample_blocks(N, C, Chunk<T>::N)) {
+        gn_sample_reduce_kernel<T, GnStatsFn<T>, 0><<<N, 1024, 0, st>>>(f, HW, C, G, (double)HW * (C / G), eps, nullptr,
+                                                                        mean, invstd, nullptr, nullptr);
+    } else {
+        gn_colreduce2_kernel<T, GnStatsFn<T>><<<dim3(nslab, N), 256, 0, st>>>(f, HW, C, rps, partials);
+        gn_stats_finalize_kernel<<<(N * C + 255) / 256, 256, 0, st>>>(partials, nslab, C, G, (long)HW * (C / G), eps, mean,
+                                                                      invstd, N * C);
+    }
     gn_apply_kernel<T><<<gn_sample_grid(N, HW, C / Chunk<T>::N), 256, 0, st>>>((const T*)y, (const T*)res, (T*)z, gamma, beta,
                                                                                mean, invstd, HW, C, G, relu);
     return launch_status();
@@ -418,11 +508,16 @@ static int gn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
     const int rps = (HW + kGnSlabs - 1) / kGnSlabs;
     const int nslab = (HW + rps - 1) / rps;
     GnBwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, mean, invstd, G, C / G, {}, {}};
-    gn_colreduce2_kernel<T, GnBwdFn<T>><<<dim3(nslab, N), 256, 0, st>>>(f, HW, C, rps, partials);
     float* gA = partials + (long)N * nslab * 2 * C;  // group sums live behind the partials
     float* gB = gA + (long)N * G;
-    gn_bwd_finalize_kernel<<<(N * C + 255) / 256, 256, 0, st>>>(partials, nslab, C, G, gamma, ps_dbeta, ps_dgamma, gA, gB,
-                                                                N * C);
+    if (gn_sample_blocks(N, C, Chunk<T>::N)) {
+        gn_sample_reduce_kernel<T, GnBwdFn<T>, 1><<<N, 1024, 0, st>>>(f, HW, C, G, 0.0, 0.f, gamma, ps_dbeta, ps_dgamma, gA,
+                                                                      gB);
+    } else {
+        gn_colreduce2_kernel<T, GnBwdFn<T>><<<dim3(nslab, N), 256, 0, st>>>(f, HW, C, rps, partials);
+        gn_bwd_finalize_kernel<<<(N * C + 255) / 256, 256, 0, st>>>(partials, nslab, C, G, gamma, ps_dbeta, ps_dgamma, gA,
+                                                                    gB, N * C);
+    }
     gn_bwd_apply_kernel<T><<<gn_sample_grid(N, HW, C / Chunk<T>::N), 256, 0, st>>>(
         (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, mean, invstd, gA, gB,
         (float)(1.0 / ((double)HW * (C / G))), HW, C, G);

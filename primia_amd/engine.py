@@ -570,11 +570,11 @@ class ResNet18Engine:
     def _wgrad_transition(self, blk, x, dy1, dyd):
         """conv1 and the downsample of a transition block: one launch where the library serves the pair."""
         c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
-        if (self.wgrad_pair and self.dp is None and self.wgrad_ws is not None and not self.wgrad_overlap
+        if (self.wgrad_pair and self.dp is None and self.wgrad_ws is not None
                 and self._pair_ws.get(blk.conv1.name, 0) > 0):
-            self._timed("wgrad", c1, lambda: call("primia_conv2d_wgrad_pair_ws", c1.desc, x, dy1, c1.acc, cd.desc, dyd,
-                                                  cd.acc, self.wgrad_ws, self.wgrad_ws_bytes, self.dt),
-                        extra_macs=self._macs(cd))
+            self._on_wgrad_stream(lambda: self._timed(
+                "wgrad", c1, lambda: call("primia_conv2d_wgrad_pair_ws", c1.desc, x, dy1, c1.acc, cd.desc, dyd, cd.acc,
+                                          self.wgrad_ws, self.wgrad_ws_bytes, self.dt), extra_macs=self._macs(cd)))
             return
         self._wgrad(blk.conv1.name, x, dy1)
         self._wgrad(blk.down.name, x, dyd)
@@ -584,9 +584,9 @@ class ResNet18Engine:
         if self.dp is not None:  # DP-SGD: weight gradients wait for the per-sample clip factors
             self.dp["wgrads"].append((name, x, dy))
             return
-        if self.wgrad_ws is not None and not self.wgrad_overlap:
-            self._timed("wgrad", c, lambda: call("primia_conv2d_wgrad_ws", c.desc, x, dy, c.acc, self.wgrad_ws,
-                                                 self.wgrad_ws_bytes, self.dt))
+        if self.wgrad_ws is not None:   # (one workspace: the weight gradients stay in order on whichever stream)
+            self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call(
+                "primia_conv2d_wgrad_ws", c.desc, x, dy, c.acc, self.wgrad_ws, self.wgrad_ws_bytes, self.dt)))
             return
         self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call("primia_conv2d_wgrad", c.desc, x, dy, c.acc,
                                                                              self.dt)))
@@ -597,7 +597,9 @@ class ResNet18Engine:
     # narrower: a layer's wgrad starts after its sibling dgrad and runs beside the BatchNorm backward chain that
     # follows (HBM-bound kernels and 7-us finalize launches); the next dgrad waits for it.  Also slower on
     # MI355X (7.10 ms serial -> 7.30 ms): kept as an option for other shapes, off by default.
-    wgrad_overlap = False
+    # Re-measured in round 3 with the workspace kernels (PRIMIA_WGRAD_OVERLAP=1: the schedule above; =2: the weight
+    # gradients free-running on the second stream until the finalize): see profiles/r03_negative_results.txt.
+    wgrad_overlap = int(os.environ.get("PRIMIA_WGRAD_OVERLAP", "0"))
     stem_bwd_fused = os.environ.get("PRIMIA_STEM_BWD_FUSED", "1") != "0"
 
     def _on_wgrad_stream(self, fn):
@@ -620,7 +622,8 @@ class ResNet18Engine:
         """Data gradient of conv `name` into dx.  `consumer`: the conv whose BatchNorm (+ReLU) backward reads dx next;
         where the kernel can, it also forms that BatchNorm's two reductions (see bwd_sums)."""
         c = self.convs[name]
-        self._join_wgrad_stream()   # (overlap mode) two MFMA-bound kernels never run side by side
+        if self.wgrad_overlap == 1:
+            self._join_wgrad_stream()   # (narrow overlap) two MFMA-bound kernels never run side by side
         b = bn_name(consumer) if consumer is not None else None
         if b is not None and b in self.bwd_sums and self.training and (not accumulate or b in self.relu_masks):
             sm, si = self.save[b]
@@ -636,7 +639,7 @@ class ResNet18Engine:
     def backward(self):
         N, t = self.N, self.t
         nc = self.spec.num_classes
-        if self.wgrad_ws is not None and not self.wgrad_overlap and self.dp is None:
+        if self.wgrad_ws is not None and self.dp is None:
             self.dw_acc[:self._acc_zero_n].zero_()      # the other layers' accumulators are overwritten
         else:
             self.dw_acc.zero_()
@@ -686,7 +689,8 @@ class ResNet18Engine:
                 if not bn_pair:
                     self._bn_bwd(blk.down.name, t[p + ".yd"], None, dout, t[p + ".dyd"], None, False)
                 c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
-                self._join_wgrad_stream()
+                if self.wgrad_overlap == 1:
+                    self._join_wgrad_stream()
                 if self.wgrad_first:
                     self._wgrad_transition(blk, x_in, t[p + ".dy1"], t[p + ".dyd"])
                 self._timed("dgrad", c1, lambda: call("primia_conv2d_dgrad_pair", c1.desc, t[p + ".dy1"], c1.w_dgrad,
@@ -706,7 +710,8 @@ class ResNet18Engine:
                     self._wgrad(blk.conv1.name, x_in, t[p + ".dy1"])
                 if masked_acc:
                     c1 = self.convs[blk.conv1.name]
-                    self._join_wgrad_stream()
+                    if self.wgrad_overlap == 1:
+                        self._join_wgrad_stream()
                     self._timed("dgrad", c1, lambda: call("primia_conv2d_dgrad_masked_acc", c1.desc, t[p + ".dy1"],
                                                           c1.w_dgrad, dx_in, self.relu_masks[b2], self.dt))
                 elif i > 0:
@@ -720,7 +725,7 @@ class ResNet18Engine:
         # the stem's tail in two launches less and without the dy tensor (411 MB at batch 256): bn1's backward sums at
         # pooled resolution, then conv1's weight gradient forming its dy tiles on the fly (primia_stem_bwd_fused)
         stem_bwd_fused = (self._stem_fused and self._stem_padded and self.dp is None and self.stem_bwd_fused
-                          and self.wgrad_ws is not None and not self.wgrad_overlap and self.dtype == torch.bfloat16
+                          and self.wgrad_ws is not None and self.dtype == torch.bfloat16
                           and self.spec.input_size % 32 == 0)
         self.stem_bwd_fused_active = stem_bwd_fused
         if stem_bwd_fused:
@@ -730,10 +735,10 @@ class ResNet18Engine:
             call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, None,
                  self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self.gviews["bn1.weight"],
                  self.gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
-            self._timed("wgrad", c, lambda: call("primia_stem_bwd_fused", self.x0p, t["stem.y"], t["pool.dout"],
-                                                 self.pool_argmax, self.views["bn1.weight"], self.views["bn1.bias"], sm,
-                                                 si, self.gviews["bn1.weight"], self.gviews["bn1.bias"], c.acc,
-                                                 self.wgrad_ws, self.wgrad_ws_bytes, N, S, S, self.dt))
+            self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call(
+                "primia_stem_bwd_fused", self.x0p, t["stem.y"], t["pool.dout"], self.pool_argmax,
+                self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self.gviews["bn1.weight"],
+                self.gviews["bn1.bias"], c.acc, self.wgrad_ws, self.wgrad_ws_bytes, N, S, S, self.dt)))
             if self.dp is None:
                 self._finalize_wgrads()
             return
@@ -751,9 +756,10 @@ class ResNet18Engine:
         if self._stem_padded and self.dp is None:
             c = self.convs["conv1"]
             S = self.spec.input_size
-            if self.wgrad_ws is not None and not self.wgrad_overlap:
-                self._timed("wgrad", c, lambda: call("primia_stem_conv_wgrad_ws", self.x0p, t["stem.dy"], c.acc,
-                                                     self.wgrad_ws, self.wgrad_ws_bytes, N, S, S, self.dt))
+            if self.wgrad_ws is not None:
+                self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call(
+                    "primia_stem_conv_wgrad_ws", self.x0p, t["stem.dy"], c.acc, self.wgrad_ws, self.wgrad_ws_bytes, N, S,
+                    S, self.dt)))
             else:
                 self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call("primia_stem_conv_wgrad", self.x0p,
                                                                                  t["stem.dy"], c.acc, N, S, S, self.dt)))

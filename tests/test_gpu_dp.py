@@ -20,9 +20,12 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("C,relu,res", [(64, 1, 0), (128, 1, 1), (512, 0, 0)])
-def test_groupnorm_kernels(cuda, dtype, C, relu, res):
-    N, H, G = 3, 6, 32
+@pytest.mark.parametrize("C,relu,res", [(64, 1, 0), (128, 1, 1), (512, 0, 0), (256, 1, 1)])
+@pytest.mark.parametrize("N,H", [(3, 6), (130, 5)])
+def test_groupnorm_kernels(cuda, dtype, C, relu, res, N, H):
+    """N = 3: the reductions run over pixel slabs + a finalize launch; N = 130 (>= 128): one block per sample with
+    the finalize folded in (gn_sample_reduce_kernel)."""
+    G = 32
     HW = H * H
     g = torch.Generator().manual_seed(C)
     rnd = lambda t: t.to(dtype).float()

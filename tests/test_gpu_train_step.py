@@ -333,3 +333,31 @@ def test_full_size_forward_and_step_are_repeatable(cuda):
         for n in names:
             assert torch.equal(ref[n], cur[n]), n
         assert torch.equal(ref_g, eng.grads)
+
+
+@pytest.mark.parametrize("batch,size", [(16, 64), (64, 224)])
+def test_weight_gradients_on_a_second_stream_give_the_same_bits(cuda, batch, size):
+    """engine.wgrad_overlap (PRIMIA_WGRAD_OVERLAP): the weight gradients are leaves of the backward graph, so they may
+    run on a second stream (1: beside the BatchNorm chain, joined before the next data gradient; 2: free-running until
+    the finalize).  Same kernels on the same operands: weights, gradients and loss after three steps are bit-equal to
+    the one-stream schedule."""
+    spec = rs.resnet18_spec(3, 3, size, "max")
+    torch.manual_seed(11)
+    sd = rs.init_state_dict(spec)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(batch, 3, size, size, generator=g).to(cuda)
+    y = torch.randint(0, 3, (batch,), generator=g).to(cuda)
+    outs = []
+    for mode in (0, 1, 2):
+        eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.bfloat16, device=cuda)
+        eng.wgrad_overlap = mode
+        eng.load_state_dict(sd)
+        for _ in range(3):
+            eng.forward(x)
+            eng.loss_backward(y)
+            eng.sgd_step(1e-2, 5e-4)
+        torch.cuda.synchronize()
+        outs.append((eng.flat.clone(), eng.grads.clone(), eng.loss.clone()))
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
