@@ -387,6 +387,12 @@ int primia_gn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
                   const float* save_mean, const float* save_invstd, float* ps_dgamma, float* ps_dbeta,
                   int N, int HW, int C, int G, int relu, void* workspace, int64_t workspace_bytes,
                   int dtype, primia_stream_t stream);
+/* The same for z = relu(gn(y)) WITHOUT a residual: the ReLU mask is recomputed from y (the value the forward pass
+ * rounded, one shared expression), so z is not read — two tensor reads instead of three in both passes.  Replaces the
+ * autograd of F.relu(GroupNorm(y)) (torchlib/models.py:362-364 norm_layer hook, :238-240 forward). */
+int primia_gn_relu_bwd(const void* y, const void* dz, void* dy, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, float* ps_dgamma, float* ps_dbeta, int N, int HW,
+                       int C, int G, void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream);
 /* sq_acc[n] += sum_j x[n][j]^2 (fp64): per-sample squared gradient norm, accumulated layer by layer. */
 int primia_persample_sqnorm(const float* x, int N, int64_t per_sample, double* sq_acc,
                             primia_stream_t stream);

@@ -68,23 +68,43 @@ struct GnStatsFn {
     }
 };
 
+// the value gn_apply_kernel stores, before its ReLU (ONE expression for the forward pass and the recomputed masks)
+__device__ __forceinline__ float gn_value(float y, float mean, float scale, float shift) {
+    return __fmaf_rn(y - mean, scale, shift);
+}
+// ... and whether the STORED relu of it is positive (bf16: a positive value below half the smallest subnormal stores 0)
+template <typename T>
+__device__ __forceinline__ bool gn_relu_open(float y, float mean, float scale, float shift) {
+    const float v = gn_value(y, mean, scale, shift);
+    if constexpr (sizeof(T) == 2) return v > 0.f && f32_to_bf16(v) != 0;
+    return v > 0.f;
+}
+
 template <typename T>
 struct GnBwdFn {
     const T* y;
-    const T* z;  // null: no relu
+    const T* z;  // null: no relu, or (gamma_beta set) the mask is recomputed from y
     const T* dz;
     const float* mean;    // [N][G]
     const float* invstd;  // [N][G]
     int G, cpg;
+    // z = relu(gn(y)) without a residual: z > 0 exactly where the value gn_apply_kernel rounded was > 0, and that value
+    // is a function of y alone — the pass then reads two tensors instead of three
+    const float* gamma;   // both set: recompute the mask
+    const float* beta;
     // a thread's sample and channels never change: their group statistics are fetched ONCE (the first version divided
     // by cpg and loaded both statistics per element and row)
-    float k_mean[Chunk<T>::N], k_invstd[Chunk<T>::N];
+    float k_mean[Chunk<T>::N], k_invstd[Chunk<T>::N], k_s[Chunk<T>::N], k_b[Chunk<T>::N];
     __device__ __forceinline__ void prepare(int n, int c0) {
 #pragma unroll
         for (int i = 0; i < Chunk<T>::N; ++i) {
             const int g = (c0 + i) / cpg;
             k_mean[i] = mean[n * G + g];
             k_invstd[i] = invstd[n * G + g];
+            if (gamma) {
+                k_s[i] = k_invstd[i] * gamma[c0 + i];
+                k_b[i] = beta[c0 + i];
+            }
         }
     }
     __device__ __forceinline__ void operator()(long off, int, int, float* s1, float* s2) const {
@@ -97,6 +117,9 @@ struct GnBwdFn {
             Chunk<T>::unpack(*(const u32x4*)(z + off), vz);
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        } else if (gamma) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vg[i] = gn_relu_open<T>(vy[i], k_mean[i], k_s[i], k_b[i]) ? vg[i] : 0.f;
         }
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
@@ -269,7 +292,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ y, 
         float v[CH];
         Chunk<T>::unpack(*(const u32x4*)(y + (base + q) * CH), v);
 #pragma unroll
-        for (int i = 0; i < CH; ++i) v[i] = (v[i] - km[i]) * ks[i] + kb[i];
+        for (int i = 0; i < CH; ++i) v[i] = gn_value(v[i], km[i], ks[i], kb[i]);
         if (res) {
             float r[CH];
             Chunk<T>::unpack(*(const u32x4*)(res + (base + q) * CH), r);
@@ -288,6 +311,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ y, 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ y, const T* __restrict__ z, const T* dz,
                                                            T* __restrict__ dy, T* g_out, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta_mask,   // set: mask from y
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gA, const float* __restrict__ gB,
                                                            float inv_m, int HW, int C, int G) {
@@ -295,7 +319,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     const int cpr = C / CH, cpg = C / G;
     const int n = blockIdx.y;
     const int c0 = (int)(threadIdx.x % cpr) * CH;
-    float km[CH], ki[CH], kg[CH], ka[CH], kbb[CH];
+    float km[CH], ki[CH], kg[CH], ka[CH], kbb[CH], kbeta[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
         const int ng = n * G + (c0 + i) / cpg;
@@ -304,6 +328,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
         kg[i] = gamma[c0 + i];
         ka[i] = gA[ng] * inv_m;
         kbb[i] = gB[ng] * inv_m;
+        kbeta[i] = beta_mask ? beta_mask[c0 + i] : 0.f;
     }
     const int cps = HW * cpr;
     const long base = (long)n * cps;
@@ -317,6 +342,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
             Chunk<T>::unpack(*(const u32x4*)(z + (base + q) * CH), vz);
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        } else if (beta_mask) {
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vg[i] = gn_relu_open<T>(vy[i], km[i], ki[i] * kg[i], kbeta[i]) ? vg[i] : 0.f;
         }
         if (g_out) *(u32x4*)(g_out + (base + q) * CH) = Chunk<T>::pack(vg);
 #pragma unroll
@@ -504,10 +532,11 @@ static int gn_fwd_impl(const void* y, const void* res, void* z, const float* gam
 template <typename T>
 static int gn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, void* g_out, const float* gamma,
                        const float* mean, const float* invstd, float* ps_dgamma, float* ps_dbeta, int N, int HW, int C,
-                       int G, int relu, float* partials, hipStream_t st) {
+                       int G, int relu, float* partials, hipStream_t st, const float* beta_mask = nullptr) {
     const int rps = (HW + kGnSlabs - 1) / kGnSlabs;
     const int nslab = (HW + rps - 1) / rps;
-    GnBwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, mean, invstd, G, C / G, {}, {}};
+    GnBwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, mean, invstd, G, C / G,
+                 beta_mask ? gamma : nullptr, beta_mask, {}, {}, {}, {}};
     float* gA = partials + (long)N * nslab * 2 * C;  // group sums live behind the partials
     float* gB = gA + (long)N * G;
     if (gn_sample_blocks(N, C, Chunk<T>::N)) {
@@ -519,7 +548,7 @@ static int gn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
                                                                     gB, N * C);
     }
     gn_bwd_apply_kernel<T><<<gn_sample_grid(N, HW, C / Chunk<T>::N), 256, 0, st>>>(
-        (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, mean, invstd, gA, gB,
+        (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, beta_mask, mean, invstd, gA, gB,
         (float)(1.0 / ((double)HW * (C / G))), HW, C, G);
     return launch_status();
 }
@@ -565,6 +594,22 @@ int primia_gn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
     if (dtype == PRIMIA_BF16)
         return gn_bwd_impl<bf16>(y, z, dz, dy, g_out, gamma, save_mean, save_invstd, ps_dgamma, ps_dbeta, N, HW, C, G,
                                  relu, (float*)workspace, st);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_gn_relu_bwd(const void* y, const void* dz, void* dy, const float* gamma, const float* beta,
+                       const float* save_mean, const float* save_invstd, float* ps_dgamma, float* ps_dbeta, int N, int HW,
+                       int C, int G, void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && dz && dy && gamma && beta && save_mean && save_invstd && ps_dgamma && ps_dbeta && workspace);
+    PRIMIA_REQUIRE(gn_shape_ok(N, HW, C, G, dtype));
+    if (workspace_bytes < primia_gn_workspace_bytes(N, C, G)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return gn_bwd_impl<float>(y, nullptr, dz, dy, nullptr, gamma, save_mean, save_invstd, ps_dgamma, ps_dbeta, N, HW, C,
+                                  G, 0, (float*)workspace, st, beta);
+    if (dtype == PRIMIA_BF16)
+        return gn_bwd_impl<bf16>(y, nullptr, dz, dy, nullptr, gamma, save_mean, save_invstd, ps_dgamma, ps_dbeta, N, HW, C,
+                                 G, 0, (float*)workspace, st, beta);
     return PRIMIA_ERR_ARG;
 }
 

@@ -536,8 +536,13 @@ class ResNet18Engine:
         if self.norm == "group":
             psg, psb = self.ps_affine[b]
             C = y.shape[1]
-            call("primia_gn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, psg, psb, self.N,
-                 y.shape[0] // self.N, C, self.groups, int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
+            if relu and g_out is None and self.gn_relu_recompute:
+                # z = relu(gn(y)), no residual: the mask is recomputed from y, z is not read
+                call("primia_gn_relu_bwd", y, dz, dy, self.views[b + ".weight"], self.views[b + ".bias"], sm, si, psg, psb,
+                     self.N, y.shape[0] // self.N, C, self.groups, self.bn_ws, self.bn_ws_bytes, self.dt)
+            else:
+                call("primia_gn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, psg, psb, self.N,
+                     y.shape[0] // self.N, C, self.groups, int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
             if self.dp is None:  # plain training: dgamma / dbeta = sum over samples
                 call("primia_weighted_colsum", psg, self.ones_n, self.gviews[b + ".weight"], self.N, C)
                 call("primia_weighted_colsum", psb, self.ones_n, self.gviews[b + ".bias"], self.N, C)
@@ -566,6 +571,7 @@ class ResNet18Engine:
              self.gviews[b + ".bias"], y.shape[0], y.shape[1], int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
 
     wgrad_pair = os.environ.get("PRIMIA_WGRAD_PAIR", "1") != "0"
+    gn_relu_recompute = os.environ.get("PRIMIA_GN_RELU_RECOMPUTE", "1") != "0"
 
     def _wgrad_transition(self, blk, x, dy1, dyd):
         """conv1 and the downsample of a transition block: one launch where the library serves the pair."""

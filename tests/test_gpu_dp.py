@@ -71,6 +71,13 @@ def test_groupnorm_kernels(cuda, dtype, C, relu, res, N, H):
     assert rel(back(dy), yr.grad) < (2e-5 if dtype == torch.float32 else 2e-2)
     assert rel(psg, torch.stack(per_g)) < (2e-5 if dtype == torch.float32 else 1e-2)
     assert rel(psb, torch.stack(per_b)) < (2e-5 if dtype == torch.float32 else 1e-2)
+    if relu and not res:
+        # the same backward with the ReLU mask recomputed from y instead of read from z: identical bits
+        dy2 = torch.empty_like(z)
+        psg2, psb2 = torch.empty(N, C, device=cuda), torch.empty(N, C, device=cuda)
+        call("primia_gn_relu_bwd", nhwc(y), nhwc(dz), dy2, gamma.to(cuda), beta.to(cuda), sm, si, psg2, psb2, N, HW, C, G,
+             ws, wsb, dt)
+        assert torch.equal(dy2, dy) and torch.equal(psg2, psg) and torch.equal(psb2, psb)
 
 
 def test_dp_sgd_gradient_matches_oracle(cuda):
