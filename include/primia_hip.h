@@ -393,6 +393,20 @@ int primia_gn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
 int primia_gn_relu_bwd(const void* y, const void* dz, void* dy, const float* gamma, const float* beta,
                        const float* save_mean, const float* save_invstd, float* ps_dgamma, float* ps_dbeta, int N, int HW,
                        int C, int G, void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream);
+
+/* Stem tail under GroupNorm, gn1 -> relu -> maxpool(3, 2, 1), as ONE op each way (the full-resolution z and dz
+ * tensors are never written): statistics + pooled output and argmax codes (0..8, first maximum); backward = per-sample
+ * reductions at pooled resolution + dy and the per-sample affine gradients.  _bwd needs even H and W
+ * (PRIMIA_ERR_UNSUPPORTED otherwise: use primia_maxpool3x3s2_bwd + primia_gn_relu_bwd).  Replaces
+ * self.maxpool(self.relu(self.bn1(x))) with norm_layer = GroupNorm (torchlib/models.py:362-364, :414-417) and its
+ * autograd. */
+int primia_gn_relu_maxpool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
+                               float* save_mean, float* save_invstd, int N, int H, int W, int C, int G, float eps,
+                               void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream);
+int primia_gn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax, void* dy,
+                               const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                               float* ps_dgamma, float* ps_dbeta, int N, int H, int W, int C, int G, void* workspace,
+                               int64_t workspace_bytes, int dtype, primia_stream_t stream);
 /* sq_acc[n] += sum_j x[n][j]^2 (fp64): per-sample squared gradient norm, accumulated layer by layer. */
 int primia_persample_sqnorm(const float* x, int N, int64_t per_sample, double* sq_acc,
                             primia_stream_t stream);

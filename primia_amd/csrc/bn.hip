@@ -400,14 +400,17 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
                                                                const float* __restrict__ beta,
                                                                const float* __restrict__ mean,
                                                                const float* __restrict__ invstd, int N, int H, int W,
-                                                               int C, int Ho, int Wo) {
+                                                               int C, int Ho, int Wo, int G) {
     constexpr int CH = Chunk<T>::N;
     constexpr int NCOL = 2 * PW + 1, NROW = 2 * PH + 1;
     __shared__ float sm[3][512];
-    for (int c = threadIdx.x; c < C; c += 256) {
-        sm[0][c] = mean[c];
-        sm[1][c] = invstd[c] * gamma[c];
-        sm[2][c] = beta[c];
+    // G > 0: GroupNorm — mean / invstd are [N][G] (per sample and group), read by each thread for its own sample
+    if (G == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            sm[0][c] = mean[c];
+            sm[1][c] = invstd[c] * gamma[c];
+            sm[2][c] = beta[c];
+        }
     }
     __syncthreads();
     const int cpr = C / CH;
@@ -438,9 +441,16 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
     float mu[CH], sc[CH], be[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        mu[i] = sm[0][c0 + i];
-        sc[i] = sm[1][c0 + i];
-        be[i] = sm[2][c0 + i];
+        if (G == 0) {
+            mu[i] = sm[0][c0 + i];
+            sc[i] = sm[1][c0 + i];
+            be[i] = sm[2][c0 + i];
+        } else {
+            const int ng = n * G + (c0 + i) / (C / G);
+            mu[i] = mean[ng];
+            sc[i] = invstd[ng] * gamma[c0 + i];
+            be[i] = beta[c0 + i];
+        }
     }
     const int w0 = wq * PW * 2 - 1;   // leftmost input column of the first window
     const int h0 = hq * PH * 2 - 1;   // topmost input row of the first window
@@ -518,13 +528,16 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* _
                                                                    const float* __restrict__ beta,
                                                                    const float* __restrict__ mean,
                                                                    const float* __restrict__ invstd, int N, int H, int W,
-                                                                   int C, int Ho, int Wo) {
+                                                                   int C, int Ho, int Wo, int G) {
     constexpr int CH = 8, NCOL = 2 * PW + 1, NROW = 2 * PH + 1;
     __shared__ float sm[3][512];
-    for (int c = threadIdx.x; c < C; c += 256) {
-        sm[0][c] = mean[c];
-        sm[1][c] = invstd[c] * gamma[c];
-        sm[2][c] = beta[c];
+    // G > 0: GroupNorm — mean / invstd are [N][G] (per sample and group), read by each thread for its own sample
+    if (G == 0) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            sm[0][c] = mean[c];
+            sm[1][c] = invstd[c] * gamma[c];
+            sm[2][c] = beta[c];
+        }
     }
     __syncthreads();
     const int cpr = C / CH;
@@ -549,9 +562,16 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* _
     float mu[CH], sc[CH], be[CH];
 #pragma unroll
     for (int i = 0; i < CH; ++i) {
-        mu[i] = sm[0][c0 + i];
-        sc[i] = sm[1][c0 + i];
-        be[i] = sm[2][c0 + i];
+        if (G == 0) {
+            mu[i] = sm[0][c0 + i];
+            sc[i] = sm[1][c0 + i];
+            be[i] = sm[2][c0 + i];
+        } else {
+            const int ng = n * G + (c0 + i) / (C / G);
+            mu[i] = mean[ng];
+            sc[i] = invstd[ng] * gamma[c0 + i];
+            be[i] = beta[c0 + i];
+        }
     }
     const int w0 = wq * PW * 2 - 1;   // leftmost input column of the first window
     const int h0 = hq * PH * 2 - 1;   // topmost input row of the first window
@@ -991,7 +1011,7 @@ static int bn_bwd_pair_impl(const void* y2, const void* yd, const void* dz, cons
 template <typename T>
 static void launch_bn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
                                     const float* mean, const float* invstd, int N, int H, int W, int C, int Ho, int Wo,
-                                    hipStream_t st) {
+                                    hipStream_t st, int G = 0) {
     static const bool one = getenv("PRIMIA_POOL_PW") && getenv("PRIMIA_POOL_PW")[0] == '1';
     // (two windows along H per thread — 25 loads for 4 windows — measured SLOWER: 265 vs 258 us for stats + pool at
     // batch 256, 160 registers / occupancy 3, and the shared row is a MALL hit anyway; opt-in: PRIMIA_POOL_PH=2)
@@ -1011,13 +1031,24 @@ static void launch_bn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax
             const unsigned kgrid = (unsigned)((ktotal + 255) / 256);
             auto kk = pw == 2 ? (kph == 2 ? bn_relu_pool_fwd_key_kernel<2, 2> : bn_relu_pool_fwd_key_kernel<2, 1>)
                               : (kph == 2 ? bn_relu_pool_fwd_key_kernel<1, 2> : bn_relu_pool_fwd_key_kernel<1, 1>);
-            kk<<<kgrid, 256, 0, st>>>((const bf16*)y, (bf16*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo);
+            kk<<<kgrid, 256, 0, st>>>((const bf16*)y, (bf16*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo, G);
             return;
         }
     }
     auto kern = pw == 2 ? (ph == 2 ? bn_relu_pool_fwd_kernel<T, 2, 2> : bn_relu_pool_fwd_kernel<T, 2, 1>)
                         : (ph == 2 ? bn_relu_pool_fwd_kernel<T, 1, 2> : bn_relu_pool_fwd_kernel<T, 1, 1>);
-    kern<<<grid, 256, 0, st>>>((const T*)y, (T*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo);
+    kern<<<grid, 256, 0, st>>>((const T*)y, (T*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo, G);
+}
+
+// GroupNorm + ReLU + max-pool apply pass (statistics [N][G] already formed): csrc/gn.hip
+void launch_gn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
+                             const float* mean, const float* invstd, int N, int H, int W, int C, int G, int dtype,
+                             hipStream_t st) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    if (dtype == PRIMIA_F32)
+        launch_bn_relu_pool_fwd<float>(y, pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo, st, G);
+    else
+        launch_bn_relu_pool_fwd<bf16>(y, pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo, st, G);
 }
 
 template <typename T>

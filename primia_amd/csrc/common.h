@@ -141,4 +141,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return base + idx;
 }
 
+// GroupNorm + ReLU + max-pool(3, 2, 1) apply pass, statistics [N][G] given (kernel: csrc/bn.hip, caller: csrc/gn.hip)
+void launch_gn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
+                             const float* mean, const float* invstd, int N, int H, int W, int C, int G, int dtype,
+                             hipStream_t st);
+
 }  // namespace primia

@@ -356,6 +356,144 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
     }
 }
 
+// ---- stem tail under GroupNorm: gn1 -> relu -> maxpool(3, 2, 1) without the full-resolution z / dz tensors ----------
+// (the BatchNorm path's fusion, csrc/bn.hip bn_relu_pool_*; the forward apply pass IS that kernel, in its group mode)
+// Backward reductions at POOLED resolution, per sample: a window passes its gradient to one input element, and where
+// ReLU was active xhat of that element is recoverable from the pooled value, xhat = (p - beta) / gamma.
+template <typename T>
+struct GnPoolScatterFn {
+    const T* p;
+    const T* dp;
+    const uint8_t* argmax;
+    const T* y;
+    const float* mean;     // [N][G]
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+    int H, W, C, Ho, Wo, G;
+    float k_beta[Chunk<T>::N], k_rgamma[Chunk<T>::N], k_mean[Chunk<T>::N], k_invstd[Chunk<T>::N];
+    bool any_zero_gamma;
+    __device__ __forceinline__ void prepare(int n, int c0) {
+        any_zero_gamma = false;
+        const int cpg = C / G;
+#pragma unroll
+        for (int i = 0; i < Chunk<T>::N; ++i) {
+            const float g = gamma[c0 + i];
+            k_beta[i] = beta[c0 + i];
+            k_rgamma[i] = g != 0.f ? 1.f / g : 0.f;
+            k_mean[i] = mean[n * G + (c0 + i) / cpg];
+            k_invstd[i] = invstd[n * G + (c0 + i) / cpg];
+            any_zero_gamma |= g == 0.f;
+        }
+    }
+    __device__ __forceinline__ void operator()(long off, int n, int c0, float* s1, float* s2) const {
+        constexpr int CH = Chunk<T>::N;
+        float vp[CH], vd[CH];
+        Chunk<T>::unpack(*(const u32x4*)(p + off), vp);
+        Chunk<T>::unpack(*(const u32x4*)(dp + off), vd);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const float g = vp[i] > 0.f ? vd[i] : 0.f;
+            s1[i] += g;
+            s2[i] += g * ((vp[i] - k_beta[i]) * k_rgamma[i]);
+        }
+        if (any_zero_gamma) {  // rare: xhat of a gamma == 0 channel from y at the argmax position
+            const long row = (off - c0) / C - (long)n * Ho * Wo;
+            const int ho = (int)(row / Wo), wo = (int)(row - (long)ho * Wo);
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                if (k_rgamma[i] != 0.f || !(vp[i] > 0.f)) continue;
+                const int code = argmax[off + i];
+                const int h = 2 * ho - 1 + code / 3, w = 2 * wo - 1 + code % 3;
+                const float yv = Elem<T>::load(y + (((long)n * H + h) * W + w) * C + c0 + i);
+                s2[i] += vd[i] * ((yv - k_mean[i]) * k_invstd[i]);
+            }
+        }
+    }
+};
+
+// Apply pass (even H, W): one thread per 2 x 2 block of input pixels x one 16-byte channel chunk.  Input pixel
+// (2a + i, 2b + j) can only be the argmax of the windows (a + di, b + dj), di <= i, dj <= j, at tap
+// (1 + i - 2 di, 1 + j - 2 dj): the four windows are loaded once.  dy = invstd (gamma g - A/m - xhat B/m).
+template <typename T>
+__global__ __launch_bounds__(256) void gn_relu_pool_bwd_apply2x2_kernel(
+    const T* __restrict__ y, const T* __restrict__ dp, const uint8_t* __restrict__ argmax, T* __restrict__ dy,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const float* __restrict__ gA, const float* __restrict__ gB, float inv_m, int N, int H,
+    int W, int C, int G, int Ho, int Wo) {
+    constexpr int CH = Chunk<T>::N;
+    const int cpr = C / CH, H2 = H >> 1, W2 = W >> 1, cpg = C / G;
+    const long total = (long)N * H2 * W2 * cpr;
+    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    if (q >= total) return;
+    const int c0 = (int)(q % cpr) * CH;
+    long t = q / cpr;
+    const int b = (int)(t % W2);
+    t /= W2;
+    const int a = (int)(t % H2), n = (int)(t / H2);
+    float km[CH], ki[CH], ks[CH], kg[CH], kb[CH], ka[CH], kbb[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int ng = n * G + (c0 + k) / cpg;
+        km[k] = mean[ng];
+        ki[k] = invstd[ng];
+        kg[k] = gamma[c0 + k];
+        ks[k] = ki[k] * kg[k];
+        kb[k] = beta[c0 + k];
+        ka[k] = gA[ng] * inv_m;
+        kbb[k] = gB[ng] * inv_m;
+    }
+    u32x4 wraw[2][2];      // the four windows, packed: gradient chunk and argmax codes (invalid: 0xff never matches)
+    u32x2 craw[2][2];
+#pragma unroll
+    for (int di = 0; di < 2; ++di)
+#pragma unroll
+        for (int dj = 0; dj < 2; ++dj) {
+            const bool ok = a + di < Ho && b + dj < Wo;
+            const long o = (((long)n * Ho + (ok ? a + di : 0)) * Wo + (ok ? b + dj : 0)) * C + c0;
+            wraw[di][dj] = *(const u32x4*)(dp + o);
+            if (CH == 8) {
+                craw[di][dj] = *(const u32x2*)(argmax + o);
+            } else {
+                craw[di][dj][0] = *(const uint32_t*)(argmax + o);
+                craw[di][dj][1] = 0xffffffffu;
+            }
+            if (!ok) craw[di][dj] = u32x2{0xffffffffu, 0xffffffffu};
+        }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long off = ((((long)n * H + 2 * a + i) * W) + 2 * b + j) * C + c0;
+            float vy[CH], g[CH];
+            Chunk<T>::unpack(*(const u32x4*)(y + off), vy);
+#pragma unroll
+            for (int k = 0; k < CH; ++k) g[k] = 0.f;
+#pragma unroll
+            for (int di = i; di >= 0; --di)
+#pragma unroll
+                for (int dj = j; dj >= 0; --dj) {
+                    const unsigned want = (unsigned)((1 + i - 2 * di) * 3 + (1 + j - 2 * dj));
+                    float wv[CH];
+                    Chunk<T>::unpack(wraw[di][dj], wv);
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const unsigned code = (craw[di][dj][k >> 2] >> (8 * (k & 3))) & 0xffu;
+                        g[k] += code == want ? wv[k] : 0.f;
+                    }
+                }
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                const float gi = gn_relu_open<T>(vy[k], km[k], ks[k], kb[k]) ? g[k] : 0.f;
+                const float xh = (vy[k] - km[k]) * ki[k];
+                vy[k] = ki[k] * (kg[k] * gi - ka[k] - xh * kbb[k]);
+            }
+            *(u32x4*)(dy + off) = Chunk<T>::pack(vy);
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+        }
+}
+
 // ---- DP-SGD per-sample pieces -------------------------------------------------------------------------
 // out[n] += sum_j x[n][j]^2   (block per (sample, chunk); fp64 block sum, one atomic per block)
 __global__ __launch_bounds__(256) void persample_sqnorm_kernel(const float* __restrict__ x, long per, double* out) {
@@ -511,8 +649,8 @@ static inline bool gn_sample_blocks(int N, int C, int ch) {
 }
 
 template <typename T>
-static int gn_fwd_impl(const void* y, const void* res, void* z, const float* gamma, const float* beta, float* mean,
-                       float* invstd, int N, int HW, int C, int G, float eps, int relu, float* partials, hipStream_t st) {
+static void gn_stats(const void* y, float* mean, float* invstd, int N, int HW, int C, int G, float eps, float* partials,
+                     hipStream_t st) {
     const int rps = (HW + kGnSlabs - 1) / kGnSlabs;
     const int nslab = (HW + rps - 1) / rps;
     GnStatsFn<T> f{(const T*)y};
@@ -524,6 +662,12 @@ static int gn_fwd_impl(const void* y, const void* res, void* z, const float* gam
         gn_stats_finalize_kernel<<<(N * C + 255) / 256, 256, 0, st>>>(partials, nslab, C, G, (long)HW * (C / G), eps, mean,
                                                                       invstd, N * C);
     }
+}
+
+template <typename T>
+static int gn_fwd_impl(const void* y, const void* res, void* z, const float* gamma, const float* beta, float* mean,
+                       float* invstd, int N, int HW, int C, int G, float eps, int relu, float* partials, hipStream_t st) {
+    gn_stats<T>(y, mean, invstd, N, HW, C, G, eps, partials, st);
     gn_apply_kernel<T><<<gn_sample_grid(N, HW, C / Chunk<T>::N), 256, 0, st>>>((const T*)y, (const T*)res, (T*)z, gamma, beta,
                                                                                mean, invstd, HW, C, G, relu);
     return launch_status();
@@ -550,6 +694,33 @@ static int gn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
     gn_bwd_apply_kernel<T><<<gn_sample_grid(N, HW, C / Chunk<T>::N), 256, 0, st>>>(
         (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, beta_mask, mean, invstd, gA, gB,
         (float)(1.0 / ((double)HW * (C / G))), HW, C, G);
+    return launch_status();
+}
+
+template <typename T>
+static int gn_relu_pool_bwd_impl(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax, void* dy,
+                                 const float* gamma, const float* beta, const float* mean, const float* invstd,
+                                 float* ps_dgamma, float* ps_dbeta, int N, int H, int W, int C, int G, float* partials,
+                                 hipStream_t st) {
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, HWp = Ho * Wo;
+    const int rps = (HWp + kGnSlabs - 1) / kGnSlabs;
+    const int nslab = (HWp + rps - 1) / rps;
+    GnPoolScatterFn<T> f{(const T*)pooled, (const T*)dpooled, argmax, (const T*)y, mean, invstd, gamma, beta,
+                         H, W, C, Ho, Wo, G, {}, {}, {}, {}, false};
+    float* gA = partials + (long)N * nslab * 2 * C;
+    float* gB = gA + (long)N * G;
+    if (gn_sample_blocks(N, C, Chunk<T>::N)) {
+        gn_sample_reduce_kernel<T, GnPoolScatterFn<T>, 1><<<N, 1024, 0, st>>>(f, HWp, C, G, 0.0, 0.f, gamma, ps_dbeta,
+                                                                              ps_dgamma, gA, gB);
+    } else {
+        gn_colreduce2_kernel<T, GnPoolScatterFn<T>><<<dim3(nslab, N), 256, 0, st>>>(f, HWp, C, rps, partials);
+        gn_bwd_finalize_kernel<<<(N * C + 255) / 256, 256, 0, st>>>(partials, nslab, C, G, gamma, ps_dbeta, ps_dgamma, gA,
+                                                                    gB, N * C);
+    }
+    const long total = (long)N * (H / 2) * (W / 2) * (C / Chunk<T>::N);
+    gn_relu_pool_bwd_apply2x2_kernel<T><<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
+        (const T*)y, (const T*)dpooled, argmax, (T*)dy, gamma, beta, mean, invstd, gA, gB,
+        (float)(1.0 / ((double)H * W * (C / G))), N, H, W, C, G, Ho, Wo);
     return launch_status();
 }
 
@@ -610,6 +781,42 @@ int primia_gn_relu_bwd(const void* y, const void* dz, void* dy, const float* gam
     if (dtype == PRIMIA_BF16)
         return gn_bwd_impl<bf16>(y, nullptr, dz, dy, nullptr, gamma, save_mean, save_invstd, ps_dgamma, ps_dbeta, N, HW, C,
                                  G, 0, (float*)workspace, st, beta);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_gn_relu_maxpool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
+                               float* save_mean, float* save_invstd, int N, int H, int W, int C, int G, float eps,
+                               void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && pooled && argmax && gamma && beta && save_mean && save_invstd && workspace);
+    PRIMIA_REQUIRE(H > 0 && W > 0 && gn_shape_ok(N, H * W, C, G, dtype));
+    if (workspace_bytes < primia_gn_workspace_bytes(N, C, G)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        gn_stats<float>(y, save_mean, save_invstd, N, H * W, C, G, eps, (float*)workspace, st);
+    else if (dtype == PRIMIA_BF16)
+        gn_stats<bf16>(y, save_mean, save_invstd, N, H * W, C, G, eps, (float*)workspace, st);
+    else
+        return PRIMIA_ERR_ARG;
+    launch_gn_relu_pool_fwd(y, pooled, argmax, gamma, beta, save_mean, save_invstd, N, H, W, C, G, dtype, st);
+    return launch_status();
+}
+
+int primia_gn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax, void* dy,
+                               const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                               float* ps_dgamma, float* ps_dbeta, int N, int H, int W, int C, int G, void* workspace,
+                               int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && pooled && dpooled && argmax && dy && gamma && beta && save_mean && save_invstd && ps_dgamma &&
+                   ps_dbeta && workspace);
+    PRIMIA_REQUIRE(H > 0 && W > 0 && gn_shape_ok(N, H * W, C, G, dtype));
+    if (H % 2 || W % 2) return PRIMIA_ERR_UNSUPPORTED;
+    if (workspace_bytes < primia_gn_workspace_bytes(N, C, G)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return gn_relu_pool_bwd_impl<float>(y, pooled, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, ps_dgamma,
+                                            ps_dbeta, N, H, W, C, G, (float*)workspace, st);
+    if (dtype == PRIMIA_BF16)
+        return gn_relu_pool_bwd_impl<bf16>(y, pooled, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, ps_dgamma,
+                                           ps_dbeta, N, H, W, C, G, (float*)workspace, st);
     return PRIMIA_ERR_ARG;
 }
 

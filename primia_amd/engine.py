@@ -421,7 +421,9 @@ class ResNet18Engine:
         elif self.training and self._atomic_stats_from is not None:
             self.stat_sums[self._atomic_stats_from:].zero_()
         self._stem_padded = self.x0p is not None and not (self.training and self.fuse_stats)
-        if not self._stem_padded or self.norm == "group":  # (the DP path's per-sample stem wgrad reads x0)
+        # (the unpadded copy is read only where the halo kernels on the padded one do not serve the shape)
+        self._x0_valid = not self._stem_padded or (self.norm == "group" and self._stem_ws_bytes <= 0)
+        if self._x0_valid:
             call("primia_nchw_to_nhwc", x_nchw, self.x0, N, self.spec.in_channels, S, S, 4, self.dt)
         if self._stem_padded:
             call("primia_nchw_to_nhwc_padded", x_nchw, self.x0p, N, self.spec.in_channels, S, S, 4, 3, 3,
@@ -443,6 +445,9 @@ class ResNet18Engine:
         hw = self.stem_hw
         self._stem_fused = (self.fuse_stem and self.training and self.norm == "batch" and self.spec.pooling == "max"
                             and not self.fuse_stats)
+        # GroupNorm: gn1 -> relu -> maxpool as one op each way (primia_gn_relu_maxpool_fwd / _bwd; _bwd wants even sizes)
+        self._stem_fused_gn = (self.fuse_stem and self.gn_stem_fused and self.norm == "group"
+                               and self.spec.pooling == "max" and hw % 2 == 0)
         if self._stem_fused and getattr(self, "_stem_has_sums", False) and self._stem_padded:
             sm, si = self.save["bn1"]
             call("primia_bn_relu_maxpool_fwd_from_sums", t["stem.y"], t["pool.out"], self.pool_argmax,
@@ -456,9 +461,13 @@ class ResNet18Engine:
                  self.views["bn1.bias"], self.views["bn1.running_mean"], self.views["bn1.running_var"], sm, si, N, hw,
                  hw, 64, BN_EPS, BN_MOMENTUM, self.bn_ws, self.bn_ws_bytes, self.dt)
             self.num_batches_tracked["bn1"] += 1
+        elif self._stem_fused_gn:
+            sm, si = self.save["bn1"]
+            call("primia_gn_relu_maxpool_fwd", t["stem.y"], t["pool.out"], self.pool_argmax, self.views["bn1.weight"],
+                 self.views["bn1.bias"], sm, si, N, hw, hw, 64, self.groups, BN_EPS, self.bn_ws, self.bn_ws_bytes, self.dt)
         else:
             self._bn("conv1", t["stem.y"], t["stem.z"], None, True)
-        if self._stem_fused:
+        if self._stem_fused or self._stem_fused_gn:
             pass
         elif self.spec.pooling == "max":
             call("primia_maxpool3x3s2_fwd", t["stem.z"], t["pool.out"], self.pool_argmax, N, hw, hw, 64, self.dt)
@@ -572,6 +581,7 @@ class ResNet18Engine:
 
     wgrad_pair = os.environ.get("PRIMIA_WGRAD_PAIR", "1") != "0"
     gn_relu_recompute = os.environ.get("PRIMIA_GN_RELU_RECOMPUTE", "1") != "0"
+    gn_stem_fused = os.environ.get("PRIMIA_GN_STEM_FUSED", "1") != "0"
 
     def _wgrad_transition(self, blk, x, dy1, dyd):
         """conv1 and the downsample of a transition block: one launch where the library serves the pair."""
@@ -753,6 +763,15 @@ class ResNet18Engine:
             call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, t["stem.dy"],
                  self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self.gviews["bn1.weight"],
                  self.gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
+        elif getattr(self, "_stem_fused_gn", False):
+            sm, si = self.save["bn1"]
+            psg, psb = self.ps_affine["bn1"]
+            call("primia_gn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, t["stem.dy"],
+                 self.views["bn1.weight"], self.views["bn1.bias"], sm, si, psg, psb, N, hw, hw, 64, self.groups,
+                 self.bn_ws, self.bn_ws_bytes, self.dt)
+            if self.dp is None:
+                call("primia_weighted_colsum", psg, self.ones_n, self.gviews["bn1.weight"], N, 64)
+                call("primia_weighted_colsum", psb, self.ones_n, self.gviews["bn1.bias"], N, 64)
         else:
             if self.spec.pooling == "max":
                 call("primia_maxpool3x3s2_bwd", t["pool.dout"], self.pool_argmax, t["stem.dz"], N, hw, hw, 64, self.dt)
@@ -838,6 +857,9 @@ class ResNet18Engine:
                     except _lib.PrimiaError:
                         done = False
                 if not done:
+                    if name == "conv1" and not self._x0_valid:
+                        raise _lib.PrimiaError("per-sample stem gradient: the padded-input kernel refused a shape it "
+                                               "advertised (primia_stem_conv_wgrad_ws_bytes > 0)")
                     call("primia_conv2d_wgrad_persample_sqnorm", c.desc, x, dy, sq, self.dt)
                 mark(name)
             clip = torch.empty(N, dtype=torch.float32, device=dev)

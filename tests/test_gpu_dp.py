@@ -151,3 +151,35 @@ def test_persample_sqnorm_matches_slab_norms(cuda, dtype, case):
     call("primia_conv2d_wgrad_persample_sqnorm", d, x, dy, sq, dt)
     assert rel(sq - 0.5, sq_ref) < 1e-6
     assert rel(sq_ref, (slab.double() ** 2).sum(1)) < 1e-10
+
+
+@pytest.mark.parametrize("dtype,batch,size", [(torch.float32, 4, 64), (torch.bfloat16, 8, 64), (torch.bfloat16, 130, 32)])
+def test_groupnorm_stem_fused_matches_the_chain(cuda, dtype, batch, size):
+    """Stem tail gn1 -> relu -> maxpool as one op each way (primia_gn_relu_maxpool_fwd / _bwd, z and dz never written)
+    against the three-op chain (primia_gn_fwd, primia_maxpool3x3s2_fwd / _bwd, primia_gn_relu_bwd): pooled activations
+    and argmax codes are bit-equal (one value expression); the gradients agree to rounding — the fused backward adds
+    the up-to-four window gradients of an element in fp32 where the chain rounds their sum to the storage type."""
+    spec = rs.resnet18_spec(3, 3, size, "max")
+    torch.manual_seed(21)
+    sd = rs.init_state_dict(spec, "group")
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(batch, 3, size, size, generator=g).to(cuda)
+    y = torch.randint(0, 3, (batch,), generator=g).to(cuda)
+    out = []
+    for fused in (True, False):
+        eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=dtype, device=cuda, norm="group")
+        eng.gn_stem_fused = fused
+        eng.load_state_dict(sd)
+        eng.forward(x)
+        eng.loss_backward(y)
+        torch.cuda.synchronize()
+        assert eng._stem_fused_gn == fused
+        out.append((eng.t["pool.out"].clone(), eng.pool_argmax.clone(), eng.logits.clone(), eng.t["stem.dy"].clone(),
+                    eng.grads.clone(), {k: eng.gviews[k].clone() for k in ("conv1.weight", "bn1.weight", "bn1.bias")}))
+    a, b = out
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert rel(a[3], b[3]) < tol
+    for k in a[5]:
+        assert rel(a[5][k], b[5][k]) < tol, k
+    assert rel(a[4], b[4]) < tol
