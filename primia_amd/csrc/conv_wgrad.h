@@ -42,6 +42,8 @@ size_t wgrad_patch_ws_bytes(const WgradParams& p);
 int wgrad_tap_dispatch(const WgradParams& p, hipStream_t st);
 int wgrad_tap_kernel_id(const WgradParams& p);
 size_t wgrad_tap_ws_bytes(const WgradParams& p);
+// DP-SGD norm pass of those layers: whole images per block, squared tile norms added to p.sqnorm (no workspace)
+int wgrad_tap_persample_dispatch(const WgradParams& p, hipStream_t st);
 // conv1 + downsample of a transition block in one launch (the downsample = a tenth tap with its own dy)
 int wgrad_tap_pair_dispatch(const WgradParams& p, const WgradParams& p2, hipStream_t st);
 size_t wgrad_tap_pair_ws_bytes(const WgradParams& p, const WgradParams& p2);

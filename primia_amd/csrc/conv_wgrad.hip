@@ -561,6 +561,8 @@ static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const voi
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
             const int rt = wgrad_tap_dispatch(p, st);     // stride-2 / 1x1 layers with a workspace
             if (rt != PRIMIA_ERR_UNSUPPORTED) return rt;
+            const int rp = wgrad_tap_persample_dispatch(p, st);   // ... and their DP-SGD norm pass
+            if (rp != PRIMIA_ERR_UNSUPPORTED) return rp;
         }
         if (!g.stem && dma) return wgrad_dma_dispatch(p, st);
         if (g.stem) return launch_wgrad<bf16, 64, 32, true>(p, st);

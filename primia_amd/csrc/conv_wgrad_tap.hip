@@ -44,6 +44,10 @@ struct TapParams {
     int pps;            // pixels per split (multiple of 64)
     int dq, dr;         // 64 / Wo, 64 % Wo
     int slow;           // counters cannot be advanced with two conditional subtractions: divide every stage
+    // per-sample norm pass (DP-SGD, template flag PS): a block walks whole images, each padded to `spi` stages of 64
+    // pixels; after an image's last stage the squares of its tile are added to sqnorm[image] and the tile starts over
+    double* sqnorm;
+    int nimg, ipb, spi;
 };
 
 __device__ __forceinline__ void tap_bdma16(unsigned voff, tap_i32x4 rsrc, unsigned lds_addr) {
@@ -68,7 +72,7 @@ __device__ __forceinline__ int tap_key(int row) {
     return ROW >= 256 ? (row & 3) : ((row >> 1) & 1);
 }
 
-template <int BMK, int BNC, int WM, int WN>
+template <int BMK, int BNC, int WM, int WN, bool PS = false>
 __global__ __launch_bounds__(512) void conv_wgrad_tap_kernel(TapParams p) {
     constexpr int KP = 64, STAGES = 3;
     constexpr int ROW_A = BMK * 2, ROW_B = BNC * 2;
@@ -96,10 +100,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_tap_kernel(TapParams p) {
     const int split = bid / ntaps_all;
     const bool second = tap >= p.ntaps;          // block-uniform
     const int tr = second ? p.pad : tap / p.S, ts = second ? p.pad : tap - (tap / p.S) * p.S;
-    const int ms = split * p.pps;
+    const int ppi = p.Ho * p.Wo;                  // PS: pixels per image
+    const int i0 = split * p.ipb;                 // PS: first image of this block
+    int i1 = i0 + p.ipb;
+    if (i1 > p.nimg) i1 = p.nimg;
+    const int ms = PS ? i0 * ppi : split * p.pps;
     int me = ms + p.pps;
     if (me > p.Md) me = p.Md;
-    const int nsteps = (me - ms + KP - 1) / KP;
+    const int nsteps = PS ? (i1 - i0) * p.spi : (me - ms + KP - 1) / KP;
 
     const tap_i32x4 rs_x = tap_rsrc(p.x, (long)(p.Md / (p.Ho * p.Wo)) * p.H * p.W * p.C * 2);
     const tap_i32x4 rs_dy = tap_rsrc(second ? p.dy2 : p.dy, (long)p.Md * p.K * 2);
@@ -117,23 +125,54 @@ __global__ __launch_bounds__(512) void conv_wgrad_tap_kernel(TapParams p) {
     }
     unsigned rel_b[PX];      // x piece: channel part of the offset
     int xm[PX], xw[PX], xh[PX], xn[PX];     // pixel of this lane's row: index, (wo, ho, n)
+    int row_b[PX], xw0[PX], xh0[PX];        // PS: the row, and its (wo, ho) in the first stage of every image
 #pragma unroll
     for (int it = 0; it < PX; ++it) {
         const int b = wave + 8 * it;
         const int row = b * (1024 / ROW_B) + lane / (ROW_B / 16), c16 = lane % (ROW_B / 16);
         const int chunk = (((c16 >> 2) ^ tap_key<ROW_B>(row)) << 2) | (c16 & 3);
         rel_b[it] = (unsigned)((ct * BNC + chunk * 8) * 2);
-        const int m = ms + row;
+        const int m = PS ? row : ms + row;
         xm[it] = m;
         xw[it] = m % p.Wo;
         const int t = m / p.Wo;
-        xh[it] = t % p.Ho;
+        xh[it] = PS ? t : t % p.Ho;
         xn[it] = t / p.Ho;
+        row_b[it] = row; xw0[it] = xw[it]; xh0[it] = xh[it];
     }
     const int hoff = tr - p.pad, woff = ts - p.pad;
     int s_issue = 0;        // stages issued so far
+    int s_img = i0, s_sj = 0;   // PS: image and stage-in-image being issued
     auto stage = [&](int buf) {
         const unsigned base = lds0 + buf * STAGE;
+        if constexpr (PS) {
+            const int r0 = s_sj * KP;                       // first pixel-in-image of the stage
+            const unsigned p0 = (unsigned)(s_img * ppi + r0);
+#pragma unroll
+            for (int it = 0; it < PA; ++it) {
+                const unsigned voff = r0 + row_a[it] < ppi ? rel_a[it] + p0 * (unsigned)(p.K * 2) : kOob;
+                tap_bdma16(voff, rs_dy, __builtin_amdgcn_readfirstlane(base + (wave + 8 * it) * 1024));
+            }
+#pragma unroll
+            for (int it = 0; it < PX; ++it) {
+                const int hs = xh[it] * p.stride + hoff, ws_ = xw[it] * p.stride + woff;
+                const bool ok = r0 + row_b[it] < ppi && (unsigned)hs < (unsigned)p.H && (unsigned)ws_ < (unsigned)p.W;
+                const unsigned pix = (unsigned)((s_img * p.H + hs) * p.W + ws_);
+                const unsigned voff = ok ? pix * (unsigned)(p.C * 2) + rel_b[it] : kOob;
+                tap_bdma16(voff, rs_x, __builtin_amdgcn_readfirstlane(base + KP * ROW_A + (wave + 8 * it) * 1024));
+                int w = xw[it] + p.dr, h = xh[it] + p.dq;   // (rows past the image end are masked by the row test)
+                if (w >= p.Wo) { w -= p.Wo; ++h; }
+                xw[it] = w;
+                xh[it] = h;
+            }
+            if (++s_sj == p.spi) {
+                s_sj = 0;
+                ++s_img;
+#pragma unroll
+                for (int it = 0; it < PX; ++it) { xw[it] = xw0[it]; xh[it] = xh0[it]; }
+            }
+            return;
+        }
         const int p0 = ms + s_issue * KP;
         ++s_issue;
 #pragma unroll
@@ -237,6 +276,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_tap_kernel(TapParams p) {
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nsteps) stage(s);
     int cur = 0, nxt = STAGES - 1;
+    int c_img = i0, c_sj = 0;     // PS: image and stage-in-image being multiplied
     for (int s = 0; s < nsteps; ++s) {
         wait_pieces(s + 1 < nsteps ? PA + PX : 0);      // stage s has landed; stage s + 1 may be in flight
         __builtin_amdgcn_s_barrier();                    // ... for every wave; buffer `nxt` is no longer read
@@ -244,7 +284,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_tap_kernel(TapParams p) {
         compute(cur);
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+        if constexpr (PS) {
+            if (++c_sj == p.spi) {     // the image's complete (tap, kt, ct) tile: its squares, then start over
+                double sq = 0.0;
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) {
+                            sq += (double)acc[i][j][e] * (double)acc[i][j][e];
+                            acc[i][j][e] = 0.f;
+                        }
+                wave_sqnorm_add(sq, p.sqnorm + c_img);
+                c_sj = 0;
+                ++c_img;
+            }
+        }
     }
+    if constexpr (PS) return;
 
     // ---- this block's BMK x BNC partial tile -> ITS workspace slot, row-major [k_local][c_local] ------------------
     // lane holds rows 32*(wm*FM + i) + 8*m + 4*(lane >> 5) + t (register 4*m + t), column 32*(wn*FN + j) + (lane & 31)
@@ -305,7 +363,7 @@ int wgrad_tap_kernel_id(const WgradParams& w) { return tap_geom(w).ok ? 17 : 0; 
 
 template <int BMK, int BNC, int WM, int WN>
 static int launch_tap(const WgradParams& w, const TapGeom& g, hipStream_t st) {
-    TapParams p;
+    TapParams p{};
     p.x = (const bf16*)w.x; p.dy = (const bf16*)w.dy; p.dy2 = nullptr; p.ws = w.ws;
     p.H = w.H; p.W = w.W; p.C = w.C; p.K = w.K; p.S = w.S; p.stride = w.stride; p.pad = w.pad; p.Ho = w.Ho; p.Wo = w.Wo;
     p.Md = (int)w.Md;
@@ -339,7 +397,7 @@ size_t wgrad_tap_pair_ws_bytes(const WgradParams& w, const WgradParams& w2) {
 
 template <int BMK, int BNC, int WM, int WN>
 static int launch_tap_pair(const WgradParams& w, const WgradParams& w2, const TapGeom& g, hipStream_t st) {
-    TapParams p;
+    TapParams p{};
     p.x = (const bf16*)w.x; p.dy = (const bf16*)w.dy; p.dy2 = (const bf16*)w2.dy; p.ws = w.ws;
     p.H = w.H; p.W = w.W; p.C = w.C; p.K = w.K; p.S = w.S; p.stride = w.stride; p.pad = w.pad; p.Ho = w.Ho; p.Wo = w.Wo;
     p.Md = (int)w.Md;
@@ -363,6 +421,44 @@ int wgrad_tap_pair_dispatch(const WgradParams& w, const WgradParams& w2, hipStre
     if (!need || !w.ws || !w.dw || !w2.dw || w.ws_bytes < need) return PRIMIA_ERR_UNSUPPORTED;
     TapGeom g = tap_geom(w, 1);
     return g.wide ? launch_tap_pair<256, 128, 2, 4>(w, w2, g, st) : launch_tap_pair<128, 64, 4, 2>(w, w2, g, st);
+}
+
+// DP-SGD norm pass: sqnorm[n] += ||dW_n||_F^2 of a stride-2 / 1x1 layer, per-sample gradients never written.  The
+// older kernels ran one block per (tile, tap, image) — at 49 or 196 pixels per image that is all prologue.
+template <int BMK, int BNC, int WM, int WN>
+static int launch_tap_persample(const WgradParams& w, const TapGeom& g, hipStream_t st) {
+    TapParams p{};
+    p.x = (const bf16*)w.x; p.dy = (const bf16*)w.dy; p.dy2 = nullptr; p.ws = nullptr;
+    p.H = w.H; p.W = w.W; p.C = w.C; p.K = w.K; p.S = w.S; p.stride = w.stride; p.pad = w.pad; p.Ho = w.Ho; p.Wo = w.Wo;
+    p.Md = (int)w.Md;
+    p.nkt = g.nkt; p.nct = g.nct; p.ntaps = w.ntaps;
+    p.dq = 64 / w.Wo; p.dr = 64 % w.Wo;
+    p.slow = 0;
+    p.sqnorm = w.sqnorm;
+    p.nimg = w.N;
+    p.spi = (w.Ho * w.Wo + 63) / 64;
+    long want = (g.wide ? 256 : 512) / g.combos;
+    if (want < 1) want = 1;
+    if (want > w.N) want = w.N;
+    p.ipb = (int)((w.N + want - 1) / want);
+    p.nsplit = (w.N + p.ipb - 1) / p.ipb;
+    p.pps = 0;
+    const int lds = 3 * 64 * (BMK + BNC) * 2;
+    auto kern = conv_wgrad_tap_kernel<BMK, BNC, WM, WN, true>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+        return PRIMIA_ERR_LAUNCH;
+    kern<<<g.combos * p.nsplit, 512, lds, st>>>(p);
+    return launch_status();
+}
+
+int wgrad_tap_persample_dispatch(const WgradParams& w, hipStream_t st) {
+    static const bool off = getenv("PRIMIA_WGTAP_PS") && getenv("PRIMIA_WGTAP_PS")[0] == '0';
+    if (off || !w.persample || !w.sqnorm) return PRIMIA_ERR_UNSUPPORTED;
+    WgradParams b = w;
+    b.persample = 0;
+    const TapGeom g = tap_geom(b);
+    if (!g.ok || w.Ho * w.Wo < 1) return PRIMIA_ERR_UNSUPPORTED;
+    return g.wide ? launch_tap_persample<256, 128, 2, 4>(w, g, st) : launch_tap_persample<128, 64, 4, 2>(w, g, st);
 }
 
 // PRIMIA_ERR_UNSUPPORTED: shape not served, or no (large enough) workspace — the caller falls back to the older kernels

@@ -127,7 +127,11 @@ def test_dp_sgd_gradient_matches_oracle(cuda):
                                   (2, 8, 256, 512, 1, 2, 0), (3, 32, 4, 64, 7, 2, 3), (5, 14, 128, 128, 3, 1, 1),
                                   # enough (image pairs x slabs) for the whole-images-per-half norm pass of the patch
                                   # kernel: 4 sub-patches per image and an odd batch; one sub-patch per image; ragged 12x12
-                                  (33, 16, 256, 256, 3, 1, 1), (40, 7, 512, 256, 3, 1, 1), (17, 12, 256, 512, 3, 1, 1)])
+                                  (33, 16, 256, 256, 3, 1, 1), (40, 7, 512, 256, 3, 1, 1), (17, 12, 256, 512, 3, 1, 1),
+                                  # whole images per block in the per-tap kernel (stride-2 / 1x1 layers): 784 / 196 / 49
+                                  # pixels per image (13 / 4 / 1 stages, the last one ragged), several images per block
+                                  (70, 56, 64, 128, 3, 2, 1), (37, 28, 128, 256, 3, 2, 1), (9, 14, 256, 512, 3, 2, 1),
+                                  (300, 14, 256, 512, 1, 2, 0), (5, 28, 128, 256, 1, 2, 0)])
 def test_persample_sqnorm_matches_slab_norms(cuda, dtype, case):
     """primia_conv2d_wgrad_persample_sqnorm (norms summed inside the wgrad kernels) against the explicit
     per-sample slabs of primia_conv2d_wgrad_persample + primia_persample_sqnorm, for every kernel family
