@@ -802,6 +802,22 @@ __global__ __launch_bounds__(256) void wgrad_patch32_reduce_kernel(const float* 
 #ifndef PRIMIA_WGP33_PIN
 #define PRIMIA_WGP33_PIN 1
 #endif
+// compile-time experiment switches (tools/micro/wgp33_bench.hip): 1 no epilogue, 2 no DMA after the prologue, 4 no MFMA,
+// 8 no fragment reads.  WGP33_PROF: per-wave cycles in DMA issue / vmcnt wait / barrier wait / compute / epilogue.
+#ifndef WGP33_DBG
+#define WGP33_DBG 0
+#endif
+#ifdef WGP33_PROF
+__device__ unsigned long long* wgp33_prof_buffer_dev;
+#define WGP33_MARK(slot)                               \
+    {                                                  \
+        const unsigned long long t_now = clock64();    \
+        prof_t[slot] += t_now - prof_prev;             \
+        prof_prev = t_now;                             \
+    }
+#else
+#define WGP33_MARK(slot)
+#endif
 template <int SW, int SH, int STAGES>
 __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) {
     constexpr int FR = SW == 8 ? 2 : 1;         // rows of a k-step fragment
@@ -822,6 +838,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = wave >> 2, kg = (wave >> 1) & 1, cg = wave & 1;
+#ifdef WGP33_PROF
+    unsigned long long prof_t[6] = {0, 0, 0, 0, 0, 0}, prof_prev = clock64();   // [5] = everything before the main loop ends... see marks
+#endif
 
     int bid = xcd_remap(blockIdx.x, gridDim.x);
     int split;
@@ -1013,15 +1032,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
             bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(px_[s][1] + j * KSTEP_X));
             return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
         };
+        if (WGP33_DBG & 8) {
 #pragma unroll
-        for (int y = 0; y < 3; ++y) Y[y] = read_y(y);
+            for (int y = 0; y < NY; ++y) asm volatile("" : "=v"(Y[y]));
 #pragma unroll
-        for (int s = 0; s < 3; ++s) X[0][s] = read_x(0, s);
+            for (int s = 0; s < 3; ++s) { asm volatile("" : "=v"(X[0][s])); asm volatile("" : "=v"(X[1][s])); }
+        } else {
+#pragma unroll
+            for (int y = 0; y < 3; ++y) Y[y] = read_y(y);
+#pragma unroll
+            for (int s = 0; s < 3; ++s) X[0][s] = read_x(0, s);
+        }
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
             // the fragments of k-step j + 1 are requested BEFORE the MFMAs of k-step j (left to itself the scheduler
             // issues them right in front of their first use: ~100-200 cycles of LDS latency per k-step in the open)
-            if (j + 1 < NK) {
+            if (j + 1 < NK && !(WGP33_DBG & 8)) {
 #pragma unroll
                 for (int s = 0; s < 3; ++s) X[(j + 1) & 1][s] = read_x(j + 1, s);
 #pragma unroll
@@ -1029,11 +1055,18 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
             }
             if (PRIMIA_WGP33_PIN) __builtin_amdgcn_sched_barrier(0);
             if (prio) __builtin_amdgcn_s_setprio(1);   // the partner wave's reads / DMA issue must not take slots from the MFMAs
+            if (WGP33_DBG & 4) {
+#pragma unroll
+                for (int y = 0; y < NY; ++y) asm volatile("" ::"v"(Y[y]));
+#pragma unroll
+                for (int s = 0; s < 3; ++s) asm volatile("" ::"v"(X[j & 1][s]));
+            } else {
 #pragma unroll
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int s = 0; s < 3; ++s)
                     acc[3 * r + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Y[FR * j + 2 - r], X[j & 1][s], acc[3 * r + s], 0, 0, 0);
+            }
             if (prio) __builtin_amdgcn_s_setprio(0);
             if (PRIMIA_WGP33_PIN) __builtin_amdgcn_sched_barrier(0);
         }
@@ -1062,20 +1095,27 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
     // the two waves of a SIMD belong to different halves: half 0 issues its DMA pieces and THEN multiplies, half 1
     // multiplies and THEN issues (see v2); two copies of the loop, one order each
     int sp_done = 0, img_pair = 0;     // pairimg: stages done of the current image pair; pairs done
+    WGP33_MARK(5)
     auto main_loop = [&](auto stage_first) {
         int cur = 0, nxt = STAGES - 1;
         for (int s = 0; s < nstages; ++s) {
             int ahead = nstages - 1 - s;
             if (ahead > STAGES - 2) ahead = STAGES - 2;
             wait_inflight(ahead);
+            WGP33_MARK(1)
             __builtin_amdgcn_s_barrier();
-            do_issue = s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2);
+            WGP33_MARK(2)
+            do_issue = s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2) && !(WGP33_DBG & 2);
             if constexpr (decltype(stage_first)::value) {
                 if (do_issue) stage(nxt);
+                WGP33_MARK(0)
                 compute(cur);
+                WGP33_MARK(3)
             } else {
                 compute(cur);
+                WGP33_MARK(3)
                 if (do_issue) stage(nxt);
+                WGP33_MARK(0)
             }
             if (p.pairimg && ++sp_done == p.PPI) {
                 // DP-SGD norm pass: each half has just finished a whole image of its own, and the wave's accumulators are
@@ -1105,7 +1145,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
         main_loop(OrderTag<false>{});
 
     if (p.pairimg) return;
-    wgrad32_epilogue(acc, p, smem, wave, lane, half, kg, cg, kt, ct, split);
+    WGP33_MARK(5)
+    if (!(WGP33_DBG & 1)) wgrad32_epilogue(acc, p, smem, wave, lane, half, kg, cg, kt, ct, split);
+    else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) asm volatile("" ::"v"(acc[t]));
+    }
+    WGP33_MARK(4)
+#ifdef WGP33_PROF
+    if (lane == 0 && wgp33_prof_buffer_dev) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) wgp33_prof_buffer_dev[((long)blockIdx.x * 8 + wave) * 6 + k] = prof_t[k];
+    }
+#endif
 }
 
 struct PatchGeom {
@@ -1229,8 +1281,10 @@ template <int SW, int SH, int STAGES = 3>
 static int launch_patch33(const WgradParams& w, const PatchGeom& g, hipStream_t st) {
     PatchParams p;
     fill_patch_params(p, w, g);
-    // the stage ring (at most 144 KiB), or the 144 KiB the two halves need to meet in after the main loop
-    const size_t lds = (size_t)kSlab * 4;
+    // the stage ring (at most 144 KiB; 160 KiB for four 8 x 8 stages), or the 144 KiB the two halves need to meet in
+    // after the main loop
+    size_t lds = (size_t)kSlab * 4;
+    if (SW == 8 && SH == 8 && STAGES == 4) lds = 163840;
     auto kern = conv_wgrad_patch33_kernel<SW, SH, STAGES>;
     static bool attr_set = false;
     if (!attr_set) {
@@ -1332,6 +1386,9 @@ int wgrad_patch_dispatch(const WgradParams& w, hipStream_t st) {
     if (!g.ok) return PRIMIA_ERR_UNSUPPORTED;
     if (use_v3()) {
         if (g.SW == 16) return g.SH == 7 ? launch_patch33<16, 7, 2>(w, g, st) : launch_patch33<16, 2>(w, g, st);
+        // (8 x 8: four stages of 40 KiB are exactly the CU's 160 KiB of LDS)
+        static const int st88 = getenv("PRIMIA_WGP_STAGES88") ? atoi(getenv("PRIMIA_WGP_STAGES88")) : 3;
+        if (g.SH == 8 && st88 == 4) return launch_patch33<8, 8, 4>(w, g, st);
         return g.SH == 8 ? launch_patch33<8, 8>(w, g, st) : launch_patch33<8, 4>(w, g, st);
     }
     return g.wide ? launch_patch<16>(w, g, st) : launch_patch<8>(w, g, st);
