@@ -189,6 +189,20 @@ int64_t primia_conv_wgrad_pair_ws_bytes(const primia_conv_desc* d, const primia_
 int primia_conv2d_wgrad_pair_ws(const primia_conv_desc* d, const void* x, const void* dy, float* dw,
                                 const primia_conv_desc* d2, const void* dy2, float* dw2, void* ws, int64_t ws_bytes,
                                 int dtype, primia_stream_t stream);
+
+/* Several layers of ONE shape (3x3 / stride 1, bf16) in one launch: a weight-gradient call carries ~25-29 us that do not
+ * shrink with the work next to a 45-55-us main loop (profiles/r03_wgp33_phase_profile.txt), and weight gradients are
+ * leaves of the backward graph — a caller may hold a layer's (x, dy) back until the siblings of its ResNet stage are
+ * ready.  _group_size: preferred group size for `count` layers of this shape (0: shape not served by the grouped
+ * kernel, 1: no gain); _group_ws_bytes: workspace of a group of n (0: not served); _group_ws: n layers, 2 <= n <= 4,
+ * unused triples null; results per layer as primia_conv2d_wgrad_ws, deterministic.  Same reference counterpart:
+ * autograd of conv3x3 (torchlib/models.py:219-235). */
+int primia_conv_wgrad_group_size(const primia_conv_desc* d, int count, int dtype);
+int64_t primia_conv_wgrad_group_ws_bytes(const primia_conv_desc* d, int n, int dtype);
+int primia_conv2d_wgrad_group_ws(const primia_conv_desc* d, int n, const void* x0, const void* dy0, float* dw_acc0,
+                                 const void* x1, const void* dy1, float* dw_acc1, const void* x2, const void* dy2,
+                                 float* dw_acc2, const void* x3, const void* dy3, float* dw_acc3, void* workspace,
+                                 int64_t workspace_bytes, int dtype, primia_stream_t stream);
 /* Per-sample weight gradients for DP-SGD: dw_ps [N][K][klen] (fwd layout, fp32, zeroed by the caller),
  * image n's gradient in slab n. */
 int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,

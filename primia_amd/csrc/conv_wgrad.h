@@ -38,6 +38,11 @@ size_t wgrad_dma_ws_bytes(const WgradParams& p);
 int wgrad_patch_dispatch(const WgradParams& p, hipStream_t st);
 int wgrad_patch_kernel_id(const WgradParams& p);
 size_t wgrad_patch_ws_bytes(const WgradParams& p);
+// up to four layers of one shape in one launch (conv_wgrad_patch.hip): preferred group size for `count` such layers
+// (0: shape not served, 1: no gain), workspace of a group of n, and the launch (p[0].ws / ws_bytes = the group's)
+int wgrad_patch_group_size(const WgradParams& p, int count);
+size_t wgrad_patch_group_ws_bytes(const WgradParams& p, int n);
+int wgrad_patch_group_dispatch(const WgradParams* p, int n, hipStream_t st);
 // per-tap kernel of the stride-2 / 1x1 layers, second generation (conv_wgrad_tap.hip); needs the workspace
 int wgrad_tap_dispatch(const WgradParams& p, hipStream_t st);
 int wgrad_tap_kernel_id(const WgradParams& p);

@@ -506,6 +506,48 @@ extern "C" int primia_conv2d_wgrad_pair_ws(const primia_conv_desc* d, const void
     return wgrad_tap_pair_dispatch(p, p2, (hipStream_t)stream);
 }
 
+// Several layers of ONE shape in one launch (conv_wgrad_patch.hip: grouped launch).  n layers, 2 <= n <= 4; unused
+// (x, dy, dw_acc) triples are null.
+extern "C" int primia_conv_wgrad_group_size(const primia_conv_desc* d, int count, int dtype) {
+    ConvGeom g;
+    WgradParams p;
+    if (!d || count < 1 || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
+    static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    if (dtype != PRIMIA_BF16 || g.stem || force) return 0;
+    p.persample = 0;
+    return wgrad_patch_group_size(p, count);
+}
+
+extern "C" int64_t primia_conv_wgrad_group_ws_bytes(const primia_conv_desc* d, int n, int dtype) {
+    ConvGeom g;
+    WgradParams p;
+    if (!d || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
+    if (dtype != PRIMIA_BF16 || g.stem) return 0;
+    p.persample = 0;
+    return (int64_t)wgrad_patch_group_ws_bytes(p, n);
+}
+
+extern "C" int primia_conv2d_wgrad_group_ws(const primia_conv_desc* d, int n, const void* x0, const void* dy0, float* dw0,
+                                            const void* x1, const void* dy1, float* dw1, const void* x2, const void* dy2,
+                                            float* dw2, const void* x3, const void* dy3, float* dw3, void* ws,
+                                            int64_t ws_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && n >= 2 && n <= 4 && ws && ws_bytes > 0);
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
+    const void* xs[4] = {x0, x1, x2, x3};
+    const void* dys[4] = {dy0, dy1, dy2, dy3};
+    float* dws[4] = {dw0, dw1, dw2, dw3};
+    WgradParams ps[4];
+    for (int i = 0; i < n; ++i) {
+        ConvGeom g;
+        PRIMIA_REQUIRE(xs[i] && dys[i] && dws[i] && fill_wgrad_params(d, ps[i], g));
+        if (g.stem) return PRIMIA_ERR_UNSUPPORTED;
+        ps[i].x = xs[i]; ps[i].dy = dys[i]; ps[i].dw = dws[i];
+        ps[i].persample = 0; ps[i].sqnorm = nullptr;
+        ps[i].ws = (float*)ws; ps[i].ws_bytes = (size_t)ws_bytes;
+    }
+    return wgrad_patch_group_dispatch(ps, n, (hipStream_t)stream);
+}
+
 extern "C" int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,
                                              float* dw_ps, int dtype, primia_stream_t stream) {
     return conv2d_wgrad_impl(d, x, dy, dw_ps, 1, dtype, stream);

@@ -60,6 +60,11 @@ struct PatchParams {
     int debug_skip_epilogue;  // timing experiments only (PRIMIA_WGP_NOEPI=1)
     int pairimg;              // v3, DP-SGD norm pass: a half owns whole images (units of t0 / per_block / total: images)
     int nimg;                 // batch size
+    // v3, grouped launch: `ngroups` layers of ONE shape share the launch — blocks [g * group_blocks, (g + 1) * group_blocks)
+    // work on layer g (x / dy of layers 1.. in xg / dyg; slabs of layer g behind those of layer g - 1)
+    int ngroups, group_blocks;
+    const bf16* xg[3];
+    const bf16* dyg[3];
 };
 
 constexpr int kSlab = 64 * 9 * 64;   // accumulator values of one block
@@ -744,13 +749,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
 }
 
 // Ordered reduction of the v2 slabs (chunk q = ((t*4 + m)*4 + wave)*64 + lane, see the kernel's store).
+struct ReduceGroup {        // grouped launch: dw of layers 1..3 and the combos of one layer (0: single layer)
+    float* dwg[3];
+    int combos;
+};
+
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad_patch32_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                                   int nsplit, int nct, int C, int klen) {
+                                                                   int nsplit, int nct, int C, int klen, ReduceGroup rg) {
     constexpr int CL = 256 / SL;
     constexpr int CPB = kSlab / 4 / CL;
     __shared__ f32x4 red[SL][CL];
-    const int combo = blockIdx.x / CPB;
+    int combo = blockIdx.x / CPB;
+    if (rg.combos > 0) {        // slabs: [layer][combo][split]
+        const int gi = combo / rg.combos;
+        combo -= gi * rg.combos;
+        ws += (long)gi * rg.combos * nsplit * kSlab;
+        if (gi > 0) dw = rg.dwg[gi - 1];
+    }
     const int q = (blockIdx.x % CPB) * CL + (threadIdx.x % CL);
     const int sl = threadIdx.x / CL;
     const float* src = ws + (long)combo * nsplit * kSlab + q * 4;
@@ -843,6 +859,11 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
 #endif
 
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int gi = 0;                                   // layer of a grouped launch (block-uniform)
+    if (p.ngroups > 1) {
+        gi = bid / p.group_blocks;
+        bid -= gi * p.group_blocks;
+    }
     int split;
     if (p.split_fastest) {
         split = bid % p.nsplit;
@@ -857,8 +878,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
     // (pairimg: t0 / t1 count IMAGES; the two halves of a stage work on the same sub-patch position of two images)
     const int nstages = p.pairimg ? ((t1 - t0 + 1) >> 1) * p.PPI : (t1 - t0 + 1) >> 1;
 
-    const bf16* __restrict__ x = p.x + ct * 64;
-    const bf16* __restrict__ dy = p.dy + kt * 64;
+    const bf16* __restrict__ x = (gi == 0 ? p.x : p.xg[gi - 1]) + ct * 64;
+    const bf16* __restrict__ dy = (gi == 0 ? p.dy : p.dyg[gi - 1]) + kt * 64;
 
     // ---- staging constants (per DMA piece `it` of this wave): piece idx = wave + 8 it; pieces [q][x: XP | dy: DP] ----
     // row bit i = image row (sub-patch origin) + i - 1, column bit 12 + i = image column origin + i - 1
@@ -1146,7 +1167,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
 
     if (p.pairimg) return;
     WGP33_MARK(5)
-    if (!(WGP33_DBG & 1)) wgrad32_epilogue(acc, p, smem, wave, lane, half, kg, cg, kt, ct, split);
+    // (grouped launch: the slab index of layer gi = that of layer 0 + gi * combos * nsplit, i.e. kt + gi * nkt)
+    if (!(WGP33_DBG & 1)) wgrad32_epilogue(acc, p, smem, wave, lane, half, kg, cg, kt + gi * p.nkt, ct, split);
     else {
 #pragma unroll
         for (int t = 0; t < 9; ++t) asm volatile("" ::"v"(acc[t]));
@@ -1186,7 +1208,8 @@ static bool wgp_tall7() {
     return t != 0;
 }
 
-static PatchGeom patch_geom(const WgradParams& w) {
+// ngroup > 1: geometry of ONE layer of a grouped launch (the layers share the 256 CUs)
+static PatchGeom patch_geom(const WgradParams& w, int ngroup = 1) {
     PatchGeom g{};
     // the v2 / v3 kernels address x and dy with 32-bit BYTE offsets through buffer resources (signed arithmetic, range
     // check against num_records): elements < 2^30; the v1 kernel indexes elements with 32-bit ints: < 2^31
@@ -1233,6 +1256,7 @@ static PatchGeom patch_geom(const WgradParams& w) {
     static const int target_blocks = getenv("PRIMIA_WGP_BLOCKS") ? atoi(getenv("PRIMIA_WGP_BLOCKS")) : 0;
     const int target = target_blocks ? target_blocks : 256;
     long want = (target + g.combos - 1) / g.combos;
+    if (ngroup > 1) want = target / ((long)ngroup * g.combos);      // all layers' blocks in ONE round
     if (want < 1) want = 1;
     long per = (g.total + want - 1) / want;
     per = (per + 1) & ~1L;
@@ -1275,6 +1299,8 @@ static void fill_patch_params(PatchParams& p, const WgradParams& w, const PatchG
     p.ws = store ? w.ws : nullptr;
     p.pairimg = pairimg_mode(w, g) ? 1 : 0;
     p.nimg = w.N;
+    p.ngroups = 1;
+    p.group_blocks = 0;
 }
 
 template <int SW, int SH, int STAGES = 3>
@@ -1296,11 +1322,11 @@ static int launch_patch33(const WgradParams& w, const PatchGeom& g, hipStream_t 
     if (p.ws) {
         const int ns = g.nsplit;
         if (ns >= 64)
-            wgrad_patch32_reduce_kernel<16><<<g.combos * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+            wgrad_patch32_reduce_kernel<16><<<g.combos * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, ReduceGroup{});
         else if (ns >= 8)
-            wgrad_patch32_reduce_kernel<4><<<g.combos * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+            wgrad_patch32_reduce_kernel<4><<<g.combos * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, ReduceGroup{});
         else
-            wgrad_patch32_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+            wgrad_patch32_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, ReduceGroup{});
     }
     return launch_status();
 }
@@ -1324,6 +1350,8 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
     p.debug_skip_epilogue = noepi;
     p.pairimg = 0;
     p.nimg = w.N;
+    p.ngroups = 1;
+    p.group_blocks = 0;
 
     const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
     p.ws = store ? w.ws : nullptr;
@@ -1345,11 +1373,11 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
         if (store) {
             const int ns = g.nsplit;
             if (ns >= 64)
-                wgrad_patch32_reduce_kernel<16><<<g.combos * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+                wgrad_patch32_reduce_kernel<16><<<g.combos * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, ReduceGroup{});
             else if (ns >= 8)
-                wgrad_patch32_reduce_kernel<4><<<g.combos * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+                wgrad_patch32_reduce_kernel<4><<<g.combos * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, ReduceGroup{});
             else
-                wgrad_patch32_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
+                wgrad_patch32_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, ReduceGroup{});
         }
         return launch_status();
     }
@@ -1372,6 +1400,77 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
         else
             wgrad_patch_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
     }
+    return launch_status();
+}
+
+// ---- grouped launch: up to four layers of ONE shape in one launch of conv_wgrad_patch33_kernel<8, 8> -------------------
+// A call of this kernel carries ~25-29 us that do not shrink with the work (launch, lane constants, first DMA round trip,
+// the halves' meeting + slab store, the reduce launch: profiles/r03_wgp33_phase_profile.txt) next to 45-55 us of main
+// loop; with n layers the blocks split n ways — each block walks n times as many sub-patches behind ONE such cost, and
+// each layer writes 1/n of the slabs.  Weight gradients are leaves of the backward graph and the layers of a ResNet
+// stage share a shape, so the caller may hold a layer's (x, dy) back until its siblings' are ready.
+// Preferred group size for `count` layers of this shape: the largest n <= min(count, 4) whose blocks fill >= 90 % of the
+// CUs in one round (0: shape not served).
+int wgrad_patch_group_size(const WgradParams& w, int count) {
+    static const bool off = getenv("PRIMIA_WGP_GROUP") && getenv("PRIMIA_WGP_GROUP")[0] == '0';
+    if (off || !use_v3() || w.persample) return 0;
+    const PatchGeom g1 = patch_geom(w);
+    if (!g1.ok || g1.SW != 8 || g1.SH != 8) return 0;
+    for (int n = count < 4 ? count : 4; n >= 2; --n) {
+        const PatchGeom g = patch_geom(w, n);
+        const long blocks = (long)n * g.combos * g.nsplit;
+        if (blocks <= 256 && blocks * 10 >= 256 * 9) return n;
+    }
+    return 1;
+}
+
+size_t wgrad_patch_group_ws_bytes(const WgradParams& w, int n) {
+    if (n < 2 || n > 4 || wgrad_patch_group_size(w, n) < n) return 0;
+    const PatchGeom g = patch_geom(w, n);
+    return (size_t)n * g.combos * g.nsplit * kSlab * sizeof(float);
+}
+
+// ws[0 .. n): the layers (same N, H, W, C, K; 3 x 3 / stride 1); the workspace of layer 0 is the group's
+int wgrad_patch_group_dispatch(const WgradParams* ws_, int n, hipStream_t st) {
+    const WgradParams& w = ws_[0];
+    const size_t need = wgrad_patch_group_ws_bytes(w, n);
+    if (!need || !w.ws || w.ws_bytes < need) return PRIMIA_ERR_UNSUPPORTED;
+    for (int i = 0; i < n; ++i)
+        if (!ws_[i].x || !ws_[i].dy || !ws_[i].dw || ws_[i].N != w.N || ws_[i].H != w.H || ws_[i].W != w.W ||
+            ws_[i].C != w.C || ws_[i].K != w.K || ws_[i].R != 3 || ws_[i].S != 3 || ws_[i].stride != 1 || ws_[i].pad != 1)
+            return PRIMIA_ERR_ARG;
+    const PatchGeom g = patch_geom(w, n);
+    PatchParams p;
+    WgradParams w0 = w;
+    w0.ws_bytes = (size_t)g.combos * g.nsplit * kSlab * sizeof(float);   // (fill_patch_params checks one layer's share)
+    fill_patch_params(p, w0, g);
+    p.ws = w.ws;
+    p.pairimg = 0;
+    p.ngroups = n;
+    p.group_blocks = g.combos * g.nsplit;
+    ReduceGroup rg{};
+    rg.combos = g.combos;
+    for (int i = 1; i < n; ++i) {
+        p.xg[i - 1] = (const bf16*)ws_[i].x;
+        p.dyg[i - 1] = (const bf16*)ws_[i].dy;
+        rg.dwg[i - 1] = ws_[i].dw;
+    }
+    const size_t lds = (size_t)kSlab * 4;
+    auto kern = conv_wgrad_patch33_kernel<8, 8, 3>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    kern<<<(unsigned)(n * p.group_blocks), 512, lds, st>>>(p);
+    const int ns = g.nsplit, all = n * g.combos;
+    if (ns >= 64)
+        wgrad_patch32_reduce_kernel<16><<<all * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, rg);
+    else if (ns >= 8)
+        wgrad_patch32_reduce_kernel<4><<<all * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, rg);
+    else
+        wgrad_patch32_reduce_kernel<1><<<all * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, rg);
     return launch_status();
 }
 

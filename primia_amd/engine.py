@@ -134,7 +134,25 @@ class ResNet18Engine:
                                                       self.convs[blk.down.name].desc, self.dt)
         # workspace of the atomic-free weight-gradient path (primia_conv2d_wgrad_ws): the layers run one after
         # the other on one stream, so they share one buffer sized for the largest (38 MB at batch 256)
-        ws_bytes = max(max(ws_need.values()), self._stem_ws_bytes, max(list(self._pair_ws.values()) + [0]))
+        # several layers of one shape in ONE weight-gradient launch (primia_conv2d_wgrad_group_ws): the 3x3 / stride-1
+        # layers of a stage share a shape; a layer's (x, dy) is held back until its siblings' are ready
+        self._wg_group = {}        # conv name -> (shape key, preferred group size)
+        self._wg_held = {}         # shape key -> [(name, x, dy), ...]
+        group_ws = [0]
+        if dtype == torch.bfloat16 and self.wgrad_group:
+            shapes = {}
+            for c in self.spec.convs:
+                d = self.convs[c.name].desc
+                if d.R == 3 and d.stride == 1 and c.name != stem.name:
+                    shapes.setdefault((d.H, d.W, d.C, d.K), []).append(c.name)
+            for key, names in shapes.items():
+                d = self.convs[names[0]].desc
+                n = query("primia_conv_wgrad_group_size", d, len(names), self.dt)
+                if n >= 2:
+                    for nm in names:
+                        self._wg_group[nm] = (key, n)
+                    group_ws.append(query("primia_conv_wgrad_group_ws_bytes", d, n, self.dt))
+        ws_bytes = max(max(ws_need.values()), self._stem_ws_bytes, max(list(self._pair_ws.values()) + [0]), max(group_ws))
         self.wgrad_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev) if ws_bytes > 0 else None
         self.wgrad_ws_bytes = ws_bytes
 
@@ -582,6 +600,7 @@ class ResNet18Engine:
     wgrad_pair = os.environ.get("PRIMIA_WGRAD_PAIR", "1") != "0"
     gn_relu_recompute = os.environ.get("PRIMIA_GN_RELU_RECOMPUTE", "1") != "0"
     gn_stem_fused = os.environ.get("PRIMIA_GN_STEM_FUSED", "1") != "0"
+    wgrad_group = os.environ.get("PRIMIA_WGRAD_GROUP", "1") != "0"
 
     def _wgrad_transition(self, blk, x, dy1, dyd):
         """conv1 and the downsample of a transition block: one launch where the library serves the pair."""
@@ -599,6 +618,13 @@ class ResNet18Engine:
         c = self.convs[name]
         if self.dp is not None:  # DP-SGD: weight gradients wait for the per-sample clip factors
             self.dp["wgrads"].append((name, x, dy))
+            return
+        if self.wgrad_ws is not None and name in self._wg_group:
+            key, n = self._wg_group[name]
+            held = self._wg_held.setdefault(key, [])
+            held.append((name, x, dy))
+            if len(held) == n:
+                self._flush_wgrad_group(key)
             return
         if self.wgrad_ws is not None:   # (one workspace: the weight gradients stay in order on whichever stream)
             self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call(
@@ -793,7 +819,29 @@ class ResNet18Engine:
         if self.dp is None:
             self._finalize_wgrads()
 
+    def _flush_wgrad_group(self, key):
+        held = self._wg_held.pop(key, [])
+        if len(held) >= 2:
+            c = self.convs[held[0][0]]
+            args = []
+            for i in range(4):
+                if i < len(held):
+                    nm, x, dy = held[i]
+                    args += [x, dy, self.convs[nm].acc]
+                else:
+                    args += [None, None, None]
+            self._on_wgrad_stream(lambda: self._timed(
+                "wgrad", c, lambda: call("primia_conv2d_wgrad_group_ws", c.desc, len(held), *args, self.wgrad_ws,
+                                         self.wgrad_ws_bytes, self.dt), extra_macs=(len(held) - 1) * self._macs(c)))
+        else:
+            for nm, x, dy in held:
+                c = self.convs[nm]
+                self._on_wgrad_stream(lambda c=c, x=x, dy=dy: self._timed("wgrad", c, lambda: call(
+                    "primia_conv2d_wgrad_ws", c.desc, x, dy, c.acc, self.wgrad_ws, self.wgrad_ws_bytes, self.dt)))
+
     def _finalize_wgrads(self):
+        for key in list(self._wg_held):      # (groups that never filled: odd layer counts)
+            self._flush_wgrad_group(key)
         self._join_wgrad_stream()
         m = self._many_args()
         call("primia_conv_wgrad_finalize_many", m["descs"], m["creal"], m["acc"], m["gw"], m["n"])

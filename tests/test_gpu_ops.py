@@ -781,6 +781,44 @@ def test_transition_block_weight_gradients_in_one_launch(cuda, N, H, C, K):
     assert relerr(g1, w1r.grad) < 1e-4 and relerr(gd, wdr.grad) < 1e-4
 
 
+@pytest.mark.parametrize("N,H,C,count", [(32, 56, 64, 4), (24, 28, 128, 3), (16, 14, 256, 3), (40, 7, 512, 3), (3, 16, 64, 2)])
+def test_same_shape_layers_share_one_weight_gradient_launch(cuda, N, H, C, count):
+    """primia_conv2d_wgrad_group_ws: n layers of one 3x3 / stride-1 shape in one launch of the patch kernel (blocks split n
+    ways, each layer's slabs reduced in split order) against n single calls — the same products, another grouping of
+    the ordered sums — and every layer bit-identical run after run."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    d = ConvDesc.make(N, H, H, C, C, 3, 3, 1, 1)
+    n = query("primia_conv_wgrad_group_size", d, count, dt)
+    assert 0 <= n <= min(count, 4)
+    if n < 2:
+        pytest.skip(f"group size {n} for this shape and batch")
+    need = query("primia_conv_wgrad_group_ws_bytes", d, n, dt)
+    assert need > 0
+    g = torch.Generator().manual_seed(H + C)
+    xs = [to_nhwc(rnd(torch.randn(N, C, H, H, generator=g).relu(), dtype), dtype, cuda) for _ in range(n)]
+    dys = [to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * 1e-2, dtype), dtype, cuda) for _ in range(n)]
+    ne = query("primia_conv_wfwd_elems", d)
+
+    def grouped():
+        ws = torch.full((need // 4,), float("nan"), device=cuda)
+        accs = [torch.full((ne,), float("nan"), device=cuda) for _ in range(n)]
+        args = []
+        for i in range(4):
+            args += [xs[i], dys[i], accs[i]] if i < n else [None, None, None]
+        call("primia_conv2d_wgrad_group_ws", d, n, *args, ws, need, dt)
+        return accs
+
+    a, b = grouped(), grouped()
+    s1 = query("primia_conv_wgrad_ws_bytes", d, dt)
+    w1 = torch.empty(max(s1, 16) // 4, device=cuda)
+    for i in range(n):
+        assert torch.equal(a[i], b[i])
+        single = torch.zeros(ne, device=cuda)
+        call("primia_conv2d_wgrad_ws", d, xs[i], dys[i], single, w1, s1, dt)
+        assert relerr(a[i], single) < 2e-6, i
+
+
 @pytest.mark.parametrize("N,S", [(2, 64), (75, 64), (3, 96), (5, 32)])
 def test_stem_backward_fused_is_bit_identical_to_the_chain(cuda, N, S):
     """primia_stem_bwd_fused (bn1 <- relu <- maxpool backward apply inside conv1's weight-gradient kernel, dy never

@@ -29,6 +29,7 @@ static float gauss() {
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 256;
     const int dense = argc > 2 ? atoi(argv[2]) : 0;
+    const int group = argc > 3 ? atoi(argv[3]) : 1;      // > 1: that many layers of the shape in ONE launch
     struct Shape { const char* name; int H, C; } shapes[] = {{"l1.3x3", 56, 64}, {"l2.3x3", 28, 128}, {"l3.3x3", 14, 256}, {"l4.3x3", 7, 512}};
     for (auto& sh : shapes) {
         const int H = sh.H, C = sh.C, K = sh.C;
@@ -46,10 +47,12 @@ int main(int argc, char** argv) {
         p.x = x; p.dy = dy; p.dw = dw;
         p.N = N; p.H = H; p.W = H; p.C = C; p.K = K; p.R = 3; p.S = 3; p.stride = 1; p.pad = 1; p.Ho = H; p.Wo = H;
         p.klen = 9 * C; p.Md = M; p.ntaps = 9;
-        const size_t wsb = wgrad_patch_ws_bytes(p);
+        int ng = group > 1 ? wgrad_patch_group_size(p, group) : 1;
+        const size_t wsb = ng > 1 ? wgrad_patch_group_ws_bytes(p, ng) : wgrad_patch_ws_bytes(p);
         hipMalloc(&ws, wsb);
         p.ws = ws; p.ws_bytes = wsb;
-        auto launch = [&]() { return wgrad_patch_dispatch(p, 0); };
+        WgradParams pg[4] = {p, p, p, p};
+        auto launch = [&]() { return ng > 1 ? wgrad_patch_group_dispatch(pg, ng, 0) : wgrad_patch_dispatch(p, 0); };
         if (launch() != 0) { printf("%s: not served\n", sh.name); continue; }
         for (int i = 0; i < 3; ++i) launch();
         hipDeviceSynchronize();
@@ -60,9 +63,9 @@ int main(int argc, char** argv) {
         for (int i = 0; i < reps; ++i) launch();
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        const double us = ms * 1e3 / reps, tf = 2.0 * M * K * C * 9 / (us * 1e-6) / 1e12;
-        printf("%s N=%d kernel+reduce: %7.1f us  %6.0f TF/s  (DBG=%d, %s data)\n", sh.name, N, us, tf, (int)WGP33_DBG,
-               dense ? "dense" : "relu-like");
+        const double us = ms * 1e3 / reps, tf = 2.0 * ng * M * K * C * 9 / (us * 1e-6) / 1e12;
+        printf("%s N=%d kernel+reduce: %7.1f us  %6.0f TF/s  (DBG=%d, %s data, %d layer(s) per launch: %.1f us per layer)\n",
+               sh.name, N, us, tf, (int)WGP33_DBG, dense ? "dense" : "relu-like", ng, us / ng);
 #ifdef WGP33_PROF
         {
             const PatchGeom g = patch_geom(p);
