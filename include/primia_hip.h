@@ -203,6 +203,16 @@ int primia_conv2d_wgrad_group_ws(const primia_conv_desc* d, int n, const void* x
                                  const void* x1, const void* dy1, float* dw_acc1, const void* x2, const void* dy2,
                                  float* dw_acc2, const void* x3, const void* dy3, float* dw_acc3, void* workspace,
                                  int64_t workspace_bytes, int dtype, primia_stream_t stream);
+
+/* ... and EVERY 3x3 / stride-1 layer of the network in one launch at the end of the backward pass (all of them are leaves):
+ * ~40 blocks per layer instead of 256, each behind one prologue / epilogue, the slab traffic of the split reduction
+ * shrinking alike.  _multi_ws_bytes: this layer's share of the workspace (0: not served, use its own call);
+ * _multi_ws: HOST arrays of n <= 16 descriptors, operands and accumulators; the workspace holds the shares of all n
+ * layers.  Results per layer as primia_conv2d_wgrad_ws up to the grouping of the ordered sums; deterministic. */
+int64_t primia_conv_wgrad_multi_ws_bytes(const primia_conv_desc* d, int dtype);
+int primia_conv2d_wgrad_multi_ws(int n, const primia_conv_desc* const* descs, const void* const* xs,
+                                 const void* const* dys, float* const* dw_accs, void* workspace,
+                                 int64_t workspace_bytes, int dtype, primia_stream_t stream);
 /* Per-sample weight gradients for DP-SGD: dw_ps [N][K][klen] (fwd layout, fp32, zeroed by the caller),
  * image n's gradient in slab n. */
 int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,

@@ -548,6 +548,34 @@ extern "C" int primia_conv2d_wgrad_group_ws(const primia_conv_desc* d, int n, co
     return wgrad_patch_group_dispatch(ps, n, (hipStream_t)stream);
 }
 
+// Every 3x3 / stride-1 layer of the network in one launch.  _multi_ws_bytes: this layer's share of the workspace (0: the
+// layer is not served — use its own call); _multi_ws: host arrays of n descriptors / operands / accumulators.
+extern "C" int64_t primia_conv_wgrad_multi_ws_bytes(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    WgradParams p;
+    if (!d || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
+    static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    if (dtype != PRIMIA_BF16 || g.stem || force) return 0;
+    p.persample = 0;
+    return (int64_t)wgrad_patch_multi_ws_bytes(p);
+}
+
+extern "C" int primia_conv2d_wgrad_multi_ws(int n, const primia_conv_desc* const* descs, const void* const* xs,
+                                            const void* const* dys, float* const* dw_accs, void* ws, int64_t ws_bytes,
+                                            int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(n >= 1 && n <= 16 && descs && xs && dys && dw_accs && ws && ws_bytes > 0);
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
+    WgradParams ps[16];
+    for (int i = 0; i < n; ++i) {
+        ConvGeom g;
+        PRIMIA_REQUIRE(descs[i] && xs[i] && dys[i] && dw_accs[i] && fill_wgrad_params(descs[i], ps[i], g));
+        if (g.stem) return PRIMIA_ERR_UNSUPPORTED;
+        ps[i].x = xs[i]; ps[i].dy = dys[i]; ps[i].dw = dw_accs[i];
+        ps[i].persample = 0; ps[i].sqnorm = nullptr; ps[i].ws = nullptr; ps[i].ws_bytes = 0;
+    }
+    return wgrad_patch_multi_dispatch(ps, n, (float*)ws, (size_t)ws_bytes, (hipStream_t)stream);
+}
+
 extern "C" int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,
                                              float* dw_ps, int dtype, primia_stream_t stream) {
     return conv2d_wgrad_impl(d, x, dy, dw_ps, 1, dtype, stream);

@@ -755,19 +755,19 @@ struct ReduceGroup {        // grouped launch: dw of layers 1..3 and the combos 
 };
 
 template <int SL>
-__global__ __launch_bounds__(256) void wgrad_patch32_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                                   int nsplit, int nct, int C, int klen, ReduceGroup rg) {
+__device__ __forceinline__ void patch32_reduce_body(const float* __restrict__ ws, float* __restrict__ dw, int nsplit, int nct,
+                                                    int C, int klen, ReduceGroup rg, int blk) {
     constexpr int CL = 256 / SL;
     constexpr int CPB = kSlab / 4 / CL;
     __shared__ f32x4 red[SL][CL];
-    int combo = blockIdx.x / CPB;
+    int combo = blk / CPB;
     if (rg.combos > 0) {        // slabs: [layer][combo][split]
         const int gi = combo / rg.combos;
         combo -= gi * rg.combos;
         ws += (long)gi * rg.combos * nsplit * kSlab;
         if (gi > 0) dw = rg.dwg[gi - 1];
     }
-    const int q = (blockIdx.x % CPB) * CL + (threadIdx.x % CL);
+    const int q = (blk % CPB) * CL + (threadIdx.x % CL);
     const int sl = threadIdx.x / CL;
     const float* src = ws + (long)combo * nsplit * kSlab + q * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
@@ -794,6 +794,29 @@ __global__ __launch_bounds__(256) void wgrad_patch32_reduce_kernel(const float* 
     const int e = t * C + ct * 64 + 32 * (wave & 1) + (lane & 31);
 #pragma unroll
     for (int j = 0; j < 4; ++j) dw[(long)(k0 + j) * klen + e] = a[j];
+}
+
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_patch32_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                                   int nsplit, int nct, int C, int klen, ReduceGroup rg) {
+    patch32_reduce_body<SL>(ws, dw, nsplit, nct, C, klen, rg, blockIdx.x);
+}
+
+// ... of many layers in one launch (conv_wgrad_patch33_multi_kernel): block b -> layer l, its block b - first[l]
+struct ReduceMulti {
+    int n;
+    int first[17];
+    const float* ws[16];
+    float* dw[16];
+    int nsplit[16], nct[16], C[16], klen[16];
+};
+
+__global__ __launch_bounds__(256) void wgrad_patch32_reduce_multi_kernel(ReduceMulti rm) {
+    const int b = blockIdx.x;
+    int l = 0;
+#pragma unroll 1
+    while (l + 1 < rm.n && b >= rm.first[l + 1]) ++l;
+    patch32_reduce_body<4>(rm.ws[l], rm.dw[l], rm.nsplit[l], rm.nct[l], rm.C[l], rm.klen[l], ReduceGroup{}, b - rm.first[l]);
 }
 
 // =====================================================================================================================
@@ -835,7 +858,7 @@ __device__ unsigned long long* wgp33_prof_buffer_dev;
 #define WGP33_MARK(slot)
 #endif
 template <int SW, int SH, int STAGES>
-__global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) {
+__device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
     constexpr int FR = SW == 8 ? 2 : 1;         // rows of a k-step fragment
     constexpr int NK = SH / FR;                 // k-steps per sub-patch
     constexpr int HSX = SW == 8 ? 10 : 20;      // x row stride in slots
@@ -858,7 +881,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
     unsigned long long prof_t[6] = {0, 0, 0, 0, 0, 0}, prof_prev = clock64();   // [5] = everything before the main loop ends... see marks
 #endif
 
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int bid = bid_in;
     int gi = 0;                                   // layer of a grouped launch (block-uniform)
     if (p.ngroups > 1) {
         gi = bid / p.group_blocks;
@@ -1182,6 +1205,31 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
 #endif
 }
 
+template <int SW, int SH, int STAGES>
+__global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) {
+    patch33_body<SW, SH, STAGES>(p, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Many layers of DIFFERENT shapes in one launch: block b belongs to the layer l with first[l] <= b < first[l + 1] and is
+// its block b - first[l]; every layer has its own parameters (operands, geometry, slab region).  See
+// wgrad_patch_multi_dispatch.
+constexpr int kMultiMax = 16;
+struct MultiParams {
+    int n;
+    int first[kMultiMax + 1];
+    PatchParams layer[kMultiMax];
+};
+
+__global__ __launch_bounds__(512) void conv_wgrad_patch33_multi_kernel(MultiParams mp) {
+    const int b = blockIdx.x;
+    int l = 0;
+#pragma unroll 1
+    while (l + 1 < mp.n && b >= mp.first[l + 1]) ++l;
+    l = __builtin_amdgcn_readfirstlane(l);
+    const int nb = mp.first[l + 1] - mp.first[l];
+    patch33_body<8, 8, 3>(mp.layer[l], xcd_remap(b - mp.first[l], nb));
+}
+
 struct PatchGeom {
     bool ok, wide;
     int SW, SH;        // v3: sub-patch shape
@@ -1471,6 +1519,90 @@ int wgrad_patch_group_dispatch(const WgradParams* ws_, int n, hipStream_t st) {
         wgrad_patch32_reduce_kernel<4><<<all * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, rg);
     else
         wgrad_patch32_reduce_kernel<1><<<all * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, rg);
+    return launch_status();
+}
+
+// ---- every 3x3 / stride-1 layer of the network in ONE launch ------------------------------------------------------------
+// The grouped launch above amortises a call's fixed cost over the layers of one stage; weight gradients being leaves, ALL
+// of them can wait for the end of the backward pass and share one launch: ~T blocks per layer (each walks 256 / T times
+// the sub-patches of the one-launch-per-layer form behind one prologue / epilogue, and the slab traffic shrinks alike),
+// blocks of the layers with the most work per block first.
+static int multi_target() {
+    static const int t = getenv("PRIMIA_WGP_MULTI_T") ? atoi(getenv("PRIMIA_WGP_MULTI_T")) : 40;
+    return t < 1 ? 1 : t;
+}
+static PatchGeom multi_geom(const WgradParams& w) {
+    PatchGeom g = patch_geom(w);
+    if (!g.ok || g.SW != 8 || g.SH != 8 || w.persample) { g.ok = false; return g; }
+    long want = (multi_target() + g.combos / 2) / g.combos;
+    if (want < 1) want = 1;
+    long per = (g.total + want - 1) / want;
+    per = (per + 1) & ~1L;
+    if (per < 2) per = 2;
+    g.per_block = (int)per;
+    g.nsplit = (int)((g.total + per - 1) / per);
+    return g;
+}
+
+bool wgrad_patch_multi_ok(const WgradParams& w) {
+    static const bool off = getenv("PRIMIA_WGP_MULTI") && getenv("PRIMIA_WGP_MULTI")[0] == '0';
+    return !off && use_v3() && multi_geom(w).ok;
+}
+
+// workspace share of one layer (the layers' slab regions follow one another in call order)
+size_t wgrad_patch_multi_ws_bytes(const WgradParams& w) {
+    const PatchGeom g = multi_geom(w);
+    return g.ok ? (size_t)g.combos * g.nsplit * kSlab * sizeof(float) : 0;
+}
+
+int wgrad_patch_multi_dispatch(const WgradParams* ws_, int n, float* wsp, size_t ws_bytes, hipStream_t st) {
+    if (n < 1 || n > kMultiMax || !wsp) return PRIMIA_ERR_UNSUPPORTED;
+    PatchGeom gs[kMultiMax];
+    size_t need = 0;
+    for (int i = 0; i < n; ++i) {
+        if (!wgrad_patch_multi_ok(ws_[i]) || !ws_[i].x || !ws_[i].dy || !ws_[i].dw) return PRIMIA_ERR_UNSUPPORTED;
+        gs[i] = multi_geom(ws_[i]);
+        need += (size_t)gs[i].combos * gs[i].nsplit * kSlab * sizeof(float);
+    }
+    if (ws_bytes < need) return PRIMIA_ERR_WORKSPACE;
+    // layers with the most sub-patches per block first (the hardware hands out blocks in index order)
+    int order[kMultiMax];
+    for (int i = 0; i < n; ++i) order[i] = i;
+    for (int i = 1; i < n; ++i)
+        for (int j = i; j > 0 && gs[order[j]].per_block > gs[order[j - 1]].per_block; --j) {
+            const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
+        }
+    MultiParams mp{};
+    ReduceMulti rm{};
+    mp.n = rm.n = n;
+    float* slab = wsp;
+    int blocks = 0, rblocks = 0;
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k];
+        WgradParams w = ws_[i];
+        w.ws = slab;
+        w.ws_bytes = (size_t)gs[i].combos * gs[i].nsplit * kSlab * sizeof(float);
+        fill_patch_params(mp.layer[k], w, gs[i]);
+        mp.layer[k].pairimg = 0;
+        mp.first[k] = blocks;
+        blocks += gs[i].combos * gs[i].nsplit;
+        rm.first[k] = rblocks;
+        rblocks += gs[i].combos * (kSlab / 4 / 64);
+        rm.ws[k] = slab; rm.dw[k] = w.dw; rm.nsplit[k] = gs[i].nsplit; rm.nct[k] = w.C / 64; rm.C[k] = w.C; rm.klen[k] = w.klen;
+        slab += (size_t)gs[i].combos * gs[i].nsplit * kSlab;
+    }
+    mp.first[n] = blocks;
+    rm.first[n] = rblocks;
+    const size_t lds = (size_t)kSlab * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void*)conv_wgrad_patch33_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
+    }
+    conv_wgrad_patch33_multi_kernel<<<(unsigned)blocks, 512, lds, st>>>(mp);
+    wgrad_patch32_reduce_multi_kernel<<<(unsigned)rblocks, 256, 0, st>>>(rm);
     return launch_status();
 }
 

@@ -152,6 +152,20 @@ class ResNet18Engine:
                     for nm in names:
                         self._wg_group[nm] = (key, n)
                     group_ws.append(query("primia_conv_wgrad_group_ws_bytes", d, n, self.dt))
+        # ... or EVERY such layer of the network in one launch at the end of the backward pass
+        # (primia_conv2d_wgrad_multi_ws); the workspace then holds the slab shares of all of them
+        self._wg_multi = {}        # conv name -> share of the workspace
+        self._wg_multi_held = []
+        if dtype == torch.bfloat16 and self.wgrad_multi:
+            for c in self.spec.convs:
+                d = self.convs[c.name].desc
+                if d.R == 3 and d.stride == 1 and c.name != stem.name:
+                    share = query("primia_conv_wgrad_multi_ws_bytes", d, self.dt)
+                    if share > 0:
+                        self._wg_multi[c.name] = share
+            if len(self._wg_multi) < 2:
+                self._wg_multi = {}
+        group_ws.append(sum(self._wg_multi.values()))
         ws_bytes = max(max(ws_need.values()), self._stem_ws_bytes, max(list(self._pair_ws.values()) + [0]), max(group_ws))
         self.wgrad_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev) if ws_bytes > 0 else None
         self.wgrad_ws_bytes = ws_bytes
@@ -601,6 +615,9 @@ class ResNet18Engine:
     gn_relu_recompute = os.environ.get("PRIMIA_GN_RELU_RECOMPUTE", "1") != "0"
     gn_stem_fused = os.environ.get("PRIMIA_GN_STEM_FUSED", "1") != "0"
     wgrad_group = os.environ.get("PRIMIA_WGRAD_GROUP", "1") != "0"
+    # (all layers at the end of the backward pass: measured no better than the per-stage groups — 5.16 vs 5.14 ms; by then
+    # every operand comes from HBM, while a stage's group still finds its newest dy in the Infinity Cache.  Opt-in.)
+    wgrad_multi = os.environ.get("PRIMIA_WGRAD_MULTI", "0") != "0"
 
     def _wgrad_transition(self, blk, x, dy1, dyd):
         """conv1 and the downsample of a transition block: one launch where the library serves the pair."""
@@ -618,6 +635,9 @@ class ResNet18Engine:
         c = self.convs[name]
         if self.dp is not None:  # DP-SGD: weight gradients wait for the per-sample clip factors
             self.dp["wgrads"].append((name, x, dy))
+            return
+        if self.wgrad_ws is not None and name in self._wg_multi:
+            self._wg_multi_held.append((name, x, dy))
             return
         if self.wgrad_ws is not None and name in self._wg_group:
             key, n = self._wg_group[name]
@@ -839,7 +859,30 @@ class ResNet18Engine:
                 self._on_wgrad_stream(lambda c=c, x=x, dy=dy: self._timed("wgrad", c, lambda: call(
                     "primia_conv2d_wgrad_ws", c.desc, x, dy, c.acc, self.wgrad_ws, self.wgrad_ws_bytes, self.dt)))
 
+    def _flush_wgrad_multi(self):
+        held, self._wg_multi_held = self._wg_multi_held, []
+        if not held:
+            return
+        import ctypes
+        key = tuple((nm, x.data_ptr(), dy.data_ptr()) for nm, x, dy in held)
+        cached = getattr(self, "_wg_multi_args", None)
+        if cached is None or cached[0] != key:     # (the engine's buffers never move: built once)
+            n = len(held)
+            arr = ctypes.c_void_p * n
+            descs = arr(*[ctypes.addressof(self.convs[nm].desc) for nm, _, _ in held])
+            xs = arr(*[x.data_ptr() for _, x, _ in held])
+            dys = arr(*[dy.data_ptr() for _, _, dy in held])
+            accs = arr(*[self.convs[nm].acc.data_ptr() for nm, _, _ in held])
+            cached = self._wg_multi_args = (key, n, descs, xs, dys, accs)
+        _, n, descs, xs, dys, accs = cached
+        c = self.convs[held[0][0]]
+        self._on_wgrad_stream(lambda: self._timed(
+            "wgrad", c, lambda: call("primia_conv2d_wgrad_multi_ws", n, descs, xs, dys, accs, self.wgrad_ws,
+                                     self.wgrad_ws_bytes, self.dt),
+            extra_macs=sum(self._macs(self.convs[nm]) for nm, _, _ in held[1:])))
+
     def _finalize_wgrads(self):
+        self._flush_wgrad_multi()
         for key in list(self._wg_held):      # (groups that never filled: odd layer counts)
             self._flush_wgrad_group(key)
         self._join_wgrad_stream()

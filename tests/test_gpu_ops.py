@@ -1087,3 +1087,40 @@ def test_batchnorm_forward_pair_is_bit_identical(cuda, dtype, N, H, C):
         outs.append((z, mask, sm2, si2, smd, sid, rm2, rv2, rmd, rvd))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+def test_all_stride1_layers_share_one_weight_gradient_launch(cuda):
+    """primia_conv2d_wgrad_multi_ws: layers of DIFFERENT shapes in one launch (block ranges per layer, each layer its own
+    slab region and ordered reduce) against single calls, and bit-identical run after run."""
+    import ctypes
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    N = 16
+    shapes = [(56, 64), (56, 64), (28, 128), (14, 256), (14, 256), (7, 512)]
+    descs = [ConvDesc.make(N, H, H, C, C, 3, 3, 1, 1) for H, C in shapes]
+    shares = [query("primia_conv_wgrad_multi_ws_bytes", d, dt) for d in descs]
+    assert all(s > 0 for s in shares)
+    g = torch.Generator().manual_seed(77)
+    xs = [to_nhwc(rnd(torch.randn(N, C, H, H, generator=g).relu(), dtype), dtype, cuda) for H, C in shapes]
+    dys = [to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * 1e-2, dtype), dtype, cuda) for H, C in shapes]
+    nes = [query("primia_conv_wfwd_elems", d) for d in descs]
+    n = len(shapes)
+    arr = ctypes.c_void_p * n
+
+    def multi():
+        ws = torch.full((sum(shares) // 4,), float("nan"), device=cuda)
+        accs = [torch.full((ne,), float("nan"), device=cuda) for ne in nes]
+        call("primia_conv2d_wgrad_multi_ws", n, arr(*[ctypes.addressof(d) for d in descs]),
+             arr(*[t.data_ptr() for t in xs]), arr(*[t.data_ptr() for t in dys]), arr(*[t.data_ptr() for t in accs]),
+             ws, sum(shares), dt)
+        torch.cuda.synchronize()
+        return accs
+
+    a, b = multi(), multi()
+    for i, d in enumerate(descs):
+        assert torch.equal(a[i], b[i])
+        s1 = query("primia_conv_wgrad_ws_bytes", d, dt)
+        w1 = torch.empty(max(s1, 16) // 4, device=cuda)
+        single = torch.zeros(nes[i], device=cuda)
+        call("primia_conv2d_wgrad_ws", d, xs[i], dys[i], single, w1, s1, dt)
+        assert relerr(a[i], single) < 2e-6, i
