@@ -961,6 +961,13 @@ class ResNet18Engine:
                 call("primia_scale_rows", dy, clip, N, dy.numel() // N, self.dt)
                 # the clipped SUM is an ordinary batched weight gradient: atomic-free kernels, and for the stem the
                 # halo kernel on the padded input (118 us instead of 444 us for the per-tap one)
+                if self.wgrad_ws is not None and name in self._wg_group:     # same-shape layers: one launch per stage
+                    key, n = self._wg_group[name]
+                    held = self._wg_held.setdefault(key, [])
+                    held.append((name, x, dy))
+                    if len(held) == n:
+                        self._flush_wgrad_group(key)
+                    continue
                 if self.wgrad_ws is None:
                     call("primia_conv2d_wgrad", c.desc, x, dy, c.acc, self.dt)
                 elif name == "conv1" and self._stem_padded:
