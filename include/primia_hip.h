@@ -136,6 +136,10 @@ int primia_conv_stat_slots(void);
  * generic kernel accumulates into primia_conv_stat_slots() zeroed slots.  Size stat_sums for this count
  * and pass it as `slots` to primia_bn_fwd_train_from_sums. */
 int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype);
+/* 1: the forward kernel of this conv WRITES its BatchNorm partial sums per tile (deterministic, nothing to zero, no
+ * statistics pass needed: primia_conv2d_fwd_stats + primia_bn_fwd_train_from_sums); 0: the generic atomic slots.  The
+ * slot count alone does not tell the two apart. */
+int primia_conv_stats_per_tile(const primia_conv_desc* d, int dtype);
 int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
                             float* stat_sums, int dtype, primia_stream_t stream);
 /* dx[N,H,W,C] = conv_transpose(dy[N,Ho,Wo,K], w).  If accumulate != 0, dx += (dx is read). */

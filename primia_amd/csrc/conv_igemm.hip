@@ -859,9 +859,13 @@ int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype) {
 
 int primia_conv_stat_slots(void) { return kStatSlots; }
 
-int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype) {
+// slots of the kernel serving this conv; *per_tile: 1 = deterministic per-tile partials WRITTEN by its write-back (nothing
+// to zero, no extra pass), 0 = the kStatSlots atomic slots
+static int conv_stat_slots_impl(const primia_conv_desc* d, int dtype, int* per_tile) {
     ConvGeom g;
+    *per_tile = 0;
     if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
+    *per_tile = 1;
     if (dtype == PRIMIA_BF16 && use_c64(g) && (long)g.N * g.H * g.W * 64 < (1L << 31)) return conv3x3_c64_grid(g.N, g.H, g.W);
     if (dtype == PRIMIA_BF16 && !use_c64(g) && lh_shape(g) && g.W <= lh_fwd_maxw()) {
         const int t2 = conv3x3_lh2_tiles_m(g.N, g.H, g.W, g.C, g.K);
@@ -871,7 +875,21 @@ int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype) {
     }
     // bf16 implicit GEMM: one partial per 128-pixel tile out of its write-back (every tile config in use has BM = 128)
     if (dtype == PRIMIA_BF16 && !g.stem && g.K % 8 == 0) return (int)(((long)g.N * g.Ho * g.Wo + 127) / 128);
+    *per_tile = 0;
     return kStatSlots;
+}
+
+int primia_conv_stat_slots_for(const primia_conv_desc* d, int dtype) {
+    int per_tile;
+    return conv_stat_slots_impl(d, dtype, &per_tile);
+}
+
+// 1: this conv's forward kernel writes the BatchNorm partial sums for free (per-tile, deterministic); 0: atomic slots.
+// (The slot COUNT does not tell: layer4's 3x3 convs at batch 256 have 64 tiles, which is also kStatSlots.)
+int primia_conv_stats_per_tile(const primia_conv_desc* d, int dtype) {
+    int per_tile;
+    const int rc = conv_stat_slots_impl(d, dtype, &per_tile);
+    return rc < 0 ? rc : per_tile;
 }
 
 int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stat_sums,

@@ -235,7 +235,7 @@ class ResNet18Engine:
         # independent of the global `fuse_stats` experiment above.
         self.free_stats = {c.name for c in self.spec.convs
                            if dtype == torch.bfloat16 and norm == "batch" and c.name != "conv1"
-                           and self.convs[c.name].stat_slots != self.stat_slots}
+                           and query("primia_conv_stats_per_tile", self.convs[c.name].desc, self.dt) == 1}
         # Experiment (PRIMIA_ATOMIC_STATS=layer3,layer4): the implicit-GEMM epilogue accumulates the batch sums with
         # atomics for the named stages only, whose separate statistics kernels are latency- rather than
         # bandwidth-bound.  Their partial slabs are the tail of stat_sums and are zeroed once per forward.
