@@ -227,6 +227,23 @@ int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, cons
  * (11 GB per step for ResNet-18 at batch 256) is never written, zeroed or re-read. */
 int primia_conv2d_wgrad_persample_sqnorm(const primia_conv_desc* d, const void* x, const void* dy,
                                          double* sqnorm, int dtype, primia_stream_t stream);
+
+/* DP-SGD where a layer's per-sample gradients are small (the stem: 64 KiB per sample; layer1's 64 -> 64 convs: 144 KiB):
+ * the norm pass KEEPS every sample's complete tile next to adding its squares, and the clipped sum  sum_n clip_n g_n  is
+ * one ordered reduce over the kept tiles weighted by the clip factors — instead of scaling the rows of dy (a read + write
+ * of the whole dy) and a second weight-gradient pass.  _slab_bytes: size of the keep buffer (0: layer not served, or its
+ * tiles exceed the budget — use primia_conv2d_wgrad_persample_sqnorm + primia_scale_rows + primia_conv2d_wgrad_ws).
+ * Replaces pytorch-dp's per-sample gradient + clip + sum for these layers (train.py:325-334). */
+int64_t primia_conv_wgrad_persample_slab_bytes(const primia_conv_desc* d, int dtype);
+int primia_conv2d_wgrad_persample_sqnorm_keep(const primia_conv_desc* d, const void* x, const void* dy, double* sqnorm,
+                                              void* slabs, int64_t slab_bytes, int dtype, primia_stream_t stream);
+int primia_conv_wgrad_clipped_sum(const primia_conv_desc* d, const void* slabs, const float* clip, float* dw_acc, int dtype,
+                                  primia_stream_t stream);
+int64_t primia_stem_conv_wgrad_persample_slab_bytes(int N, int H, int W);
+int primia_stem_conv_wgrad_persample_sqnorm_keep(const void* x_padded, const void* dy, double* sqnorm, void* slabs,
+                                                 int64_t slab_bytes, int N, int H, int W, int dtype,
+                                                 primia_stream_t stream);
+int primia_stem_conv_wgrad_clipped_sum(const void* slabs, const float* clip, float* dw_acc, int N, primia_stream_t stream);
 /* dw_oihw[K][c_real][R][S] = transpose(dw_acc) (drops padding). */
 int primia_conv_wgrad_finalize(const primia_conv_desc* d, int c_real, const float* dw_acc,
                                float* dw_oihw, primia_stream_t stream);

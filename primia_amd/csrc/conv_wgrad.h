@@ -62,7 +62,13 @@ int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, i
 size_t stem_wgrad_halo_ws_bytes(int N, int H, int W);   // 0: shape not served by the halo kernel
 bool stem_wgrad_halo_blocks(int N, int H, int W, int* total, int* per_block, int* grid);
 // dw tile (kt, tap, ct) = sum over nsplit partial tiles of ws [combo][split][BMK*BNC], in split order
+// (wgt: DP-SGD clipped sum — split s is sample s, weighted by wgt[s])
 void wgrad_tile_reduce(const float* ws, float* dw, int nsplit, int combos, int BMK, int BNC, int nkt, int nct, int C,
-                       int klen, int stem, hipStream_t st);
+                       int klen, int stem, hipStream_t st, const float* wgt = nullptr);
+// DP-SGD: the patch kernel's norm pass keeping every sample's tiles ([combo][image][slab]); bytes (0: not served / too
+// large to be worth it), the pass, and the clipped sum over the kept tiles
+size_t wgrad_patch_keep_bytes(const WgradParams& p);
+int wgrad_patch_keep_dispatch(const WgradParams& p, hipStream_t st);
+int wgrad_patch_clipped_sum(const WgradParams& p, const float* slabs, const float* clip, hipStream_t st);
 
 }  // namespace primia

@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad_tile_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                 int nsplit, int BMK, int BNC, int nkt, int nct, int C,
-                                                                int klen, int stem) {
+                                                                int klen, int stem, const float* __restrict__ wgt) {
     constexpr int CL = 256 / SL;
     __shared__ f32x4 red[SL][CL];
     const int tile4 = BMK * BNC / 4;                // float4 chunks per tile
@@ -280,7 +280,9 @@ __global__ __launch_bounds__(256) void wgrad_tile_reduce_kernel(const float* __r
     const bool live = q < tile4;
     const float* src = ws + (long)combo * nsplit * (BMK * BNC) + (live ? q : 0) * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
+    if (live && wgt) {      // DP-SGD: split s = sample s, weighted by its clip factor (same order)
+        for (int s = sl; s < nsplit; s += SL) a += *(const f32x4*)(src + (long)s * (BMK * BNC)) * wgt[s];
+    } else if (live) {
         int s = sl;
 #pragma unroll 1
         for (; s + 3 * SL < nsplit; s += 4 * SL) {
@@ -307,17 +309,17 @@ __global__ __launch_bounds__(256) void wgrad_tile_reduce_kernel(const float* __r
 }
 
 void wgrad_tile_reduce(const float* ws, float* dw, int nsplit, int combos, int BMK, int BNC, int nkt, int nct, int C,
-                       int klen, int stem, hipStream_t st) {
+                       int klen, int stem, hipStream_t st, const float* wgt) {
     const int tile4 = BMK * BNC / 4;
     if (nsplit >= 32)
         wgrad_tile_reduce_kernel<16><<<combos * ((tile4 + 15) / 16), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C,
-                                                                                 klen, stem);
+                                                                                 klen, stem, wgt);
     else if (nsplit >= 4)
         wgrad_tile_reduce_kernel<4><<<combos * ((tile4 + 63) / 64), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C,
-                                                                                klen, stem);
+                                                                                klen, stem, wgt);
     else
         wgrad_tile_reduce_kernel<1><<<combos * ((tile4 + 255) / 256), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C,
-                                                                                  klen, stem);
+                                                                                  klen, stem, wgt);
 }
 
 static void launch_tile_reduce(const WgradParams& p, int BMK, int BNC, int stem, hipStream_t st) {
@@ -574,6 +576,69 @@ extern "C" int primia_conv2d_wgrad_multi_ws(int n, const primia_conv_desc* const
         ps[i].persample = 0; ps[i].sqnorm = nullptr; ps[i].ws = nullptr; ps[i].ws_bytes = 0;
     }
     return wgrad_patch_multi_dispatch(ps, n, (float*)ws, (size_t)ws_bytes, (hipStream_t)stream);
+}
+
+// ---- DP-SGD: per-sample gradient tiles KEPT by the norm pass, clipped sum = a weighted reduce --------------------------
+// Where a layer's per-sample gradients are small (the stem: 64 KiB per sample; the 64 -> 64 convs of layer1: 144 KiB),
+// the norm pass stores each sample's complete tile next to adding its squares, and the clipped sum  sum_n clip_n g_n  is
+// ONE ordered reduce over those tiles weighted by the clip factors — instead of scaling the rows of dy (a read + write
+// of the layer's whole dy: 411 MB for the stem) and running the weight gradient a second time.
+extern "C" int64_t primia_stem_conv_wgrad_persample_slab_bytes(int N, int H, int W) {
+    if (N <= 0 || H <= 0 || W <= 0) return PRIMIA_ERR_ARG;
+    return stem_wgrad_halo_ws_bytes(N, H, W) > 0 ? (int64_t)N * 64 * 256 * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int primia_stem_conv_wgrad_persample_sqnorm_keep(const void* x_padded, const void* dy, double* sqnorm, void* slabs,
+                                                            int64_t slab_bytes, int N, int H, int W, int dtype,
+                                                            primia_stream_t stream) {
+    PRIMIA_REQUIRE(x_padded && dy && sqnorm && slabs && N > 0 && H > 0 && W > 0);
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
+    if (slab_bytes < (int64_t)N * 64 * 256 * (int64_t)sizeof(float)) return PRIMIA_ERR_WORKSPACE;
+    return stem_wgrad_halo_dispatch((const bf16*)x_padded, (const bf16*)dy, nullptr, N, H, W, (hipStream_t)stream,
+                                    (float*)slabs, (size_t)slab_bytes, sqnorm);
+}
+
+extern "C" int primia_stem_conv_wgrad_clipped_sum(const void* slabs, const float* clip, float* dw_acc, int N,
+                                                  primia_stream_t stream) {
+    PRIMIA_REQUIRE(slabs && clip && dw_acc && N > 0);
+    wgrad_tile_reduce((const float*)slabs, dw_acc, N, 1, 64, 256, 1, 1, 4, 256, 1, (hipStream_t)stream, clip);
+    return launch_status();
+}
+
+extern "C" int64_t primia_conv_wgrad_persample_slab_bytes(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    WgradParams p;
+    if (!d || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
+    static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    if (dtype != PRIMIA_BF16 || g.stem || force) return 0;
+    p.persample = 1;
+    return (int64_t)wgrad_patch_keep_bytes(p);
+}
+
+extern "C" int primia_conv2d_wgrad_persample_sqnorm_keep(const primia_conv_desc* d, const void* x, const void* dy,
+                                                         double* sqnorm, void* slabs, int64_t slab_bytes, int dtype,
+                                                         primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && x && dy && sqnorm && slabs);
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
+    ConvGeom g;
+    WgradParams p;
+    PRIMIA_REQUIRE(fill_wgrad_params(d, p, g));
+    if (g.stem) return PRIMIA_ERR_UNSUPPORTED;
+    p.x = x; p.dy = dy; p.dw = nullptr;
+    p.persample = 1; p.sqnorm = sqnorm;
+    p.ws = (float*)slabs; p.ws_bytes = (size_t)slab_bytes;
+    return wgrad_patch_keep_dispatch(p, (hipStream_t)stream);
+}
+
+extern "C" int primia_conv_wgrad_clipped_sum(const primia_conv_desc* d, const void* slabs, const float* clip, float* dw_acc,
+                                             int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && slabs && clip && dw_acc);
+    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
+    ConvGeom g;
+    WgradParams p;
+    PRIMIA_REQUIRE(fill_wgrad_params(d, p, g));
+    p.persample = 1; p.dw = dw_acc;
+    return wgrad_patch_clipped_sum(p, (const float*)slabs, clip, (hipStream_t)stream);
 }
 
 extern "C" int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,

@@ -428,7 +428,7 @@ __device__ __forceinline__ void wgrad32_epilogue(f32x16 (&acc)[9], const PatchPa
 #pragma unroll
             for (int j = 0; j < 16; ++j) sq += (double)acc[t][j] * (double)acc[t][j];
         wave_sqnorm_add(sq, p.sqnorm + split);
-        return;
+        if (!p.ws) return;      // (ws set: the sample's tile is KEPT for the clipped sum — one split per image)
     }
     if (p.ws) {
         // slab chunk ((t*4 + m)*4 + wave)*64 + lane = registers 4m..4m+3 of accumulator t (wgrad_patch32_reduce_kernel)
@@ -752,6 +752,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) 
 struct ReduceGroup {        // grouped launch: dw of layers 1..3 and the combos of one layer (0: single layer)
     float* dwg[3];
     int combos;
+    const float* wgt;       // DP-SGD clipped sum: split s is sample s, weighted by wgt[s] (null: plain sum)
 };
 
 template <int SL>
@@ -772,6 +773,9 @@ __device__ __forceinline__ void patch32_reduce_body(const float* __restrict__ ws
     const float* src = ws + (long)combo * nsplit * kSlab + q * 4;
     f32x4 a = {0.f, 0.f, 0.f, 0.f};
     int s = sl;
+    if (rg.wgt) {
+        for (; s < nsplit; s += SL) a += *(const f32x4*)(src + (long)s * kSlab) * rg.wgt[s];
+    }
 #pragma unroll 1
     for (; s + 3 * SL < nsplit; s += 4 * SL) {
         const f32x4 v0 = *(const f32x4*)(src + (long)s * kSlab);
@@ -1170,6 +1174,15 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
                 const int img = t0 + 2 * img_pair + half;
                 ++img_pair;
                 double sq = 0.0;
+                if (p.ws && img < t1) {     // (stores first: they drain while the squares are summed)
+                    float* o = p.ws + ((long)(kt * p.nct + ct) * p.nimg + img) * kSlab + ((wave & 3) * 64 + lane) * 4;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t)
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                            *(f32x4*)(o + (t * 4 + m) * 1024) =
+                                f32x4{acc[t][4 * m], acc[t][4 * m + 1], acc[t][4 * m + 2], acc[t][4 * m + 3]};
+                }
 #pragma unroll
                 for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -1603,6 +1616,47 @@ int wgrad_patch_multi_dispatch(const WgradParams* ws_, int n, float* wsp, size_t
     }
     conv_wgrad_patch33_multi_kernel<<<(unsigned)blocks, 512, lds, st>>>(mp);
     wgrad_patch32_reduce_multi_kernel<<<(unsigned)rblocks, 256, 0, st>>>(rm);
+    return launch_status();
+}
+
+// ---- DP-SGD: norm pass that KEEPS every sample's tiles, clipped sum as a weighted reduce (see conv_wgrad.hip) ----------
+size_t wgrad_patch_keep_bytes(const WgradParams& w) {
+    static const long budget = getenv("PRIMIA_DP_KEEP_MB") ? atol(getenv("PRIMIA_DP_KEEP_MB")) << 20 : 64L << 20;
+    WgradParams q = w;
+    q.persample = 1;
+    double dummy;
+    q.sqnorm = &dummy;
+    const PatchGeom g = patch_geom(q);
+    if (!g.ok || !use_v3()) return 0;       // (whole images per half, or one block per (image, slab): both keep)
+    const size_t n = (size_t)g.combos * w.N * kSlab * sizeof(float);
+    return (long)n <= budget ? n : 0;
+}
+
+int wgrad_patch_keep_dispatch(const WgradParams& w, hipStream_t st) {
+    const size_t need = wgrad_patch_keep_bytes(w);
+    if (!need || !w.sqnorm || !w.ws) return PRIMIA_ERR_UNSUPPORTED;
+    if (w.ws_bytes < need) return PRIMIA_ERR_WORKSPACE;
+    const PatchGeom g = patch_geom(w);
+    PatchParams p;
+    fill_patch_params(p, w, g);      // (persample: p.ws = null)
+    if (!p.pairimg && g.nsplit != w.N) return PRIMIA_ERR_UNSUPPORTED;
+    p.ws = w.ws;
+    const size_t lds = (size_t)kSlab * 4;
+    void (*kern)(PatchParams);
+    if (g.SW == 16) kern = g.SH == 7 ? conv_wgrad_patch33_kernel<16, 7, 2> : conv_wgrad_patch33_kernel<16, 2, 3>;
+    else kern = g.SH == 8 ? conv_wgrad_patch33_kernel<8, 8, 3> : conv_wgrad_patch33_kernel<8, 4, 3>;
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return PRIMIA_ERR_LAUNCH;
+    kern<<<(unsigned)(g.combos * g.nsplit), 512, lds, st>>>(p);
+    return launch_status();
+}
+
+int wgrad_patch_clipped_sum(const WgradParams& w, const float* slabs, const float* clip, hipStream_t st) {
+    if (!wgrad_patch_keep_bytes(w) || !w.dw) return PRIMIA_ERR_UNSUPPORTED;
+    const int combos = (w.C / 64) * (w.K / 64);
+    ReduceGroup rg{};
+    rg.wgt = clip;
+    wgrad_patch32_reduce_kernel<16><<<combos * (kSlab / 4 / 16), 256, 0, st>>>(slabs, w.dw, w.N, w.C / 64, w.C, w.klen, rg);
     return launch_status();
 }
 

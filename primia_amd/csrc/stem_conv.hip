@@ -485,7 +485,7 @@ __global__ __launch_bounds__(512) void stem_conv_wgrad_kernel(StemWgParams p) {
             }
         }
         wave_sqnorm_add(sq, p.sqnorm + blockIdx.x);
-        return;
+        if (!p.ws) return;       // (ws set: the sample's tile is KEPT for the clipped sum, slot = image)
     }
     if (p.ws) {   // atomic-free path: the block's whole [64][256] slab (zeros in the padding) to ITS workspace slot
         float* o = p.ws + (long)blockIdx.x * (64 * 256);
@@ -568,8 +568,9 @@ int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, i
         p.per_block = p.PPI;
         grid = N;
     }
-    const bool store = !sqnorm && ws && ws_bytes >= (size_t)grid * 64 * 256 * sizeof(float);
+    const bool store = ws && ws_bytes >= (size_t)grid * 64 * 256 * sizeof(float);   // (norm pass: one slab per image)
     p.ws = store ? ws : nullptr;
+    if (sqnorm && ws && !store) return PRIMIA_ERR_WORKSPACE;
     const size_t lds = (size_t)3 * (7 + 16) * 1024;
     static bool attr_set = false;
     if (!attr_set) {
@@ -580,7 +581,7 @@ int stem_wgrad_halo_dispatch(const bf16* xp, const bf16* dy, float* dw, int N, i
     }
     stem_conv_wgrad_kernel<<<grid, 512, lds, st>>>(p);
     // the slabs are [k][e] tiles of the accumulator itself: one "tile" of 64 x 256, one tap, `grid` splits
-    if (store) wgrad_tile_reduce(ws, dw, grid, 1, 64, 256, 1, 1, 4, 256, 1, st);
+    if (store && !sqnorm) wgrad_tile_reduce(ws, dw, grid, 1, 64, 256, 1, 1, 4, 256, 1, st);
     return launch_status();
 }
 

@@ -937,9 +937,22 @@ class ResNet18Engine:
                     call("primia_persample_sqnorm", psg, N, psg.shape[1], sq)
                     call("primia_persample_sqnorm", psb, N, psb.shape[1], sq)
                     mark(b)
+            # layers whose per-sample gradient tiles are small enough to KEEP (the stem, layer1's 64 -> 64 convs): the
+            # norm pass stores them and the clipped sum is a weighted reduce — no row scaling of dy, no second pass
+            kept = self._dp_keep_buffers()
             for name, x, dy in self.dp["wgrads"]:
                 c = self.convs[name]
                 done = False
+                if name in kept:
+                    if name == "conv1":
+                        S = self.spec.input_size
+                        call("primia_stem_conv_wgrad_persample_sqnorm_keep", self.x0p, dy, sq, kept[name],
+                             kept[name].numel() * 4, N, S, S, self.dt)
+                    else:
+                        call("primia_conv2d_wgrad_persample_sqnorm_keep", c.desc, x, dy, sq, kept[name],
+                             kept[name].numel() * 4, self.dt)
+                    mark(name)
+                    continue
                 if name == "conv1" and self._stem_padded:   # halo kernel on the padded input, one block per image
                     S = self.spec.input_size
                     try:
@@ -958,6 +971,12 @@ class ResNet18Engine:
             # clipped sums
             for name, x, dy in self.dp["wgrads"]:
                 c = self.convs[name]
+                if name in kept:
+                    if name == "conv1":
+                        call("primia_stem_conv_wgrad_clipped_sum", kept[name], clip, c.acc, N)
+                    else:
+                        call("primia_conv_wgrad_clipped_sum", c.desc, kept[name], clip, c.acc, self.dt)
+                    continue
                 call("primia_scale_rows", dy, clip, N, dy.numel() // N, self.dt)
                 # the clipped SUM is an ordinary batched weight gradient: atomic-free kernels, and for the stem the
                 # halo kernel on the padded input (118 us instead of 444 us for the per-tap one)
@@ -999,6 +1018,25 @@ class ResNet18Engine:
         call("primia_dp_add_noise", self.grads, noise, self.P, float(noise_multiplier * max_grad_norm), 1.0 / N)
         self.dp_stats = {"sq_norms": sq, "clip": clip}
         return self.loss
+
+    dp_keep = os.environ.get("PRIMIA_DP_KEEP", "1") != "0"
+
+    def _dp_keep_buffers(self):
+        """{conv name: fp32 buffer} for the layers whose per-sample tiles the DP-SGD norm pass keeps (built once)."""
+        if getattr(self, "_dp_keep", None) is None:
+            self._dp_keep = {}
+            if self.dp_keep and self.dtype == torch.bfloat16 and self.wgrad_ws is not None:
+                for c in self.spec.convs:
+                    if c.name == "conv1":
+                        S = self.spec.input_size
+                        n = query("primia_stem_conv_wgrad_persample_slab_bytes", self.N, S, S) if self.x0p is not None else 0
+                    else:
+                        n = query("primia_conv_wgrad_persample_slab_bytes", self.convs[c.name].desc, self.dt)
+                    if n > 0:
+                        self._dp_keep[c.name] = torch.empty(n // 4, dtype=torch.float32, device=self.device)
+        if "conv1" in self._dp_keep and not self._stem_padded:
+            return {k: v for k, v in self._dp_keep.items() if k != "conv1"}
+        return self._dp_keep
 
     # ------------------------------------------------------------------------------------------
     # optimizer

@@ -187,3 +187,95 @@ def test_groupnorm_stem_fused_matches_the_chain(cuda, dtype, batch, size):
     for k in a[5]:
         assert rel(a[5][k], b[5][k]) < tol, k
     assert rel(a[4], b[4]) < tol
+
+
+@pytest.mark.parametrize("case", [(140, 16, 64, 64), (9, 24, 64, 64), (300, 8, 64, 64), (20, 14, 128, 128)])
+def test_kept_per_sample_tiles_give_the_clipped_sum(cuda, case):
+    """DP-SGD for layers with small per-sample gradients: primia_conv2d_wgrad_persample_sqnorm_keep stores every sample's
+    tile while adding its squares; primia_conv_wgrad_clipped_sum = the ordered reduce of the kept tiles weighted by the
+    clip factors.  Against the explicit per-sample slabs (primia_conv2d_wgrad_persample): norms to 1e-6, the clipped sum
+    to fp32 rounding — both walk whole images per half-block (large batches) or one block per image."""
+    from primia_amd._lib import ConvDesc
+
+    N, H, C, K = case
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    d = ConvDesc.make(N, H, H, C, K, 3, 3, 1, 1)
+    need = query("primia_conv_wgrad_persample_slab_bytes", d, dt)
+    assert need > 0
+    g = torch.Generator().manual_seed(N + H)
+    x = torch.randn(N * H * H, C, generator=g).relu().to(dtype).to(cuda)
+    dy = (torch.randn(N * H * H, K, generator=g) * 1e-2).to(dtype).to(cuda)
+    ne = query("primia_conv_wfwd_elems", d)
+    slab = torch.zeros(N, ne, device=cuda)
+    call("primia_conv2d_wgrad_persample", d, x, dy, slab, dt)
+    sq_ref = (slab.double() ** 2).sum(1)
+    clip = (torch.rand(N, generator=g) * 0.9 + 0.1).to(cuda)
+    want = (slab * clip[:, None]).sum(0)
+    keep = torch.full((need // 4,), float("nan"), device=cuda)
+    sq = torch.zeros(N, dtype=torch.float64, device=cuda)
+    call("primia_conv2d_wgrad_persample_sqnorm_keep", d, x, dy, sq, keep, need, dt)
+    assert rel(sq, sq_ref) < 1e-6
+    acc = torch.full((ne,), float("nan"), device=cuda)
+    call("primia_conv_wgrad_clipped_sum", d, keep, clip, acc, dt)
+    assert rel(acc, want) < 2e-6
+
+
+def test_stem_kept_per_sample_tiles_give_the_clipped_sum(cuda):
+    from primia_amd._lib import ConvDesc
+
+    N, S = 6, 64
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    need = query("primia_stem_conv_wgrad_persample_slab_bytes", N, S, S)
+    assert need == N * 64 * 256 * 4
+    g = torch.Generator().manual_seed(3)
+    xp = torch.zeros(N, S + 6, S + 8, 4)
+    xp[:, 3:3 + S, 3:3 + S, :3] = torch.randn(N, S, S, 3, generator=g)
+    xp = xp.to(dtype).to(cuda)
+    dy = (torch.randn(N * (S // 2) ** 2, 64, generator=g) * 1e-2).to(dtype).to(cuda)
+    keep = torch.full((need // 4,), float("nan"), device=cuda)
+    sq = torch.zeros(N, dtype=torch.float64, device=cuda)
+    call("primia_stem_conv_wgrad_persample_sqnorm_keep", xp, dy, sq, keep, need, N, S, S, dt)
+    sq_ref = torch.zeros(N, dtype=torch.float64, device=cuda)
+    call("primia_stem_conv_wgrad_persample_sqnorm", xp, dy, sq_ref, N, S, S, dt)
+    assert rel(sq, sq_ref) < 1e-9
+    tiles = keep.view(N, 64 * 256)
+    assert rel((tiles.double() ** 2).sum(1), sq_ref) < 1e-6
+    clip = (torch.rand(N, generator=g) * 0.9 + 0.1).to(cuda)
+    acc = torch.full((64 * 256,), float("nan"), device=cuda)
+    call("primia_stem_conv_wgrad_clipped_sum", keep, clip, acc, N)
+    assert rel(acc, (tiles * clip[:, None]).sum(0)) < 2e-6
+    # and against the batched kernel on the row-scaled dy (what the engine did before): bf16 rounding of the scaled rows
+    dys = dy.clone()
+    call("primia_scale_rows", dys, clip, N, dys.numel() // N, dt)
+    wsb = query("primia_stem_conv_wgrad_ws_bytes", N, S, S)
+    ws = torch.empty(wsb // 4, device=cuda)
+    acc2 = torch.zeros(64 * 256, device=cuda)
+    call("primia_stem_conv_wgrad_ws", xp, dys, acc2, ws, wsb, N, S, S, dt)
+    assert rel(acc, acc2) < 1e-2
+
+
+def test_dp_step_with_kept_tiles_matches_the_two_pass_form(cuda):
+    """bf16 DP-SGD engine step with the kept-tile path (stem + layer1) against the same step with PRIMIA_DP_KEEP off:
+    same norms and clip factors (to fp64 summation order), clipped gradient within the bf16 rounding of the scaled rows."""
+    batch, size = 130, 32
+    spec = rs.resnet18_spec(3, 3, size, "max")
+    torch.manual_seed(31)
+    sd = rs.init_state_dict(spec, "group")
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(batch, 3, size, size, generator=g).to(cuda)
+    y = torch.randint(0, 3, (batch,), generator=g).to(cuda)
+    out = []
+    for keep in (True, False):
+        eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.bfloat16, device=cuda, norm="group")
+        eng.dp_keep = keep
+        eng.load_state_dict(sd)
+        eng.forward(x)
+        eng.dp_loss_backward(y, 1.0, 0.0, noise=torch.zeros(eng.P, device=cuda))
+        torch.cuda.synchronize()
+        assert bool(eng._dp_keep_buffers()) == keep
+        out.append((eng.dp_stats["sq_norms"].clone(), eng.dp_stats["clip"].clone(), eng.grads.clone()))
+    a, b = out
+    assert rel(a[0], b[0]) < 1e-9 and rel(a[1], b[1]) < 1e-6
+    assert rel(a[2], b[2]) < 2e-2
