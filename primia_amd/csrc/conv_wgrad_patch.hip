@@ -1621,7 +1621,7 @@ int wgrad_patch_multi_dispatch(const WgradParams* ws_, int n, float* wsp, size_t
 
 // ---- DP-SGD: norm pass that KEEPS every sample's tiles, clipped sum as a weighted reduce (see conv_wgrad.hip) ----------
 size_t wgrad_patch_keep_bytes(const WgradParams& w) {
-    static const long budget = getenv("PRIMIA_DP_KEEP_MB") ? atol(getenv("PRIMIA_DP_KEEP_MB")) << 20 : 64L << 20;
+    static const long budget = getenv("PRIMIA_DP_KEEP_MB") ? atol(getenv("PRIMIA_DP_KEEP_MB")) << 20 : 160L << 20;   // (layer1: 38 MB per layer, layer2: 151; layer3 would be 604 MB written and read back: a loss)
     WgradParams q = w;
     q.persample = 1;
     double dummy;
