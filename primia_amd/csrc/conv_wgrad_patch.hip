@@ -1480,7 +1480,8 @@ int wgrad_patch_group_size(const WgradParams& w, int count) {
     for (int n = count < 4 ? count : 4; n >= 2; --n) {
         const PatchGeom g = patch_geom(w, n);
         const long blocks = (long)n * g.combos * g.nsplit;
-        if (blocks <= 256 && blocks * 10 >= 256 * 9) return n;
+        static const int minfill = getenv("PRIMIA_WGP_GROUP_MINFILL") ? atoi(getenv("PRIMIA_WGP_GROUP_MINFILL")) : 90;
+        if (blocks <= 256 && blocks * 100 >= 256 * minfill) return n;
     }
     return 1;
 }
