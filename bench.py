@@ -141,6 +141,9 @@ def main():
     eng = ResNet18Engine(a.batch, 3, 3, a.size, "max", dtype=dtype, device=dev, norm="group" if a.dp else "batch")
     if a.dp:
         eng.dp_params = {"max_grad_norm": 1.0, "noise_multiplier": 1.3}   # train.py:325-334
+    # SGD follows the backward pass directly: gradient finalize + update + weight refresh as one pass per weight tile
+    # (what EngineOptimizer("SGD") switches on for the training loops; PRIMIA_FUSE_SGD=0: the three unfused passes)
+    eng.fuse_sgd_tail = os.environ.get("PRIMIA_FUSE_SGD", "1") != "0"
     torch.manual_seed(42)           # the reference's default seed (pneumonia-resnet-pretrained.ini:17)
     eng.init_weights()
     g = torch.Generator().manual_seed(1000 + rank)

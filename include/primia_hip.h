@@ -89,6 +89,19 @@ int primia_conv_wgrad_finalize_many(const primia_conv_desc* descs_host, const in
                                     const float* const* dw_acc_host, float* const* dw_oihw_host, int n,
                                     primia_stream_t stream);
 
+/* loss.backward() tail + optimizer.step() of the reference's batch loop (torchlib/utils.py:1016-1030, train.py:280-303
+ * with optimizer = SGD) for the regular convolutions, as ONE pass per 32 x 64 x R*S weight tile: accumulator -> OIHW
+ * gradient (still written: the caller finds every .grad), w <- w - lr * (g + weight_decay * w) on the fp32 master
+ * (the expression of primia_sgd_step, bit-identical to it), master -> w_fwd / w_dgrad copies.  Replaces
+ * primia_conv_wgrad_finalize_many + primia_sgd_step (on these ranges) + primia_conv_weight_prepare_many.
+ * Only layers for which primia_conv_sgd_fusable() returns 1 (C % 64 == 0, c_real == C, 3x3 or 1x1) — the others, and
+ * every other parameter, go through the unfused calls / primia_sgd_step_ranges.  Host arrays as above. */
+int primia_conv_sgd_fusable(const primia_conv_desc* d, int c_real);
+int primia_conv_sgd_step_many(const primia_conv_desc* descs_host, const int* c_real_host,
+                              const float* const* dw_acc_host, float* const* dw_oihw_host,
+                              float* const* w_oihw_host, void* const* w_fwd_host, void* const* w_dgrad_host,
+                              int n, float lr, float weight_decay, int dtype, primia_stream_t stream);
+
 /* y[N,Ho,Wo,K] = conv(x[N,H,W,C], w). */
 int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
                       int dtype, primia_stream_t stream);
@@ -524,6 +537,10 @@ int primia_xent_soft(const float* logits, const float* target, const float* clas
  * ------------------------------------------------------------------------------------------ */
 int primia_sgd_step(float* p, const float* g, int64_t n, float lr, float weight_decay,
                     primia_stream_t stream);
+/* The same SGD step over n <= 32 element ranges [begin, begin + len) of the arena in one launch (host arrays): what
+ * primia_conv_sgd_step_many leaves over (BatchNorm / fc parameters, the stem filter). */
+int primia_sgd_step_ranges(float* p, const float* g, const int64_t* begin_host, const int64_t* len_host, int n,
+                           float lr, float weight_decay, primia_stream_t stream);
 int primia_adam_step(float* p, const float* g, float* exp_avg, float* exp_avg_sq, int64_t n,
                      float lr, float beta1, float beta2, float eps, float weight_decay,
                      int64_t step, primia_stream_t stream);

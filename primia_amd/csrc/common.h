@@ -119,6 +119,10 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// torch.optim.SGD without momentum: d_p = g + wd*p ; p = p - lr*d_p.  ONE definition for the flat optimizer kernel
+// (optim.hip) and the fused gradient-finalize + step + weight-refresh tiles (layout.hip): the two must agree bit for bit.
+__device__ __forceinline__ float sgd_update(float p, float g, float lr, float wd) { return p - lr * (g + wd * p); }
+
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
 // Post-launch error check -> C-ABI code.

@@ -218,6 +218,44 @@ struct TileArgs {
 // (16-byte loads on the fp32 side and 4-byte stores of channel / out-channel pairs on the bf16 side: the first
 // version moved one element per instruction — 72 dependent-free but single-element trips per thread — and ran at
 // 2.4 TB/s on 90 MB)
+// LDS tile [32 out-channels][64 in-channels * RS taps] in OIHW order -> the forward layout [K][tap][C] and (if dst2) the
+// data-gradient layout [C][R][S][K], in the compute dtype
+template <typename T, int RS, int KT = 32>
+__device__ __forceinline__ void prepare_tile_emit(void* dst_, void* dst2_, int klen, int C, int K, int k0, int c0,
+                                                  const float* lds) {
+    constexpr int ROW = 64 * RS, PITCH = ROW + 1;
+    T* dst = (T*)dst_;
+    if constexpr (sizeof(T) == 2) {
+        for (int idx = threadIdx.x; idx < KT * ROW / 2; idx += 256) {
+            const int k = idx / (ROW / 2), j = (idx - k * (ROW / 2)) * 2;     // j = t * 64 + c, c even
+            const int t = j >> 6, c = j & 63;
+            const uint32_t lo = f32_to_bf16(lds[k * PITCH + c * RS + t]), hi = f32_to_bf16(lds[k * PITCH + (c + 1) * RS + t]);
+            *(uint32_t*)((uint16_t*)dst + (long)(k0 + k) * klen + t * C + c0 + c) = lo | (hi << 16);
+        }
+        if (dst2_) {
+            uint16_t* d2 = (uint16_t*)dst2_;  // [C][R][S][K]
+            for (int idx = threadIdx.x; idx < KT / 2 * ROW; idx += 256) {
+                const int k = (idx % (KT / 2)) * 2, j = idx / (KT / 2);  // j = c * RS + t
+                const uint32_t lo = f32_to_bf16(lds[k * PITCH + j]), hi = f32_to_bf16(lds[(k + 1) * PITCH + j]);
+                *(uint32_t*)(d2 + ((long)c0 * RS + j) * K + k0 + k) = lo | (hi << 16);
+            }
+        }
+    } else {
+        for (int idx = threadIdx.x; idx < KT * ROW; idx += 256) {
+            const int k = idx / ROW, j = idx - k * ROW;
+            const int t = j >> 6, c = j & 63;
+            Elem<T>::store(dst + (long)(k0 + k) * klen + t * C + c0 + c, lds[k * PITCH + c * RS + t]);
+        }
+        if (dst2_) {
+            T* d2 = (T*)dst2_;  // [C][R][S][K]
+            for (int idx = threadIdx.x; idx < KT * ROW; idx += 256) {
+                const int k = idx % KT, j = idx / KT;  // j = c * RS + t
+                Elem<T>::store(d2 + ((long)c0 * RS + j) * K + k0 + k, lds[k * PITCH + j]);
+            }
+        }
+    }
+}
+
 template <typename T, int RS>
 __device__ __forceinline__ void prepare_tile(const ManyEntry& en, int tile, float* lds) {
     constexpr int ROW = 64 * RS, PITCH = ROW + 1;
@@ -232,36 +270,7 @@ __device__ __forceinline__ void prepare_tile(const ManyEntry& en, int tile, floa
         for (int e = 0; e < 4; ++e) lds[k * PITCH + j + e] = v[e];
     }
     __syncthreads();
-    T* dst = (T*)en.dst;
-    if constexpr (sizeof(T) == 2) {
-        for (int idx = threadIdx.x; idx < 32 * ROW / 2; idx += 256) {
-            const int k = idx / (ROW / 2), j = (idx - k * (ROW / 2)) * 2;     // j = t * 64 + c, c even
-            const int t = j >> 6, c = j & 63;
-            const uint32_t lo = f32_to_bf16(lds[k * PITCH + c * RS + t]), hi = f32_to_bf16(lds[k * PITCH + (c + 1) * RS + t]);
-            *(uint32_t*)((uint16_t*)dst + (long)(k0 + k) * en.g.klen + t * C + c0 + c) = lo | (hi << 16);
-        }
-        if (en.dst2) {
-            uint16_t* d2 = (uint16_t*)en.dst2;  // [C][R][S][K]
-            for (int idx = threadIdx.x; idx < 16 * ROW; idx += 256) {
-                const int k = (idx & 15) * 2, j = idx >> 4;  // j = c * RS + t
-                const uint32_t lo = f32_to_bf16(lds[k * PITCH + j]), hi = f32_to_bf16(lds[(k + 1) * PITCH + j]);
-                *(uint32_t*)(d2 + ((long)c0 * RS + j) * K + k0 + k) = lo | (hi << 16);
-            }
-        }
-    } else {
-        for (int idx = threadIdx.x; idx < 32 * ROW; idx += 256) {
-            const int k = idx / ROW, j = idx - k * ROW;
-            const int t = j >> 6, c = j & 63;
-            Elem<T>::store(dst + (long)(k0 + k) * en.g.klen + t * C + c0 + c, lds[k * PITCH + c * RS + t]);
-        }
-        if (en.dst2) {
-            T* d2 = (T*)en.dst2;  // [C][R][S][K]
-            for (int idx = threadIdx.x; idx < 32 * ROW; idx += 256) {
-                const int k = idx & 31, j = idx >> 5;  // j = c * RS + t
-                Elem<T>::store(d2 + ((long)c0 * RS + j) * K + k0 + k, lds[k * PITCH + j]);
-            }
-        }
-    }
+    prepare_tile_emit<T, RS>(en.dst, en.dst2, en.g.klen, C, K, k0, c0, lds);
 }
 
 template <typename T>
@@ -311,6 +320,119 @@ __global__ __launch_bounds__(256) void wgrad_finalize_tiled_kernel(TileArgs a) {
         finalize_tile<9>(en, tile, lds);
     else
         finalize_tile<1>(en, tile, lds);
+}
+
+// ---- gradient finalize + SGD step + weight refresh of every regular conv in ONE pass ------------------------------
+// The three tiled passes above move the same 32 x 64 x R*S tile three times (accumulator -> OIHW gradient; master
+// weights and gradient -> master weights; master weights -> kernel layouts: 90 + 135 + 90 MB for ResNet-18).  Here a
+// block keeps its tile in LDS: the gradient goes out in OIHW order as before (the caller still finds every .grad), the
+// master weights are read once, updated with the flat optimizer's expression (sgd_update: bit-identical to
+// primia_sgd_step on the same range) and written once, and the compute-dtype copies are formed from the LDS tile.
+struct SgdTileEntry {
+    int C, K, klen, RS;
+    const float* acc;   // [K][klen] weight-gradient accumulator (forward layout)
+    float* grad;        // OIHW gradient (out)
+    float* w;           // OIHW master weights (in / out)
+    void* wf;           // forward-layout copy (out)
+    void* wd;           // data-gradient-layout copy (out) or null
+};
+struct SgdTileArgs {
+    SgdTileEntry e[kMaxConvs];
+    int tile_begin[kMaxConvs + 1];
+    int n;
+    float lr, wd;
+};
+
+// KT out-channels per tile: 16 for the 3x3 layers (37 KB of LDS: four blocks per CU instead of two, 1,200 tiles instead of
+// 600 — the pass is a chain of memory round trips per block and lives on blocks in flight), 32 for the 1x1 layers.
+// Both loads of a tile (accumulator rows, master weights) are requested before the first barrier.
+template <typename T, int RS, int KT>
+__device__ __forceinline__ void sgd_tile(const SgdTileEntry& en, int tile, float* lds, float lr, float wd) {
+    constexpr int ROW = 64 * RS, PITCH = ROW + 1;
+    constexpr int NV = KT * ROW / 4;                 // float4 pieces of the tile
+    constexpr int PER = (NV + 255) / 256;            // per thread
+    const int C = en.C, nct = C / 64;
+    const int kt = tile / nct, ct = tile - kt * nct;
+    const int k0 = kt * KT, c0 = ct * 64;
+    const long o0 = ((long)k0 * C + c0) * RS;
+    f32x4 ga[PER], w[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int idx = threadIdx.x + 256 * u;
+        if (idx < NV) {
+            const int k = idx / (ROW / 4), j = (idx - k * (ROW / 4)) * 4;     // accumulator side: j = t * 64 + c
+            const int t = j >> 6, c = j & 63;
+            ga[u] = *(const f32x4*)(en.acc + (long)(k0 + k) * en.klen + t * C + c0 + c);
+            w[u] = *(const f32x4*)(en.w + o0 + (long)k * C * RS + j);        // OIHW side: j = c * RS + t
+        }
+    }
+    // gradient tile -> LDS in OIHW order [k][c * RS + t] (finalize_tile's first half)
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int idx = threadIdx.x + 256 * u;
+        if (idx < NV) {
+            const int k = idx / (ROW / 4), j = (idx - k * (ROW / 4)) * 4;
+            const int t = j >> 6, c = j & 63;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds[k * PITCH + (c + e) * RS + t] = ga[u][e];
+        }
+    }
+    __syncthreads();
+    // OIHW side: gradient out, master weights out; the LDS tile then holds the NEW weights.  (A thread reads and
+    // rewrites its own four LDS words: no barrier inside this loop.)
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+        const int idx = threadIdx.x + 256 * u;
+        if (idx < NV) {
+            const int k = idx / (ROW / 4), j = (idx - k * (ROW / 4)) * 4;
+            const long o = o0 + (long)k * C * RS + j;
+            f32x4 g;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = lds[k * PITCH + j + e];
+            *(f32x4*)(en.grad + o) = g;
+            f32x4 wn = w[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) wn[e] = sgd_update(wn[e], g[e], lr, wd);
+            *(f32x4*)(en.w + o) = wn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) lds[k * PITCH + j + e] = wn[e];
+        }
+    }
+    __syncthreads();
+    prepare_tile_emit<T, RS, KT>(en.wf, en.wd, en.klen, C, en.K, k0, c0, lds);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void conv_sgd_tiled_kernel(SgdTileArgs a) {
+    __shared__ float lds[16 * (64 * 9 + 1)];
+    int c = 0;
+    while (c + 1 < a.n && (int)blockIdx.x >= a.tile_begin[c + 1]) ++c;
+    const SgdTileEntry& en = a.e[c];
+    const int tile = blockIdx.x - a.tile_begin[c];
+    if (en.RS == 9)
+        sgd_tile<T, 9, 16>(en, tile, lds, a.lr, a.wd);
+    else
+        sgd_tile<T, 1, 32>(en, tile, lds, a.lr, a.wd);
+}
+
+// SGD over up to 32 element ranges of a flat arena in one launch (what the fused tiles leave over: BatchNorm / fc
+// parameters, the stem filter) — scalar accesses, the ranges are a few thousand elements each
+constexpr int kMaxRanges = 32;
+struct SgdRanges {
+    long begin[kMaxRanges], len[kMaxRanges];
+    int n;
+    long total;
+};
+__global__ __launch_bounds__(256) void sgd_ranges_kernel(float* __restrict__ p, const float* __restrict__ g, SgdRanges r,
+                                                         float lr, float wd) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < r.total; i += stride) {
+        long j = i;
+        int k = 0;
+        while (k + 1 < r.n && j >= r.len[k]) j -= r.len[k++];
+        const long o = r.begin[k] + j;
+        p[o] = sgd_update(p[o], g[o], lr, wd);
+    }
 }
 
 // regular conv that the tiled kernels cover
@@ -541,6 +663,62 @@ int primia_conv_wgrad_finalize_many(const primia_conv_desc* descs, const int* c_
         const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
         wgrad_finalize_many_kernel<<<blocks, 256, 0, st>>>(a);
     }
+    return launch_status();
+}
+
+int primia_conv_sgd_fusable(const primia_conv_desc* d, int c_real) {
+    if (!d) return PRIMIA_ERR_ARG;
+    ConvGeom g;
+    if (!g.init(*d)) return PRIMIA_ERR_ARG;
+    return tiled_ok(g, c_real) ? 1 : 0;
+}
+
+int primia_conv_sgd_step_many(const primia_conv_desc* descs, const int* c_real, const float* const* dw_acc,
+                              float* const* dw_oihw, float* const* w_oihw, void* const* w_fwd, void* const* w_dgrad,
+                              int n, float lr, float weight_decay, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(descs && c_real && dw_acc && dw_oihw && w_oihw && w_fwd && w_dgrad && n > 0 && n <= kMaxConvs);
+    PRIMIA_REQUIRE(dtype == PRIMIA_F32 || dtype == PRIMIA_BF16);
+    SgdTileArgs ta;
+    ta.n = 0;
+    ta.lr = lr;
+    ta.wd = weight_decay;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        ConvGeom g;
+        PRIMIA_REQUIRE(g.init(descs[i]) && dw_acc[i] && dw_oihw[i] && w_oihw[i] && w_fwd[i]);
+        if (!tiled_ok(g, c_real[i])) return PRIMIA_ERR_UNSUPPORTED;      // ask primia_conv_sgd_fusable first
+        PRIMIA_REQUIRE((((uintptr_t)dw_acc[i] | (uintptr_t)dw_oihw[i] | (uintptr_t)w_oihw[i] | (uintptr_t)w_fwd[i] |
+                         (uintptr_t)w_dgrad[i]) & 15) == 0);
+        SgdTileEntry& en = ta.e[ta.n];
+        en.C = g.C; en.K = g.K; en.klen = g.klen; en.RS = g.R * g.S;
+        en.acc = dw_acc[i]; en.grad = dw_oihw[i]; en.w = w_oihw[i]; en.wf = w_fwd[i]; en.wd = w_dgrad[i];
+        ta.tile_begin[ta.n++] = tiles;
+        tiles += (g.K / (en.RS == 9 ? 16 : 32)) * (g.C / 64);
+    }
+    ta.tile_begin[ta.n] = tiles;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        conv_sgd_tiled_kernel<float><<<tiles, 256, 0, st>>>(ta);
+    else
+        conv_sgd_tiled_kernel<bf16><<<tiles, 256, 0, st>>>(ta);
+    return launch_status();
+}
+
+int primia_sgd_step_ranges(float* p, const float* g, const int64_t* begin_host, const int64_t* len_host, int n, float lr,
+                           float weight_decay, primia_stream_t stream) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(p && g && begin_host && len_host && n > 0 && n <= kMaxRanges);
+    SgdRanges r;
+    r.n = n;
+    r.total = 0;
+    for (int i = 0; i < n; ++i) {
+        PRIMIA_REQUIRE(begin_host[i] >= 0 && len_host[i] > 0);
+        r.begin[i] = begin_host[i];
+        r.len[i] = len_host[i];
+        r.total += len_host[i];
+    }
+    const int blocks = (int)((r.total + 255) / 256 < 1024 ? (r.total + 255) / 256 : 1024);
+    sgd_ranges_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(p, g, r, lr, weight_decay);
     return launch_status();
 }
 

@@ -18,7 +18,7 @@ struct SgdFn {
     const float* g;
     float lr, wd;
     // torch.optim.SGD without momentum: d_p = g + wd*p ; p = p - lr*d_p
-    __device__ __forceinline__ float upd(float p_, float g_) const { return p_ - lr * (g_ + wd * p_); }
+    __device__ __forceinline__ float upd(float p_, float g_) const { return sgd_update(p_, g_, lr, wd); }
     __device__ __forceinline__ void vec(long q) const {
         f32x4 a = ((f32x4*)p)[q];
         const f32x4 b = ((const f32x4*)g)[q];

@@ -30,6 +30,9 @@ class EngineOptimizer:
         group["params"] = list(range(len(engine.p_entries)))
         self.param_groups = [group]
         engine.reset_optimizer()
+        # SGD: step() follows the backward pass directly, so the engine may leave the conv gradients in their
+        # accumulators and finish them, the update and the weight refresh in one pass (engine.fuse_sgd_tail)
+        engine.fuse_sgd_tail = kind == "SGD"
 
     @classmethod
     def from_args(cls, engine, args, lr=None):

@@ -361,3 +361,48 @@ def test_weight_gradients_on_a_second_stream_give_the_same_bits(cuda, batch, siz
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dtype,batch,size", [(torch.bfloat16, 8, 64), (torch.float32, 4, 64), (torch.bfloat16, 16, 224)])
+def test_fused_sgd_tail_gives_the_same_bits(cuda, dtype, batch, size):
+    """engine.fuse_sgd_tail (primia_conv_sgd_step_many + primia_sgd_step_ranges) against the three unfused passes
+    (finalize -> primia_sgd_step -> weight refresh): gradients, master weights and both kernel-layout copies of every
+    convolution bit for bit, over two steps; a reader that comes between backward and step (materialize_grads, Adam)
+    finds the gradients the unfused pass would have written."""
+    g = torch.Generator().manual_seed(7)
+    xs = [torch.randn(batch, 3, size, size, generator=g).to(cuda) for _ in range(2)]
+    ys = [torch.randint(0, 3, (batch,), generator=g).to(cuda) for _ in range(2)]
+
+    def run(fused):
+        eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=dtype, device=cuda)
+        torch.manual_seed(3)
+        eng.init_weights()
+        eng.fuse_sgd_tail = fused
+        for x, y in zip(xs, ys):
+            eng.forward(x)
+            eng.loss_backward(y)
+            assert eng._grads_pending == fused
+            eng.sgd_step(1e-2, 5e-4)
+            assert not eng._grads_pending
+        return eng
+
+    a, b = run(False), run(True)
+    assert torch.equal(a.grads, b.grads)
+    assert torch.equal(a.flat, b.flat)
+    for name, ca in a.convs.items():
+        cb = b.convs[name]
+        assert torch.equal(ca.w_fwd.view(torch.int16 if dtype == torch.bfloat16 else torch.int32),
+                           cb.w_fwd.view(torch.int16 if dtype == torch.bfloat16 else torch.int32)), name
+        if ca.w_dgrad is not None:
+            assert torch.equal(ca.w_dgrad.float(), cb.w_dgrad.float()), name
+    # a reader between backward and step
+    b.forward(xs[0]); b.loss_backward(ys[0])
+    a.forward(xs[0]); a.loss_backward(ys[0])
+    assert b._grads_pending
+    b.materialize_grads()
+    assert not b._grads_pending and torch.equal(a.grads, b.grads)
+    b.forward(xs[1]); b.loss_backward(ys[1])
+    a.forward(xs[1]); a.loss_backward(ys[1])
+    a.adam_step(1e-3)
+    b.adam_step(1e-3)
+    assert torch.equal(a.flat, b.flat)
