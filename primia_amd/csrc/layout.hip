@@ -209,6 +209,12 @@ __global__ __launch_bounds__(256) void wgrad_finalize_many_kernel(ManyArgs a) {
 // kernel-layout side (contiguous in c per tap, or in k for the dgrad copy) are accessed in whole rows.
 // The element-wise kernels above gather with a stride of R*S floats and spend ~100 instructions of index
 // arithmetic per element (193 us for the network's 11 M weights; this form: see profiles/).
+// Out-channels per tile: 16 for the 3x3 layers (37 KB of LDS, four blocks per CU, ~1,200 tiles for ResNet-18) — with 32
+// (74 KB, two blocks per CU, ~600 tiles) a pass was a chain of memory round trips on too few blocks in flight (the fused
+// step tail below: 69 -> 43 us) — and 32 for the 1x1 layers.
+constexpr int kTileK9 = 16;
+static inline int tiles_of(int K, int C, int RS) { return (K / (RS == 9 ? kTileK9 : 32)) * (C / 64); }
+
 struct TileArgs {
     ManyEntry e[kMaxConvs];
     int tile_begin[kMaxConvs + 1];
@@ -256,43 +262,45 @@ __device__ __forceinline__ void prepare_tile_emit(void* dst_, void* dst2_, int k
     }
 }
 
-template <typename T, int RS>
+template <typename T, int RS, int KT>
 __device__ __forceinline__ void prepare_tile(const ManyEntry& en, int tile, float* lds) {
     constexpr int ROW = 64 * RS, PITCH = ROW + 1;
     const int C = en.g.C, K = en.g.K, nct = C / 64;
     const int kt = tile / nct, ct = tile - kt * nct;
-    const int k0 = kt * 32, c0 = ct * 64;
+    const int k0 = kt * KT, c0 = ct * 64;
     const float* src = en.src + ((long)k0 * C + c0) * RS;
-    for (int idx = threadIdx.x; idx < 32 * ROW / 4; idx += 256) {
+#pragma unroll
+    for (int idx = threadIdx.x; idx < KT * ROW / 4; idx += 256) {
         const int k = idx / (ROW / 4), j = (idx - k * (ROW / 4)) * 4;
         const f32x4 v = *(const f32x4*)(src + (long)k * C * RS + j);
 #pragma unroll
         for (int e = 0; e < 4; ++e) lds[k * PITCH + j + e] = v[e];
     }
     __syncthreads();
-    prepare_tile_emit<T, RS>(en.dst, en.dst2, en.g.klen, C, K, k0, c0, lds);
+    prepare_tile_emit<T, RS, KT>(en.dst, en.dst2, en.g.klen, C, K, k0, c0, lds);
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void weight_prepare_tiled_kernel(TileArgs a) {
-    __shared__ float lds[32 * (64 * 9 + 1)];
+    __shared__ float lds[kTileK9 * (64 * 9 + 1)];
     int c = 0;
     while (c + 1 < a.n && (int)blockIdx.x >= a.tile_begin[c + 1]) ++c;
     const ManyEntry& en = a.e[c];
     const int tile = blockIdx.x - a.tile_begin[c];
     if (en.g.R * en.g.S == 9)
-        prepare_tile<T, 9>(en, tile, lds);
+        prepare_tile<T, 9, kTileK9>(en, tile, lds);
     else
-        prepare_tile<T, 1>(en, tile, lds);
+        prepare_tile<T, 1, 32>(en, tile, lds);
 }
 
-template <int RS>
+template <int RS, int KT>
 __device__ __forceinline__ void finalize_tile(const ManyEntry& en, int tile, float* lds) {
     constexpr int ROW = 64 * RS, PITCH = ROW + 1;
     const int C = en.g.C, nct = C / 64;
     const int kt = tile / nct, ct = tile - kt * nct;
-    const int k0 = kt * 32, c0 = ct * 64;
-    for (int idx = threadIdx.x; idx < 32 * ROW / 4; idx += 256) {
+    const int k0 = kt * KT, c0 = ct * 64;
+#pragma unroll
+    for (int idx = threadIdx.x; idx < KT * ROW / 4; idx += 256) {
         const int k = idx / (ROW / 4), j = (idx - k * (ROW / 4)) * 4;     // j = t * 64 + c, c a multiple of 4
         const int t = j >> 6, c = j & 63;
         const f32x4 v = *(const f32x4*)(en.src + (long)(k0 + k) * en.g.klen + t * C + c0 + c);
@@ -301,7 +309,7 @@ __device__ __forceinline__ void finalize_tile(const ManyEntry& en, int tile, flo
     }
     __syncthreads();
     float* dst = (float*)en.dst + ((long)k0 * C + c0) * RS;
-    for (int idx = threadIdx.x; idx < 32 * ROW / 4; idx += 256) {
+    for (int idx = threadIdx.x; idx < KT * ROW / 4; idx += 256) {
         const int k = idx / (ROW / 4), j = (idx - k * (ROW / 4)) * 4;
         f32x4 v;
 #pragma unroll
@@ -311,15 +319,15 @@ __device__ __forceinline__ void finalize_tile(const ManyEntry& en, int tile, flo
 }
 
 __global__ __launch_bounds__(256) void wgrad_finalize_tiled_kernel(TileArgs a) {
-    __shared__ float lds[32 * (64 * 9 + 1)];
+    __shared__ float lds[kTileK9 * (64 * 9 + 1)];
     int c = 0;
     while (c + 1 < a.n && (int)blockIdx.x >= a.tile_begin[c + 1]) ++c;
     const ManyEntry& en = a.e[c];
     const int tile = blockIdx.x - a.tile_begin[c];
     if (en.g.R * en.g.S == 9)
-        finalize_tile<9>(en, tile, lds);
+        finalize_tile<9, kTileK9>(en, tile, lds);
     else
-        finalize_tile<1>(en, tile, lds);
+        finalize_tile<1, 32>(en, tile, lds);
 }
 
 // ---- gradient finalize + SGD step + weight refresh of every regular conv in ONE pass ------------------------------
@@ -404,13 +412,13 @@ __device__ __forceinline__ void sgd_tile(const SgdTileEntry& en, int tile, float
 
 template <typename T>
 __global__ __launch_bounds__(256) void conv_sgd_tiled_kernel(SgdTileArgs a) {
-    __shared__ float lds[16 * (64 * 9 + 1)];
+    __shared__ float lds[kTileK9 * (64 * 9 + 1)];
     int c = 0;
     while (c + 1 < a.n && (int)blockIdx.x >= a.tile_begin[c + 1]) ++c;
     const SgdTileEntry& en = a.e[c];
     const int tile = blockIdx.x - a.tile_begin[c];
     if (en.RS == 9)
-        sgd_tile<T, 9, 16>(en, tile, lds, a.lr, a.wd);
+        sgd_tile<T, 9, kTileK9>(en, tile, lds, a.lr, a.wd);
     else
         sgd_tile<T, 1, 32>(en, tile, lds, a.lr, a.wd);
 }
@@ -599,7 +607,7 @@ int primia_conv_weight_prepare_many(const primia_conv_desc* descs, const int* c_
         if (tiled_ok(en.g, c_real[i]) && (((uintptr_t)en.src | (uintptr_t)en.dst | (uintptr_t)en.dst2) & 15) == 0) {   // (16-byte accesses)
             ta.tile_begin[ta.n] = tiles;
             ta.e[ta.n++] = en;
-            tiles += (descs[i].K / 32) * (descs[i].C / 64);
+            tiles += tiles_of(descs[i].K, descs[i].C, descs[i].R * descs[i].S);
         } else {
             en.begin = total;
             a.e[a.n++] = en;
@@ -646,7 +654,7 @@ int primia_conv_wgrad_finalize_many(const primia_conv_desc* descs, const int* c_
         if (tiled_ok(en.g, c_real[i]) && (((uintptr_t)en.src | (uintptr_t)en.dst | (uintptr_t)en.dst2) & 15) == 0) {   // (16-byte accesses)
             ta.tile_begin[ta.n] = tiles;
             ta.e[ta.n++] = en;
-            tiles += (descs[i].K / 32) * (descs[i].C / 64);
+            tiles += tiles_of(descs[i].K, descs[i].C, descs[i].R * descs[i].S);
         } else {
             en.begin = total;
             a.e[a.n++] = en;
@@ -693,7 +701,7 @@ int primia_conv_sgd_step_many(const primia_conv_desc* descs, const int* c_real, 
         en.C = g.C; en.K = g.K; en.klen = g.klen; en.RS = g.R * g.S;
         en.acc = dw_acc[i]; en.grad = dw_oihw[i]; en.w = w_oihw[i]; en.wf = w_fwd[i]; en.wd = w_dgrad[i];
         ta.tile_begin[ta.n++] = tiles;
-        tiles += (g.K / (en.RS == 9 ? 16 : 32)) * (g.C / 64);
+        tiles += tiles_of(g.K, g.C, en.RS);
     }
     ta.tile_begin[ta.n] = tiles;
     hipStream_t st = (hipStream_t)stream;
