@@ -445,6 +445,18 @@ int primia_gn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
                   const float* save_mean, const float* save_invstd, float* ps_dgamma, float* ps_dbeta,
                   int N, int HW, int C, int G, int relu, void* workspace, int64_t workspace_bytes,
                   int dtype, primia_stream_t stream);
+/* Residual layers, z = relu(gn(y) + residual) (BasicBlock.forward, torchlib/models.py:238-247 with the GroupNorm
+ * norm_layer of train.py:308): the forward pass also writes one mask byte per 16-byte chunk (bit i = stored z_i > 0)
+ * and the backward passes read that byte instead of z — 1/16 of the bytes; with g_out = NULL the masked gradient is not
+ * written either (primia_conv2d_dgrad_masked_acc applies the mask to the residual gradient itself).  Same results as
+ * primia_gn_fwd(relu = 1) / primia_gn_bwd(relu = 1), bit for bit. */
+int primia_gn_fwd_mask(const void* y, const void* residual, void* z, uint8_t* relu_mask, const float* gamma,
+                       const float* beta, float* save_mean, float* save_invstd, int N, int HW, int C, int G,
+                       float eps, void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream);
+int primia_gn_bwd_mask(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
+                       const float* gamma, const float* save_mean, const float* save_invstd, float* ps_dgamma,
+                       float* ps_dbeta, int N, int HW, int C, int G, void* workspace, int64_t workspace_bytes,
+                       int dtype, primia_stream_t stream);
 /* The same for z = relu(gn(y)) WITHOUT a residual: the ReLU mask is recomputed from y (the value the forward pass
  * rounded, one shared expression), so z is not read — two tensor reads instead of three in both passes.  Replaces the
  * autograd of F.relu(GroupNorm(y)) (torchlib/models.py:362-364 norm_layer hook, :238-240 forward). */

@@ -92,6 +92,7 @@ struct GnBwdFn {
     // is a function of y alone — the pass then reads two tensors instead of three
     const float* gamma;   // both set: recompute the mask
     const float* beta;
+    const uint8_t* mask;  // or: one byte per 16-byte chunk written by the forward pass (bit i = stored z_i > 0)
     // a thread's sample and channels never change: their group statistics are fetched ONCE (the first version divided
     // by cpg and loaded both statistics per element and row)
     float k_mean[Chunk<T>::N], k_invstd[Chunk<T>::N], k_s[Chunk<T>::N], k_b[Chunk<T>::N];
@@ -117,6 +118,10 @@ struct GnBwdFn {
             Chunk<T>::unpack(*(const u32x4*)(z + off), vz);
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        } else if (mask) {
+            const unsigned m = mask[off / CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vg[i] = (m >> i) & 1u ? vg[i] : 0.f;
         } else if (gamma) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = gn_relu_open<T>(vy[i], k_mean[i], k_s[i], k_b[i]) ? vg[i] : 0.f;
@@ -272,7 +277,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ y, const T* __restrict__ res,
                                                        T* __restrict__ z, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ mean,
-                                                       const float* __restrict__ invstd, int HW, int C, int G, int relu) {
+                                                       const float* __restrict__ invstd, int HW, int C, int G, int relu,
+                                                       uint8_t* __restrict__ mask_out = nullptr) {
     constexpr int CH = Chunk<T>::N;
     const int cpr = C / CH, cpg = C / G;
     const int n = blockIdx.y;
@@ -304,6 +310,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const T* __restrict__ y, 
             for (int i = 0; i < CH; ++i) v[i] = fmaxf(v[i], 0.f);
         }
         *(u32x4*)(z + (base + q) * CH) = Chunk<T>::pack(v);
+        if (mask_out) {   // bit i = (stored z_i > 0): the backward passes of a residual layer read it instead of z
+            unsigned m = 0;
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                bool open = v[i] > 0.f;
+                if constexpr (sizeof(T) == 2) open = open && f32_to_bf16(v[i]) != 0;
+                m |= (open ? 1u : 0u) << i;
+            }
+            mask_out[base + q] = (uint8_t)m;
+        }
     }
 }
 
@@ -314,7 +330,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ beta_mask,   // set: mask from y
                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
                                                            const float* __restrict__ gA, const float* __restrict__ gB,
-                                                           float inv_m, int HW, int C, int G) {
+                                                           float inv_m, int HW, int C, int G,
+                                                           const uint8_t* __restrict__ mask = nullptr) {
     constexpr int CH = Chunk<T>::N;
     const int cpr = C / CH, cpg = C / G;
     const int n = blockIdx.y;
@@ -342,6 +359,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
             Chunk<T>::unpack(*(const u32x4*)(z + (base + q) * CH), vz);
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = vz[i] > 0.f ? vg[i] : 0.f;
+        } else if (mask) {
+            const unsigned m = mask[base + q];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) vg[i] = (m >> i) & 1u ? vg[i] : 0.f;
         } else if (beta_mask) {
 #pragma unroll
             for (int i = 0; i < CH; ++i) vg[i] = gn_relu_open<T>(vy[i], km[i], ki[i] * kg[i], kbeta[i]) ? vg[i] : 0.f;
@@ -666,21 +687,23 @@ static void gn_stats(const void* y, float* mean, float* invstd, int N, int HW, i
 
 template <typename T>
 static int gn_fwd_impl(const void* y, const void* res, void* z, const float* gamma, const float* beta, float* mean,
-                       float* invstd, int N, int HW, int C, int G, float eps, int relu, float* partials, hipStream_t st) {
+                       float* invstd, int N, int HW, int C, int G, float eps, int relu, float* partials, hipStream_t st,
+                       uint8_t* mask_out = nullptr) {
     gn_stats<T>(y, mean, invstd, N, HW, C, G, eps, partials, st);
     gn_apply_kernel<T><<<gn_sample_grid(N, HW, C / Chunk<T>::N), 256, 0, st>>>((const T*)y, (const T*)res, (T*)z, gamma, beta,
-                                                                               mean, invstd, HW, C, G, relu);
+                                                                               mean, invstd, HW, C, G, relu, mask_out);
     return launch_status();
 }
 
 template <typename T>
 static int gn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, void* g_out, const float* gamma,
                        const float* mean, const float* invstd, float* ps_dgamma, float* ps_dbeta, int N, int HW, int C,
-                       int G, int relu, float* partials, hipStream_t st, const float* beta_mask = nullptr) {
+                       int G, int relu, float* partials, hipStream_t st, const float* beta_mask = nullptr,
+                       const uint8_t* mask = nullptr) {
     const int rps = (HW + kGnSlabs - 1) / kGnSlabs;
     const int nslab = (HW + rps - 1) / rps;
     GnBwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, mean, invstd, G, C / G,
-                 beta_mask ? gamma : nullptr, beta_mask, {}, {}, {}, {}};
+                 beta_mask ? gamma : nullptr, beta_mask, mask, {}, {}, {}, {}};
     float* gA = partials + (long)N * nslab * 2 * C;  // group sums live behind the partials
     float* gB = gA + (long)N * G;
     if (gn_sample_blocks(N, C, Chunk<T>::N)) {
@@ -693,7 +716,7 @@ static int gn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
     }
     gn_bwd_apply_kernel<T><<<gn_sample_grid(N, HW, C / Chunk<T>::N), 256, 0, st>>>(
         (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, beta_mask, mean, invstd, gA, gB,
-        (float)(1.0 / ((double)HW * (C / G))), HW, C, G);
+        (float)(1.0 / ((double)HW * (C / G))), HW, C, G, mask);
     return launch_status();
 }
 
@@ -765,6 +788,39 @@ int primia_gn_bwd(const void* y, const void* z, const void* dz, void* dy, void* 
     if (dtype == PRIMIA_BF16)
         return gn_bwd_impl<bf16>(y, z, dz, dy, g_out, gamma, save_mean, save_invstd, ps_dgamma, ps_dbeta, N, HW, C, G,
                                  relu, (float*)workspace, st);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_gn_fwd_mask(const void* y, const void* residual, void* z, uint8_t* relu_mask, const float* gamma,
+                       const float* beta, float* save_mean, float* save_invstd, int N, int HW, int C, int G, float eps,
+                       void* workspace, int64_t workspace_bytes, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && residual && z && relu_mask && gamma && beta && save_mean && save_invstd && workspace);
+    PRIMIA_REQUIRE(gn_shape_ok(N, HW, C, G, dtype));
+    if (workspace_bytes < primia_gn_workspace_bytes(N, C, G)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return gn_fwd_impl<float>(y, residual, z, gamma, beta, save_mean, save_invstd, N, HW, C, G, eps, 1,
+                                  (float*)workspace, st, relu_mask);
+    if (dtype == PRIMIA_BF16)
+        return gn_fwd_impl<bf16>(y, residual, z, gamma, beta, save_mean, save_invstd, N, HW, C, G, eps, 1,
+                                 (float*)workspace, st, relu_mask);
+    return PRIMIA_ERR_ARG;
+}
+
+int primia_gn_bwd_mask(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
+                       const float* gamma, const float* save_mean, const float* save_invstd, float* ps_dgamma,
+                       float* ps_dbeta, int N, int HW, int C, int G, void* workspace, int64_t workspace_bytes, int dtype,
+                       primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && relu_mask && dz && dy && gamma && save_mean && save_invstd && ps_dgamma && ps_dbeta && workspace);
+    PRIMIA_REQUIRE(gn_shape_ok(N, HW, C, G, dtype));
+    if (workspace_bytes < primia_gn_workspace_bytes(N, C, G)) return PRIMIA_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        return gn_bwd_impl<float>(y, nullptr, dz, dy, g_out, gamma, save_mean, save_invstd, ps_dgamma, ps_dbeta, N, HW, C, G,
+                                  0, (float*)workspace, st, nullptr, relu_mask);
+    if (dtype == PRIMIA_BF16)
+        return gn_bwd_impl<bf16>(y, nullptr, dz, dy, g_out, gamma, save_mean, save_invstd, ps_dgamma, ps_dbeta, N, HW, C, G,
+                                 0, (float*)workspace, st, nullptr, relu_mask);
     return PRIMIA_ERR_ARG;
 }
 

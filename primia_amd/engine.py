@@ -381,6 +381,13 @@ class ResNet18Engine:
         g, be = self.views[b + ".weight"], self.views[b + ".bias"]
         if self.norm == "group":  # identical in train and eval mode: no running statistics
             sm, si = self.save[b]
+            if self.training and residual is not None and relu and self.use_relu_masks and self.gn_relu_masks:
+                # residual layer: also write the 1-bit ReLU mask the backward passes read instead of z
+                if b not in self.relu_masks:
+                    self.relu_masks[b] = torch.empty(y.numel() * y.element_size() // 16, dtype=torch.uint8, device=y.device)
+                call("primia_gn_fwd_mask", y, residual, z, self.relu_masks[b], g, be, sm, si, self.N, M // self.N, C,
+                     self.groups, BN_EPS, self.bn_ws, self.bn_ws_bytes, self.dt)
+                return
             call("primia_gn_fwd", y, residual, z, g, be, sm, si, self.N, M // self.N, C, self.groups, BN_EPS, int(relu),
                  self.bn_ws, self.bn_ws_bytes, self.dt)
             return
@@ -581,6 +588,11 @@ class ResNet18Engine:
                 # z = relu(gn(y)), no residual: the mask is recomputed from y, z is not read
                 call("primia_gn_relu_bwd", y, dz, dy, self.views[b + ".weight"], self.views[b + ".bias"], sm, si, psg, psb,
                      self.N, y.shape[0] // self.N, C, self.groups, self.bn_ws, self.bn_ws_bytes, self.dt)
+            elif relu and g_out is not None and b in self.relu_masks:
+                # residual layer: mask bytes instead of z; keep_g = False: the masked gradient is not written either
+                call("primia_gn_bwd_mask", y, self.relu_masks[b], dz, dy, g_out if keep_g else None,
+                     self.views[b + ".weight"], sm, si, psg, psb, self.N, y.shape[0] // self.N, C, self.groups, self.bn_ws,
+                     self.bn_ws_bytes, self.dt)
             else:
                 call("primia_gn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, psg, psb, self.N,
                      y.shape[0] // self.N, C, self.groups, int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
@@ -613,6 +625,8 @@ class ResNet18Engine:
 
     wgrad_pair = os.environ.get("PRIMIA_WGRAD_PAIR", "1") != "0"
     gn_relu_recompute = os.environ.get("PRIMIA_GN_RELU_RECOMPUTE", "1") != "0"
+    # GroupNorm residual layers with the BatchNorm path's 1-bit ReLU masks (and its mask-applying accumulate dgrad)
+    gn_relu_masks = os.environ.get("PRIMIA_GN_RELU_MASKS", "1") != "0"
     gn_stem_fused = os.environ.get("PRIMIA_GN_STEM_FUSED", "1") != "0"
     wgrad_group = os.environ.get("PRIMIA_WGRAD_GROUP", "1") != "0"
     # (all layers at the end of the backward pass: measured no better than the per-stage groups — 5.16 vs 5.14 ms; by then
@@ -722,7 +736,7 @@ class ResNet18Engine:
             # bn2 (+residual, relu): dy2, and the masked gradient g written back over dout — unless this is an identity
             # block whose conv1 data gradient can mask the old values itself (one tensor write less)
             b2 = bn_name(blk.conv2.name)
-            masked_acc = (blk.down is None and self.masked_acc_ok.get(blk.conv1.name, False) and self.norm == "batch"
+            masked_acc = (blk.down is None and self.masked_acc_ok.get(blk.conv1.name, False)
                           and b2 in self.relu_masks and not self.bwd_sums)
             # transition block: bn2 and the downsample BatchNorm share the incoming gradient -> ONE fused backward
             bn_pair = (blk.down is not None and self.pair_dgrad and self.bn_pair and self.norm == "batch"

@@ -279,3 +279,32 @@ def test_dp_step_with_kept_tiles_matches_the_two_pass_form(cuda):
     a, b = out
     assert rel(a[0], b[0]) < 1e-9 and rel(a[1], b[1]) < 1e-6
     assert rel(a[2], b[2]) < 2e-2
+
+
+@pytest.mark.parametrize("dtype,batch,size", [(torch.float32, 4, 64), (torch.bfloat16, 8, 64), (torch.bfloat16, 130, 32)])
+def test_groupnorm_relu_masks_give_the_same_bits(cuda, dtype, batch, size):
+    """GroupNorm residual layers on 1-bit ReLU masks (primia_gn_fwd_mask / primia_gn_bwd_mask, identity blocks through
+    primia_conv2d_dgrad_masked_acc: z is not read and the masked gradient not written) against the z-reading chain
+    (primia_gn_fwd / primia_gn_bwd): logits, every gradient and the DP-SGD clipped sums bit for bit."""
+    spec = rs.resnet18_spec(3, 3, size, "max")
+    torch.manual_seed(31)
+    sd = rs.init_state_dict(spec, "group")
+    g = torch.Generator().manual_seed(32)
+    x = torch.randn(batch, 3, size, size, generator=g).to(cuda)
+    y = torch.randint(0, 3, (batch,), generator=g).to(cuda)
+    out = []
+    for masks in (True, False):
+        eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=dtype, device=cuda, norm="group")
+        eng.gn_relu_masks = masks
+        eng.load_state_dict(sd)
+        eng.forward(x)
+        eng.loss_backward(y)
+        assert (len(eng.relu_masks) == 8) == masks
+        plain = (eng.logits.clone(), eng.grads.clone())
+        eng.forward(x)
+        eng.dp_loss_backward(y, 1.0, 0.0, noise=torch.zeros(eng.P, device=cuda))
+        out.append(plain + (eng.grads.clone(), eng.dp_stats["sq_norms"].clone()))
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert torch.equal(a, b)
+    # (the fp32 norm pass adds its squares with atomics: equal to fp64 rounding, not to the bit)
+    assert torch.allclose(out[0][3], out[1][3], rtol=1e-10, atol=0.0)
