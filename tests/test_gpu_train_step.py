@@ -177,7 +177,10 @@ def test_bf16_full_size_step_against_oracle(cuda):
       1. logits within 3e-2 and loss within 2e-3 of the fp32 CPU oracle on the same batch;
       2. every convolution at full size on the ENGINE'S OWN operands: forward output within 3e-3 of
          conv2d(x, w) in fp32 (= one bf16 rounding of the result), weight gradient within 1e-4 of
-         conv2d_weight(x, dy), data gradient (where it lands in a buffer of its own) within 3e-3;
+         conv2d_weight(x, dy), data gradient (where it lands in a buffer of its own; the conv1 + downsample pair of the
+         transition blocks: test_transition_dgrad_pair_at_full_size) within 3e-3; every block's BatchNorm forward passes (batch statistics, ReLU, residual /
+         downsample branch) within 3e-3 and bn1's backward pass (dy within 3e-3, dgamma / dbeta within 1e-4) from the
+         buffers the kernels read and wrote — each link of the backward chain is held at full size, not only the ends;
       3. end-to-end gradients against the fp32 oracle: bf16 STORAGE makes them deviate by 25-50 % per tensor on this
          randomly initialised network — the CPU oracle with nothing but bf16 rounding at the engine's storage points
          (O.forward(bf16_storage=True)) is as far from the fp32 oracle as the engine is — so the bound is that band,
@@ -218,6 +221,37 @@ def test_bf16_full_size_step_against_oracle(cuda):
                 dxref = torch.nn.grad.conv2d_input(xc.shape, w, dyc, d.stride, d.pad)
                 dx = _nchw(eng.t[f"{p}.{dxn}"], B)
                 assert (dx - dxref).norm() <= 3e-3 * dxref.norm(), f"{c.name} dgrad"
+        # ---- 2b. the BatchNorm passes of the block at full size, on the engine's own operands -------------------------
+        # forward: a1 = relu(bn1(y1)), out = relu(bn2(y2) + residual) with batch statistics (one bf16 rounding: 3e-3);
+        # backward of bn1 from the buffers it read (da1 = conv2's data gradient, y1) and wrote (dy1, dgamma, dbeta)
+        def bn_ref(yt, name):
+            yv = _nchw(yt, B).double()
+            mean = yv.mean((0, 2, 3), keepdim=True)
+            invstd = (yv.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-5).rsqrt()
+            gam = sd[name + ".weight"].double().view(1, -1, 1, 1)
+            bet = sd[name + ".bias"].double().view(1, -1, 1, 1)
+            xh = (yv - mean) * invstd
+            return xh, invstd, gam, xh * gam + bet
+
+        xh1, invstd1, gam1, z1 = bn_ref(eng.t[p + ".y1"], rs.bn_name(blk.conv1.name))
+        a1 = _nchw(eng.t[p + ".a1"], B).double()
+        assert (a1 - z1.clamp_min(0)).norm() <= 3e-3 * a1.norm(), f"{p} bn1 forward"
+        _, _, _, z2 = bn_ref(eng.t[p + ".y2"], rs.bn_name(blk.conv2.name))
+        if blk.down is None:
+            res = _nchw(xin, B).double()
+        else:   # the downsample branch's BatchNorm output is rounded to the storage type before the add
+            res = bn_ref(eng.t[p + ".yd"], rs.bn_name(blk.down.name))[3].float().bfloat16().double()
+        outv = _nchw(eng.t[p + ".out"], B).double()
+        assert (outv - (z2 + res).clamp_min(0)).norm() <= 3e-3 * outv.norm(), f"{p} bn2 forward"
+        gin = _nchw(eng.t[p + ".da1"], B).double() * (a1 > 0)
+        m = gin.numel() / gin.shape[1]
+        dbeta, dgamma = gin.sum((0, 2, 3)), (gin * xh1).sum((0, 2, 3))
+        dyref = gam1 * invstd1 * (gin - dbeta.view(1, -1, 1, 1) / m - xh1 * dgamma.view(1, -1, 1, 1) / m)
+        dy1 = _nchw(eng.t[p + ".dy1"], B).double()
+        assert (dy1 - dyref).norm() <= 3e-3 * dyref.norm(), f"{p} bn1 backward {((dy1 - dyref).norm() / dyref.norm()).item():.2e}"
+        b1 = rs.bn_name(blk.conv1.name)
+        assert (eng.gviews[b1 + ".bias"].double().cpu() - dbeta).norm() <= 1e-4 * dbeta.norm() + 1e-9, f"{p} bn1 dbeta"
+        assert (eng.gviews[b1 + ".weight"].double().cpu() - dgamma).norm() <= 1e-4 * dgamma.norm() + 1e-9, f"{p} bn1 dgamma"
     # ---- 3. end to end ------------------------------------------------------------------------------------------------
     osd = {k: v.clone() for k, v in sd.items()}
     for k in O.param_keys(osd):
@@ -406,3 +440,35 @@ def test_fused_sgd_tail_gives_the_same_bits(cuda, dtype, batch, size):
     a.adam_step(1e-3)
     b.adam_step(1e-3)
     assert torch.equal(a.flat, b.flat)
+
+
+def test_transition_dgrad_pair_at_full_size(cuda):
+    """conv1 (3x3 / 2) + downsample (1x1 / 2) data gradients of the three transition blocks in one pass
+    (primia_conv2d_dgrad_pair) at batch 256 on the engine's weight copies, against conv2d_input in fp32: 3e-3 (one bf16
+    rounding of the sum).  In the training step this buffer is consumed in place by the block before, so the full-size
+    step test cannot look at it afterwards."""
+    from primia_amd._lib import call
+
+    B, S = 256, 224
+    torch.manual_seed(44)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, S, "max"))
+    eng = ResNet18Engine(B, 3, 3, S, "max", dtype=torch.bfloat16, device=cuda)
+    eng.load_state_dict(sd)
+    g = torch.Generator().manual_seed(45)
+    for blk in eng.spec.blocks:
+        if blk.down is None:
+            continue
+        c1, cd = eng.convs[blk.conv1.name], eng.convs[blk.down.name]
+        d = c1.desc
+        M = B * d.Ho * d.Wo
+        dy1 = torch.randn(M, d.K, generator=g).bfloat16().to(cuda)
+        dyd = torch.randn(M, d.K, generator=g).bfloat16().to(cuda)
+        dx = torch.empty(B * d.H * d.W, d.C, dtype=torch.bfloat16, device=cuda)
+        call("primia_conv2d_dgrad_pair", c1.desc, dy1, c1.w_dgrad, cd.desc, dyd, cd.w_dgrad, dx, eng.dt)
+        w1 = sd[blk.conv1.name + ".weight"].bfloat16().float()
+        wd = sd[blk.down.name + ".weight"].bfloat16().float()
+        xs = (B, d.C, d.H, d.W)
+        ref = (torch.nn.grad.conv2d_input(xs, w1, _nchw(dy1, B), d.stride, d.pad)
+               + torch.nn.grad.conv2d_input(xs, wd, _nchw(dyd, B), cd.desc.stride, cd.desc.pad))
+        got = _nchw(dx, B)
+        assert (got - ref).norm() <= 3e-3 * ref.norm(), f"{blk.prefix}: {((got - ref).norm() / ref.norm()).item():.2e}"
