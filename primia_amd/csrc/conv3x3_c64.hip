@@ -68,8 +68,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // values in the write-back phase (coalesced row loads, fp32 add, ONE rounding)
     constexpr int OPIX = ACC ? 256 : 128;  // bytes per staged pixel row
     constexpr int OUTB = 64 * OPIX;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE + 2 * OUTB
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE + 2 * OUTB (+ 8 KiB of old rows: ACC)
     char* const sout = smem + STAGES * STAGE;
+    // accumulate form: the OLD rows of the patch being computed, fetched by LDS-DMA one iteration before the write-back
+    // adds them (64 pixels x 128 B, row group g at g * 1 KiB, lane-linear: pixel lane / 8, 16-B chunk lane % 8)
+    char* const sold = sout + 2 * OUTB;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 1, ph = wave & 1;
@@ -240,6 +243,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.f;
 
+    // Accumulate form: the old rows (and their ReLU-mask bytes) of the patch the write-back cursor points at, requested
+    // one iteration AHEAD of the write-back that adds them — the first version loaded them inside the write-back, a full
+    // memory latency per stage in front of the stores, with the compiler's conservative vmcnt(0) draining the DMA ring
+    // on top (93 us against 58 us for the plain form, for 103 MB more).  The rows travel by LDS-DMA (a row group = 8
+    // pixels x 128 B = one instruction, no registers across the matrix phase: the kernel sits at 242 of 256), the mask
+    // bytes by an inline-asm byte load the compiler's wait counting does not see; both are older than the halo pieces
+    // requested after them, so the counted wait at the top of the next iteration covers them.
+    c64_i32x4 rsrc_dst = rsrc;
+    unsigned mk[2] = {0xffu, 0xffu};
+    if constexpr (ACC) {
+        const unsigned long long a = (unsigned long long)p.dst;
+        rsrc_dst[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rsrc_dst[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+    }
+    auto prefetch_old = [&]() {
+        if constexpr (ACC) {
+            const int px = lane >> 3, c16 = lane & 7;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int g = 2 * wave + q;
+                const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
+                const bool live = cw.t < t1 && ho < p.H && wo < p.W;
+                const unsigned eoff = (unsigned)(((cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8);   // elements (< 2^31)
+                const unsigned voff = live ? eoff * 2u : kOob;
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + g * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(voff), "s"(rsrc_dst), "s"(m0v) : "memory");
+                if (p.acc_mask) {
+                    const uint8_t* mp = p.acc_mask + (live ? (eoff >> 3) : 0u);
+                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(mk[q]) : "v"(mp) : "memory");
+                }
+            }
+        }
+    };
+
     auto writeback = [&](int obuf) {
         const int px = lane >> 3, c16 = lane & 7;  // pixel of the row, 16-B chunk
         bool live[2];
@@ -251,13 +289,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
             live[q] = cw.t < t1 && ho < p.H && wo < p.W;
             gp[q] = p.dst + ((long)(cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8;
-            // accumulate form: both old rows are requested before anything is stored — a load waited for AFTER a
-            // store would also wait for that store to complete (one vmcnt for both)
             old[q] = u32x4{0, 0, 0, 0};
-            if (ACC && live[q]) {
-                old[q] = *(const u32x4*)gp[q];
+            if constexpr (ACC) {
+                // (requested by prefetch_old() an iteration ago, by THIS wave: no barrier between the DMA and this read)
+                old[q] = *(const u32x4*)(sold + g * 1024 + lane * 16);
                 if (p.acc_mask) {   // old value = gradient through a ReLU whose mask is applied here, not stored
-                    const unsigned m = p.acc_mask[(gp[q] - p.dst) >> 3];
+                    const unsigned m = mk[q];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
                         old[q][k] &= ((m >> (2 * k)) & 1u ? 0x0000ffffu : 0u) | ((m >> (2 * k + 1)) & 1u ? 0xffff0000u : 0u);
@@ -305,6 +342,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // images, the accumulate form (its loads are waited for by the compiler, conservatively) and the last stage use
     // vmcnt(0).
     const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !(p.debug & 3);
+    prefetch_old();            // patch 0's old rows: older than every halo piece, landed by the first counted wait
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nstages) stage(s);
@@ -328,12 +366,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the other waves read them (a raw s_barrier does not wait for the wave's own outstanding ds_write; with two
         // blocks per CU competing for the LDS the write-back occasionally read a stale 1-KiB row)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if constexpr (ACC) asm volatile("" : "+v"(mk[0]), "+v"(mk[1])::"memory");   // (the mask bytes are valid from here)
         __builtin_amdgcn_s_barrier();
-        if (s > 0) writeback((s - 1) & 1);
+        if (s > 0) {
+            writeback((s - 1) & 1);
+            prefetch_old();    // the cursor now points at patch s, written back in iteration s + 1
+        }
         if (s + STAGES - 1 < nstages && !(p.debug & 2)) stage(nxt);
         compute(cur, s & 1);
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+    }
+    if constexpr (ACC) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(mk[0]), "+v"(mk[1])::"memory");
     }
     __syncthreads();
     writeback((nstages - 1) & 1);
@@ -395,10 +441,10 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     // plain form: a 4-deep ring (68 KiB per block, two blocks per CU) keeps 78 KB per CU in flight instead of 52
     static const int deep = getenv("PRIMIA_C64_STAGES") ? atoi(getenv("PRIMIA_C64_STAGES")) : 4;
     const int stages = (!accumulate && deep == 4) ? 4 : 3;
-    const size_t lds = (size_t)stages * 13 * 1024 + 2 * 64 * (accumulate ? 256 : 128);
+    const size_t lds = (size_t)stages * 13 * 1024 + 2 * 64 * (accumulate ? 256 : 128) + (accumulate ? 8192 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        const int lds_plain = 3 * 13 * 1024 + 2 * 64 * 128, lds_acc = 3 * 13 * 1024 + 2 * 64 * 256;
+        const int lds_plain = 3 * 13 * 1024 + 2 * 64 * 128, lds_acc = 3 * 13 * 1024 + 2 * 64 * 256 + 8192;
         const int lds_plain4 = 4 * 13 * 1024 + 2 * 64 * 128;
         if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_plain) != hipSuccess ||
