@@ -102,6 +102,15 @@ int primia_conv_sgd_step_many(const primia_conv_desc* descs_host, const int* c_r
                               float* const* w_oihw_host, void* const* w_fwd_host, void* const* w_dgrad_host,
                               int n, float lr, float weight_decay, int dtype, primia_stream_t stream);
 
+/* A transition block's two forward convolutions of the same x — conv1 (3x3, stride 2) and the downsample (1x1, stride 2;
+ * torchlib/models.py:236-247 `identity = self.downsample(x)` beside `out = self.conv1(x)`) — in ONE launch, each with its
+ * per-tile BatchNorm partial sums (stat_sums may be NULL) exactly as primia_conv2d_fwd_stats writes them: same tiles,
+ * same results bit for bit.  primia_conv_fwd_pair_ok() = 1 where the pair is served (bf16, K % 128 == 0). */
+int primia_conv_fwd_pair_ok(const primia_conv_desc* d, const primia_conv_desc* d_ds, int dtype);
+int primia_conv2d_fwd_stats_pair(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
+                                 float* stat_sums, const primia_conv_desc* d_ds, const void* w_fwd_ds, void* y_ds,
+                                 float* stat_sums_ds, int dtype, primia_stream_t stream);
+
 /* y[N,Ho,Wo,K] = conv(x[N,H,W,C], w). */
 int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y,
                       int dtype, primia_stream_t stream);

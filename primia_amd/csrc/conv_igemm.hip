@@ -97,7 +97,7 @@ __device__ __forceinline__ ig_i32x4 ig_rsrc(const void* base, long bytes) {
 
 // WM x WN waves per block (pixels x channels); STAGES LDS buffers (STAGES-1 k-steps of DMA in flight).
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool DGRAD, bool STEM>
-__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p) {
+__device__ __forceinline__ void conv_igemm_body(const IgemmParams& p, int bid, int nblk) {
     constexpr int NW = WM * WN, NT = 64 * NW;
     constexpr int KE = MmaTraits<T>::KE;
     constexpr int CH = Elem<T>::kPerChunk;  // elements per 16-B chunk
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
     const int lane = tid & 63, wid = tid >> 6;
     const int wm = wid / WN, wn = wid % WN;  // wave position: pixels, channels
 
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int tile = xcd_remap(bid, nblk);
     const int tn = tile % p.ntile_n;
     int tm = tile / p.ntile_n;
     const int n0 = tn * BN;
@@ -705,23 +705,66 @@ __global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p)
 }
 
 template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool DGRAD, bool STEM>
-static int launch_igemm(const IgemmParams& p, hipStream_t st) {
-    IgemmParams q = p;
-    q.ntile_n = p.Nd / BN;
-    int ntm = ceil_div(p.Md, BM);
-    if (DGRAD && p.s2_classes) {
-        q.ntm_class = ceil_div((long)p.Nb * (p.Hd / 2) * (p.Wd / 2), BM);
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_kernel(IgemmParams p) {
+    conv_igemm_body<T, BM, BN, WM, WN, STAGES, DGRAD, STEM>(p, blockIdx.x, gridDim.x);
+}
+
+// Two forward convolutions that read the same x in ONE launch (a transition block's 3x3 / 2 conv1 and its 1x1 / 2
+// downsample): blocks [0, na) walk the tiles of a, the rest those of b.  The downsample alone is a launch of short
+// tiles (one or a few k-steps) that never fills the chip for long — 24 / 15 / 11 us for 3.3 GFLOP each — behind the
+// last, 77 %-full round of conv1's tiles; its tiles now run in that tail.
+struct IgemmPair {
+    IgemmParams a, b;
+    int na;
+};
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+__global__ __launch_bounds__(64 * WM * WN) void conv_igemm_pair_kernel(IgemmPair pp) {
+    const bool first = (int)blockIdx.x < pp.na;
+    conv_igemm_body<T, BM, BN, WM, WN, STAGES, false, false>(first ? pp.a : pp.b, first ? (int)blockIdx.x : (int)blockIdx.x - pp.na,
+                                                             first ? pp.na : (int)gridDim.x - pp.na);
+}
+
+// per-launch fields derived from the tile configuration; returns the grid
+template <int BM, int BN, bool DGRAD>
+static int igemm_finish_params(IgemmParams& q) {
+    q.ntile_n = q.Nd / BN;
+    int ntm = ceil_div(q.Md, BM);
+    if (DGRAD && q.s2_classes) {
+        q.ntm_class = ceil_div((long)q.Nb * (q.Hd / 2) * (q.Wd / 2), BM);
         ntm = 4 * q.ntm_class;
     }
-    {
-        const int Hc = (DGRAD && p.s2_classes) ? p.Hd >> 1 : p.Hd, Wc = (DGRAD && p.s2_classes) ? p.Wd >> 1 : p.Wd;
-        const long Mc = (DGRAD && p.s2_classes) ? (long)p.Nb * Hc * Wc : p.Md;
-        const long dmax = Hc > Wc ? Hc : Wc;
-        q.fastdiv = (Hc > 1 && Wc > 1 && (Mc + BM) * dmax < (1L << 32)) ? 1 : 0;
-        q.magicW = q.fastdiv ? (unsigned)(((1ULL << 32) + Wc - 1) / Wc) : 0u;
-        q.magicH = q.fastdiv ? (unsigned)(((1ULL << 32) + Hc - 1) / Hc) : 0u;
+    const int Hc = (DGRAD && q.s2_classes) ? q.Hd >> 1 : q.Hd, Wc = (DGRAD && q.s2_classes) ? q.Wd >> 1 : q.Wd;
+    const long Mc = (DGRAD && q.s2_classes) ? (long)q.Nb * Hc * Wc : q.Md;
+    const long dmax = Hc > Wc ? Hc : Wc;
+    q.fastdiv = (Hc > 1 && Wc > 1 && (Mc + BM) * dmax < (1L << 32)) ? 1 : 0;
+    q.magicW = q.fastdiv ? (unsigned)(((1ULL << 32) + Wc - 1) / Wc) : 0u;
+    q.magicH = q.fastdiv ? (unsigned)(((1ULL << 32) + Hc - 1) / Hc) : 0u;
+    return ntm * q.ntile_n;
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES>
+static int launch_igemm_pair(const IgemmParams& pa, const IgemmParams& pb, hipStream_t st) {
+    IgemmPair pp;
+    pp.a = pa;
+    pp.b = pb;
+    pp.na = igemm_finish_params<BM, BN, false>(pp.a);
+    const int nb = igemm_finish_params<BM, BN, false>(pp.b);
+    const size_t lds = (size_t)STAGES * (BM + BN) * 128;
+    auto kern = conv_igemm_pair_kernel<T, BM, BN, WM, WN, STAGES>;
+    static bool attr_set = false;
+    if (lds > 48 * 1024 && !attr_set) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set = true;
     }
-    const int grid = ntm * q.ntile_n;
+    kern<<<pp.na + nb, 64 * WM * WN, lds, st>>>(pp);
+    return launch_status();
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int STAGES, bool DGRAD, bool STEM>
+static int launch_igemm(const IgemmParams& p, hipStream_t st) {
+    IgemmParams q = p;
+    const int grid = igemm_finish_params<BM, BN, DGRAD>(q);
     const size_t lds = (size_t)STAGES * (BM + BN) * 128;
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN, STAGES, DGRAD, STEM>;
     static bool attr_set = false;  // once per instantiation (not per launch: keeps graph capture legal)
@@ -841,6 +884,51 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
 int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y, int dtype,
                       primia_stream_t stream) {
     return conv2d_fwd_impl(d, x, w_fwd, y, nullptr, dtype, stream);
+}
+
+// a transition block's conv1 (3x3 / 2) and downsample (1x1 / 2) forward in one launch: both on the bf16 implicit GEMM,
+// same input, output channels a multiple of 128
+static bool fwd_pair_shape(const ConvGeom& g, const ConvGeom& gd, int dtype) {
+    static const bool off = getenv("PRIMIA_FWD_PAIR") && getenv("PRIMIA_FWD_PAIR")[0] == '0';
+    if (off || dtype != PRIMIA_BF16 || g.stem || gd.stem) return false;
+    if (gd.N != g.N || gd.H != g.H || gd.W != g.W || gd.C != g.C || gd.Ho != g.Ho || gd.Wo != g.Wo) return false;
+    if (g.stride != 2 || gd.stride != 2 || g.R != 3 || g.S != 3 || gd.R != 1 || gd.S != 1 || gd.pad != 0) return false;
+    if (g.K % 128 || gd.K % 128) return false;
+    return (long)g.N * g.H * g.W * g.C < (1L << 31);
+}
+
+int primia_conv_fwd_pair_ok(const primia_conv_desc* d, const primia_conv_desc* d_ds, int dtype) {
+    ConvGeom g, gd;
+    if (!d || !d_ds || !g.init(*d) || !gd.init(*d_ds)) return PRIMIA_ERR_ARG;
+    return fwd_pair_shape(g, gd, dtype) ? 1 : 0;
+}
+
+int primia_conv2d_fwd_stats_pair(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stat_sums,
+                                 const primia_conv_desc* d_ds, const void* w_fwd_ds, void* y_ds, float* stat_sums_ds,
+                                 int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && d_ds && x && w_fwd && y && w_fwd_ds && y_ds);
+    ConvGeom g, gd;
+    PRIMIA_REQUIRE(g.init(*d) && gd.init(*d_ds));
+    if (!fwd_pair_shape(g, gd, dtype)) return PRIMIA_ERR_UNSUPPORTED;
+    auto fill = [&](IgemmParams& p, const ConvGeom& c, const void* w, void* out, float* sums) {
+        p.src = x; p.wt = w; p.dst = out;
+        p.Nb = c.N; p.Hd = c.Ho; p.Wd = c.Wo; p.Nd = c.K;
+        p.Hs = c.H; p.Ws = c.W; p.Cs = c.C;
+        p.R = c.R; p.S = c.S; p.stride = c.stride; p.pad = c.pad;
+        p.klen = c.klen;
+        p.nsteps = c.klen / 64;
+        p.Md = (long)c.N * c.Ho * c.Wo;
+        p.accumulate = 0;
+        p.stat_sums = sums;
+        p.stat_tiles = sums ? 1 : 0;
+        p.s2_classes = 0;
+        p.ntm_class = 0;
+        p.src2 = nullptr; p.wt2 = nullptr;
+    };
+    IgemmParams pa, pb;
+    fill(pa, g, w_fwd, y, stat_sums);
+    fill(pb, gd, w_fwd_ds, y_ds, stat_sums_ds);
+    return launch_igemm_pair<bf16, 128, 128, 4, 2, 2>(pa, pb, (hipStream_t)stream);
 }
 
 int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype) {

@@ -449,6 +449,24 @@ class ResNet18Engine:
         else:
             self._timed("fwd", c, lambda: call("primia_conv2d_fwd", c.desc, x, c.w_fwd, y, self.dt))
 
+    fwd_pair = os.environ.get("PRIMIA_FWD_PAIR", "1") != "0"
+
+    def _conv_fwd_pair(self, blk, x, y1, yd):
+        """conv1 + downsample of a transition block as one launch; False where the library does not serve the pair."""
+        c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
+        if getattr(c1, "pair_ok", None) is None:
+            c1.pair_ok = self.fwd_pair and query("primia_conv_fwd_pair_ok", c1.desc, cd.desc, self.dt) == 1
+        if not c1.pair_ok:
+            return False
+        stats = self.training and self.norm == "batch"
+        s1 = c1.sums if stats and (self.fuse_stats or blk.conv1.name in self.free_stats) else None
+        sd = cd.sums if stats and (self.fuse_stats or blk.down.name in self.free_stats) else None
+        if stats and (s1 is None or sd is None):
+            return False        # (a layer whose statistics come from a separate pass: keep the single launches)
+        self._timed("fwd", c1, lambda: call("primia_conv2d_fwd_stats_pair", c1.desc, x, c1.w_fwd, y1, s1, cd.desc, cd.w_fwd,
+                                            yd, sd, self.dt), extra_macs=self._macs(cd))
+        return True
+
     def forward(self, x_nchw):
         """x_nchw: fp32 [N, in_channels, S, S] on this GPU.  Returns fp32 logits [N, classes]."""
         N, S, t = self.N, self.spec.input_size, self.t
@@ -515,13 +533,17 @@ class ResNet18Engine:
         x = t["pool.out"]
         for blk in self.spec.blocks:
             p = blk.prefix
-            self._conv_fwd(blk.conv1.name, x, t[p + ".y1"])
+            # transition block: conv1 and the downsample read the same x — one launch (primia_conv2d_fwd_stats_pair)
+            down_done = blk.down is not None and self._conv_fwd_pair(blk, x, t[p + ".y1"], t[p + ".yd"])
+            if not down_done:
+                self._conv_fwd(blk.conv1.name, x, t[p + ".y1"])
             self._bn(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], None, True)
             self._conv_fwd(blk.conv2.name, t[p + ".a1"], t[p + ".y2"])
             idn = x
             if blk.down is not None and self.training and self.norm == "batch" and self.use_relu_masks and self.bn_pair:
                 # transition block: both BatchNorms in one apply pass (the downsample branch's output is never stored)
-                self._conv_fwd(blk.down.name, x, t[p + ".yd"])
+                if not down_done:
+                    self._conv_fwd(blk.down.name, x, t[p + ".yd"])
                 b2, bd = bn_name(blk.conv2.name), bn_name(blk.down.name)
                 y2 = t[p + ".y2"]
                 if b2 not in self.relu_masks:
@@ -543,7 +565,8 @@ class ResNet18Engine:
                 x = t[p + ".out"]
                 continue
             if blk.down is not None:
-                self._conv_fwd(blk.down.name, x, t[p + ".yd"])
+                if not down_done:
+                    self._conv_fwd(blk.down.name, x, t[p + ".yd"])
                 self._bn(blk.down.name, t[p + ".yd"], t[p + ".idn"], None, False)
                 idn = t[p + ".idn"]
             self._bn(blk.conv2.name, t[p + ".y2"], t[p + ".out"], idn, True)

@@ -472,3 +472,42 @@ def test_transition_dgrad_pair_at_full_size(cuda):
                + torch.nn.grad.conv2d_input(xs, wd, _nchw(dyd, B), cd.desc.stride, cd.desc.pad))
         got = _nchw(dx, B)
         assert (got - ref).norm() <= 3e-3 * ref.norm(), f"{blk.prefix}: {((got - ref).norm() / ref.norm()).item():.2e}"
+
+
+@pytest.mark.parametrize("batch,size", [(6, 64), (16, 224)])
+def test_transition_forward_pair_gives_the_same_bits(cuda, batch, size):
+    """conv1 (3x3 / 2) + downsample (1x1 / 2) of a transition block in one launch (primia_conv2d_fwd_stats_pair) against
+    the two single launches (primia_conv2d_fwd_stats): outputs and per-tile BatchNorm partials bit for bit (ragged last
+    tiles included), and the whole step with and without the pairing."""
+    from primia_amd._lib import call, query
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(batch, 3, size, size, generator=g).to(cuda)
+    y = torch.randint(0, 3, (batch,), generator=g).to(cuda)
+    res = []
+    for pair in (True, False):
+        eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.bfloat16, device=cuda)
+        torch.manual_seed(5)
+        eng.init_weights()
+        eng.fwd_pair = pair
+        eng.forward(x)
+        eng.loss_backward(y)
+        res.append((eng.logits.clone(), eng.grads.clone(), eng))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+    eng = res[0][2]
+    blocks = eng.spec.blocks
+    for i, blk in enumerate(blocks):
+        if blk.down is None:
+            continue
+        c1, cd = eng.convs[blk.conv1.name], eng.convs[blk.down.name]
+        assert query("primia_conv_fwd_pair_ok", c1.desc, cd.desc, eng.dt) == 1
+        xin = eng.t[blocks[i - 1].prefix + ".out"]
+        y1, yd = torch.empty_like(eng.t[blk.prefix + ".y1"]), torch.empty_like(eng.t[blk.prefix + ".yd"])
+        s1, sd = torch.zeros_like(c1.sums), torch.zeros_like(cd.sums)
+        call("primia_conv2d_fwd_stats", c1.desc, xin, c1.w_fwd, y1, s1, eng.dt)
+        call("primia_conv2d_fwd_stats", cd.desc, xin, cd.w_fwd, yd, sd, eng.dt)
+        p1, pd = torch.empty_like(y1), torch.empty_like(yd)
+        q1, qd = torch.zeros_like(s1), torch.zeros_like(sd)
+        call("primia_conv2d_fwd_stats_pair", c1.desc, xin, c1.w_fwd, p1, q1, cd.desc, cd.w_fwd, pd, qd, eng.dt)
+        assert torch.equal(p1.view(torch.int16), y1.view(torch.int16)) and torch.equal(pd.view(torch.int16), yd.view(torch.int16))
+        assert torch.equal(q1, s1) and torch.equal(qd, sd), blk.prefix
