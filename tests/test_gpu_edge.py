@@ -106,3 +106,45 @@ def test_xent_out_of_range_label_poisons_instead_of_reading_out_of_bounds(cuda):
         assert torch.isnan(loss).all() and torch.isnan(dl[2]).all()
     call("primia_xent_hard", logits, torch.tensor([0, 1, 2, 2, 1], device=cuda), cw, loss, dl, N, C)
     assert torch.isfinite(loss).all() and torch.isfinite(dl).all()
+
+
+def test_round3_fused_entry_points_refuse_what_they_do_not_serve(cuda):
+    """The fused forms added in round 3 answer with a query / an error code, never with a wrong result: the step tail
+    for a layer the tiles do not cover, the paired transition forward on shapes that are not a transition pair, empty
+    SGD range lists; primia_sgd_step_ranges equals primia_sgd_step on the ranges it is given and leaves the rest."""
+    import ctypes
+
+    from primia_amd._lib import query
+
+    stem = ConvDesc.make(1, 32, 32, 4, 64, 7, 7, 2, 3)
+    c33 = ConvDesc.make(2, 8, 8, 64, 128, 3, 3, 2, 1)
+    c11 = ConvDesc.make(2, 8, 8, 64, 128, 1, 1, 2, 0)
+    c33s1 = ConvDesc.make(2, 8, 8, 64, 128, 3, 3, 1, 1)
+    assert query("primia_conv_sgd_fusable", stem, 3) == 0
+    assert query("primia_conv_sgd_fusable", c33, 64) == 1 and query("primia_conv_sgd_fusable", c11, 64) == 1
+    assert query("primia_conv_fwd_pair_ok", c33, c11, _lib.PRIMIA_BF16) == 1
+    assert query("primia_conv_fwd_pair_ok", c33, c11, _lib.PRIMIA_F32) == 0      # bf16 only
+    assert query("primia_conv_fwd_pair_ok", c33s1, c11, _lib.PRIMIA_BF16) == 0   # not a stride-2 pair
+    x = torch.zeros(2 * 8 * 8 * 64, dtype=torch.bfloat16, device=cuda)
+    w = torch.zeros(128 * 9 * 64, dtype=torch.bfloat16, device=cuda)
+    y = torch.zeros(2 * 8 * 8 * 128, dtype=torch.bfloat16, device=cuda)
+    with pytest.raises(PrimiaError, match="PRIMIA_ERR_UNSUPPORTED"):
+        call("primia_conv2d_fwd_stats_pair", c33s1, x, w, y, None, c11, w, y, None, _lib.PRIMIA_BF16)
+    # the step tail refuses the stem filter (the caller asks primia_conv_sgd_fusable first)
+    one = lambda t: (ctypes.c_void_p * 1)(ctypes.c_void_p(t.data_ptr()))
+    f = torch.zeros(64 * 256, device=cuda)
+    with pytest.raises(PrimiaError, match="PRIMIA_ERR_UNSUPPORTED"):
+        call("primia_conv_sgd_step_many", (ConvDesc * 1)(stem), (ctypes.c_int * 1)(3), one(f), one(f), one(f), one(x), one(x), 1,
+             0.1, 0.0, _lib.PRIMIA_BF16)
+    # ranges: nothing to do is fine; two ranges = primia_sgd_step on each, the gap untouched
+    g = torch.Generator(device=cuda).manual_seed(3)
+    p0 = torch.randn(1000, device=cuda, generator=g)
+    gr = torch.randn(1000, device=cuda, generator=g)
+    call("primia_sgd_step_ranges", p0, gr, None, None, 0, 0.1, 0.0)
+    a, b = p0.clone(), p0.clone()
+    call("primia_sgd_step_ranges", a, gr, (ctypes.c_int64 * 2)(0, 500), (ctypes.c_int64 * 2)(128, 333), 2, 1e-2, 5e-4)
+    call("primia_sgd_step", b[:128], gr[:128], 128, 1e-2, 5e-4)
+    bb = b[500:833].clone(); gg = gr[500:833].clone()       # (16-byte aligned copies for the flat kernel)
+    call("primia_sgd_step", bb, gg, 333, 1e-2, 5e-4)
+    b[500:833] = bb
+    assert torch.equal(a, b)
