@@ -66,6 +66,9 @@ struct Lh2Params {
 #ifndef LH2_SWAP
 #define LH2_SWAP 0
 #endif
+#ifndef LH2_RF
+#define LH2_RF 1
+#endif
 #ifdef LH2_PROF
 #define LH2_MARK(slot)                                 \
     {                                                  \
@@ -413,7 +416,10 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
     int tri = 0;        // second-half ring slot of the step being loaded (t % 3)
     int tri_m = 0;      // ... of the step whose matrix segment runs next
     int hbuf = 0;       // halo buffer of the chunk being loaded
-    auto load_segment = [&](auto tap_tag) {
+    // LH2_RF = 1: a load segment requests its fragment reads FIRST and its LDS-DMA pieces behind them — a piece blocks the
+    // wave while the CU's memory queue is full (the four waves of a half issue theirs at the same moment), and the LDS
+    // pipe serves the reads meanwhile; with the pieces in front, the reads only started once the last piece was accepted
+    auto load_issue = [&](auto tap_tag) {
         constexpr int tap = decltype(tap_tag)::value;
         if (!(LH2_DBG & 8)) {
             const char* w0p = smem + kL2OffA0 + par * kL2Half;
@@ -430,6 +436,8 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
                 b[j] = *(const bf16x8_t*)(smem + (bad[j] + j * 1024));
             }
         }
+    };
+    auto load_finish = [&]() {
         // (the builtin, not inline asm: the compiler's own wait-count bookkeeping then knows these reads have landed and
         // puts no further waits for them between the MFMAs of the matrix segment)
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
@@ -524,6 +532,10 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
             auto step = [&](auto tap_tag) {
                 constexpr int tap = decltype(tap_tag)::value;
                 if constexpr (ISA) {
+                    if (LH2_RF) {
+                        load_issue(tap_tag);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (staging) {      // first half of step t+1, and this half's share of its second half
                         const int t1 = tri == 2 ? 0 : tri + 1;       // (t + 1) % 3
                         if (tap < 8) {
@@ -536,7 +548,8 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
                             wt_piece(wh, nx_n0, 0, nx_c, 1, kL2OffA1 + t1 * kL2Half);
                         }
                     }
-                    load_segment(tap_tag);
+                    if (!LH2_RF) load_issue(tap_tag);
+                    load_finish();
                     LH2_MARK(0)
                     __builtin_amdgcn_s_barrier();
                     LH2_MARK(2)
@@ -569,6 +582,10 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
                     __builtin_amdgcn_s_barrier();
                     LH2_MARK(2)
                     issued = 0;
+                    if (LH2_RF) {
+                        load_issue(tap_tag);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                     if (staging) {
                         // this half's share of the second half of step t+2
                         const int t2 = tri == 0 ? 2 : tri - 1;       // (t + 2) % 3
@@ -591,7 +608,8 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
                             }
                         }
                     }
-                    load_segment(tap_tag);
+                    if (!LH2_RF) load_issue(tap_tag);
+                    load_finish();
                     if (tap == 0 && c == 0 && pending_combine) {
                         stat_combine(prev_tm, prev_n0);
                         pending_combine = false;
