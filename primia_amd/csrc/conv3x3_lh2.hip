@@ -67,7 +67,7 @@ struct Lh2Params {
 #define LH2_SWAP 0
 #endif
 #ifndef LH2_RF
-#define LH2_RF 1
+#define LH2_RF 0
 #endif
 #ifdef LH2_PROF
 #define LH2_MARK(slot)                                 \
@@ -416,9 +416,10 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
     int tri = 0;        // second-half ring slot of the step being loaded (t % 3)
     int tri_m = 0;      // ... of the step whose matrix segment runs next
     int hbuf = 0;       // halo buffer of the chunk being loaded
-    // LH2_RF = 1: a load segment requests its fragment reads FIRST and its LDS-DMA pieces behind them — a piece blocks the
-    // wave while the CU's memory queue is full (the four waves of a half issue theirs at the same moment), and the LDS
-    // pipe serves the reads meanwhile; with the pieces in front, the reads only started once the last piece was accepted
+    // LH2_RF = 1 (experiment, measured SLOWER: 58.9 -> 60.6 / 51.9 -> 54.1 us, layer2 / layer3 forward): a load segment
+    // requests its fragment reads first and its LDS-DMA pieces behind them.  The load segments do get shorter (B half:
+    // 33 k -> 25 k cycles per launch), but the partner's matrix segments grow by as much (35.7 k -> 38.7 k) and so do the
+    // barrier waits: the pieces are accepted later, land later, and their LDS writes then sit in the matrix segments' reads
     auto load_issue = [&](auto tap_tag) {
         constexpr int tap = decltype(tap_tag)::value;
         if (!(LH2_DBG & 8)) {
