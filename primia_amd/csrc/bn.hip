@@ -521,8 +521,12 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
 // orders first by value, then by EARLIER tap: max over the window's keys = (maximum, first position attaining it) — two
 // instructions per tap (v_lshl_or_b32, v_max_u32), and the same result as the generic kernel bit for bit (a NaN, the
 // largest pattern, wins as it does there).
+// Block size: 256 threads, or ROWS whole output rows (PRIMIA_POOL_ROWS = 2 | 4, opt-in): consecutive blocks go to different
+// XCDs, so the input row two vertically neighbouring windows share is fetched once per block that touches it; a block of
+// whole rows shares them inside one CU.  Measured: step 4.925 / 4.937 ms (256 threads) vs 4.938 / 4.944 (2 rows) and
+// 4.944 / 4.972 (4 rows) — the 1.5x fetch of this pass is served by the Infinity Cache and is not what bounds it.
 template <int PW, int PH>
-__global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* __restrict__ y, bf16* __restrict__ pooled,
+__global__ __launch_bounds__(1024) void bn_relu_pool_fwd_key_kernel(const bf16* __restrict__ y, bf16* __restrict__ pooled,
                                                                    uint8_t* __restrict__ argmax,
                                                                    const float* __restrict__ gamma,
                                                                    const float* __restrict__ beta,
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* _
     __shared__ float sm[3][512];
     // G > 0: GroupNorm — mean / invstd are [N][G] (per sample and group), read by each thread for its own sample
     if (G == 0) {
-        for (int c = threadIdx.x; c < C; c += 256) {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
             sm[0][c] = mean[c];
             sm[1][c] = invstd[c] * gamma[c];
             sm[2][c] = beta[c];
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_key_kernel(const bf16* _
     const int cpr = C / CH;
     const int Wq = Wo / PW, Hq = Ho / PH;
     const long total = (long)N * Hq * Wq * cpr;
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
+    const long q = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (q >= total) return;
     const int cc = (int)(q % cpr);
     long t = q / cpr;
@@ -1028,10 +1032,17 @@ static void launch_bn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax
             static const bool keyph2 = getenv("PRIMIA_POOL_KEYPH") && getenv("PRIMIA_POOL_KEYPH")[0] == '2';
             const int kph = (Ho % 2 == 0 && keyph2) ? 2 : 1;
             const long ktotal = (long)N * (Ho / kph) * (Wo / pw) * (C / 8);
-            const unsigned kgrid = (unsigned)((ktotal + 255) / 256);
+            // whole output rows per block where a row is a multiple of a wave (the stem: 28 window pairs x 8 chunks = 224)
+            static const int rows_env = getenv("PRIMIA_POOL_ROWS") ? atoi(getenv("PRIMIA_POOL_ROWS")) : 0;   // (measured: no gain)
+            const int row_threads = (Wo / pw) * (C / 8);
+            int bt = 256;
+            if (rows_env > 0 && row_threads % 32 == 0 && (row_threads * rows_env) % 64 == 0 && row_threads * rows_env <= 1024 &&
+                (Ho / kph) % rows_env == 0)
+                bt = row_threads * rows_env;
+            const unsigned kgrid = (unsigned)((ktotal + bt - 1) / bt);
             auto kk = pw == 2 ? (kph == 2 ? bn_relu_pool_fwd_key_kernel<2, 2> : bn_relu_pool_fwd_key_kernel<2, 1>)
                               : (kph == 2 ? bn_relu_pool_fwd_key_kernel<1, 2> : bn_relu_pool_fwd_key_kernel<1, 1>);
-            kk<<<kgrid, 256, 0, st>>>((const bf16*)y, (bf16*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo, G);
+            kk<<<kgrid, bt, 0, st>>>((const bf16*)y, (bf16*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo, G);
             return;
         }
     }
