@@ -58,13 +58,13 @@ class ResNet18Engine:
         self.P = sum(int(torch.Size(s).numel()) for _, s in self.p_entries)
         self.B = sum(int(torch.Size(s).numel()) for _, s in self.b_entries)
         self.flat = torch.zeros(self.P + self.B, dtype=torch.float32, device=dev)
-        self.grads = torch.zeros(self.P, dtype=torch.float32, device=dev)
+        self._grads = torch.zeros(self.P, dtype=torch.float32, device=dev)   # (read through the `grads` property)
         self.views, self.gviews = {}, {}
         off = 0
         for k, s in self.p_entries:
             n = int(torch.Size(s).numel())
             self.views[k] = self.flat[off:off + n].view(s)
-            self.gviews[k] = self.grads[off:off + n].view(s)
+            self.gviews[k] = self._grads[off:off + n].view(s)
             off += n
         for k, s in self.b_entries:
             n = int(torch.Size(s).numel())
@@ -981,6 +981,14 @@ class ResNet18Engine:
                                   (ctypes.c_int64 * nr)(*[r[1] for r in ranges]), nr)
         return self._sgd_plan or None
 
+    @property
+    def grads(self):
+        """The flat gradient arena.  Reading it finishes a deferred conv-gradient pass first (fuse_sgd_tail), so a
+        caller never sees gradients that still live in the accumulators; `gviews[...]` are views of the same storage —
+        call materialize_grads() before reading THOSE between loss_backward() and sgd_step() under fuse_sgd_tail."""
+        self.materialize_grads()
+        return self._grads
+
     def materialize_grads(self):
         """Write the conv gradients out of the accumulators if a fused tail has left them there."""
         if self._grads_pending:
@@ -1164,7 +1172,7 @@ class ResNet18Engine:
                  fus["wd"], fus["n"], float(lr), float(weight_decay), self.dt)
             if rest is not None:
                 call("primia_conv_wgrad_finalize_many", rest["descs"], rest["creal"], rest["acc"], rest["gw"], rest["n"])
-            call("primia_sgd_step_ranges", self.flat, self.grads, rb, rl, nr, float(lr), float(weight_decay))
+            call("primia_sgd_step_ranges", self.flat, self._grads, rb, rl, nr, float(lr), float(weight_decay))
             if rest is not None:
                 call("primia_conv_weight_prepare_many", rest["descs"], rest["creal"], rest["w"], rest["wf"], rest["wd"],
                      rest["n"], self.dt)
