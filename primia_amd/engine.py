@@ -1076,8 +1076,25 @@ class ResNet18Engine:
             clip = torch.empty(N, dtype=torch.float32, device=dev)
             call("primia_dp_clip_factors", sq, clip, N, float(max_grad_norm))
             # clipped sums
+            # (a transition block's conv1 + downsample: ONE launch as in plain training, once both dy are scaled)
+            pair_of, pair_wait = {}, {}
+            if self.wgrad_pair and self.wgrad_ws is not None:
+                for blk in self.spec.blocks:
+                    if (blk.down is not None and self._pair_ws.get(blk.conv1.name, 0) > 0
+                            and blk.conv1.name not in kept and blk.down.name not in kept):
+                        pair_of[blk.conv1.name] = pair_of[blk.down.name] = blk
             for name, x, dy in self.dp["wgrads"]:
                 c = self.convs[name]
+                if name in pair_of:
+                    blk = pair_of[name]
+                    call("primia_scale_rows", dy, clip, N, dy.numel() // N, self.dt)
+                    got = pair_wait.setdefault(blk.prefix, {})
+                    got[name] = (x, dy)
+                    if len(got) == 2:
+                        c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
+                        call("primia_conv2d_wgrad_pair_ws", c1.desc, got[blk.conv1.name][0], got[blk.conv1.name][1], c1.acc,
+                             cd.desc, got[blk.down.name][1], cd.acc, self.wgrad_ws, self.wgrad_ws_bytes, self.dt)
+                    continue
                 if name in kept:
                     if name == "conv1":
                         call("primia_stem_conv_wgrad_clipped_sum", kept[name], clip, c.acc, N)
