@@ -650,6 +650,7 @@ class ResNet18Engine:
     gn_relu_recompute = os.environ.get("PRIMIA_GN_RELU_RECOMPUTE", "1") != "0"
     # GroupNorm residual layers with the BatchNorm path's 1-bit ReLU masks (and its mask-applying accumulate dgrad)
     gn_relu_masks = os.environ.get("PRIMIA_GN_RELU_MASKS", "1") != "0"
+    gn_ds_mask = os.environ.get("PRIMIA_GN_DS_MASK", "1") != "0"
     gn_stem_fused = os.environ.get("PRIMIA_GN_STEM_FUSED", "1") != "0"
     wgrad_group = os.environ.get("PRIMIA_WGRAD_GROUP", "1") != "0"
     # (all layers at the end of the backward pass: measured no better than the per-stage groups — 5.16 vs 5.14 ms; by then
@@ -773,8 +774,12 @@ class ResNet18Engine:
                      self.gviews[bd + ".bias"], t[p + ".y2"].shape[0], t[p + ".y2"].shape[1], self.bn_ws,
                      self.bn_ws_bytes, self.dt)
             else:
+                # GroupNorm transition block: the downsample's backward pass applies bn2's ReLU mask to dout itself
+                # (primia_gn_bwd_mask on yd), so the masked gradient is not written here either
+                gn_ds_mask = (blk.down is not None and self.norm == "group" and self.pair_dgrad and self.gn_ds_mask
+                              and b2 in self.relu_masks)
                 self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True,
-                             keep_g=not masked_acc)
+                             keep_g=not (masked_acc or gn_ds_mask))
             # data gradient first: the weight gradient (a leaf) then runs beside the BatchNorm chain that follows
             if self.wgrad_first:   # weight gradient, then data gradient, so that the BatchNorm backward pass which
                 # follows finds the data gradient it reads still in the Infinity Cache
@@ -786,7 +791,17 @@ class ResNet18Engine:
             self._bn_bwd(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], t[p + ".da1"], t[p + ".dy1"], None, True)
             if blk.down is not None and self.pair_dgrad:
                 # both BatchNorm backward passes first, then ONE data-gradient pass for conv1 + downsample
-                if not bn_pair:
+                if not bn_pair and gn_ds_mask:
+                    bd = bn_name(blk.down.name)
+                    (smd, sid), (psg, psb) = self.save[bd], self.ps_affine[bd]
+                    yd = t[p + ".yd"]
+                    call("primia_gn_bwd_mask", yd, self.relu_masks[b2], dout, t[p + ".dyd"], None, self.views[bd + ".weight"],
+                         smd, sid, psg, psb, self.N, yd.shape[0] // self.N, yd.shape[1], self.groups, self.bn_ws,
+                         self.bn_ws_bytes, self.dt)
+                    if self.dp is None:
+                        call("primia_weighted_colsum", psg, self.ones_n, self.gviews[bd + ".weight"], self.N, yd.shape[1])
+                        call("primia_weighted_colsum", psb, self.ones_n, self.gviews[bd + ".bias"], self.N, yd.shape[1])
+                elif not bn_pair:
                     self._bn_bwd(blk.down.name, t[p + ".yd"], None, dout, t[p + ".dyd"], None, False)
                 c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
                 if self.wgrad_overlap == 1:
