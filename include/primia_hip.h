@@ -498,6 +498,9 @@ int primia_dp_clip_factors(const double* sq, float* clip, int N, float max_grad_
 /* x[n][:] *= s[n] for N consecutive blocks of elems_per_sample elements (dtype tensor, in place). */
 int primia_scale_rows(void* x, const float* s, int N, int64_t elems_per_sample, int dtype,
                       primia_stream_t stream);
+/* The same for up to 16 tensors in one launch (host arrays of pointers / per-sample element counts). */
+int primia_scale_rows_many(void* const* xs_host, const int64_t* elems_per_sample_host, int count, const float* s,
+                           int N, int dtype, primia_stream_t stream);
 /* out[c] = sum_n w[n] * x[n][c]. */
 int primia_weighted_colsum(const float* x, const float* w, float* out, int N, int C,
                            primia_stream_t stream);

@@ -575,6 +575,30 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(T* x, const float* __re
     }
 }
 
+// ... of up to 16 tensors in one launch (blockIdx.z = tensor): the DP-SGD batch pass scales the dy of every layer whose
+// per-sample tiles are not kept — a dozen launches of 7-19 us each, none of which fills the chip for long
+constexpr int kScaleMany = 16;
+struct ScaleManyArgs {
+    void* x[kScaleMany];
+    long cps[kScaleMany];
+};
+template <typename T>
+__global__ __launch_bounds__(256) void scale_rows_many_kernel(ScaleManyArgs a, const float* __restrict__ s) {
+    constexpr int CH = Chunk<T>::N;
+    T* x = (T*)a.x[blockIdx.z];
+    const long cps = a.cps[blockIdx.z];
+    const float f = s[blockIdx.y];
+    const long base = (long)blockIdx.y * cps;
+    const long stride = (long)gridDim.x * 256;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < cps; q += stride) {
+        float v[CH];
+        Chunk<T>::unpack(*(const u32x4*)(x + (base + q) * CH), v);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) v[i] *= f;
+        *(u32x4*)(x + (base + q) * CH) = Chunk<T>::pack(v);
+    }
+}
+
 // out[c] = sum_n w[n] * x[n][c]
 __global__ __launch_bounds__(256) void weighted_colsum_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               float* __restrict__ out, int N, int C) {
@@ -913,6 +937,30 @@ int primia_scale_rows(void* x, const float* s, int N, int64_t elems_per_sample, 
     } else {
         return PRIMIA_ERR_ARG;
     }
+    return launch_status();
+}
+
+int primia_scale_rows_many(void* const* xs_host, const int64_t* elems_per_sample_host, int count, const float* s, int N,
+                           int dtype, primia_stream_t stream) {
+    if (count == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(xs_host && elems_per_sample_host && s && N > 0 && count > 0 && count <= kScaleMany);
+    PRIMIA_REQUIRE(dtype == PRIMIA_F32 || dtype == PRIMIA_BF16);
+    const int ch = dtype == PRIMIA_F32 ? 4 : 8;
+    ScaleManyArgs a;
+    long cmax = 0;
+    for (int i = 0; i < count; ++i) {
+        PRIMIA_REQUIRE(xs_host[i] && elems_per_sample_host[i] > 0 && elems_per_sample_host[i] % ch == 0);
+        a.x[i] = xs_host[i];
+        a.cps[i] = elems_per_sample_host[i] / ch;
+        if (a.cps[i] > cmax) cmax = a.cps[i];
+    }
+    dim3 g = gn_rows_grid(N, cmax);
+    g.z = (unsigned)count;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_F32)
+        scale_rows_many_kernel<float><<<g, 256, 0, st>>>(a, s);
+    else
+        scale_rows_many_kernel<bf16><<<g, 256, 0, st>>>(a, s);
     return launch_status();
 }
 

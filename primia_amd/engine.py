@@ -1098,11 +1098,23 @@ class ResNet18Engine:
                     if (blk.down is not None and self._pair_ws.get(blk.conv1.name, 0) > 0
                             and blk.conv1.name not in kept and blk.down.name not in kept):
                         pair_of[blk.conv1.name] = pair_of[blk.down.name] = blk
+            # every dy of a layer whose tiles are not kept, scaled by the clip factors in ONE launch (a dozen tensors)
+            to_scale = [dy for name, _, dy in self.dp["wgrads"] if name not in kept]
+            many = self.dp_scale_many and 0 < len(to_scale) <= 16
+            if many:
+                key = tuple(tt.data_ptr() for tt in to_scale)
+                if getattr(self, "_scale_many", (None,))[0] != key:
+                    import ctypes
+
+                    self._scale_many = (key, (ctypes.c_void_p * len(key))(*key),
+                                        (ctypes.c_int64 * len(key))(*[tt.numel() // N for tt in to_scale]))
+                call("primia_scale_rows_many", self._scale_many[1], self._scale_many[2], len(key), clip, N, self.dt)
             for name, x, dy in self.dp["wgrads"]:
                 c = self.convs[name]
                 if name in pair_of:
                     blk = pair_of[name]
-                    call("primia_scale_rows", dy, clip, N, dy.numel() // N, self.dt)
+                    if not many:
+                        call("primia_scale_rows", dy, clip, N, dy.numel() // N, self.dt)
                     got = pair_wait.setdefault(blk.prefix, {})
                     got[name] = (x, dy)
                     if len(got) == 2:
@@ -1116,7 +1128,8 @@ class ResNet18Engine:
                     else:
                         call("primia_conv_wgrad_clipped_sum", c.desc, kept[name], clip, c.acc, self.dt)
                     continue
-                call("primia_scale_rows", dy, clip, N, dy.numel() // N, self.dt)
+                if not many:
+                    call("primia_scale_rows", dy, clip, N, dy.numel() // N, self.dt)
                 # the clipped SUM is an ordinary batched weight gradient: atomic-free kernels, and for the stem the
                 # halo kernel on the padded input (118 us instead of 444 us for the per-tap one)
                 if self.wgrad_ws is not None and name in self._wg_group:     # same-shape layers: one launch per stage
@@ -1159,6 +1172,7 @@ class ResNet18Engine:
         return self.loss
 
     dp_keep = os.environ.get("PRIMIA_DP_KEEP", "1") != "0"
+    dp_scale_many = os.environ.get("PRIMIA_DP_SCALE_MANY", "1") != "0"
 
     def _dp_keep_buffers(self):
         """{conv name: fp32 buffer} for the layers whose per-sample tiles the DP-SGD norm pass keeps (built once)."""
