@@ -646,9 +646,21 @@ extern "C" int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const vo
     return conv2d_wgrad_impl(d, x, dy, dw_ps, 1, dtype, stream);
 }
 
+namespace primia {
+int dp_ghost_sqnorm_dispatch(const void* x, const void* dy, double* sq, int N, int H, int W, int C, int K, int R, int S,
+                             int stride, int pad, hipStream_t st);
+}
+
 extern "C" int primia_conv2d_wgrad_persample_sqnorm(const primia_conv_desc* d, const void* x, const void* dy,
                                                     double* sqnorm, int dtype, primia_stream_t stream) {
     PRIMIA_REQUIRE(sqnorm);
+    if (d && x && dy && dtype == PRIMIA_BF16) {
+        // 7x7 images, 3x3 / stride 1: the norms come out of two Gram matrices per sample (dp_ghost.hip), the per-sample
+        // gradients are never formed
+        const int rc = dp_ghost_sqnorm_dispatch(x, dy, sqnorm, d->N, d->H, d->W, d->C, d->K, d->R, d->S, d->stride, d->pad,
+                                                (hipStream_t)stream);
+        if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+    }
     return conv2d_wgrad_impl(d, x, dy, nullptr, 1, dtype, stream, sqnorm);
 }
 

@@ -1,0 +1,167 @@
+// DP-SGD: per-sample squared gradient norms of a 3x3 / stride-1 / pad-1 convolution on 7x7 images WITHOUT forming the
+// per-sample gradients ("ghost" norms), bf16, gfx950.
+//
+// The per-sample weight gradient of sample n is  g = sum_p dy_p (x) u_p  (dy_p: the K output-gradient channels of pixel p,
+// u_p: its 9 C unfolded input values), so
+//     ||g||^2 = sum_{p,q} (dy_p . dy_q) (u_p . u_q)
+// and with XX = the Gram matrix of the 81 pixels of the zero-padded 9x9 input halo,
+//     u_p . u_q = sum over the 9 taps t of XX[h(p) + t][h(q) + t].
+// For layer4 of ResNet-18 (49 pixels, C = K = 512) that is 49^2 (512 + 512 (81/49)^2 ...) ~ 14 MFLOP per sample on
+// the matrix cores instead of the 231 MFLOP of the per-sample gradient itself (and none of its 8x8-sub-patch padding):
+// the norm pass of the three such layers took 127 us each (profiles/r03_dp_step_timeline.txt), the same FLOPs as their
+// batch pass at half the speed.
+//
+// One 4-wave block per sample, everything in LDS: x halo rows and dy rows as [row][C or K] bf16 with a 16-byte pad per
+// row (row pitch = 65 sixteen-byte chunks: the 16 rows of a fragment land in 16 different bank groups), both Gram
+// matrices by v_mfma_f32_16x16x32_bf16 (A and B fragments are the same 16-byte row reads: a Gram matrix is X X^T), the
+// tap sum and the final contraction on the vector ALU, the result added to sqnorm[n] in fp64.
+//
+// Replaces pytorch-dp's per-sample gradient norm for these layers (train.py:325-334 PrivacyEngine; clip rule in
+// primia_dp_clip_factors); same quantity as primia_conv2d_wgrad_persample + primia_persample_sqnorm to fp32 rounding.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace primia {
+
+struct GhostParams {
+    const bf16* x;    // [N][49][C]
+    const bf16* dy;   // [N][49][K]
+    double* sq;       // [N], accumulated into
+    int C, K;
+};
+
+constexpr int kGhHalo = 81;   // 9 x 9 halo pixels; row 81 = zeros
+constexpr int kGhPix = 49;    // 7 x 7 pixels; dy row 49 = zeros
+
+// Gram tile row block `ti` (16 rows) against NTJ column blocks, rows / columns beyond `nrows` read the zero row
+template <int NTJ>
+__device__ __forceinline__ void gram_rows(const char* base, int pitch, int nrows, int klen, int ti, int lane, f32x4 (&acc)[NTJ]) {
+    const int fr = lane & 15, fg = lane >> 4;
+    const int ra = 16 * ti + fr;
+    const char* pa = base + (ra < nrows ? ra : nrows) * pitch + fg * 16;
+    const char* pb[NTJ];
+#pragma unroll
+    for (int tj = 0; tj < NTJ; ++tj) {
+        const int rb = 16 * tj + fr;
+        pb[tj] = base + (rb < nrows ? rb : nrows) * pitch + fg * 16;
+        acc[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int k = 0; k < klen; k += 32) {
+        const bf16x8_t a = *(const bf16x8_t*)(pa + k * 2);
+#pragma unroll
+        for (int tj = 0; tj < NTJ; ++tj) {
+            const bf16x8_t b = *(const bf16x8_t*)(pb[tj] + k * 2);
+            acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[tj], 0, 0, 0);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dp_ghost_sqnorm7_kernel(GhostParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = blockIdx.x;
+    const int C = p.C, K = p.K;
+    const int px = C * 2 + 16, pd = K * 2 + 16;            // row pitches in bytes
+    char* const sx = smem;                                   // 82 rows
+    char* const sd = sx + (kGhHalo + 1) * px;               // 50 rows; later: XX [81][84] fp32
+    constexpr int G1P = 52, XXP = 84;
+    const int sdb = (kGhPix + 1) * pd > kGhHalo * XXP * 4 ? (kGhPix + 1) * pd : kGhHalo * XXP * 4;   // dy rows, later XX
+    float* const g1 = (float*)(sd + sdb);                    // [49][52] fp32
+
+    // ---- stage: halo rows of x (border and row 81: zeros), rows of dy (row 49: zeros) ---------------------------------
+    {
+        const int cpr = C / 8;                               // 16-byte chunks per row
+        const bf16* xs = p.x + (long)n * kGhPix * C;
+        for (int i = tid; i < (kGhHalo + 1) * cpr; i += 256) {
+            const int row = i / cpr, ch = i - row * cpr;
+            const int hy = row / 9, hx = row - hy * 9;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < kGhHalo && hy >= 1 && hy <= 7 && hx >= 1 && hx <= 7)
+                v = *(const u32x4*)(xs + ((hy - 1) * 7 + hx - 1) * C + ch * 8);
+            *(u32x4*)(sx + row * px + ch * 16) = v;
+        }
+        const int kpr = K / 8;
+        const bf16* ds = p.dy + (long)n * kGhPix * K;
+        for (int i = tid; i < (kGhPix + 1) * kpr; i += 256) {
+            const int row = i / kpr, ch = i - row * kpr;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < kGhPix) v = *(const u32x4*)(ds + row * K + ch * 8);
+            *(u32x4*)(sd + row * pd + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+    const int fr = lane & 15, fg = lane >> 4;
+    // ---- G1 = dy dy^T (49 x 49 in a 64 x 64 grid of 16 tiles: wave w = tile row w) -------------------------------------
+    {
+        f32x4 acc[4];
+        gram_rows<4>(sd, pd, kGhPix, K, wave, lane, acc);
+        // lane (fr, fg) holds rows 4 fg .. +3 of column fr of each tile
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 16 * wave + 4 * fg + e, c = 16 * tj + fr;
+                if (r < kGhPix && c < kGhPix) g1[r * G1P + c] = acc[tj][e];
+            }
+    }
+    // ---- XX = X X^T (81 x 81 in a 96 x 96 grid: wave w = tile rows w and w + 4), kept in registers until dy is dead ------
+    f32x4 xa[6], xb[6];
+    gram_rows<6>(sx, px, kGhHalo, C, wave, lane, xa);
+    if (wave < 2) gram_rows<6>(sx, px, kGhHalo, C, wave + 4, lane, xb);
+    __syncthreads();                                         // every wave has read its dy rows: the region becomes XX
+    float* const xx = (float*)sd;
+#pragma unroll
+    for (int tj = 0; tj < 6; ++tj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 16 * tj + fr;
+            const int r0 = 16 * wave + 4 * fg + e, r1 = r0 + 64;
+            if (r0 < kGhHalo && c < kGhHalo) xx[r0 * XXP + c] = xa[tj][e];
+            if (wave < 2 && r1 < kGhHalo && c < kGhHalo) xx[r1 * XXP + c] = xb[tj][e];
+        }
+    __syncthreads();
+    // ---- sum_{p,q} G1[p][q] * sum_taps XX[h(p) + t][h(q) + t] -------------------------------------------------------------
+    double part = 0.0;
+    for (int i = tid; i < kGhPix * kGhPix; i += 256) {
+        const int pp = i / kGhPix, qq = i - pp * kGhPix;
+        const int hp = (pp / 7) * 9 + pp % 7, hq = (qq / 7) * 9 + qq % 7;
+        float g2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s) g2 += xx[(hp + 9 * r + s) * XXP + hq + 9 * r + s];
+        part += (double)g1[pp * G1P + qq] * (double)g2;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    __shared__ double wsum[4];
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    if (tid == 0) p.sq[n] += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// PRIMIA_ERR_UNSUPPORTED where the form does not apply (the caller keeps its per-sample weight-gradient pass)
+int dp_ghost_sqnorm_dispatch(const void* x, const void* dy, double* sq, int N, int H, int W, int C, int K, int R, int S,
+                             int stride, int pad, hipStream_t st) {
+    static const bool off = getenv("PRIMIA_DP_GHOST") && getenv("PRIMIA_DP_GHOST")[0] == '0';
+    if (off || H != 7 || W != 7 || R != 3 || S != 3 || stride != 1 || pad != 1) return PRIMIA_ERR_UNSUPPORTED;
+    if (C % 32 || K % 32 || C < 32 || K < 32) return PRIMIA_ERR_UNSUPPORTED;
+    size_t sdb = (size_t)(kGhPix + 1) * (K * 2 + 16);
+    if (sdb < (size_t)kGhHalo * 84 * 4) sdb = (size_t)kGhHalo * 84 * 4;
+    const size_t lds = (size_t)(kGhHalo + 1) * (C * 2 + 16) + sdb + (size_t)kGhPix * 52 * 4;
+    if (lds > 160 * 1024) return PRIMIA_ERR_UNSUPPORTED;
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void*)dp_ghost_sqnorm7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        lds_set = lds;
+    }
+    GhostParams p{(const bf16*)x, (const bf16*)dy, sq, C, K};
+    dp_ghost_sqnorm7_kernel<<<N, 256, lds, st>>>(p);
+    return launch_status();
+}
+
+}  // namespace primia
