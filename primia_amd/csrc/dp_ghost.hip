@@ -142,12 +142,104 @@ __global__ __launch_bounds__(256) void dp_ghost_sqnorm7_kernel(GhostParams p) {
     if (tid == 0) p.sq[n] += wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
+// ---- the stride-2 sibling: 14x14 input -> 7x7 output (a transition block's conv1) -------------------------------------
+// u_p . u_q = sum over the 9 taps t of x[2p + t] . x[2q + t]: nine Gram matrices of the 49 pixels a tap samples, summed in
+// the accumulators (a 225 x 225 Gram matrix of the whole 15 x 15 halo would not fit LDS).  dy is staged first, its Gram
+// tiles stay in registers (wave w: tile row w, 16 registers), then the input halo takes dy's place in LDS; the contraction
+// sum G1 * G2 happens in the accumulator layout, no Gram matrix is ever stored.
+__global__ __launch_bounds__(256) void dp_ghost_sqnorm7s2_kernel(GhostParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 15, fg = lane >> 4;
+    const int n = blockIdx.x;
+    const int C = p.C, K = p.K;
+    const int px = C * 2 + 16, pd = K * 2 + 16;
+    constexpr int HALO = 225;                               // 15 x 15: halo (hy, hx) = input (hy - 1, hx - 1); row 225 = zeros
+    {
+        const int kpr = K / 8;
+        const bf16* ds = p.dy + (long)n * kGhPix * K;
+        for (int i = tid; i < (kGhPix + 1) * kpr; i += 256) {
+            const int row = i / kpr, ch = i - row * kpr;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < kGhPix) v = *(const u32x4*)(ds + row * K + ch * 8);
+            *(u32x4*)(smem + row * pd + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+    f32x4 g1[4];
+    gram_rows<4>(smem, pd, kGhPix, K, wave, lane, g1);
+    __syncthreads();                                         // dy is dead: the input halo takes its place
+    {
+        const int cpr = C / 8;
+        const bf16* xs = p.x + (long)n * 196 * C;
+        for (int i = tid; i < (HALO + 1) * cpr; i += 256) {
+            const int row = i / cpr, ch = i - row * cpr;
+            const int hy = row / 15, hx = row - hy * 15;
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (row < HALO && hy >= 1 && hx >= 1) v = *(const u32x4*)(xs + ((hy - 1) * 14 + hx - 1) * C + ch * 8);
+            *(u32x4*)(smem + row * px + ch * 16) = v;
+        }
+    }
+    __syncthreads();
+    // halo row of output pixel q at tap (0, 0): (2 qy) * 15 + 2 qx; tap (r, s): + 15 r + s; pixels >= 49: the zero row
+    auto hrow = [&](int q) { return q < kGhPix ? (2 * (q / 7)) * 15 + 2 * (q % 7) : -1; };
+    const int ha = hrow(16 * wave + fr);
+    int hb[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) hb[tj] = hrow(16 * tj + fr);
+    f32x4 g2[4];
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj) g2[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < 9; ++t) {
+        const int off = 15 * (t / 3) + t % 3;
+        const char* pa = smem + (ha < 0 ? HALO : ha + off) * px + fg * 16;
+        const char* pb[4];
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) pb[tj] = smem + (hb[tj] < 0 ? HALO : hb[tj] + off) * px + fg * 16;
+        for (int k = 0; k < C; k += 32) {
+            const bf16x8_t a = *(const bf16x8_t*)(pa + k * 2);
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                const bf16x8_t b = *(const bf16x8_t*)(pb[tj] + k * 2);
+                g2[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, g2[tj], 0, 0, 0);
+            }
+        }
+    }
+    double part = 0.0;      // (rows / columns beyond the 49 pixels are Gram entries of the zero row: zero)
+#pragma unroll
+    for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) part += (double)g1[tj][e] * (double)g2[tj][e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+    __shared__ double wsum[4];
+    if (lane == 0) wsum[wave] = part;
+    __syncthreads();
+    if (tid == 0) p.sq[n] += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
 // PRIMIA_ERR_UNSUPPORTED where the form does not apply (the caller keeps its per-sample weight-gradient pass)
 int dp_ghost_sqnorm_dispatch(const void* x, const void* dy, double* sq, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, hipStream_t st) {
     static const bool off = getenv("PRIMIA_DP_GHOST") && getenv("PRIMIA_DP_GHOST")[0] == '0';
-    if (off || H != 7 || W != 7 || R != 3 || S != 3 || stride != 1 || pad != 1) return PRIMIA_ERR_UNSUPPORTED;
-    if (C % 32 || K % 32 || C < 32 || K < 32) return PRIMIA_ERR_UNSUPPORTED;
+    if (off || R != 3 || S != 3 || pad != 1 || C % 32 || K % 32 || C < 32 || K < 32) return PRIMIA_ERR_UNSUPPORTED;
+    if (H == 14 && W == 14 && stride == 2) {
+        size_t a = (size_t)226 * (C * 2 + 16), b = (size_t)(kGhPix + 1) * (K * 2 + 16);
+        const size_t lds2 = a > b ? a : b;
+        if (lds2 > 160 * 1024) return PRIMIA_ERR_UNSUPPORTED;
+        static size_t lds2_set = 0;
+        if (lds2 > lds2_set) {
+            if (hipFuncSetAttribute((const void*)dp_ghost_sqnorm7s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds2) != hipSuccess)
+                return PRIMIA_ERR_LAUNCH;
+            lds2_set = lds2;
+        }
+        GhostParams p2{(const bf16*)x, (const bf16*)dy, sq, C, K};
+        dp_ghost_sqnorm7s2_kernel<<<N, 256, lds2, st>>>(p2);
+        return launch_status();
+    }
+    if (H != 7 || W != 7 || stride != 1) return PRIMIA_ERR_UNSUPPORTED;
     size_t sdb = (size_t)(kGhPix + 1) * (K * 2 + 16);
     if (sdb < (size_t)kGhHalo * 84 * 4) sdb = (size_t)kGhHalo * 84 * 4;
     const size_t lds = (size_t)(kGhHalo + 1) * (C * 2 + 16) + sdb + (size_t)kGhPix * 52 * 4;
