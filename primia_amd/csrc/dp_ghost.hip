@@ -34,6 +34,33 @@ struct GhostParams {
 constexpr int kGhHalo = 81;   // 9 x 9 halo pixels; row 81 = zeros
 constexpr int kGhPix = 49;    // 7 x 7 pixels; dy row 49 = zeros
 
+// Stage `rows` rows of `cpr` 16-byte chunks into LDS rows of `pitch` bytes, EIGHT chunks per thread in flight (a block is alone
+// on its CU: one chunk at a time was a chain of ~20 memory round trips, 29 us per launch for 14 MFLOP).  src(row, ch)
+// returns the global address of a chunk or nullptr for a zero chunk.
+template <typename F>
+__device__ __forceinline__ void ghost_stage(char* dst, int pitch, int rows, int cpr, F src) {
+    const int total = rows * cpr;
+    for (int i0 = threadIdx.x; i0 < total; i0 += 256 * 8) {
+        u32x4 v[8];
+        int off[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + 256 * u;
+            v[u] = u32x4{0u, 0u, 0u, 0u};
+            off[u] = -1;
+            if (i < total) {
+                const int row = i / cpr, ch = i - row * cpr;
+                off[u] = row * pitch + ch * 16;
+                const u32x4* g = src(row, ch);
+                if (g) v[u] = *g;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (off[u] >= 0) *(u32x4*)(dst + off[u]) = v[u];
+    }
+}
+
 // Gram tile row block `ti` (16 rows) against NTJ column blocks, rows / columns beyond `nrows` read the zero row
 template <int NTJ>
 __device__ __forceinline__ void gram_rows(const char* base, int pitch, int nrows, int klen, int ti, int lane, f32x4 (&acc)[NTJ]) {
@@ -72,24 +99,17 @@ __global__ __launch_bounds__(256) void dp_ghost_sqnorm7_kernel(GhostParams p) {
 
     // ---- stage: halo rows of x (border and row 81: zeros), rows of dy (row 49: zeros) ---------------------------------
     {
-        const int cpr = C / 8;                               // 16-byte chunks per row
         const bf16* xs = p.x + (long)n * kGhPix * C;
-        for (int i = tid; i < (kGhHalo + 1) * cpr; i += 256) {
-            const int row = i / cpr, ch = i - row * cpr;
+        ghost_stage(sx, px, kGhHalo + 1, C / 8, [&](int row, int ch) -> const u32x4* {
             const int hy = row / 9, hx = row - hy * 9;
-            u32x4 v = {0u, 0u, 0u, 0u};
             if (row < kGhHalo && hy >= 1 && hy <= 7 && hx >= 1 && hx <= 7)
-                v = *(const u32x4*)(xs + ((hy - 1) * 7 + hx - 1) * C + ch * 8);
-            *(u32x4*)(sx + row * px + ch * 16) = v;
-        }
-        const int kpr = K / 8;
+                return (const u32x4*)(xs + ((hy - 1) * 7 + hx - 1) * C + ch * 8);
+            return nullptr;
+        });
         const bf16* ds = p.dy + (long)n * kGhPix * K;
-        for (int i = tid; i < (kGhPix + 1) * kpr; i += 256) {
-            const int row = i / kpr, ch = i - row * kpr;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < kGhPix) v = *(const u32x4*)(ds + row * K + ch * 8);
-            *(u32x4*)(sd + row * pd + ch * 16) = v;
-        }
+        ghost_stage(sd, pd, kGhPix + 1, K / 8, [&](int row, int ch) -> const u32x4* {
+            return row < kGhPix ? (const u32x4*)(ds + row * K + ch * 8) : nullptr;
+        });
     }
     __syncthreads();
     const int fr = lane & 15, fg = lane >> 4;
@@ -157,29 +177,22 @@ __global__ __launch_bounds__(256) void dp_ghost_sqnorm7s2_kernel(GhostParams p) 
     const int px = C * 2 + 16, pd = K * 2 + 16;
     constexpr int HALO = 225;                               // 15 x 15: halo (hy, hx) = input (hy - 1, hx - 1); row 225 = zeros
     {
-        const int kpr = K / 8;
         const bf16* ds = p.dy + (long)n * kGhPix * K;
-        for (int i = tid; i < (kGhPix + 1) * kpr; i += 256) {
-            const int row = i / kpr, ch = i - row * kpr;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < kGhPix) v = *(const u32x4*)(ds + row * K + ch * 8);
-            *(u32x4*)(smem + row * pd + ch * 16) = v;
-        }
+        ghost_stage(smem, pd, kGhPix + 1, K / 8, [&](int row, int ch) -> const u32x4* {
+            return row < kGhPix ? (const u32x4*)(ds + row * K + ch * 8) : nullptr;
+        });
     }
     __syncthreads();
     f32x4 g1[4];
     gram_rows<4>(smem, pd, kGhPix, K, wave, lane, g1);
     __syncthreads();                                         // dy is dead: the input halo takes its place
     {
-        const int cpr = C / 8;
         const bf16* xs = p.x + (long)n * 196 * C;
-        for (int i = tid; i < (HALO + 1) * cpr; i += 256) {
-            const int row = i / cpr, ch = i - row * cpr;
+        ghost_stage(smem, px, HALO + 1, C / 8, [&](int row, int ch) -> const u32x4* {
             const int hy = row / 15, hx = row - hy * 15;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (row < HALO && hy >= 1 && hx >= 1) v = *(const u32x4*)(xs + ((hy - 1) * 14 + hx - 1) * C + ch * 8);
-            *(u32x4*)(smem + row * px + ch * 16) = v;
-        }
+            if (row < HALO && hy >= 1 && hx >= 1) return (const u32x4*)(xs + ((hy - 1) * 14 + hx - 1) * C + ch * 8);
+            return nullptr;
+        });
     }
     __syncthreads();
     // halo row of output pixel q at tap (0, 0): (2 qy) * 15 + 2 qx; tap (r, s): + 15 r + s; pixels >= 49: the zero row
