@@ -215,8 +215,15 @@ __global__ __launch_bounds__(1024) void gn_sample_reduce_kernel(F f, int HW, int
     F lf = f;
     lf.prepare(n, cc * CH);
     const long base = (long)n * HW * C + cc * CH;
+    // rows per trip = loads in flight per thread: a block is alone on its CU, and a tensor that does not come out of the
+    // Infinity Cache (the stem's 411 MB) wants ~128 KB in flight per CU (statistics pass: one load per row -> 8 rows)
+    if constexpr (MODE == 0) {
+#pragma unroll 8
+        for (int r = rg; r < HW; r += rpp) lf(base + (long)r * C, n, cc * CH, s1, s2);
+    } else {
 #pragma unroll 4
-    for (int r = rg; r < HW; r += rpp) lf(base + (long)r * C, n, cc * CH, s1, s2);
+        for (int r = rg; r < HW; r += rpp) lf(base + (long)r * C, n, cc * CH, s1, s2);
+    }
     __shared__ float red[2][1024 * CH];       // [q][row group][channel]
     __shared__ double chs[2][512];
 #pragma unroll
