@@ -669,6 +669,15 @@ int primia_newton_reciprocal_local(const int64_t* v0, const int64_t* v1, const i
  *   matmul: z[M,N] = delta[M,K] @ b[K,N] + a[M,K] @ eps[K,N] + c (+ delta @ eps if j == 0);
  *           `scratch` holds K*N int64 (b + eps for party 0).
  * spdz_mask (spdz.py:21-45) is primia_ring_sub. */
+/* spdz_mask of both operands of a product in one launch: d = x - a (n elements), e = y - b (nb elements) — two
+ * primia_ring_sub calls; and spdz_compute (mul) followed by the party's own truncation of its share by `div`
+ * (FixedPrecisionTensor.__mul__, precision.py:309-316, 356-358: toward zero, like primia_trunc_div) without writing the
+ * product share in between.  Party-local: valid in every deployment; bit-identical to the separate calls. */
+int primia_beaver_mask(const int64_t* x, const int64_t* a, int64_t* d, int64_t n, const int64_t* y, const int64_t* b,
+                       int64_t* e, int64_t nb, primia_stream_t stream);
+int primia_beaver_combine_mul_trunc(int j, const int64_t* delta, const int64_t* eps, const int64_t* a,
+                                    const int64_t* b, const int64_t* c, int64_t* z, int64_t n, int64_t nb,
+                                    int64_t div, primia_stream_t stream);
 int primia_beaver_combine_mul(int j, const int64_t* delta, const int64_t* eps, const int64_t* a,
                               const int64_t* b, const int64_t* c, int64_t* z, int64_t n,
                               int64_t nb, primia_stream_t stream);

@@ -123,6 +123,38 @@ __global__ __launch_bounds__(256) void beaver_mul_kernel(int j, const u64* __res
     }
 }
 
+// ... followed by the party's truncation of ITS share (precision.py:309-316: FPT * FPT = Beaver product, then each share
+// divided by the scale toward zero): the product share is not written and read back in between
+__global__ __launch_bounds__(256) void beaver_mul_trunc_kernel(int j, const u64* __restrict__ delta,
+                                                               const u64* __restrict__ eps, const u64* __restrict__ a,
+                                                               const u64* __restrict__ b, const u64* __restrict__ c,
+                                                               int64_t* __restrict__ z, long n, long nb, u64 div) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const long ib = nb == n ? i : i % nb;
+        const u64 d = delta[i], e = eps[ib];
+        u64 v = d * b[ib] + a[i] * e + c[i];
+        if (j == 0) v += d * e;
+        const int64_t sv = (int64_t)v;
+        const u64 mag = sv < 0 ? (u64)0 - v : v;
+        const u64 q = mag / div;
+        z[i] = sv < 0 ? (int64_t)((u64)0 - q) : (int64_t)q;
+    }
+}
+
+// spdz_mask of both operands in one launch: d = x - a (n elements), e = y - b (nb elements)
+__global__ __launch_bounds__(256) void beaver_mask_kernel(const u64* __restrict__ x, const u64* __restrict__ a,
+                                                          u64* __restrict__ d, long n, const u64* __restrict__ y,
+                                                          const u64* __restrict__ b, u64* __restrict__ e, long nb) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n + nb; i += stride) {
+        if (i < n)
+            d[i] = x[i] - a[i];
+        else
+            e[i - n] = y[i - n] - b[i - n];
+    }
+}
+
 // ---- FixedPrecisionTensor.reciprocal(method="newton") for two parties hosted in ONE process -------------------------
 // precision.py:507-518:   x = (C + 1 - v) / C;  79 x { y = C + 1 - v * (x * x);  x = y * x / C },  C = 20,
 // every product a Beaver multiplication followed by each party's truncation of ITS share, every `C + 1 - t` the
@@ -377,6 +409,26 @@ int primia_newton_reciprocal_local(const int64_t* v0, const int64_t* v1, const i
     newton_local_kernel<<<ceil_div(n, 64), 64, 0, (hipStream_t)st>>>((const u64*)v0, (const u64*)v1,
                                                                       (const u64* const*)prim, (u64)scale, (u64*)x0,
                                                                       (u64*)x1, n);
+    return launch_status();
+}
+
+int primia_beaver_mask(const int64_t* x, const int64_t* a, int64_t* d, int64_t n, const int64_t* y, const int64_t* b,
+                       int64_t* e, int64_t nb, primia_stream_t st) {
+    if (n + nb == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(n >= 0 && nb >= 0 && (n == 0 || (x && a && d)) && (nb == 0 || (y && b && e)));
+    beaver_mask_kernel<<<ew_blocks(n + nb), 256, 0, (hipStream_t)st>>>((const u64*)x, (const u64*)a, (u64*)d, n,
+                                                                       (const u64*)y, (const u64*)b, (u64*)e, nb);
+    return launch_status();
+}
+
+int primia_beaver_combine_mul_trunc(int j, const int64_t* delta, const int64_t* eps, const int64_t* a, const int64_t* b,
+                                    const int64_t* c, int64_t* z, int64_t n, int64_t nb, int64_t div,
+                                    primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE((j == 0 || j == 1) && delta && eps && a && b && c && z && n >= 0 && nb > 0 && nb <= n && div > 0);
+    PRIMIA_REQUIRE(n % nb == 0);
+    beaver_mul_trunc_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)st>>>(j, (const u64*)delta, (const u64*)eps, (const u64*)a,
+                                                                        (const u64*)b, (const u64*)c, z, n, nb, (u64)div);
     return launch_status();
 }
 

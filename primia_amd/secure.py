@@ -22,6 +22,8 @@ Reference map (paths under syft/frameworks/torch/):
   conv2d / pools / bn / lin  nn/functional.py:10-14, 44-75, 204-308, 460-525
   public add / sub / rsub    additive_shared.py:440-527 (constants are RE-SHARED with fresh randomness)
 """
+import os
+
 import torch
 
 from . import _lib
@@ -290,9 +292,12 @@ class SecureContext:
         return self.sub(a, self.share(c))
 
     # ---- Beaver -----------------------------------------------------------------------------------
-    def beaver_mul(self, x, y):
-        """Element-wise private product (no truncation).  One operand may be a vector broadcast over
-        the other's leading dims; the ring product is symmetric so the big one is taken first."""
+    fuse_beaver = os.environ.get("PRIMIA_SECURE_FUSE", "1") != "0"
+
+    def beaver_mul(self, x, y, trunc=None):
+        """Element-wise private product; trunc = d: followed by each party's truncation of its share by d (fpt_mul).
+        One operand may be a vector broadcast over the other's leading dims; the ring product is symmetric so the
+        big one is taken first."""
         xr, yr = self._ref(x), self._ref(y)
         swap = xr.numel() < yr.numel()
         t = self.dealer.triple("mul", tuple(xr.shape), tuple(yr.shape))
@@ -303,17 +308,25 @@ class SecureContext:
         d, e = [None, None], [None, None]
         for j in self.parties:  # spdz_mask
             d[j], e[j] = _empty_like(xr), _empty_like(yr)
-            call("primia_ring_sub", x[j], t[j][0], d[j], n, n)
-            call("primia_ring_sub", y[j], t[j][1], e[j], nb, nb)
+            if self.fuse_beaver:
+                call("primia_beaver_mask", x[j], t[j][0], d[j], n, y[j], t[j][1], e[j], nb)
+            else:
+                call("primia_ring_sub", x[j], t[j][0], d[j], n, n)
+                call("primia_ring_sub", y[j], t[j][1], e[j], nb, nb)
         delta, eps = self.opener.open(d), self.opener.open(e)
+        fused_trunc = trunc is not None and self.fuse_beaver
 
         def one(j):  # spdz_compute
             o = _empty_like(xr)
-            call("primia_beaver_combine_mul", j, delta, eps, t[j][0], t[j][1], t[j][2], o, n, nb)
+            if fused_trunc:
+                call("primia_beaver_combine_mul_trunc", j, delta, eps, t[j][0], t[j][1], t[j][2], o, n, nb, int(trunc))
+            else:
+                call("primia_beaver_combine_mul", j, delta, eps, t[j][0], t[j][1], t[j][2], o, n, nb)
             return o
 
         self.stats["beaver_mul"] += 1
-        return self._each(one)
+        out = self._each(one)
+        return self.trunc(out, trunc) if (trunc is not None and not fused_trunc) else out
 
     def beaver_matmul(self, x, y):
         xr, yr = self._ref(x), self._ref(y)
@@ -323,8 +336,11 @@ class SecureContext:
         d, e = [None, None], [None, None]
         for j in self.parties:
             d[j], e[j] = _empty_like(xr), _empty_like(yr)
-            call("primia_ring_sub", x[j], t[j][0], d[j], xr.numel(), xr.numel())
-            call("primia_ring_sub", y[j], t[j][1], e[j], yr.numel(), yr.numel())
+            if self.fuse_beaver:
+                call("primia_beaver_mask", x[j], t[j][0], d[j], xr.numel(), y[j], t[j][1], e[j], yr.numel())
+            else:
+                call("primia_ring_sub", x[j], t[j][0], d[j], xr.numel(), xr.numel())
+                call("primia_ring_sub", y[j], t[j][1], e[j], yr.numel(), yr.numel())
         delta, eps = self.opener.open(d), self.opener.open(e)
         scratch = torch.empty(K * N, dtype=I64, device=xr.device)
 
@@ -338,7 +354,7 @@ class SecureContext:
 
     def fpt_mul(self, x, y):
         """FPT * FPT (precision.py:309-316, 356-358): Beaver mul, then per-share truncation."""
-        return self.trunc(self.beaver_mul(x, y), self.scale)
+        return self.beaver_mul(x, y, trunc=self.scale)
 
     def fpt_matmul(self, x, y):
         """FPT @ FPT (precision.py:419-463)."""
