@@ -130,7 +130,7 @@ def test_dp_sgd_gradient_matches_oracle(cuda):
                                   (33, 16, 256, 256, 3, 1, 1), (40, 7, 512, 256, 3, 1, 1), (17, 12, 256, 512, 3, 1, 1),
                                   # 7x7 images: "ghost" norms from two Gram matrices per sample (dp_ghost.hip)
                                   (12, 7, 512, 512, 3, 1, 1), (5, 7, 64, 128, 3, 1, 1), (7, 7, 256, 64, 3, 1, 1),
-                                  (11, 14, 256, 512, 3, 2, 1), (3, 14, 64, 64, 3, 2, 1),
+                                  (11, 14, 256, 512, 3, 2, 1), (3, 14, 64, 64, 3, 2, 1), (9, 14, 256, 256, 3, 1, 1),
                                   # whole images per block in the per-tap kernel (stride-2 / 1x1 layers): 784 / 196 / 49
                                   # pixels per image (13 / 4 / 1 stages, the last one ragged), several images per block
                                   (70, 56, 64, 128, 3, 2, 1), (37, 28, 128, 256, 3, 2, 1), (9, 14, 256, 512, 3, 2, 1),
