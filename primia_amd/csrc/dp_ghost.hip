@@ -238,6 +238,8 @@ __global__ __launch_bounds__(256) void dp_ghost_sqnorm7s2_kernel(GhostParams p) 
 // computed: 91 tiles instead of 169, off-diagonal tiles counted twice.  ~120 MFLOP per sample against the 231 of the
 // per-sample gradient, with dy's Gram tiles (up to 28 per wave) kept in registers while the halo replaces dy in LDS.
 // Wave w owns tile rows w, w + 4, w + 8 (, 12).
+// Correct (norms equal to the slab norms at 1e-6) but NOT faster: one 4-wave block per CU reads a fragment per MFMA from
+// LDS, and the per-sample pass it would replace already runs at 0.74 PFLOP/s.  Kept opt-in (PRIMIA_DP_GHOST14=1).
 __global__ __launch_bounds__(256) void dp_ghost_sqnorm14_kernel(GhostParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -345,7 +347,9 @@ int dp_ghost_sqnorm_dispatch(const void* x, const void* dy, double* sq, int N, i
         return launch_status();
     }
     if (H == 14 && W == 14 && stride == 1) {
-        static const bool on14 = !(getenv("PRIMIA_DP_GHOST14") && getenv("PRIMIA_DP_GHOST14")[0] == '0');
+        // measured SLOWER than the per-sample weight-gradient pass it would replace (DP-SGD step 6.42 -> 6.56 ms: three
+        // launches of ~125 us against ~80): opt-in
+        static const bool on14 = getenv("PRIMIA_DP_GHOST14") && getenv("PRIMIA_DP_GHOST14")[0] == '1';
         size_t a = (size_t)257 * (C * 2 + 16), b = (size_t)197 * (K * 2 + 16);
         const size_t lds3 = a > b ? a : b;
         if (!on14 || lds3 > 160 * 1024) return PRIMIA_ERR_UNSUPPORTED;
