@@ -117,9 +117,29 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks as a CHILD (one process per GPU under
+        # torch.distributed.run) before this process has made any GPU call, relay rank 0's JSON line and the exit
+        # code.  (Never re-exec a process that touched the GPU; this parent never does.)
+        import socket
+        import subprocess
+
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+        line = next((ln for ln in reversed(r.stdout.splitlines()) if ln.startswith('{"metric"')), None)
+        if line is not None:
+            print(line)
+        else:
+            sys.stdout.write(r.stdout)
+        raise SystemExit(r.returncode if (r.returncode or line is not None) else 1)
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, "
+                         "or run `python bench.py --gpus N` on its own")
     import torch.distributed as dist
 
     ndev = torch.cuda.device_count()

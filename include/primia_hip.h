@@ -151,6 +151,12 @@ int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_ac
  *   15 the stem's (stem_conv_wgrad_kernel on the padded bf16 input, conv_wgrad_kernel<STEM> otherwise) */
 int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype);
 int primia_conv_wgrad_kernel_id(const primia_conv_desc* d, int dtype);
+/* ... and the kernel that serves primia_conv2d_wgrad_persample_sqnorm (the DP-SGD norm pass, train.py:325-334) for `d`:
+ *   21 dp_ghost_sqnorm7_kernel (7x7 outputs, two Gram matrices per sample)   22 dp_ghost_sqnorm7s2_kernel (stride 2)
+ *   23 dp_ghost_sqnorm14_kernel   24 conv_wgrad_patch33_kernel, one block per (image, slab)
+ *   25 conv_wgrad_patch33_kernel, whole images per half-block   26 conv_wgrad_tap_kernel, whole images per block
+ *   13 / 14 / 15 as above */
+int primia_conv_wgrad_persample_kernel_id(const primia_conv_desc* d, int dtype);
 
 int primia_conv_stat_slots(void);
 /* Slots the kernel chosen for `d` writes: kernels that own whole output rows (layer1's 64->64 convolution)

@@ -232,7 +232,8 @@ def fedavg_secure(state_dicts, weights=None, precision_fractional=16, base=10):
     return out
 
 
-def dp_gradients(sd, x, target, max_grad_norm=1.0, noise_multiplier=1.3, noise=None, pooling="max"):
+def dp_gradients(sd, x, target, max_grad_norm=1.0, noise_multiplier=1.3, noise=None, pooling="max", bf16_storage=False,
+                 return_per_sample=False):
     """DP-SGD gradient as pytorch-dp 0.1b1's PrivacyEngine computes it for the optimizer
     (parameter values: train.py:325-334): per-sample gradients of each sample's own loss, flat L2
     clip to C with factor min(1, C / (norm + 1e-6)), sum, + N(0, (noise_multiplier*C)^2), / batch.
@@ -241,7 +242,8 @@ def dp_gradients(sd, x, target, max_grad_norm=1.0, noise_multiplier=1.3, noise=N
     GroupNorm network makes samples independent, so they are batch-of-1 gradients, and
     tests/golden/make_train_golden.py (mint_dp) checks them against the reference's model class
     (norm_layer=GroupNorm) differentiated by torch.func.vmap(grad) — tests/golden/dp_ref.npz.
-    `noise`: dict key -> standard-normal tensor (explicit randomness).  Returns (grads, norms, clip)."""
+    `noise`: dict key -> standard-normal tensor (explicit randomness).  Returns (grads, norms, clip).
+    `bf16_storage` (tests only): the forward pass rounds to bf16 where the bf16 engine stores (see forward())."""
     keys = param_keys(sd)
     B = x.shape[0]
     per = []
@@ -249,7 +251,7 @@ def dp_gradients(sd, x, target, max_grad_norm=1.0, noise_multiplier=1.3, noise=N
         for k in keys:
             sd[k].requires_grad_(True)
             sd[k].grad = None
-        logits = forward(sd, x[n:n + 1], True, pooling, x.shape[-1])
+        logits = forward(sd, x[n:n + 1], True, pooling, x.shape[-1], bf16_storage=bf16_storage)
         F.cross_entropy(logits, target[n:n + 1]).backward()
         per.append(OrderedDict((k, sd[k].grad.detach().clone()) for k in keys))
     for k in keys:
@@ -262,4 +264,6 @@ def dp_gradients(sd, x, target, max_grad_norm=1.0, noise_multiplier=1.3, noise=N
         if noise is not None:
             s = s + noise[k] * (noise_multiplier * max_grad_norm)
         out[k] = s / B
+    if return_per_sample:
+        return out, norms, clip, per
     return out, norms, clip

@@ -37,6 +37,9 @@ size_t wgrad_dma_ws_bytes(const WgradParams& p);
 // halo-patch kernel (3x3, stride 1, bf16); returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered
 int wgrad_patch_dispatch(const WgradParams& p, hipStream_t st);
 int wgrad_patch_kernel_id(const WgradParams& p);
+int wgrad_patch_persample_kernel_id(const WgradParams& p);
+int wgrad_tap_persample_kernel_id(const WgradParams& p);
+int dp_ghost_kernel_id(int H, int W, int C, int K, int R, int S, int stride, int pad);
 size_t wgrad_patch_ws_bytes(const WgradParams& p);
 // up to four layers of one shape in one launch (conv_wgrad_patch.hip): preferred group size for `count` such layers
 // (0: shape not served, 1: no gain), workspace of a group of n, and the launch (p[0].ws / ws_bytes = the group's)

@@ -664,6 +664,26 @@ extern "C" int primia_conv2d_wgrad_persample_sqnorm(const primia_conv_desc* d, c
     return conv2d_wgrad_impl(d, x, dy, nullptr, 1, dtype, stream, sqnorm);
 }
 
+extern "C" int primia_conv_wgrad_persample_kernel_id(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    WgradParams p;
+    if (!d || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
+    p.persample = 1;
+    if (g.stem) return 15;
+    if (dtype != PRIMIA_BF16) return 14;
+    const int gh = dp_ghost_kernel_id(d->H, d->W, d->C, d->K, d->R, d->S, d->stride, d->pad);
+    if (gh) return gh;
+    const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    if (!force) {
+        const int id = wgrad_patch_persample_kernel_id(p);
+        if (id) return id;
+        const int idt = wgrad_tap_persample_kernel_id(p);
+        if (idt) return idt;
+    }
+    const bool dma = force == 'd' || (force != 'o' && (g.C >= 256 || (g.K >= 256 && g.C >= 128)));
+    return dma ? 13 : 14;
+}
+
 extern "C" int primia_conv_wgrad_kernel_id(const primia_conv_desc* d, int dtype) {
     ConvGeom g;
     WgradParams p;

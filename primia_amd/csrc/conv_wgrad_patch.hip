@@ -1667,6 +1667,15 @@ int wgrad_patch_kernel_id(const WgradParams& w) {
     return use_v3() ? 16 : (use_v2() ? 11 : 12);
 }
 
+// DP-SGD norm pass on this kernel: 0 shape not served, 24 one block per (image, slab), 25 whole images per half-block
+int wgrad_patch_persample_kernel_id(const WgradParams& w) {
+    WgradParams q = w;
+    q.persample = 1;
+    const PatchGeom g = patch_geom(q);
+    if (!g.ok) return 0;
+    return pairimg_mode(q, g) ? 25 : 24;
+}
+
 int wgrad_patch_dispatch(const WgradParams& w, hipStream_t st) {
     const PatchGeom g = patch_geom(w);
     if (!g.ok) return PRIMIA_ERR_UNSUPPORTED;

@@ -451,6 +451,14 @@ static int launch_tap_persample(const WgradParams& w, const TapGeom& g, hipStrea
     return launch_status();
 }
 
+// 26 = conv_wgrad_tap_kernel's norm pass (whole images per block), 0 = shape not served
+int wgrad_tap_persample_kernel_id(const WgradParams& w) {
+    static const bool off = getenv("PRIMIA_WGTAP_PS") && getenv("PRIMIA_WGTAP_PS")[0] == '0';
+    WgradParams b = w;
+    b.persample = 0;
+    return (off || !tap_geom(b).ok || w.Ho * w.Wo < 1) ? 0 : 26;
+}
+
 int wgrad_tap_persample_dispatch(const WgradParams& w, hipStream_t st) {
     static const bool off = getenv("PRIMIA_WGTAP_PS") && getenv("PRIMIA_WGTAP_PS")[0] == '0';
     if (off || !w.persample || !w.sqnorm) return PRIMIA_ERR_UNSUPPORTED;

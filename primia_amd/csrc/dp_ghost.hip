@@ -327,6 +327,27 @@ __global__ __launch_bounds__(256) void dp_ghost_sqnorm14_kernel(GhostParams p) {
 }
 
 // PRIMIA_ERR_UNSUPPORTED where the form does not apply (the caller keeps its per-sample weight-gradient pass)
+// which Gram-matrix kernel serves the norm pass of this layer: 0 none, 21 dp_ghost_sqnorm7_kernel (7x7, stride 1),
+// 22 dp_ghost_sqnorm7s2_kernel (14x14 -> 7x7, stride 2), 23 dp_ghost_sqnorm14_kernel (opt-in)
+int dp_ghost_kernel_id(int H, int W, int C, int K, int R, int S, int stride, int pad) {
+    static const bool off = getenv("PRIMIA_DP_GHOST") && getenv("PRIMIA_DP_GHOST")[0] == '0';
+    if (off || R != 3 || S != 3 || pad != 1 || C % 32 || K % 32 || C < 32 || K < 32) return 0;
+    if (H == 14 && W == 14 && stride == 2) {
+        size_t a = (size_t)226 * (C * 2 + 16), b = (size_t)(kGhPix + 1) * (K * 2 + 16);
+        return (a > b ? a : b) > 160 * 1024 ? 0 : 22;
+    }
+    if (H == 14 && W == 14 && stride == 1) {
+        static const bool on14 = getenv("PRIMIA_DP_GHOST14") && getenv("PRIMIA_DP_GHOST14")[0] == '1';
+        size_t a = (size_t)257 * (C * 2 + 16), b = (size_t)197 * (K * 2 + 16);
+        return (!on14 || (a > b ? a : b) > 160 * 1024) ? 0 : 23;
+    }
+    if (H != 7 || W != 7 || stride != 1) return 0;
+    size_t sdb = (size_t)(kGhPix + 1) * (K * 2 + 16);
+    if (sdb < (size_t)kGhHalo * 84 * 4) sdb = (size_t)kGhHalo * 84 * 4;
+    const size_t lds = (size_t)(kGhHalo + 1) * (C * 2 + 16) + sdb + (size_t)kGhPix * 52 * 4;
+    return lds > 160 * 1024 ? 0 : 21;
+}
+
 int dp_ghost_sqnorm_dispatch(const void* x, const void* dy, double* sq, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, hipStream_t st) {
     static const bool off = getenv("PRIMIA_DP_GHOST") && getenv("PRIMIA_DP_GHOST")[0] == '0';

@@ -169,24 +169,43 @@ def register_federated(samples, onehot, orders, mix: Optional[MixUp]):
     return data, tgts
 
 
-def calc_class_weights(args, train_loader, num_classes):
-    """torchlib/utils.py:469-513: every class's share of 1 / (its number of training targets), normalised to sum 1.
-    `train_loader` is one loader, or {worker: loader} when federated; soft / one-hot targets (mixup or federated
-    weight_classes) count for their arg-max class.  No target at all -> ones (the reference warns the same way)."""
+def class_counts(train_loader, num_classes):
+    """Occurrences of every class over the training targets (the counting loop of calc_class_weights,
+    torchlib/utils.py:479-497).  A loader that holds its targets (`.targets`: hard labels or one-hot / mixed rows, which
+    count for their arg-max class) is counted from them directly — the ragged last batch included, as the reference's
+    loader yields it, and without drawing a single augmentation or shuffle; anything else is iterated."""
+    loaders = list(train_loader.values()) if isinstance(train_loader, dict) else [train_loader]
+    occ = torch.zeros(num_classes, dtype=torch.float64)
+
+    def count(target):
+        if target.dim() == 2:
+            target = target.max(dim=1)[1]
+        return torch.bincount(target.reshape(-1).to(torch.int64), minlength=num_classes)[:num_classes].double().cpu()
+
+    for tl in loaders:
+        held = getattr(tl, "targets", None)
+        if held is not None:
+            occ += count(held)
+        else:
+            for _, target in tl:
+                occ += count(target)
+    return occ.to(torch.float32)
+
+
+def class_weights_from_counts(occ):
+    """torchlib/utils.py:498-513: 1 / count, normalised to sum 1; no target at all -> ones (the reference warns)."""
     from warnings import warn
 
-    loaders = list(train_loader.values()) if isinstance(train_loader, dict) else [train_loader]
-    soft = bool(getattr(args, "train_federated", False) and (args.mixup or args.weight_classes))
-    occ = torch.zeros(num_classes, dtype=torch.float64)
-    for tl in loaders:
-        for _, target in tl:
-            if soft:
-                target = target.max(dim=1)[1]
-            occ += torch.bincount(target.reshape(-1).to(torch.int64), minlength=num_classes)[:num_classes].double().cpu()
-    occ = occ.to(torch.float32)
     if torch.sum(occ).item() == 0:
         warn("class weights could not be calculated - no weights are used")
-        return torch.ones((num_classes,))
+        return torch.ones((occ.numel(),))
     cw = 1.0 / occ
     cw /= torch.sum(cw)
     return cw
+
+
+def calc_class_weights(args, train_loader, num_classes):
+    """torchlib/utils.py:469-513: every class's share of 1 / (its number of training targets), normalised to sum 1.
+    `train_loader` is one loader, or {worker: loader} when federated; soft / one-hot targets (mixup or federated
+    weight_classes) count for their arg-max class."""
+    return class_weights_from_counts(class_counts(train_loader, num_classes))

@@ -1164,6 +1164,8 @@ class ResNet18Engine:
                  nc * 512)
             call("primia_weighted_colsum", ps_fc[:, nc * 512:].contiguous(), clip, self.gviews["fc.bias"], N, nc)
         finally:
+            if getattr(self, "dp_keep_operands", False):      # tests: the (layer, x, dy) triples the norm pass walked
+                self.dp_operands = list(self.dp["wgrads"])
             self.dp = None
         if noise is None:
             noise = torch.randn(self.P, dtype=torch.float32, device=dev, generator=generator)

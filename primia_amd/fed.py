@@ -197,6 +197,15 @@ def exchange_mean_std(mean, std, group=None, ops=None, precision_fractional=3, b
     return out[:n].reshape(mean.shape), out[n:].reshape(std.shape)
 
 
+def masked_sum(counts, masks, group=None):
+    """Ring sum of small non-negative integer vectors (per-class sample counts) across the ranks under the pairwise
+    one-time masks: what leaves a client is uniformly random, the masks cancel in the sum.  Returns fp32 counts."""
+    q = counts.to(torch.int64).contiguous()
+    masks.apply(q)
+    dist.all_reduce(q, op=dist.ReduceOp.SUM, group=group)
+    return q.to(torch.float32)
+
+
 def secure_mean_of(stats, ops=None, precision_fractional=3, base=10):
     """exchange_mean_std for clients that live in ONE process: `stats` = [(mean, std), ...]; same arithmetic
     (encode each, ring sum, decode, / K)."""

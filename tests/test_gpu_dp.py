@@ -311,3 +311,105 @@ def test_groupnorm_relu_masks_give_the_same_bits(cuda, dtype, batch, size):
         assert torch.equal(a, b)
     # (the fp32 norm pass adds its squares with atomics: equal to fp64 rounding, not to the bit)
     assert torch.allclose(out[0][3], out[1][3], rtol=1e-10, atol=0.0)
+
+
+PS_KERNEL = {21: "ghost 7x7", 22: "ghost 14->7 stride 2", 24: "patch, block per image", 25: "patch, whole images per half",
+             26: "per-tap, whole images per block", 13: "dma", 14: "generic", 15: "stem"}
+
+
+def _norm_pass_kernels(eng):
+    """{conv name: 'kept' | id of the kernel primia_conv2d_wgrad_persample_sqnorm dispatches to}."""
+    kept = eng._dp_keep_buffers()
+    return {c.name: ("kept" if c.name in kept else query("primia_conv_wgrad_persample_kernel_id", eng.convs[c.name].desc, eng.dt))
+            for c in eng.spec.convs}
+
+
+def test_dp_step_bf16_at_224_against_oracle(cuda):
+    """BASELINE configs[3] at the resolution and dtype `bench.py --dp` times (224x224, bf16; batch 16 so that the oracle's
+    per-sample loop stays in seconds): layer4 is 7x7 here, so the Gram-matrix norm kernels (dp_ghost.hip), the kept-tile
+    clipped sums (stem, layer1, layer2) and the per-tap whole-image norm pass (transition blocks) are the paths taken —
+    asserted — and their per-sample norms, clip factors and clipped sum are held to O.dp_gradients
+    (reference rule: train.py:325-334).  Two oracles: the fp32 one (what the reference computes) and the same with
+    nothing but bf16 rounding at the engine's storage points, which separates storage format from kernel error."""
+    batch, size = 16, 224
+    torch.manual_seed(41)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, size, "max"), "group")
+    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.bfloat16, device=cuda, norm="group")
+    eng.load_state_dict(sd)
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(batch, 3, size, size, generator=g)
+    y = torch.randint(0, 3, (batch,), generator=g)
+    eng.forward(x.to(cuda))
+    kern = _norm_pass_kernels(eng)
+    assert kern["conv1"] == "kept" and all(kern[f"layer{l}.{b}.conv{c}"] == "kept" for l in (1, 2) for b in (0, 1)
+                                           for c in (1, 2) if (l, b, c) != (2, 0, 1)), kern
+    assert [kern[k] for k in ("layer4.0.conv2", "layer4.1.conv1", "layer4.1.conv2")] == [21, 21, 21], kern
+    assert kern["layer4.0.conv1"] == 22, kern
+    for k in ("layer2.0.conv1", "layer2.0.downsample.0", "layer3.0.conv1", "layer3.0.downsample.0", "layer4.0.downsample.0"):
+        assert kern[k] == 26, (k, kern[k])
+    C = 0.05       # clips most samples at this initialisation, not all of them
+    eng.forward(x.to(cuda))
+    eng.dp_loss_backward(y.to(cuda), C, 0.0, noise=torch.zeros(eng.P, device=cuda))
+    got_norms = eng.dp_stats["sq_norms"].sqrt().cpu()
+    got_clip = eng.dp_stats["clip"].cpu().double()
+    fresh = lambda: {k: v.clone() for k, v in sd.items()}
+    want32, norms32, clip32 = O.dp_gradients(fresh(), x, y, C, 0.0, None)
+    want16, norms16, clip16 = O.dp_gradients(fresh(), x, y, C, 0.0, None, bf16_storage=True)
+    e32 = ((got_norms - norms32).abs() / norms32).max().item()
+    e16 = ((got_norms - norms16).abs() / norms16).max().item()
+    o16 = ((norms16 - norms32).abs() / norms32).max().item()
+    print(f"per-sample norms: engine vs fp32 oracle {e32:.3e}, vs bf16-storage oracle {e16:.3e}, oracle bf16 vs fp32 {o16:.3e}")
+    assert e16 < 2e-2 and e32 < max(3e-2, 2 * o16), (e16, e32, o16)
+    assert (clip32 < 1).any() or (clip16 < 1).any(), "test should exercise clipping"
+    assert torch.allclose(got_clip, clip16, rtol=2e-2) and torch.allclose(got_clip, clip32, rtol=max(3e-2, 2 * o16))
+    flat = lambda d: torch.cat([d[k].reshape(-1).double() for k, _ in eng.p_entries])
+    gvec = torch.cat([eng.gviews[k].reshape(-1).double().cpu() for k, _ in eng.p_entries])
+    d32, d16, oo = rel(gvec, flat(want32)), rel(gvec, flat(want16)), rel(flat(want16), flat(want32))
+    print(f"clipped mean gradient (all 62 tensors): engine vs fp32 {d32:.3e}, vs bf16-storage oracle {d16:.3e}, "
+          f"oracle bf16 vs fp32 {oo:.3e}")
+    # the engine is held to the band the storage format alone opens (as the BatchNorm path's bf16 gradient test does)
+    assert d16 < 1.25 * oo + 0.02 and d32 < 1.25 * oo + 0.02, (d32, d16, oo)
+    assert gvec.norm().item() <= C * 1.02
+
+
+def test_dp_norm_pass_at_batch_256_against_explicit_slabs(cuda):
+    """The DP bench's own size (batch 256, 224x224, bf16): every layer's contribution to ||g_n||^2 as the norm pass
+    produced it (Gram-matrix, kept-tile, whole-images-per-half patch and per-tap kernels) against the squares of the
+    EXPLICIT per-sample gradient slabs (primia_conv2d_wgrad_persample) formed from the same (x, dy) buffers."""
+    from collections import OrderedDict
+
+    batch, size = 256, 224
+    torch.manual_seed(43)
+    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.bfloat16, device=cuda, norm="group")
+    eng.init_weights()
+    g = torch.Generator().manual_seed(44)
+    x = torch.randn(batch, 3, size, size, generator=g).to(cuda)
+    y = torch.randint(0, 3, (batch,), generator=g).to(cuda)
+    eng.forward(x)
+    kern = _norm_pass_kernels(eng)
+    assert {kern[f"layer3.{b}.conv{c}"] for b, c in ((0, 2), (1, 1), (1, 2))} == {25}, kern    # whole images per half
+    assert kern["layer4.1.conv1"] == 21 and kern["layer4.0.conv1"] == 22 and kern["layer3.0.conv1"] == 26
+    eng.dp_trace, eng.dp_keep_operands = OrderedDict(), True
+    eng.forward(x)
+    # C so large that every clip factor is exactly 1: the in-place row scaling of dy that follows the norm pass is x 1.0
+    eng.dp_loss_backward(y, 1e12, 0.0, noise=torch.zeros(eng.P, device=cuda))
+    torch.cuda.synchronize()
+    assert torch.all(eng.dp_stats["clip"] == 1.0)
+    prev, inc = None, {}
+    for name, cum in eng.dp_trace.items():
+        inc[name] = cum - prev if prev is not None else cum.clone()
+        prev = cum
+    x4 = torch.zeros(batch, size, size, 4, dtype=torch.bfloat16, device=cuda)
+    x4[..., :3] = x.permute(0, 2, 3, 1).to(torch.bfloat16)
+    worst = 0.0
+    for name, xin, dy in eng.dp_operands:
+        d = eng.convs[name].desc
+        ne = query("primia_conv_wfwd_elems", d)
+        slab = torch.zeros(batch, ne, device=cuda)
+        call("primia_conv2d_wgrad_persample", d, x4.view(-1, 4) if name == "conv1" else xin, dy, slab, eng.dt)
+        ref = (slab.double() ** 2).sum(1)
+        e = ((inc[name] - ref).abs() / ref).max().item()
+        worst = max(worst, e)
+        assert e < 2e-5, (name, kern[name], e)
+        del slab
+    print(f"batch-256 norm pass vs explicit slabs: worst per-sample relative error {worst:.2e}")

@@ -115,7 +115,7 @@ def test_federated_epoch_tracks_oracle(cuda):
 
 
 def run(cmd, env=None):
-    e = dict(os.environ)
+    e = dict(os.environ, PRIMIA_ALLOW_RANDOM_INIT="1")   # the smoke preset says pretrained = yes; no ImageNet file here
     e.update(env or {})
     r = subprocess.run([sys.executable] + cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -168,6 +168,21 @@ def test_bench_two_ranks_control_flow(tmp_path, secure):
     assert d["config"]["secure_aggregation"] is secure
     assert d["hip_graph"] is True   # the local step is replayed as a graph at every rank count, the exchange is not
     assert d["value"] > 0 and abs(d["value"] - 2 * d["images_per_sec_per_client"]) < 1e-3 * d["value"]
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment: the parent (which never touches the GPU) starts
+    the two ranks as a child under torch.distributed.run, relays rank 0's JSON line and the exit code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(PRIMIA_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "4", "--warmup", "1", "--batch", "8", "--size", "64",
+           "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines          # ONE JSON line on stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["clients"] == 2 and d["fedavg_ms_per_sync"] is not None
 
 
 def test_aggregation_kernels_match_reference_aggregation(cuda, golden_dir):

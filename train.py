@@ -71,51 +71,60 @@ class SyntheticLoader:
     def __iter__(self):
         return iter(self.data)
 
-
-def class_counts(train_loader, num_classes, soft_targets):
-    """Occurrences of every class over this process's training targets (the counting loop of calc_class_weights)."""
-    loaders = list(train_loader.values()) if isinstance(train_loader, dict) else [train_loader]
-    occ = torch.zeros(num_classes, dtype=torch.float32)
-    for tl in loaders:
-        for _, target in tl:
-            if soft_targets and target.dim() == 2:
-                target = target.max(dim=1)[1]
-            occ += torch.bincount(target.reshape(-1).to(torch.int64), minlength=num_classes)[:num_classes].float().cpu()
-    return occ
+    @property
+    def targets(self):
+        return torch.cat([t for _, t in self.data])
 
 
 PRETRAINED_FILES = ("resnet18-5c106cde.pth", "resnet18-f37072fd.pth")      # torchvision's ImageNet ResNet-18 files
 
 
-def load_pretrained(engine, num_classes):
+def load_pretrained(engine, num_classes, rank=0, world=1):
     """`pretrained = yes` (torchlib/models.py:488-496): the ImageNet state dict goes into the freshly constructed
     network, then `fc` is REPLACED by a new Linear(512, num_classes) with torch's default initialisation.  The
     reference downloads the file; here it is read from PRIMIA_PRETRAINED_RESNET18 or torch's hub cache
-    (~/.cache/torch/hub/checkpoints/) — there is no network on the training box.  Without the file the run continues
-    from the random initialisation with a warning (it still has the three-channel stem `pretrained` selects)."""
-    cands = [os.environ.get("PRIMIA_PRETRAINED_RESNET18")] + [
-        path.join(path.expanduser("~"), ".cache", "torch", "hub", "checkpoints", f) for f in PRETRAINED_FILES]
-    src = next((c for c in cands if c and path.isfile(c)), None)
-    if src is None:
-        warn("pretrained = yes, but no ImageNet ResNet-18 state dict was found (set PRIMIA_PRETRAINED_RESNET18 to a "
-             "torchvision resnet18 .pth): training starts from the random initialisation")
-        return False
-    sd = torch.load(src, map_location="cpu", weights_only=True)
-    own = engine.state_dict()
+    (~/.cache/torch/hub/checkpoints/) — there is no network on the training box.  A missing file ENDS the run (the
+    reference's main preset depends on these weights; training from scratch instead would be a different experiment)
+    unless PRIMIA_ALLOW_RANDOM_INIT=1 says that is what is wanted.  Under torch.distributed.run rank 0 reads the file
+    and every rank takes rank 0's arena, so all clients start from the same model whatever their own caches hold."""
     if engine.norm != "batch":
         raise SystemExit("pretrained ImageNet weights carry BatchNorm statistics; differentially_private = yes builds "
                          "a GroupNorm network (train.py:304-334)")
-    for k, v in sd.items():
-        if k.startswith("fc."):
-            continue
-        if k not in own or tuple(own[k].shape) != tuple(v.shape):
-            raise SystemExit("{:s}: {:s} does not fit this network ({} vs {})".format(
-                src, k, tuple(v.shape), tuple(own[k].shape) if k in own else None))
-        own[k] = v.to(torch.float32)
-    fc = torch.nn.Linear(512, num_classes)            # model.fc = nn.Linear(512 * block.expansion, num_classes)
-    own["fc.weight"], own["fc.bias"] = fc.weight.detach().clone(), fc.bias.detach().clone()
-    engine.load_state_dict(own)
-    return True
+    found = True
+    if rank == 0:
+        cands = [os.environ.get("PRIMIA_PRETRAINED_RESNET18")] + [
+            path.join(path.expanduser("~"), ".cache", "torch", "hub", "checkpoints", f) for f in PRETRAINED_FILES]
+        src = next((c for c in cands if c and path.isfile(c)), None)
+        found = src is not None
+        if found:
+            sd = torch.load(src, map_location="cpu", weights_only=True)
+            own = engine.state_dict()
+            for k, v in sd.items():
+                if k.startswith("fc."):
+                    continue
+                if k not in own or tuple(own[k].shape) != tuple(v.shape):
+                    raise SystemExit("{:s}: {:s} does not fit this network ({} vs {})".format(
+                        src, k, tuple(v.shape), tuple(own[k].shape) if k in own else None))
+                own[k] = v.to(torch.float32)
+            fc = torch.nn.Linear(512, num_classes)        # model.fc = nn.Linear(512 * block.expansion, num_classes)
+            own["fc.weight"], own["fc.bias"] = fc.weight.detach().clone(), fc.bias.detach().clone()
+            engine.load_state_dict(own)
+    if world > 1:
+        import torch.distributed as dist
+
+        flag = torch.tensor([1 if found else 0], device=engine.flat.device)
+        dist.broadcast(flag, 0)
+        found = bool(flag.item())
+    if not found:
+        msg = ("pretrained = yes, but no ImageNet ResNet-18 state dict was found (set PRIMIA_PRETRAINED_RESNET18 to a "
+               "torchvision resnet18 .pth)")
+        if os.environ.get("PRIMIA_ALLOW_RANDOM_INIT") != "1":
+            raise SystemExit(msg + "; PRIMIA_ALLOW_RANDOM_INIT=1 trains from the random initialisation instead")
+        warn(msg + ": training starts from the random initialisation (PRIMIA_ALLOW_RANDOM_INIT=1)")
+    if world > 1:
+        dist.broadcast(engine.flat, 0)          # found or not: every client starts from rank 0's model
+        engine.refresh_weights()
+    return found
 
 
 def setup_workers(args):
@@ -196,6 +205,10 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
         raise NotImplementedError("only resnet-18 is on the accelerated path")
     if world > 1 and not args.train_federated:
         raise SystemExit("several ranks are several federated clients: launch with --train_federated")
+    if args.differentially_private and (args.weight_classes or args.mixup):
+        # the per-sample (DP-SGD) loss gradient takes hard, unweighted labels: say so before any data is registered
+        raise SystemExit("differentially_private = yes cannot be combined with weight_classes / mixup: the per-sample "
+                         "clipped gradients are formed from hard, unweighted targets")
     dtype = torch.float32 if os.environ.get("PRIMIA_DTYPE", "bf16") == "f32" else torch.bfloat16
     n_batches = int(os.environ.get("PRIMIA_SYNTHETIC_BATCHES", 8))
     synthetic = args.data_dir in (None, "synthetic")
@@ -218,7 +231,7 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
     local = make_engine()
     local.init_weights()
     if args.pretrained:
-        load_pretrained(local, num_classes)
+        load_pretrained(local, num_classes, rank, world)
     val_mean_std = (torch.zeros(channels), torch.ones(channels))
     exp_name = "{:s}_{:s}".format("federated" if args.train_federated else "vanilla", args.name)
     group = None
@@ -285,16 +298,22 @@ def main(args, verbose=True, optuna_trial=None, cmd_args=None):
     # class weights (train.py:192-195, utils.py:469-513): counted over the training targets of every client — across
     # ranks the per-class counts are summed — and handed to every engine's loss
     if args.weight_classes:
-        from primia_amd.datapipe import calc_class_weights
+        from primia_amd.datapipe import class_counts, class_weights_from_counts
 
-        cw = calc_class_weights(args, train_loader, num_classes)
+        # counted from the loaders' held targets (no batch is drawn: the augmentation and shuffle streams stay where
+        # they are); across ranks the per-class COUNTS are summed (the weights are not additive), under the pairwise
+        # masks when aggregation is secure
+        occ = class_counts(train_loader, num_classes)
         if world > 1:
             import torch.distributed as dist
 
-            # (the weights are not additive across clients: the counts are what is exchanged)
-            occ = class_counts(train_loader, num_classes, soft_targets=bool(args.train_federated)).to(device)
-            dist.all_reduce(occ)
-            cw = torch.ones(num_classes) if occ.sum().item() == 0 else ((1.0 / occ) / (1.0 / occ).sum()).float().cpu()
+            if masks is not None:
+                occ = fed.masked_sum(occ.to(device), masks).cpu()
+            else:
+                occ = occ.to(device)
+                dist.all_reduce(occ)
+                occ = occ.cpu()
+        cw = class_weights_from_counts(occ)
         engines = [m for m in model.values()] if isinstance(model, dict) else [model]
         for m in engines:
             m.class_weight = cw.to(device).float().contiguous()
