@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--no-secure", action="store_true", help="skip the encrypted-inference leg (second BASELINE metric)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel from Python instead of replaying a hipGraph")
     ap.add_argument("--cpu-baseline-batch", type=int, default=256)   # N = 256
+    ap.add_argument("--no-fuse-sgd", action="store_true", help="gradient finalize, SGD and weight refresh as three passes")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="primia_set_option(NAME, VALUE) before anything is built (A/B runs; csrc/options.h)")
+    ap.add_argument("--engine-opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="ResNet18Engine(options={NAME: VALUE}) (schedule switches of the engine)")
     return ap.parse_args()
 
 
@@ -157,13 +162,23 @@ def main():
     from primia_amd import fed
     from primia_amd.engine import ResNet18Engine
 
+    from primia_amd import _lib as _plib
+
+    for kv in a.opt:
+        k, _, v = kv.partition("=")
+        _plib.set_option(k, int(v))
+    eopts = {}
+    for kv in a.engine_opt:
+        k, _, v = kv.partition("=")
+        eopts[k] = {"true": True, "false": False}.get(v.lower(), int(v) if v.lstrip("-").isdigit() else v)
     dtype = torch.bfloat16 if a.dtype == "bf16" else torch.float32
-    eng = ResNet18Engine(a.batch, 3, 3, a.size, "max", dtype=dtype, device=dev, norm="group" if a.dp else "batch")
+    eng = ResNet18Engine(a.batch, 3, 3, a.size, "max", dtype=dtype, device=dev, norm="group" if a.dp else "batch",
+                         options=eopts)
     if a.dp:
         eng.dp_params = {"max_grad_norm": 1.0, "noise_multiplier": 1.3}   # train.py:325-334
     # SGD follows the backward pass directly: gradient finalize + update + weight refresh as one pass per weight tile
-    # (what EngineOptimizer("SGD") switches on for the training loops; PRIMIA_FUSE_SGD=0: the three unfused passes)
-    eng.fuse_sgd_tail = os.environ.get("PRIMIA_FUSE_SGD", "1") != "0"
+    # (what EngineOptimizer("SGD") switches on for the training loops; --no-fuse-sgd: the three unfused passes)
+    eng.fuse_sgd_tail = not a.no_fuse_sgd
     torch.manual_seed(42)           # the reference's default seed (pneumonia-resnet-pretrained.ini:17)
     eng.init_weights()
     g = torch.Generator().manual_seed(1000 + rank)
@@ -293,10 +308,8 @@ def main():
     from primia_amd import _lib
     from primia_amd._lib import query
 
-    KNAME = {1: "conv_igemm_kernel", 2: "conv3x3_c64_kernel (fwd + dgrad)", 3: "conv3x3_lh_kernel (fwd + dgrad)",
-             4: "conv3x3_lh2_kernel (fwd + dgrad)", 11: "conv_wgrad_patch32_kernel + wgrad_patch32_reduce_kernel",
-             12: "conv_wgrad_patch_kernel + wgrad_patch_reduce_kernel", 13: "conv_wgrad_dma_kernel (per-tap, stride 2 / 1x1)",
-             14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)",
+    KNAME = {1: "conv_igemm_kernel", 2: "conv3x3_c64_kernel (fwd + dgrad)", 4: "conv3x3_lh2_kernel (fwd + dgrad)",
+             13: "conv_wgrad_dma_kernel (per-tap, stride 2 / 1x1)", 14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)",
              16: "conv_wgrad_patch33_kernel + wgrad_patch32_reduce_kernel",
              17: "conv_wgrad_tap_kernel + wgrad_tile_reduce_kernel (per-tap, stride 2 / 1x1)"}
     dtc = _lib.dtype_code(dtype)

@@ -42,6 +42,21 @@ typedef void* primia_stream_t; /* hipStream_t */
 
 int primia_abi_version(void);
 
+/* ---- options -------------------------------------------------------------------------------------------------------
+ * The library never reads the environment.  Every switch that selects between kernels or sizes a launch (the A/B knobs
+ * of the measurements under profiles/) is an entry of ONE process-wide table with the defaults the benchmarks run on:
+ * primia_set_option("lh2", 0) keeps the wide 3x3 layers on the implicit GEMM, ("wgp_group", 0) launches every weight
+ * gradient on its own, ("dp_ghost", 0) takes the DP-SGD norms from the weight-gradient kernels, ...  The names, defaults
+ * and meanings are listed in primia_amd/csrc/options.h; unknown names return PRIMIA_ERR_ARG.  Options are read when a
+ * call dispatches (and by the *_bytes / *_ok / *_kernel_id queries, which therefore must be asked again after a
+ * change); they are not thread-synchronised — set them before the streams start.  The reference has no counterpart
+ * (torch picks its own kernels). */
+int primia_set_option(const char* name, int value);
+int primia_get_option(const char* name, int* value);
+int primia_reset_options(void);
+int primia_option_count(void);
+int primia_option_name(int index, char* buf, int buf_len);
+
 /* ------------------------------------------------------------------------------------------
  * Layout conversion at the boundary.  The reference hands NCHW fp32 batches to the model
  * (torchlib/utils.py:1169-1170); kernels run NHWC.  c_pad >= C pads channels with zeros
@@ -142,11 +157,11 @@ int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_ac
  * BatchNorm that follows — are accumulated into stat_sums, laid out [slots][2][K] with
  * slots = primia_conv_stat_slots() partial sums (spread to keep atomics uncontended); caller zeroes it. */
 /* Which kernel the library's dispatch rules select for a convolution (measurement tooling: bench.py names its
- * roofline families with it, so a run under PRIMIA_LH2=0 / PRIMIA_WGP32=0 / PRIMIA_WGRAD=... reports the kernel that
+ * roofline families with it, so a run under primia_set_option("lh2", 0) / ("wgrad_kernel", 2) / ... reports the kernel that
  * actually ran).  pass 0 = forward, 1 = data gradient:
- *   1 conv_igemm_kernel   2 conv3x3_c64_kernel   3 conv3x3_lh_kernel   4 conv3x3_lh2_kernel
+ *   1 conv_igemm_kernel   2 conv3x3_c64_kernel   4 conv3x3_lh2_kernel   (3: conv3x3_lh_kernel, removed in round 4)
  * weight gradient:
- *   11 conv_wgrad_patch32_kernel   12 conv_wgrad_patch_kernel   13 conv_wgrad_dma_kernel   14 conv_wgrad_kernel
+ *   13 conv_wgrad_dma_kernel   14 conv_wgrad_kernel   (11 / 12: the first two patch kernels, removed in round 4)
  *   16 conv_wgrad_patch33_kernel (3 + 3 fragments per k-step; the default)   17 conv_wgrad_tap_kernel
  *   15 the stem's (stem_conv_wgrad_kernel on the padded bf16 input, conv_wgrad_kernel<STEM> otherwise) */
 int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype);
@@ -173,17 +188,6 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
 /* dx[N,H,W,C] = conv_transpose(dy[N,Ho,Wo,K], w).  If accumulate != 0, dx += (dx is read). */
 int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                         int accumulate, int dtype, primia_stream_t stream);
-/* Data gradient that also forms the two reductions of the BatchNorm backward pass which consumes dx (the layer
- * torchlib/models.py:261-264 / :277-282 in front of this conv): sums [slots][2][C] = per-tile partial
- * (sum g, sum g*(y - mean)) with g = dx AS STORED where the ReLU passed — relu_mask bits (primia_bn_fwd_train_mask)
- * if given, else recomputed from bn_y as fma(y - mean, invstd*gamma, beta) > 0.  primia_bn_bwd_from_sums then needs
- * no reduction pass over y and dx.  slots = primia_conv_dgrad_bnsum_slots (0: this conv's data gradient cannot emit
- * them — call primia_conv2d_dgrad and the ordinary BatchNorm backward); bf16 only. */
-int primia_conv_dgrad_bnsum_slots(const primia_conv_desc* d, int dtype);
-int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
-                               const void* bn_y, const uint8_t* relu_mask, const float* gamma, const float* beta,
-                               const float* save_mean, const float* save_invstd, float* sums, int dtype,
-                               primia_stream_t stream);
 /* Identity block (torchlib/models.py:268-284, `out += identity; out = relu(out)`): dx = mask(dx) + dgrad(dy), where dx
  * holds the gradient of the block's OUTPUT and relu_mask the bits of that ReLU (primia_bn_fwd_train_mask).  The
  * masked residual gradient is then never written by the BatchNorm backward pass (g_out = NULL there): one tensor
@@ -236,15 +240,6 @@ int primia_conv2d_wgrad_group_ws(const primia_conv_desc* d, int n, const void* x
                                  float* dw_acc2, const void* x3, const void* dy3, float* dw_acc3, void* workspace,
                                  int64_t workspace_bytes, int dtype, primia_stream_t stream);
 
-/* ... and EVERY 3x3 / stride-1 layer of the network in one launch at the end of the backward pass (all of them are leaves):
- * ~40 blocks per layer instead of 256, each behind one prologue / epilogue, the slab traffic of the split reduction
- * shrinking alike.  _multi_ws_bytes: this layer's share of the workspace (0: not served, use its own call);
- * _multi_ws: HOST arrays of n <= 16 descriptors, operands and accumulators; the workspace holds the shares of all n
- * layers.  Results per layer as primia_conv2d_wgrad_ws up to the grouping of the ordered sums; deterministic. */
-int64_t primia_conv_wgrad_multi_ws_bytes(const primia_conv_desc* d, int dtype);
-int primia_conv2d_wgrad_multi_ws(int n, const primia_conv_desc* const* descs, const void* const* xs,
-                                 const void* const* dys, float* const* dw_accs, void* workspace,
-                                 int64_t workspace_bytes, int dtype, primia_stream_t stream);
 /* Per-sample weight gradients for DP-SGD: dw_ps [N][K][klen] (fwd layout, fp32, zeroed by the caller),
  * image n's gradient in slab n. */
 int primia_conv2d_wgrad_persample(const primia_conv_desc* d, const void* x, const void* dy,
@@ -401,12 +396,6 @@ int primia_bn_bwd_pair(const void* y2, const void* yd, const void* dz, const uin
                        const float* save_mean_d, const float* save_invstd_d, float* dgamma2, float* dbeta2,
                        float* dgamma_d, float* dbeta_d, int64_t M, int C, void* workspace, int64_t workspace_bytes,
                        int dtype, primia_stream_t stream);
-/* BatchNorm backward from the partial sums a data-gradient kernel already formed (primia_conv2d_dgrad_bnsums):
- * finalize + apply pass; relu_mask (bits) or, if NULL, the ReLU mask recomputed from y (beta required). */
-int primia_bn_bwd_from_sums(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
-                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
-                            float* dgamma, float* dbeta, const float* sums, int slots, int64_t M, int C, int dtype,
-                            primia_stream_t stream);
 /* The stem's tail fused: pooled, argmax = MaxPool2d(3, 2, 1)(relu(bn1(y))) straight from the conv
  * output (torchlib/models.py:468-471), batch statistics included — z = relu(bn(y)), the largest
  * activation of the network, is never written.  Same results as primia_bn_fwd_train(relu = 1)

@@ -139,6 +139,31 @@ def query(name, *args):
     return fn(*[_conv(a) for a in args])
 
 
+def set_option(name, value):
+    """primia_set_option: an explicit dispatch / tuning switch of the kernel library (csrc/options.h)."""
+    rc = lib().primia_set_option(name.encode(), int(value))
+    if rc != 0:
+        raise PrimiaError(f"primia_set_option({name!r}) failed: {_ERR.get(rc, rc)}")
+
+
+def get_option(name):
+    v = ctypes.c_int(0)
+    rc = lib().primia_get_option(name.encode(), ctypes.cast(ctypes.pointer(v), ctypes.c_void_p))
+    if rc != 0:
+        raise PrimiaError(f"primia_get_option({name!r}) failed: {_ERR.get(rc, rc)}")
+    return v.value
+
+
+def options():
+    """{name: current value} of every option the library knows."""
+    out = {}
+    buf = ctypes.create_string_buffer(64)
+    for i in range(lib().primia_option_count()):
+        lib().primia_option_name(i, ctypes.cast(buf, ctypes.c_void_p), 64)
+        out[buf.value.decode()] = get_option(buf.value.decode())
+    return out
+
+
 def dtype_code(dt):
     import torch
 

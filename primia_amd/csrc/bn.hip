@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void bn_relu_pool_fwd_kernel(const T* __restri
 // orders first by value, then by EARLIER tap: max over the window's keys = (maximum, first position attaining it) — two
 // instructions per tap (v_lshl_or_b32, v_max_u32), and the same result as the generic kernel bit for bit (a NaN, the
 // largest pattern, wins as it does there).
-// Block size: 256 threads, or ROWS whole output rows (PRIMIA_POOL_ROWS = 2 | 4, opt-in): consecutive blocks go to different
+// Block size: 256 threads (whole output rows per block were measured: no gain); consecutive blocks go to different
 // XCDs, so the input row two vertically neighbouring windows share is fetched once per block that touches it; a block of
 // whole rows shares them inside one CU.  Measured: step 4.925 / 4.937 ms (256 threads) vs 4.938 / 4.944 (2 rows) and
 // 4.944 / 4.972 (4 rows) — the 1.5x fetch of this pass is served by the Infinity Cache and is not what bounds it.
@@ -800,10 +800,10 @@ __global__ __launch_bounds__(256) void bn_relu_pool_bwd_apply_kernel(
 }
 
 static inline void reduce_geometry(long M, int C, int& nblk, long& rows_per_block) {
-    // <= 1024 blocks; at least `min_rows` rows per block (PRIMIA_BN_MINROWS, default 32: the small late
+    // <= 1024 blocks; at least `min_rows` rows per block (option bn_minrows, default 32: the small late
     // layers are latency-bound with few blocks — 256 rows per block left layer4 with 49 blocks; measured
     // 6.518 / 6.492 / 6.508 ms per step at 64 / 32 / 16).
-    static const long min_rows = getenv("PRIMIA_BN_MINROWS") ? atol(getenv("PRIMIA_BN_MINROWS")) : 32;
+    const long min_rows = PRIMIA_OPT(bn_minrows) > 0 ? PRIMIA_OPT(bn_minrows) : 32;
     long nb = (M + min_rows - 1) / min_rows;
     if (nb > kMaxPartialBlocks) nb = kMaxPartialBlocks;
     if (nb < 1) nb = 1;
@@ -849,14 +849,10 @@ static int bn_bwd_impl(const void* y, const void* z, const void* dz, void* dy, v
     long rpb;
     reduce_geometry(M, C, nblk, rpb);
     BwdFn<T> f{(const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, save_mean, save_invstd, gamma, beta, mask};
-    static const int runroll = getenv("PRIMIA_BN_RUNROLL") ? atoi(getenv("PRIMIA_BN_RUNROLL")) : 0;
-    if (runroll == 4)
-        colreduce2_kernel<T, BwdFn<T>, 4><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
-    else
-        colreduce2_kernel<T, BwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
+    colreduce2_kernel<T, BwdFn<T>><<<nblk, 256, 0, st>>>(f, M, C, rpb, partials);
     bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(partials, nblk, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
     const long nchunks = M * C / Chunk<T>::N;
-    static const int unroll = getenv("PRIMIA_BN_UNROLL") ? atoi(getenv("PRIMIA_BN_UNROLL")) : 2;
+    const int unroll = PRIMIA_OPT(bn_unroll);
     if (unroll == 2 && nchunks >= 4L * 2048 * 256)
         bn_bwd_apply_kernel<T, 2><<<stream_blocks(nchunks), 256, 0, st>>>(
             (const T*)y, relu ? (const T*)z : nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean,
@@ -1035,38 +1031,21 @@ template <typename T>
 static void launch_bn_relu_pool_fwd(const void* y, void* pooled, uint8_t* argmax, const float* gamma, const float* beta,
                                     const float* mean, const float* invstd, int N, int H, int W, int C, int Ho, int Wo,
                                     hipStream_t st, int G = 0) {
-    static const bool one = getenv("PRIMIA_POOL_PW") && getenv("PRIMIA_POOL_PW")[0] == '1';
-    // (two windows along H per thread — 25 loads for 4 windows — measured SLOWER: 265 vs 258 us for stats + pool at
-    // batch 256, 160 registers / occupancy 3, and the shared row is a MALL hit anyway; opt-in: PRIMIA_POOL_PH=2)
-    static const bool twoh = getenv("PRIMIA_POOL_PH") && getenv("PRIMIA_POOL_PH")[0] == '2';
-    const int pw = (Wo % 2 == 0 && !one) ? 2 : 1;
-    const int ph = (Ho % 2 == 0 && twoh) ? 2 : 1;
-    const long total = (long)N * (Ho / ph) * (Wo / pw) * (C / Chunk<T>::N);
-    const unsigned grid = (unsigned)((total + 255) / 256);
-    static const bool key_off = getenv("PRIMIA_POOL_KEY") && getenv("PRIMIA_POOL_KEY")[0] == '0';
+    // Two windows along W per thread where the pooled row is even.  Variants measured and not kept (profiles/
+    // r03_negative_results.txt): two windows along H as well (265 vs 258 us generic, 236 vs 225 us packed keys, batch
+    // 256), whole output rows per block (no gain).
+    const int pw = Wo % 2 == 0 ? 2 : 1;
     if constexpr (sizeof(T) == 2) {
-        if (!key_off) {       // packed (value, first position) keys: half the vector instructions
-            // (two windows along H per thread as well — 25 loads and evaluations for 4 windows instead of 30 — measured
-            // slower again: 236 vs 225 us for statistics + pool at batch 256; opt-in: PRIMIA_POOL_KEYPH=2)
-            static const bool keyph2 = getenv("PRIMIA_POOL_KEYPH") && getenv("PRIMIA_POOL_KEYPH")[0] == '2';
-            const int kph = (Ho % 2 == 0 && keyph2) ? 2 : 1;
-            const long ktotal = (long)N * (Ho / kph) * (Wo / pw) * (C / 8);
-            // whole output rows per block where a row is a multiple of a wave (the stem: 28 window pairs x 8 chunks = 224)
-            static const int rows_env = getenv("PRIMIA_POOL_ROWS") ? atoi(getenv("PRIMIA_POOL_ROWS")) : 0;   // (measured: no gain)
-            const int row_threads = (Wo / pw) * (C / 8);
-            int bt = 256;
-            if (rows_env > 0 && row_threads % 32 == 0 && (row_threads * rows_env) % 64 == 0 && row_threads * rows_env <= 1024 &&
-                (Ho / kph) % rows_env == 0)
-                bt = row_threads * rows_env;
-            const unsigned kgrid = (unsigned)((ktotal + bt - 1) / bt);
-            auto kk = pw == 2 ? (kph == 2 ? bn_relu_pool_fwd_key_kernel<2, 2> : bn_relu_pool_fwd_key_kernel<2, 1>)
-                              : (kph == 2 ? bn_relu_pool_fwd_key_kernel<1, 2> : bn_relu_pool_fwd_key_kernel<1, 1>);
-            kk<<<kgrid, bt, 0, st>>>((const bf16*)y, (bf16*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo, G);
-            return;
-        }
+        // bf16: packed (value, first position) keys — half the vector instructions of the generic form
+        const long ktotal = (long)N * Ho * (Wo / pw) * (C / 8);
+        const unsigned kgrid = (unsigned)((ktotal + 255) / 256);
+        auto kk = pw == 2 ? bn_relu_pool_fwd_key_kernel<2, 1> : bn_relu_pool_fwd_key_kernel<1, 1>;
+        kk<<<kgrid, 256, 0, st>>>((const bf16*)y, (bf16*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo, G);
+        return;
     }
-    auto kern = pw == 2 ? (ph == 2 ? bn_relu_pool_fwd_kernel<T, 2, 2> : bn_relu_pool_fwd_kernel<T, 2, 1>)
-                        : (ph == 2 ? bn_relu_pool_fwd_kernel<T, 1, 2> : bn_relu_pool_fwd_kernel<T, 1, 1>);
+    const long total = (long)N * Ho * (Wo / pw) * (C / Chunk<T>::N);
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    auto kern = pw == 2 ? bn_relu_pool_fwd_kernel<T, 2, 1> : bn_relu_pool_fwd_kernel<T, 1, 1>;
     kern<<<grid, 256, 0, st>>>((const T*)y, (T*)pooled, argmax, gamma, beta, mean, invstd, N, H, W, C, Ho, Wo, G);
 }
 
@@ -1219,21 +1198,6 @@ static int bn_relu_pool_bwd_impl(const void* y, const void* pooled, const void* 
 }  // namespace primia
 
 using namespace primia;
-
-// BatchNorm backward whose two reductions were already formed by the data-gradient kernel that produced dz
-// (primia_conv2d_dgrad_bnsums): sums [slots][2][C] = partial (sum g, sum g*(y - mean)); finalize + apply pass only.
-template <typename T>
-static int bn_bwd_from_sums_impl(const void* y, const uint8_t* mask, const void* dz, void* dy, void* g_out,
-                                 const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
-                                 float* dgamma, float* dbeta, const float* sums, int slots, long M, int C, hipStream_t st) {
-    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(sums, slots, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr,
-                                                                  nullptr, save_invstd);
-    const long nchunks = M * C / Chunk<T>::N;
-    bn_bwd_apply_kernel<T><<<stream_blocks(nchunks), 256, 0, st>>>(
-        (const T*)y, nullptr, (const T*)dz, (T*)dy, (T*)g_out, gamma, save_mean, save_invstd, dbeta, dgamma,
-        (float)(1.0 / (double)M), nchunks, C, mask ? nullptr : beta, mask);
-    return launch_status();
-}
 
 template <typename T>
 static int bn_fwd_train_pair_impl(const void* y2, const void* yd, void* z, uint8_t* relu_mask, const float* gamma2,
@@ -1503,23 +1467,6 @@ int primia_bn_bwd_mask(const void* y, const uint8_t* relu_mask, const void* dz, 
     if (dtype == PRIMIA_BF16)
         return bn_bwd_impl<bf16>(y, nullptr, dz, dy, g_out, gamma, save_mean, save_invstd, dgamma, dbeta, M, C, 0,
                                  (float*)workspace, st, nullptr, relu_mask);
-    return PRIMIA_ERR_ARG;
-}
-
-int primia_bn_bwd_from_sums(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
-                            const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
-                            float* dgamma, float* dbeta, const float* sums, int slots, int64_t M, int C, int dtype,
-                            primia_stream_t stream) {
-    PRIMIA_REQUIRE(y && dz && dy && gamma && save_mean && save_invstd && dgamma && dbeta && sums && slots >= 1);
-    PRIMIA_REQUIRE(relu_mask || beta);
-    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype));
-    hipStream_t st = (hipStream_t)stream;
-    if (dtype == PRIMIA_F32)
-        return bn_bwd_from_sums_impl<float>(y, relu_mask, dz, dy, g_out, gamma, beta, save_mean, save_invstd, dgamma, dbeta,
-                                            sums, slots, M, C, st);
-    if (dtype == PRIMIA_BF16)
-        return bn_bwd_from_sums_impl<bf16>(y, relu_mask, dz, dy, g_out, gamma, beta, save_mean, save_invstd, dgamma, dbeta,
-                                           sums, slots, M, C, st);
     return PRIMIA_ERR_ARG;
 }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #include "../../include/primia_hip.h"
+#include "options.h"
 
 namespace primia {
 

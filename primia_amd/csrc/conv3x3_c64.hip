@@ -52,7 +52,7 @@ struct C64Params {
     int total;        // patches overall
     int per_block;    // patches per block
     float* stat_partials;  // if set: per-block BatchNorm partial sums [grid][2][64] of the values AS STORED
-    int debug;        // timing experiments only (PRIMIA_C64_DEBUG): 1 no stores, 2 no staging, 4 no MFMA loop
+    int debug;        // timing experiments only (set by tools/micro builds, 0 in the library): 1 no stores, 2 no staging, 4 no MFMA loop
 };
 
 // Block = 4 waves (256 threads), TWO blocks per CU: the two waves of a SIMD belong to different blocks, so they are
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 // returns PRIMIA_ERR_UNSUPPORTED when the shape is not covered (caller falls back to the implicit GEMM)
 int conv3x3_c64_grid(int N, int H, int W) {
     const long total = (long)N * ((H + 7) / 8) * ((W + 7) / 8);
-    static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 512;
+    const int target = PRIMIA_OPT(c64_blocks) > 0 ? PRIMIA_OPT(c64_blocks) : 512;
     long per = (total + target - 1) / target;
     if (per < 1) per = 1;
     return (int)((total + per - 1) / per);
@@ -431,15 +431,14 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     p.acc_mask = accumulate ? acc_mask : nullptr;
     p.PH = (H + 7) / 8; p.PW = (W + 7) / 8; p.PPI = p.PH * p.PW;
     p.total = N * p.PPI;
-    static const int target = getenv("PRIMIA_C64_BLOCKS") ? atoi(getenv("PRIMIA_C64_BLOCKS")) : 512;   // 2 per CU
+    const int target = PRIMIA_OPT(c64_blocks) > 0 ? PRIMIA_OPT(c64_blocks) : 512;   // 2 per CU
     long per = (p.total + target - 1) / target;
     if (per < 1) per = 1;
     p.per_block = (int)per;
-    static const int dbg = getenv("PRIMIA_C64_DEBUG") ? atoi(getenv("PRIMIA_C64_DEBUG")) : 0;
-    p.debug = dbg;
+    p.debug = 0;       // (timing-experiment bits of tools/micro; never set by the library)
     const int grid = (int)((p.total + per - 1) / per);
     // plain form: a 4-deep ring (68 KiB per block, two blocks per CU) keeps 78 KB per CU in flight instead of 52
-    static const int deep = getenv("PRIMIA_C64_STAGES") ? atoi(getenv("PRIMIA_C64_STAGES")) : 4;
+    const int deep = PRIMIA_OPT(c64_stages);
     const int stages = (!accumulate && deep == 4) ? 4 : 3;
     const size_t lds = (size_t)stages * 13 * 1024 + 2 * 64 * (accumulate ? 256 : 128) + (accumulate ? 8192 : 0);
     static bool attr_set = false;

@@ -695,8 +695,7 @@ static int lh2_num_cus() {
 
 // tile height in pixels for a shape (0: not served).  392 when that gives every CU at least one tile, else 196.
 static int lh2_bm(int N, int H, int W, int Cs, int Nd) {
-    static const int off = getenv("PRIMIA_LH2") ? (getenv("PRIMIA_LH2")[0] == '0') : 0;
-    static const int force = getenv("PRIMIA_LH2_BM") ? atoi(getenv("PRIMIA_LH2_BM")) : 0;
+    const int off = !PRIMIA_OPT(lh2), force = PRIMIA_OPT(lh2_bm);
     if (off || W > 28 || W < 2 || H < 2 || Cs % 64 || Nd % 128) return 0;
     const long M = (long)N * H * W;
     if (M * (Cs > Nd ? Cs : Nd) >= (1L << 30)) return 0;     // byte offsets stay below 2^31

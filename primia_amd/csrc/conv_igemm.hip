@@ -780,7 +780,7 @@ static int launch_igemm(const IgemmParams& p, hipStream_t st) {
 // Tile choice.  Default 'e': 128-pixel tile, 8 waves (4 x 2), double-buffered LDS-DMA, 2 blocks/CU —
 // measured fastest on the ResNet-18 shapes (profiles/r01_conv_layers_*.txt): the kernel is bound by
 // the L2 -> LDS fill rate per CU, so waves in flight beat pipeline depth (the 3-stage variants lose
-// the second resident block).  PRIMIA_CONV_CFG=<letter> selects an alternative for A/B runs:
+// the second resident block).  option conv_cfg = 0..5 (a..f) selects an alternative for A/B runs:
 //   a 128 px 2x2 waves 2 stages | b 128 px 2x2 3 stages | c 256 px 4x2 2 stages | d 256 px 4x2 3 stages
 //   e 128 px 4x2 waves 2 stages | f 128 px 4x2 3 stages
 template <typename T, bool DGRAD>
@@ -790,7 +790,7 @@ static int dispatch_igemm(const IgemmParams& p, bool stem, hipStream_t st) {
         return launch_igemm<T, 128, 64, 2, 2, 2, false, true>(p, st);
     }
     if ((long)p.Nb * p.Hs * p.Ws * p.Cs >= (1L << 31)) return PRIMIA_ERR_ARG;  // 32-bit element offsets
-    static const char cfg_env = getenv("PRIMIA_CONV_CFG") ? getenv("PRIMIA_CONV_CFG")[0] : 'e';
+    const char cfg_env = (char)('a' + PRIMIA_OPT(conv_cfg));      // option conv_cfg 0..5 = a..f
     const char cfg = p.stat_tiles ? 'e' : cfg_env;   // per-tile statistics assume the 128-pixel tile
     const bool wide = p.Nd % 128 == 0;
 #define PRIMIA_IGEMM_CASE(L, BM, WM_, WN_, ST)                                                   \
@@ -822,20 +822,18 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
 int conv3x3_c64_grid(int N, int H, int W);
 }
 
-// wide 3x3 / stride-1 layers (layer2-4): linear-halo kernel (conv3x3_lh.hip); PRIMIA_LH=0 keeps the implicit GEMM
-static int lh_fwd_maxw() {   // forward only: widest image the linear-halo kernel takes (A/B: PRIMIA_LH_FWD_MAXW)
-    static const int v = getenv("PRIMIA_LH_FWD_MAXW") ? atoi(getenv("PRIMIA_LH_FWD_MAXW")) : 30;
-    return v;
+// wide 3x3 / stride-1 layers (layer2-4): linear-halo kernel (conv3x3_lh2.hip); option lh2 = 0 keeps the implicit GEMM
+static int lh_fwd_maxw() {   // forward only: widest image the linear-halo kernel takes (option lh_fwd_maxw)
+    return PRIMIA_OPT(lh_fwd_maxw);
 }
 static bool lh_shape(const ConvGeom& g) {
     return !g.stem && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1;
 }
 
 // layer1 shape (3x3, stride 1, pad 1, 64 -> 64 channels, bf16): weight-stationary halo kernel (conv3x3_c64.hip);
-// PRIMIA_C64=0 keeps the implicit GEMM (A/B measurements)
+// option c64 = 0 keeps the implicit GEMM (A/B measurements)
 static bool use_c64(const ConvGeom& g) {
-    static const bool off = getenv("PRIMIA_C64") && getenv("PRIMIA_C64")[0] == '0';
-    return !off && !g.stem && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.C == 64 && g.K == 64;
+    return PRIMIA_OPT(c64) && !g.stem && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.C == 64 && g.K == 64;
 }
 
 extern "C" {
@@ -871,9 +869,6 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
             const int rc2 = conv3x3_lh2_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, g.C, g.K, 0,
                                                  0, st, stat_sums);
             if (rc2 != PRIMIA_ERR_UNSUPPORTED) return rc2;
-            const int rc = conv3x3_lh_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, g.C, g.K, 0, 0,
-                                               st, stat_sums);
-            if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         }
         p.nsteps = g.klen / 64;
         return dispatch_igemm<bf16, false>(p, g.stem, st);
@@ -889,8 +884,7 @@ int primia_conv2d_fwd(const primia_conv_desc* d, const void* x, const void* w_fw
 // a transition block's conv1 (3x3 / 2) and downsample (1x1 / 2) forward in one launch: both on the bf16 implicit GEMM,
 // same input, output channels a multiple of 128
 static bool fwd_pair_shape(const ConvGeom& g, const ConvGeom& gd, int dtype) {
-    static const bool off = getenv("PRIMIA_FWD_PAIR") && getenv("PRIMIA_FWD_PAIR")[0] == '0';
-    if (off || dtype != PRIMIA_BF16 || g.stem || gd.stem) return false;
+    if (!PRIMIA_OPT(fwd_pair) || dtype != PRIMIA_BF16 || g.stem || gd.stem) return false;
     if (gd.N != g.N || gd.H != g.H || gd.W != g.W || gd.C != g.C || gd.Ho != g.Ho || gd.Wo != g.Wo) return false;
     if (g.stride != 2 || gd.stride != 2 || g.R != 3 || g.S != 3 || gd.R != 1 || gd.S != 1 || gd.pad != 0) return false;
     if (g.K % 128 || gd.K % 128) return false;
@@ -940,7 +934,6 @@ int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype) {
     if (lh_shape(g) && (pass == 1 || g.W <= lh_fwd_maxw())) {
         const int cs = pass == 0 ? g.C : g.K, nd = pass == 0 ? g.K : g.C;
         if (conv3x3_lh2_tiles_m(g.N, g.H, g.W, cs, nd) > 0) return 4;
-        if (conv3x3_lh_tiles_m(g.N, g.H, g.W, cs, nd) > 0) return 3;
     }
     return 1;
 }
@@ -958,8 +951,6 @@ static int conv_stat_slots_impl(const primia_conv_desc* d, int dtype, int* per_t
     if (dtype == PRIMIA_BF16 && !use_c64(g) && lh_shape(g) && g.W <= lh_fwd_maxw()) {
         const int t2 = conv3x3_lh2_tiles_m(g.N, g.H, g.W, g.C, g.K);
         if (t2 > 0) return t2;
-        const int t = conv3x3_lh_tiles_m(g.N, g.H, g.W, g.C, g.K);
-        if (t > 0) return t;
     }
     // bf16 implicit GEMM: one partial per 128-pixel tile out of its write-back (every tile config in use has BM = 128)
     if (dtype == PRIMIA_BF16 && !g.stem && g.K % 8 == 0) return (int)(((long)g.N * g.Ho * g.Wo + 127) / 128);
@@ -988,7 +979,7 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
 
 static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                              int accumulate, const void* dy2, const void* w_dgrad2, int dtype, primia_stream_t stream,
-                             const LhBnArgs* bn = nullptr, const uint8_t* acc_mask = nullptr) {
+                             const uint8_t* acc_mask = nullptr) {
     PRIMIA_REQUIRE(d && dy && w_dgrad && dx);
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
@@ -1004,7 +995,7 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
     p.accumulate = accumulate;
     p.stat_sums = nullptr;
     p.stat_tiles = 0;
-    static const bool no_classes = getenv("PRIMIA_DGRAD_CLASSES") && getenv("PRIMIA_DGRAD_CLASSES")[0] == '0';
+    const bool no_classes = !PRIMIA_OPT(dgrad_classes);
     p.s2_classes = (g.stride == 2 && g.H % 2 == 0 && g.W % 2 == 0 && !no_classes) ? 1 : 0;
     p.ntm_class = 0;
     if (p.src2 && !p.s2_classes) return PRIMIA_ERR_UNSUPPORTED;   // the pairing lives in the parity-class walk
@@ -1018,16 +1009,10 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
                                                 accumulate, st, nullptr, acc_mask);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
         } else if (lh_shape(g) && !p.src2) {
-            if (!bn) {   // (the BatchNorm-backward sums are emitted by the first-generation kernel only)
-                const int rc2 = conv3x3_lh2_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K,
-                                                     g.C, 1, accumulate, st, nullptr, acc_mask);
-                if (rc2 != PRIMIA_ERR_UNSUPPORTED) return rc2;
-            }
-            const int rc = conv3x3_lh_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C, 1,
-                                               accumulate, st, nullptr, bn, acc_mask);
-            if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+            const int rc2 = conv3x3_lh2_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C,
+                                                 1, accumulate, st, nullptr, acc_mask);
+            if (rc2 != PRIMIA_ERR_UNSUPPORTED) return rc2;
         }
-        if (bn) return PRIMIA_ERR_UNSUPPORTED;   // only the linear-halo kernel emits the sums
         if (acc_mask) return PRIMIA_ERR_UNSUPPORTED;   // only the 64->64 and linear-halo write-backs mask the old values
         p.nsteps = p.klen / 64;
         return dispatch_igemm<bf16, true>(p, false, st);
@@ -1040,37 +1025,19 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
     return conv2d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, dtype, stream);
 }
 
-int primia_conv_dgrad_bnsum_slots(const primia_conv_desc* d, int dtype) {
-    ConvGeom g;
-    if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
-    if (dtype != PRIMIA_BF16 || use_c64(g) || !lh_shape(g)) return 0;
-    const int t = conv3x3_lh_tiles_m(g.N, g.H, g.W, g.K, g.C);
-    return t > 0 ? t : 0;
-}
-
-int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, int accumulate,
-                               const void* bn_y, const uint8_t* relu_mask, const float* gamma, const float* beta,
-                               const float* save_mean, const float* save_invstd, float* sums, int dtype,
-                               primia_stream_t stream) {
-    PRIMIA_REQUIRE(bn_y && gamma && save_mean && save_invstd && sums && (relu_mask || beta));
-    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
-    LhBnArgs bn{bn_y, relu_mask, gamma, beta, save_mean, save_invstd, sums};
-    return conv2d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, dtype, stream, &bn);
-}
-
 int primia_conv_dgrad_masked_acc_ok(const primia_conv_desc* d, int dtype) {
     ConvGeom g;
     if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
     if (dtype != PRIMIA_BF16) return 0;
     if (use_c64(g)) return (long)g.N * g.H * g.W * 64 < (1L << 31) ? 1 : 0;
-    return lh_shape(g) && conv3x3_lh_tiles_m(g.N, g.H, g.W, g.K, g.C) > 0 ? 1 : 0;
+    return lh_shape(g) && conv3x3_lh2_tiles_m(g.N, g.H, g.W, g.K, g.C) > 0 ? 1 : 0;
 }
 
 int primia_conv2d_dgrad_masked_acc(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                                    const uint8_t* relu_mask, int dtype, primia_stream_t stream) {
     PRIMIA_REQUIRE(relu_mask);
     if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
-    return conv2d_dgrad_impl(d, dy, w_dgrad, dx, 1, nullptr, nullptr, dtype, stream, nullptr, relu_mask);
+    return conv2d_dgrad_impl(d, dy, w_dgrad, dx, 1, nullptr, nullptr, dtype, stream, relu_mask);
 }
 
 int primia_conv2d_dgrad_pair(const primia_conv_desc* d, const void* dy, const void* w_dgrad,

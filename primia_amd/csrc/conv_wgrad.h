@@ -46,10 +46,6 @@ size_t wgrad_patch_ws_bytes(const WgradParams& p);
 int wgrad_patch_group_size(const WgradParams& p, int count);
 size_t wgrad_patch_group_ws_bytes(const WgradParams& p, int n);
 int wgrad_patch_group_dispatch(const WgradParams* p, int n, hipStream_t st);
-// every 3x3 / stride-1 layer in one launch: is this layer served, its share of the workspace, the launch
-bool wgrad_patch_multi_ok(const WgradParams& p);
-size_t wgrad_patch_multi_ws_bytes(const WgradParams& p);
-int wgrad_patch_multi_dispatch(const WgradParams* p, int n, float* ws, size_t ws_bytes, hipStream_t st);
 // per-tap kernel of the stride-2 / 1x1 layers, second generation (conv_wgrad_tap.hip); needs the workspace
 int wgrad_tap_dispatch(const WgradParams& p, hipStream_t st);
 int wgrad_tap_kernel_id(const WgradParams& p);

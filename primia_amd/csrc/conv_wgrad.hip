@@ -18,6 +18,12 @@
 
 namespace primia {
 
+// option wgrad_kernel: 0 = by shape, else the per-tap kernel named: 'o' register-staged, 'd' LDS-DMA, 't' either by shape
+static inline char wgrad_force() {
+    const int v = PRIMIA_OPT(wgrad_kernel);
+    return v == 1 ? 'o' : v == 2 ? 'd' : v == 3 ? 't' : 0;
+}
+
 
 template <typename T, int BMK, int BNC, bool STEM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
@@ -334,7 +340,7 @@ static void wgrad_geometry(WgradParams& p) {
     p.nct = STEM ? 1 : p.C / BNC;
     const int combos = p.ntaps * p.nkt * p.nct;
     // enough blocks to fill 256 CUs a few times over, but at least 8 steps per block
-    static const int target_blocks = getenv("PRIMIA_WGT_BLOCKS") ? atoi(getenv("PRIMIA_WGT_BLOCKS")) : 4 * 256;
+    const int target_blocks = PRIMIA_OPT(wgt_blocks) > 0 ? PRIMIA_OPT(wgt_blocks) : 4 * 256;
     long want = (target_blocks + combos - 1) / combos;
     long max_split = (p.Md + 8 * KP - 1) / (8 * KP);
     if (want > max_split) want = max_split;
@@ -468,7 +474,7 @@ extern "C" int64_t primia_conv_wgrad_ws_bytes(const primia_conv_desc* d, int dty
         return (int64_t)wgrad_ws_need<float, 64, 64, false>(p);
     }
     if (dtype != PRIMIA_BF16) return PRIMIA_ERR_ARG;
-    static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    const char force = wgrad_force();
     const bool dma = force == 'd' || (force != 'o' && (g.C >= 256 || (g.K >= 256 && g.C >= 128)));
     if (!force && !g.stem) {
         const size_t n = wgrad_patch_ws_bytes(p);
@@ -491,7 +497,7 @@ extern "C" int64_t primia_conv_wgrad_pair_ws_bytes(const primia_conv_desc* d, co
     WgradParams p, p2;
     ConvGeom g, g2;
     if (!fill_wgrad_params(d, p, g) || !fill_wgrad_params(d2, p2, g2)) return PRIMIA_ERR_ARG;
-    if (dtype != PRIMIA_BF16 || getenv("PRIMIA_WGRAD")) return 0;
+    if (dtype != PRIMIA_BF16 || wgrad_force()) return 0;
     return (int64_t)wgrad_tap_pair_ws_bytes(p, p2);
 }
 
@@ -502,7 +508,7 @@ extern "C" int primia_conv2d_wgrad_pair_ws(const primia_conv_desc* d, const void
     WgradParams p, p2;
     ConvGeom g, g2;
     PRIMIA_REQUIRE(fill_wgrad_params(d, p, g) && fill_wgrad_params(d2, p2, g2));
-    if (dtype != PRIMIA_BF16 || getenv("PRIMIA_WGRAD")) return PRIMIA_ERR_UNSUPPORTED;
+    if (dtype != PRIMIA_BF16 || wgrad_force()) return PRIMIA_ERR_UNSUPPORTED;
     p.x = x; p.dy = dy; p.dw = dw; p.ws = (float*)ws; p.ws_bytes = ws && ws_bytes > 0 ? (size_t)ws_bytes : 0;
     p2.x = x; p2.dy = dy2; p2.dw = dw2;
     return wgrad_tap_pair_dispatch(p, p2, (hipStream_t)stream);
@@ -514,7 +520,7 @@ extern "C" int primia_conv_wgrad_group_size(const primia_conv_desc* d, int count
     ConvGeom g;
     WgradParams p;
     if (!d || count < 1 || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
-    static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    const char force = wgrad_force();
     if (dtype != PRIMIA_BF16 || g.stem || force) return 0;
     p.persample = 0;
     return wgrad_patch_group_size(p, count);
@@ -550,34 +556,6 @@ extern "C" int primia_conv2d_wgrad_group_ws(const primia_conv_desc* d, int n, co
     return wgrad_patch_group_dispatch(ps, n, (hipStream_t)stream);
 }
 
-// Every 3x3 / stride-1 layer of the network in one launch.  _multi_ws_bytes: this layer's share of the workspace (0: the
-// layer is not served — use its own call); _multi_ws: host arrays of n descriptors / operands / accumulators.
-extern "C" int64_t primia_conv_wgrad_multi_ws_bytes(const primia_conv_desc* d, int dtype) {
-    ConvGeom g;
-    WgradParams p;
-    if (!d || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
-    static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
-    if (dtype != PRIMIA_BF16 || g.stem || force) return 0;
-    p.persample = 0;
-    return (int64_t)wgrad_patch_multi_ws_bytes(p);
-}
-
-extern "C" int primia_conv2d_wgrad_multi_ws(int n, const primia_conv_desc* const* descs, const void* const* xs,
-                                            const void* const* dys, float* const* dw_accs, void* ws, int64_t ws_bytes,
-                                            int dtype, primia_stream_t stream) {
-    PRIMIA_REQUIRE(n >= 1 && n <= 16 && descs && xs && dys && dw_accs && ws && ws_bytes > 0);
-    if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
-    WgradParams ps[16];
-    for (int i = 0; i < n; ++i) {
-        ConvGeom g;
-        PRIMIA_REQUIRE(descs[i] && xs[i] && dys[i] && dw_accs[i] && fill_wgrad_params(descs[i], ps[i], g));
-        if (g.stem) return PRIMIA_ERR_UNSUPPORTED;
-        ps[i].x = xs[i]; ps[i].dy = dys[i]; ps[i].dw = dw_accs[i];
-        ps[i].persample = 0; ps[i].sqnorm = nullptr; ps[i].ws = nullptr; ps[i].ws_bytes = 0;
-    }
-    return wgrad_patch_multi_dispatch(ps, n, (float*)ws, (size_t)ws_bytes, (hipStream_t)stream);
-}
-
 // ---- DP-SGD: per-sample gradient tiles KEPT by the norm pass, clipped sum = a weighted reduce --------------------------
 // Where a layer's per-sample gradients are small (the stem: 64 KiB per sample; the 64 -> 64 convs of layer1: 144 KiB),
 // the norm pass stores each sample's complete tile next to adding its squares, and the clipped sum  sum_n clip_n g_n  is
@@ -609,7 +587,7 @@ extern "C" int64_t primia_conv_wgrad_persample_slab_bytes(const primia_conv_desc
     ConvGeom g;
     WgradParams p;
     if (!d || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
-    static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    const char force = wgrad_force();
     if (dtype != PRIMIA_BF16 || g.stem || force) return 0;
     p.persample = 1;
     return (int64_t)wgrad_patch_keep_bytes(p);
@@ -673,7 +651,7 @@ extern "C" int primia_conv_wgrad_persample_kernel_id(const primia_conv_desc* d, 
     if (dtype != PRIMIA_BF16) return 14;
     const int gh = dp_ghost_kernel_id(d->H, d->W, d->C, d->K, d->R, d->S, d->stride, d->pad);
     if (gh) return gh;
-    const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    const char force = wgrad_force();
     if (!force) {
         const int id = wgrad_patch_persample_kernel_id(p);
         if (id) return id;
@@ -690,7 +668,7 @@ extern "C" int primia_conv_wgrad_kernel_id(const primia_conv_desc* d, int dtype)
     if (!d || !fill_wgrad_params(d, p, g)) return PRIMIA_ERR_ARG;
     if (g.stem) return 15;
     if (dtype != PRIMIA_BF16) return 14;
-    const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+    const char force = wgrad_force();
     if (!force) {
         const int id = wgrad_patch_kernel_id(p);
         if (id) return id;
@@ -719,9 +697,9 @@ static int conv2d_wgrad_impl(const primia_conv_desc* d, const void* x, const voi
     } else if (dtype == PRIMIA_BF16) {
         // Measured per layer (profiles/r01_conv_layers_*): the halo-patch kernel (conv_wgrad_patch.hip) wins
         // on every 3x3 / stride-1 layer; of the per-tap kernels the LDS-DMA one wins on the wide, few-pixel
-        // layers (layer3/4) and the register-staged one elsewhere.  PRIMIA_WGRAD=old|dma|tap forces one
+        // layers (layer3/4) and the register-staged one elsewhere.  option wgrad_kernel = 1 (old) | 2 (dma) | 3 (tap) forces one
         // (tap = per-tap kernels with the default old/dma choice).
-        static const char force = getenv("PRIMIA_WGRAD") ? getenv("PRIMIA_WGRAD")[0] : 0;
+        const char force = wgrad_force();
         const bool dma = force == 'd' || (force != 'o' && (g.C >= 256 || (g.K >= 256 && g.C >= 128)));
         if (!force && !g.stem) {
             const int rc = wgrad_patch_dispatch(p, st);
@@ -933,7 +911,7 @@ static bool wgrad_dma_geometry(WgradParams& p) {
     const int combos = p.ntaps * p.nkt * p.nct;
     // Blocks of one launch: ONE round at two resident blocks per CU.  Every block ends with a BMK x BNC fp32 flush, so
     // fewer, longer blocks halve that traffic too (1024 -> 504: layer3.0.conv1 100 -> 84 us, layer4.0.conv1 97 -> 83).
-    static const int target_blocks = getenv("PRIMIA_WG_BLOCKS") ? atoi(getenv("PRIMIA_WG_BLOCKS")) : 504;
+    const int target_blocks = PRIMIA_OPT(wg_blocks) > 0 ? PRIMIA_OPT(wg_blocks) : 504;
     long want = (target_blocks + combos - 1) / combos;
     long max_split = (p.Md + 8 * KP - 1) / (8 * KP);
     if (want > max_split) want = max_split;

@@ -2,25 +2,23 @@
 //
 //   dw[k, (r,s,c)] += sum_m dy[m, k] * x[pix(m, r, s), c]
 //
-// The per-tap kernels of conv_wgrad.hip stage a dy tile and an x tile per (tap, pixel step): every
-// activation and every output gradient travels L2 -> LDS nine times.  Here one block owns a
-// [64 out-chan] x [9 taps x 64 in-chan] slab of dw and walks 2-D sub-patches of 32 output pixels
-// (SH x SW = 4x8 or 2x16).  Per sub-patch it stages
-//     dy : 32 pixels x 64 channels                       (once, shared by the 9 taps)
-//     x  : (SH+2) x (SW+2) halo pixels x 64 channels     (once, shared by the 9 taps)
-// and the nine taps read the SAME LDS halo at shifted pixel slots.  The block has 8 waves: wave
-// (kh, cq) owns out-channels 32*kh..+31 and in-channels 16*cq..+15 of all nine taps (72 accumulator
-// registers), so per k-step (32 pixels) it issues 2 dy-fragment + 9 x-fragment transposing reads
-// (ds_read_b64_tr_b16 pairs) for 18 MFMAs; L2 -> LDS traffic drops from 9x to ~1.9x of the tensors.
+// The per-tap kernels of conv_wgrad.hip stage a dy tile and an x tile per (tap, pixel step): every activation and every
+// output gradient travels L2 -> LDS nine times.  Here one 8-wave block owns a [64 out-chan] x [9 taps x 64 in-chan] slab
+// of dw and walks 2-D sub-patches of the image; per sub-patch dy and x are staged ONCE (with a row / column halo) and
+// the nine taps read the same LDS images at shifted pixel slots.
 //
-// Staging is LDS-DMA (global_load_lds_dwordx4): one wave instruction fills 8 pixel slots of
-// 128 B.  The 32-B channel groups of a slot are XOR-permuted on the SOURCE side with a key chosen
-// so that the 8 slots x 32 B touched by one LDS cycle of a transposing read cover all 64 banks:
-//     dy slots (linear k)          key = bit1(slot) | bit3(slot) << 1
-//     x halo, SW = 8 (row 12 slots) key = (slot >> 1) & 3
-//     x halo, SW = 16 (row 18 slots) key = bit1(slot) | bit3(slot) << 1
-// Out-of-image halo pixels (the conv's zero padding), ragged patch edges and the tail of a block's
-// range are loaded from a zero page.
+// This file holds the third generation of the scheme (conv_wgrad_patch33_kernel, "3 + 3 fragments").  Rounds 1 and 2
+// built it on v_mfma_f32_16x16x32_bf16 (2 + 9 fragment reads for 18 MFMAs, 72 accumulators per wave) and then on
+// v_mfma_f32_32x32x16_bf16 with the two sub-patches of a stage going to the two HALVES of the block (1 + 9 fragments per
+// 9 MFMAs, 81 -> 71 us per layer); both were superseded and removed (profiles/r02_wgrad32_experiments.txt,
+// profiles/r03_wgp33_phase_profile.txt keep their measurements).  What v3 inherits from them:
+//   * LDS image: a pixel slot is 128 B = two 64-B channel groups; group g of slot s sits in half g ^ bit1(s), so the
+//     four consecutive slots one 32-lane phase of ds_read_b64_tr_b16 touches always cover all 64 banks, for any slot
+//     alignment (tap shifts!);
+//   * staging = buffer-addressed LDS-DMA (out-of-image / dead lanes get an offset beyond num_records: hardware zeros);
+//   * wave (half, kg, cg) owns out-channels 32*kg.., in-channels 32*cg.. of all nine taps for ITS half's sub-patch =
+//     nine f32x16 accumulators; half 0 issues its pieces then multiplies, half 1 multiplies then issues; the halves
+//     meet in LDS once after the loop; one partial slab per block -> ordered reduce (deterministic).
 #include <stdlib.h>
 
 #include "conv_wgrad.h"
@@ -57,7 +55,6 @@ struct PatchParams {
     double* sqnorm;           // per-sample norm pass (see WgradParams::sqnorm)
     int nsplit, split_fastest;
     float* ws;                // if set: every block stores its partial slab here (no atomics), see below
-    int debug_skip_epilogue;  // timing experiments only (PRIMIA_WGP_NOEPI=1)
     int pairimg;              // v3, DP-SGD norm pass: a half owns whole images (units of t0 / per_block / total: images)
     int nimg;                 // batch size
     // v3, grouped launch: `ngroups` layers of ONE shape share the launch — blocks [g * group_blocks, (g + 1) * group_blocks)
@@ -69,322 +66,12 @@ struct PatchParams {
 
 constexpr int kSlab = 64 * 9 * 64;   // accumulator values of one block
 
-template <int SW, int STAGES>
-__global__ __launch_bounds__(512) void conv_wgrad_patch_kernel(PatchParams p) {
-    constexpr int SH = 32 / SW;
-    constexpr int HR = SH + 2;                  // halo rows
-    constexpr int HS = SW == 8 ? 12 : 18;       // halo row stride in pixel slots
-    constexpr int XSLOTS = HR * HS;             // 72 for both shapes = 9 DMA instructions
-    static_assert(XSLOTS == 72, "halo must fill whole DMA instructions");
-    constexpr int X_BYTES = XSLOTS * 128;       // one sub-patch halo
-    constexpr int DY_BYTES = 64 * 128;          // two sub-patches of dy
-    constexpr int STAGE = 2 * X_BYTES + DY_BYTES;
-    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
+// compile-time experiment switches (tools/micro/wgp33_bench.hip): 1 no epilogue, 2 no DMA after the prologue, 4 no MFMA,
+// 8 no fragment reads.  WGP33_PROF: per-wave cycles in DMA issue / vmcnt wait / barrier wait / compute / epilogue.
+#ifndef WGP33_DBG
+#define WGP33_DBG 0
+#endif
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: wave-uniform branches stay SALU
-    const int kh = wave >> 2, wid = wave & 3;                   // out-chan half, in-chan quarter
-
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    int split;
-    if (p.split_fastest) {   // the blocks that add into one slab are neighbours: same XCD
-        split = bid % p.nsplit;
-        bid /= p.nsplit;
-    }
-    const int ct = bid % p.nct; bid /= p.nct;
-    const int kt = bid % p.nkt;
-    if (!p.split_fastest) split = bid / p.nkt;
-    const int t0 = split * p.per_block;
-    int t1 = t0 + p.per_block;
-    if (t1 > p.total) t1 = p.total;
-    const int nstages = (t1 - t0 + 1) >> 1;
-
-    const bf16* __restrict__ x = p.x + ct * 64;
-    const bf16* __restrict__ dy = p.dy + kt * 64;
-
-    // ---- staging: 26 DMA instructions per stage (2 x 9 halo + 8 dy), round-robin over the 8 waves ----
-    // Everything that does not depend on the sub-patch is computed once: per DMA instruction `it` of this
-    // wave the lane's pixel offset inside the sub-patch (drow, dcol), its element offset `rel` and the
-    // swizzled source channel.  Per stage only the two sub-patch origins change (scalar).
-    int drow[4], dcol[4], rel[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = wave + 8 * it;
-        const int sl = lane & 7;
-        if (idx < 18) {
-            const int j = idx >= 9 ? idx - 9 : idx;
-            const int slot = j * 8 + (lane >> 3);
-            const int hy = slot / HS, hx = slot - hy * HS;
-            const int chunk = ((((sl >> 1) ^ key_halo<SW>(slot)) << 1) | (sl & 1));
-            drow[it] = hy - 1;
-            dcol[it] = hx < SW + 2 ? hx - 1 : (1 << 20);      // pad slots of the halo row: never valid
-            rel[it] = ((hy - 1) * p.W + (hx - 1)) * p.C + chunk * 8;
-        } else {
-            const int slot = (idx - 18) * 8 + (lane >> 3);
-            const int k = slot & 31;
-            const int py = SW == 8 ? (k >> 3) : (k >> 4), px = SW == 8 ? (k & 7) : (k & 15);
-            const int chunk = ((((sl >> 1) ^ key_lin(slot)) << 1) | (sl & 1));
-            drow[it] = py;
-            dcol[it] = px;
-            rel[it] = (py * p.W + px) * p.K + chunk * 8;
-        }
-    }
-    // running origin of the next sub-patch to stage (stages are issued strictly in order)
-    int sn, sph, spw;
-    {
-        sn = t0 / p.PPI;
-        const int rem = t0 - sn * p.PPI;
-        sph = rem / p.PW;
-        spw = rem - sph * p.PW;
-    }
-    int st = t0;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    auto stage = [&](int buf) {
-        int rb[2], cb[2], pixbase[2];
-        bool live[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            live[q] = st < t1;
-            rb[q] = sph * SH;
-            cb[q] = spw * SW;
-            pixbase[q] = (sn * p.H + rb[q]) * p.W + cb[q];
-            ++st;
-            if (++spw == p.PW) {
-                spw = 0;
-                if (++sph == p.PH) {
-                    sph = 0;
-                    ++sn;
-                }
-            }
-        }
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            const int idx = wave + 8 * it;      // wave-uniform
-            if (idx >= 26) break;
-            const bool isx = idx < 18;
-            const int q = isx ? (idx >= 9) : (idx >= 22);
-            const int dst = isx ? q * X_BYTES + (idx - 9 * q) * 1024 : 2 * X_BYTES + (idx - 18) * 1024;
-            const int row = rb[q] + drow[it], col = cb[q] + dcol[it];
-            const bool ok = live[q] && (unsigned)row < (unsigned)p.H && (unsigned)col < (unsigned)p.W;
-            const bf16* src = isx ? x : dy;
-            const int elem = pixbase[q] * (isx ? p.C : p.K) + rel[it];
-            const bf16* g = ok ? src + elem : (const bf16*)kWpZeroPage;
-            dma16(g, __builtin_amdgcn_readfirstlane(lds0 + buf * STAGE + dst));
-        }
-    };
-
-    f32x4 acc[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) acc[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- per-lane LDS byte offsets of the transposing reads (constant over the whole kernel) --------
-    const int fr = lane & 15, fg = lane >> 4;
-    const int tp = fr >> 2, tc8 = (fr & 3) * 8;
-    // dy: slot = 8*fg + tp (+4); channel group i
-    int offa[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) offa[h] = 8 * fg + tp + 4 * h;   // slot index; swizzle applied per fragment
-    // x: k = 8*fg + tp (+4) -> (py, px); slot = (py + r)*HS + px + s; this wave's channel group = wid
-    int offx[9][2];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int r = t / 3, s = t - 3 * r;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int k = 8 * fg + tp + 4 * h;
-            const int py = SW == 8 ? (k >> 3) : (k >> 4), px = SW == 8 ? (k & 7) : (k & 15);
-            const int slot = (py + r) * HS + px + s;
-            offx[t][h] = slot * 128 + ((wid ^ key_halo<SW>(slot)) << 5) + tc8;
-        }
-    }
-
-    // One stage = two k-steps.  All 44 fragment reads of the stage are issued up front (the LDS queue
-    // throttles itself at 15 outstanding), then the 36 MFMAs consume them in issue order: the LDS latency
-    // is paid once per stage instead of once per tap.
-    auto compute = [&](int buf) {
-        const char* sb = smem + buf * STAGE;
-        bf16x8_t a[2][2], b[2][9];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const char* lx = sb + q * X_BYTES;
-            const char* la = sb + 2 * X_BYTES + q * 32 * 128;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                // key_lin(slot) is the same for slot and slot + 32*q (bits 1 and 3 only)
-                const int cg = 2 * kh + i;  // 16-channel group of dy
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (lds4_t)(la + offa[0] * 128 + ((cg ^ key_lin(offa[0])) << 5) + tc8));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-                    (lds4_t)(la + offa[1] * 128 + ((cg ^ key_lin(offa[1])) << 5) + tc8));
-                a[q][i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(lx + offx[t][0]));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(lx + offx[t][1]));
-                b[q][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[q][i], b[q][t], acc[t][i], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-
-    // STAGES-deep LDS ring, one raw barrier per stage; a counted vmcnt keeps the newer stage's DMA in
-    // flight across it (waves 0,1 issue 4 DMA instructions per stage, waves 2..7 issue 3).
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nstages) stage(s);
-    int cur = 0, nxt = STAGES - 1;
-    for (int s = 0; s < nstages; ++s) {
-        int ahead = nstages - 1 - s;            // newer stages that may stay in flight
-        if (ahead > STAGES - 2) ahead = STAGES - 2;
-        if (ahead >= 2) {
-            if (wave < 2)
-                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else if (ahead == 1) {
-            if (wave < 2)
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();  // stage s visible to all waves; buffer `nxt` no longer read
-        if (s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2)) stage(nxt);
-        if (!(p.debug_skip_epilogue & 4)) compute(cur);
-        cur = cur + 1 == STAGES ? 0 : cur + 1;
-        nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
-    }
-
-    // ---- accumulate: lane holds out-chan rows 32*kh + 16*i + fg*4 + j, in-chan column 16*wid + fr ----
-    if ((p.debug_skip_epilogue & 1) && acc[0][0][0] != 12345.f) return;
-    if (p.sqnorm) {
-        double sq = 0.0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) sq += (double)acc[t][i][j] * (double)acc[t][i][j];
-        wave_sqnorm_add(sq, p.sqnorm + split);
-        return;
-    }
-    if (p.ws) {
-        // Deterministic path: this block's 64 x 576 partial goes to ITS OWN slab of the workspace as nine
-        // x two 1-KiB-per-wave stores (lane-major, exactly the accumulator registers); wgrad_patch_reduce_kernel
-        // adds the slabs of a (kt, ct) tile in split order.  9.4 M fp32 atomics per launch (~25 us) become
-        // 38 MB of streaming stores and a reduction that reads them back while they are still in the
-        // Infinity Cache.
-        float* o = p.ws + ((long)(kt * p.nct + ct) * p.nsplit + split) * kSlab + (wave * 64 + lane) * 4;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) *(f32x4*)(o + (t * 2 + i) * 2048) = acc[t][i];
-        return;
-    }
-    float* out = p.dw + (long)split * p.split_stride;
-    // Blocks that share a (kt, ct) slab finish together and add into the same addresses: start each block at
-    // a different tap so that at any instant the blocks of a slab hit different cache lines.
-    auto flush = [&](int t) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = kt * 64 + 32 * kh + 16 * i + fg * 4 + j;
-                const int e = t * p.C + ct * 64 + 16 * wid + fr;
-                unsafeAtomicAdd(out + (long)k * p.klen + e, acc[t][i][j]);
-            }
-    };
-    const int rot = p.debug_skip_epilogue & 8 ? 0 : split % 9;
-#define PRIMIA_FLUSH_FROM(R)                       \
-    case R:                                        \
-        _Pragma("unroll") for (int t = 0; t < 9; ++t) flush((t + R) % 9); \
-        break;
-    switch (rot) {
-        PRIMIA_FLUSH_FROM(0)
-        PRIMIA_FLUSH_FROM(1)
-        PRIMIA_FLUSH_FROM(2)
-        PRIMIA_FLUSH_FROM(3)
-        PRIMIA_FLUSH_FROM(4)
-        PRIMIA_FLUSH_FROM(5)
-        PRIMIA_FLUSH_FROM(6)
-        PRIMIA_FLUSH_FROM(7)
-        PRIMIA_FLUSH_FROM(8)
-    }
-#undef PRIMIA_FLUSH_FROM
-}
-
-// dw[k][e] = sum over splits of the partial slabs, in split order (deterministic).  Block = CL float4
-// chunks x SL split lanes (CL * SL = 256); a chunk q = ((t*2 + i)*8 + wave)*64 + lane of the slab is the
-// accumulator acc[t][i] of that lane, i.e. out-channels 32*(wave>>2) + 16*i + 4*(lane>>4) + 0..3 at
-// in-channel 16*(wave&3) + (lane&15) of tap t.
-template <int SL>
-__global__ __launch_bounds__(256) void wgrad_patch_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                                 int nsplit, int nct, int C, int klen) {
-    constexpr int CL = 256 / SL;
-    constexpr int CPB = kSlab / 4 / CL;            // blocks per slab
-    __shared__ f32x4 red[SL][CL];
-    const int combo = blockIdx.x / CPB;
-    const int q = (blockIdx.x % CPB) * CL + (threadIdx.x % CL);
-    const int sl = threadIdx.x / CL;
-    const float* src = ws + (long)combo * nsplit * kSlab + q * 4;
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    int s = sl;
-#pragma unroll 1
-    for (; s + 3 * SL < nsplit; s += 4 * SL) {       // four independent loads in flight
-        const f32x4 v0 = *(const f32x4*)(src + (long)s * kSlab);
-        const f32x4 v1 = *(const f32x4*)(src + (long)(s + SL) * kSlab);
-        const f32x4 v2 = *(const f32x4*)(src + (long)(s + 2 * SL) * kSlab);
-        const f32x4 v3 = *(const f32x4*)(src + (long)(s + 3 * SL) * kSlab);
-        a += v0; a += v1; a += v2; a += v3;
-    }
-    for (; s < nsplit; s += SL) a += *(const f32x4*)(src + (long)s * kSlab);
-    if (SL > 1) {
-        red[sl][threadIdx.x % CL] = a;
-        __syncthreads();
-        if (sl != 0) return;
-#pragma unroll
-        for (int k = 1; k < SL; ++k) a += red[k][threadIdx.x % CL];
-    }
-    const int lane = q & 63, wave = (q >> 6) & 7, ti = q >> 9;
-    const int t = ti >> 1, i = ti & 1;
-    const int kt = combo / nct, ct = combo - kt * nct;
-    const int k0 = kt * 64 + 32 * (wave >> 2) + 16 * i + (lane >> 4) * 4;
-    const int e = t * C + ct * 64 + 16 * (wave & 3) + (lane & 15);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) dw[(long)(k0 + j) * klen + e] = a[j];
-}
-
-
-// =====================================================================================================================
-// v2: the same halo-patch scheme on v_mfma_f32_32x32x16_bf16.
-//
-// What changed against the kernel above, and why (measured, profiles/r02_wgrad32_*.txt):
-//   * fragment traffic: a 32x32x16 MFMA does twice the MACs of a 16x16x32 per operand byte fetched from LDS, and the
-//     old stage body (all 44 transposing reads up front, then 36 dependent-issue MFMAs) ran at ~1.0 PFLOP/s with the
-//     staging switched off; the body below sustains 1.43 PFLOP/s alone (tools/micro/mfma_stage32.hip);
-//   * the two sub-patches of a stage go to the two HALVES of the block (waves 0-3 / 4-7) instead of every wave walking
-//     both: wave (half, kg, cg) owns out-channels 32*kg.., in-channels 32*cg.. of all nine taps for ITS sub-patch =
-//     nine f32x16 accumulators (144 registers, as before) and per 16-pixel k-step 1 dy + 9 x fragments for 9 MFMAs;
-//     the halves are added through LDS once, after the main loop;
-//   * LDS image: a pixel slot is 128 B = two 64-B channel groups; group g of slot s sits in half g ^ bit1(s), so the
-//     four consecutive slots one 32-lane phase of ds_read_b64_tr_b16 touches always cover all 64 banks, for any slot
-//     alignment (tap shifts!).  The halo row stride is a multiple of 4 slots (12 / 20) so that tap rows and k-steps
-//     are compile-time byte offsets from 3 x 2 + 2 address registers.
-// Staging (LDS-DMA pieces of 8 slots, source-side swizzle, zero page for padding), the split over pixel ranges, the
-// slab workspace and the three epilogues are those of the kernel above.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 template <bool V>
 struct OrderTag {
@@ -398,7 +85,7 @@ __device__ __forceinline__ int key32(int slot) { return (slot >> 1) & 1; }
 __device__ __forceinline__ void wgrad32_epilogue(f32x16 (&acc)[9], const PatchParams& p, char* smem, int wave, int lane,
                                                  int half, int kg, int cg, int kt, int ct, int split) {
     // ---- the two halves meet in LDS: waves 4-7 park their accumulators, waves 0-3 add them ---------------------------
-    if ((p.debug_skip_epilogue & 1) && acc[0][0] != 12345.f) return;
+    if ((WGP33_DBG & 1) && acc[0][0] != 12345.f) return;     // compile-time experiment switch (tools/micro/wgp33_bench.hip)
     __syncthreads();                                   // every wave is done reading the stage ring
     {
         f32x4* park = (f32x4*)smem + ((wave & 3) * 36) * 64 + lane;     // [wave & 3][t * 4 + m][lane] chunks of 16 B
@@ -468,286 +155,6 @@ __device__ __forceinline__ void wgrad32_epilogue(f32x16 (&acc)[9], const PatchPa
 #undef PRIMIA_FLUSH32_FROM
 }
 
-template <int SW, int STAGES>
-__global__ __launch_bounds__(512) void conv_wgrad_patch32_kernel(PatchParams p) {
-    constexpr int SH = 32 / SW;
-    constexpr int HR = SH + 2;
-    constexpr int HS = SW == 8 ? 12 : 20;       // halo row stride in slots: a multiple of 4 (see above)
-    constexpr int XSLOTS = HR * HS;             // 72 | 80: whole 8-slot DMA pieces
-    constexpr int XP = XSLOTS / 8;              // pieces per sub-patch halo
-    constexpr int NPIECE = 2 * XP + 8;          // per stage: two halos + 64 dy slots
-    constexpr int X_BYTES = XSLOTS * 128;
-    constexpr int STAGE = 2 * X_BYTES + 64 * 128;
-    constexpr int NW4 = NPIECE - 24;            // waves that issue four pieces per stage (the others three)
-    static_assert(XSLOTS % 8 == 0 && NW4 >= 0 && NW4 <= 8, "piece bookkeeping");
-    typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, kg = (wave >> 1) & 1, cg = wave & 1;
-
-    int bid = xcd_remap(blockIdx.x, gridDim.x);
-    int split;
-    if (p.split_fastest) {
-        split = bid % p.nsplit;
-        bid /= p.nsplit;
-    }
-    const int ct = bid % p.nct; bid /= p.nct;
-    const int kt = bid % p.nkt;
-    if (!p.split_fastest) split = bid / p.nkt;
-    const int t0 = split * p.per_block;
-    int t1 = t0 + p.per_block;
-    if (t1 > p.total) t1 = p.total;
-    const int nstages = (t1 - t0 + 1) >> 1;
-
-    const bf16* __restrict__ x = p.x + ct * 64;
-    const bf16* __restrict__ dy = p.dy + kt * 64;
-
-    // ---- staging constants (per DMA instruction `it` of this wave) ------------------------------------------------
-    // Everything that does not depend on the sub-patch is fixed here, per lane: the byte offset `rel` of the lane's
-    // 16 bytes from the sub-patch origin and `lbits` = one bit for its halo row and one for its halo column; per wave
-    // (scalars): which sub-patch q the piece belongs to, whether it carries x or dy, its LDS offset in the stage.
-    // Per stage a piece then costs four vector instructions (and, compare, add, select): the stage loop issues
-    // instructions at ~one per 4-5 cycles per wave, and the first version of this block — ~50 instructions per piece —
-    // took as long as the stage's MFMAs (profiles/r02_wgrad32_experiments.txt).
-    int rel[4];
-    unsigned lbits[4];
-    int pq[4], pisx[4], pdst[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = wave + 8 * it;
-        const int c16 = lane & 7;                       // 16-byte chunk of the 128-byte slot row
-        int drow, dcol;
-        if (idx < 2 * XP) {
-            const int j = idx >= XP ? idx - XP : idx;
-            const int slot = j * 8 + (lane >> 3);
-            const int hy = slot / HS, hx = slot - hy * HS;
-            const int grp = (c16 >> 2) ^ key32(slot);   // the channel group that lives in this half of the row
-            drow = hy - 1;
-            dcol = hx < SW + 2 ? hx - 1 : -2;           // pad slots of the halo row: never valid
-            rel[it] = (((hy - 1) * p.W + (hx - 1)) * p.C + (grp * 4 + (c16 & 3)) * 8) * 2;   // bytes
-        } else {
-            const int slot = (idx - 2 * XP) * 8 + (lane >> 3);
-            const int k = slot & 31;
-            const int py = SW == 8 ? (k >> 3) : (k >> 4), px = SW == 8 ? (k & 7) : (k & 15);
-            const int grp = (c16 >> 2) ^ key32(slot);
-            drow = py;
-            dcol = px;
-            rel[it] = ((py * p.W + px) * p.K + (grp * 4 + (c16 & 3)) * 8) * 2;
-        }
-        lbits[it] = dcol < -1 ? 0x80000000u : (1u << (drow + 1)) | (1u << (8 + dcol + 1));
-        const bool isx = idx < 2 * XP;
-        const int q = isx ? (idx >= XP) : (idx >= 2 * XP + 4);
-        pisx[it] = __builtin_amdgcn_readfirstlane((int)isx);
-        pq[it] = __builtin_amdgcn_readfirstlane(q);
-        pdst[it] = __builtin_amdgcn_readfirstlane(isx ? q * X_BYTES + (idx - XP * q) * 1024 : 2 * X_BYTES + (idx - 2 * XP) * 1024);
-    }
-    // Buffer resources over the two tensors (from this block's channel tile to the tensor's end).  A lane whose halo
-    // pixel lies outside the image (the convolution's zero padding), in a dead sub-patch or in the pad slots of a halo
-    // row gets an offset beyond num_records: the hardware returns zeros for it — no zero page, no pointer select.
-    typedef int i32x4 __attribute__((ext_vector_type(4)));
-    const long xbytes = ((long)p.total / p.PPI * p.H * p.W * p.C - ct * 64) * 2;
-    const long dybytes = ((long)p.total / p.PPI * p.H * p.W * p.K - kt * 64) * 2;
-    auto make_rsrc = [](const void* base, long bytes) {
-        const unsigned long long a = (unsigned long long)base;
-        i32x4 r;
-        r[0] = (int)(unsigned)a;
-        r[1] = (int)(unsigned)(a >> 32) & 0xffff;       // stride 0: raw buffer
-        r[2] = (int)(unsigned)(bytes > 0xfffffff0L ? 0xfffffff0L : bytes);
-        r[3] = 0x00020000;
-        return r;
-    };
-    i32x4 rsrc_x = make_rsrc(x, xbytes), rsrc_dy = make_rsrc(dy, dybytes);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        rsrc_x[j] = __builtin_amdgcn_readfirstlane(rsrc_x[j]);
-        rsrc_dy[j] = __builtin_amdgcn_readfirstlane(rsrc_dy[j]);
-    }
-    constexpr unsigned kOob = 0xfffffff0u;
-    int sn, sph, spw;
-    {
-        sn = t0 / p.PPI;
-        const int rem = t0 - sn * p.PPI;
-        sph = rem / p.PW;
-        spw = rem - sph * p.PW;
-    }
-    int st = t0;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    unsigned voff[4];      // the stage being issued: per-lane byte offset of each of this wave's pieces (or kOob) ...
-    unsigned gdst[4];      // ... and its wave-uniform LDS destination
-    auto prep = [&](int buf) {
-        unsigned smask[2];
-        int xo[2], dyo[2];
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const bool live = st < t1;
-            const int rb = sph * SH, cb = spw * SW;
-            const int pixbase = (sn * p.H + rb) * p.W + cb;
-            // valid halo rows: bit (drow + 1) for -rb <= drow < H - rb, columns likewise, shifted by 8
-            int rhi = p.H - rb + 1, chi = p.W - cb + 1;
-            rhi = rhi > SH + 2 ? SH + 2 : rhi;
-            chi = chi > SW + 2 ? SW + 2 : chi;
-            const unsigned rowm = ((1u << rhi) - 1u) & ~(rb == 0 ? 1u : 0u);
-            const unsigned colm = ((1u << chi) - 1u) & ~(cb == 0 ? 1u : 0u);
-            smask[q] = live ? rowm | (colm << 8) : 0u;
-            xo[q] = pixbase * p.C * 2;
-            dyo[q] = pixbase * p.K * 2;
-            ++st;
-            if (++spw == p.PW) {
-                spw = 0;
-                if (++sph == p.PH) {
-                    sph = 0;
-                    ++sn;
-                }
-            }
-        }
-        const unsigned base = lds0 + buf * STAGE;
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            if (wave + 8 * it >= NPIECE) break;
-            const unsigned m = pq[it] ? smask[1] : smask[0];
-            const int org = pisx[it] ? (pq[it] ? xo[1] : xo[0]) : (pq[it] ? dyo[1] : dyo[0]);
-            // (the sub-patch origin goes into the per-lane offset, not into soffset: the range check must see it)
-            voff[it] = (lbits[it] & m) == lbits[it] ? (unsigned)(rel[it] + org) : kOob;
-            gdst[it] = base + pdst[it];
-        }
-    };
-    bool do_issue = true;               // false in the last STAGES - 1 intervals (nothing left to fetch)
-    auto issue = [&](int it) {          // one LDS-DMA piece (wave-uniform guards: waves >= NW4 have three)
-        if (do_issue && wave + 8 * it < NPIECE && !(p.debug_skip_epilogue & 128)) {
-            const unsigned m0v = __builtin_amdgcn_readfirstlane(gdst[it]);
-            if (wave + 8 * it < 2 * XP)
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-                             ::"v"(voff[it]), "s"(rsrc_x), "s"(m0v) : "memory");
-            else
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-                             ::"v"(voff[it]), "s"(rsrc_dy), "s"(m0v) : "memory");
-        }
-    };
-    auto stage = [&](int buf) {
-        prep(buf);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) issue(it);
-    };
-
-    f32x16 acc[9];
-#pragma unroll
-    for (int t = 0; t < 9; ++t)
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
-
-    // ---- fragment addresses: lane (16-lane group g16, fr) reads pixel 8*(g16>>1) + (fr>>2) (+4) of the k-step,
-    //      channels 16*(g16&1) + 4*(fr&3) .. +3 of the wave's group --------------------------------------------------
-    const int fr = lane & 15, g16 = lane >> 4;
-    const int cbyte = (16 * (g16 & 1) + 4 * (fr & 3)) * 2;
-    int offa[2], offx[3][2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        const int kk = 8 * (g16 >> 1) + (fr >> 2) + 4 * h;            // pixel of the FIRST k-step of the sub-patch
-        const int py = SW == 8 ? (kk >> 3) : 0, px = SW == 8 ? (kk & 7) : kk;
-        const int sa = half * 32 + kk;
-        offa[h] = 2 * X_BYTES + sa * 128 + ((kg ^ key32(sa)) << 6) + cbyte;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const int slot = py * HS + px + s;
-            offx[s][h] = half * X_BYTES + slot * 128 + ((cg ^ key32(slot)) << 6) + cbyte;
-        }
-    }
-    constexpr int KSTEP_X = (SW == 8 ? 2 * HS : HS) * 128;   // second k-step: two rows (SW 8) / one row (SW 16) further
-    constexpr int KSTEP_A = 16 * 128;
-
-    // One stage of this wave's sub-patch: 2 k-steps x (1 dy + 9 x fragments, 9 MFMAs); the scheduler is left free to
-    // place the 40 transposing reads among the 18 MFMAs (pinning groups with sched_barrier cost 20 %).
-    auto compute = [&](int buf) {
-        // eight address registers per stage (3 tap columns x 2 halves + 2 for dy); tap rows and the second k-step are
-        // immediate offsets of the ds_read instructions — a wave issues one instruction per ~4-5 cycles, so every
-        // address add per fragment read would cost as much issue time as the MFMA it feeds
-        typedef __attribute__((address_space(3))) char* ldsp_t;
-        const ldsp_t sb = (ldsp_t)(size_t)(lds0 + buf * STAGE);
-        ldsp_t pa[2], px_[3][2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            pa[h] = sb + offa[h];
-#pragma unroll
-            for (int s = 0; s < 3; ++s) px_[s][h] = sb + offx[s][h];
-        }
-        bf16x8_t a[2], b[2][9];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            {
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(pa[0] + j * KSTEP_A));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(pa[1] + j * KSTEP_A));
-                a[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, s = t - 3 * r;
-                bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(px_[s][0] + (j * KSTEP_X + r * HS * 128)));
-                bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds4_t)(px_[s][1] + (j * KSTEP_X + r * HS * 128)));
-                b[j][t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 9; ++t)
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[j], b[j][t], acc[t], 0, 0, 0);
-    };
-
-#pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nstages) stage(s);
-    // The two waves of a SIMD belong to different halves.  Inside one barrier interval half 0 issues its DMA pieces
-    // (address arithmetic: VALU / SALU issue) and THEN multiplies, half 1 multiplies and THEN issues — so on every
-    // SIMD one wave feeds the matrix pipe while the other feeds the address pipe.  Legal because staging writes a ring
-    // slot nobody reads in that interval.  Two copies of the loop (one order each) keep one call site per lambda in
-    // each: both orders in ONE loop body made the register allocator spill 275 VGPRs.
-    // The two waves of a SIMD belong to different halves.  Inside one barrier interval half 0 issues its DMA pieces and
-    // THEN multiplies, half 1 multiplies and THEN issues: on every SIMD one wave feeds the matrix pipe while the other
-    // feeds the address pipe.  Legal because staging writes a ring slot nobody reads in that interval.  Two copies of
-    // the loop (one order each): both orders in ONE loop body made the register allocator spill 275 VGPRs.
-    auto main_loop = [&](auto stage_first) {
-        int cur = 0, nxt = STAGES - 1;
-        for (int s = 0; s < nstages; ++s) {
-            int ahead = nstages - 1 - s;
-            if (ahead > STAGES - 2) ahead = STAGES - 2;
-            if (ahead >= 2) {
-                if (wave < NW4)
-                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            } else if (ahead == 1) {
-                if (wave < NW4)
-                    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                else
-                    asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            do_issue = s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2);
-            // (no run-time switch around compute(): a conditional MFMA chain makes the compiler copy all 144
-            // accumulator registers every stage — 128 v_mov_b64 per iteration in the first version of this loop)
-            if constexpr (decltype(stage_first)::value) {
-                if (do_issue) stage(nxt);
-                compute(cur);
-            } else {
-                compute(cur);
-                if (do_issue) stage(nxt);
-            }
-            cur = cur + 1 == STAGES ? 0 : cur + 1;
-            nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
-        }
-    };
-    if (half == 0 || (p.debug_skip_epilogue & 16))
-        main_loop(OrderTag<true>{});
-    else
-        main_loop(OrderTag<false>{});
-
-    wgrad32_epilogue(acc, p, smem, wave, lane, half, kg, cg, kt, ct, split);
-}
-
 // Ordered reduction of the v2 slabs (chunk q = ((t*4 + m)*4 + wave)*64 + lane, see the kernel's store).
 struct ReduceGroup {        // grouped launch: dw of layers 1..3 and the combos of one layer (0: single layer)
     float* dwg[3];
@@ -806,23 +213,6 @@ __global__ __launch_bounds__(256) void wgrad_patch32_reduce_kernel(const float* 
     patch32_reduce_body<SL>(ws, dw, nsplit, nct, C, klen, rg, blockIdx.x);
 }
 
-// ... of many layers in one launch (conv_wgrad_patch33_multi_kernel): block b -> layer l, its block b - first[l]
-struct ReduceMulti {
-    int n;
-    int first[17];
-    const float* ws[16];
-    float* dw[16];
-    int nsplit[16], nct[16], C[16], klen[16];
-};
-
-__global__ __launch_bounds__(256) void wgrad_patch32_reduce_multi_kernel(ReduceMulti rm) {
-    const int b = blockIdx.x;
-    int l = 0;
-#pragma unroll 1
-    while (l + 1 < rm.n && b >= rm.first[l + 1]) ++l;
-    patch32_reduce_body<4>(rm.ws[l], rm.dw[l], rm.nsplit[l], rm.nct[l], rm.C[l], rm.klen[l], ReduceGroup{}, b - rm.first[l]);
-}
-
 // =====================================================================================================================
 // v3 ("3 + 3"): the nine taps of a k-step from THREE row-shifted dy fragments and THREE column-shifted x fragments.
 //
@@ -844,11 +234,6 @@ __global__ __launch_bounds__(256) void wgrad_patch32_reduce_multi_kernel(ReduceM
 // multiple of 4 slots = an immediate offset), dy [SH + 2 rows][SW slots] (row halo).
 #ifndef PRIMIA_WGP33_PIN
 #define PRIMIA_WGP33_PIN 1
-#endif
-// compile-time experiment switches (tools/micro/wgp33_bench.hip): 1 no epilogue, 2 no DMA after the prologue, 4 no MFMA,
-// 8 no fragment reads.  WGP33_PROF: per-wave cycles in DMA issue / vmcnt wait / barrier wait / compute / epilogue.
-#ifndef WGP33_DBG
-#define WGP33_DBG 0
 #endif
 #ifdef WGP33_PROF
 __device__ unsigned long long* wgp33_prof_buffer_dev;
@@ -1013,7 +398,7 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
     };
     bool do_issue = true;
     auto issue = [&](int it) {
-        if (do_issue && it < npc && !(p.debug_skip_epilogue & 128)) {
+        if (do_issue && it < npc) {
             const unsigned m0v = __builtin_amdgcn_readfirstlane(gdst[it]);
             if (pisx[it])
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
@@ -1057,7 +442,7 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
 
     // One stage of this wave's sub-patch: NK k-steps x 9 MFMAs.  Y[y] = dy fragment whose first row is image row y - 1
     // of the sub-patch; tap row r of k-step j needs Y[FR j + 2 - r].
-    const bool prio = (p.debug_skip_epilogue & 64) != 0;
+    constexpr bool prio = false;       // (s_setprio around the MFMAs: measured, no gain — profiles/r03_negative_results.txt)
     auto compute = [&](int buf) {
         typedef __attribute__((address_space(3))) char* ldsp_t;
         const ldsp_t sb = (ldsp_t)(size_t)(lds0 + buf * STAGE);
@@ -1153,7 +538,7 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
             WGP33_MARK(1)
             __builtin_amdgcn_s_barrier();
             WGP33_MARK(2)
-            do_issue = s + STAGES - 1 < nstages && !(p.debug_skip_epilogue & 2) && !(WGP33_DBG & 2);
+            do_issue = s + STAGES - 1 < nstages && !(WGP33_DBG & 2);
             if constexpr (decltype(stage_first)::value) {
                 if (do_issue) stage(nxt);
                 WGP33_MARK(0)
@@ -1196,7 +581,7 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
             nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
         }
     };
-    if (half == 0 || (p.debug_skip_epilogue & 16))
+    if (half == 0)
         main_loop(OrderTag<true>{});
     else
         main_loop(OrderTag<false>{});
@@ -1223,98 +608,52 @@ __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) 
     patch33_body<SW, SH, STAGES>(p, xcd_remap(blockIdx.x, gridDim.x));
 }
 
-// Many layers of DIFFERENT shapes in one launch: block b belongs to the layer l with first[l] <= b < first[l + 1] and is
-// its block b - first[l]; every layer has its own parameters (operands, geometry, slab region).  See
-// wgrad_patch_multi_dispatch.
-constexpr int kMultiMax = 16;
-struct MultiParams {
-    int n;
-    int first[kMultiMax + 1];
-    PatchParams layer[kMultiMax];
-};
-
-__global__ __launch_bounds__(512) void conv_wgrad_patch33_multi_kernel(MultiParams mp) {
-    const int b = blockIdx.x;
-    int l = 0;
-#pragma unroll 1
-    while (l + 1 < mp.n && b >= mp.first[l + 1]) ++l;
-    l = __builtin_amdgcn_readfirstlane(l);
-    const int nb = mp.first[l + 1] - mp.first[l];
-    patch33_body<8, 8, 3>(mp.layer[l], xcd_remap(b - mp.first[l], nb));
-}
-
 struct PatchGeom {
     bool ok, wide;
     int SW, SH;        // v3: sub-patch shape
     int PH, PW, PPI, total, per_block, nsplit, combos;
 };
 
-// PRIMIA_WGP32: 0 = round 1's kernel (16x16x32), 1 = v2 (32x32x16, 1 + 9 fragments), 3 = v3 (3 + 3 fragments, default)
-static int wgp_version() {
-    static const int v = getenv("PRIMIA_WGP32") ? atoi(getenv("PRIMIA_WGP32")) : 3;
-    return v;
-}
-static bool use_v2() { return wgp_version() != 0; }    // v2 and v3 share the byte-offset addressing and the slab format
-static bool use_v3() { return wgp_version() >= 3; }
-static bool wgp_pairimg() {
-    static const int t = getenv("PRIMIA_WGP_PAIRIMG") ? atoi(getenv("PRIMIA_WGP_PAIRIMG")) : 1;
-    return t != 0;
-}
 // DP-SGD norm pass with whole images per half: needs at least two images per block for every slab
 static bool pairimg_mode(const WgradParams& w, const PatchGeom& g) {
-    return w.persample && w.sqnorm && use_v3() && wgp_pairimg() && w.N >= 2 && (long)g.combos * ((w.N + 1) / 2) >= 256;   // (else: one block per image, as before)
+    return w.persample && w.sqnorm && PRIMIA_OPT(wgp_pairimg) && w.N >= 2 && (long)g.combos * ((w.N + 1) / 2) >= 256;   // (else: one block per image, as before)
 }
-static bool wgp_tall7() {
-    static const int t = getenv("PRIMIA_WGP_TALL7") ? atoi(getenv("PRIMIA_WGP_TALL7")) : 0;   // measured: no gain (2-stage ring, 9 spilled registers)
-    return t != 0;
-}
-
 // ngroup > 1: geometry of ONE layer of a grouped launch (the layers share the 256 CUs)
 static PatchGeom patch_geom(const WgradParams& w, int ngroup = 1) {
     PatchGeom g{};
-    // the v2 / v3 kernels address x and dy with 32-bit BYTE offsets through buffer resources (signed arithmetic, range
-    // check against num_records): elements < 2^30; the v1 kernel indexes elements with 32-bit ints: < 2^31
+    // x and dy are addressed with 32-bit BYTE offsets through buffer resources (signed arithmetic, range check against
+    // num_records): elements < 2^30
     g.ok = !(w.R != 3 || w.S != 3 || w.stride != 1 || w.pad != 1 || w.C % 64 || w.K % 64) &&
-           (long)w.N * w.H * w.W * (w.C > w.K ? w.C : w.K) < (use_v2() ? (1L << 30) : (1L << 31));
+           (long)w.N * w.H * w.W * (w.C > w.K ? w.C : w.K) < (1L << 30);
     if (!g.ok) return g;
     int SW, SH;
-    if (use_v3()) {
+    {
         // 8 x 8 unless it pads the image more than 35 % beyond the best shape: measured at batch 256, us per call incl.
         // the reduce, 8 x 8 | best-fitting shape: 28 x 28 images (pads to 32 x 32, +14 %) 77 | 81 (8 x 4), 14 x 14 (16 x 16,
         // +14 %) 75 | 83 (16 x 2) — a stage of 64 pixels per half with one barrier beats 32 pixels without padding
-        static const int cand[4][2] = {{8, 8}, {8, 4}, {16, 2}, {16, 7}};
-        static const int force = getenv("PRIMIA_WGP_SHAPE") ? atoi(getenv("PRIMIA_WGP_SHAPE")) : -1;   // 0 .. 3
-        long slots[4], best = -1;
-        for (int i = 0; i < 4; ++i) {
+        // (7-row bands of 16-column strips for H = 28 / 14 were measured: no gain, 9 spilled registers — not kept)
+        static const int cand[3][2] = {{8, 8}, {8, 4}, {16, 2}};
+        const int force = PRIMIA_OPT(wgp_shape);       // 0 .. 2, -1: by image size
+        long slots[3], best = -1;
+        for (int i = 0; i < 3; ++i) {
             slots[i] = (long)((w.W + cand[i][0] - 1) / cand[i][0] * cand[i][0]) * ((w.H + cand[i][1] - 1) / cand[i][1] * cand[i][1]);
-            if (i < 3 && (best < 0 || slots[i] < best)) best = slots[i];
+            if (best < 0 || slots[i] < best) best = slots[i];
         }
         int pick = 0;
-        if (force >= 0 && force < 4) {
+        if (force >= 0 && force < 3) {
             pick = force;
-        } else if (wgp_tall7() && w.H % 7 == 0 && slots[3] * 100 <= slots[0] * 90) {
-            pick = 3;        // 7-row bands of 16-column strips (a 2-stage ring of 72 KiB stages): H = 28, 14
         } else if (slots[0] * 100 > best * 135) {
             pick = slots[1] <= slots[2] ? 1 : 2;
         }
         SW = cand[pick][0]; SH = cand[pick][1];
         g.wide = SW == 16;
-    } else {
-        // 16-wide sub-patches when they waste fewer slots on the ragged right edge (W = 14: 16 vs 2 x 8)
-        const int waste8 = (w.W + 7) / 8 * 8 - w.W, waste16 = (w.W + 15) / 16 * 16 - w.W;
-        const int rows8 = (w.H + 3) / 4 * 4 - w.H, rows16 = (w.H + 1) / 2 * 2 - w.H;
-        const long slots8 = (long)(w.W + waste8) * (w.H + rows8), slots16 = (long)(w.W + waste16) * (w.H + rows16);
-        static const char force = getenv("PRIMIA_WGP_SW") ? getenv("PRIMIA_WGP_SW")[0] : 0;  // '8' | '1'(6)
-        g.wide = force ? force == '1' : slots16 < slots8;
-        SW = g.wide ? 16 : 8;
-        SH = 32 / SW;
     }
     g.SW = SW; g.SH = SH;
     g.PH = (w.H + SH - 1) / SH; g.PW = (w.W + SW - 1) / SW; g.PPI = g.PH * g.PW;
     g.total = w.N * g.PPI;
     g.combos = (w.C / 64) * (w.K / 64);
     // one 8-wave block per CU
-    static const int target_blocks = getenv("PRIMIA_WGP_BLOCKS") ? atoi(getenv("PRIMIA_WGP_BLOCKS")) : 0;
+    const int target_blocks = PRIMIA_OPT(wgp_blocks);
     const int target = target_blocks ? target_blocks : 256;
     long want = (target + g.combos - 1) / g.combos;
     if (ngroup > 1) want = target / ((long)ngroup * g.combos);      // all layers' blocks in ONE round
@@ -1350,12 +689,9 @@ static void fill_patch_params(PatchParams& p, const WgradParams& w, const PatchG
     p.total = g.total;
     p.per_block = g.per_block;
     p.nsplit = g.nsplit;
-    static const int order = getenv("PRIMIA_WGP_ORDER") ? atoi(getenv("PRIMIA_WGP_ORDER")) : 0;
-    p.split_fastest = order;
+    p.split_fastest = PRIMIA_OPT(wgp_order);
     p.split_stride = w.persample ? (long)w.K * w.klen : 0;
     p.sqnorm = w.persample ? w.sqnorm : nullptr;
-    static const int noepi = getenv("PRIMIA_WGP_NOEPI") ? atoi(getenv("PRIMIA_WGP_NOEPI")) : 0;
-    p.debug_skip_epilogue = noepi;
     const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
     p.ws = store ? w.ws : nullptr;
     p.pairimg = pairimg_mode(w, g) ? 1 : 0;
@@ -1392,78 +728,6 @@ static int launch_patch33(const WgradParams& w, const PatchGeom& g, hipStream_t 
     return launch_status();
 }
 
-template <int SW>
-static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st) {
-    constexpr int SH = 32 / SW;
-    PatchParams p;
-    p.x = (const bf16*)w.x; p.dy = (const bf16*)w.dy; p.dw = w.dw;
-    p.H = w.H; p.W = w.W; p.C = w.C; p.K = w.K; p.klen = w.klen;
-    p.nct = w.C / 64; p.nkt = w.K / 64;
-    p.PH = g.PH; p.PW = g.PW; p.PPI = g.PPI;
-    p.total = g.total;
-    p.per_block = g.per_block;
-    p.nsplit = g.nsplit;
-    static const int order = getenv("PRIMIA_WGP_ORDER") ? atoi(getenv("PRIMIA_WGP_ORDER")) : 0;
-    p.split_fastest = order;
-    p.split_stride = w.persample ? (long)w.K * w.klen : 0;
-    p.sqnorm = w.persample ? w.sqnorm : nullptr;
-    static const int noepi = getenv("PRIMIA_WGP_NOEPI") ? atoi(getenv("PRIMIA_WGP_NOEPI")) : 0;
-    p.debug_skip_epilogue = noepi;
-    p.pairimg = 0;
-    p.nimg = w.N;
-    p.ngroups = 1;
-    p.group_blocks = 0;
-
-    const bool store = !w.persample && w.ws && w.ws_bytes >= (size_t)g.combos * g.nsplit * kSlab * sizeof(float);
-    p.ws = store ? w.ws : nullptr;
-    const bool v2 = use_v2();
-    static const int stages = getenv("PRIMIA_WGP_STAGES") ? atoi(getenv("PRIMIA_WGP_STAGES")) : 3;
-    if (v2) {
-        constexpr int XS2 = (SH + 2) * (SW == 8 ? 12 : 20);
-        // the stage ring, or the 144 KiB the two halves need to meet in after the main loop
-        size_t lds = (size_t)(stages == 4 ? 4 : 3) * (2 * XS2 * 128 + 64 * 128);
-        if (lds < (size_t)kSlab * 4) lds = (size_t)kSlab * 4;
-        auto kern = stages == 4 ? conv_wgrad_patch32_kernel<SW, 4> : conv_wgrad_patch32_kernel<SW, 3>;
-        static bool attr_set2 = false;
-        if (!attr_set2) {
-            if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return PRIMIA_ERR_LAUNCH;
-            attr_set2 = true;
-        }
-        kern<<<(unsigned)(g.combos * g.nsplit), 512, lds, st>>>(p);
-        if (store) {
-            const int ns = g.nsplit;
-            if (ns >= 64)
-                wgrad_patch32_reduce_kernel<16><<<g.combos * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, ReduceGroup{});
-            else if (ns >= 8)
-                wgrad_patch32_reduce_kernel<4><<<g.combos * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, ReduceGroup{});
-            else
-                wgrad_patch32_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen, ReduceGroup{});
-        }
-        return launch_status();
-    }
-    constexpr int XS = (SH + 2) * (SW == 8 ? 12 : 18);
-    const size_t lds = (size_t)(stages == 4 ? 4 : 3) * (2 * XS * 128 + 64 * 128);
-    auto kern = stages == 4 ? conv_wgrad_patch_kernel<SW, 4> : conv_wgrad_patch_kernel<SW, 3>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return PRIMIA_ERR_LAUNCH;
-        attr_set = true;
-    }
-    kern<<<(unsigned)(g.combos * g.nsplit), 512, lds, st>>>(p);
-    if (store) {
-        const int ns = g.nsplit;
-        if (ns >= 64)
-            wgrad_patch_reduce_kernel<16><<<g.combos * (kSlab / 4 / 16), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
-        else if (ns >= 8)
-            wgrad_patch_reduce_kernel<4><<<g.combos * (kSlab / 4 / 64), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
-        else
-            wgrad_patch_reduce_kernel<1><<<g.combos * (kSlab / 4 / 256), 256, 0, st>>>(w.ws, w.dw, ns, p.nct, w.C, w.klen);
-    }
-    return launch_status();
-}
-
 // ---- grouped launch: up to four layers of ONE shape in one launch of conv_wgrad_patch33_kernel<8, 8> -------------------
 // A call of this kernel carries ~25-29 us that do not shrink with the work (launch, lane constants, first DMA round trip,
 // the halves' meeting + slab store, the reduce launch: profiles/r03_wgp33_phase_profile.txt) next to 45-55 us of main
@@ -1473,14 +737,13 @@ static int launch_patch(const WgradParams& w, const PatchGeom& g, hipStream_t st
 // Preferred group size for `count` layers of this shape: the largest n <= min(count, 4) whose blocks fill >= 90 % of the
 // CUs in one round (0: shape not served).
 int wgrad_patch_group_size(const WgradParams& w, int count) {
-    static const bool off = getenv("PRIMIA_WGP_GROUP") && getenv("PRIMIA_WGP_GROUP")[0] == '0';
-    if (off || !use_v3() || w.persample) return 0;
+    if (!PRIMIA_OPT(wgp_group) || w.persample) return 0;
     const PatchGeom g1 = patch_geom(w);
     if (!g1.ok || g1.SW != 8 || g1.SH != 8) return 0;
     for (int n = count < 4 ? count : 4; n >= 2; --n) {
         const PatchGeom g = patch_geom(w, n);
         const long blocks = (long)n * g.combos * g.nsplit;
-        static const int minfill = getenv("PRIMIA_WGP_GROUP_MINFILL") ? atoi(getenv("PRIMIA_WGP_GROUP_MINFILL")) : 90;
+        const int minfill = PRIMIA_OPT(wgp_group_minfill);
         if (blocks <= 256 && blocks * 100 >= 256 * minfill) return n;
     }
     return 1;
@@ -1536,99 +799,15 @@ int wgrad_patch_group_dispatch(const WgradParams* ws_, int n, hipStream_t st) {
     return launch_status();
 }
 
-// ---- every 3x3 / stride-1 layer of the network in ONE launch ------------------------------------------------------------
-// The grouped launch above amortises a call's fixed cost over the layers of one stage; weight gradients being leaves, ALL
-// of them can wait for the end of the backward pass and share one launch: ~T blocks per layer (each walks 256 / T times
-// the sub-patches of the one-launch-per-layer form behind one prologue / epilogue, and the slab traffic shrinks alike),
-// blocks of the layers with the most work per block first.
-static int multi_target() {
-    static const int t = getenv("PRIMIA_WGP_MULTI_T") ? atoi(getenv("PRIMIA_WGP_MULTI_T")) : 40;
-    return t < 1 ? 1 : t;
-}
-static PatchGeom multi_geom(const WgradParams& w) {
-    PatchGeom g = patch_geom(w);
-    if (!g.ok || g.SW != 8 || g.SH != 8 || w.persample) { g.ok = false; return g; }
-    long want = (multi_target() + g.combos / 2) / g.combos;
-    if (want < 1) want = 1;
-    long per = (g.total + want - 1) / want;
-    per = (per + 1) & ~1L;
-    if (per < 2) per = 2;
-    g.per_block = (int)per;
-    g.nsplit = (int)((g.total + per - 1) / per);
-    return g;
-}
-
-bool wgrad_patch_multi_ok(const WgradParams& w) {
-    static const bool off = getenv("PRIMIA_WGP_MULTI") && getenv("PRIMIA_WGP_MULTI")[0] == '0';
-    return !off && use_v3() && multi_geom(w).ok;
-}
-
-// workspace share of one layer (the layers' slab regions follow one another in call order)
-size_t wgrad_patch_multi_ws_bytes(const WgradParams& w) {
-    const PatchGeom g = multi_geom(w);
-    return g.ok ? (size_t)g.combos * g.nsplit * kSlab * sizeof(float) : 0;
-}
-
-int wgrad_patch_multi_dispatch(const WgradParams* ws_, int n, float* wsp, size_t ws_bytes, hipStream_t st) {
-    if (n < 1 || n > kMultiMax || !wsp) return PRIMIA_ERR_UNSUPPORTED;
-    PatchGeom gs[kMultiMax];
-    size_t need = 0;
-    for (int i = 0; i < n; ++i) {
-        if (!wgrad_patch_multi_ok(ws_[i]) || !ws_[i].x || !ws_[i].dy || !ws_[i].dw) return PRIMIA_ERR_UNSUPPORTED;
-        gs[i] = multi_geom(ws_[i]);
-        need += (size_t)gs[i].combos * gs[i].nsplit * kSlab * sizeof(float);
-    }
-    if (ws_bytes < need) return PRIMIA_ERR_WORKSPACE;
-    // layers with the most sub-patches per block first (the hardware hands out blocks in index order)
-    int order[kMultiMax];
-    for (int i = 0; i < n; ++i) order[i] = i;
-    for (int i = 1; i < n; ++i)
-        for (int j = i; j > 0 && gs[order[j]].per_block > gs[order[j - 1]].per_block; --j) {
-            const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t;
-        }
-    MultiParams mp{};
-    ReduceMulti rm{};
-    mp.n = rm.n = n;
-    float* slab = wsp;
-    int blocks = 0, rblocks = 0;
-    for (int k = 0; k < n; ++k) {
-        const int i = order[k];
-        WgradParams w = ws_[i];
-        w.ws = slab;
-        w.ws_bytes = (size_t)gs[i].combos * gs[i].nsplit * kSlab * sizeof(float);
-        fill_patch_params(mp.layer[k], w, gs[i]);
-        mp.layer[k].pairimg = 0;
-        mp.first[k] = blocks;
-        blocks += gs[i].combos * gs[i].nsplit;
-        rm.first[k] = rblocks;
-        rblocks += gs[i].combos * (kSlab / 4 / 64);
-        rm.ws[k] = slab; rm.dw[k] = w.dw; rm.nsplit[k] = gs[i].nsplit; rm.nct[k] = w.C / 64; rm.C[k] = w.C; rm.klen[k] = w.klen;
-        slab += (size_t)gs[i].combos * gs[i].nsplit * kSlab;
-    }
-    mp.first[n] = blocks;
-    rm.first[n] = rblocks;
-    const size_t lds = (size_t)kSlab * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)conv_wgrad_patch33_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                (int)lds) != hipSuccess)
-            return PRIMIA_ERR_LAUNCH;
-        attr_set = true;
-    }
-    conv_wgrad_patch33_multi_kernel<<<(unsigned)blocks, 512, lds, st>>>(mp);
-    wgrad_patch32_reduce_multi_kernel<<<(unsigned)rblocks, 256, 0, st>>>(rm);
-    return launch_status();
-}
-
 // ---- DP-SGD: norm pass that KEEPS every sample's tiles, clipped sum as a weighted reduce (see conv_wgrad.hip) ----------
 size_t wgrad_patch_keep_bytes(const WgradParams& w) {
-    static const long budget = getenv("PRIMIA_DP_KEEP_MB") ? atol(getenv("PRIMIA_DP_KEEP_MB")) << 20 : 160L << 20;   // (layer1: 38 MB per layer, layer2: 151; layer3 would be 604 MB written and read back: a loss)
+    const long budget = (long)PRIMIA_OPT(dp_keep_mb) << 20;   // (layer1: 38 MB per layer, layer2: 151; layer3 would be 604 MB written and read back: a loss)
     WgradParams q = w;
     q.persample = 1;
     double dummy;
     q.sqnorm = &dummy;
     const PatchGeom g = patch_geom(q);
-    if (!g.ok || !use_v3()) return 0;       // (whole images per half, or one block per (image, slab): both keep)
+    if (!g.ok) return 0;       // (whole images per half, or one block per (image, slab): both keep)
     const size_t n = (size_t)g.combos * w.N * kSlab * sizeof(float);
     return (long)n <= budget ? n : 0;
 }
@@ -1664,13 +843,15 @@ int wgrad_patch_clipped_sum(const WgradParams& w, const float* slabs, const floa
 // 16 = conv_wgrad_patch33_kernel, 11 = conv_wgrad_patch32_kernel, 12 = conv_wgrad_patch_kernel (round 1), 0 = shape not served
 int wgrad_patch_kernel_id(const WgradParams& w) {
     if (!patch_geom(w).ok) return 0;
-    return use_v3() ? 16 : (use_v2() ? 11 : 12);
+    return 16;
 }
 
 // DP-SGD norm pass on this kernel: 0 shape not served, 24 one block per (image, slab), 25 whole images per half-block
 int wgrad_patch_persample_kernel_id(const WgradParams& w) {
     WgradParams q = w;
+    static double dummy;
     q.persample = 1;
+    q.sqnorm = &dummy;       // (never dereferenced: the mode test only asks whether a norm pass was requested)
     const PatchGeom g = patch_geom(q);
     if (!g.ok) return 0;
     return pairimg_mode(q, g) ? 25 : 24;
@@ -1679,14 +860,10 @@ int wgrad_patch_persample_kernel_id(const WgradParams& w) {
 int wgrad_patch_dispatch(const WgradParams& w, hipStream_t st) {
     const PatchGeom g = patch_geom(w);
     if (!g.ok) return PRIMIA_ERR_UNSUPPORTED;
-    if (use_v3()) {
-        if (g.SW == 16) return g.SH == 7 ? launch_patch33<16, 7, 2>(w, g, st) : launch_patch33<16, 2>(w, g, st);
-        // (8 x 8: four stages of 40 KiB are exactly the CU's 160 KiB of LDS)
-        static const int st88 = getenv("PRIMIA_WGP_STAGES88") ? atoi(getenv("PRIMIA_WGP_STAGES88")) : 3;
-        if (g.SH == 8 && st88 == 4) return launch_patch33<8, 8, 4>(w, g, st);
-        return g.SH == 8 ? launch_patch33<8, 8>(w, g, st) : launch_patch33<8, 4>(w, g, st);
-    }
-    return g.wide ? launch_patch<16>(w, g, st) : launch_patch<8>(w, g, st);
+    if (g.SW == 16) return launch_patch33<16, 2>(w, g, st);
+    // (8 x 8: four stages of 40 KiB are exactly the CU's 160 KiB of LDS)
+    if (g.SH == 8 && PRIMIA_OPT(wgp_stages88) == 4) return launch_patch33<8, 8, 4>(w, g, st);
+    return g.SH == 8 ? launch_patch33<8, 8>(w, g, st) : launch_patch33<8, 4>(w, g, st);
 }
 
 }  // namespace primia

@@ -327,7 +327,7 @@ struct TapGeom {
 // extra_taps: taps of a paired layer that ride in the same launch (they count for the one-round block budget)
 static TapGeom tap_geom(const WgradParams& w, int extra_taps = 0) {
     TapGeom g{};
-    static const bool off = getenv("PRIMIA_WGTAP") && getenv("PRIMIA_WGTAP")[0] == '0';
+    const bool off = !PRIMIA_OPT(wgtap);
     g.ok = !off && !w.persample && !w.xpad && (w.stride == 2 || (w.R == 1 && w.S == 1)) && w.ntaps == w.R * w.S &&
            w.Md < (1L << 24) && (long)w.N * w.H * w.W * w.C < (1L << 31) && w.Md * w.K < (1L << 31) && w.K % 128 == 0 &&
            w.C % 64 == 0;
@@ -339,7 +339,7 @@ static TapGeom tap_geom(const WgradParams& w, int extra_taps = 0) {
     g.nct = w.C / g.BNC;
     g.combos = w.ntaps * g.nkt * g.nct;
     // one round of blocks: one per CU for the wide tile (144 KiB of LDS), two for the narrow one (72 KiB)
-    static const int tb = getenv("PRIMIA_WGTAP_BLOCKS") ? atoi(getenv("PRIMIA_WGTAP_BLOCKS")) : 0;
+    const int tb = PRIMIA_OPT(wgtap_blocks);
     const int target = tb ? tb : (g.wide ? 256 : 512);
     long want = target / ((w.ntaps + extra_taps) * g.nkt * g.nct);
     if (want < 1) want = 1;
@@ -453,14 +453,14 @@ static int launch_tap_persample(const WgradParams& w, const TapGeom& g, hipStrea
 
 // 26 = conv_wgrad_tap_kernel's norm pass (whole images per block), 0 = shape not served
 int wgrad_tap_persample_kernel_id(const WgradParams& w) {
-    static const bool off = getenv("PRIMIA_WGTAP_PS") && getenv("PRIMIA_WGTAP_PS")[0] == '0';
+    const bool off = !PRIMIA_OPT(wgtap_persample);
     WgradParams b = w;
     b.persample = 0;
     return (off || !tap_geom(b).ok || w.Ho * w.Wo < 1) ? 0 : 26;
 }
 
 int wgrad_tap_persample_dispatch(const WgradParams& w, hipStream_t st) {
-    static const bool off = getenv("PRIMIA_WGTAP_PS") && getenv("PRIMIA_WGTAP_PS")[0] == '0';
+    const bool off = !PRIMIA_OPT(wgtap_persample);
     if (off || !w.persample || !w.sqnorm) return PRIMIA_ERR_UNSUPPORTED;
     WgradParams b = w;
     b.persample = 0;

@@ -232,130 +232,35 @@ __global__ __launch_bounds__(256) void dp_ghost_sqnorm7s2_kernel(GhostParams p) 
     if (tid == 0) p.sq[n] += wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 
-// ---- 14x14 images, 3x3 / stride 1 (layer3): 196 pixels -----------------------------------------------------------------
-// A 256 x 256 Gram matrix of the halo has nowhere to live, so u_p . u_q is formed as the sum of the nine tap Grams (as in
-// the stride-2 kernel) — and only the upper triangle of the 13 x 13 tile grid of the (symmetric) Gram matrices is
-// computed: 91 tiles instead of 169, off-diagonal tiles counted twice.  ~120 MFLOP per sample against the 231 of the
-// per-sample gradient, with dy's Gram tiles (up to 28 per wave) kept in registers while the halo replaces dy in LDS.
-// Wave w owns tile rows w, w + 4, w + 8 (, 12).
-// Correct (norms equal to the slab norms at 1e-6) but NOT faster: one 4-wave block per CU reads a fragment per MFMA from
-// LDS, and the per-sample pass it would replace already runs at 0.74 PFLOP/s.  Kept opt-in (PRIMIA_DP_GHOST14=1).
-__global__ __launch_bounds__(256) void dp_ghost_sqnorm14_kernel(GhostParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int fr = lane & 15, fg = lane >> 4;
-    const int n = blockIdx.x;
-    const int C = p.C, K = p.K;
-    const int px = C * 2 + 16, pd = K * 2 + 16;
-    constexpr int P = 196, HALO = 256, NT = 13;             // 16 x 16 halo: halo (hy, hx) = input (hy - 1, hx - 1); row 256 = zeros
-    {
-        const bf16* ds = p.dy + (long)n * P * K;
-        ghost_stage(smem, pd, P + 1, K / 8, [&](int row, int ch) -> const u32x4* {
-            return row < P ? (const u32x4*)(ds + row * K + ch * 8) : nullptr;
-        });
-    }
-    __syncthreads();
-    // one tile row of a Gram matrix: rows ra[], columns of tiles tj >= ti, k over klen; row index < 0 = the zero row
-    auto gram_row = [&](const char* base, int pitch, int zero_row, int klen, int ti, int ra, const int (&rb)[NT], int off,
-                        f32x4 (&acc)[NT]) {
-        const char* pa = base + (ra < 0 ? zero_row : ra + off) * pitch + fg * 16;
-        const char* pb[NT];
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj) pb[tj] = base + (rb[tj] < 0 ? zero_row : rb[tj] + off) * pitch + fg * 16;
-        for (int k = 0; k < klen; k += 32) {
-            const bf16x8_t a = *(const bf16x8_t*)(pa + k * 2);
-#pragma unroll
-            for (int tj = 0; tj < NT; ++tj)
-                if (tj >= ti) {
-                    const bf16x8_t b = *(const bf16x8_t*)(pb[tj] + k * 2);
-                    acc[tj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[tj], 0, 0, 0);
-                }
-        }
-    };
-    int rq[NT];                                              // pixel of this lane in column tile tj (or -1)
-#pragma unroll
-    for (int tj = 0; tj < NT; ++tj) rq[tj] = 16 * tj + fr < P ? 16 * tj + fr : -1;
-    f32x4 g1[4][NT];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int ti = wave + 4 * m;
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj) g1[m][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (ti < NT) gram_row(smem, pd, P, K, ti, 16 * ti + fr < P ? 16 * ti + fr : -1, rq, 0, g1[m]);
-    }
-    __syncthreads();                                         // dy is dead: the input halo takes its place
-    {
-        const bf16* xs = p.x + (long)n * P * C;
-        ghost_stage(smem, px, HALO + 1, C / 8, [&](int row, int ch) -> const u32x4* {
-            const int hy = row >> 4, hx = row & 15;
-            if (row < HALO && hy >= 1 && hy <= 14 && hx >= 1 && hx <= 14) return (const u32x4*)(xs + ((hy - 1) * 14 + hx - 1) * C + ch * 8);
-            return nullptr;
-        });
-    }
-    __syncthreads();
-    // halo row of pixel q at tap (0, 0): qy * 16 + qx; tap (r, s): + 16 r + s
-    int hq[NT];
-#pragma unroll
-    for (int tj = 0; tj < NT; ++tj) hq[tj] = rq[tj] < 0 ? -1 : (rq[tj] / 14) * 16 + rq[tj] % 14;
-    double part = 0.0;
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {
-        const int ti = wave + 4 * m;
-        if (ti >= NT) break;
-        f32x4 g2[NT];
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj) g2[tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int pa_ = 16 * ti + fr;
-        const int ha = pa_ < P ? (pa_ / 14) * 16 + pa_ % 14 : -1;
-        for (int t = 0; t < 9; ++t) gram_row(smem, px, HALO, C, ti, ha, hq, 16 * (t / 3) + t % 3, g2);
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj)
-            if (tj >= ti) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) sacc += (double)g1[m][tj][e] * (double)g2[tj][e];
-                part += tj == ti ? sacc : 2.0 * sacc;
-            }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-    __shared__ double wsum[4];
-    if (lane == 0) wsum[wave] = part;
-    __syncthreads();
-    if (tid == 0) p.sq[n] += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+// PRIMIA_ERR_UNSUPPORTED where the form does not apply (the caller keeps its per-sample weight-gradient pass)
+static size_t ghost7_lds_bytes(int C, int K) {
+    size_t sdb = (size_t)(kGhPix + 1) * (K * 2 + 16);
+    if (sdb < (size_t)kGhHalo * 84 * 4) sdb = (size_t)kGhHalo * 84 * 4;
+    return (size_t)(kGhHalo + 1) * (C * 2 + 16) + sdb + (size_t)kGhPix * 52 * 4;
 }
 
-// PRIMIA_ERR_UNSUPPORTED where the form does not apply (the caller keeps its per-sample weight-gradient pass)
 // which Gram-matrix kernel serves the norm pass of this layer: 0 none, 21 dp_ghost_sqnorm7_kernel (7x7, stride 1),
-// 22 dp_ghost_sqnorm7s2_kernel (14x14 -> 7x7, stride 2), 23 dp_ghost_sqnorm14_kernel (opt-in)
+// 22 dp_ghost_sqnorm7s2_kernel (14x14 -> 7x7, stride 2)
 int dp_ghost_kernel_id(int H, int W, int C, int K, int R, int S, int stride, int pad) {
-    static const bool off = getenv("PRIMIA_DP_GHOST") && getenv("PRIMIA_DP_GHOST")[0] == '0';
-    if (off || R != 3 || S != 3 || pad != 1 || C % 32 || K % 32 || C < 32 || K < 32) return 0;
+    if (!PRIMIA_OPT(dp_ghost) || R != 3 || S != 3 || pad != 1 || C % 32 || K % 32 || C < 32 || K < 32) return 0;
     if (H == 14 && W == 14 && stride == 2) {
         size_t a = (size_t)226 * (C * 2 + 16), b = (size_t)(kGhPix + 1) * (K * 2 + 16);
         return (a > b ? a : b) > 160 * 1024 ? 0 : 22;
     }
-    if (H == 14 && W == 14 && stride == 1) {
-        static const bool on14 = getenv("PRIMIA_DP_GHOST14") && getenv("PRIMIA_DP_GHOST14")[0] == '1';
-        size_t a = (size_t)257 * (C * 2 + 16), b = (size_t)197 * (K * 2 + 16);
-        return (!on14 || (a > b ? a : b) > 160 * 1024) ? 0 : 23;
-    }
+    // (14 x 14 / stride 1 as Gram matrices was built and measured SLOWER than the per-sample weight-gradient pass it would
+    // replace — DP-SGD step 6.42 -> 6.56 ms, profiles/r03_negative_results.txt — and is not kept)
     if (H != 7 || W != 7 || stride != 1) return 0;
-    size_t sdb = (size_t)(kGhPix + 1) * (K * 2 + 16);
-    if (sdb < (size_t)kGhHalo * 84 * 4) sdb = (size_t)kGhHalo * 84 * 4;
-    const size_t lds = (size_t)(kGhHalo + 1) * (C * 2 + 16) + sdb + (size_t)kGhPix * 52 * 4;
-    return lds > 160 * 1024 ? 0 : 21;
+    return ghost7_lds_bytes(C, K) > 160 * 1024 ? 0 : 21;
 }
 
 int dp_ghost_sqnorm_dispatch(const void* x, const void* dy, double* sq, int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad, hipStream_t st) {
-    static const bool off = getenv("PRIMIA_DP_GHOST") && getenv("PRIMIA_DP_GHOST")[0] == '0';
-    if (off || R != 3 || S != 3 || pad != 1 || C % 32 || K % 32 || C < 32 || K < 32) return PRIMIA_ERR_UNSUPPORTED;
-    if (H == 14 && W == 14 && stride == 2) {
+    const int id = dp_ghost_kernel_id(H, W, C, K, R, S, stride, pad);
+    if (!id) return PRIMIA_ERR_UNSUPPORTED;
+    GhostParams p{(const bf16*)x, (const bf16*)dy, sq, C, K};
+    if (id == 22) {
         size_t a = (size_t)226 * (C * 2 + 16), b = (size_t)(kGhPix + 1) * (K * 2 + 16);
         const size_t lds2 = a > b ? a : b;
-        if (lds2 > 160 * 1024) return PRIMIA_ERR_UNSUPPORTED;
         static size_t lds2_set = 0;
         if (lds2 > lds2_set) {
             if (hipFuncSetAttribute((const void*)dp_ghost_sqnorm7s2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -363,33 +268,10 @@ int dp_ghost_sqnorm_dispatch(const void* x, const void* dy, double* sq, int N, i
                 return PRIMIA_ERR_LAUNCH;
             lds2_set = lds2;
         }
-        GhostParams p2{(const bf16*)x, (const bf16*)dy, sq, C, K};
-        dp_ghost_sqnorm7s2_kernel<<<N, 256, lds2, st>>>(p2);
+        dp_ghost_sqnorm7s2_kernel<<<N, 256, lds2, st>>>(p);
         return launch_status();
     }
-    if (H == 14 && W == 14 && stride == 1) {
-        // measured SLOWER than the per-sample weight-gradient pass it would replace (DP-SGD step 6.42 -> 6.56 ms: three
-        // launches of ~125 us against ~80): opt-in
-        static const bool on14 = getenv("PRIMIA_DP_GHOST14") && getenv("PRIMIA_DP_GHOST14")[0] == '1';
-        size_t a = (size_t)257 * (C * 2 + 16), b = (size_t)197 * (K * 2 + 16);
-        const size_t lds3 = a > b ? a : b;
-        if (!on14 || lds3 > 160 * 1024) return PRIMIA_ERR_UNSUPPORTED;
-        static size_t lds3_set = 0;
-        if (lds3 > lds3_set) {
-            if (hipFuncSetAttribute((const void*)dp_ghost_sqnorm14_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds3) != hipSuccess)
-                return PRIMIA_ERR_LAUNCH;
-            lds3_set = lds3;
-        }
-        GhostParams p3{(const bf16*)x, (const bf16*)dy, sq, C, K};
-        dp_ghost_sqnorm14_kernel<<<N, 256, lds3, st>>>(p3);
-        return launch_status();
-    }
-    if (H != 7 || W != 7 || stride != 1) return PRIMIA_ERR_UNSUPPORTED;
-    size_t sdb = (size_t)(kGhPix + 1) * (K * 2 + 16);
-    if (sdb < (size_t)kGhHalo * 84 * 4) sdb = (size_t)kGhHalo * 84 * 4;
-    const size_t lds = (size_t)(kGhHalo + 1) * (C * 2 + 16) + sdb + (size_t)kGhPix * 52 * 4;
-    if (lds > 160 * 1024) return PRIMIA_ERR_UNSUPPORTED;
+    const size_t lds = ghost7_lds_bytes(C, K);
     static size_t lds_set = 0;
     if (lds > lds_set) {
         if (hipFuncSetAttribute((const void*)dp_ghost_sqnorm7_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -397,7 +279,6 @@ int dp_ghost_sqnorm_dispatch(const void* x, const void* dy, double* sq, int N, i
             return PRIMIA_ERR_LAUNCH;
         lds_set = lds;
     }
-    GhostParams p{(const bf16*)x, (const bf16*)dy, sq, C, K};
     dp_ghost_sqnorm7_kernel<<<N, 256, lds, st>>>(p);
     return launch_status();
 }

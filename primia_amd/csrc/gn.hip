@@ -729,7 +729,7 @@ static inline bool gn_shape_ok(int N, int HW, int C, int G, int dtype) {
 
 // one block per sample (gn_sample_reduce_kernel): the batch fills the chip that way and 2C columns fit the block
 static inline bool gn_sample_blocks(int N, int C, int ch) {
-    static const int sw = getenv("PRIMIA_GN_SAMPLE") ? atoi(getenv("PRIMIA_GN_SAMPLE")) : 1;
+    const int sw = PRIMIA_OPT(gn_sample);
     const int tpr = C / ch;
     return sw && N >= kGnSampleBlockMinN && 2 * C <= 1024 && 1024 % tpr == 0 && 1024 / tpr >= 1024 / (2 * C);
 }

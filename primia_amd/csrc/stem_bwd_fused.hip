@@ -79,7 +79,7 @@ struct StemFusedParams {
     int N, Hp, Wp, Ho, Wo, Hq, Wq;
     int PH, PW, PPI;
     int total, per_block;
-    int debug;              // timing experiments only (PRIMIA_STEM_FUSED_DEBUG): 1 no transform, 2 no MFMAs, 4 no raw staging
+    int debug;              // timing experiments only (0 in the library): 1 no transform, 2 no MFMAs, 4 no raw staging
 };
 
 constexpr int kSbfXB = 7 * 1024;                 // one input patch: 21 rows x 320 B by 7 DMA pieces
@@ -432,8 +432,7 @@ extern "C" int primia_stem_bwd_fused(const void* x_padded, const void* y, const 
     const int64_t slab_bytes = (int64_t)grid * 64 * 256 * (int64_t)sizeof(float);
     const bool store = ws && ws_bytes >= slab_bytes;
     p.ws = store ? (float*)ws : nullptr;
-    static const int dbg = getenv("PRIMIA_STEM_FUSED_DEBUG") ? atoi(getenv("PRIMIA_STEM_FUSED_DEBUG")) : 0;
-    p.debug = dbg;
+    p.debug = 0;       // (timing-experiment bits of tools/micro; never set by the library)
     static bool attr_set = false;
     if (!attr_set) {
         if (hipFuncSetAttribute((const void*)stem_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kSbfLds) !=

@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512) void stem_conv_fwd_kernel(StemFwdParams p) {
 
 static int stem_fwd_grid(int N, int H, int W, int* per_block) {
     const long total = (long)N * (H / 2 / 8) * (W / 2 / 16);
-    static const int target = getenv("PRIMIA_STEM_BLOCKS") ? atoi(getenv("PRIMIA_STEM_BLOCKS")) : 256;
+    const int target = PRIMIA_OPT(stem_blocks) > 0 ? PRIMIA_OPT(stem_blocks) : 256;
     long per = (total + target - 1) / target;
     per = (per + 1) & ~1L;
     if (per < 2) per = 2;
@@ -523,15 +523,14 @@ __global__ __launch_bounds__(512) void stem_conv_wgrad_kernel(StemWgParams p) {
 static bool stem_wgrad_halo_ok(int N, int H, int W) {
     if (H % 32 != 0 || W % 32 != 0) return false;
     if ((long)N * (H + 6) * (W + 8) * 4 >= (1L << 31) || (long)N * (H / 2) * (W / 2) * 64 >= (1L << 31)) return false;
-    static const bool off = getenv("PRIMIA_STEM_WGRAD") && getenv("PRIMIA_STEM_WGRAD")[0] == 'o';  // old kernel (A/B)
-    return !off;
+    return PRIMIA_OPT(stem_wgrad_halo) != 0;     // (0: the per-tap stem kernel of conv_wgrad.hip, for A/B)
 }
 
 // two blocks per CU (76 VGPRs, 69 KiB of LDS each): independent blocks cover each other's barriers and DMA waits
 // (127 -> 113 us); every block flushes one [64][256] slab
 static void stem_wgrad_geometry(int N, int H, int W, int& total, int& per_block, int& grid) {
     total = N * (H / 2 / 8) * (W / 2 / 16);
-    static const int target = getenv("PRIMIA_STEM_WG_BLOCKS") ? atoi(getenv("PRIMIA_STEM_WG_BLOCKS")) : 512;
+    const int target = PRIMIA_OPT(stem_wg_blocks) > 0 ? PRIMIA_OPT(stem_wg_blocks) : 512;
     long per = (total + target - 1) / target;
     if (per < 1) per = 1;
     per_block = (int)per;

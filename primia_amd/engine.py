@@ -34,10 +34,17 @@ class _Conv:
 
 class ResNet18Engine:
     def __init__(self, batch_size, num_classes=3, in_channels=3, input_size=224, pooling="max",
-                 dtype=torch.bfloat16, device="cuda:0", norm="batch", groups=32):
+                 dtype=torch.bfloat16, device="cuda:0", norm="batch", groups=32, options=None):
         """norm="batch": the reference model.  norm="group": GroupNorm(groups, C) in place of every
         BatchNorm (ResNet's `norm_layer` hook, torchlib/models.py:355) — the BN-free network the
-        DP-SGD configuration needs (train.py:308)."""
+        DP-SGD configuration needs (train.py:308).
+        `options`: {name: value} overriding the schedule switches below (class attributes such as wgrad_group,
+        wgrad_overlap, masked_acc, stem_bwd_fused, dp_keep ...) for THIS engine before its buffers are sized.  Nothing here
+        reads the environment; the kernel library's own switches are `_lib.set_option` (primia_set_option)."""
+        for k, v in (options or {}).items():
+            if not hasattr(type(self), k):
+                raise ValueError(f"unknown engine option {k!r}")
+            setattr(self, k, v)
         if not torch.cuda.is_available():
             raise _lib.PrimiaError("ResNet18Engine needs a GPU (HIP kernels only, no CPU fallback)")
         _lib.lib()
@@ -152,20 +159,6 @@ class ResNet18Engine:
                     for nm in names:
                         self._wg_group[nm] = (key, n)
                     group_ws.append(query("primia_conv_wgrad_group_ws_bytes", d, n, self.dt))
-        # ... or EVERY such layer of the network in one launch at the end of the backward pass
-        # (primia_conv2d_wgrad_multi_ws); the workspace then holds the slab shares of all of them
-        self._wg_multi = {}        # conv name -> share of the workspace
-        self._wg_multi_held = []
-        if dtype == torch.bfloat16 and self.wgrad_multi:
-            for c in self.spec.convs:
-                d = self.convs[c.name].desc
-                if d.R == 3 and d.stride == 1 and c.name != stem.name:
-                    share = query("primia_conv_wgrad_multi_ws_bytes", d, self.dt)
-                    if share > 0:
-                        self._wg_multi[c.name] = share
-            if len(self._wg_multi) < 2:
-                self._wg_multi = {}
-        group_ws.append(sum(self._wg_multi.values()))
         ws_bytes = max(max(ws_need.values()), self._stem_ws_bytes, max(list(self._pair_ws.values()) + [0]), max(group_ws))
         self.wgrad_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev) if ws_bytes > 0 else None
         self.wgrad_ws_bytes = ws_bytes
@@ -236,42 +229,12 @@ class ResNet18Engine:
         self.free_stats = {c.name for c in self.spec.convs
                            if dtype == torch.bfloat16 and norm == "batch" and c.name != "conv1"
                            and query("primia_conv_stats_per_tile", self.convs[c.name].desc, self.dt) == 1}
-        # Experiment (PRIMIA_ATOMIC_STATS=layer3,layer4): the implicit-GEMM epilogue accumulates the batch sums with
-        # atomics for the named stages only, whose separate statistics kernels are latency- rather than
-        # bandwidth-bound.  Their partial slabs are the tail of stat_sums and are zeroed once per forward.
-        self._atomic_stats_from = None
-        pref = tuple(p for p in os.environ.get("PRIMIA_ATOMIC_STATS", "").split(",") if p)
-        if pref and dtype == torch.bfloat16 and norm == "batch":
-            off = 0
-            for c in self.spec.convs:
-                if c.name.startswith(pref) and c.name not in self.free_stats:
-                    self.free_stats.add(c.name)
-                    if self._atomic_stats_from is None:
-                        self._atomic_stats_from = off
-                elif self._atomic_stats_from is not None:
-                    raise _lib.PrimiaError("PRIMIA_ATOMIC_STATS must name a suffix of the network's stages")
-                off += per(c)
-        # BatchNorm backward sums formed by the data-gradient kernel that produces the BatchNorm's input gradient
-        # (primia_conv2d_dgrad_bnsums; layer2-4's 3x3 / stride-1 convs): bn1 of a block is fed by its conv2's data
-        # gradient, bn2 of a block by the (accumulating) conv1 data gradient of the identity block after it.
-        # Measured on MI355X at batch 256 it LOSES (6.375 -> 6.449 ms per step: the 9 write-backs get a dependent read
-        # of y and ~400 VALU per thread on a CU that holds one block, which costs more than the 9 streaming reduction
-        # passes it removes), so it is opt-in: PRIMIA_BWD_SUMS=1.
-        self.bwd_sums, self._bwd_sums_ready = {}, set()
-        if dtype == torch.bfloat16 and norm == "batch" and os.environ.get("PRIMIA_BWD_SUMS", "0") == "1":
-            blks = self.spec.blocks
-            for i, blk in enumerate(blks):
-                feeders = [(blk.conv1, blk.conv2)]
-                if i + 1 < len(blks) and blks[i + 1].down is None:
-                    feeders.append((blk.conv2, blks[i + 1].conv1))
-                for consumer, producer in feeders:
-                    slots = query("primia_conv_dgrad_bnsum_slots", self.convs[producer.name].desc, self.dt)
-                    if slots > 0:
-                        self.bwd_sums[bn_name(consumer.name)] = torch.zeros(slots, 2, consumer.cout, dtype=torch.float32,
-                                                                            device=dev)
+        # (Two experiments lived here and were measured to lose, profiles/r01_negative_results.txt: atomically accumulated
+        # batch sums for the late stages, and BatchNorm-backward sums emitted by the data-gradient kernels' write-backs —
+        # 6.375 -> 6.449 ms per step.)
         # identity blocks: can conv1's accumulating data gradient apply bn2's ReLU mask to the old values itself?
         self.masked_acc_ok = {}
-        if os.environ.get("PRIMIA_MASKED_ACC", "1") != "0":
+        if self.masked_acc:
             for blk in self.spec.blocks:
                 if blk.down is None:
                     self.masked_acc_ok[blk.conv1.name] = query("primia_conv_dgrad_masked_acc_ok",
@@ -421,12 +384,14 @@ class ResNet18Engine:
 
     # conv1 + downsample data gradients of a transition block in one pass (primia_conv2d_dgrad_pair)
     pair_dgrad = True
+    # identity blocks: conv1's accumulating data gradient applies bn2's ReLU mask to the old values itself
+    masked_acc = True
     # transition blocks: bn2's and the downsample BatchNorm's backward passes as one (primia_bn_bwd_pair)
-    bn_pair = os.environ.get("PRIMIA_BN_PAIR", "1") != "0"
+    bn_pair = True
     # order of a layer's two gradient kernels: weight gradient first, so that the BatchNorm backward pass that follows
-    # the data gradient reads it while it is still in the Infinity Cache (6.42 -> 6.39 ms per step; PRIMIA_WGRAD_FIRST=0
+    # the data gradient reads it while it is still in the Infinity Cache (6.42 -> 6.39 ms per step; wgrad_first = False
     # restores the other order)
-    wgrad_first = os.environ.get("PRIMIA_WGRAD_FIRST", "1") == "1"
+    wgrad_first = True
 
     @staticmethod
     def _macs(c):
@@ -449,7 +414,7 @@ class ResNet18Engine:
         else:
             self._timed("fwd", c, lambda: call("primia_conv2d_fwd", c.desc, x, c.w_fwd, y, self.dt))
 
-    fwd_pair = os.environ.get("PRIMIA_FWD_PAIR", "1") != "0"
+    fwd_pair = True
 
     def _conv_fwd_pair(self, blk, x, y1, yd):
         """conv1 + downsample of a transition block as one launch; False where the library does not serve the pair."""
@@ -475,8 +440,6 @@ class ResNet18Engine:
         x_nchw = x_nchw.contiguous()
         if self.training and self.fuse_stats:
             self.stat_sums.zero_()
-        elif self.training and self._atomic_stats_from is not None:
-            self.stat_sums[self._atomic_stats_from:].zero_()
         self._stem_padded = self.x0p is not None and not (self.training and self.fuse_stats)
         # (the unpadded copy is read only where the halo kernels on the padded one do not serve the shape)
         self._x0_valid = not self._stem_padded or (self.norm == "group" and self._stem_ws_bytes <= 0)
@@ -623,14 +586,6 @@ class ResNet18Engine:
                 call("primia_weighted_colsum", psg, self.ones_n, self.gviews[b + ".weight"], self.N, C)
                 call("primia_weighted_colsum", psb, self.ones_n, self.gviews[b + ".bias"], self.N, C)
             return
-        if b in self._bwd_sums_ready:   # both reductions came out of the data-gradient kernel's write-back
-            self._bwd_sums_ready.discard(b)
-            mask = self.relu_masks[b] if g_out is not None else None
-            sums = self.bwd_sums[b]
-            call("primia_bn_bwd_from_sums", y, mask, dz, dy, g_out, self.views[b + ".weight"], self.views[b + ".bias"],
-                 sm, si, self.gviews[b + ".weight"], self.gviews[b + ".bias"], sums, sums.shape[0], y.shape[0],
-                 y.shape[1], self.dt)
-            return
         if relu and g_out is not None and b in self.relu_masks:
             call("primia_bn_bwd_mask", y, self.relu_masks[b], dz, dy, g_out if keep_g else None,
                  self.views[b + ".weight"], sm, si,
@@ -646,16 +601,16 @@ class ResNet18Engine:
         call("primia_bn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, self.gviews[b + ".weight"],
              self.gviews[b + ".bias"], y.shape[0], y.shape[1], int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
 
-    wgrad_pair = os.environ.get("PRIMIA_WGRAD_PAIR", "1") != "0"
-    gn_relu_recompute = os.environ.get("PRIMIA_GN_RELU_RECOMPUTE", "1") != "0"
+    wgrad_pair = True
+    gn_relu_recompute = True
     # GroupNorm residual layers with the BatchNorm path's 1-bit ReLU masks (and its mask-applying accumulate dgrad)
-    gn_relu_masks = os.environ.get("PRIMIA_GN_RELU_MASKS", "1") != "0"
-    gn_ds_mask = os.environ.get("PRIMIA_GN_DS_MASK", "1") != "0"
-    gn_stem_fused = os.environ.get("PRIMIA_GN_STEM_FUSED", "1") != "0"
-    wgrad_group = os.environ.get("PRIMIA_WGRAD_GROUP", "1") != "0"
-    # (all layers at the end of the backward pass: measured no better than the per-stage groups — 5.16 vs 5.14 ms; by then
-    # every operand comes from HBM, while a stage's group still finds its newest dy in the Infinity Cache.  Opt-in.)
-    wgrad_multi = os.environ.get("PRIMIA_WGRAD_MULTI", "0") != "0"
+    gn_relu_masks = True
+    gn_ds_mask = True
+    gn_stem_fused = True
+    wgrad_group = True
+    # (all 13 layers in ONE launch at the end of the backward pass was built and measured no better than the per-stage
+    # groups — 5.16 vs 5.14 ms: by then every operand comes from HBM, while a stage's group still finds its newest dy in
+    # the Infinity Cache — and is not kept: profiles/r03_negative_results.txt)
 
     def _wgrad_transition(self, blk, x, dy1, dyd):
         """conv1 and the downsample of a transition block: one launch where the library serves the pair."""
@@ -673,9 +628,6 @@ class ResNet18Engine:
         c = self.convs[name]
         if self.dp is not None:  # DP-SGD: weight gradients wait for the per-sample clip factors
             self.dp["wgrads"].append((name, x, dy))
-            return
-        if self.wgrad_ws is not None and name in self._wg_multi:
-            self._wg_multi_held.append((name, x, dy))
             return
         if self.wgrad_ws is not None and name in self._wg_group:
             key, n = self._wg_group[name]
@@ -697,10 +649,10 @@ class ResNet18Engine:
     # narrower: a layer's wgrad starts after its sibling dgrad and runs beside the BatchNorm backward chain that
     # follows (HBM-bound kernels and 7-us finalize launches); the next dgrad waits for it.  Also slower on
     # MI355X (7.10 ms serial -> 7.30 ms): kept as an option for other shapes, off by default.
-    # Re-measured in round 3 with the workspace kernels (PRIMIA_WGRAD_OVERLAP=1: the schedule above; =2: the weight
+    # Re-measured in round 3 with the workspace kernels (wgrad_overlap = 1: the schedule above; = 2: the weight
     # gradients free-running on the second stream until the finalize): see profiles/r03_negative_results.txt.
-    wgrad_overlap = int(os.environ.get("PRIMIA_WGRAD_OVERLAP", "0"))
-    stem_bwd_fused = os.environ.get("PRIMIA_STEM_BWD_FUSED", "1") != "0"
+    wgrad_overlap = 0
+    stem_bwd_fused = True
 
     def _on_wgrad_stream(self, fn):
         if not self.wgrad_overlap or self.prof is not None:
@@ -719,20 +671,11 @@ class ResNet18Engine:
             self._wg_pending = False
 
     def _dgrad(self, name, dy, dx, accumulate, consumer=None, consumer_y=None):
-        """Data gradient of conv `name` into dx.  `consumer`: the conv whose BatchNorm (+ReLU) backward reads dx next;
-        where the kernel can, it also forms that BatchNorm's two reductions (see bwd_sums)."""
+        """Data gradient of conv `name` into dx (`consumer`, `consumer_y`: the conv whose BatchNorm backward reads dx
+        next — kept in the signature for the callers; the kernels no longer form that BatchNorm's sums, see __init__)."""
         c = self.convs[name]
         if self.wgrad_overlap == 1:
             self._join_wgrad_stream()   # (narrow overlap) two MFMA-bound kernels never run side by side
-        b = bn_name(consumer) if consumer is not None else None
-        if b is not None and b in self.bwd_sums and self.training and (not accumulate or b in self.relu_masks):
-            sm, si = self.save[b]
-            mask = self.relu_masks[b] if accumulate else None   # bn2 (residual, mask bits) / bn1 (mask from y)
-            self._timed("dgrad", c, lambda: call("primia_conv2d_dgrad_bnsums", c.desc, dy, c.w_dgrad, dx, int(accumulate),
-                                                 consumer_y, mask, self.views[b + ".weight"], self.views[b + ".bias"], sm,
-                                                 si, self.bwd_sums[b], self.dt))
-            self._bwd_sums_ready.add(b)
-            return
         self._timed("dgrad", c,
                     lambda: call("primia_conv2d_dgrad", c.desc, dy, c.w_dgrad, dx, int(accumulate), self.dt))
 
@@ -761,10 +704,10 @@ class ResNet18Engine:
             # block whose conv1 data gradient can mask the old values itself (one tensor write less)
             b2 = bn_name(blk.conv2.name)
             masked_acc = (blk.down is None and self.masked_acc_ok.get(blk.conv1.name, False)
-                          and b2 in self.relu_masks and not self.bwd_sums)
+                          and b2 in self.relu_masks)
             # transition block: bn2 and the downsample BatchNorm share the incoming gradient -> ONE fused backward
             bn_pair = (blk.down is not None and self.pair_dgrad and self.bn_pair and self.norm == "batch"
-                       and b2 in self.relu_masks and not self.bwd_sums)
+                       and b2 in self.relu_masks)
             if bn_pair:
                 bd = bn_name(blk.down.name)
                 (sm2, si2), (smd, sid) = self.save[b2], self.save[bd]
@@ -912,30 +855,7 @@ class ResNet18Engine:
                 self._on_wgrad_stream(lambda c=c, x=x, dy=dy: self._timed("wgrad", c, lambda: call(
                     "primia_conv2d_wgrad_ws", c.desc, x, dy, c.acc, self.wgrad_ws, self.wgrad_ws_bytes, self.dt)))
 
-    def _flush_wgrad_multi(self):
-        held, self._wg_multi_held = self._wg_multi_held, []
-        if not held:
-            return
-        import ctypes
-        key = tuple((nm, x.data_ptr(), dy.data_ptr()) for nm, x, dy in held)
-        cached = getattr(self, "_wg_multi_args", None)
-        if cached is None or cached[0] != key:     # (the engine's buffers never move: built once)
-            n = len(held)
-            arr = ctypes.c_void_p * n
-            descs = arr(*[ctypes.addressof(self.convs[nm].desc) for nm, _, _ in held])
-            xs = arr(*[x.data_ptr() for _, x, _ in held])
-            dys = arr(*[dy.data_ptr() for _, _, dy in held])
-            accs = arr(*[self.convs[nm].acc.data_ptr() for nm, _, _ in held])
-            cached = self._wg_multi_args = (key, n, descs, xs, dys, accs)
-        _, n, descs, xs, dys, accs = cached
-        c = self.convs[held[0][0]]
-        self._on_wgrad_stream(lambda: self._timed(
-            "wgrad", c, lambda: call("primia_conv2d_wgrad_multi_ws", n, descs, xs, dys, accs, self.wgrad_ws,
-                                     self.wgrad_ws_bytes, self.dt),
-            extra_macs=sum(self._macs(self.convs[nm]) for nm, _, _ in held[1:])))
-
     def _finalize_wgrads(self):
-        self._flush_wgrad_multi()
         for key in list(self._wg_held):      # (groups that never filled: odd layer counts)
             self._flush_wgrad_group(key)
         self._join_wgrad_stream()
@@ -1173,8 +1093,8 @@ class ResNet18Engine:
         self.dp_stats = {"sq_norms": sq, "clip": clip}
         return self.loss
 
-    dp_keep = os.environ.get("PRIMIA_DP_KEEP", "1") != "0"
-    dp_scale_many = os.environ.get("PRIMIA_DP_SCALE_MANY", "1") != "0"
+    dp_keep = True
+    dp_scale_many = True
 
     def _dp_keep_buffers(self):
         """{conv name: fp32 buffer} for the layers whose per-sample tiles the DP-SGD norm pass keeps (built once)."""

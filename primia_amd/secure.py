@@ -292,7 +292,7 @@ class SecureContext:
         return self.sub(a, self.share(c))
 
     # ---- Beaver -----------------------------------------------------------------------------------
-    fuse_beaver = os.environ.get("PRIMIA_SECURE_FUSE", "1") != "0"
+    fuse_beaver = True
 
     def beaver_mul(self, x, y, trunc=None):
         """Element-wise private product; trunc = d: followed by each party's truncation of its share by d (fpt_mul).

@@ -260,7 +260,7 @@ def test_stem_kept_per_sample_tiles_give_the_clipped_sum(cuda):
 
 
 def test_dp_step_with_kept_tiles_matches_the_two_pass_form(cuda):
-    """bf16 DP-SGD engine step with the kept-tile path (stem + layer1) against the same step with PRIMIA_DP_KEEP off:
+    """bf16 DP-SGD engine step with the kept-tile path (stem + layer1) against the same step with dp_keep off:
     same norms and clip factors (to fp64 summation order), clipped gradient within the bf16 rounding of the scaled rows."""
     batch, size = 130, 32
     spec = rs.resnet18_spec(3, 3, size, "max")
@@ -340,6 +340,10 @@ def test_dp_step_bf16_at_224_against_oracle(cuda):
     x = torch.randn(batch, 3, size, size, generator=g)
     y = torch.randint(0, 3, (batch,), generator=g)
     eng.forward(x.to(cuda))
+    # at batch 16 every layer's per-sample tiles would fit the keep budget; keep what a batch-256 step keeps (stem,
+    # layer1, layer2) so that layer3 / layer4 take the norm-pass kernels the benchmark runs
+    for k in [k for k in eng._dp_keep_buffers() if k.startswith(("layer3", "layer4"))]:
+        del eng._dp_keep[k]
     kern = _norm_pass_kernels(eng)
     assert kern["conv1"] == "kept" and all(kern[f"layer{l}.{b}.conv{c}"] == "kept" for l in (1, 2) for b in (0, 1)
                                            for c in (1, 2) if (l, b, c) != (2, 0, 1)), kern

@@ -937,63 +937,6 @@ def test_conv_dgrad_pair_matches_two_passes(cuda, dtype, N, H, C, K):
         call("primia_conv2d_dgrad_pair", d1, dy1d, w1d, d1, dydd, wdd, dx, dt)
 
 
-@pytest.mark.parametrize("N,H,C,K,acc", [(2, 28, 128, 128, 0), (4, 14, 256, 256, 1), (5, 7, 512, 512, 0), (3, 10, 128, 256, 1)])
-def test_dgrad_emits_batchnorm_backward_sums(cuda, N, H, C, K, acc):
-    """primia_conv2d_dgrad_bnsums + primia_bn_bwd_from_sums == primia_conv2d_dgrad + the BatchNorm backward with its
-    own reduction pass: dx bit-identical, dy / dgamma / dbeta equal up to the summation order.  acc = 0: bn1 form
-    (ReLU mask recomputed from y); acc = 1: bn2 form (accumulating data gradient, 1-bit mask from the forward pass)."""
-    dtype = torch.bfloat16
-    dt = _lib.dtype_code(dtype)
-    g = torch.Generator().manual_seed(7 * H + C)
-    desc = ConvDesc.make(N, H, H, C, K, 3, 3, 1, 1)
-    slots = query("primia_conv_dgrad_bnsum_slots", desc, dt)
-    M = N * H * H
-    assert slots == (M + 223) // 224      # 224-pixel tiles (conv3x3_lh.hip)
-    w = rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype)
-    _, wd = prep_weights(desc, w, dtype, cuda, C)
-    dyc = to_nhwc(rnd(torch.randn(N, K, H, H, generator=g), dtype), dtype, cuda)          # gradient entering the conv
-    y = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * 1.5 + 0.3, dtype), dtype, cuda)  # the BatchNorm's input
-    base = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
-    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(cuda), (torch.randn(C, generator=g) * 0.3).to(cuda)
-    ws_bytes = query("primia_bn_workspace_bytes", M, C)
-    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=cuda)
-    rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
-    sm, si, z = torch.empty(C, device=cuda), torch.empty(C, device=cuda), torch.empty_like(y)
-    mask = torch.empty(M * C // 8, dtype=torch.uint8, device=cuda)
-    if acc:   # residual form: z = relu(bn(y) + res), mask bits written by the forward pass
-        res = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
-        call("primia_bn_fwd_train_mask", y, res, z, mask, gamma, beta, rm, rv, sm, si, None, 0, M, C, 1e-5, 0.1, ws,
-             ws_bytes, dt)
-    else:
-        call("primia_bn_fwd_train", y, None, z, gamma, beta, rm, rv, sm, si, M, C, 1e-5, 0.1, 1, ws, ws_bytes, dt)
-
-    def run(fused):
-        dx = base.clone() if acc else torch.empty_like(base)
-        dyb, gout = torch.empty_like(y), (torch.empty_like(y) if acc else None)
-        dga, dbe = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
-        if fused:
-            sums = torch.full((slots, 2, C), float("nan"), device=cuda)
-            call("primia_conv2d_dgrad_bnsums", desc, dyc, wd, dx, acc, y, mask if acc else None, gamma, beta, sm, si, sums, dt)
-            call("primia_bn_bwd_from_sums", y, mask if acc else None, dx, dyb, gout, gamma, beta, sm, si, dga, dbe, sums,
-                 slots, M, C, dt)
-        else:
-            call("primia_conv2d_dgrad", desc, dyc, wd, dx, acc, dt)
-            if acc:
-                call("primia_bn_bwd_mask", y, mask, dx, dyb, gout, gamma, sm, si, dga, dbe, M, C, ws, ws_bytes, dt)
-            else:
-                call("primia_bn_relu_bwd", y, dx, dyb, gamma, beta, sm, si, dga, dbe, M, C, ws, ws_bytes, dt)
-        return dx, dyb, gout, dga, dbe
-
-    a, b = run(False), run(True)
-    assert torch.equal(a[0], b[0])
-    if acc:
-        assert torch.equal(a[2], b[2])
-    assert relerr(b[3], a[3]) < 1e-4 and relerr(b[4], a[4]) < 1e-4
-    assert relerr(b[1], a[1]) < 1e-3   # bf16 outputs: a 1-ulp flip where the sums differ in the last bits
-    c = run(True)
-    assert all(torch.equal(u, v) for u, v in zip(b, c) if u is not None)
-
-
 @pytest.mark.parametrize("N,H,C", [(2, 16, 64), (1, 56, 64), (2, 28, 128), (4, 14, 256), (5, 7, 512)])
 def test_dgrad_masked_accumulate(cuda, N, H, C):
     """primia_conv2d_dgrad_masked_acc: dx = relu_mask(dx) + dgrad(dy), bit-identical to masking dx first and then
@@ -1089,38 +1032,3 @@ def test_batchnorm_forward_pair_is_bit_identical(cuda, dtype, N, H, C):
         assert torch.equal(a, b)
 
 
-def test_all_stride1_layers_share_one_weight_gradient_launch(cuda):
-    """primia_conv2d_wgrad_multi_ws: layers of DIFFERENT shapes in one launch (block ranges per layer, each layer its own
-    slab region and ordered reduce) against single calls, and bit-identical run after run."""
-    import ctypes
-    dtype = torch.bfloat16
-    dt = _lib.dtype_code(dtype)
-    N = 16
-    shapes = [(56, 64), (56, 64), (28, 128), (14, 256), (14, 256), (7, 512)]
-    descs = [ConvDesc.make(N, H, H, C, C, 3, 3, 1, 1) for H, C in shapes]
-    shares = [query("primia_conv_wgrad_multi_ws_bytes", d, dt) for d in descs]
-    assert all(s > 0 for s in shares)
-    g = torch.Generator().manual_seed(77)
-    xs = [to_nhwc(rnd(torch.randn(N, C, H, H, generator=g).relu(), dtype), dtype, cuda) for H, C in shapes]
-    dys = [to_nhwc(rnd(torch.randn(N, C, H, H, generator=g) * 1e-2, dtype), dtype, cuda) for H, C in shapes]
-    nes = [query("primia_conv_wfwd_elems", d) for d in descs]
-    n = len(shapes)
-    arr = ctypes.c_void_p * n
-
-    def multi():
-        ws = torch.full((sum(shares) // 4,), float("nan"), device=cuda)
-        accs = [torch.full((ne,), float("nan"), device=cuda) for ne in nes]
-        call("primia_conv2d_wgrad_multi_ws", n, arr(*[ctypes.addressof(d) for d in descs]),
-             arr(*[t.data_ptr() for t in xs]), arr(*[t.data_ptr() for t in dys]), arr(*[t.data_ptr() for t in accs]),
-             ws, sum(shares), dt)
-        torch.cuda.synchronize()
-        return accs
-
-    a, b = multi(), multi()
-    for i, d in enumerate(descs):
-        assert torch.equal(a[i], b[i])
-        s1 = query("primia_conv_wgrad_ws_bytes", d, dt)
-        w1 = torch.empty(max(s1, 16) // 4, device=cuda)
-        single = torch.zeros(nes[i], device=cuda)
-        call("primia_conv2d_wgrad_ws", d, xs[i], dys[i], single, w1, s1, dt)
-        assert relerr(a[i], single) < 2e-6, i

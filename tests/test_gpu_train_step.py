@@ -371,7 +371,7 @@ def test_full_size_forward_and_step_are_repeatable(cuda):
 
 @pytest.mark.parametrize("batch,size", [(16, 64), (64, 224)])
 def test_weight_gradients_on_a_second_stream_give_the_same_bits(cuda, batch, size):
-    """engine.wgrad_overlap (PRIMIA_WGRAD_OVERLAP): the weight gradients are leaves of the backward graph, so they may
+    """engine.wgrad_overlap: the weight gradients are leaves of the backward graph, so they may
     run on a second stream (1: beside the BatchNorm chain, joined before the next data gradient; 2: free-running until
     the finalize).  Same kernels on the same operands: weights, gradients and loss after three steps are bit-equal to
     the one-stream schedule."""

@@ -39,7 +39,7 @@ for name, H, C, K, R, s, p, cnt in layers:
     wf = torch.empty(query("primia_conv_wfwd_elems", d), dtype=dtype, device=dev)
     wd = torch.empty(query("primia_conv_wdgrad_elems", d), dtype=dtype, device=dev) if name != "stem" else None
     call("primia_conv_weight_prepare", d, creal, w, wf, wd, dt)
-    acc = torch.zeros(max(query("primia_conv_wfwd_elems", d), 300 * 36864 if os.environ.get("PRIMIA_WGP_NOEPI") == "16" else 0), dtype=torch.float32, device=dev)
+    acc = torch.zeros(query("primia_conv_wfwd_elems", d), dtype=torch.float32, device=dev)
     fl = 2.0 * N * d.Ho * d.Wo * K * creal * R * R
     if name == "stem" and dtype == torch.bfloat16:   # the padded-input stem kernels the engine uses
         xp = torch.zeros(N * (H + 6) * (H + 8), 4, dtype=dtype, device=dev)
