@@ -293,7 +293,20 @@ int primia_image_prepare(const uint8_t* src, int Hin, int Win, int C, int R, int
  *   primia_clahe_u8              a.CLAHE(clip_limit, tile grid 8 x 8): OpenCV's algorithm on the plane (C = 1) or on L of
  *                                CIE L*a*b* (C = 3); workspace = primia_clahe_workspace_bytes.  in-place allowed.
  *   primia_image_lut_u8          cv2.LUT with the 256-entry table albumentations builds (RandomGamma, RandomBrightness).
- *   primia_image_box_blur_u8     a.Blur -> cv2.blur(k, k), BORDER_REFLECT_101.  out != in.
+ *   primia_image_box_blur_u8     a.Blur -> cv2.blur(k, k), BORDER_REFLECT_101, anchor k / 2 (any k <= 63).  out != in.
+ *   primia_image_remap_u8        cv2.remap(INTER_LINEAR, BORDER_REFLECT_101) with float32 coordinate maps [H][W]: the
+ *                                sampling pass of a.ElasticTransform / a.OpticalDistortion / a.GridDistortion
+ *                                (torchlib/dataloader.py:167-172; albumentations 0.4.6 functional.py).  out != src.
+ *   primia_warp_map_affine       maps of cv2.warpAffine from the INVERSE 2 x 3 matrix (ElasticTransform's first stage).
+ *   primia_warp_map_optical      cv2.initUndistortRectifyMap(camera (fx, fy, cx, cy), distortion (k, k, 0, 0, 0), new
+ *                                camera (fx, fy, new_cx, new_cy)) — F.optical_distortion.
+ *   primia_warp_map_grid         meshgrid(xx[W], yy[H]) — F.grid_distortion's piecewise-linear axes (built by the host).
+ *   primia_warp_map_elastic      (x + dx, y + dy) with d = gaussian_filter(2 field - 1, sigma) * alpha: F.elastic_transform's
+ *                                second stage from the two uniform [0, 1) fields of numpy's RandomState (float64 [H][W]);
+ *                                workspace >= 16 H W bytes.
+ *   primia_image_fog_u8          F.add_fog's haze discs: per (x, y) of haze_xy a white disc of radius hw / 2 centred at
+ *                                (x + hw / 2, y + hw / 2) blended with cv2.addWeighted(alpha); follow with
+ *                                primia_image_box_blur_u8(hw / 10).  a.RandomFog, torchlib/dataloader.py:188-189.
  *   primia_image_add_noise_u8    a.GaussNoise: uint8(clip(img + noise, 0, 255)), noise fp32 per element.
  *   primia_image_finish          a.ToFloat(255) -> a.Normalize(mean, std, 1.0): uint8 HWC -> fp32 [C][S][S]. */
 int primia_image_affine_u8(const uint8_t* src, int H, int W, int C, float a, float b, float c, float d, float e, float f,
@@ -305,6 +318,19 @@ int primia_clahe_u8(const uint8_t* img, int H, int W, int C, float clip_limit, v
                     uint8_t* out, primia_stream_t stream);
 int primia_image_lut_u8(const uint8_t* in, int64_t n, const uint8_t* table256, uint8_t* out, primia_stream_t stream);
 int primia_image_box_blur_u8(const uint8_t* in, int H, int W, int C, int k, uint8_t* out, primia_stream_t stream);
+int primia_image_remap_u8(const uint8_t* src, int H, int W, int C, const float* map_x, const float* map_y, uint8_t* out,
+                          primia_stream_t stream);
+int primia_warp_map_affine(int H, int W, double a, double b, double c, double d, double e, double f, float* map_x,
+                           float* map_y, primia_stream_t stream);
+int primia_warp_map_optical(int H, int W, double k, double fx, double fy, double cx, double cy, double new_cx,
+                            double new_cy, float* map_x, float* map_y, primia_stream_t stream);
+int primia_warp_map_grid(int H, int W, const float* xx, const float* yy, float* map_x, float* map_y,
+                         primia_stream_t stream);
+int primia_warp_map_elastic(int H, int W, const double* field_x, const double* field_y, double sigma, double alpha,
+                            void* workspace, int64_t workspace_bytes, float* map_x, float* map_y,
+                            primia_stream_t stream);
+int primia_image_fog_u8(const uint8_t* in, int H, int W, int C, const int32_t* haze_xy, int n_haze, int hw, float alpha,
+                        uint8_t* out, primia_stream_t stream);
 int primia_image_add_noise_u8(const uint8_t* in, const float* noise, int64_t n, uint8_t* out, primia_stream_t stream);
 int primia_image_finish(const uint8_t* in, int S, int C, const float* mean, const float* std, float* out,
                         primia_stream_t stream);

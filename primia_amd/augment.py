@@ -6,11 +6,17 @@ image arithmetic on the GPU (csrc/augment.hip) and the random PARAMETERS drawn o
     a.Compose([a.VerticalFlip, a.RandomGamma, a.RandomBrightness, a.Blur, ..., a.GaussNoise], p = albu_prob)
     a.ToFloat(255) -> a.Normalize(mean, std, 1.0)
 
-Built: RandomAffine, Resize, RandomCrop, CLAHE, VerticalFlip, RandomGamma, RandomBrightness, Blur, GaussNoise, ToFloat,
-Normalize.  NOT built (warping / synthetic-weather transforms of albumentations): elastic, optical_distortion,
-grid_distortion, grid_shuffle, hsv, invert, cutout, shadow, fog, sun_flare, solarize, equalize, grid_dropout — a
-configuration that enables one of them is REFUSED (`unsupported(args)`), unless PRIMIA_SKIP_UNSUPPORTED_AUG=1 asks to
-train without them (a warning names what was dropped).
+Built: RandomAffine, Resize, RandomCrop, CLAHE, VerticalFlip, RandomGamma, RandomBrightness, Blur, ElasticTransform,
+OpticalDistortion, GridDistortion, RandomFog, GaussNoise, ToFloat, Normalize — every member the reference's shipped
+preset (configs/torch/pneumonia-resnet-pretrained.ini) switches on.  NOT built: grid_shuffle, hsv, invert, cutout,
+shadow, sun_flare, solarize, equalize, grid_dropout (all `no` in the shipped presets) — a configuration that enables one
+of them is REFUSED (`unsupported(args)`), unless PRIMIA_SKIP_UNSUPPORTED_AUG=1 asks to train without them (a warning
+names what was dropped).
+
+The three warping transforms are `cv2.remap` with a generated coordinate field (albumentations 0.4.6, the release the
+reference pins: functional.py elastic_transform / optical_distortion / grid_distortion): the host draws their few
+parameters (ElasticTransform: a seed for numpy's RandomState, whose two uniform fields are the only bulk data that
+crosses to the device), the maps are formed and sampled on the GPU (primia_warp_map_*, primia_image_remap_u8).
 
 Draw order (Python's `random`, as torchvision's RandomAffine.get_params and albumentations' BasicTransform.__call__ use
 it): affine angle, [translate x, y], scale, shear; crop h, w; Compose coin; then per enabled transform its own coin and,
@@ -27,8 +33,7 @@ import torch
 
 from ._lib import call, query
 
-UNBUILT = ("elastic", "optical_distortion", "grid_distortion", "grid_shuffle", "hsv", "invert", "cutout", "shadow", "fog",
-           "sun_flare", "solarize", "equalize", "grid_dropout")
+UNBUILT = ("grid_shuffle", "hsv", "invert", "cutout", "shadow", "sun_flare", "solarize", "equalize", "grid_dropout")
 
 
 def unsupported(args):
@@ -75,6 +80,58 @@ def brightness_table(alpha, beta):
     return np.clip(lut, 0, 255).astype(np.uint8)
 
 
+def affine_from_points(pts1, pts2):
+    """cv2.getAffineTransform: the 2 x 3 float64 matrix mapping the three points pts1 onto pts2."""
+    a = np.zeros((6, 6), np.float64)
+    b = np.zeros(6, np.float64)
+    for i in range(3):
+        x, y = float(pts1[i][0]), float(pts1[i][1])
+        a[2 * i] = [x, y, 1, 0, 0, 0]
+        a[2 * i + 1] = [0, 0, 0, x, y, 1]
+        b[2 * i], b[2 * i + 1] = float(pts2[i][0]), float(pts2[i][1])
+    return np.linalg.solve(a, b).reshape(2, 3)
+
+
+def invert_affine(m):
+    """cv2.invertAffineTransform (warpAffine samples the source through the inverse)."""
+    d = m[0, 0] * m[1, 1] - m[0, 1] * m[1, 0]
+    d = 1.0 / d if d != 0 else 0.0
+    a11, a22, a12, a21 = m[1, 1] * d, m[0, 0] * d, -m[0, 1] * d, -m[1, 0] * d
+    return np.array([[a11, a12, -a11 * m[0, 2] - a12 * m[1, 2]], [a21, a22, -a21 * m[0, 2] - a22 * m[1, 2]]], np.float64)
+
+
+def grid_axis(n, num_steps, steps):
+    """One axis of albumentations' F.grid_distortion: float32 source positions of n pixels."""
+    step = n // num_steps
+    xx = np.zeros(n, np.float32)
+    prev = 0
+    for idx, x in enumerate(range(0, n, step)):
+        start, end = x, x + step
+        if end > n:
+            end, cur = n, n
+        else:
+            cur = prev + step * steps[idx]
+        xx[start:end] = np.linspace(prev, cur, end - start)
+        prev = cur
+    return xx
+
+
+def fog_params(H, W, rng, fog_coef_lower=0.3, fog_coef_upper=1.0):
+    """RandomFog.get_params_dependent_on_targets: fog_coef and the haze points, from Python's `random` stream."""
+    fog_coef = rng.uniform(fog_coef_lower, fog_coef_upper)
+    hw = max(1, int(W // 3 * fog_coef))
+    haze = []
+    midx, midy = W // 2 - 2 * hw, H // 2 - hw
+    index = 1
+    while midx > -hw or midy > -hw:
+        for _ in range(hw // 10 * index):
+            haze.append((rng.randint(midx, W - midx - hw), rng.randint(midy, H - midy - hw)))
+        midx -= 3 * hw * W // (H + W)
+        midy -= 3 * hw * H // (H + W)
+        index += 1
+    return fog_coef, haze
+
+
 class TrainTransform:
     """create_albu_transform(args, mean, std) for device-resident uint8 HWC images: `tf(img, rng) -> fp32 [C, S, S]`."""
 
@@ -84,7 +141,8 @@ class TrainTransform:
 
         # (keys a hand-built `args` may lack count as switched off, like an INI with every probability at zero)
         keys = dict(rotation=0.0, translate=0.0, scale=0.0, shear=0.0, albu_prob=0.0, individual_albu_probs=0.0,
-                    noise_std=0.0, noise_prob=0.0, clahe=False, randomgamma=False, randombrightness=False, blur=False)
+                    noise_std=0.0, noise_prob=0.0, clahe=False, randomgamma=False, randombrightness=False, blur=False,
+                    elastic=False, optical_distortion=False, grid_distortion=False, fog=False)
         self.cfg = SimpleNamespace(inference_resolution=args.inference_resolution, train_resolution=args.train_resolution,
                                    **{k: getattr(args, k, v) for k, v in keys.items()})
         self.device, self.C = torch.device(device), channels
@@ -94,6 +152,66 @@ class TrainTransform:
         S = args.train_resolution
         self.ws_bytes = query("primia_clahe_workspace_bytes", S, S, channels)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=self.device)
+        # coordinate maps and the elastic workspace (float64 plane + two float32 planes), built once
+        self.map_x = torch.empty(S, S, dtype=torch.float32, device=self.device)
+        self.map_y = torch.empty(S, S, dtype=torch.float32, device=self.device)
+        self.warp_ws = torch.empty(S * S * 16, dtype=torch.uint8, device=self.device)
+        if self.cfg.fog and channels != 3:
+            raise AssertionError("RandomFog needs 3 channels")          # torchlib/dataloader.py:188
+
+    def _remap(self, cur):
+        out = torch.empty_like(cur)
+        S = cur.shape[0]
+        call("primia_image_remap_u8", cur, S, S, self.C, self.map_x, self.map_y, out)
+        return out
+
+    def elastic(self, cur, seed, alpha=1.0, sigma=50.0, alpha_affine=50.0):
+        """a.ElasticTransform().apply(img, random_state=seed) (F.elastic_transform, approximate=False)."""
+        S, dev = cur.shape[0], self.device
+        rs = np.random.RandomState(seed)
+        center_square = np.float32((S, S)) // 2
+        square_size = min((S, S)) // 3
+        pts1 = np.float32([center_square + square_size, [center_square[0] + square_size, center_square[1] - square_size],
+                           center_square - square_size])
+        pts2 = pts1 + rs.uniform(-alpha_affine, alpha_affine, size=pts1.shape).astype(np.float32)
+        inv = invert_affine(affine_from_points(pts1, pts2))
+        call("primia_warp_map_affine", S, S, *[float(v) for v in inv.reshape(-1)], self.map_x, self.map_y)
+        cur = self._remap(cur)
+        fx = torch.from_numpy(rs.rand(S, S)).to(dev)
+        fy = torch.from_numpy(rs.rand(S, S)).to(dev)
+        call("primia_warp_map_elastic", S, S, fx, fy, float(sigma), float(alpha), self.warp_ws, self.warp_ws.numel(),
+             self.map_x, self.map_y)
+        return self._remap(cur)
+
+    def optical(self, cur, k, dx, dy):
+        """F.optical_distortion (albumentations 0.4.6: fx = fy = width)."""
+        S = cur.shape[0]
+        call("primia_warp_map_optical", S, S, float(np.float32(k)), float(S), float(S), S * 0.5 + dx, S * 0.5 + dy,
+             (S - 1) * 0.5, (S - 1) * 0.5, self.map_x, self.map_y)
+        return self._remap(cur)
+
+    def grid(self, cur, xsteps, ysteps, num_steps=5):
+        """F.grid_distortion: piecewise-linear axes (host, a few hundred values), meshgrid + remap on the device."""
+        S, dev = cur.shape[0], self.device
+        xx = torch.from_numpy(grid_axis(S, num_steps, xsteps)).to(dev)
+        yy = torch.from_numpy(grid_axis(S, num_steps, ysteps)).to(dev)
+        call("primia_warp_map_grid", S, S, xx, yy, self.map_x, self.map_y)
+        return self._remap(cur)
+
+    def fog(self, cur, fog_coef, haze_list, alpha_coef=0.08):
+        """F.add_fog: haze discs blended in list order, then cv2.blur(hw // 10)."""
+        S, dev = cur.shape[0], self.device
+        hw = max(int(S // 3 * fog_coef), 10)
+        hz = torch.tensor(haze_list, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev)
+        out = torch.empty_like(cur)
+        call("primia_image_fog_u8", cur, S, S, self.C, hz if len(haze_list) else None, len(haze_list), hw,
+             float(np.float32(alpha_coef * fog_coef)), out)
+        k = hw // 10
+        if k <= 1:
+            return out
+        blurred = torch.empty_like(out)
+        call("primia_image_box_blur_u8", out, S, S, self.C, k, blurred)
+        return blurred
 
     def __call__(self, img, rng, augment=True):
         dev, C = self.device, self.C
@@ -133,6 +251,19 @@ class TrainTransform:
                 out = torch.empty_like(cur)
                 call("primia_image_box_blur_u8", cur, S, S, C, k, out)
                 cur = out
+            if a.elastic and rng.random() < p:                      # get_params: random.randint(0, 10000)
+                cur = self.elastic(cur, rng.randint(0, 10000))
+            if a.optical_distortion and rng.random() < p:           # distort_limit 0.05, shift_limit 0.05
+                k = rng.uniform(-0.05, 0.05)
+                dx, dy = round(rng.uniform(-0.05, 0.05)), round(rng.uniform(-0.05, 0.05))
+                cur = self.optical(cur, k, dx, dy)
+            if a.grid_distortion and rng.random() < p:              # num_steps 5, distort_limit 0.3
+                xsteps = [1 + rng.uniform(-0.3, 0.3) for _ in range(6)]
+                ysteps = [1 + rng.uniform(-0.3, 0.3) for _ in range(6)]
+                cur = self.grid(cur, xsteps, ysteps)
+            if a.fog and rng.random() < p:                          # fog_coef (0.3, 1), alpha_coef 0.08
+                fog_coef, haze = fog_params(S, S, rng)
+                cur = self.fog(cur, fog_coef, haze)
             if rng.random() < a.noise_prob:                                            # a.GaussNoise(var_limit = noise_std^2)
                 var = rng.uniform(0.0, a.noise_std ** 2)
                 noise = torch.randn(cur.numel(), generator=self.gen, device=dev) * (var ** 0.5)

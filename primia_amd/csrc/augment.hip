@@ -183,14 +183,117 @@ __global__ __launch_bounds__(256) void box_blur_u8_kernel(const uint8_t* __restr
                                                           uint8_t* __restrict__ out) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= H * W) return;
-    const int y = idx / W, x = idx - y * W, r = k / 2;
+    const int y = idx / W, x = idx - y * W, a = k / 2;      // window [p - k / 2, p - k / 2 + k - 1]: cv2's default anchor
     for (int c = 0; c < C; ++c) {
         int s = 0;
-        for (int dy = -r; dy <= r; ++dy)
-            for (int dx = -r; dx <= r; ++dx)
+        for (int dy = -a; dy < k - a; ++dy)
+            for (int dx = -a; dx < k - a; ++dx)
                 s += in[((long)reflect101(y + dy, H) * W + reflect101(x + dx, W)) * C + c];
         out[(long)idx * C + c] = sat_u8((float)s / (float)(k * k));
     }
+}
+
+// ---- the warping transforms of albumentations 0.4.6 (ElasticTransform, OpticalDistortion, GridDistortion) ----------
+// All three are cv2.remap(img, map_x, map_y, INTER_LINEAR, BORDER_REFLECT_101) with a generated coordinate field
+// (torchlib/dataloader.py:167-172): the maps are formed on the device from the few parameters the host draws, one remap
+// kernel samples them.  Bilinear weights in fp32, result rounded to nearest even (cv2's 8-bit path uses 5-bit fixed-point
+// coordinates: unpinned, see oracle/augment_oracle.py).
+__global__ __launch_bounds__(256) void remap_u8_kernel(const uint8_t* __restrict__ src, int H, int W, int C,
+                                                       const float* __restrict__ mx, const float* __restrict__ my,
+                                                       uint8_t* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const float x = mx[idx], y = my[idx];
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f;
+    // (coordinates far outside the image — a degenerate affine draw — are clamped before the integer conversion; the
+    // reflection below is periodic, so the clamp only has to keep the value representable)
+    const int x0 = (int)fminf(fmaxf(x0f, -1.0e6f), 1.0e6f), y0 = (int)fminf(fmaxf(y0f, -1.0e6f), 1.0e6f);
+    const int xa = reflect101(x0, W), xb = reflect101(x0 + 1, W), ya = reflect101(y0, H), yb = reflect101(y0 + 1, H);
+    for (int c = 0; c < C; ++c) {
+        const float p00 = src[((long)ya * W + xa) * C + c], p01 = src[((long)ya * W + xb) * C + c];
+        const float p10 = src[((long)yb * W + xa) * C + c], p11 = src[((long)yb * W + xb) * C + c];
+        const float top = p00 * (1.f - fx) + p01 * fx, bot = p10 * (1.f - fx) + p11 * fx;
+        out[(long)idx * C + c] = sat_u8(top * (1.f - fy) + bot * fy);
+    }
+}
+
+// kind 0: affine  (p = inverse matrix a b c d e f: source = (a x + b y + c, d x + e y + f)), cv2.warpAffine
+// kind 1: optical (p = k, fx, fy, cx, cy, ncx, ncy): cv2.initUndistortRectifyMap with distortion (k, k, 0, 0, 0)
+__global__ __launch_bounds__(256) void warp_map_kernel(int H, int W, int kind, double p0, double p1, double p2, double p3,
+                                                       double p4, double p5, double p6, float* __restrict__ mx,
+                                                       float* __restrict__ my) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const double y = idx / W, x = idx - (idx / W) * W;
+    if (kind == 0) {
+        mx[idx] = (float)(p0 * x + p1 * y + p2);
+        my[idx] = (float)(p3 * x + p4 * y + p5);
+    } else {
+        const double u = (x - p5) / p1, v = (y - p6) / p2;
+        const double r2 = u * u + v * v;
+        const double kr = 1.0 + p0 * r2 + p0 * r2 * r2;
+        mx[idx] = (float)(p1 * (u * kr) + p3);
+        my[idx] = (float)(p2 * (v * kr) + p4);
+    }
+}
+
+// GridDistortion: map_x, map_y = meshgrid(xx, yy)  |  ElasticTransform: map = float32(index + displacement)
+__global__ __launch_bounds__(256) void grid_map_kernel(int H, int W, const float* __restrict__ xx, const float* __restrict__ yy,
+                                                       const float* __restrict__ dx, const float* __restrict__ dy,
+                                                       float* __restrict__ mx, float* __restrict__ my) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W;
+    mx[idx] = xx ? xx[x] : (float)x + dx[idx];
+    my[idx] = yy ? yy[y] : (float)y + dy[idx];
+}
+
+// scipy.ndimage.gaussian_filter's 1-D pass (correlate1d, mode "reflect": d c b a | a b c d | d c b a), float64, on
+// u = 2 r - 1 of a uniform field r (first pass) or on the first pass's output; `scale`: factor applied to the result
+// (alpha after the second pass), which is stored as float32 when `out32` is given.
+__global__ __launch_bounds__(256) void gauss1d_kernel(const double* __restrict__ in, int H, int W, int axis, double sigma,
+                                                      int radius, int affine_in, double scale, double* __restrict__ out,
+                                                      float* __restrict__ out32) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W;
+    const int n = axis == 0 ? H : W, p = axis == 0 ? y : x;
+    double wsum = 0.0;
+    for (int t = -radius; t <= radius; ++t) wsum += exp(-0.5 / (sigma * sigma) * (double)t * (double)t);
+    double acc = 0.0;
+    for (int t = -radius; t <= radius; ++t) {
+        int q = p + t;
+        const int period = 2 * n;                      // half-sample symmetric reflection
+        q %= period;
+        if (q < 0) q += period;
+        if (q >= n) q = period - 1 - q;
+        double v = in[axis == 0 ? (long)q * W + x : (long)y * W + q];
+        if (affine_in) v = v * 2.0 - 1.0;
+        acc += v * (exp(-0.5 / (sigma * sigma) * (double)t * (double)t) / wsum);
+    }
+    acc *= scale;
+    if (out32) out32[idx] = (float)acc;
+    else out[idx] = acc;
+}
+
+// ---- RandomFog (F.add_fog): per haze point a white disc of radius hw / 2 blended in with cv2.addWeighted(alpha) ---------
+// sequentially (a pixel covered by m discs is blended m times, in list order); the cv2.blur(hw / 10) that follows is
+// primia_image_box_blur_u8.
+__global__ __launch_bounds__(256) void fog_u8_kernel(const uint8_t* __restrict__ in, int H, int W, int C,
+                                                     const int* __restrict__ haze, int n, int hw, float alpha, float beta,
+                                                     uint8_t* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W, rad = hw / 2;
+    float v[3];
+    for (int c = 0; c < C; ++c) v[c] = in[(long)idx * C + c];
+    for (int i = 0; i < n; ++i) {
+        const int dx = x - (haze[2 * i] + hw / 2), dy = y - (haze[2 * i + 1] + hw / 2);
+        if (dx * dx + dy * dy <= rad * rad)
+            for (int c = 0; c < C; ++c) v[c] = fminf(fmaxf(rintf(255.f * alpha + v[c] * beta), 0.f), 255.f);
+    }
+    for (int c = 0; c < C; ++c) out[(long)idx * C + c] = (uint8_t)v[c];
 }
 
 // ---- GaussNoise: image + noise (fp32, given), clipped to [0, 255], cast to uint8 (truncation, as ndarray.astype) -----
@@ -271,8 +374,64 @@ int primia_image_lut_u8(const uint8_t* in, int64_t n, const uint8_t* table256, u
 }
 
 int primia_image_box_blur_u8(const uint8_t* in, int H, int W, int C, int k, uint8_t* out, primia_stream_t st) {
-    PRIMIA_REQUIRE(in && out && in != out && H > 0 && W > 0 && (C == 1 || C == 3) && k >= 1 && (k & 1) && k <= 15);
+    PRIMIA_REQUIRE(in && out && in != out && H > 0 && W > 0 && (C == 1 || C == 3) && k >= 1 && k <= 63);
     box_blur_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(in, H, W, C, k, out);
+    return launch_status();
+}
+
+int primia_image_remap_u8(const uint8_t* src, int H, int W, int C, const float* map_x, const float* map_y, uint8_t* out,
+                          primia_stream_t st) {
+    PRIMIA_REQUIRE(src && out && src != out && map_x && map_y && H > 0 && W > 0 && (C == 1 || C == 3));
+    remap_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(src, H, W, C, map_x, map_y, out);
+    return launch_status();
+}
+
+int primia_warp_map_affine(int H, int W, double a, double b, double c, double d, double e, double f, float* map_x,
+                           float* map_y, primia_stream_t st) {
+    PRIMIA_REQUIRE(map_x && map_y && H > 0 && W > 0);
+    warp_map_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(H, W, 0, a, b, c, d, e, f, 0.0, map_x, map_y);
+    return launch_status();
+}
+
+int primia_warp_map_optical(int H, int W, double k, double fx, double fy, double cx, double cy, double new_cx,
+                            double new_cy, float* map_x, float* map_y, primia_stream_t st) {
+    PRIMIA_REQUIRE(map_x && map_y && H > 0 && W > 0 && fx != 0.0 && fy != 0.0);
+    warp_map_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(H, W, 1, k, fx, fy, cx, cy, new_cx, new_cy, map_x,
+                                                                              map_y);
+    return launch_status();
+}
+
+int primia_warp_map_grid(int H, int W, const float* xx, const float* yy, float* map_x, float* map_y, primia_stream_t st) {
+    PRIMIA_REQUIRE(xx && yy && map_x && map_y && H > 0 && W > 0);
+    grid_map_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(H, W, xx, yy, nullptr, nullptr, map_x, map_y);
+    return launch_status();
+}
+
+int primia_warp_map_elastic(int H, int W, const double* field_x, const double* field_y, double sigma, double alpha,
+                            void* workspace, int64_t workspace_bytes, float* map_x, float* map_y, primia_stream_t st) {
+    PRIMIA_REQUIRE(field_x && field_y && workspace && map_x && map_y && H > 0 && W > 0 && sigma > 0.0);
+    // workspace: one float64 plane (first pass) + two float32 planes (the displacements)
+    const int64_t need = (int64_t)H * W * (8 + 4 + 4);
+    if (workspace_bytes < need) return PRIMIA_ERR_WORKSPACE;
+    double* tmp = (double*)workspace;
+    float* dx = (float*)(tmp + (long)H * W);
+    float* dy = dx + (long)H * W;
+    const int radius = (int)(4.0 * sigma + 0.5);          // scipy: truncate = 4.0
+    const unsigned grid = ceil_div((long)H * W, 256);
+    hipStream_t s = (hipStream_t)st;
+    gauss1d_kernel<<<grid, 256, 0, s>>>(field_x, H, W, 0, sigma, radius, 1, 1.0, tmp, nullptr);
+    gauss1d_kernel<<<grid, 256, 0, s>>>(tmp, H, W, 1, sigma, radius, 0, alpha, nullptr, dx);
+    gauss1d_kernel<<<grid, 256, 0, s>>>(field_y, H, W, 0, sigma, radius, 1, 1.0, tmp, nullptr);
+    gauss1d_kernel<<<grid, 256, 0, s>>>(tmp, H, W, 1, sigma, radius, 0, alpha, nullptr, dy);
+    grid_map_kernel<<<grid, 256, 0, s>>>(H, W, nullptr, nullptr, dx, dy, map_x, map_y);
+    return launch_status();
+}
+
+int primia_image_fog_u8(const uint8_t* in, int H, int W, int C, const int32_t* haze_xy, int n_haze, int hw, float alpha,
+                        uint8_t* out, primia_stream_t st) {
+    PRIMIA_REQUIRE(in && out && H > 0 && W > 0 && (C == 1 || C == 3) && n_haze >= 0 && (haze_xy || n_haze == 0) && hw >= 1);
+    fog_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(in, H, W, C, (const int*)haze_xy, n_haze, hw, alpha,
+                                                                          1.f - alpha, out);
     return launch_status();
 }
 

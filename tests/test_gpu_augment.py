@@ -107,5 +107,78 @@ def test_transform_chain_draws_and_refuses_unbuilt_transforms(cuda):
     assert not torch.equal(a, c)
     plain = tf(img, random.Random(7), augment=False)
     assert torch.isfinite(plain).all()
-    with pytest.raises(SystemExit, match="elastic"):
-        TrainTransform(SimpleNamespace(**base, elastic=True, fog=True), mean, std, cuda, 3)
+    with pytest.raises(SystemExit, match="hsv"):
+        TrainTransform(SimpleNamespace(**base, hsv=True, elastic=True), mean, std, cuda, 3)
+    # the reference's shipped preset (elastic, optical_distortion, grid_distortion, fog = yes) is served
+    full = TrainTransform(SimpleNamespace(**base, elastic=True, optical_distortion=True, grid_distortion=True, fog=True),
+                          mean, std, cuda, 3, seed=3)
+    outs = [full(img, random.Random(s_)) for s_ in range(40)]          # p = 0.75 x 0.2 each: every transform fires
+    assert all(o.shape == (3, 64, 64) and torch.isfinite(o).all() for o in outs)
+
+
+def _u8(rng, H, W, C):
+    return img_of(rng, H, W, C)
+
+
+@pytest.mark.parametrize("S,C", [(64, 1), (224, 3), (96, 3)])
+def test_warping_transforms_match_the_oracle(cuda, S, C):
+    """ElasticTransform / OpticalDistortion / GridDistortion (albumentations 0.4.6 restated in oracle/augment_oracle.py):
+    the device-built coordinate maps against the oracle's, and the remapped images bit for bit where the maps agree (the
+    maps may differ in the last float32 bit where the device's fp64 Gaussian sums in another order than SciPy's)."""
+    from types import SimpleNamespace
+
+    from primia_amd.augment import TrainTransform
+
+    rng = np.random.default_rng(S + C)
+    img = _u8(rng, S, S, C)
+    d_img = dev(img, cuda)
+    tf = TrainTransform(SimpleNamespace(train_resolution=S, inference_resolution=S), None, None, cuda, C)
+    # remap on given maps: bit-exact
+    mx = (np.mgrid[0:S, 0:S][1] + rng.uniform(-3, 3, (S, S))).astype(np.float32)
+    my = (np.mgrid[0:S, 0:S][0] + rng.uniform(-3, 3, (S, S))).astype(np.float32)
+    mx[0, :4], my[:4, 0] = -7.25, S + 5.5          # far outside: reflected
+    out = torch.empty_like(d_img)
+    call("primia_image_remap_u8", d_img, S, S, C, dev(mx, cuda), dev(my, cuda), out)
+    assert np.array_equal(out.cpu().numpy(), A.remap_bilinear(img, mx, my))
+    # optical distortion: maps and image
+    for k, dx, dy in [(0.05, 0, 0), (-0.031, 0, 0), (0.0, 0, 0)]:
+        got = tf.optical(d_img, k, dx, dy).cpu().numpy()
+        wx, wy = A.optical_maps(S, S, k, dx, dy)
+        assert np.array_equal(tf.map_x.cpu().numpy(), wx) and np.array_equal(tf.map_y.cpu().numpy(), wy)
+        assert np.array_equal(got, A.optical_distortion(img, k, dx, dy))
+    # grid distortion
+    r = random.Random(S)
+    xs, ys = [1 + r.uniform(-0.3, 0.3) for _ in range(6)], [1 + r.uniform(-0.3, 0.3) for _ in range(6)]
+    assert np.array_equal(tf.grid(d_img, xs, ys).cpu().numpy(), A.grid_distortion(img, xs, ys))
+    # elastic: affine stage bit-exact, displacement fields to fp32 rounding, image within one grey level on a few pixels
+    for seed in (0, 1234, 9999):
+        got = tf.elastic(d_img, seed).cpu().numpy()
+        inv, dx, dy, _ = A.elastic_params(S, S, seed)
+        want_mx = np.float32(np.mgrid[0:S, 0:S][1] + dx)
+        assert np.abs(tf.map_x.cpu().numpy() - want_mx).max() <= 2e-5 * S
+        want = A.elastic_transform(img, seed)
+        diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
+        assert diff.max() <= 1 and (diff > 0).mean() < 2e-3, (diff.max(), (diff > 0).mean())
+        assert not np.array_equal(got, img)
+
+
+@pytest.mark.parametrize("S", [64, 224])
+def test_fog_matches_the_oracle(cuda, S):
+    from types import SimpleNamespace
+
+    from primia_amd.augment import TrainTransform, fog_params
+
+    rng = np.random.default_rng(S)
+    img = _u8(rng, S, S, 3)
+    tf = TrainTransform(SimpleNamespace(train_resolution=S, inference_resolution=S), None, None, cuda, 3)
+    for seed in (1, 2, 3):
+        fc, haze = fog_params(S, S, random.Random(seed))
+        fc2, haze2 = A.fog_params(S, S, random.Random(seed))
+        assert fc == fc2 and haze == haze2 and len(haze) > 0
+        got = tf.fog(dev(img, cuda), fc, haze).cpu().numpy()
+        assert np.array_equal(got, A.add_fog(img, fc, haze))
+        assert got.mean() > img.mean()            # fog brightens
+    for k in (2, 4, 6, 17):                       # even kernels: cv2's anchor k // 2
+        out = torch.empty(S, S, 3, dtype=torch.uint8, device=cuda)
+        call("primia_image_box_blur_u8", dev(img, cuda), S, S, 3, k, out)
+        assert np.array_equal(out.cpu().numpy(), A.box_blur_anchor(img, k)), k

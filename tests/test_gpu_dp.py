@@ -363,9 +363,10 @@ def test_dp_step_bf16_at_224_against_oracle(cuda):
     e16 = ((got_norms - norms16).abs() / norms16).max().item()
     o16 = ((norms16 - norms32).abs() / norms32).max().item()
     print(f"per-sample norms: engine vs fp32 oracle {e32:.3e}, vs bf16-storage oracle {e16:.3e}, oracle bf16 vs fp32 {o16:.3e}")
-    assert e16 < 2e-2 and e32 < max(3e-2, 2 * o16), (e16, e32, o16)
-    assert (clip32 < 1).any() or (clip16 < 1).any(), "test should exercise clipping"
-    assert torch.allclose(got_clip, clip16, rtol=2e-2) and torch.allclose(got_clip, clip32, rtol=max(3e-2, 2 * o16))
+    # measured on MI355X: 3.2e-3 / 1.8e-3 (the fp32 and the bf16-storage oracle are 2.6e-3 apart themselves)
+    assert e16 < 5e-3 and e32 < 5e-3, (e16, e32, o16)
+    assert (clip32 < 1).any() and (clip32 == 1).any(), "test should exercise clipped and unclipped samples"
+    assert torch.allclose(got_clip, clip16, rtol=5e-3) and torch.allclose(got_clip, clip32, rtol=5e-3)
     flat = lambda d: torch.cat([d[k].reshape(-1).double() for k, _ in eng.p_entries])
     gvec = torch.cat([eng.gviews[k].reshape(-1).double().cpu() for k, _ in eng.p_entries])
     d32, d16, oo = rel(gvec, flat(want32)), rel(gvec, flat(want16)), rel(flat(want16), flat(want32))

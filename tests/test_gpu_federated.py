@@ -462,3 +462,41 @@ def test_c_abi_comm_entry_points_on_an_rccl_communicator(cuda):
     torch.cuda.synchronize()
     assert torch.equal(buf, keep)
     rccl.ncclCommDestroy(comm)
+
+
+def test_reference_style_setup_through_the_worker_shim(cuda):
+    """A set-up written like the reference's (train.py:88-97, torchlib/utils.py:516-860) on primia_syft_compat: hook,
+    setup_pysyft -> (train_loader keyed by VirtualWorker, val_loader, total_L, workers, names, crypto_provider,
+    val_mean_std), then one federated epoch of torchlib_compat.train_federated on exactly those objects."""
+    import primia_syft_compat as sy
+    from primia_amd.optim import EngineOptimizer
+
+    args = SimpleNamespace(batch_size=4, train_resolution=64, inference_resolution=64, seed=1, pretrained=True,
+                           unencrypted_aggregation=False, websockets=False, data_dir="synthetic", mixup=False,
+                           weight_classes=False, train_federated=True, repetitions_dataset=1, lr=1e-3, end_lr=1e-4,
+                           optimizer="SGD", weight_decay=5e-4, beta1=0.9, beta2=0.99, sync_every_n_batch=2,
+                           weighted_averaging=True, keep_optim_dict=False, precision_fractional=16, log_interval=10,
+                           differentially_private=False)
+    hook = sy.TorchHook(torch)
+    train_loader, val_loader, total_L, workers, names, crypto_provider, val_mean_std = sy.setup_pysyft(
+        args, hook, device=cuda, websockets_config=os.path.join(ROOT, "configs", "websetting", "config.csv"))
+    assert names == ["alice", "bob", "charlie"] and crypto_provider.id == "crypto_provider"
+    assert set(train_loader) == set(workers.values()) and total_L == 4 * (4 + 3 + 2)
+    assert [len(train_loader[workers[n]]) for n in names] == [4, 3, 2]
+    assert val_mean_std.shape == (2, 3) and torch.equal(val_mean_std[0], torch.zeros(3))
+    torch.manual_seed(3)
+    init = rs.init_state_dict(rs.resnet18_spec(3, 3, 64, "max"))
+
+    def make():
+        e = ResNet18Engine(4, 3, 3, 64, "max", dtype=torch.float32, device=cuda)
+        e.load_state_dict(init)
+        return e
+
+    model = {"local_model": make(), **{w.id: make() for w in workers.values()}}
+    optimizer = {w.id: EngineOptimizer.from_args(model[w.id], args) for w in workers.values()}
+    loss_fn = {w.id: None for w in workers.values()}
+    model = train_federated(args, model, cuda, train_loader, optimizer, 1, loss_fn, crypto_provider, verbose=False)
+    new = model["local_model"].state_dict()
+    assert any(not torch.equal(new[k], init[k]) for k in ("conv1.weight", "fc.weight"))
+    for w in workers.values():          # every client adopted the last average
+        assert torch.equal(model[w.id].flat, model["local_model"].flat)

@@ -157,3 +157,93 @@ def test_distribute_data_tool_deals_like_the_reference_script(tmp_path):
                         "--label_skew", "0.3", "-s"])
     assert sorted(i for s in shards2 for i in s) == list(range(len(names)))
     assert len({len(s) for s in shards2}) > 1            # skewed shards are uneven
+
+
+def test_syft_worker_shim_objects():
+    """The worker-facing objects of the reference's federated set-up (torchlib/utils.py:578-760) on CPU tensors: tag,
+    load_data, object_store.clear_objects, PrivateGridNetwork.search, FederatedDataLoader over a searched dataset."""
+    import torch
+
+    import primia_syft_compat as sy
+
+    hook = sy.TorchHook(torch)
+    workers = {n: sy.VirtualWorker(hook, id=n, verbose=False) for n in ("alice", "bob")}
+    crypto = sy.VirtualWorker(hook, id="crypto_provider", verbose=False)
+    for w in workers.values():
+        w.object_store.clear_objects()
+    g = torch.Generator().manual_seed(0)
+    held = {}
+    for i, w in enumerate(workers.values()):
+        mean, std = torch.full((3,), float(i)), torch.ones(3)
+        mean.tag("#datamean")
+        std.tag("#datastd")
+        w.load_data([mean, std])
+        data, targets = torch.randn(10 + i, 3, 4, 4, generator=g), torch.randint(0, 3, (10 + i,), generator=g)
+        data.tag("#traindata")
+        targets.tag("#traintargets")
+        w.load_data([data, targets])
+        held[w.id] = (data, targets)
+    grid = sy.PrivateGridNetwork(*(list(workers.values()) + [crypto]))
+    data, target = grid.search("#traindata"), grid.search("#traintargets")
+    assert set(data) == {"alice", "bob"} and "crypto_provider" not in grid.search("#datamean")
+    assert [m[0][0].item() for m in grid.search("#datamean").values()] == [0.0, 1.0]
+    train_loader = {}
+    for w in data:
+        assert data[w][0] is held[w][0] and target[w][0] is held[w][1]
+        ds = sy.FederatedDataset([sy.BaseDataset(data[w][0], target[w][0])])
+        assert len(ds) == len(held[w][0])
+        train_loader[workers[w]] = sy.FederatedDataLoader(ds, batch_size=4, shuffle=True)
+    assert train_loader["alice"] is train_loader[workers["alice"]]        # worker objects and ids key the same entry
+    tl = train_loader[workers["bob"]]
+    assert len(tl) == 2 and torch.equal(tl.targets, held["bob"][1])
+    seen = torch.cat([d for d, _ in tl])
+    assert seen.shape == (8, 3, 4, 4)
+    rows = {tuple(r.reshape(-1).tolist()) for r in held["bob"][0]}
+    assert all(tuple(r.reshape(-1).tolist()) in rows for r in seen)      # a shuffled selection of the registered samples
+    workers["alice"].object_store.clear_objects()
+    assert "alice" not in sy.PrivateGridNetwork(*workers.values()).search("#traindata")
+
+
+def test_augment_oracle_warps_and_fog_properties():
+    """oracle/augment_oracle.py's restatement of albumentations 0.4.6's warping transforms and RandomFog: properties
+    that hold whatever cv2's rounding does (identity maps, symmetry of the distortion field, monotone grid axes,
+    published random streams) — the GPU tests hold the kernels to these functions."""
+    import random
+
+    import numpy as np
+
+    from oracle import augment_oracle as A
+    from primia_amd import augment as P
+
+    rng = np.random.RandomState(0)
+    img = rng.randint(0, 256, (48, 48, 3)).astype(np.uint8)
+    xs, ys = np.meshgrid(np.arange(48), np.arange(48))
+    assert np.array_equal(A.remap_bilinear(img, xs.astype(np.float32), ys.astype(np.float32)), img)
+    # reflect-101 borders: sampling one pixel outside mirrors the pixel one inside
+    assert np.array_equal(A.remap_bilinear(img, (xs - 49).astype(np.float32), ys.astype(np.float32))[:, 48:], img[:, :0])
+    assert np.array_equal(A.remap_bilinear(img, -xs.astype(np.float32), ys.astype(np.float32)), img)
+    # optical: radial field, symmetric about the new principal point; k = 0 is the pure half-pixel shift of 0.4.6
+    mx, my = A.optical_maps(48, 48, 0.05, 0, 0)
+    assert np.allclose(mx - 0.5 - xs, -(mx - 0.5 - xs)[:, ::-1], atol=1e-4) and np.allclose(my, mx.T)
+    mx0, _ = A.optical_maps(48, 48, 0.0, 0, 0)
+    assert np.array_equal(mx0, (xs + 0.5).astype(np.float32))
+    # grid axes: monotone, start at 0, last segment ends at n; host helper of the product == oracle
+    steps = [1 + random.Random(3).uniform(-0.3, 0.3) for _ in range(6)]
+    ax = A.grid_axis(224, 5, steps)
+    assert ax[0] == 0 and np.all(np.diff(ax) >= 0) and abs(ax[-1] - 224) < 1e-3
+    assert np.array_equal(ax, P.grid_axis(224, 5, steps))
+    # elastic: numpy's legacy stream and the affine solve (three points map exactly)
+    inv, dx, dy, _ = A.elastic_params(64, 64, 1234)
+    inv2, dx2, _, _ = A.elastic_params(64, 64, 1234)
+    assert np.array_equal(inv, inv2) and np.array_equal(dx, dx2) and np.abs(dx).max() < 0.1      # alpha = 1: sub-pixel
+    m = A.affine_from_points([(1, 2), (5, 2), (1, 7)], [(2, 2), (6, 3), (1, 9)])
+    assert np.allclose(m @ np.array([5, 2, 1.0]), (6, 3)) and np.allclose(A.invert_affine(m) @ np.array([6, 3, 1.0]), (5, 2))
+    assert np.allclose(P.invert_affine(P.affine_from_points([(1, 2), (5, 2), (1, 7)], [(2, 2), (6, 3), (1, 9)])),
+                       A.invert_affine(m))
+    # fog: same draws from the same `random` stream in product helper and oracle; blending brightens, never darkens
+    fc, hz = A.fog_params(96, 96, random.Random(4))
+    assert (fc, hz) == P.fog_params(96, 96, random.Random(4)) and 0.3 <= fc <= 1 and len(hz) > 0
+    dark = np.full((96, 96, 3), 10, np.uint8)
+    fog = A.add_fog(dark, fc, hz)
+    assert fog.min() >= 10 and fog.max() > 10
+    assert np.array_equal(A.box_blur_anchor(img, 5), A.box_blur(img, 5))
