@@ -1,0 +1,789 @@
+// EXPERIMENT (round 4, not part of the library): conv3x3_lh2.hip with the step's weight fragments loaded straight into the
+// registers of the waves that multiply with them (packed weight image, eight 1-KiB buffer loads per wave and step), no
+// weight rings in LDS, and — LH3_FREE=1 — no per-step barriers: the halo double buffer changes hands once per chunk.
+// Bit-identical to conv3x3_lh2 (tools/micro/lh3_bench.hip checks outputs and BatchNorm partials).  What it showed
+// (profiles/r04_lh3_experiments.txt): the matrix segments drop to their MFMA floor (47 k -> 32-36 k cycles per launch), the
+// load phases grow by as much (eight texture-path instructions per wave and step), launch time ends up within 3 % of
+// conv3x3_lh2 either way; with the weight loads switched off altogether the layer2 / layer3 shapes do not get faster.
+// 3x3 / stride-1 / pad-1 convolution, forward and data gradient, wide stages (ResNet-18 layer2-4), bf16, gfx950:
+// second generation of the "linear halo" implicit GEMM (conv3x3_lh.hip), rebuilt around what round 2 measured about it —
+// of a 67-84 us launch only 38-40 us was the MFMA phase; the rest was per-tile skeleton (launch, first-halo latency,
+// write-back) that nothing overlapped, a 77 %-full last round of tiles, and load segments longer than the MFMA
+// segments they alternate with.
+//
+//   * PERSISTENT: one 8-wave block per CU walks a contiguous range of tiles; the LDS rings (2 halo buffers, the weight
+//     rings) run straight through tile boundaries, so the next tile's first halo chunk and weights are already
+//     resident when the current tile's last step ends.  Results leave from the accumulator registers (no LDS
+//     staging: the rings never stop), as 16-byte stores after a v_permlane16_swap transpose.
+//   * BALANCED tiles: BM = 392 pixels (two per CU on 28x28, one per CU and channel half on 14x14 at batch 256) or
+//     196 pixels (7x7 images; small problems).  25 (13) pixel fragments of 16 are split 7 / 6 / 6 / 6 (4 / 3 / 3 / 3)
+//     over the four pixel groups; the ping-pong halves (waves 0-3 | 4-7) then carry 13 | 12 (7 | 6) fragments, and on
+//     every SIMD a matrix segment of one half runs beside the load segment of the other.
+//   * the tile is 1.75x the old one at the same weight traffic: 287 flop per L2 -> LDS byte instead of 176 (the
+//     matrix pipe needs 174 at its peak), and 22 fragment reads feed 56 MFMAs per wave and step (was 16 for 32).
+//   * registers: only the first 32-channel half of a step's fragments is read in the load segment; the second half
+//     is read INSIDE the matrix segment, each pixel fragment into the registers its first half has just released
+//     (112 accumulator + 60 fragment registers for 7 fragments instead of 112 + 88).
+//   * matrix segments hold nothing but MFMAs and those reads: every LDS-DMA piece is issued in a LOAD segment (its
+//     issue costs the wave 100-200 cycles, which must run beside the partner's MFMAs, not in front of its own).
+//
+// A block owns BM CONSECUTIVE NHWC pixels x 128 output channels.  Per 64-channel chunk the pixel run plus W + 1
+// pixels either side ("linear halo", <= 450 slots of 128 B) is staged ONCE for all 9 taps: tap (r, s) of output
+// pixel m reads source pixel m + (r-1) W + (s-1), i.e. the same buffer at a tap-uniform slot shift; a tap that leaves
+// the image reads an all-zero slot instead (9-bit validity per pixel fragment and lane, one select per fragment and
+// step).  Staging is buffer-addressed LDS-DMA, so out-of-range pixels and dead slots are zero-filled by the hardware
+// range check; the halo image carries the XOR chunk swizzle (chunk ^ ((slot >> 1) & 7)) on the DMA source side.
+//
+// Weights of a step (tap, chunk) = 128 rows x 64 channels, staged as two half tiles of 128 rows x 64 B (channels
+// 0-31 | 32-63), because the halves live differently: the first is read in the load segments of step t (ring of 2:
+// requested by the A waves in load(t-1)), the second in the matrix segments of step t, which end one segment later
+// (ring of 3: requested by the B waves in load(t-2)).  64-byte rows: four rows span the 64 banks; chunk c of row r
+// sits at c ^ key(r >> 2), key = {0, 2, 3, 1}, which keeps every 16-lane group of a ds_read_b128 conflict-free.
+//
+// Data gradient = the same kernel on (dy, w_dgrad [C][R][S][K]) with the tap direction flipped (FLIP).
+#include <stdlib.h>
+
+#include "../../../primia_amd/csrc/conv3x3_lh.h"
+
+namespace primia {
+
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+struct Lh3Params {
+    const bf16* src;   // [M][Cs]
+    const bf16* wt;    // [Nd][9][Cs]
+    bf16* dst;         // [M][Nd]
+    int H, W, Cs, Nd;
+    int M;             // N*H*W
+    const uint8_t* acc_mask;   // accumulate form: ReLU mask bits applied to the OLD values (one byte per 8 channels)
+    float* stat_partials;      // forward only: BatchNorm partial sums [tiles_m][2][Nd] of the values AS STORED (or null)
+    int ntile_n, ntiles;
+    unsigned magicW, magicH;   // ceil(2^16 / W), ceil(2^16 / H)
+    unsigned long long* prof;  // LH2_PROF builds: [block][wave][4] cycles in load / matrix / barrier-wait / write-back
+};
+
+// compile-time experiment switches (tools/micro/lh2_bench.hip): 1 no write-back (accumulators kept alive), 2 no DMA
+// after the prologue, 4 no MFMA, 8 no fragment reads
+#ifndef LH2_DBG
+#define LH2_DBG 0
+#endif
+#ifndef LH2_PRIO
+#define LH2_PRIO 1
+#endif
+#ifndef LH2_SWAP
+#define LH2_SWAP 0
+#endif
+#ifndef LH2_RF
+#define LH2_RF 0
+#endif
+#ifdef LH2_PROF
+#define LH2_MARK(slot)                                 \
+    {                                                  \
+        const unsigned long long t_now = clock64();    \
+        prof_t[slot] += t_now - prof_prev;             \
+        prof_prev = t_now;                             \
+    }
+#else
+#define LH2_MARK(slot)
+#endif
+
+constexpr int kL3Slots = 464;                       // halo slots per buffer
+constexpr int kL3Plane = kL3Slots * 64;             // 29,696 B: one 32-channel half of every slot (29 DMA pieces of 16 slots)
+constexpr int kL3Halo = 2 * kL3Plane;               // 59,392 B
+constexpr int kL3OffScr = 2 * kL3Halo;              // BatchNorm partials of the four pixel groups [4][2][128] fp32
+constexpr int kL3Lds = kL3OffScr + 4 * 2 * 128 * 4; // 122,880 B (the weights never pass through LDS)
+constexpr int kL3ZeroSlot = kL3Slots - 1;           // never live (live slots <= 450): zero-filled with every chunk
+static_assert(kL3Lds <= 163840, "LDS budget");
+constexpr unsigned kL3Oob = 0xfffffff0u;
+
+__device__ __forceinline__ void l3_dma(unsigned voff, i32x4_t rsrc, unsigned soff, unsigned lds_addr) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 ::"v"(voff), "s"(rsrc), "s"(soff), "s"(lds_addr) : "memory");
+}
+
+__device__ __forceinline__ i32x4_t l3_rsrc(const void* base, long bytes) {
+    const unsigned long long a = (unsigned long long)base;
+    i32x4_t r;
+    r[0] = (int)(unsigned)a;
+    r[1] = (int)(unsigned)(a >> 32) & 0xffff;       // stride 0: raw buffer
+    r[2] = (int)(unsigned)(bytes > 0x7ffffff0L ? 0x7ffffff0L : bytes);
+    r[3] = 0x00020000;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_readfirstlane(r[j]);
+    return r;
+}
+
+// The step's 128 x 64 weight tile goes straight to the registers of the waves that multiply with it: wave (wn, *) loads the
+// eight A fragments of ITS 64 output channels with eight buffer_load_dwordx4 from the PACKED weight image
+//     wp[n-tile][tap][chunk][wn][q = 2 i + h][lane][8 bf16]      (fragment (i, h): row 16 i + fr, channels 32 h + 8 fg ..)
+// in which a fragment is the 1 KiB a wave instruction reads — eight whole cache lines (fragment-shaped reads of the
+// row-major image, 16 rows x 64 B per instruction, ran the texture path at a quarter of its rate: 85-143 us per launch).
+// The four waves of a channel half ask for the same lines within one segment: three of the four requests hit the L1.
+// Inline asm (the compiler must neither count these loads nor wait for them: a visible load in a DMA pipeline costs a
+// vmcnt(0) that drains every LDS-DMA piece in flight); outputs early-clobber, completion by l3_wwait below.
+__device__ __forceinline__ void l3_wload(bf16x8_t (&a0)[4], bf16x8_t (&a1)[4], unsigned voff, i32x4_t rsrc, unsigned s0,
+                                         unsigned s1) {
+    asm volatile(
+        "s_nop 4\n\t"
+        "buffer_load_dwordx4 %0, %8, %9, %10 offen\n\t"
+        "buffer_load_dwordx4 %4, %8, %9, %10 offen offset:1024\n\t"
+        "buffer_load_dwordx4 %1, %8, %9, %10 offen offset:2048\n\t"
+        "buffer_load_dwordx4 %5, %8, %9, %10 offen offset:3072\n\t"
+        "buffer_load_dwordx4 %2, %8, %9, %11 offen\n\t"
+        "buffer_load_dwordx4 %6, %8, %9, %11 offen offset:1024\n\t"
+        "buffer_load_dwordx4 %3, %8, %9, %11 offen offset:2048\n\t"
+        "buffer_load_dwordx4 %7, %8, %9, %11 offen offset:3072"
+        : "=&v"(a0[0]), "=&v"(a0[1]), "=&v"(a0[2]), "=&v"(a0[3]), "=&v"(a1[0]), "=&v"(a1[1]), "=&v"(a1[2]), "=&v"(a1[3])
+        : "v"(voff), "s"(rsrc), "s"(s0), "s"(s1)
+        : "memory");
+}
+// all but the `N` youngest vector-memory operations of this wave have completed; names the fragment registers so that no
+// consumer is scheduled above the wait (cdna_hip_programming.md section 5.7, form (ii))
+template <int N>
+__device__ __forceinline__ void l3_wwait(bf16x8_t (&a0)[4], bf16x8_t (&a1)[4]) {
+    asm volatile("s_waitcnt vmcnt(%8)"
+                 : "+v"(a0[0]), "+v"(a0[1]), "+v"(a0[2]), "+v"(a0[3]), "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3])
+                 : "i"(N)
+                 : "memory");
+}
+
+__device__ __forceinline__ void l3_wait_vmcnt(int n) {   // wave-uniform n
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    }
+}
+
+// sum over the 16 lanes of a DPP row (lanes with equal lane >> 4), result in every lane, fixed order
+__device__ __forceinline__ float l3_row_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));   // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));   // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));  // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));  // row_mirror
+    return v;
+}
+
+// v_permlane16_swap: lanes 16-31 (48-63) of `a` trade places with lanes 0-15 (32-47) of `b`
+__device__ __forceinline__ void l3_swap16(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+
+template <int J>
+struct LhJ3 {
+    static constexpr int value = J;
+};
+
+// One wave's whole life.  JW = pixel fragments of this wave, F0 = its first fragment, ISA = first ping-pong half.
+template <int BM, int JW, int F0, bool ISA, bool FLIP, bool ACC>
+__device__ __forceinline__ void lh3_run(const Lh3Params& p, char* smem, int tile_first, int tile_count) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wh = wave & 3;           // channel half; index inside the ping-pong half
+    const int fr = lane & 15, fg = lane >> 4;
+    const int W = p.W, H = p.H, Cs = p.Cs, Nd = p.Nd;
+    const int nchunks = Cs >> 6;
+    const int klen = 9 * Cs;
+    const int nslots = BM + 2 * W + 2;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    constexpr bool staging = !(LH2_DBG & 2);
+#ifdef LH2_PROF
+    unsigned long long prof_t[5] = {0, 0, 0, 0, 0}, prof_prev = clock64();
+#endif
+
+    const i32x4_t rs_src = l3_rsrc(p.src, (long)p.M * Cs * 2);
+    const i32x4_t rs_wt = l3_rsrc(p.wt, (long)Nd * klen * 2);
+    bf16x8_t a0[4], a1[4];             // the step's weight fragments, both 32-channel halves (loaded, not staged)
+
+    // ---- staging addresses ------------------------------------------------------------------------------
+    // Halo image of a chunk = two planes (channels 0-31 | 32-63 of every slot, 64 B each): the second half of a pixel
+    // fragment then sits at a CONSTANT distance from the first (an immediate offset of its ds_read, no address
+    // arithmetic inside the matrix segment).  Piece q (0..57): plane q / 29, slots 16 (q % 29) .. +15; this lane: slot
+    // + lane / 4, LDS chunk lane % 4 <- source chunk (lane % 4) ^ key(slot >> 2), and (slot >> 2) & 3 = lane >> 4 for
+    // every piece, so ONE per-lane byte offset serves all pieces; the pixel part goes into the per-lane offset as well
+    // (not into soffset: the range check must see it).
+    // A wave stages ONE plane (wave & 1) and every second (prologue: fourth) piece of it: piece r = r0 + step * k.
+    const int hplane = wave & 1;
+    int hr0 = wh >> 1;                                   // main loop (B waves): r = (wh >> 1) + 2k; prologue: (wave >> 1) + 4k
+    auto halo_piece = [&](int k, int step, int hm0, int c, int buf) {
+        const int hslot = (lane >> 2) + 16 * hr0;        // slot of piece r0 (per-lane, loop-invariant)
+        const unsigned hvbase = (unsigned)((hslot * Cs + (((lane & 3) ^ ((0x78 >> (2 * (lane >> 4))) & 3)) << 3)) * 2);
+        unsigned voff = hvbase + (unsigned)((hm0 + 16 * step * k) * Cs * 2);
+        if (hslot + 16 * step * k >= nslots) voff = kL3Oob;
+        l3_dma(voff, rs_src, __builtin_amdgcn_readfirstlane((unsigned)(c * 128 + hplane * 64)),
+               __builtin_amdgcn_readfirstlane(lds0 + buf * kL3Halo + hplane * kL3Plane + (hr0 + step * k) * 1024));
+    };
+    // Weight fragments (see l3_wload): this lane reads row fr of a 16-row fragment, 16-byte chunk fg of a 32-channel half;
+    // the fragment's first row and the step (tap, chunk) go into the scalar offsets.
+    const unsigned wvoff = (unsigned)(lane * 16);
+    auto wload = [&](int n0_, int tap, int c) {
+        if (LH2_DBG & 16) {      // experiment: no weight loads (the fragment registers keep whatever they hold)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(a0[i]), "+v"(a1[i]));
+            return;
+        }
+        const unsigned s0 = __builtin_amdgcn_readfirstlane(
+            (unsigned)(((((long)(n0_ >> 7) * 9 + tap) * nchunks + c) * 2 + wn) * 8192));
+        l3_wload(a0, a1, wvoff, rs_wt, s0, s0 + 4096u);
+    };
+
+    // ---- fragment read addresses ---------------------------------------------------------------------------
+    // pixels: fragment j covers tile pixels 16 (F0 + j) + fr, halo slot at shift 0 = that + W + 1; + j * 1024
+    int sj0 = 16 * F0 + fr + W + 1;
+
+    f32x4 acc[4][JW];
+    bf16x8_t b[JW];                    // 32-channel half 0 of the step's pixel fragments; half 1 is read INSIDE the matrix
+    int bad[JW];                       // segment, each fragment into the registers half 0 has just released
+    unsigned pmask[3] = {0u, 0u, 0u};  // bit 9 (j % 3) + t of word j / 3: tap t of fragment j stays inside the image
+
+    int m0 = 0, n0 = 0, tm = 0;
+    auto tile_coords = [&](int tile, int& tm_, int& m0_, int& n0_) {
+        tm_ = tile / p.ntile_n;
+        n0_ = (tile - tm_ * p.ntile_n) * 128;
+        m0_ = tm_ * BM;
+    };
+    // per-tile lane constants: 9-bit tap validity of every pixel fragment (forward tap numbering; FLIP mirrors it)
+    auto tile_setup = [&]() {
+        const int w0 = m0 % W, h0 = (m0 / W) % H;          // wave-uniform
+        unsigned pm[3] = {0u, 0u, 0u};
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            const int pl = 16 * (F0 + j) + fr;
+            const unsigned t = (unsigned)(w0 + pl);
+            const unsigned q = (t * p.magicW) >> 16;
+            const int w = (int)(t - q * W);
+            const unsigned hr = (unsigned)h0 + q;
+            const int h = (int)(hr - ((hr * p.magicH) >> 16) * H);
+            unsigned mask = 0;
+            if (pl < BM && m0 + pl < p.M) {
+                const unsigned cm = (w > 0 ? 1u : 0u) | 2u | (w < W - 1 ? 4u : 0u);
+                mask = (h > 0 ? cm : 0u) | (cm << 3) | (h < H - 1 ? cm << 6 : 0u);
+            }
+            if (FLIP) {   // tap t of the flipped direction = tap 8 - t of the forward one
+                unsigned rv = 0;
+#pragma unroll
+                for (int t9 = 0; t9 < 9; ++t9) rv |= ((mask >> t9) & 1u) << (8 - t9);
+                mask = rv;
+            }
+            pm[j / 3] |= mask << (9 * (j % 3));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        pmask[0] = pm[0]; pmask[1] = pm[1]; pmask[2] = pm[2];
+    };
+
+    // ---- write-back from the accumulator registers -----------------------------------------------------------
+    // A lane (fr, fg) holds channels 16i + 4fg .. +3 (i = 0..3) of pixel 16 (F0 + j) + fr.
+    //  (1) per pair of fragments (i = 2b, 2b+1) a v_permlane16_swap between the lane rows fg = 2a and 2a+1 leaves an
+    //      even row with channels 16 (2b) + 8a .. +7 and an odd row with channels 16 (2b+1) + 8a .. +7: 16 contiguous
+    //      bytes per lane, i.e. pieces P0 (channels 0-31 of the wave's 64) and P1 (32-63) of the lane's pixel;
+    //  (2) the two 8-lane halves of every row trade pieces (DPP row_ror:8), so that ONE store instruction carries
+    //      complete 128-byte lines: pixels fr & 7 in the first, 8 + (fr & 7) in the second (lanes fr < 8 hold P0, lanes
+    //      fr >= 8 hold P1).  The CU's store path takes ~16 B/clk whatever the pattern (tools/micro/store_burst.hip:
+    //      16.1 B/clk for whole lines, 13.8 for half lines, 7.9 for 8-byte stores): a 100-KB tile is ~6,500 cycles of
+    //      store issue, which is why the stores go FIRST and the BatchNorm sums are formed while they drain.
+    auto epilogue = [&]() {
+        if (LH2_DBG & 1) {
+#pragma unroll
+            for (int j = 0; j < JW; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) asm volatile("" ::"v"(acc[i][j]));
+            return;
+        }
+        unsigned row0 = (unsigned)(m0 + 16 * F0 + (fr & 7));
+        const int hi8 = fr >> 3;                            // 0: this lane stores P0 pieces, 1: P1 pieces
+        // this lane's 16-byte piece: fragment 2 hi8 + (fg & 1), channels 8 (fg >> 1) .. +7 of it
+        const unsigned col0 = (unsigned)(n0 + wn * 64 + 32 * hi8 + 16 * (fg & 1) + 8 * (fg >> 1));
+        // (m0 / n0 are known when the tile starts: without this the store addresses are computed there and stay in
+        // registers through the whole main loop)
+        asm volatile("" : "+v"(row0));
+        auto ror8 = [](uint32_t v) {
+            return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);   // row_ror:8
+        };
+        // accumulate form: EVERY old row (and mask byte) of the tile is requested before the first store — a load that
+        // is waited for after a store also waits for that store (one vmcnt for both), and the compiler cannot move a
+        // load of dst above a store to dst: fragment by fragment, the tile paid seven store -> load round trips (the
+        // fragment registers of the main loop are dead here: 70 registers are free)
+        u32x4 oldA_[JW], oldB_[JW];
+        unsigned mkA_[JW], mkB_[JW];
+        if constexpr (ACC) {
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                const int plA = 16 * (F0 + j) + (fr & 7), plB = plA + 8;
+                const bool okA = plA < BM && m0 + plA < p.M, okB = plB < BM && m0 + plB < p.M;
+                const unsigned eoA = (row0 + 16 * j) * (unsigned)Nd + col0, eoB = eoA + 8u * (unsigned)Nd;
+                oldA_[j] = oldB_[j] = u32x4{0u, 0u, 0u, 0u};
+                mkA_[j] = mkB_[j] = 0xffu;
+                if (okA) {
+                    oldA_[j] = *(const u32x4*)((const char*)p.dst + (size_t)(eoA * 2u));
+                    if (p.acc_mask) mkA_[j] = p.acc_mask[eoA >> 3];
+                }
+                if (okB) {
+                    oldB_[j] = *(const u32x4*)((const char*)p.dst + (size_t)(eoB * 2u));
+                    if (p.acc_mask) mkB_[j] = p.acc_mask[eoB >> 3];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            // rows of this lane in the two stores of fragment j: pixels (fr & 7) and 8 + (fr & 7)
+            const int plA = 16 * (F0 + j) + (fr & 7), plB = plA + 8;
+            const bool okA = plA < BM && m0 + plA < p.M, okB = plB < BM && m0 + plB < p.M;
+            const unsigned eoA = (row0 + 16 * j) * (unsigned)Nd + col0, eoB = eoA + 8u * (unsigned)Nd;
+            u32x4 oldA = {0u, 0u, 0u, 0u}, oldB = {0u, 0u, 0u, 0u};
+            unsigned mkA = 0xffu, mkB = 0xffu;
+            if constexpr (ACC) {
+                oldA = oldA_[j]; oldB = oldB_[j];
+                mkA = mkA_[j]; mkB = mkB_[j];
+            }
+            f32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = acc[i][j];
+            if constexpr (ACC) {
+                // the old values travel the two exchanges backwards into the accumulators' lane layout, are added in
+                // fp32 and the sum is rounded once
+                auto masked = [](u32x4 o, unsigned mk) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        o[e] &= ((mk >> (2 * e)) & 1u ? 0x0000ffffu : 0u) | ((mk >> (2 * e + 1)) & 1u ? 0xffff0000u : 0u);
+                    return o;
+                };
+                const u32x4 a_ = masked(oldA, mkA), b_ = masked(oldB, mkB);
+                // lanes fr < 8 hold (own P0 of pixel fr in A, P0 of pixel fr + 8 in B); lanes fr >= 8 hold (P1 of pixel
+                // fr - 8 in A, own P1 in B): what is not the lane's own pixel goes back across the row halves
+                u32x4 p0, p1;       // this lane's pixel: pieces P0 and P1 (post-swap layout)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const uint32_t give = hi8 ? a_[e] : b_[e];
+                    const uint32_t got = ror8(give);
+                    p0[e] = hi8 ? got : a_[e];
+                    p1[e] = hi8 ? b_[e] : got;
+                }
+#pragma unroll
+                for (int bq = 0; bq < 2; ++bq) {
+                    const u32x4 ov = bq ? p1 : p0;
+                    uint32_t x0 = ov[0], x1 = ov[1], y0 = ov[2], y1 = ov[3];   // (x | y) = quarters (2a | 2a+1) of a fragment
+                    l3_swap16(x0, y0);
+                    l3_swap16(x1, y1);
+                    // now x = fragment 2bq, y = fragment 2bq+1, both this lane's own quarter fg
+                    const uint32_t ox[2][2] = {{x0, x1}, {y0, y1}};
+#pragma unroll
+                    for (int s_ = 0; s_ < 2; ++s_) {
+                        const int i = 2 * bq + s_;
+                        v[i][0] += __uint_as_float(ox[s_][0] << 16);
+                        v[i][1] += __uint_as_float(ox[s_][0] & 0xffff0000u);
+                        v[i][2] += __uint_as_float(ox[s_][1] << 16);
+                        v[i][3] += __uint_as_float(ox[s_][1] & 0xffff0000u);
+                    }
+                }
+            }
+            u32x4 pc[2];        // P0, P1 of this lane's pixel
+#pragma unroll
+            for (int bq = 0; bq < 2; ++bq) {
+                uint32_t x0 = (uint32_t)f32_to_bf16(v[2 * bq][0]) | ((uint32_t)f32_to_bf16(v[2 * bq][1]) << 16);
+                uint32_t x1 = (uint32_t)f32_to_bf16(v[2 * bq][2]) | ((uint32_t)f32_to_bf16(v[2 * bq][3]) << 16);
+                uint32_t y0 = (uint32_t)f32_to_bf16(v[2 * bq + 1][0]) | ((uint32_t)f32_to_bf16(v[2 * bq + 1][1]) << 16);
+                uint32_t y1 = (uint32_t)f32_to_bf16(v[2 * bq + 1][2]) | ((uint32_t)f32_to_bf16(v[2 * bq + 1][3]) << 16);
+                l3_swap16(x0, y0);
+                l3_swap16(x1, y1);
+                pc[bq] = u32x4{x0, x1, y0, y1};
+            }
+            u32x4 stA, stB;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t give = hi8 ? pc[0][e] : pc[1][e];       // the piece the other half of the row stores
+                const uint32_t got = ror8(give);
+                stA[e] = hi8 ? got : pc[0][e];                         // pixel fr & 7:       P0 from lanes < 8, P1 via lanes >= 8
+                stB[e] = hi8 ? pc[1][e] : got;                         // pixel 8 + (fr & 7)
+            }
+            if (okA) *(u32x4*)((char*)p.dst + (size_t)(eoA * 2u)) = stA;
+            if (okB) *(u32x4*)((char*)p.dst + (size_t)(eoB * 2u)) = stB;
+        }
+        if (!ACC && p.stat_partials) {
+            // BatchNorm partial sums of the values AS STORED, formed while the stores drain: the accumulators are still
+            // intact, rounding them again gives the stored bits.  Fold the 16 pixels of a row (same fg), then one lane per
+            // fg parks the pixel group's partial in LDS; the B half adds the four groups in a fixed order after the next
+            // barrier (stat_combine).
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 s1[4][2], s2[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) s1[i][h] = s2[i][h] = f32x2{0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                const int pl = 16 * (F0 + j) + fr;
+                const bool ok = pl < BM && m0 + pl < p.M;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        f32x2 r = {bf16_to_f32(f32_to_bf16(acc[i][j][2 * h])), bf16_to_f32(f32_to_bf16(acc[i][j][2 * h + 1]))};
+                        if (!ok) r = f32x2{0.f, 0.f};
+                        s1[i][h] += r;
+                        s2[i][h] += r * r;
+                    }
+            }
+            float* scr = (float*)(smem + kL3OffScr) + (F0 == 0 ? 0 : (F0 - 1) / (BM == 392 ? 6 : 3)) * 256;   // pixel group 0..3
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t1 = l3_row_sum(s1[i][e >> 1][e & 1]), t2 = l3_row_sum(s2[i][e >> 1][e & 1]);
+                    if (fr == 0) {
+                        const int ch = wn * 64 + 16 * i + 4 * fg + e;
+                        scr[ch] = t1;
+                        scr[128 + ch] = t2;
+                    }
+                }
+        }
+    };
+    // B half, one segment after both halves' write-back: thread -> (q, channel); groups added in the order 0,1,2,3
+    auto stat_combine = [&](int tm_, int n0_) {
+        if (ACC || !p.stat_partials || ISA) return;
+        const int t = tid & 255;
+        const int q = t >> 7, ch = t & 127;
+        const float* scr = (const float*)(smem + kL3OffScr);
+        float s = scr[q * 128 + ch];
+#pragma unroll
+        for (int g = 1; g < 4; ++g) s += scr[g * 256 + q * 128 + ch];
+        p.stat_partials[((long)tm_ * 2 + q) * Nd + n0_ + ch] = s;
+    };
+
+    // ---- the two kinds of segment ---------------------------------------------------------------------------
+    int hbuf = 0;       // halo buffer of the chunk being loaded
+    // LH2_RF = 1 (experiment, measured SLOWER: 58.9 -> 60.6 / 51.9 -> 54.1 us, layer2 / layer3 forward): a load segment
+    // requests its fragment reads first and its LDS-DMA pieces behind them.  The load segments do get shorter (B half:
+    // 33 k -> 25 k cycles per launch), but the partner's matrix segments grow by as much (35.7 k -> 38.7 k) and so do the
+    // barrier waits: the pieces are accepted later, land later, and their LDS writes then sit in the matrix segments' reads
+    auto load_issue = [&](auto tap_tag) {
+        constexpr int tap = decltype(tap_tag)::value;
+        if (!(LH2_DBG & 8)) {
+            constexpr int tr = tap / 3, ts = tap - 3 * tr;
+            const int slot = sj0 + (FLIP ? (1 - tr) * W + (1 - ts) : (tr - 1) * W + (ts - 1));
+            const int offt = slot * 64 + ((fg ^ ((0x78 >> (2 * ((slot >> 2) & 3))) & 3)) << 4) + hbuf * kL3Halo;
+            const int zoff = kL3ZeroSlot * 64 + hbuf * kL3Halo;
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+                // an invalid tap reads the zero slot (minus the fragment's immediate offset)
+                bad[j] = ((pmask[j / 3] >> (9 * (j % 3) + tap)) & 1u) ? offt : zoff - j * 1024;
+                b[j] = *(const bf16x8_t*)(smem + (bad[j] + j * 1024));
+            }
+        }
+    };
+    auto load_finish = [&]() {
+        // (the builtin, not inline asm: the compiler's own wait-count bookkeeping then knows these reads have landed and
+        // puts no further waits for them between the MFMAs of the matrix segment)
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0)
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_segment = [&]() {
+#if LH2_PRIO
+        __builtin_amdgcn_s_setprio(LH2_PRIO);   // the partner's load segment must not take issue slots from the MFMAs
+#endif
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            if (!(LH2_DBG & 4)) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(LH2_DBG & 8))
+                b[j] = *(const bf16x8_t*)(smem + (bad[j] + (j * 1024 + kL3Plane)));  // half 1 of this fragment, same registers
+        }
+        if (!(LH2_DBG & 4)) {
+            // fragment order pinned: the second half of fragment 0 was requested first and has long landed when this
+            // phase starts, that of fragment JW-1 arrives while the earlier groups multiply (left to itself the
+            // scheduler starts with a late fragment and waits for ALL reads: lgkmcnt(0), ~150-300 exposed cycles)
+#pragma unroll
+            for (int j = 0; j < JW; ++j) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[i], b[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#if LH2_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    };
+
+    // ---- prologue: first tile's chunk 0 (all waves) ----------------------------------------------------------------
+    tile_coords(tile_first, tm, m0, n0);
+    {
+        hr0 = wave >> 1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (hr0 + 4 * k < kL3Slots / 16) halo_piece(k, 4, m0 - (W + 1), 0, 0);
+#ifndef LH3_FREE
+#define LH3_FREE 1
+#endif
+        if (!LH3_FREE) hr0 = wh >> 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#if LH3_FREE
+    // ---- free-running form -------------------------------------------------------------------------------------------
+    // With the weights out of LDS the halo double buffer is the only shared state left, and it changes hands once per
+    // 64-channel chunk: ONE barrier per chunk (9 steps) instead of two per step.  Every wave runs
+    //     step: [its share of the next chunk's halo pieces] -> weight loads -> first halves of its pixel fragments ->
+    //           wait -> 56 | 48 MFMAs with the second halves read in between
+    // at its own pace; the two waves of a SIMD fall into alternation by themselves (one waits for its loads while the
+    // other multiplies), the SIMDs drift apart, and the texture path sees a steady trickle of loads instead of 32 at once.
+    // Halo pieces: every wave stages its plane (wave & 1) and every fourth piece of it, one per step (taps 0..7).
+    {
+        int prev_tm = 0, prev_n0 = 0;
+        for (int it = 0; it < tile_count; ++it) {
+            const bool more_tiles = it + 1 < tile_count;
+            int ntm = 0, nm0 = 0, nn0 = 0;
+            if (more_tiles) tile_coords(tile_first + it + 1, ntm, nm0, nn0);
+            tile_setup();
+            for (int c = 0; c < nchunks; ++c) {
+                asm volatile("" : "+v"(pmask[0]), "+v"(pmask[1]), "+v"(pmask[2]), "+v"(sj0), "+s"(hr0));
+                const bool last_chunk = c + 1 == nchunks;
+                const bool has_next = !last_chunk || more_tiles;
+                const int nx_hm0 = (last_chunk ? nm0 : m0) - (W + 1), nx_c = last_chunk ? 0 : c + 1;
+                auto step = [&](auto tap_tag) {
+                    constexpr int tap = decltype(tap_tag)::value;
+                    if (staging && tap < 8 && has_next && hr0 + 4 * tap < kL3Slots / 16)
+                        halo_piece(tap, 4, nx_hm0, nx_c, hbuf ^ 1);
+                    wload(n0, tap, c);
+                    load_issue(tap_tag);
+                    load_finish();
+                    LH2_MARK(0)
+                    l3_wwait<0>(a0, a1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    LH2_MARK(4)
+                    mfma_segment();
+                    LH2_MARK(1)
+                };
+                step(LhJ3<0>{}); step(LhJ3<1>{}); step(LhJ3<2>{}); step(LhJ3<3>{}); step(LhJ3<4>{});
+                step(LhJ3<5>{}); step(LhJ3<6>{}); step(LhJ3<7>{}); step(LhJ3<8>{});
+                if (last_chunk) {
+                    epilogue();        // (stores, then the BatchNorm partials of this wave's pixel group into LDS)
+                    LH2_MARK(3)
+                }
+                // the chunk boundary: every wave's halo pieces for the next chunk have landed (its wait above covered
+                // them: they are older than the last step's weight loads), every wave is done reading this chunk's buffer
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                LH2_MARK(2)
+                hbuf ^= 1;
+                if (last_chunk) {
+                    stat_combine(tm, n0);     // (waves 4-7; the next write of the scratch area is a whole tile away)
+                }
+            }
+            prev_tm = tm; prev_n0 = n0;
+            if (more_tiles) { tm = ntm; m0 = nm0; n0 = nn0; }
+        }
+        (void)prev_tm; (void)prev_n0;
+    }
+#else
+
+    // Both halves run the SAME loop — load(t) | barrier | matrix(t) | barrier — half a step apart: the B half passes one
+    // extra barrier before its first step, the A half one after its last.  Segment 2t = { A: load(t) | B: matrix(t-1) },
+    // segment 2t+1 = { A: matrix(t) | B: load(t) }.  A load segment requests, in this order: the step's OWN weight
+    // fragments (registers; waited for after the barrier, at the start of the matrix segment — the partner's matrix segment
+    // is their latency budget), then (B half, taps 0..6 of chunk g) the halo pieces of chunk g+1 -> buffer (g+1) & 1,
+    // last read in chunk g-1, then the first halves of the step's pixel fragments.  The wait at the start of the matrix
+    // segment leaves the halo pieces of this load segment in flight (they are younger than the weight loads): vmcnt(issued).
+    // Load and wait of a weight fragment sit in ONE straight-line step: the compiler never sees a loop edge between them
+    // (at a back-edge it may copy registers whose asynchronous load has not landed).
+    // A tile's results leave right after its last step's closing barrier: the A half's write-back runs beside the B half's
+    // last matrix segment, the B half's beside the A half's first matrix segment of the next tile.
+    int prev_tm = 0, prev_n0 = 0;
+    bool pending_combine = false;
+    auto wwait = [&](int n) {         // wave-uniform n: this wave's weight fragments have landed
+        switch (n) {
+            case 0: l3_wwait<0>(a0, a1); break;
+            case 1: l3_wwait<1>(a0, a1); break;
+            case 2: l3_wwait<2>(a0, a1); break;
+            default: l3_wwait<3>(a0, a1); break;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (!ISA) __builtin_amdgcn_s_barrier();
+    for (int it = 0; it < tile_count; ++it) {
+        const bool more_tiles = it + 1 < tile_count;
+        int ntm = 0, nm0 = 0, nn0 = 0;
+        if (more_tiles) tile_coords(tile_first + it + 1, ntm, nm0, nn0);
+        tile_setup();
+        for (int c = 0; c < nchunks; ++c) {
+            // (the selects of the load segments are invariant over the chunks of a tile: left alone, the compiler hoists
+            // all 9 x JW of them out of this loop and keeps them in registers)
+            asm volatile("" : "+v"(pmask[0]), "+v"(pmask[1]), "+v"(pmask[2]), "+v"(sj0), "+s"(hr0));
+            const bool last_chunk = c + 1 == nchunks;
+            // the chunk after this one (same tile, or the next tile's first)
+            const bool has_next = !last_chunk || more_tiles;
+            const int nx_hm0 = (last_chunk ? nm0 : m0) - (W + 1), nx_c = last_chunk ? 0 : c + 1;
+            auto step = [&](auto tap_tag) {
+                constexpr int tap = decltype(tap_tag)::value;
+                int issued = 0;       // DMA pieces requested behind the weight loads of this load segment
+                if (!ISA && tap == 1 && c == 0 && pending_combine) {
+                    // both halves' write-backs of the previous tile (and a barrier after them) are behind us
+                    stat_combine(prev_tm, prev_n0);
+                    pending_combine = false;
+                }
+#ifndef LH3_DMA_A
+#define LH3_DMA_A 1
+#endif
+                // halo pieces of the next chunk: 3, 2, 2, 2, 2, 2, 2 over the taps T0 .. T0 + 6.  The buffer they go to was
+                // last read by the B half's matrix segment of the previous chunk's tap 8, which runs beside the A half's
+                // load segment of tap 0: an A-half issuer starts at tap 1.
+                constexpr int T0 = LH3_DMA_A ? 1 : 0;
+                if ((LH3_DMA_A ? ISA : !ISA) && staging) {
+                    if (tap >= T0 && tap <= T0 + 6 && has_next) {
+                        constexpr int tq = tap - T0;
+                        constexpr int k0 = tq == 0 ? 0 : 2 * tq + 1, k1 = 2 * tq + 3;
+#pragma unroll
+                        for (int k = k0; k < k1; ++k) {
+                            if (hr0 + 2 * k < kL3Slots / 16) {
+                                halo_piece(k, 2, nx_hm0, nx_c, hbuf ^ 1);
+                                ++issued;
+                            }
+                        }
+                    }
+                }
+                wload(n0, tap, c);
+                load_issue(tap_tag);
+                load_finish();
+                LH2_MARK(0)
+                __builtin_amdgcn_s_barrier();
+                LH2_MARK(2)
+                (void)issued;
+                wwait(0);         // (LDS-DMA pieces and register loads do not retire in order with each other: no counted wait)
+                LH2_MARK(4)
+                mfma_segment();
+                LH2_MARK(1)
+                __builtin_amdgcn_s_barrier();
+                LH2_MARK(2)
+            };
+            step(LhJ3<0>{}); step(LhJ3<1>{}); step(LhJ3<2>{}); step(LhJ3<3>{}); step(LhJ3<4>{});
+            step(LhJ3<5>{}); step(LhJ3<6>{}); step(LhJ3<7>{}); step(LhJ3<8>{});
+            hbuf ^= 1;
+        }
+        // tile boundary
+        epilogue();
+        LH2_MARK(3)
+        pending_combine = true;
+        prev_tm = tm; prev_n0 = n0;
+        if (more_tiles) { tm = ntm; m0 = nm0; n0 = nn0; }
+    }
+    if (ISA) __builtin_amdgcn_s_barrier();
+    if (!ACC && p.stat_partials) {
+        __syncthreads();
+        stat_combine(prev_tm, prev_n0);
+    }
+#endif
+#ifdef LH2_PROF
+    if (p.prof && lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p.prof[((long)blockIdx.x * 8 + wave) * 5 + k] = prof_t[k];
+    }
+#endif
+}
+
+// BM = 392: fragments 7 | 6 | 6 | 6; BM = 196: 4 | 3 | 3 | 3
+template <int BM, bool FLIP, bool ACC>
+__global__ __launch_bounds__(512) void conv3x3_lh3_kernel(Lh3Params p) {
+    constexpr int J0 = BM == 392 ? 7 : 4, J = BM == 392 ? 6 : 3;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // contiguous tile range of this block, XCD-aware: blocks b, b+8, ... share an XCD and get neighbouring ranges
+    const int nb = gridDim.x;
+    const int lb = xcd_remap(blockIdx.x, nb);
+    const int first = (int)(((long)lb * p.ntiles) / nb), last = (int)(((long)(lb + 1) * p.ntiles) / nb);
+    const int count = last - first;
+    if (count <= 0) return;
+#if LH2_SWAP
+    const int wm = (wave >> 1) ^ 2;      // experiment: the YOUNGER waves (4-7) play the A role
+#else
+    const int wm = wave >> 1;
+#endif
+    if (wm == 0) lh3_run<BM, J0, 0, true, FLIP, ACC>(p, smem, first, count);
+    else if (wm == 1) lh3_run<BM, J, J0, true, FLIP, ACC>(p, smem, first, count);
+    else if (wm == 2) lh3_run<BM, J, J0 + J, false, FLIP, ACC>(p, smem, first, count);
+    else lh3_run<BM, J, J0 + 2 * J, false, FLIP, ACC>(p, smem, first, count);
+}
+
+#ifdef LH2_PROF
+unsigned long long* lh3_prof_buffer = nullptr;
+#endif
+
+static int lh3_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// tile height in pixels for a shape (0: not served).  392 when that gives every CU at least one tile, else 196.
+static int lh3_bm(int N, int H, int W, int Cs, int Nd) {
+    const int off = !PRIMIA_OPT(lh2), force = PRIMIA_OPT(lh2_bm);
+    if (off || W > 28 || W < 2 || H < 2 || Cs % 64 || Nd % 128) return 0;
+    const long M = (long)N * H * W;
+    if (M * (Cs > Nd ? Cs : Nd) >= (1L << 30)) return 0;     // byte offsets stay below 2^31
+    if (force == 392 || force == 196) return force;
+    const long t392 = (M + 391) / 392 * (Nd / 128);
+    return t392 >= lh3_num_cus() ? 392 : 196;
+}
+
+int conv3x3_lh3_tiles_m(int N, int H, int W, int Cs, int Nd) {
+    const int bm = lh3_bm(N, H, W, Cs, Nd);
+    if (!bm) return PRIMIA_ERR_UNSUPPORTED;
+    return (int)(((long)N * H * W + bm - 1) / bm);
+}
+
+int conv3x3_lh3_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
+                         int accumulate, hipStream_t st, float* stat_partials, const uint8_t* acc_mask) {
+    const int bm = lh3_bm(N, H, W, Cs, Nd);
+    if (!bm) return PRIMIA_ERR_UNSUPPORTED;
+    if (stat_partials && (flip || accumulate)) return PRIMIA_ERR_ARG;
+    if (accumulate && !flip) return PRIMIA_ERR_UNSUPPORTED;
+    const long M = (long)N * H * W;
+    Lh3Params p;
+    p.src = src; p.wt = wt; p.dst = dst;
+    p.H = H; p.W = W; p.Cs = Cs; p.Nd = Nd; p.M = (int)M;
+    p.acc_mask = accumulate ? acc_mask : nullptr;
+    p.stat_partials = stat_partials;
+    p.ntile_n = Nd / 128;
+    p.ntiles = (int)((M + bm - 1) / bm) * p.ntile_n;
+    p.magicW = (65536u + W - 1) / W;
+    p.magicH = (65536u + H - 1) / H;
+#ifdef LH2_PROF
+    p.prof = lh3_prof_buffer;
+#else
+    p.prof = nullptr;
+#endif
+    const int ncu = lh3_num_cus();
+    const int grid = p.ntiles < ncu ? p.ntiles : ncu;
+    void (*kern)(Lh3Params);
+    int slot;
+    if (bm == 392) {
+        kern = !flip ? conv3x3_lh3_kernel<392, false, false> : (accumulate ? conv3x3_lh3_kernel<392, true, true> : conv3x3_lh3_kernel<392, true, false>);
+        slot = !flip ? 0 : (accumulate ? 2 : 1);
+    } else {
+        kern = !flip ? conv3x3_lh3_kernel<196, false, false> : (accumulate ? conv3x3_lh3_kernel<196, true, true> : conv3x3_lh3_kernel<196, true, false>);
+        slot = 3 + (!flip ? 0 : (accumulate ? 2 : 1));
+    }
+    static bool attr_set[6] = {false, false, false, false, false, false};
+    if (!attr_set[slot]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kL3Lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set[slot] = true;
+    }
+    kern<<<grid, 512, kL3Lds, st>>>(p);
+    return launch_status();
+}
+
+}  // namespace primia
