@@ -357,8 +357,19 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
                 stA[e] = hi8 ? got : pc[0][e];                         // pixel fr & 7:       P0 from lanes < 8, P1 via lanes >= 8
                 stB[e] = hi8 ? pc[1][e] : got;                         // pixel 8 + (fr & 7)
             }
-            if (okA) *(u32x4*)((char*)p.dst + (size_t)(eoA * 2u)) = stA;
-            if (okB) *(u32x4*)((char*)p.dst + (size_t)(eoB * 2u)) = stB;
+            // non-temporal stores for the plain forms (the accumulate form re-reads what it wrote a launch earlier): the
+            // tile's 100 KB do not displace the weight and halo lines the next tile reads — same-box A/B, 20 + 200 steps:
+            // family 1002 -> 1030 TFLOP/s, step 5.04 -> 5.00 ms (profiles/r04_lh3_experiments.txt)
+#ifndef LH2_NT
+#define LH2_NT 1
+#endif
+            if (LH2_NT && !ACC) {
+                if (okA) __builtin_nontemporal_store(stA, (u32x4*)((char*)p.dst + (size_t)(eoA * 2u)));
+                if (okB) __builtin_nontemporal_store(stB, (u32x4*)((char*)p.dst + (size_t)(eoB * 2u)));
+            } else {
+                if (okA) *(u32x4*)((char*)p.dst + (size_t)(eoA * 2u)) = stA;
+                if (okB) *(u32x4*)((char*)p.dst + (size_t)(eoB * 2u)) = stB;
+            }
         }
         if (!ACC && p.stat_partials) {
             // BatchNorm partial sums of the values AS STORED, formed while the stores drain: the accumulators are still
