@@ -684,6 +684,57 @@ int primia_pool_unroll_syft(const int64_t* x, int64_t* out, int B, int C, int H,
  * triple(x*x) as (a0, b0, c0, a1, b1, c1) [n each], triple(v*xx), the constant's mask [1], triple(y*x). */
 int primia_newton_reciprocal_local(const int64_t* v0, const int64_t* v1, const int64_t* const* prim, int64_t scale,
                                    int64_t* x0, int64_t* x1, int64_t n, primia_stream_t stream);
+/* ---- in-process deployment: both parties' shares on this GPU (what inference.py's VirtualWorker run is) ----------
+ * With both shares side by side an "open" (mpc/spdz.py:162-176) is an addition, so a layer's chain
+ * mask -> open -> combine -> truncate -> re-layout runs as ONE pass in which a thread does what each party does, in the
+ * party's own arithmetic; the provider's primitives are requested by the host in the reference's order and handed in by
+ * pointer.  Bit-identical to the step-by-step entry points above (tests/test_gpu_secure_local.py); the three-role
+ * deployment keeps those.  Suffix _2p: the same per-share operation for both parties in one launch; _local: a protocol
+ * step that includes its opens.  Triples are (a0, b0, c0, a1, b1, c1): a masks the first operand, b the second.
+ *   primia_ring_ew_2p            o_j = a_j + b_j (op 0) | a_j - b_j (op 1), b broadcast when nb < n
+ *   primia_fpt_mul_local         FPT * FPT (precision.py:309-316): Beaver product + each party's truncation by `div`
+ *                                (0: none) + optional addend; y (nb elements) broadcasts
+ *   primia_dif_eval_local        fss.le(x1, x2) (mpc/fss.py:97-185): mask_builder, the mod-2^32 open and both parties'
+ *                                DIF evaluations; x1 / x2 may be column ranges [start, start + len) of a [rows][w]
+ *                                matrix; x1 == NULL: shares of zero (AST.relu, additive_shared.py:922-925)
+ *   primia_max_combine_local     left + (right >= left) * (right - left) (nn/functional.py:494) on column ranges
+ *   primia_bn_eval_local         batch_norm in eval mode (nn/functional.py:44-75) of one image: NCHW in, NCHW out, both
+ *                                FPT products and the row / column re-layouts inside; t1 / t2: HOST arrays of the two
+ *                                triples' six pointers (t1: a ~ inv [C], b, c ~ rows [HW, C]; t2: a, c ~ rows, b ~ weight)
+ *   primia_im2col_syft_2p, primia_pool_unroll_syft_2p   the PySyft layouts of both shares
+ *   primia_beaver_matmul_local   spdz_mul "matmul": both opens, then z_j = c_j + delta @ (b_j [+ eps]) + a_j @ eps for
+ *                                both parties in one grid; scratch = primia_beaver_matmul_local_scratch_elems int64
+ *   primia_trunc_col2out_2p      each party's truncation of its product share + conv2d's output re-layout (+ bias) */
+int primia_ring_ew_2p(int op, const int64_t* a0, const int64_t* a1, const int64_t* b0, const int64_t* b1, int64_t* o0,
+                      int64_t* o1, int64_t n, int64_t nb, primia_stream_t stream);
+int primia_fpt_mul_local(const int64_t* x0, const int64_t* x1, const int64_t* y0, const int64_t* y1, const int64_t* a0,
+                         const int64_t* b0, const int64_t* c0, const int64_t* a1, const int64_t* b1, const int64_t* c1,
+                         const int64_t* add0, const int64_t* add1, int64_t* z0, int64_t* z1, int64_t n, int64_t nb,
+                         int64_t div, primia_stream_t stream);
+int primia_dif_eval_local(const int64_t* x1_0, const int64_t* x1_1, int w1, int start1, const int64_t* x2_0,
+                          const int64_t* x2_1, int w2, int start2, int len, const uint64_t* alpha0, const uint64_t* alpha1,
+                          const uint64_t* s0_0, const uint64_t* s0_1, const uint8_t* cw_bits, const uint64_t* cw_sigma,
+                          const uint64_t* cw_s, const int32_t* cw_leaf, int64_t* out0, int64_t* out1, int64_t n,
+                          primia_stream_t stream);
+int primia_max_combine_local(const int64_t* bit0, const int64_t* bit1, const int64_t* left0, const int64_t* left1, int wl,
+                             int start_left, const int64_t* right0, const int64_t* right1, int wr, int start_right,
+                             const int64_t* a0, const int64_t* b0, const int64_t* c0, const int64_t* a1, const int64_t* b1,
+                             const int64_t* c1, int64_t* out0, int64_t* out1, int64_t rows, int len,
+                             primia_stream_t stream);
+int primia_bn_eval_local(const int64_t* x0, const int64_t* x1, const int64_t* mean0, const int64_t* mean1,
+                         const int64_t* inv0, const int64_t* inv1, const int64_t* w0, const int64_t* w1,
+                         const int64_t* bias0, const int64_t* bias1, const int64_t* const* t1, const int64_t* const* t2,
+                         int64_t* out0, int64_t* out1, int C, int HW, int64_t div, primia_stream_t stream);
+int primia_im2col_syft_2p(const int64_t* x0, const int64_t* x1, int64_t* im0, int64_t* im1, int B, int C, int H, int W, int R,
+                          int S, int stride, int pad, primia_stream_t stream);
+int64_t primia_beaver_matmul_local_scratch_elems(int M, int K, int N);
+int primia_beaver_matmul_local(const int64_t* x0, const int64_t* x1, const int64_t* y0, const int64_t* y1, const int64_t* a0,
+                               const int64_t* b0, const int64_t* c0, const int64_t* a1, const int64_t* b1, const int64_t* c1,
+                               int64_t* z0, int64_t* z1, int64_t* scratch, int M, int K, int N, primia_stream_t stream);
+int primia_trunc_col2out_2p(const int64_t* res0, const int64_t* res1, const int64_t* bias0, const int64_t* bias1,
+                            int64_t* out0, int64_t* out1, int B, int HoWo, int O, int64_t div, primia_stream_t stream);
+int primia_pool_unroll_syft_2p(const int64_t* x0, const int64_t* x1, int64_t* out0, int64_t* out1, int B, int C, int H, int W,
+                               int k, int stride, int pad, primia_stream_t stream);
 /* spdz_compute (mpc/spdz.py:63-122), party j in {0,1}:
  *   mul   : z = delta*b + a*eps + c (+ delta*eps if j == 0), element-wise; b / eps hold nb
  *           elements and broadcast over the leading dims when nb < n;

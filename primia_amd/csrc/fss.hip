@@ -212,6 +212,61 @@ __global__ __launch_bounds__(256, 2) void dif_eval_kernel(int b, const u32* __re
     out[i] = (int64_t)acc;
 }
 
+// ---- fss.le for both parties hosted on this GPU (mpc/fss.py:97-185): mask_builder, the open and evaluate in ONE launch --
+// masked = ((x1_0 - x2_0 + alpha_0) + (x1_1 - x2_1 + alpha_1)) mod 2^32, then each party's DIF.eval of it with ITS seed
+// (blockIdx.y = party; the correction words are common).  x1 / x2 may be column ranges of a [rows][w] matrix (the
+// unrolled pool image): element i = (row i / len, column start + i % len); x1 == NULL stands for shares of zero (relu).
+struct LeOperand {
+    const u64 *p0, *p1;
+    int w, start;
+};
+__global__ __launch_bounds__(256, 2) void dif_eval_local_kernel(LeOperand x1, LeOperand x2, int len, const u64* __restrict__ alpha0,
+                                                               const u64* __restrict__ alpha1, const u64* __restrict__ s0_0,
+                                                               const u64* __restrict__ s0_1,
+                                                               const uint8_t* __restrict__ cw_bits,
+                                                               const u64* __restrict__ cw_sigma, const u64* __restrict__ cw_s,
+                                                               const int32_t* __restrict__ cw_leaf, int64_t* __restrict__ out0,
+                                                               int64_t* __restrict__ out1, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int b = blockIdx.y;
+    const long r = i / len, c = i - r * len;
+    const long i2 = r * x2.w + x2.start + c;
+    u64 m0 = alpha0[i] - x2.p0[i2], m1 = alpha1[i] - x2.p1[i2];
+    if (x1.p0) {
+        const long i1 = r * x1.w + x1.start + c;
+        m0 += x1.p0[i1];
+        m1 += x1.p1[i1];
+    }
+    const u32 xv = (u32)(m0 + m1);
+    const u64* __restrict__ s0 = b ? s0_1 : s0_0;
+    u64 sa = s0[i], sb = s0[n + i];
+    u64 t = (u64)b;
+    u64 acc = 0;
+    const long sgn = b ? -1 : 1;
+    for (int lvl = 0; lvl < 32; ++lvl) {
+        u64 buf[8];
+        sha512_seed(sa, sb, buf);
+        const int bit = (xv >> (31 - lvl)) & 1;
+        HSide hs = h_side(buf, bit);
+        const u64 m = (u64)0 - t;
+        const u32 cb = cw_bits[(long)lvl * n + i];
+        const u64 csg1 = cw_sigma[((long)lvl * 2 + 1) * n + i];
+        const u64 cs0 = cw_s[((long)lvl * 2 + 0) * n + i], cs1 = cw_s[((long)lvl * 2 + 1) * n + i];
+        const u64 ctau = (cb >> (2 * bit)) & 1, ct = (cb >> (2 * bit + 1)) & 1;
+        const u64 sg1 = hs.sg1 ^ (csg1 & m);
+        const u64 tau = hs.tau ^ (ctau & m);
+        sa = hs.s0 ^ (cs0 & m);
+        sb = hs.s1 ^ (cs1 & m);
+        t = hs.t ^ (ct & m);
+        const long leaf = (long)cw_leaf[(long)lvl * n + i];
+        acc += (u64)(sgn * ((long)tau * leaf + conv31(sg1)));
+    }
+    const long leaf = (long)cw_leaf[32L * n + i];
+    acc += (u64)(sgn * ((long)t * leaf + conv31(sb)));
+    (b ? out1 : out0)[i] = (int64_t)acc;
+}
+
 // ---- DPF.eval (fss.py:320-338) ------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void dpf_eval_kernel(int b, const u32* __restrict__ x, const u64* __restrict__ s0,
                                                        const uint8_t* __restrict__ cw_bits,
@@ -407,6 +462,23 @@ int primia_dif_eval(int b, const uint32_t* x, const uint64_t* s0, const uint8_t*
     if (n == 0) return PRIMIA_OK;
     dif_eval_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)st>>>(b, x, (const u64*)s0, cw_bits, (const u64*)cw_sigma,
                                                                     (const u64*)cw_s, cw_leaf, out, n);
+    return launch_status();
+}
+
+int primia_dif_eval_local(const int64_t* x1_0, const int64_t* x1_1, int w1, int start1, const int64_t* x2_0,
+                          const int64_t* x2_1, int w2, int start2, int len, const uint64_t* alpha0, const uint64_t* alpha1,
+                          const uint64_t* s0_0, const uint64_t* s0_1, const uint8_t* cw_bits, const uint64_t* cw_sigma,
+                          const uint64_t* cw_s, const int32_t* cw_leaf, int64_t* out0, int64_t* out1, int64_t n,
+                          primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(x2_0 && x2_1 && ((x1_0 == nullptr) == (x1_1 == nullptr)) && alpha0 && alpha1 && s0_0 && s0_1 && cw_bits &&
+                   cw_sigma && cw_s && cw_leaf && out0 && out1 && n > 0 && len > 0 && n % len == 0);
+    PRIMIA_REQUIRE(w2 >= len && start2 >= 0 && start2 + len <= w2 && (!x1_0 || (w1 >= len && start1 >= 0 && start1 + len <= w1)));
+    const dim3 grid((unsigned)ceil_div(n, 256), 2);
+    dif_eval_local_kernel<<<grid, 256, 0, (hipStream_t)st>>>(
+        LeOperand{(const u64*)x1_0, (const u64*)x1_1, w1, start1}, LeOperand{(const u64*)x2_0, (const u64*)x2_1, w2, start2}, len,
+        (const u64*)alpha0, (const u64*)alpha1, (const u64*)s0_0, (const u64*)s0_1, cw_bits, (const u64*)cw_sigma,
+        (const u64*)cw_s, cw_leaf, out0, out1, n);
     return launch_status();
 }
 

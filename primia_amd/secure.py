@@ -201,6 +201,17 @@ class SecureContext:
         self.stats = {"beaver_mul": 0, "beaver_matmul": 0, "dif_evals": 0}
         self.fuse_newton = True
         self._newton_tables, self._newton_calls = [], 0     # see _reciprocal_newton_fused
+        self._wt_cache = {}                                 # transposed weight shares of conv2d / linear (static per model)
+
+    # Both parties hosted here: a layer's mask -> open -> combine -> truncate -> re-layout chain runs as one pass over the
+    # shares of party 0 AND party 1 (csrc/secure_local.hip; an open is an addition of two values that sit side by side).
+    # The dealer's primitives are requested in exactly the order of the step-by-step chain, results are bit-identical;
+    # `local_fused = False` selects the chain (what a three-role run executes, where the opens are messages).
+    local_fused = True
+
+    @property
+    def _local(self):
+        return self.party is None and isinstance(self.opener, LocalOpener) and self.local_fused
 
     # ---- encode / share / reconstruct -----------------------------------------------------------
     def encode(self, x):
@@ -253,6 +264,15 @@ class SecureContext:
 
     # ---- local (per-share) ops -------------------------------------------------------------------
     def _ew(self, fn, a, b):
+        if self._local and fn in ("primia_ring_add", "primia_ring_sub"):
+            big, small = a[0], b[0]
+            if small.numel() > big.numel():
+                raise ValueError("second operand must not be larger")
+            o = [_empty_like(big), _empty_like(big)]
+            call("primia_ring_ew_2p", 0 if fn == "primia_ring_add" else 1, a[0], a[1], b[0], b[1], o[0], o[1], big.numel(),
+                 small.numel())
+            return o
+
         def one(j):
             big, small = (a[j], b[j])
             if small.numel() > big.numel():
@@ -305,6 +325,12 @@ class SecureContext:
             x, y, xr, yr = y, x, yr, xr
             t = [None if tj is None else (tj[1], tj[0], tj[2]) for tj in t]
         n, nb = xr.numel(), yr.numel()
+        if self._local:
+            out = [_empty_like(xr), _empty_like(xr)]
+            call("primia_fpt_mul_local", x[0], x[1], y[0], y[1], t[0][0], t[0][1], t[0][2], t[1][0], t[1][1], t[1][2],
+                 None, None, out[0], out[1], n, nb, 0 if trunc is None else int(trunc))
+            self.stats["beaver_mul"] += 1
+            return out
         d, e = [None, None], [None, None]
         for j in self.parties:  # spdz_mask
             d[j], e[j] = _empty_like(xr), _empty_like(yr)
@@ -333,6 +359,13 @@ class SecureContext:
         M, K = xr.shape[-2], xr.shape[-1]
         N = yr.shape[-1]
         t = self.dealer.triple("matmul", tuple(xr.shape), tuple(yr.shape))
+        if self._local:
+            out = [torch.empty(*xr.shape[:-1], N, dtype=I64, device=xr.device) for _ in range(2)]
+            scratch = torch.empty(M * K + 2 * K * N, dtype=I64, device=xr.device)
+            call("primia_beaver_matmul_local", x[0], x[1], y[0], y[1], t[0][0], t[0][1], t[0][2], t[1][0], t[1][1], t[1][2],
+                 out[0], out[1], scratch, M, K, N)
+            self.stats["beaver_matmul"] += 1
+            return out
         d, e = [None, None], [None, None]
         for j in self.parties:
             d[j], e[j] = _empty_like(xr), _empty_like(yr)
@@ -361,10 +394,25 @@ class SecureContext:
         return self.trunc(self.beaver_matmul(x, y), self.scale)
 
     # ---- FSS comparison ------------------------------------------------------------------------------
+    def _le_local(self, x1, x2, n, shape, cols1=(1, 0), cols2=(1, 0), length=1):
+        """fss.le with both parties here: mask_builder, the open and both DIF evaluations in one launch.  x1 = None stands
+        for shares of zero; colsK = (row width, first column) when operand K is a column range of a matrix."""
+        keys = self.dealer.dif_keys(n)
+        dev = x2[0].device
+        out = [torch.empty(shape, dtype=I64, device=dev), torch.empty(shape, dtype=I64, device=dev)]
+        k0, k1 = keys
+        call("primia_dif_eval_local", None if x1 is None else x1[0], None if x1 is None else x1[1], cols1[0], cols1[1],
+             x2[0], x2[1], cols2[0], cols2[1], length, k0["alpha"], k1["alpha"], k0["s0"], k1["s0"], k0["bits"],
+             k0["cw_sigma"], k0["cw_s"], k0["cw_leaf"], out[0], out[1], n)
+        self.stats["dif_evals"] += n
+        return out
+
     def le(self, x1, x2):
         """fss.le(x1, x2) (mpc/fss.py:97-185, 279): int64 shares of the bit [x1 <= x2]."""
         xr = self._ref(x1)
         n = xr.numel()
+        if self._local:
+            return self._le_local(x1, x2, n, tuple(xr.shape))
         keys = self.dealer.dif_keys(n)
         r = [None, None]
         for j in self.parties:  # mask_builder
@@ -388,6 +436,9 @@ class SecureContext:
 
     def relu(self, x):
         """AST.relu under fss (additive_shared.py:922-925): x * (x >= 0), (x >= 0) = le(x - x, x)."""
+        if self._local:      # le(x - x, x): the first operand is a sharing of zero (no launch for it)
+            xr = x[0]
+            return self.beaver_mul(x, self._le_local(None, x, xr.numel(), tuple(xr.shape)))
         zero = self.sub(x, x)
         return self.beaver_mul(x, self.le(zero, x))
 
@@ -395,6 +446,18 @@ class SecureContext:
         """left + (right >= left) * (right - left)  (nn/functional.py:494)."""
         bit = self.le(left, right)
         return self.add(left, self.beaver_mul(bit, self.sub(right, left)))
+
+    def _max_pair_cols(self, left, wl, sl, right, wr, sr, rows, length):
+        """_max_pair on column ranges (both parties here): comparison, Beaver product and the final add in two launches."""
+        n = rows * length
+        bit = self._le_local(left, right, n, (rows, length), (wl, sl), (wr, sr), length)
+        t = self.dealer.triple("mul", (rows, length), (rows, length))
+        dev = left[0].device
+        out = [torch.empty(rows, length, dtype=I64, device=dev), torch.empty(rows, length, dtype=I64, device=dev)]
+        call("primia_max_combine_local", bit[0], bit[1], left[0], left[1], wl, sl, right[0], right[1], wr, sr, t[0][0],
+             t[0][1], t[0][2], t[1][0], t[1][1], t[1][2], out[0], out[1], rows, length)
+        self.stats["beaver_mul"] += 1
+        return out
 
     def _cols(self, x, rows, w, start, length):
         def one(j):
@@ -412,6 +475,15 @@ class SecureContext:
         O, _, R, S = self._ref(w).shape
         Ho, Wo = (H + 2 * padding - R) // stride + 1, (W + 2 * padding - S) // stride + 1
         K = C * R * S
+        if self._local:
+            dev = x[0].device
+            im = [torch.empty(B, Ho * Wo, K, dtype=I64, device=dev), torch.empty(B, Ho * Wo, K, dtype=I64, device=dev)]
+            call("primia_im2col_syft_2p", x[0], x[1], im[0], im[1], B, C, H, W, R, S, stride, padding)
+            wt = self._weight_t(w, O, K)
+            res = self.beaver_matmul(im, wt)
+            out = [torch.empty(B, O, Ho, Wo, dtype=I64, device=dev), torch.empty(B, O, Ho, Wo, dtype=I64, device=dev)]
+            call("primia_trunc_col2out_2p", res[0], res[1], None, None, out[0], out[1], B, Ho * Wo, O, int(self.scale))
+            return out
         im, wt = [None, None], [None, None]
         for j in self.parties:
             a = torch.empty(B, Ho * Wo, K, dtype=I64, device=x[j].device)
@@ -429,6 +501,19 @@ class SecureContext:
             return o
 
         return self._each(one)
+
+    def _weight_t(self, w, O, K):
+        """weight.reshape(O, -1).t() of both parties' (static) weight shares, formed once per model."""
+        key = (w[0].data_ptr(), w[1].data_ptr(), O, K)
+        hit = self._wt_cache.get(key)
+        if hit is None:
+            hit = []
+            for j in (0, 1):
+                t = torch.empty(K, O, dtype=I64, device=w[j].device)
+                call("primia_col2out_syft", w[j], None, t, 1, O, K)
+                hit.append(t)
+            self._wt_cache[key] = hit
+        return hit
 
     def reciprocal_newton(self, v):
         """FPT.reciprocal(method="newton") (precision.py:507-518), C = 20, 80 iterations.
@@ -502,6 +587,21 @@ class SecureContext:
             call("primia_col2out_syft", x[j], None, o, 1, C, B * H * W)
             return o
 
+        if self._local:
+            if inv is None:
+                inv = self.reciprocal_newton(var)
+            import ctypes
+
+            HW = B * H * W
+            t1 = self.dealer.triple("mul", (C,), (HW, C))           # fpt_mul(inv, rows - mean)
+            t2 = self.dealer.triple("mul", (HW, C), (C,))           # fpt_mul(normalized, weight)
+            arr = lambda t: (ctypes.c_void_p * 6)(*[q.data_ptr() for q in (t[0][0], t[0][1], t[0][2], t[1][0], t[1][1], t[1][2])])
+            dev = x[0].device
+            out = [torch.empty(B, C, H, W, dtype=I64, device=dev), torch.empty(B, C, H, W, dtype=I64, device=dev)]
+            call("primia_bn_eval_local", x[0], x[1], mean[0], mean[1], inv[0], inv[1], weight[0], weight[1], bias[0], bias[1],
+                 arr(t1), arr(t2), out[0], out[1], C, HW, int(self.scale))
+            self.stats["beaver_mul"] += 2
+            return out
         rows = self._each(to_rows)
         if inv is None:
             inv = self.reciprocal_newton(var)
@@ -527,6 +627,15 @@ class SecureContext:
             call("primia_pool_unroll_syft", x[j], o, B, C, H, W, 3, 2, 1)
             return o
 
+        if self._local:
+            dev = x[0].device
+            im = [torch.empty(rows, 9, dtype=I64, device=dev), torch.empty(rows, 9, dtype=I64, device=dev)]
+            call("primia_pool_unroll_syft_2p", x[0], x[1], im[0], im[1], B, C, H, W, 3, 2, 1)
+            res = self._max_pair_cols(im, 9, 0, im, 9, 4, rows, 4)
+            res = self._max_pair_cols(res, 4, 0, res, 4, 2, rows, 2)
+            left = self._max_pair_cols(res, 2, 0, res, 2, 1, rows, 1)
+            res = self._max_pair_cols(left, 1, 0, im, 9, 8, rows, 1)
+            return [r.view(B, C, Ho, Wo) for r in res]
         im = self._each(unroll)
         res = self._max_pair(self._cols(im, rows, 9, 0, 4), self._cols(im, rows, 9, 4, 4))
         res = self._max_pair(self._cols(res, rows, 4, 0, 2), self._cols(res, rows, 4, 2, 2))
@@ -562,6 +671,8 @@ class SecureContext:
             call("primia_col2out_syft", w[j], None, t, 1, O, I)
             return t
 
+        if self._local:
+            return self.add(self.fpt_matmul(x, self._weight_t(w, O, I)), b)
         return self.add(self.fpt_matmul(x, self._each(tr)), b)
 
 

@@ -1,5 +1,5 @@
 import sys, os, collections
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from primia_amd import _lib, resnet_spec as rs
 from primia_amd.secure import Dealer, PreloadedDealer, SecureContext, SecureResNet18
