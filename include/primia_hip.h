@@ -453,6 +453,7 @@ int primia_bn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dp
  * pass of primia_bn_relu_maxpool_bwd moved into the operand staging of the weight-gradient kernel (the reference's
  * loss.backward() through conv1 <- bn1 <- relu <- maxpool, torchlib/models.py:466-471).  dw_acc is bit-identical to
  * the two-call chain.  bf16, H and W multiples of 32; PRIMIA_ERR_UNSUPPORTED otherwise (use the chain). */
+int primia_stem_bwd_fused_ok(int N, int H, int W, int dtype);
 int primia_stem_bwd_fused(const void* x_padded, const void* y, const void* dpooled, const uint8_t* argmax,
                           const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                           const float* dgamma, const float* dbeta, float* dw_acc, void* ws, int64_t ws_bytes, int N,

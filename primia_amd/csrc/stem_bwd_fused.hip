@@ -405,6 +405,14 @@ __global__ __launch_bounds__(1024) void stem_bwd_fused_kernel(StemFusedParams p)
 
 using namespace primia;
 
+// 1: primia_stem_bwd_fused serves this shape (the caller then skips the dy buffer altogether); 0: use the two-call chain
+extern "C" int primia_stem_bwd_fused_ok(int N, int H, int W, int dtype) {
+    if (dtype != PRIMIA_BF16 || N <= 0 || H <= 0 || W <= 0 || H % 32 != 0 || W % 32 != 0) return 0;
+    if ((long)N * (H + 6) * (W + 8) * 4 >= (1L << 31) || (long)N * (H / 2) * (W / 2) * 64 >= (1L << 31)) return 0;
+    int total, per_block, grid;
+    return stem_wgrad_halo_blocks(N, H, W, &total, &per_block, &grid) ? 1 : 0;
+}
+
 extern "C" int primia_stem_bwd_fused(const void* x_padded, const void* y, const void* dpooled, const uint8_t* argmax,
                                      const float* gamma, const float* beta, const float* save_mean,
                                      const float* save_invstd, const float* dgamma, const float* dbeta, float* dw_acc,

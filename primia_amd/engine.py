@@ -782,9 +782,11 @@ class ResNet18Engine:
         hw = self.stem_hw
         # the stem's tail in two launches less and without the dy tensor (411 MB at batch 256): bn1's backward sums at
         # pooled resolution, then conv1's weight gradient forming its dy tiles on the fly (primia_stem_bwd_fused)
+        if getattr(self, "_stem_bwd_fused_ok", None) is None:     # asked once: the library's own gate for this shape
+            S0 = self.spec.input_size
+            self._stem_bwd_fused_ok = query("primia_stem_bwd_fused_ok", N, S0, S0, self.dt) == 1
         stem_bwd_fused = (self._stem_fused and self._stem_padded and self.dp is None and self.stem_bwd_fused
-                          and self.wgrad_ws is not None and self.dtype == torch.bfloat16
-                          and self.spec.input_size % 32 == 0)
+                          and self.wgrad_ws is not None and self._stem_bwd_fused_ok)
         self.stem_bwd_fused_active = stem_bwd_fused
         if stem_bwd_fused:
             sm, si = self.save["bn1"]

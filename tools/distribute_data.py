@@ -58,19 +58,32 @@ def main(argv=None):
         shards = iid_round_robin_split(len(samples), a.num_workers, a.seed)
     else:
         shards = label_skew_split([c for _, c in samples], a.num_workers, a.label_skew, a.seed)
+    def rel(src, root, cls):
+        """Path below the class directory (files of nested sub-folders keep their sub-path: equal basenames do not
+        overwrite each other)."""
+        return os.path.relpath(src, os.path.join(root, cls))
+
+    def put(src, dst):
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        if os.path.lexists(dst) and dst in written:
+            raise SystemExit("two source images map to {:s}".format(dst))
+        written.add(dst)
+        place(src, dst, a.symbolic)
+
+    written = set()
     for i, idcs in enumerate(shards):
         for c in classes:
             os.makedirs(os.path.join(a.out, "worker{:d}".format(i + 1), c), exist_ok=True)
         for idx in idcs:
             src, ci = samples[idx]
-            place(src, os.path.join(a.out, "worker{:d}".format(i + 1), classes[ci], os.path.basename(src)), a.symbolic)
+            put(src, os.path.join(a.out, "worker{:d}".format(i + 1), classes[ci], rel(src, a.train_data_src, classes[ci])))
     n_val = 0
     if a.test_data_src and os.path.isdir(a.test_data_src):
         tclasses, tsamples = scan(a.test_data_src)
-        for c in classes:
+        for c in tclasses:
             os.makedirs(os.path.join(a.out, "validation", c), exist_ok=True)
         for src, ci in tsamples:
-            place(src, os.path.join(a.out, "validation", tclasses[ci], os.path.basename(src)), a.symbolic)
+            put(src, os.path.join(a.out, "validation", tclasses[ci], rel(src, a.test_data_src, tclasses[ci])))
         n_val = len(tsamples)
     print("{:d} training images -> {:s}; {:d} validation images".format(
         len(samples), ", ".join("worker{:d}: {:d}".format(i + 1, len(s)) for i, s in enumerate(shards)), n_val))
