@@ -143,6 +143,31 @@ int primia_stem_conv_fwd(const void* x_padded, const void* w_fwd, void* y, int N
 int primia_stem_conv_stat_slots(int N, int H, int W);
 int primia_stem_conv_fwd_stats(const void* x_padded, const void* w_fwd, void* y, float* stat_partials, int N, int H,
                                int W, int dtype, primia_stream_t stream);
+/* The stem's forward tail WITHOUT conv1's output (411 MB at batch 256; torchlib/models.py:466-471 conv1 -> bn1 -> relu ->
+ * maxpool), two passes over the padded input:
+ *   primia_stem_conv_stats  conv1's tiles -> bn1's partial sums [primia_stem_conv_stat_slots][2][64]; nothing stored
+ *   (finalize: primia_bn_finalize_stats)
+ *   primia_stem_conv_pool   conv1 recomputed -> scale / shift -> ReLU -> 3x3 / 2 max pool: pooled [N,H/4,W/4,64] + first-
+ *                           maximum codes, bit-identical to primia_bn_relu_maxpool_fwd_from_sums on a stored y; y != NULL
+ *                           also stores conv1's output (tests, and callers whose backward pass reads it).
+ * bf16, H and W multiples of 32, W <= 256 (primia_stem_conv_pool_ok). */
+int primia_stem_conv_stats(const void* x_padded, const void* w_fwd, float* stat_partials, int N, int H, int W, int dtype,
+                           primia_stream_t stream);
+int primia_stem_conv_pool_ok(int N, int H, int W, int dtype);
+int primia_stem_conv_pool(const void* x_padded, const void* w_fwd, void* y, void* pooled, uint8_t* argmax,
+                          const float* gamma, const float* beta, const float* save_mean, const float* save_invstd, int N,
+                          int H, int W, int dtype, primia_stream_t stream);
+/* nn.BatchNorm2d in eval mode: the whole stem head (conv1 -> bn1 -> relu -> maxpool, torchlib/models.py:466-471) in one
+ * pass over the input; equals primia_stem_conv_fwd -> primia_bn_fwd_eval -> primia_maxpool3x3s2_fwd bit for bit.  One block
+ * per image: pays from about 160 images per launch (below that the three-kernel chain fills the chip better). */
+int primia_stem_conv_pool_eval(const void* x_padded, const void* w_fwd, void* pooled, uint8_t* argmax, const float* gamma,
+                               const float* beta, const float* running_mean, const float* running_var, float eps, int N,
+                               int H, int W, int dtype, primia_stream_t stream);
+/* Batch statistics from partial sums [slots][2][C] alone (what the *_from_sums entry points run first): mean / invstd of
+ * M elements per channel, running statistics updated as nn.BatchNorm2d does (unbiased variance, momentum). */
+int primia_bn_finalize_stats(const float* sums, int slots, int64_t M, int C, float eps, float momentum,
+                             float* running_mean, float* running_var, float* save_mean, float* save_invstd,
+                             primia_stream_t stream);
 /* Weight gradient of conv1 from the same padded input (accumulates into dw_acc like primia_conv2d_wgrad). */
 int primia_stem_conv_wgrad(const void* x_padded, const void* dy, float* dw_acc, int N, int H, int W, int dtype,
                            primia_stream_t stream);

@@ -248,7 +248,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
             for (int i = 0; i < CH; ++i) v[i] = fmaxf(v[i], 0.f);
         }
-        *(u32x4*)(z + q * CH) = Chunk<T>::pack(v);
+        // (non-temporal: the activation is read again a kernel later from HBM / the Infinity Cache anyway, and not
+        // allocating it in the L2 is worth -0.5 % on the step — same-box A/B, profiles/r04_lh3_experiments.txt)
+        __builtin_nontemporal_store(Chunk<T>::pack(v), (u32x4*)(z + q * CH));
         if (mask_out) {
             unsigned m = 0;
 #pragma unroll
@@ -1342,6 +1344,15 @@ int primia_bn_relu_maxpool_fwd(const void* y, void* pooled, uint8_t* argmax, con
         return bn_relu_pool_fwd_impl<bf16>(y, pooled, argmax, gamma, beta, running_mean, running_var, save_mean,
                                            save_invstd, N, H, W, C, eps, momentum, (float*)workspace, st);
     return PRIMIA_ERR_ARG;
+}
+
+int primia_bn_finalize_stats(const float* sums, int slots, int64_t M, int C, float eps, float momentum, float* running_mean,
+                             float* running_var, float* save_mean, float* save_invstd, primia_stream_t stream) {
+    PRIMIA_REQUIRE(sums && slots >= 1 && M > 0 && C > 0 && save_mean && save_invstd);
+    PRIMIA_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, (hipStream_t)stream>>>(sums, slots, C, M, 0, eps, momentum, save_mean,
+                                                                                  save_invstd, running_mean, running_var);
+    return launch_status();
 }
 
 int primia_bn_relu_maxpool_fwd_from_sums(const void* y, void* pooled, uint8_t* argmax, const float* gamma,

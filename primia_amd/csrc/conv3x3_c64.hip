@@ -321,7 +321,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 v = *(const u32x4*)(sout + obuf * OUTB + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
             }
             if (live[q] && !((p.debug & 1) && v[0] != 12345u)) {
-                *(u32x4*)gp[q] = v;
+                *(u32x4*)gp[q] = v;      // (non-temporal stores: measured, no change — 4.862 vs 4.861 ms per step)
                 if (p.stat_partials) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {

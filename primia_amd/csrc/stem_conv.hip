@@ -180,7 +180,8 @@ __global__ __launch_bounds__(512) void stem_conv_fwd_kernel(StemFwdParams p) {
                 const int opix = wave * 16 + px;
                 const u32x4 v = *(const u32x4*)(sout + obuf * OUTB + q * 16384 + opix * 128 + ((c16 ^ ((opix >> 1) & 7)) << 4));
                 if (live) {
-                    *(u32x4*)(rowp + px * 64 + c16 * 8) = v;
+                    // (non-temporal: -0.2 % on the step, same-box A/B; y == NULL: statistics only, nothing is stored)
+                    if (p.y) __builtin_nontemporal_store(v, (u32x4*)(rowp + px * 64 + c16 * 8));
                     if (p.stat_partials) {
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -280,7 +281,7 @@ int primia_stem_pad_dims(int H, int W, int* Hp, int* Wp) {
 
 static int stem_conv_fwd_impl(const void* x_padded, const void* w_fwd, void* y, float* stat_partials, int N, int H,
                               int W, int dtype, primia_stream_t stream) {
-    PRIMIA_REQUIRE(x_padded && w_fwd && y && N > 0 && H > 0 && W > 0);
+    PRIMIA_REQUIRE(x_padded && w_fwd && (y || stat_partials) && N > 0 && H > 0 && W > 0);
     if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
     // 8 x 16 output patches must tile the output exactly (every legal PriMIA input size is a multiple of 32)
     if (H % 32 != 0 || W % 32 != 0) return PRIMIA_ERR_UNSUPPORTED;
@@ -313,6 +314,13 @@ int primia_stem_conv_fwd(const void* x_padded, const void* w_fwd, void* y, int N
 int primia_stem_conv_stat_slots(int N, int H, int W) {
     if (N <= 0 || H <= 0 || W <= 0 || H % 32 || W % 32) return PRIMIA_ERR_ARG;
     return stem_fwd_grid(N, H, W, nullptr);
+}
+
+// pass 1 of the stem without its activation (stem_fwd_fused.hip): conv1's tiles -> bn1's partial sums, nothing stored
+int primia_stem_conv_stats(const void* x_padded, const void* w_fwd, float* stat_partials, int N, int H, int W, int dtype,
+                           primia_stream_t stream) {
+    PRIMIA_REQUIRE(stat_partials);
+    return stem_conv_fwd_impl(x_padded, w_fwd, nullptr, stat_partials, N, H, W, dtype, stream);
 }
 
 int primia_stem_conv_fwd_stats(const void* x_padded, const void* w_fwd, void* y, float* stat_partials, int N, int H,

@@ -415,6 +415,17 @@ class ResNet18Engine:
             self._timed("fwd", c, lambda: call("primia_conv2d_fwd", c.desc, x, c.w_fwd, y, self.dt))
 
     fwd_pair = True
+    # eval mode, BatchNorm + max pooling: the stem head as one kernel (primia_stem_conv_pool_eval).  One block per image —
+    # from this batch size on it beats the three-kernel chain (178 us for any batch up to 256; the chain: 1.4 us per image)
+    stem_eval_one_pass_min_batch = 160
+
+    def _stem_eval_one_pass(self):
+        if self.training or self.norm != "batch" or self.spec.pooling != "max" or self.prof is not None:
+            return False
+        if self.N < self.stem_eval_one_pass_min_batch:
+            return False
+        S = self.spec.input_size
+        return query("primia_stem_conv_pool_ok", self.N, S, S, self.dt) == 1
 
     def _conv_fwd_pair(self, blk, x, y1, yd):
         """conv1 + downsample of a transition block as one launch; False where the library does not serve the pair."""
@@ -445,6 +456,7 @@ class ResNet18Engine:
         self._x0_valid = not self._stem_padded or (self.norm == "group" and self._stem_ws_bytes <= 0)
         if self._x0_valid:
             call("primia_nchw_to_nhwc", x_nchw, self.x0, N, self.spec.in_channels, S, S, 4, self.dt)
+        stem_done = False
         if self._stem_padded:
             call("primia_nchw_to_nhwc_padded", x_nchw, self.x0p, N, self.spec.in_channels, S, S, 4, 3, 3,
                  self.x0p_dims[0], self.x0p_dims[1], self.dt)
@@ -456,6 +468,13 @@ class ResNet18Engine:
                 self._timed("fwd", c, lambda: call("primia_stem_conv_fwd_stats", self.x0p, c.w_fwd, t["stem.y"],
                                                    self._stem_sums, N, S, S, self.dt))
                 self._stem_has_sums = True
+            elif self._stem_eval_one_pass():
+                # eval mode: conv1 -> bn1 -> relu -> maxpool as one pass over the input (neither stem tensor is written)
+                call("primia_stem_conv_pool_eval", self.x0p, c.w_fwd, t["pool.out"], self.pool_argmax,
+                     self.views["bn1.weight"], self.views["bn1.bias"], self.views["bn1.running_mean"],
+                     self.views["bn1.running_var"], BN_EPS, N, S, S, self.dt)
+                self._stem_has_sums = False
+                stem_done = True
             else:
                 self._timed("fwd", c, lambda: call("primia_stem_conv_fwd", self.x0p, c.w_fwd, t["stem.y"], N, S, S,
                                                    self.dt))
@@ -468,7 +487,9 @@ class ResNet18Engine:
         # GroupNorm: gn1 -> relu -> maxpool as one op each way (primia_gn_relu_maxpool_fwd / _bwd; _bwd wants even sizes)
         self._stem_fused_gn = (self.fuse_stem and self.gn_stem_fused and self.norm == "group"
                                and self.spec.pooling == "max" and hw % 2 == 0)
-        if self._stem_fused and getattr(self, "_stem_has_sums", False) and self._stem_padded:
+        if stem_done:
+            pass
+        elif self._stem_fused and getattr(self, "_stem_has_sums", False) and self._stem_padded:
             sm, si = self.save["bn1"]
             call("primia_bn_relu_maxpool_fwd_from_sums", t["stem.y"], t["pool.out"], self.pool_argmax,
                  self.views["bn1.weight"], self.views["bn1.bias"], self.views["bn1.running_mean"],
@@ -487,7 +508,7 @@ class ResNet18Engine:
                  self.views["bn1.bias"], sm, si, N, hw, hw, 64, self.groups, BN_EPS, self.bn_ws, self.bn_ws_bytes, self.dt)
         else:
             self._bn("conv1", t["stem.y"], t["stem.z"], None, True)
-        if self._stem_fused or self._stem_fused_gn:
+        if self._stem_fused or self._stem_fused_gn or stem_done:
             pass
         elif self.spec.pooling == "max":
             call("primia_maxpool3x3s2_fwd", t["stem.z"], t["pool.out"], self.pool_argmax, N, hw, hw, 64, self.dt)

@@ -819,6 +819,58 @@ def test_same_shape_layers_share_one_weight_gradient_launch(cuda, N, H, C, count
         assert relerr(a[i], single) < 2e-6, i
 
 
+@pytest.mark.parametrize("N,S", [(2, 64), (7, 224), (3, 96), (5, 32), (2, 256)])
+def test_stem_forward_without_its_activation(cuda, N, S):
+    """primia_stem_conv_stats -> primia_bn_finalize_stats -> primia_stem_conv_pool (conv1's output is never stored) against
+    primia_stem_conv_fwd_stats -> primia_bn_relu_maxpool_fwd_from_sums on a stored y: the same partial sums, statistics,
+    pooled activations and argmax codes BIT for bit; with y requested, the same conv output.  (5, 32): one patch per band
+    and per image row (every halo comes from the image border or a one-patch carry); (2, 256): eight patches per row."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(2000 + N + S)
+    x = rnd(torch.randn(N, 3, S, S, generator=g), dtype)
+    w = rnd(torch.randn(64, 3, 7, 7, generator=g) * 0.05, dtype)
+    desc = ConvDesc.make(N, S, S, 4, 64, 7, 7, 2, 3)
+    wf, _ = prep_weights(desc, w, dtype, cuda, 3, need_dgrad=False)
+    xp = torch.zeros(N * (S + 6) * (S + 8), 4, dtype=dtype, device=cuda)
+    call("primia_nchw_to_nhwc_padded", x.to(cuda), xp, N, 3, S, S, 4, 3, 3, S + 6, S + 8, dt)
+    Ho, Hq = S // 2, S // 4
+    M = N * Ho * Ho
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(cuda), (torch.randn(64, generator=g) * 0.3).to(cuda)
+    gamma[5] = -gamma[5]          # a negative scale: the maximum of z is then a minimum of y
+    slots = query("primia_stem_conv_stat_slots", N, S, S)
+    # the chain on a stored y
+    y0 = torch.empty(M, 64, dtype=dtype, device=cuda)
+    sums0 = torch.full((slots, 2, 64), float("nan"), device=cuda)
+    call("primia_stem_conv_fwd_stats", xp, wf, y0, sums0, N, S, S, dt)
+    rm0, rv0 = torch.zeros(64, device=cuda), torch.ones(64, device=cuda)
+    sm0, si0 = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+    p0 = torch.empty(N * Hq * Hq, 64, dtype=dtype, device=cuda)
+    a0 = torch.empty(N * Hq * Hq, 64, dtype=torch.uint8, device=cuda)
+    call("primia_bn_relu_maxpool_fwd_from_sums", y0, p0, a0, gamma, beta, rm0, rv0, sm0, si0, sums0, slots, N, Ho, Ho, 64, 1e-5,
+         0.1, dt)
+    # two passes over the input
+    assert query("primia_stem_conv_pool_ok", N, S, S, dt) == 1
+    sums1 = torch.full((slots, 2, 64), float("nan"), device=cuda)
+    call("primia_stem_conv_stats", xp, wf, sums1, N, S, S, dt)
+    assert torch.equal(sums1, sums0)
+    rm1, rv1 = torch.zeros(64, device=cuda), torch.ones(64, device=cuda)
+    sm1, si1 = torch.empty(64, device=cuda), torch.empty(64, device=cuda)
+    call("primia_bn_finalize_stats", sums1, slots, M, 64, 1e-5, 0.1, rm1, rv1, sm1, si1)
+    for a, b in ((sm1, sm0), (si1, si0), (rm1, rm0), (rv1, rv0)):
+        assert torch.equal(a, b)
+    for with_y in (False, True):
+        p1 = torch.full((N * Hq * Hq, 64), float("nan"), dtype=dtype, device=cuda)
+        a1 = torch.full((N * Hq * Hq, 64), 99, dtype=torch.uint8, device=cuda)
+        y1 = torch.full((M, 64), float("nan"), dtype=dtype, device=cuda) if with_y else None
+        call("primia_stem_conv_pool", xp, wf, y1, p1, a1, gamma, beta, sm1, si1, N, S, S, dt)
+        assert torch.equal(p1, p0), f"{int((p1 != p0).sum())} of {p0.numel()} pooled values differ"
+        assert torch.equal(a1, a0), f"{int((a1 != a0).sum())} argmax codes differ"
+        if with_y:
+            assert torch.equal(y1, y0)
+    assert int(a0.max()) <= 8 and float(p0.float().max()) > 0
+
+
 @pytest.mark.parametrize("N,S", [(2, 64), (75, 64), (3, 96), (5, 32)])
 def test_stem_backward_fused_is_bit_identical_to_the_chain(cuda, N, S):
     """primia_stem_bwd_fused (bn1 <- relu <- maxpool backward apply inside conv1's weight-gradient kernel, dy never

@@ -317,6 +317,36 @@ def test_state_dict_roundtrip_and_eval(cuda):
         eng.load_state_dict({"conv1.weight": sd["conv1.weight"]})
 
 
+@pytest.mark.parametrize("batch,size", [(160, 64), (5, 96)])
+def test_eval_stem_as_one_pass_equals_the_chain(cuda, batch, size):
+    """Eval mode, bf16: conv1 -> bn1 -> relu -> maxpool as ONE kernel over the input (primia_stem_conv_pool_eval; the
+    engine takes it from 160 images per batch) against primia_stem_conv_fwd -> primia_bn_fwd_eval ->
+    primia_maxpool3x3s2_fwd: same pooled tensor, same logits, bit for bit, on running statistics that are not (0, 1)."""
+    torch.manual_seed(11)
+    spec = rs.resnet18_spec(3, 3, size, "max")
+    sd = rs.init_state_dict(spec)
+    sd["bn1.running_mean"] = torch.randn(64) * 0.2
+    sd["bn1.running_var"] = torch.rand(64) + 0.3
+    sd["bn1.weight"] = torch.rand(64) + 0.5
+    sd["bn1.weight"][3] *= -1
+    sd["bn1.bias"] = torch.randn(64) * 0.3
+    x = torch.randn(batch, 3, size, size).to(cuda)
+    outs = []
+    for one_pass in (True, False):
+        eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.bfloat16, device=cuda)
+        eng.load_state_dict(sd)
+        eng.eval()
+        eng.stem_eval_one_pass_min_batch = 1 if one_pass else 10 ** 9
+        assert eng._stem_eval_one_pass() == one_pass
+        eng.t["stem.y"].fill_(float("nan"))
+        logits = eng.forward(x).clone()
+        assert bool(torch.isnan(eng.t["stem.y"].float()).all()) == one_pass      # conv1's output: never written
+        outs.append((logits, eng.t["pool.out"].clone()))
+    assert torch.equal(outs[0][1], outs[1][1])
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert float(outs[0][1].float().abs().max()) > 0
+
+
 @pytest.mark.parametrize("dtype,batch,size", [(torch.bfloat16, 16, 64), (torch.float32, 4, 64), (torch.bfloat16, 6, 96)])
 def test_training_step_is_bitwise_deterministic(cuda, dtype, batch, size):
     """Every weight gradient leaves through per-block partial tiles added in a fixed order (primia_conv2d_wgrad_ws,
