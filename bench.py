@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md
 GFLOP_PER_IMAGE = 10.881                            # SURVEY.md §8d (fwd 3.627 + bwd 7.254)
-TRAFFIC_FILE = "r03_hbm_traffic.json"               # rocprofv3 PMC passes over this command, see tools/hbm_traffic.py
+TRAFFIC_FILE = "r04_hbm_traffic.json"               # rocprofv3 PMC passes over this command, see tools/hbm_traffic.py
 
 
 def parse():
@@ -351,18 +351,24 @@ def main():
     dom = max(fam, key=lambda k: fam[k]["ms"])
     conv_ms = sum(d["ms"] for d in agg.values()) / nprof
     conv_fl = sum(d["flops"] for d in agg.values()) / nprof
-    # `traffic` needs PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes), which cannot be
-    # collected from inside the timed process: it is null here, and `traffic_offline` quotes the companion passes
-    # over this same command that are committed under profiles/ (file and kernel named, so the number can be checked).
+    # `traffic` needs PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, tools/profile_round.sh),
+    # which cannot be collected from inside the timed process.  The committed passes over this same command carry the
+    # sha256 of the library sources they ran (primia_amd.build.source_digest): `traffic` is their per-launch figure when
+    # that digest equals the one of the code running NOW, null otherwise (then `traffic_offline` still names the file,
+    # marked stale).
     traffic = None
     traffic_offline = None
     tpath = os.path.join(ROOT, "profiles", TRAFFIC_FILE)
     if os.path.exists(tpath) and a.batch == 256 and a.size == 224 and a.dtype == "bf16":
+        from primia_amd.build import source_digest
         rec = json.load(open(tpath))
         key = dom.split(" ")[0].split("<")[0]     # the kernel that ran; no record for it -> traffic_offline stays null
         if key in rec:
+            same = rec.get("_source_sha256") == source_digest()
             traffic_offline = {"hbm_bytes_per_launch": rec[key].get("hbm_bytes_per_launch"), "kernel": key,
-                               "source": "profiles/" + TRAFFIC_FILE}
+                               "source": "profiles/" + TRAFFIC_FILE, "same_sources_as_this_run": same}
+            if same:
+                traffic = rec[key].get("hbm_bytes_per_launch")
     roof = {"bound": "mfma", "kernel": dom,
             "launch": "median over %d steps of the HIP-event bracket around one C-ABI call (a weight-gradient call = the "
                       "kernel + its ordered reduce)" % nprof,

@@ -17,6 +17,23 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
 
 
+def source_digest(files=None):
+    """sha256 over the library's sources (csrc/*.hip, csrc/*.h, include/primia_hip.h; or the named csrc files only):
+    profiles recorded with rocprofv3 carry it, and bench.py quotes a counter from a profile only when the digest of the
+    code it is running equals the profile's."""
+    import hashlib
+
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))) if files is None else sorted(files)
+    paths = [os.path.join(CSRC, f) for f in names]
+    if files is None:
+        paths.append(os.path.join(HERE, "..", "include", "primia_hip.h"))
+    h = hashlib.sha256()
+    for q in paths:
+        h.update(os.path.basename(q).encode() + b"\0")
+        h.update(open(q, "rb").read())
+    return h.hexdigest()
+
+
 def _hipcc():
     for c in ("/opt/rocm/bin/hipcc", "hipcc"):
         if os.path.isabs(c) and os.path.exists(c):

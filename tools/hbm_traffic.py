@@ -35,4 +35,8 @@ for f in FAMS:
 res["_note"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over bench.py --steps 4 --warmup 1 --no-graph "
                 "--no-secure --no-cpu-baseline; FETCH_SIZE (KiB) doubled per MI355X_MICROARCH.md (gfx950 reports half of "
                 "wide coalesced reads); WRITE_SIZE uncalibrated; averages over all launches of a kernel family")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from primia_amd.build import source_digest  # noqa: E402
+res["_source_sha256"] = source_digest()      # the code these passes ran: bench.py quotes `traffic` only for this digest
 print(json.dumps(res, indent=1))
