@@ -351,12 +351,14 @@ def test_dp_step_bf16_at_224_against_oracle(cuda):
     assert kern["layer4.0.conv1"] == 22, kern
     for k in ("layer2.0.conv1", "layer2.0.downsample.0", "layer3.0.conv1", "layer3.0.downsample.0", "layer4.0.downsample.0"):
         assert kern[k] == 26, (k, kern[k])
-    C = 0.05       # clips most samples at this initialisation, not all of them
+    fresh = lambda: {k: v.clone() for k, v in sd.items()}
+    # the clipping norm: the oracle's median per-sample norm, so that half of the samples are clipped and half are not
+    _, norms_any, _ = O.dp_gradients(fresh(), x, y, 1.0, 0.0, None)
+    C = float(norms_any.median())
     eng.forward(x.to(cuda))
     eng.dp_loss_backward(y.to(cuda), C, 0.0, noise=torch.zeros(eng.P, device=cuda))
     got_norms = eng.dp_stats["sq_norms"].sqrt().cpu()
     got_clip = eng.dp_stats["clip"].cpu().double()
-    fresh = lambda: {k: v.clone() for k, v in sd.items()}
     want32, norms32, clip32 = O.dp_gradients(fresh(), x, y, C, 0.0, None)
     want16, norms16, clip16 = O.dp_gradients(fresh(), x, y, C, 0.0, None, bf16_storage=True)
     e32 = ((got_norms - norms32).abs() / norms32).max().item()
