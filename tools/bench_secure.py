@@ -86,9 +86,12 @@ def main():
     def fss_roofline():
         """The dominant secure kernel alone: fss.le of 2^20 comparisons for BOTH parties (primia_dif_eval_local: mask, open
         and 2 x 32 SHA-512 compressions per comparison; 1,204 bytes of key per comparison, read by both parties' threads).
-        Bound: vector-instruction ISSUE.  64-bit integer code runs on 32-bit vector instructions (add + add-with-carry,
-        v_alignbit rotates, v_bitop3 Ch / Maj); a wave64 vector instruction occupies its SIMD for 4 cycles, so the chip
-        issues at most 256 CUs x 4 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions per second (MI355X_MICROARCH.md).
+        Bound: vector-instruction ISSUE.  64-bit integer code runs on 32-bit vector instructions (v_lshl_add_u64 adds,
+        v_alignbit rotates, v_bitop3 Ch / Maj / xor3).  `peak` is the architectural issue rate: a SIMD-32 issues a wave64
+        vector instruction over 2 cycles, 256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1,228.8 G wave-instructions per second
+        (MI355X_MICROARCH.md, "Wave scheduling").  `mix_ceiling` is what the instructions THIS kernel is made of reach in
+        a register-only loop on the same chip (tools/micro/valu_rate.hip, profiles/r04_valu_issue_rate.txt): the
+        three-operand forms issue every ~4 cycles (518-584 G/s), two-operand adds / xors at 828-868 G/s.
         `achieved` = the kernel's COUNTED instructions per launch (SQ_INSTS_VALU of the committed PMC pass over this very
         command, profiles/r04_secure_valu_pmc.json) / the launch time measured here."""
         n = 1 << 20
@@ -112,7 +115,8 @@ def main():
             call("primia_dif_eval_local", *args)
         e1.record(); torch.cuda.synchronize()
         t = e0.elapsed_time(e1) / reps * 1e-3
-        peak = 256 * 4 * 2.4e9 / 4
+        peak = 256 * 4 * 2.4e9 / 2
+        mix_ceiling = 584.1e9      # v_bitop3_b32, the fastest of the kernel's three-operand instructions, alone
         pmc = valu_pmc()
         insts = (pmc or {}).get("dif_eval_local_kernel", {}).get("SQ_INSTS_VALU")
         rec = {"bound": "valu-issue", "kernel": "dif_eval_local_kernel", "peak": round(peak / 1e9, 1),
@@ -122,8 +126,12 @@ def main():
         if insts:
             rec.update(achieved=round(insts / t / 1e9, 1), frac=round(insts / t / peak, 4), insts_per_launch=int(insts),
                        insts_source="profiles/" + PMC_FILE,
-                       note="frac ~1.0-1.06: the kernel issues 0.26-0.27 vector instructions per SIMD and cycle where the "
-                            "4-cycle model allows 0.25 (a few of its instructions are cheaper): it sits on the issue limit")
+                       mix_ceiling=round(mix_ceiling / 1e9, 1), frac_of_mix_ceiling=round(insts / t / mix_ceiling, 4),
+                       note="three-operand integer instructions (80 % of this kernel: v_alignbit_b32, v_lshl_add_u64, "
+                            "v_bitop3_b32) issue every ~4 cycles, not 2: alone in a register-only loop they reach 518-584 G/s "
+                            "(profiles/r04_valu_issue_rate.txt).  frac_of_mix_ceiling > 1 because the other 20 % are "
+                            "two-operand instructions at 828-868 G/s: the kernel sits on its issue limit, only fewer "
+                            "instructions would make it faster")
         else:
             rec.update(achieved=None, frac=None, insts_source="no PMC record for this kernel: run tools/pmc_secure.sh")
         rec["valu_pmc"] = pmc

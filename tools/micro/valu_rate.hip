@@ -1,0 +1,86 @@
+// Issue rate of the integer vector instructions the FSS kernels are made of (csrc/fss.hip: v_alignbit_b32, v_lshl_add_u64,
+// v_bitop3_b32, v_add_u32, v_add_co/v_addc pairs), W waves per SIMD, CH independent chains per wave, no memory traffic.
+//   hipcc --offload-arch=gfx950 -O3 tools/micro/valu_rate.hip -o tools/micro/valu_rate
+// Prints wave-instructions per SIMD and cycle at the nominal 2.4 GHz, and the shader clock derived from s_memtime against
+// s_memrealtime (100 MHz) inside the same kernel.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+
+enum Op { ADD32, ALIGNBIT, LSHLADD64, BITOP3, ADD64PAIR, XOR32, MIX };
+
+template <int OP, int CH>
+__global__ __launch_bounds__(512) void k(uint64_t* out, int iters, uint64_t* clk) {
+    uint32_t a[CH], b[CH];
+    uint64_t q[CH];
+    for (int c = 0; c < CH; ++c) {
+        a[c] = threadIdx.x * 2654435761u + c;
+        b[c] = threadIdx.x * 40503u + 7 * c + 1;
+        q[c] = ((uint64_t)a[c] << 32) | b[c];
+    }
+    const uint64_t t0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                if (OP == ADD32) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]));
+                if (OP == XOR32) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]));
+                if (OP == ALIGNBIT) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[c]) : "v"(b[c]));
+                if (OP == BITOP3) asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(a[c]) : "v"(b[c]));
+                if (OP == LSHLADD64) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[c]) : "v"(q[(c + 1) % CH]));
+                if (OP == ADD64PAIR) {
+                    asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc"
+                                 : "+v"(a[c]), "+v"(b[c]) : "v"(b[(c + 1) % CH]), "v"(a[(c + 1) % CH]) : "vcc");
+                }
+                if (OP == MIX) {      // the SHA-512 round's proportions: 3 alignbit : 2 lshl_add_u64 : 2 bitop3
+                    asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[c]) : "v"(b[c]));
+                    asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[c]) : "v"(q[(c + 1) % CH]));
+                    asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(b[c]) : "v"(a[c]));
+                    asm volatile("v_alignbit_b32 %0, %0, %1, 9" : "+v"(a[c]) : "v"(b[c]));
+                    asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[c]) : "v"(q[(c + 2) % CH]));
+                    asm volatile("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96" : "+v"(b[c]) : "v"(a[c]));
+                    asm volatile("v_alignbit_b32 %0, %0, %1, 13" : "+v"(a[c]) : "v"(b[c]));
+                }
+            }
+        }
+    }
+    const uint64_t t1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    uint64_t s = 0;
+    for (int c = 0; c < CH; ++c) s += a[c] + b[c] + q[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = t1 - t0; clk[1] = w1 - w0; }
+}
+
+template <int OP, int CH>
+void run(const char* name, int threads, int per_iter) {
+    const int iters = 20000, grid = 256;
+    uint64_t *out, *clk;
+    hipMalloc(&out, (size_t)grid * threads * 8);
+    hipMalloc(&clk, 16);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<OP, CH><<<grid, threads>>>(out, 200, clk);
+    hipEventRecord(e0);
+    k<OP, CH><<<grid, threads>>>(out, iters, clk);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    uint64_t h[2]; hipMemcpy(h, clk, 16, hipMemcpyDeviceToHost);
+    const double insts = (double)iters * 8 * CH * per_iter * (threads / 64) * grid;       // wave-instructions
+    const double per_simd_cycle = insts / (1024.0 * 2.4e9 * ms * 1e-3);
+    printf("%-28s waves/SIMD=%d chains=%d: %.4f wave-instr / SIMD / cycle@2.4GHz (%.1f G/s)  s_memtime/s_memrealtime = %.2f -> %.0f MHz\n",
+           name, threads / 256, CH, per_simd_cycle, insts / ms / 1e6, (double)h[0] / h[1], 100.0 * h[0] / h[1]);
+    hipFree(out); hipFree(clk);
+}
+
+int main() {
+    run<ADD32, 8>("v_add_u32", 512, 1);
+    run<ADD32, 8>("v_add_u32", 256, 1);
+    run<XOR32, 8>("v_xor_b32", 512, 1);
+    run<ALIGNBIT, 8>("v_alignbit_b32", 512, 1);
+    run<BITOP3, 8>("v_bitop3_b32", 512, 1);
+    run<LSHLADD64, 8>("v_lshl_add_u64", 512, 1);
+    run<ADD64PAIR, 8>("v_add_co + v_addc", 512, 2);
+    run<MIX, 4>("SHA-512 mix 3:2:2", 512, 7);
+    run<MIX, 4>("SHA-512 mix 3:2:2", 1024, 7);
+    return 0;
+}
