@@ -356,6 +356,31 @@ int primia_warp_map_elastic(int H, int W, const double* field_x, const double* f
                             primia_stream_t stream);
 int primia_image_fog_u8(const uint8_t* in, int H, int W, int C, const int32_t* haze_xy, int n_haze, int hw, float alpha,
                         uint8_t* out, primia_stream_t stream);
+/* The rest of create_albu_transform's members (torchlib/dataloader.py:173-201; `yes` in configs/torch/
+ * pneumonia-resnet-pretrained-fast.ini).  InvertImg and Solarize are tables for primia_image_lut_u8.
+ *   primia_image_equalize_u8     a.Equalize(mode "cv", by_channels): cv2.equalizeHist per channel; workspace >= 3840 bytes.
+ *   primia_image_fill_rects_u8   F.cutout: rects[n][4] = (x1, y1, x2, y2) filled in place — a.Cutout's five holes,
+ *                                a.GridDropout's grid (both lists are built by the host from the reference's draws).
+ *   primia_image_swap_tiles_u8   F.swap_tiles_on_image (a.RandomGridShuffle): tiles[n][6] = (y, x, old_y, old_x, h, w).
+ *   primia_image_hsv_shift_u8    F._shift_hsv_uint8 (a.HueSaturationValue): cv2 RGB2HSV -> luts[3][256] (hue, saturation,
+ *                                value tables) -> cv2 HSV2RGB, 3 channels.
+ *   primia_image_shadow_u8       F.add_shadow (a.RandomShadow): lightness halved in HLS under the union of the polygons
+ *                                vertices[n_polygons][n_vertices][2] = (x, y), 3 channels.
+ *   primia_image_sun_flare_u8    F.add_sun_flare (a.RandomSunFlare): steps[n][6] = (x, y, radius, r, g, b) filled circles
+ *                                drawn onto the overlay, blended with alpha[k] / beta[k] after each; the overlay restarts
+ *                                from the output at step n_first (the main flare's 40 growing circles), 3 channels. */
+int primia_image_equalize_u8(const uint8_t* in, int H, int W, int C, void* workspace, int64_t workspace_bytes, uint8_t* out,
+                             primia_stream_t stream);
+int primia_image_fill_rects_u8(uint8_t* img, int H, int W, int C, const int32_t* rects, int n, int fill,
+                               primia_stream_t stream);
+int primia_image_swap_tiles_u8(const uint8_t* src, int H, int W, int C, const int32_t* tiles, int n, uint8_t* dst,
+                               primia_stream_t stream);
+int primia_image_hsv_shift_u8(const uint8_t* in, int H, int W, const uint8_t* luts3x256, uint8_t* out,
+                              primia_stream_t stream);
+int primia_image_shadow_u8(const uint8_t* in, int H, int W, const int32_t* vertices, int n_polygons, int n_vertices,
+                           uint8_t* out, primia_stream_t stream);
+int primia_image_sun_flare_u8(const uint8_t* in, int H, int W, const int32_t* steps, const float* alpha, const float* beta,
+                              int n_steps, int n_first, uint8_t* out, primia_stream_t stream);
 int primia_image_add_noise_u8(const uint8_t* in, const float* noise, int64_t n, uint8_t* out, primia_stream_t stream);
 int primia_image_finish(const uint8_t* in, int S, int C, const float* mean, const float* std, float* out,
                         primia_stream_t stream);

@@ -357,3 +357,313 @@ def box_blur_anchor(img, k):
         for dx in range(k):
             s += ext[dy:dy + H, dx:dx + W]
     return np.clip(np.rint(s.astype(np.float32) / np.float32(k * k)), 0, 255).astype(np.uint8)
+
+
+# ---- round 4, second batch: the nine remaining members of create_albu_transform (dataloader.py:173-201) --------------
+# RandomGridShuffle, HueSaturationValue, InvertImg, Cutout, RandomShadow, RandomSunFlare, Solarize, Equalize, GridDropout
+# (albumentations 0.4.6 augmentations/transforms.py + functional.py; OpenCV color_hsv.cpp, histogram.cpp).  Restated from
+# the published sources; where a raster rule of cv2's drawing functions is approximated it is said at the function.
+
+def invert_table():
+    """F.invert: 255 - img."""
+    return (255 - np.arange(256)).astype(np.uint8)
+
+
+def solarize_table(threshold=128):
+    """F.solarize (uint8): lut[i] = i if i < threshold else 255 - i."""
+    i = np.arange(256)
+    return np.where(i < threshold, i, 255 - i).astype(np.uint8)
+
+
+def equalize_table(hist):
+    """cv2.equalizeHist's table from a 256-bin histogram (imgproc/src/histogram.cpp, EqualizeHistLut_Invoker)."""
+    hist = np.asarray(hist, np.int64)
+    total = int(hist.sum())
+    i0 = int(np.nonzero(hist)[0][0])
+    lut = np.zeros(256, np.uint8)
+    if hist[i0] == total:
+        lut[:] = i0
+        return lut
+    scale = np.float32(255.0) / np.float32(total - hist[i0])
+    s = np.cumsum(hist[i0 + 1:]).astype(np.float32) * scale
+    lut[i0 + 1:] = np.clip(np.rint(s), 0, 255).astype(np.uint8)
+    return lut
+
+
+def equalize(img):
+    """F.equalize(mode='cv', by_channels=True): cv2.equalizeHist per channel."""
+    out = np.empty_like(img)
+    planes = img.reshape(img.shape[0], img.shape[1], -1)
+    o = out.reshape(planes.shape)
+    for c in range(planes.shape[2]):
+        o[..., c] = equalize_table(np.bincount(planes[..., c].reshape(-1), minlength=256))[planes[..., c]]
+    return out
+
+
+def cutout_holes(H, W, rng, num_holes=5, max_h_size=80, max_w_size=80):
+    """a.Cutout.get_params_dependent_on_targets: (x1, y1, x2, y2) per hole, Python's `random` stream."""
+    holes = []
+    for _ in range(num_holes):
+        y, x = rng.randint(0, H), rng.randint(0, W)
+        y1 = int(np.clip(y - max_h_size // 2, 0, H))
+        y2 = int(np.clip(y1 + max_h_size, 0, H))
+        x1 = int(np.clip(x - max_w_size // 2, 0, W))
+        x2 = int(np.clip(x1 + max_w_size, 0, W))
+        holes.append((x1, y1, x2, y2))
+    return holes
+
+
+def grid_dropout_holes(H, W, ratio=0.5):
+    """a.GridDropout defaults (no unit size limits, no hole counts, shift 0, no random offset): the hole rectangles."""
+    unit_w = max(2, W // 10)
+    unit_h = max(min(unit_w, H), 2)
+    hole_w = min(max(int(unit_w * ratio), 1), unit_w - 1)
+    hole_h = min(max(int(unit_h * ratio), 1), unit_h - 1)
+    holes = []
+    for i in range(W // unit_w + 1):
+        for j in range(H // unit_h + 1):
+            x1, y1 = min(unit_w * i, W), min(unit_h * j, H)
+            holes.append((x1, y1, min(x1 + hole_w, W), min(y1 + hole_h, H)))
+    return holes
+
+
+def fill_rects(img, holes, fill=0):
+    """F.cutout: img[y1:y2, x1:x2] = fill_value."""
+    out = img.copy()
+    for x1, y1, x2, y2 in holes:
+        out[y1:y2, x1:x2] = fill
+    return out
+
+
+def grid_shuffle_tiles(H, W, seed, grid=(3, 3)):
+    """a.RandomGridShuffle.get_params_dependent_on_targets: rows of (y, x, old_y, old_x, height, width)."""
+    n, m = grid
+    rs = np.random.RandomState(seed)
+    hs = np.linspace(0, H, n + 1, dtype=np.int64)
+    ws = np.linspace(0, W, m + 1, dtype=np.int64)
+    hm, wm = np.meshgrid(hs, ws, indexing="ij")
+    ih, iw = hm[:-1, :-1], wm[:-1, :-1]
+    sizes = np.stack((hm[1:, 1:] - ih, wm[1:, 1:] - iw), axis=2)
+    new_index = np.stack(np.indices((n, m)), axis=2)
+    for size in np.unique(sizes.reshape(-1, 2), axis=0):
+        eq = np.all(sizes == size, axis=2)
+        new_index[eq] = rs.permutation(new_index[eq])
+    a, b = new_index[..., 0], new_index[..., 1]
+    return np.stack([ih.reshape(-1), iw.reshape(-1), ih[a, b].reshape(-1), iw[a, b].reshape(-1),
+                     sizes[..., 0].reshape(-1), sizes[..., 1].reshape(-1)], axis=1).astype(np.int32)
+
+
+def swap_tiles(img, tiles):
+    """F.swap_tiles_on_image."""
+    out = img.copy()
+    for y, x, oy, ox, h, w in tiles:
+        out[y:y + h, x:x + w] = img[oy:oy + h, ox:ox + w]
+    return out
+
+
+_HSV_SHIFT = 12
+_SDIV = np.zeros(256, np.int64)
+_HDIV180 = np.zeros(256, np.int64)
+_SDIV[1:] = np.rint((255 << _HSV_SHIFT) / (1.0 * np.arange(1, 256))).astype(np.int64)
+_HDIV180[1:] = np.rint((180 << _HSV_SHIFT) / (6.0 * np.arange(1, 256))).astype(np.int64)
+
+
+def rgb2hsv_u8(img):
+    """cv2.cvtColor(COLOR_RGB2HSV) on uint8 (color_hsv.cpp RGB2HSV_b, hrange 180): 12-bit fixed-point division tables."""
+    r, g, b = [img[..., i].astype(np.int64) for i in range(3)]
+    v = np.maximum(np.maximum(r, g), b)
+    vmin = np.minimum(np.minimum(r, g), b)
+    diff = v - vmin
+    s = (diff * _SDIV[v] + (1 << (_HSV_SHIFT - 1))) >> _HSV_SHIFT
+    h = np.where(v == r, g - b, np.where(v == g, b - r + 2 * diff, r - g + 4 * diff))
+    h = (h * _HDIV180[diff] + (1 << (_HSV_SHIFT - 1))) >> _HSV_SHIFT
+    h = np.where(h < 0, h + 180, h)
+    return np.stack([h, s, v], axis=-1).astype(np.uint8)
+
+
+_SECTOR = np.array([[1, 3, 0], [1, 0, 2], [3, 0, 1], [0, 2, 1], [0, 1, 3], [2, 1, 0]])
+
+
+def _sector_rgb(tab, sector):
+    """(b, g, r) = tab[sector_data[sector][0..2]] of OpenCV's HSV2RGB_f / HLS2RGB_f; returns (r, g, b)."""
+    pick = lambda k: np.take_along_axis(tab, _SECTOR[sector][..., k][..., None], axis=-1)[..., 0]
+    return pick(2), pick(1), pick(0)
+
+
+def hsv2rgb_u8(hsv):
+    """cv2.cvtColor(COLOR_HSV2RGB) on uint8: HSV2RGB_f in float32 on (h, s / 255, v / 255), x 255, round, saturate."""
+    f = np.float32
+    h = hsv[..., 0].astype(f) * f(6.0 / 180.0)
+    s = hsv[..., 1].astype(f) * f(1.0 / 255.0)
+    v = hsv[..., 2].astype(f) * f(1.0 / 255.0)
+    h = np.where(h >= 6, h - f(6), h)
+    sector = np.floor(h).astype(np.int64)
+    hf = h - sector.astype(f)
+    bad = (sector < 0) | (sector >= 6)
+    sector, hf = np.where(bad, 0, sector), np.where(bad, f(0), hf)
+    tab = np.stack([v, v * (f(1) - s), v * (f(1) - s * hf), v * (f(1) - s * (f(1) - hf))], axis=-1).astype(f)
+    r, g, b = _sector_rgb(tab, sector)
+    grey = s == 0
+    out = [np.where(grey, v, c) for c in (r, g, b)]
+    return np.stack([np.clip(np.rint(c * f(255)), 0, 255) for c in out], axis=-1).astype(np.uint8)
+
+
+def shift_hsv(img, hue_shift, sat_shift, val_shift):
+    """F._shift_hsv_uint8: RGB -> HSV, three cv2.LUT tables, HSV -> RGB."""
+    hsv = rgb2hsv_u8(img)
+    i = np.arange(256, dtype=np.int16)
+    lut_h = np.mod(i + hue_shift, 180).astype(np.uint8)
+    lut_s = np.clip(i + sat_shift, 0, 255).astype(np.uint8)
+    lut_v = np.clip(i + val_shift, 0, 255).astype(np.uint8)
+    return hsv2rgb_u8(np.stack([lut_h[hsv[..., 0]], lut_s[hsv[..., 1]], lut_v[hsv[..., 2]]], axis=-1)), (lut_h, lut_s, lut_v)
+
+
+def rgb2hls_u8(img):
+    """cv2.cvtColor(COLOR_RGB2HLS) on uint8: RGB2HLS_f in float32 on x / 255, then (h / 2, l * 255, s * 255) rounded."""
+    f = np.float32
+    r, g, b = [img[..., i].astype(f) * f(1.0 / 255.0) for i in range(3)]
+    vmax = np.maximum(np.maximum(r, g), b)
+    vmin = np.minimum(np.minimum(r, g), b)
+    diff = (vmax - vmin).astype(f)
+    l = ((vmax + vmin) * f(0.5)).astype(f)
+    has = diff > np.finfo(f).eps
+    safe = np.where(has, diff, f(1))
+    s = np.where(l < f(0.5), diff / np.where(has, vmax + vmin, f(1)), diff / np.where(has, f(2) - vmax - vmin, f(1))).astype(f)
+    d60 = (f(60.0) / safe).astype(f)
+    h = np.where(vmax == r, (g - b) * d60, np.where(vmax == g, (b - r) * d60 + f(120), (r - g) * d60 + f(240))).astype(f)
+    h = np.where(h < 0, h + f(360), h)
+    h, s = np.where(has, h, f(0)), np.where(has, s, f(0))
+    cv = lambda x: np.clip(np.rint(x), 0, 255)
+    return np.stack([cv(h * f(0.5)), cv(l * f(255)), cv(s * f(255))], axis=-1).astype(np.uint8)
+
+
+def hls2rgb_u8(hls):
+    """cv2.cvtColor(COLOR_HLS2RGB) on uint8: HLS2RGB_f in float32 on (h, l / 255, s / 255)."""
+    f = np.float32
+    h = hls[..., 0].astype(f) * f(6.0 / 180.0)
+    l = hls[..., 1].astype(f) * f(1.0 / 255.0)
+    s = hls[..., 2].astype(f) * f(1.0 / 255.0)
+    p2 = np.where(l <= f(0.5), l * (f(1) + s), l + s - l * s).astype(f)
+    p1 = (f(2) * l - p2).astype(f)
+    h = np.where(h >= 6, h - f(6), h)
+    sector = np.floor(h).astype(np.int64)
+    hf = h - sector.astype(f)
+    bad = (sector < 0) | (sector >= 6)
+    sector, hf = np.where(bad, 0, sector), np.where(bad, f(0), hf)
+    tab = np.stack([p2, p1, p1 + (p2 - p1) * (f(1) - hf), p1 + (p2 - p1) * hf], axis=-1).astype(f)
+    r, g, b = _sector_rgb(tab, sector)
+    grey = s == 0
+    out = [np.where(grey, l, c) for c in (r, g, b)]
+    return np.stack([np.clip(np.rint(c * f(255)), 0, 255) for c in out], axis=-1).astype(np.uint8)
+
+
+def shadow_vertices(H, W, rng, shadow_roi=(0, 0.5, 1, 1), lower=1, upper=2, dimension=5):
+    """a.RandomShadow.get_params_dependent_on_targets: [num_shadows][dimension][2] (x, y) vertices."""
+    n = rng.randint(lower, upper)
+    x_min, y_min, x_max, y_max = shadow_roi
+    x_min, x_max, y_min, y_max = int(x_min * W), int(x_max * W), int(y_min * H), int(y_max * H)
+    return np.array([[(rng.randint(x_min, x_max), rng.randint(y_min, y_max)) for _ in range(dimension)] for _ in range(n)],
+                    np.int32)
+
+
+def polygon_mask(H, W, verts):
+    """The pixels cv2.fillPoly(mask, [verts], 255) sets, restated as: even-odd interior test at integer pixel coordinates
+    (an edge counts for rows y0 <= y < y1) OR on one of the polygon's edges drawn as a DDA line (minor coordinate rounded
+    half up).  cv2's fixed-point scanline may differ from this rule on individual boundary pixels."""
+    ys, xs = np.mgrid[0:H, 0:W]
+    inside = np.zeros((H, W), bool)
+    edge = np.zeros((H, W), bool)
+    n = len(verts)
+    for k in range(n):
+        x0, y0 = [int(v) for v in verts[k]]
+        x1, y1 = [int(v) for v in verts[(k + 1) % n]]
+        if y0 != y1:
+            dy = y1 - y0
+            strad = (y0 <= ys) != (y1 <= ys)
+            lhs, rhs = xs * dy, x0 * dy + (ys - y0) * (x1 - x0)
+            inside ^= strad & (lhs < rhs if dy > 0 else lhs > rhs)
+        adx, ady = abs(x1 - x0), abs(y1 - y0)
+        if adx >= ady:
+            (xa, ya), (xb, yb) = ((x0, y0), (x1, y1)) if x0 <= x1 else ((x1, y1), (x0, y0))
+            d = xb - xa
+            if d == 0:
+                edge |= (xs == xa) & (ys == ya)
+            else:
+                yy = ya + np.floor_divide(2 * (xs - xa) * (yb - ya) + d, 2 * d)
+                edge |= (xs >= xa) & (xs <= xb) & (ys == yy)
+        else:
+            (xa, ya), (xb, yb) = ((x0, y0), (x1, y1)) if y0 <= y1 else ((x1, y1), (x0, y0))
+            d = yb - ya
+            xx = xa + np.floor_divide(2 * (ys - ya) * (xb - xa) + d, 2 * d)
+            edge |= (ys >= ya) & (ys <= yb) & (xs == xx)
+    return inside | edge
+
+
+def add_shadow(img, vertices_list):
+    """F.add_shadow: RGB -> HLS, L *= 0.5 (stored back into uint8: truncation) under the union of the polygons, HLS -> RGB."""
+    H, W = img.shape[:2]
+    hls = rgb2hls_u8(img)
+    mask = np.zeros((H, W), bool)
+    for verts in vertices_list:
+        mask |= polygon_mask(H, W, verts)
+    hls[..., 1] = np.where(mask, hls[..., 1] >> 1, hls[..., 1])
+    return hls2rgb_u8(hls)
+
+
+def sun_flare_params(H, W, rng, flare_roi=(0, 0, 1, 0.5), angle_lower=0.0, angle_upper=1.0, circles_lower=6,
+                     circles_upper=10, src_radius=400, src_color=(255, 255, 255)):
+    """a.RandomSunFlare.get_params_dependent_on_targets: the small circles, the flare centre."""
+    import math
+
+    angle = 2 * math.pi * rng.uniform(angle_lower, angle_upper)
+    lx, ly, ux, uy = flare_roi
+    cx, cy = rng.uniform(lx, ux), rng.uniform(ly, uy)
+    cx, cy = int(W * cx), int(H * cy)
+    num = rng.randint(circles_lower, circles_upper)
+    xs, ys = [], []
+    for rx in range(0, W, 10):
+        ry = math.tan(angle) * (rx - cx) + cy
+        xs.append(rx)
+        ys.append(2 * cy - ry)
+    circles = []
+    for _ in range(num):
+        alpha = rng.uniform(0.05, 0.2)
+        r = rng.randint(0, len(xs) - 1)
+        rad = rng.randint(1, max(H // 100 - 2, 2))
+        col = tuple(rng.randint(max(c - 50, 0), c) for c in src_color)
+        circles.append((alpha, (int(xs[r]), int(ys[r])), rad ** 3, col))
+    return cx, cy, circles
+
+
+def sun_flare_steps(cx, cy, circles, src_radius=400, src_color=(255, 255, 255)):
+    """F.add_sun_flare as a flat list of (x, y, radius, r, g, b), weights, and the index where `overlay = output.copy()`."""
+    geo = [(x, y, rad, *col) for _, (x, y), rad, col in circles]
+    alpha = [a for a, *_ in circles]
+    n_first = len(geo)
+    num_times = src_radius // 10
+    al = np.linspace(0.0, 1, num=num_times)
+    rad = np.linspace(1, src_radius, num=num_times)
+    for i in range(num_times):
+        geo.append((cx, cy, int(rad[i]), *src_color))
+        alpha.append(al[num_times - i - 1] ** 3)
+    return np.array(geo, np.int32).reshape(-1, 6), np.array(alpha, np.float64), n_first
+
+
+def add_sun_flare(img, cx, cy, circles, src_radius=400, src_color=(255, 255, 255)):
+    """F.add_sun_flare: cv2.circle(filled) onto `overlay`, cv2.addWeighted(overlay, a, output, 1 - a, 0, output) after
+    every circle.  A filled circle is restated as the disc dx^2 + dy^2 <= r^2 (cv2's midpoint raster differs on
+    individual rim pixels); addWeighted in float32, rounded half to even, saturated."""
+    geo, alpha, n_first = sun_flare_steps(cx, cy, circles, src_radius, src_color)
+    f = np.float32
+    H, W = img.shape[:2]
+    ys, xs = np.mgrid[0:H, 0:W]
+    overlay, output = img.astype(f), img.astype(f)
+    for k in range(len(geo)):
+        if k == n_first:
+            overlay = output.copy()
+        x, y, r = [int(v) for v in geo[k, :3]]
+        inside = (xs - x).astype(np.int64) ** 2 + (ys - y).astype(np.int64) ** 2 <= r * r
+        overlay = np.where(inside[..., None], geo[k, 3:6].astype(f), overlay)
+        a, b = f(alpha[k]), f(1.0 - alpha[k])
+        output = np.clip(np.rint(overlay * a + output * b), 0, 255).astype(f)
+    return output.astype(np.uint8)

@@ -6,12 +6,11 @@ image arithmetic on the GPU (csrc/augment.hip) and the random PARAMETERS drawn o
     a.Compose([a.VerticalFlip, a.RandomGamma, a.RandomBrightness, a.Blur, ..., a.GaussNoise], p = albu_prob)
     a.ToFloat(255) -> a.Normalize(mean, std, 1.0)
 
-Built: RandomAffine, Resize, RandomCrop, CLAHE, VerticalFlip, RandomGamma, RandomBrightness, Blur, ElasticTransform,
-OpticalDistortion, GridDistortion, RandomFog, GaussNoise, ToFloat, Normalize — every member the reference's shipped
-preset (configs/torch/pneumonia-resnet-pretrained.ini) switches on.  NOT built: grid_shuffle, hsv, invert, cutout,
-shadow, sun_flare, solarize, equalize, grid_dropout (all `no` in the shipped presets) — a configuration that enables one
-of them is REFUSED (`unsupported(args)`), unless PRIMIA_SKIP_UNSUPPORTED_AUG=1 asks to train without them (a warning
-names what was dropped).
+Built: every member of create_albu_transform — RandomAffine, Resize, RandomCrop, CLAHE, VerticalFlip, RandomGamma,
+RandomBrightness, Blur, ElasticTransform, OpticalDistortion, GridDistortion, RandomGridShuffle, HueSaturationValue,
+InvertImg, Cutout, RandomShadow, RandomFog, RandomSunFlare, Solarize, Equalize, GridDropout, GaussNoise, ToFloat,
+Normalize — so both shipped presets (configs/torch/pneumonia-resnet-pretrained.ini and ...-fast.ini, which switches every
+one of them on) run as written.  `UNBUILT` is empty; `check(args)` stays as the place a future gap would be refused.
 
 The three warping transforms are `cv2.remap` with a generated coordinate field (albumentations 0.4.6, the release the
 reference pins: functional.py elastic_transform / optical_distortion / grid_distortion): the host draws their few
@@ -33,7 +32,7 @@ import torch
 
 from ._lib import call, query
 
-UNBUILT = ("grid_shuffle", "hsv", "invert", "cutout", "shadow", "sun_flare", "solarize", "equalize", "grid_dropout")
+UNBUILT = ()
 
 
 def unsupported(args):
@@ -132,6 +131,105 @@ def fog_params(H, W, rng, fog_coef_lower=0.3, fog_coef_upper=1.0):
     return fog_coef, haze
 
 
+def cutout_holes(H, W, rng, num_holes=5, max_h_size=80, max_w_size=80):
+    """a.Cutout.get_params_dependent_on_targets (dataloader.py:178-182: 5 holes of at most 80 x 80)."""
+    holes = []
+    for _ in range(num_holes):
+        y, x = rng.randint(0, H), rng.randint(0, W)
+        y1 = min(max(y - max_h_size // 2, 0), H)
+        y2 = min(max(y1 + max_h_size, 0), H)
+        x1 = min(max(x - max_w_size // 2, 0), W)
+        x2 = min(max(x1 + max_w_size, 0), W)
+        holes.append((x1, y1, x2, y2))
+    return holes
+
+
+def grid_dropout_holes(H, W, ratio=0.5):
+    """a.GridDropout with its defaults: unit = max(2, W // 10), holes of ratio x unit at the unit grid's corners."""
+    unit_w = max(2, W // 10)
+    unit_h = max(min(unit_w, H), 2)
+    hole_w = min(max(int(unit_w * ratio), 1), unit_w - 1)
+    hole_h = min(max(int(unit_h * ratio), 1), unit_h - 1)
+    holes = []
+    for i in range(W // unit_w + 1):
+        for j in range(H // unit_h + 1):
+            x1, y1 = min(unit_w * i, W), min(unit_h * j, H)
+            holes.append((x1, y1, min(x1 + hole_w, W), min(y1 + hole_h, H)))
+    return holes
+
+
+def grid_shuffle_tiles(H, W, seed, grid=(3, 3)):
+    """a.RandomGridShuffle.get_params_dependent_on_targets: tiles of equal shape are permuted among themselves by
+    np.random.RandomState(seed); rows (y, x, old_y, old_x, height, width)."""
+    n, m = grid
+    rs = np.random.RandomState(seed)
+    hs = np.linspace(0, H, n + 1, dtype=np.int64)
+    ws = np.linspace(0, W, m + 1, dtype=np.int64)
+    hm, wm = np.meshgrid(hs, ws, indexing="ij")
+    ih, iw = hm[:-1, :-1], wm[:-1, :-1]
+    sizes = np.stack((hm[1:, 1:] - ih, wm[1:, 1:] - iw), axis=2)
+    new_index = np.stack(np.indices((n, m)), axis=2)
+    for size in np.unique(sizes.reshape(-1, 2), axis=0):
+        eq = np.all(sizes == size, axis=2)
+        new_index[eq] = rs.permutation(new_index[eq])
+    a, b = new_index[..., 0], new_index[..., 1]
+    return np.stack([ih.reshape(-1), iw.reshape(-1), ih[a, b].reshape(-1), iw[a, b].reshape(-1),
+                     sizes[..., 0].reshape(-1), sizes[..., 1].reshape(-1)], axis=1).astype(np.int32)
+
+
+def hsv_tables(hue_shift, sat_shift, val_shift):
+    """F._shift_hsv_uint8's three cv2.LUT tables (hue mod 180; saturation and value clipped)."""
+    i = np.arange(256, dtype=np.int16)
+    return np.stack([np.mod(i + hue_shift, 180).astype(np.uint8), np.clip(i + sat_shift, 0, 255).astype(np.uint8),
+                     np.clip(i + val_shift, 0, 255).astype(np.uint8)])
+
+
+def solarize_table(threshold):
+    i = np.arange(256)
+    return np.where(i < threshold, i, 255 - i).astype(np.uint8)
+
+
+def shadow_vertices(H, W, rng, shadow_roi=(0, 0.5, 1, 1), lower=1, upper=2, dimension=5):
+    """a.RandomShadow.get_params_dependent_on_targets: [num_shadows][5][(x, y)] in the lower half of the image."""
+    n = rng.randint(lower, upper)
+    x_min, y_min, x_max, y_max = shadow_roi
+    x_min, x_max, y_min, y_max = int(x_min * W), int(x_max * W), int(y_min * H), int(y_max * H)
+    return np.array([[(rng.randint(x_min, x_max), rng.randint(y_min, y_max)) for _ in range(dimension)] for _ in range(n)],
+                    np.int32)
+
+
+def sun_flare_steps(H, W, rng, flare_roi=(0, 0, 1, 0.5), angle_lower=0.0, angle_upper=1.0, circles_lower=6,
+                    circles_upper=10, src_radius=400, src_color=(255, 255, 255)):
+    """a.RandomSunFlare.get_params_dependent_on_targets + the drawing schedule of F.add_sun_flare: rows
+    (x, y, radius, r, g, b), their blend weights, and the step at which the overlay restarts from the output."""
+    angle = 2 * math.pi * rng.uniform(angle_lower, angle_upper)
+    lx, ly, ux, uy = flare_roi
+    cx, cy = rng.uniform(lx, ux), rng.uniform(ly, uy)
+    cx, cy = int(W * cx), int(H * cy)
+    num = rng.randint(circles_lower, circles_upper)
+    xs, ys = [], []
+    for rx in range(0, W, 10):
+        xs.append(rx)
+        ys.append(2 * cy - (math.tan(angle) * (rx - cx) + cy))
+    geo, alpha = [], []
+    for _ in range(num):
+        a = rng.uniform(0.05, 0.2)
+        r = rng.randint(0, len(xs) - 1)
+        rad = rng.randint(1, max(H // 100 - 2, 2))
+        col = tuple(rng.randint(max(c - 50, 0), c) for c in src_color)
+        geo.append((int(xs[r]), int(ys[r]), rad ** 3, *col))
+        alpha.append(a)
+    n_first = len(geo)
+    num_times = src_radius // 10
+    al = np.linspace(0.0, 1, num=num_times)
+    rad = np.linspace(1, src_radius, num=num_times)
+    for i in range(num_times):
+        geo.append((cx, cy, int(rad[i]), *src_color))
+        alpha.append(al[num_times - i - 1] ** 3)
+    geo = np.clip(np.array(geo, np.int64), -2 ** 30, 2 ** 30).astype(np.int32).reshape(-1, 6)
+    return geo, np.array(alpha, np.float64), n_first
+
+
 class TrainTransform:
     """create_albu_transform(args, mean, std) for device-resident uint8 HWC images: `tf(img, rng) -> fp32 [C, S, S]`."""
 
@@ -142,7 +240,9 @@ class TrainTransform:
         # (keys a hand-built `args` may lack count as switched off, like an INI with every probability at zero)
         keys = dict(rotation=0.0, translate=0.0, scale=0.0, shear=0.0, albu_prob=0.0, individual_albu_probs=0.0,
                     noise_std=0.0, noise_prob=0.0, clahe=False, randomgamma=False, randombrightness=False, blur=False,
-                    elastic=False, optical_distortion=False, grid_distortion=False, fog=False)
+                    elastic=False, optical_distortion=False, grid_distortion=False, fog=False, grid_shuffle=False, hsv=False,
+                    invert=False, cutout=False, shadow=False, sun_flare=False, solarize=False, equalize=False,
+                    grid_dropout=False)
         self.cfg = SimpleNamespace(inference_resolution=args.inference_resolution, train_resolution=args.train_resolution,
                                    **{k: getattr(args, k, v) for k, v in keys.items()})
         self.device, self.C = torch.device(device), channels
@@ -156,8 +256,12 @@ class TrainTransform:
         self.map_x = torch.empty(S, S, dtype=torch.float32, device=self.device)
         self.map_y = torch.empty(S, S, dtype=torch.float32, device=self.device)
         self.warp_ws = torch.empty(S * S * 16, dtype=torch.uint8, device=self.device)
-        if self.cfg.fog and channels != 3:
-            raise AssertionError("RandomFog needs 3 channels")          # torchlib/dataloader.py:188
+        for key, name in (("shadow", "RandomShadows"), ("fog", "RandomFog"), ("sun_flare", "RandomSunFlare")):
+            if getattr(self.cfg, key) and channels != 3:
+                raise AssertionError(name + " needs 3 channels")          # torchlib/dataloader.py:184-191
+        if self.cfg.hsv and channels != 3:
+            raise AssertionError("HueSaturationValue needs 3 channels")   # (albumentations raises for grayscale input)
+        self.eq_ws = torch.empty(3 * 256 * 5, dtype=torch.uint8, device=self.device)
 
     def _remap(self, cur):
         out = torch.empty_like(cur)
@@ -213,6 +317,52 @@ class TrainTransform:
         call("primia_image_box_blur_u8", out, S, S, self.C, k, blurred)
         return blurred
 
+    def _i32(self, rows):
+        return torch.from_numpy(np.ascontiguousarray(rows, dtype=np.int32)).to(self.device)
+
+    def grid_shuffle(self, cur, seed):
+        S = cur.shape[0]
+        tiles = grid_shuffle_tiles(S, S, seed)
+        out = torch.empty_like(cur)
+        call("primia_image_swap_tiles_u8", cur, S, S, self.C, self._i32(tiles), len(tiles), out)
+        return out
+
+    def hsv_shift(self, cur, hue_shift, sat_shift, val_shift):
+        S = cur.shape[0]
+        luts = torch.from_numpy(hsv_tables(hue_shift, sat_shift, val_shift)).to(self.device)
+        out = torch.empty_like(cur)
+        call("primia_image_hsv_shift_u8", cur, S, S, luts, out)
+        return out
+
+    def lut(self, cur, table):
+        call("primia_image_lut_u8", cur, cur.numel(), torch.from_numpy(table).to(self.device), cur)
+        return cur
+
+    def fill_rects(self, cur, holes, fill=0):
+        S = cur.shape[0]
+        call("primia_image_fill_rects_u8", cur, S, S, self.C, self._i32(holes), len(holes), int(fill))
+        return cur
+
+    def shadow(self, cur, vertices):
+        S = cur.shape[0]
+        out = torch.empty_like(cur)
+        call("primia_image_shadow_u8", cur, S, S, self._i32(vertices), vertices.shape[0], vertices.shape[1], out)
+        return out
+
+    def sun_flare(self, cur, geo, alpha, n_first):
+        S = cur.shape[0]
+        a32 = torch.from_numpy(alpha.astype(np.float32)).to(self.device)
+        b32 = torch.from_numpy((1.0 - alpha).astype(np.float32)).to(self.device)
+        out = torch.empty_like(cur)
+        call("primia_image_sun_flare_u8", cur, S, S, self._i32(geo), a32, b32, len(geo), n_first, out)
+        return out
+
+    def equalize(self, cur):
+        S = cur.shape[0]
+        out = torch.empty_like(cur)
+        call("primia_image_equalize_u8", cur, S, S, self.C, self.eq_ws, self.eq_ws.numel(), out)
+        return out
+
     def __call__(self, img, rng, augment=True):
         dev, C = self.device, self.C
         a = self.cfg
@@ -261,9 +411,28 @@ class TrainTransform:
                 xsteps = [1 + rng.uniform(-0.3, 0.3) for _ in range(6)]
                 ysteps = [1 + rng.uniform(-0.3, 0.3) for _ in range(6)]
                 cur = self.grid(cur, xsteps, ysteps)
+            if a.grid_shuffle and rng.random() < p:                 # grid (3, 3); get_params: random.randint(0, 10000)
+                cur = self.grid_shuffle(cur, rng.randint(0, 10000))
+            if a.hsv and rng.random() < p:                          # hue 20, saturation 30, value 20
+                hs, ss, vs = rng.uniform(-20, 20), rng.uniform(-30, 30), rng.uniform(-20, 20)
+                cur = self.hsv_shift(cur, hs, ss, vs)
+            if a.invert and rng.random() < p:
+                cur = self.lut(cur, (255 - np.arange(256)).astype(np.uint8))
+            if a.cutout and rng.random() < p:                       # num_holes 5, 80 x 80 (dataloader.py:178-182)
+                cur = self.fill_rects(cur, cutout_holes(S, S, rng))
+            if a.shadow and rng.random() < p:
+                cur = self.shadow(cur, shadow_vertices(S, S, rng))
             if a.fog and rng.random() < p:                          # fog_coef (0.3, 1), alpha_coef 0.08
                 fog_coef, haze = fog_params(S, S, rng)
                 cur = self.fog(cur, fog_coef, haze)
+            if a.sun_flare and rng.random() < p:
+                cur = self.sun_flare(cur, *sun_flare_steps(S, S, rng))
+            if a.solarize and rng.random() < p:                     # threshold (128, 128): the draw is still made
+                cur = self.lut(cur, solarize_table(rng.uniform(128, 128)))
+            if a.equalize and rng.random() < p:
+                cur = self.equalize(cur)
+            if a.grid_dropout and rng.random() < p:
+                cur = self.fill_rects(cur, grid_dropout_holes(S, S))
             if rng.random() < a.noise_prob:                                            # a.GaussNoise(var_limit = noise_std^2)
                 var = rng.uniform(0.0, a.noise_std ** 2)
                 noise = torch.randn(cur.numel(), generator=self.gen, device=dev) * (var ** 0.5)

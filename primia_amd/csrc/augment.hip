@@ -316,6 +316,222 @@ __global__ __launch_bounds__(256) void finish_u8_kernel(const uint8_t* __restric
     }
 }
 
+// ---- round 4, second batch: RandomGridShuffle, HueSaturationValue, Cutout / GridDropout, RandomShadow, RandomSunFlare,
+// Equalize (InvertImg and Solarize are tables for lut_u8_kernel).  albumentations 0.4.6 functional.py + OpenCV's
+// color_hsv.cpp / histogram.cpp, restated in oracle/augment_oracle.py (where the raster approximations are named).
+
+// cv2.equalizeHist: per-channel histogram (int32 [C][256], zeroed by the caller), table, apply
+__global__ __launch_bounds__(256) void hist_u8_kernel(const uint8_t* __restrict__ in, long npix, int C, int* __restrict__ hist) {
+    __shared__ int h[3 * 256];
+    for (int i = threadIdx.x; i < C * 256; i += 256) h[i] = 0;
+    __syncthreads();
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix * C; i += stride) atomicAdd(&h[(int)(i % C) * 256 + in[i]], 1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * 256; i += 256)
+        if (h[i]) atomicAdd(&hist[i], h[i]);
+}
+
+__global__ __launch_bounds__(64) void equalize_lut_kernel(const int* __restrict__ hist, long total, uint8_t* __restrict__ lut) {
+    if (threadIdx.x != 0) return;           // 256 bins: one thread per channel walks them (histogram.cpp's scalar loop)
+    const int* h = hist + blockIdx.x * 256;
+    uint8_t* t = lut + blockIdx.x * 256;
+    int i = 0;
+    while (i < 255 && !h[i]) ++i;
+    if (h[i] == total) {
+        for (int k = 0; k < 256; ++k) t[k] = (uint8_t)i;
+        return;
+    }
+    const float scale = 255.f / (float)(total - h[i]);
+    for (int k = 0; k <= i; ++k) t[k] = 0;
+    long sum = 0;
+    for (int k = i + 1; k < 256; ++k) {
+        sum += h[k];
+        const float v = rintf((float)sum * scale);
+        t[k] = (uint8_t)fminf(fmaxf(v, 0.f), 255.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void lut_c_u8_kernel(const uint8_t* __restrict__ in, long n, int C,
+                                                       const uint8_t* __restrict__ tables, uint8_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = tables[(int)(i % C) * 256 + in[i]];
+}
+
+// F.cutout: every rectangle (x1, y1, x2, y2) filled (Cutout's five holes, GridDropout's grid)
+__global__ __launch_bounds__(256) void fill_rects_u8_kernel(uint8_t* __restrict__ img, int H, int W, int C,
+                                                            const int* __restrict__ rects, int n, int fill) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W;
+    bool hit = false;
+    for (int k = 0; k < n && !hit; ++k) hit = x >= rects[4 * k] && x < rects[4 * k + 2] && y >= rects[4 * k + 1] && y < rects[4 * k + 3];
+    if (hit)
+        for (int c = 0; c < C; ++c) img[(long)idx * C + c] = (uint8_t)fill;
+}
+
+// F.swap_tiles_on_image: tile k = (y, x, old_y, old_x, h, w): dst[y.., x..] = src[old_y.., old_x..]; the tiles partition the image
+__global__ __launch_bounds__(256) void swap_tiles_u8_kernel(const uint8_t* __restrict__ src, int H, int W, int C,
+                                                            const int* __restrict__ tiles, int n, uint8_t* __restrict__ dst) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W;
+    int sy = y, sx = x;
+    for (int k = 0; k < n; ++k) {
+        const int* t = tiles + 6 * k;
+        if (y >= t[0] && y < t[0] + t[4] && x >= t[1] && x < t[1] + t[5]) {
+            sy = t[2] + (y - t[0]);
+            sx = t[3] + (x - t[1]);
+        }
+    }
+    for (int c = 0; c < C; ++c) dst[(long)idx * C + c] = src[((long)sy * W + sx) * C + c];
+}
+
+
+// (b, g, r) = tab[sector_data[sector]] of OpenCV's HSV2RGB_f / HLS2RGB_f
+__device__ __forceinline__ void sector_rgb(const float* tab, int sector, float& r, float& g, float& b) {
+    const int sd[6][3] = {{1, 3, 0}, {1, 0, 2}, {3, 0, 1}, {0, 2, 1}, {0, 1, 3}, {2, 1, 0}};
+    b = tab[sd[sector][0]];
+    g = tab[sd[sector][1]];
+    r = tab[sd[sector][2]];
+}
+
+// F._shift_hsv_uint8: RGB2HSV_b (12-bit fixed-point division tables, hrange 180) -> three tables -> HSV2RGB_f in float32
+__global__ __launch_bounds__(256) void hsv_shift_u8_kernel(const uint8_t* __restrict__ in, long npix,
+                                                           const uint8_t* __restrict__ luts, uint8_t* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const int r = in[3 * i], g = in[3 * i + 1], b = in[3 * i + 2];
+    const int v = max(max(r, g), b), vmin = min(min(r, g), b), diff = v - vmin;
+    const int sdiv = v ? (int)rint((double)(255 << 12) / (1.0 * v)) : 0;
+    const int hdiv = diff ? (int)rint((double)(180 << 12) / (6.0 * diff)) : 0;
+    const int s = (diff * sdiv + (1 << 11)) >> 12;
+    int h = v == r ? g - b : (v == g ? b - r + 2 * diff : r - g + 4 * diff);
+    h = (h * hdiv + (1 << 11)) >> 12;
+    if (h < 0) h += 180;
+    const int h2 = luts[h & 255], s2 = luts[256 + (s & 255)], v2 = luts[512 + v];
+    float hf = (float)h2 * (float)(6.0 / 180.0);
+    const float sf = (float)s2 * (float)(1.0 / 255.0), vf = (float)v2 * (float)(1.0 / 255.0);
+    float rr = vf, gg = vf, bb = vf;
+    if (sf != 0.f) {
+        if (hf >= 6.f) hf -= 6.f;
+        int sector = (int)floorf(hf);
+        hf -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; hf = 0.f; }
+        const float tab[4] = {vf, vf * (1.f - sf), vf * (1.f - sf * hf), vf * (1.f - sf * (1.f - hf))};
+        sector_rgb(tab, sector, rr, gg, bb);
+    }
+    out[3 * i] = sat_u8(rr * 255.f);
+    out[3 * i + 1] = sat_u8(gg * 255.f);
+    out[3 * i + 2] = sat_u8(bb * 255.f);
+}
+
+// F.add_shadow: RGB2HLS_f on x / 255 -> uint8 (h / 2, 255 l, 255 s); L >>= 1 under the union of the polygons (even-odd
+// interior at integer pixel coordinates, or on an edge's DDA line); HLS2RGB_f
+__global__ __launch_bounds__(256) void shadow_u8_kernel(const uint8_t* __restrict__ in, int H, int W,
+                                                        const int* __restrict__ verts, int npoly, int nv,
+                                                        uint8_t* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W;
+    bool covered = false;
+    for (int pnum = 0; pnum < npoly; ++pnum) {
+        const int* pv = verts + (long)pnum * nv * 2;
+        bool inside = false, edge = false;
+        for (int k = 0; k < nv; ++k) {
+            const int x0 = pv[2 * k], y0 = pv[2 * k + 1];
+            const int k1 = k + 1 == nv ? 0 : k + 1;
+            const int x1 = pv[2 * k1], y1 = pv[2 * k1 + 1];
+            if (y0 != y1 && ((y0 <= y) != (y1 <= y))) {
+                const long dy = y1 - y0, lhs = (long)x * dy, rhs = (long)x0 * dy + (long)(y - y0) * (x1 - x0);
+                if (dy > 0 ? lhs < rhs : lhs > rhs) inside = !inside;
+            }
+            const int adx = abs(x1 - x0), ady = abs(y1 - y0);
+            if (adx >= ady) {
+                const bool fw = x0 <= x1;
+                const int xa = fw ? x0 : x1, ya = fw ? y0 : y1, xb = fw ? x1 : x0, yb = fw ? y1 : y0;
+                const int d = xb - xa;
+                if (d == 0) {
+                    edge |= x == xa && y == ya;
+                } else if (x >= xa && x <= xb) {
+                    const long num = 2L * (x - xa) * (yb - ya) + d, den = 2L * d;
+                    long q = num / den;
+                    if (num % den != 0 && num < 0) --q;          // floor division
+                    edge |= y == ya + (int)q;
+                }
+            } else {
+                const bool fw = y0 <= y1;
+                const int xa = fw ? x0 : x1, ya = fw ? y0 : y1, xb = fw ? x1 : x0, yb = fw ? y1 : y0;
+                const int d = yb - ya;
+                if (y >= ya && y <= yb) {
+                    const long num = 2L * (y - ya) * (xb - xa) + d, den = 2L * d;
+                    long q = num / den;
+                    if (num % den != 0 && num < 0) --q;
+                    edge |= x == xa + (int)q;
+                }
+            }
+        }
+        covered |= inside || edge;
+    }
+    const float k255 = (float)(1.0 / 255.0);
+    const float r = (float)in[3L * idx] * k255, g = (float)in[3L * idx + 1] * k255, b = (float)in[3L * idx + 2] * k255;
+    const float vmax = fmaxf(fmaxf(r, g), b), vmin = fminf(fminf(r, g), b);
+    float diff = vmax - vmin, h = 0.f, s = 0.f;
+    const float l = (vmax + vmin) * 0.5f;
+    if (diff > 1.1920929e-07f) {
+        s = l < 0.5f ? diff / (vmax + vmin) : diff / (2.f - vmax - vmin);
+        diff = 60.f / diff;
+        if (vmax == r) h = (g - b) * diff;
+        else if (vmax == g) h = (b - r) * diff + 120.f;
+        else h = (r - g) * diff + 240.f;
+        if (h < 0.f) h += 360.f;
+    }
+    const int hq = sat_u8(h * 0.5f), sq = sat_u8(s * 255.f);
+    int lq = sat_u8(l * 255.f);
+    if (covered) lq >>= 1;
+    // back
+    float hf = (float)hq * (float)(6.0 / 180.0);
+    const float lf = (float)lq * k255, sf = (float)sq * k255;
+    float rr = lf, gg = lf, bb = lf;
+    if (sf != 0.f) {
+        const float p2 = lf <= 0.5f ? lf * (1.f + sf) : lf + sf - lf * sf;
+        const float p1 = 2.f * lf - p2;
+        if (hf >= 6.f) hf -= 6.f;
+        int sector = (int)floorf(hf);
+        hf -= (float)sector;
+        if ((unsigned)sector >= 6u) { sector = 0; hf = 0.f; }
+        const float tab[4] = {p2, p1, p1 + (p2 - p1) * (1.f - hf), p1 + (p2 - p1) * hf};
+        sector_rgb(tab, sector, rr, gg, bb);
+    }
+    out[3L * idx] = sat_u8(rr * 255.f);
+    out[3L * idx + 1] = sat_u8(gg * 255.f);
+    out[3L * idx + 2] = sat_u8(bb * 255.f);
+}
+
+// F.add_sun_flare: step k draws a filled circle (x, y, r, colour) onto `overlay` and blends overlay into output with weight
+// alpha[k]; at step n_first overlay = output.copy().  Every pixel walks the steps on its own.
+__global__ __launch_bounds__(256) void sun_flare_u8_kernel(const uint8_t* __restrict__ in, int H, int W,
+                                                           const int* __restrict__ geo, const float* __restrict__ alpha,
+                                                           const float* __restrict__ beta, int n, int n_first,
+                                                           uint8_t* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int y = idx / W, x = idx - y * W;
+    float ov[3], o[3];
+    for (int c = 0; c < 3; ++c) ov[c] = o[c] = (float)in[3L * idx + c];
+    for (int k = 0; k < n; ++k) {
+        if (k == n_first)
+            for (int c = 0; c < 3; ++c) ov[c] = o[c];
+        const int* g = geo + 6 * k;
+        const long dx = x - g[0], dy = y - g[1], r = g[2];
+        if (dx * dx + dy * dy <= r * r)
+            for (int c = 0; c < 3; ++c) ov[c] = (float)g[3 + c];
+        const float a = alpha[k], b = beta[k];
+        for (int c = 0; c < 3; ++c) o[c] = fminf(fmaxf(rintf(ov[c] * a + o[c] * b), 0.f), 255.f);
+    }
+    for (int c = 0; c < 3; ++c) out[3L * idx + c] = (uint8_t)o[c];
+}
+
 }  // namespace primia
 
 using namespace primia;
@@ -446,6 +662,57 @@ int primia_image_finish(const uint8_t* in, int S, int C, const float* mean, cons
                         primia_stream_t st) {
     PRIMIA_REQUIRE(in && out && S > 0 && (C == 1 || C == 3) && ((mean == nullptr) == (stdv == nullptr)));
     finish_u8_kernel<<<ceil_div((long)S * S, 256), 256, 0, (hipStream_t)st>>>(in, S, C, mean, stdv, out);
+    return launch_status();
+}
+
+int primia_image_equalize_u8(const uint8_t* in, int H, int W, int C, void* workspace, int64_t workspace_bytes, uint8_t* out,
+                             primia_stream_t st) {
+    PRIMIA_REQUIRE(in && out && workspace && H > 0 && W > 0 && (C == 1 || C == 3) && workspace_bytes >= 3 * 256 * 5);
+    hipStream_t s = (hipStream_t)st;
+    int* hist = (int*)workspace;
+    uint8_t* lut = (uint8_t*)workspace + 3 * 256 * 4;
+    if (hipMemsetAsync(hist, 0, 3 * 256 * 4, s) != hipSuccess) return PRIMIA_ERR_LAUNCH;
+    const long npix = (long)H * W;
+    const int nb = (int)(ceil_div(npix * C, 256) < 512 ? ceil_div(npix * C, 256) : 512);
+    hist_u8_kernel<<<nb, 256, 0, s>>>(in, npix, C, hist);
+    equalize_lut_kernel<<<C, 64, 0, s>>>(hist, npix, lut);
+    lut_c_u8_kernel<<<ceil_div(npix * C, 256), 256, 0, s>>>(in, npix * C, C, lut, out);
+    return launch_status();
+}
+
+int primia_image_fill_rects_u8(uint8_t* img, int H, int W, int C, const int32_t* rects, int n, int fill, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(img && rects && H > 0 && W > 0 && (C == 1 || C == 3) && n > 0 && fill >= 0 && fill <= 255);
+    fill_rects_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(img, H, W, C, (const int*)rects, n, fill);
+    return launch_status();
+}
+
+int primia_image_swap_tiles_u8(const uint8_t* src, int H, int W, int C, const int32_t* tiles, int n, uint8_t* dst,
+                               primia_stream_t st) {
+    PRIMIA_REQUIRE(src && dst && src != dst && tiles && H > 0 && W > 0 && (C == 1 || C == 3) && n > 0);
+    swap_tiles_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(src, H, W, C, (const int*)tiles, n, dst);
+    return launch_status();
+}
+
+int primia_image_hsv_shift_u8(const uint8_t* in, int H, int W, const uint8_t* luts3x256, uint8_t* out, primia_stream_t st) {
+    PRIMIA_REQUIRE(in && out && luts3x256 && H > 0 && W > 0);
+    hsv_shift_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(in, (long)H * W, luts3x256, out);
+    return launch_status();
+}
+
+int primia_image_shadow_u8(const uint8_t* in, int H, int W, const int32_t* vertices, int n_polygons, int n_vertices,
+                           uint8_t* out, primia_stream_t st) {
+    PRIMIA_REQUIRE(in && out && vertices && H > 0 && W > 0 && n_polygons > 0 && n_vertices >= 3);
+    shadow_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(in, H, W, (const int*)vertices, n_polygons,
+                                                                             n_vertices, out);
+    return launch_status();
+}
+
+int primia_image_sun_flare_u8(const uint8_t* in, int H, int W, const int32_t* steps, const float* alpha, const float* beta,
+                              int n_steps, int n_first, uint8_t* out, primia_stream_t st) {
+    PRIMIA_REQUIRE(in && out && steps && alpha && beta && H > 0 && W > 0 && n_steps > 0 && n_first >= 0 && n_first <= n_steps);
+    sun_flare_u8_kernel<<<ceil_div((long)H * W, 256), 256, 0, (hipStream_t)st>>>(in, H, W, (const int*)steps, alpha, beta,
+                                                                                n_steps, n_first, out);
     return launch_status();
 }
 

@@ -87,7 +87,7 @@ def test_affine_lut_blur_noise_finish_match_the_oracle(cuda):
         assert np.array_equal(out.cpu().numpy(), A.finish(sq, mean, std))
 
 
-def test_transform_chain_draws_and_refuses_unbuilt_transforms(cuda):
+def test_transform_chain_draws_and_serves_both_shipped_presets(cuda):
     from types import SimpleNamespace
 
     from primia_amd.augment import TrainTransform
@@ -107,13 +107,21 @@ def test_transform_chain_draws_and_refuses_unbuilt_transforms(cuda):
     assert not torch.equal(a, c)
     plain = tf(img, random.Random(7), augment=False)
     assert torch.isfinite(plain).all()
-    with pytest.raises(SystemExit, match="hsv"):
-        TrainTransform(SimpleNamespace(**base, hsv=True, elastic=True), mean, std, cuda, 3)
-    # the reference's shipped preset (elastic, optical_distortion, grid_distortion, fog = yes) is served
-    full = TrainTransform(SimpleNamespace(**base, elastic=True, optical_distortion=True, grid_distortion=True, fog=True),
-                          mean, std, cuda, 3, seed=3)
-    outs = [full(img, random.Random(s_)) for s_ in range(40)]          # p = 0.75 x 0.2 each: every transform fires
+    with pytest.raises(AssertionError, match="3 channels"):          # torchlib/dataloader.py:184-191
+        TrainTransform(SimpleNamespace(**base, shadow=True), mean[:1], std[:1], cuda, 1)
+    # both shipped presets are served: pneumonia-resnet-pretrained.ini (elastic, optical_distortion, grid_distortion, fog)
+    # and ...-fast.ini, which switches EVERY member of create_albu_transform on
+    every = dict(elastic=True, optical_distortion=True, grid_distortion=True, grid_shuffle=True, hsv=True, invert=True,
+                 cutout=True, shadow=True, fog=True, sun_flare=True, solarize=True, equalize=True, grid_dropout=True)
+    full = TrainTransform(SimpleNamespace(**base, **every), mean, std, cuda, 3, seed=3)
+    fired = set()
+    for name in ("grid_shuffle", "hsv_shift", "lut", "fill_rects", "shadow", "fog", "sun_flare", "equalize", "elastic",
+                 "optical", "grid"):
+        orig = getattr(full, name)
+        setattr(full, name, (lambda f, n: lambda *a_, **k_: (fired.add(n), f(*a_, **k_))[1])(orig, name))
+    outs = [full(img, random.Random(s_)) for s_ in range(60)]          # p = 0.75 x 0.2 each: every transform fires
     assert all(o.shape == (3, 64, 64) and torch.isfinite(o).all() for o in outs)
+    assert len(fired) == 11, fired
 
 
 def _u8(rng, H, W, C):
@@ -185,3 +193,62 @@ def test_fog_matches_the_oracle(cuda, S):
         out = torch.empty(S, S, 3, dtype=torch.uint8, device=cuda)
         call("primia_image_box_blur_u8", dev(img, cuda), S, S, 3, k, out)
         assert np.array_equal(out.cpu().numpy(), A.box_blur_anchor(img, k)), k
+
+
+@pytest.mark.parametrize("S", [224, 96])
+def test_remaining_albumentations_members_match_the_oracle(cuda, S):
+    """RandomGridShuffle, HueSaturationValue, InvertImg, Cutout, RandomShadow, RandomSunFlare, Solarize, Equalize,
+    GridDropout (create_albu_transform, torchlib/dataloader.py:173-201; all `yes` in pneumonia-resnet-pretrained-fast.ini):
+    parameters drawn by the product helpers equal the oracle's draws from the same `random` stream, and the device images
+    equal oracle/augment_oracle.py's bit for bit."""
+    from types import SimpleNamespace
+
+    import primia_amd.augment as P
+
+    rng = np.random.default_rng(S)
+    img = _u8(rng, S, S, 3)
+    img[: S // 4, : S // 4] = 255                        # a saturated and a black patch: grey pixels (s = 0) and v = 0
+    img[S // 4: S // 2, : S // 4] = 0
+    d_img = dev(img, cuda)
+    tf = P.TrainTransform(SimpleNamespace(train_resolution=S, inference_resolution=S), None, None, cuda, 3)
+    for seed in (0, 1, 2):
+        r1, r2 = random.Random(seed), random.Random(seed)
+        # grid shuffle
+        s1 = r1.randint(0, 10000); r2.randint(0, 10000)
+        tiles = P.grid_shuffle_tiles(S, S, s1)
+        assert np.array_equal(tiles, A.grid_shuffle_tiles(S, S, s1))
+        assert np.array_equal(tf.grid_shuffle(d_img, s1).cpu().numpy(), A.swap_tiles(img, tiles))
+        # hue / saturation / value
+        hs, ss, vs = r1.uniform(-20, 20), r1.uniform(-30, 30), r1.uniform(-20, 20)
+        want, luts = A.shift_hsv(img, hs, ss, vs)
+        assert np.array_equal(P.hsv_tables(hs, ss, vs), np.stack(luts))
+        assert np.array_equal(tf.hsv_shift(d_img, hs, ss, vs).cpu().numpy(), want)
+        # invert, solarize
+        assert np.array_equal(tf.lut(d_img.clone(), A.invert_table()).cpu().numpy(), 255 - img)
+        assert np.array_equal(P.solarize_table(128.0), A.solarize_table(128.0))
+        assert np.array_equal(tf.lut(d_img.clone(), P.solarize_table(128.0)).cpu().numpy(), A.solarize_table(128)[img])
+        # cutout, grid dropout
+        r2.uniform(0, 1), r2.uniform(0, 1), r2.uniform(0, 1)
+        holes = P.cutout_holes(S, S, r1)
+        assert holes == A.cutout_holes(S, S, r2)
+        assert np.array_equal(tf.fill_rects(d_img.clone(), holes).cpu().numpy(), A.fill_rects(img, holes))
+        gh = P.grid_dropout_holes(S, S)
+        assert gh == A.grid_dropout_holes(S, S)
+        got = tf.fill_rects(d_img.clone(), gh).cpu().numpy()
+        assert np.array_equal(got, A.fill_rects(img, gh)) and 0.15 < (got == 0).all(axis=2).mean() < 0.35
+        # shadow
+        verts = P.shadow_vertices(S, S, r1)
+        assert np.array_equal(verts, A.shadow_vertices(S, S, r2))
+        got = tf.shadow(d_img, verts).cpu().numpy()
+        assert np.array_equal(got, A.add_shadow(img, verts))
+        assert got.astype(int).sum() < A.hls2rgb_u8(A.rgb2hls_u8(img)).astype(int).sum()        # something got darker
+        # sun flare
+        geo, alpha, n_first = P.sun_flare_steps(S, S, r1)
+        cx, cy, circles = A.sun_flare_params(S, S, r2)
+        geo2, alpha2, n2 = A.sun_flare_steps(cx, cy, circles)
+        assert np.array_equal(geo, geo2) and np.array_equal(alpha, alpha2) and n_first == n2
+        assert np.array_equal(tf.sun_flare(d_img, geo, alpha, n_first).cpu().numpy(), A.add_sun_flare(img, cx, cy, circles))
+        # equalize
+        assert np.array_equal(tf.equalize(d_img).cpu().numpy(), A.equalize(img))
+    flat = np.full((S, S, 3), 77, np.uint8)               # one grey level per channel: cv2.equalizeHist returns it unchanged
+    assert np.array_equal(tf.equalize(dev(flat, cuda)).cpu().numpy(), A.equalize(flat))

@@ -247,3 +247,56 @@ def test_augment_oracle_warps_and_fog_properties():
     fog = A.add_fog(dark, fc, hz)
     assert fog.min() >= 10 and fog.max() > 10
     assert np.array_equal(A.box_blur_anchor(img, 5), A.box_blur(img, 5))
+
+
+def test_augment_oracle_second_batch_properties():
+    """The nine remaining albumentations members as oracle/augment_oracle.py restates them: properties that hold whatever
+    cv2's rounding (the restatement is unpinned against cv2's binaries, as its header says)."""
+    import random
+
+    import numpy as np
+
+    import primia_amd.augment as P
+    from oracle import augment_oracle as A
+
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (96, 96, 3), dtype=np.uint8)
+    # colour spaces: primaries, greys, round trips within cv2's own 8-bit error
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [255, 255, 255], [0, 0, 0], [128, 128, 128]]], np.uint8)
+    assert A.rgb2hsv_u8(px).tolist() == [[[0, 255, 255], [60, 255, 255], [120, 255, 255], [0, 0, 255], [0, 0, 0], [0, 0, 128]]]
+    assert A.rgb2hls_u8(px)[0, :3, 0].tolist() == [0, 60, 120] and A.rgb2hls_u8(px)[0, 3:, 2].tolist() == [0, 0, 0]
+    assert np.array_equal(A.hsv2rgb_u8(A.rgb2hsv_u8(px)), px)
+    assert np.abs(A.hsv2rgb_u8(A.rgb2hsv_u8(img)).astype(int) - img).max() <= 6
+    assert np.abs(A.hls2rgb_u8(A.rgb2hls_u8(img)).astype(int) - img).max() <= 6
+    same, _ = A.shift_hsv(img, 0.0, 0.0, 0.0)
+    assert np.array_equal(same, A.hsv2rgb_u8(A.rgb2hsv_u8(img)))
+    # equalize: monotone table, full range, constant image untouched
+    t = A.equalize_table(np.bincount(img[..., 0].reshape(-1), minlength=256))
+    assert (np.diff(t.astype(int)) >= 0).all() and t[-1] == 255 and t[0] == 0
+    assert np.array_equal(A.equalize(np.full((8, 8, 3), 9, np.uint8)), np.full((8, 8, 3), 9, np.uint8))
+    # tiles: a permutation of equal-shaped tiles that partition the image
+    tiles = A.grid_shuffle_tiles(96, 96, 7)
+    assert len(tiles) == 9 and int((tiles[:, 4] * tiles[:, 5]).sum()) == 96 * 96
+    assert sorted(A.swap_tiles(img, tiles).reshape(-1).tolist()) == sorted(img.reshape(-1).tolist())
+    assert np.array_equal(tiles, P.grid_shuffle_tiles(96, 96, 7))
+    # holes and polygons
+    assert A.cutout_holes(300, 300, random.Random(1)) == P.cutout_holes(300, 300, random.Random(1))
+    assert all(x2 - x1 <= 80 and y2 - y1 <= 80 for x1, y1, x2, y2 in A.cutout_holes(300, 300, random.Random(1)))
+    assert A.grid_dropout_holes(224, 224) == P.grid_dropout_holes(224, 224) and len(A.grid_dropout_holes(224, 224)) == 121
+    tri = np.array([[10, 10], [50, 10], [10, 50]], np.int32)
+    m = A.polygon_mask(64, 64, tri)
+    assert m[10, 10] and m[10, 50] and m[50, 10] and m[20, 20] and not m[40, 40] and not m[5, 5]
+    assert abs(int(m.sum()) - 861) < 45                   # area 800 + boundary
+    v = A.shadow_vertices(96, 96, random.Random(2))
+    assert np.array_equal(v, P.shadow_vertices(96, 96, random.Random(2))) and v.shape[1:] == (5, 2) and (v[..., 1] >= 48).all()
+    dark = A.add_shadow(img, v)
+    base = A.hls2rgb_u8(A.rgb2hls_u8(img))
+    assert (dark.astype(int).sum(axis=2) <= base.astype(int).sum(axis=2) + 3).all() and not np.array_equal(dark, base)
+    # sun flare: schedule equal in product helper and oracle; the flare only brightens towards the source colour
+    geo, alpha, n_first = P.sun_flare_steps(224, 224, random.Random(3))
+    cx, cy, circles = A.sun_flare_params(224, 224, random.Random(3))
+    geo2, alpha2, n2 = A.sun_flare_steps(cx, cy, circles)
+    assert np.array_equal(geo, geo2) and np.array_equal(alpha, alpha2) and n_first == n2 == len(circles) and len(geo) == n2 + 40
+    black = np.zeros((224, 224, 3), np.uint8)
+    fl = A.add_sun_flare(black, cx, cy, circles)
+    assert fl[cy, cx].tolist() == [255, 255, 255] and fl.max() == 255 and (fl >= black).all()
