@@ -419,6 +419,28 @@ def test_cli_per_rank_training_on_a_real_folder_and_resume(tmp_path):
         os.remove(f)
 
 
+def test_cli_runs_the_fast_preset_with_every_augmentation_on(tmp_path):
+    """configs/torch/pneumonia-resnet-pretrained-fast.ini — the reference preset that switches EVERY albumentations member
+    on — through train.py --train_federated on real image folders (two clients in one process, MixUp at registration as
+    the reference does), with nothing edited but the sizes (64-pixel images, batch 8) and the per-transform probabilities
+    raised so that every member fires within the few images of the test."""
+    data = str(tmp_path / "data")
+    _write_tree(data, workers=2, per_class=8)
+    csv = tmp_path / "workers.csv"
+    csv.write_text("id,alice,bob,crypto_provider\nhost,127.0.0.1,127.0.0.1,127.0.0.1\nport,8777,8778,8780\n")
+    ini = tmp_path / "fast.ini"
+    text = open(os.path.join(ROOT, "configs", "torch", "pneumonia-resnet-pretrained-fast.ini")).read()
+    for a_, b_ in (("batch_size = 200", "batch_size = 8"), ("train_resolution = 224", "train_resolution = 64"),
+                   ("overall_prob = 0.75", "overall_prob = 1.0"), ("individual_probs = 0.2", "individual_probs = 0.6")):
+        assert a_ in text, a_
+        text = text.replace(a_, b_)
+    ini.write_text(text)
+    out = run(["train.py", "--config", str(ini), "--cuda", "--data_dir", data, "--train_federated", "--training_name",
+               "fastpreset"], {"PRIMIA_WEBSOCKETS_CONFIG": str(csv)})
+    assert "Train Epoch: 1" in out and "matthews coeff" in out and "not part of the accelerated data path" not in out
+    os.remove(os.path.join(ROOT, "model_weights", "final_federated_fastpreset.pt"))
+
+
 def test_c_abi_comm_entry_points_on_an_rccl_communicator(cuda):
     """§8b "comm": primia_fedavg_allreduce / primia_open2 take the CALLER's ncclComm_t.  A one-rank communicator made
     with the RCCL that torch ships (ctypes: ncclGetUniqueId / ncclCommInitRank) exercises the whole call path on one
