@@ -34,13 +34,15 @@ class _Conv:
 
 class ResNet18Engine:
     def __init__(self, batch_size, num_classes=3, in_channels=3, input_size=224, pooling="max",
-                 dtype=torch.bfloat16, device="cuda:0", norm="batch", groups=32, options=None):
+                 dtype=torch.bfloat16, device="cuda:0", norm="batch", groups=32, options=None, share=None):
         """norm="batch": the reference model.  norm="group": GroupNorm(groups, C) in place of every
         BatchNorm (ResNet's `norm_layer` hook, torchlib/models.py:355) — the BN-free network the
         DP-SGD configuration needs (train.py:308).
         `options`: {name: value} overriding the schedule switches below (class attributes such as wgrad_group,
         wgrad_overlap, masked_acc, stem_bwd_fused, dp_keep ...) for THIS engine before its buffers are sized.  Nothing here
-        reads the environment; the kernel library's own switches are `_lib.set_option` (primia_set_option)."""
+        reads the environment; the kernel library's own switches are `_lib.set_option` (primia_set_option).
+        `share`: another engine of the same network whose PARAMETERS this one uses (see `sibling`)."""
+        self._root = self if share is None else share._root
         for k, v in (options or {}).items():
             if not hasattr(type(self), k):
                 raise ValueError(f"unknown engine option {k!r}")
@@ -64,8 +66,14 @@ class ResNet18Engine:
         self.b_entries = buffer_entries(self.spec, norm)
         self.P = sum(int(torch.Size(s).numel()) for _, s in self.p_entries)
         self.B = sum(int(torch.Size(s).numel()) for _, s in self.b_entries)
-        self.flat = torch.zeros(self.P + self.B, dtype=torch.float32, device=dev)
-        self._grads = torch.zeros(self.P, dtype=torch.float32, device=dev)   # (read through the `grads` property)
+        if share is None:
+            self.flat = torch.zeros(self.P + self.B, dtype=torch.float32, device=dev)
+            self._grads = torch.zeros(self.P, dtype=torch.float32, device=dev)   # (read through the `grads` property)
+        else:       # the same arenas: a step of either engine moves the one set of weights
+            if (share.spec.num_classes, share.spec.in_channels, share.spec.input_size, share.spec.pooling, share.norm,
+                    share.dtype) != (num_classes, in_channels, input_size, pooling, norm, dtype):
+                raise ValueError("a sibling engine must be the same network, norm and dtype as the engine it shares with")
+            self.flat, self._grads = share.flat, share._grads
         self.views, self.gviews = {}, {}
         off = 0
         for k, s in self.p_entries:
@@ -80,9 +88,11 @@ class ResNet18Engine:
         # BatchNorm's num_batches_tracked (only ever READ by torch when momentum is None, never by this network): a host
         # counter advanced by forward(); a captured hipGraph replays kernels, not Python, so a caller that replays steps
         # (bench.py) and then exports state_dict() must add its replay count itself (note_replayed_steps).
-        self.num_batches_tracked = {bn_name(c.name): 0 for c in self.spec.convs}
-        self.opt_state = None  # Adam moments, created lazily
-        self.opt_steps = 0
+        self.num_batches_tracked = ({bn_name(c.name): 0 for c in self.spec.convs} if share is None
+                                    else share.num_batches_tracked)
+        if share is None:
+            self._opt_state = None  # Adam moments, created lazily
+            self._opt_steps = 0
 
         # ---- conv descriptors, weight copies --------------------------------------------------
         N = self.N
@@ -128,6 +138,10 @@ class ResNet18Engine:
                 self._acc_zero_n = acc_total
         self.dw_acc = torch.zeros(acc_total, dtype=torch.float32, device=dev)
         for c in self.convs.values():
+            if share is not None:       # kernel-layout weight copies do not depend on the batch size: one set
+                c.w_fwd, c.w_dgrad = share.convs[c.spec.name].w_fwd, share.convs[c.spec.name].w_dgrad
+                c.acc = self.dw_acc[c.acc_off:c.acc_off + c.wfwd_n]
+                continue
             c.w_fwd = torch.empty(c.wfwd_n, dtype=dtype, device=dev)
             c.w_dgrad = None
             if c.spec.name != stem.name:
@@ -321,6 +335,40 @@ class ResNet18Engine:
                 acc=(ctypes.c_void_p * n)(*[vp(c.acc) for c in cs]),
                 gw=(ctypes.c_void_p * n)(*[vp(self.gviews[c.spec.name + ".weight"]) for c in cs]))
         return self._many
+
+    # Adam's moments and step count belong to the PARAMETERS: siblings read and write the root engine's
+    @property
+    def opt_state(self):
+        return self._root._opt_state
+
+    @opt_state.setter
+    def opt_state(self, v):
+        self._root._opt_state = v
+
+    @property
+    def opt_steps(self):
+        return self._root._opt_steps
+
+    @opt_steps.setter
+    def opt_steps(self, v):
+        self._root._opt_steps = v
+
+    def sibling(self, batch_size):
+        """An engine for ANOTHER batch size on the SAME parameters, gradients, running statistics, kernel-layout weight
+        copies and optimizer state (activations and workspaces are its own): forward / loss_backward / sgd_step /
+        adam_step on either one train the one model.  The reference's local training loop needs it — MixUp halves a batch
+        with probability mixup_prob (torchlib/utils.py:1262-1267, :336-347), so consecutive steps see B or B / 2 samples."""
+        n = int(batch_size)
+        if n == self.N:
+            return self
+        sib = self._root.__dict__.setdefault("_siblings", {})
+        if n not in sib:
+            sib[n] = ResNet18Engine(n, self.spec.num_classes, self.spec.in_channels, self.spec.input_size,
+                                    self.spec.pooling, dtype=self.dtype, device=self.device, norm=self.norm,
+                                    groups=self.groups, share=self._root)
+        sib[n].fuse_sgd_tail = self._root.fuse_sgd_tail
+        sib[n].train(self.training)
+        return sib[n]
 
     def refresh_weights(self):
         """fp32 master (OIHW) -> compute-dtype implicit-GEMM copies; call after any change of `flat`."""

@@ -8,14 +8,11 @@ through create_albu_transform (torchlib/dataloader.py:138-217) with that mean / 
 
 Here the decode (PIL, host) produces uint8 HWC arrays; everything after it runs on the GPU: `primia_image_prepare`
 (resize, crop, to-float, normalise — one launch per image into the client's device-resident dataset tensor) and
-`primia_mean_std`.  The transform chain is primia_amd.augment.TrainTransform: RandomAffine, Resize, RandomCrop, CLAHE,
-VerticalFlip, RandomGamma, RandomBrightness, Blur, ElasticTransform, OpticalDistortion, GridDistortion, RandomFog,
-GaussNoise, ToFloat, Normalize on the GPU — everything the reference's shipped preset enables; a configuration that
-enables one of the remaining albumentations transforms (hsv, cutout, shadow, ...) is refused instead of silently
-training on different data (PRIMIA_SKIP_UNSUPPORTED_AUG=1 trains without them, with a warning).
+`primia_mean_std`.  The transform chain is primia_amd.augment.TrainTransform: every member of the reference's
+create_albu_transform on the GPU (both shipped presets run as written).
 
-The engine runs a fixed batch size, so a ragged final batch is dropped (the reference's loader would yield it):
-`len(loader)` = floor(n / batch_size).
+A ragged final batch is dropped (the reference's loader would yield it): `len(loader)` = floor(n / batch_size).
+(Batches that MixUp halves in the local training loop are served by ResNet18Engine.sibling.)
 """
 import os
 import random

@@ -46,12 +46,17 @@ class EngineOptimizer:
     def zero_grad(self):
         pass   # every backward pass of the engine overwrites the gradient arena
 
-    def step(self):
+    def step(self, engine=None):
+        """`engine`: the engine whose backward pass produced the gradients, when it is a sibling of the one this optimizer
+        was built on (ResNet18Engine.sibling: same parameters and optimizer state, another batch size)."""
+        eng = self.engine if engine is None else engine
+        if eng._root is not self.engine._root:
+            raise ValueError("optimizer.step(engine): not a sibling of the optimizer's engine")
         g = self.param_groups[0]
         if self.kind == "SGD":
-            self.engine.sgd_step(g["lr"], g["weight_decay"])
+            eng.sgd_step(g["lr"], g["weight_decay"])
         else:
-            self.engine.adam_step(g["lr"], g["betas"], g["eps"], g["weight_decay"])
+            eng.adam_step(g["lr"], g["betas"], g["eps"], g["weight_decay"])
 
     # ---- torch's checkpoint format --------------------------------------------------------------------------------
     def _slices(self):

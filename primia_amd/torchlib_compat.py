@@ -337,7 +337,6 @@ def train(args, model, device, train_loader, optimizer, epoch, loss_fn, num_clas
     losses = []
     optimizer = _as_optimizer(model, optimizer, args)
     if getattr(args, "mixup", False):
-        from ._lib import PrimiaError
         from .datapipe import MixUp, To_one_hot
 
         mixup = MixUp(λ=args.mixup_lambda, p=args.mixup_prob)
@@ -348,15 +347,13 @@ def train(args, model, device, train_loader, optimizer, epoch, loss_fn, num_clas
             target = oh_converter(target)
             data, target = mixup((data, target))
             soft = True
-            if data.shape[0] != model.N:
-                raise PrimiaError(
-                    "MixUp produced a batch of {:d}, the engine is built for {:d}: with mixup_prob < 1 the batch "
-                    "size changes from step to step; use mixup_prob = 1.0 (batch_size is doubled, as the reference "
-                    "does) or build the engine for the mixed size".format(data.shape[0], model.N))
+        # MixUp mixes the two halves of a batch with probability mixup_prob and passes it on whole otherwise: consecutive
+        # steps see B or B / 2 samples (:1262-1267).  A sibling engine serves the other size on the same parameters.
+        eng = model if data.shape[0] == model.N else model.sibling(data.shape[0])
         optimizer.zero_grad()
-        model.forward(data)
-        loss = model.loss_backward(target, soft=soft)
-        optimizer.step()
+        eng.forward(data)
+        loss = eng.loss_backward(target, soft=soft)
+        optimizer.step(eng)
         if batch_idx % args.log_interval == 0:
             losses.append(loss.item())
             if verbose:

@@ -441,6 +441,24 @@ def test_cli_runs_the_fast_preset_with_every_augmentation_on(tmp_path):
     os.remove(os.path.join(ROOT, "model_weights", "final_federated_fastpreset.pt"))
 
 
+def test_cli_local_training_with_mixup_halving_batches(tmp_path):
+    """train.py WITHOUT --train_federated on the shipped default preset's MixUp settings (mixup = yes, mixup_prob = 0.9:
+    a batch arrives whole with probability 0.1 and as its mixed halves otherwise, torchlib/utils.py:1262-1267)."""
+    data = str(tmp_path / "data")
+    _write_tree(data, workers=1, per_class=12)
+    ini = tmp_path / "local.ini"
+    text = open(os.path.join(ROOT, "configs", "torch", "pneumonia-resnet-pretrained.ini")).read()
+    for a_, b_ in (("batch_size = 200", "batch_size = 8"), ("train_resolution = 224", "train_resolution = 64"),
+                   ("epochs = 40", "epochs = 3"), ("mixup_prob = 0.9", "mixup_prob = 0.5")):
+        assert a_ in text, a_
+        text = text.replace(a_, b_)
+    ini.write_text(text)
+    out = run(["train.py", "--config", str(ini), "--cuda", "--data_dir", os.path.join(data, "worker1"), "--training_name",
+               "localmix"])
+    assert "Train Epoch: 3" in out and "matthews coeff" in out
+    os.remove(os.path.join(ROOT, "model_weights", "final_vanilla_localmix.pt"))
+
+
 def test_c_abi_comm_entry_points_on_an_rccl_communicator(cuda):
     """§8b "comm": primia_fedavg_allreduce / primia_open2 take the CALLER's ncclComm_t.  A one-rank communicator made
     with the RCCL that torch ships (ctypes: ncclGetUniqueId / ncclCommInitRank) exercises the whole call path on one

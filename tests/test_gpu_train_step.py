@@ -317,6 +317,51 @@ def test_state_dict_roundtrip_and_eval(cuda):
         eng.load_state_dict({"conv1.weight": sd["conv1.weight"]})
 
 
+@pytest.mark.parametrize("kind,dtype", [("SGD", torch.bfloat16), ("Adam", torch.float32)])
+def test_sibling_engine_trains_the_same_model_at_another_batch_size(cuda, kind, dtype):
+    """ResNet18Engine.sibling(n): another batch size on the SAME parameters, running statistics, kernel-layout weight
+    copies and optimizer state — what the reference's local loop needs when MixUp halves a batch with probability
+    mixup_prob (torchlib/utils.py:1262-1267).  Steps of 8, 4, 8 samples through root + sibling against two separate
+    engines that hand the model and the optimizer over as state dicts: the same bits."""
+    from primia_amd.optim import EngineOptimizer
+
+    B, S = 8, 64
+    torch.manual_seed(21)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, S, "max"))
+    g = torch.Generator().manual_seed(22)
+    seq = [(torch.randn(n, 3, S, S, generator=g).to(cuda), torch.randint(0, 3, (n,), generator=g).to(cuda)) for n in (B, B // 2, B)]
+    kw = dict(lr=0.05, weight_decay=1e-4) if kind == "SGD" else dict(lr=1e-3, weight_decay=5e-4, betas=(0.5, 0.99))
+    root = ResNet18Engine(B, 3, 3, S, "max", dtype=dtype, device=cuda)
+    root.load_state_dict(sd)
+    opt = EngineOptimizer(root, kind, **kw)
+    for x, y in seq:
+        eng = root.sibling(x.shape[0])
+        assert (eng is root) == (x.shape[0] == B) and eng.flat.data_ptr() == root.flat.data_ptr()
+        eng.forward(x)
+        eng.loss_backward(y)
+        opt.step(eng)
+    got, got_opt = root.state_dict(), opt.state_dict()
+    engines = {n: ResNet18Engine(n, 3, 3, S, "max", dtype=dtype, device=cuda) for n in (B, B // 2)}
+    cur, cur_opt = sd, None
+    for x, y in seq:
+        e = engines[x.shape[0]]
+        e.load_state_dict(cur)
+        o = EngineOptimizer(e, kind, **kw)
+        if cur_opt is not None:
+            o.load_state_dict(cur_opt)
+        e.forward(x)
+        e.loss_backward(y)
+        o.step()
+        cur, cur_opt = e.state_dict(), o.state_dict()
+    for k in cur:
+        assert torch.equal(got[k].cpu(), cur[k].cpu()), k
+    if kind == "Adam":
+        assert got_opt["state"][0]["step"] == 3 == cur_opt["state"][0]["step"]
+        assert torch.equal(got_opt["state"][5]["exp_avg_sq"], cur_opt["state"][5]["exp_avg_sq"])
+    with pytest.raises(ValueError):
+        opt.step(engines[B])                      # not a sibling
+
+
 @pytest.mark.parametrize("batch,size", [(160, 64), (5, 96)])
 def test_eval_stem_as_one_pass_equals_the_chain(cuda, batch, size):
     """Eval mode, bf16: conv1 -> bn1 -> relu -> maxpool as ONE kernel over the input (primia_stem_conv_pool_eval; the
