@@ -67,12 +67,14 @@ def prepare(samples, args, device, channels, rng, mean=None, std=None):
 class DeviceLoader:
     """FederatedDataLoader(batch_size, shuffle=True) over a device-resident (data, targets) pair."""
 
-    def __init__(self, data, targets, batch_size, shuffle, seed):
+    def __init__(self, data, targets, batch_size, shuffle, seed, drop_last=True):
         self.data, self.targets, self.batch_size, self.shuffle = data, targets, batch_size, shuffle
         self.gen = torch.Generator().manual_seed(seed)
+        self.drop_last = drop_last       # False: the ragged final batch is yielded too (validation: every sample counts)
 
     def __len__(self):
-        return self.data.shape[0] // self.batch_size
+        n, b = self.data.shape[0], self.batch_size
+        return n // b if self.drop_last else (n + b - 1) // b
 
     def __iter__(self):
         n = self.data.shape[0]
@@ -163,4 +165,4 @@ def validation_loader(root, args, device, channels, val_mean_std):
         img = torch.from_numpy(np.ascontiguousarray(decode(fn, channels))).to(device)
         call("primia_image_prepare", img, img.shape[0], img.shape[1], channels, R, off, off, S, 0, mean, std, out[i])
     targets = torch.tensor([t for _, t in samples], dtype=torch.int64, device=device)
-    return DeviceLoader(out, targets, args.batch_size, False, 0)
+    return DeviceLoader(out, targets, args.batch_size, False, 0, drop_last=False)

@@ -407,16 +407,21 @@ def test(args, model, device, val_loader, epoch, loss_fn, num_classes, verbose=T
     import torch
 
     model.eval()
-    losses, preds, tgts, scores = [], [], [], []
+    nll, preds, tgts, scores = [], [], [], []
     for data, target in val_loader:
-        logits = model.forward(data)
+        # (a ragged final batch — every validation sample counts — runs on a sibling engine of that size; eval-mode
+        # BatchNorm makes the logits independent of how the samples are batched)
+        logits = model.sibling(data.shape[0]).forward(data)
         ls = torch.log_softmax(logits, dim=1)
-        losses.append(float(-ls.gather(1, target.view(-1, 1)).mean().item()))
+        nll.append(-ls.gather(1, target.view(-1, 1)).reshape(-1).double().cpu())
         scores.append(logits.detach().float().cpu().numpy().copy())
         preds += logits.argmax(1).tolist()
         tgts += target.tolist()
     model.train()
-    test_loss = float(np.mean(losses))
+    # the reference averages the loss per batch of test_batch_size, then over batches (:1392-1412)
+    nll = torch.cat(nll)
+    tbs = max(1, int(getattr(args, "test_batch_size", 1) or 1))
+    test_loss = float(np.mean([float(nll[i:i + tbs].mean()) for i in range(0, nll.numel(), tbs)]))
     total_scores = np.concatenate(scores)
     total_scores -= total_scores.min(axis=1)[:, np.newaxis]
     total_scores = total_scores / total_scores.sum(axis=1)[:, np.newaxis]

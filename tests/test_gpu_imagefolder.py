@@ -98,3 +98,31 @@ def test_client_loader_statistics_and_batches(cuda, tmp_path):
     e2 = [x.clone() for x, _ in vl]
     assert all(x.shape == (4, 3, 64, 64) and torch.isfinite(x).all() for x in e1)
     assert not all(torch.equal(a, b) for a, b in zip(e1, e2))
+
+
+def test_validation_counts_every_sample(cuda):
+    """torchlib/utils.py:1354-1467: the validation pass sees the WHOLE folder — 11 samples through an engine built for 8
+    (the ragged tail of 3 runs on a sibling engine; eval-mode BatchNorm makes the logits independent of the batching) —
+    and averages the loss per batch of test_batch_size, then over batches."""
+    from primia_amd import resnet_spec as rs
+    from primia_amd.engine import ResNet18Engine
+    from primia_amd.torchlib_compat import test as validate
+
+    torch.manual_seed(5)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, 64, "max"))
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(11, 3, 64, 64, generator=g).to(cuda)
+    y = torch.randint(0, 3, (11,), generator=g).to(cuda)
+    eng = ResNet18Engine(8, 3, 3, 64, "max", dtype=torch.float32, device=cuda)
+    eng.load_state_dict(sd)
+    loader = imagefolder.DeviceLoader(x, y, 8, False, 0, drop_last=False)
+    assert len(loader) == 2 and [d.shape[0] for d, _ in loader] == [8, 3]
+    assert len(imagefolder.DeviceLoader(x, y, 8, False, 0)) == 1
+    whole = ResNet18Engine(11, 3, 3, 64, "max", dtype=torch.float32, device=cuda)
+    whole.load_state_dict(sd)
+    whole.eval()
+    nll = -torch.log_softmax(whole.forward(x), dim=1).gather(1, y.view(-1, 1)).reshape(-1).double().cpu()
+    for tbs, want in ((1, float(nll.mean())), (4, float(np.mean([float(nll[i:i + 4].mean()) for i in (0, 4, 8)])))):
+        loss, _ = validate(SimpleNamespace(test_batch_size=tbs), eng, cuda, loader, 1, None, 3, verbose=False)
+        assert abs(loss - want) < 1e-5 * abs(want), (tbs, loss, want)
+    assert eng.training                      # test() leaves the model in training mode, like the reference
