@@ -299,9 +299,10 @@ def federated_epoch(engine, loader, args, optimizer=None, group=None, ops=None, 
         if sched.trains(rank, batch_idx):
             data, target = next(it)
             optimizer.zero_grad()
-            engine.forward(data)
-            losses.append(engine.loss_backward(target, soft=soft_targets).clone())
-            optimizer.step()
+            eng = engine.sibling(data.shape[0])          # (the ragged final batch of a client's loader)
+            eng.forward(data)
+            losses.append(eng.loss_backward(target, soft=soft_targets).clone())
+            optimizer.step(eng)
         if sched.sync_after(batch_idx):
             sync(False, batch_idx)
             if not args.keep_optim_dict:

@@ -11,8 +11,9 @@ Here the decode (PIL, host) produces uint8 HWC arrays; everything after it runs 
 `primia_mean_std`.  The transform chain is primia_amd.augment.TrainTransform: every member of the reference's
 create_albu_transform on the GPU (both shipped presets run as written).
 
-A ragged final batch is dropped (the reference's loader would yield it): `len(loader)` = floor(n / batch_size).
-(Batches that MixUp halves in the local training loop are served by ResNet18Engine.sibling.)
+Loaders yield the ragged final batch as the reference's do (DataLoader / FederatedDataLoader, drop_last = False):
+`len(loader)` = ceil(n / batch_size); such a batch — and the batches MixUp halves in the local training loop — run on a
+sibling engine of their size (ResNet18Engine.sibling: same parameters, its own activations).
 """
 import os
 import random
@@ -65,7 +66,8 @@ def prepare(samples, args, device, channels, rng, mean=None, std=None):
 
 
 class DeviceLoader:
-    """FederatedDataLoader(batch_size, shuffle=True) over a device-resident (data, targets) pair."""
+    """FederatedDataLoader(batch_size, shuffle=True) over a device-resident (data, targets) pair (drop_last as given:
+    synthetic / fixed-size callers keep whole batches only)."""
 
     def __init__(self, data, targets, batch_size, shuffle, seed, drop_last=True):
         self.data, self.targets, self.batch_size, self.shuffle = data, targets, batch_size, shuffle
@@ -94,7 +96,7 @@ class AugmentingLoader:
         self.gen = torch.Generator().manual_seed(seed)
 
     def __len__(self):
-        return len(self.images) // self.batch_size
+        return (len(self.images) + self.batch_size - 1) // self.batch_size      # DataLoader's default: drop_last = False
 
     def __iter__(self):
         order = torch.randperm(len(self.images), generator=self.gen).tolist()
@@ -148,7 +150,7 @@ def client_loader(root, args, device, channels, seed):
     reps = int(getattr(args, "repetitions_dataset", 1) or 1)
     walks = [torch.stack([tf(img, rng) for img in images]) for _ in range(reps)]   # utils.py:704-717: one pass per walk
     data, targets = register(walks, targets, args, len(classes), seed)
-    return DeviceLoader(data, targets, args.batch_size, True, seed), (mean, std)
+    return DeviceLoader(data, targets, args.batch_size, True, seed, drop_last=False), (mean, std)
 
 
 def validation_loader(root, args, device, channels, val_mean_std):

@@ -299,9 +299,10 @@ def secure_aggregation_epoch(args, models, device, train_loaders, optimizers, ep
                 continue
             optimizers[i].zero_grad()
             data, target = next(it)
-            models[i].forward(data)
-            loss = models[i].loss_backward(target, soft=getattr(loss_fns.get(i), "soft", False) if loss_fns else False)
-            optimizers[i].step()
+            eng = models[i].sibling(data.shape[0])       # (the ragged final batch of a client's loader)
+            eng.forward(data)
+            loss = eng.loss_backward(target, soft=getattr(loss_fns.get(i), "soft", False) if loss_fns else False)
+            optimizers[i].step(eng)
             avg_loss.append(loss.item())
         if batch_idx > 0 and batch_idx % args.sync_every_n_batch == 0:
             models["local_model"] = aggregation(models["local_model"], models, train_loaders.keys(), crypto_provider,

@@ -77,6 +77,10 @@ def test_client_loader_statistics_and_batches(cuda, tmp_path):
                            train_federated=True)       # a federated client registers its dataset repetitions_dataset times
     loader, (mean, std) = imagefolder.client_loader(str(tmp_path), args, cuda, 3, seed=1)
     assert len(loader) == (18 * 2) // 4
+    args5 = SimpleNamespace(inference_resolution=64, train_resolution=64, batch_size=5, repetitions_dataset=1,
+                            train_federated=True)
+    l5, _ = imagefolder.client_loader(str(tmp_path), args5, cuda, 3, seed=1)
+    assert len(l5) == 4 and [x.shape[0] for x, _ in l5] == [5, 5, 5, 3]      # FederatedDataLoader: drop_last = False
     # the dataset is normalised with its own statistics: per-channel mean 0 / std 1 (torch.std_mean, unbiased)
     s, m = torch.std_mean(loader.data, dim=(0, 2, 3))
     assert m.abs().max() < 1e-4 and (s - 1).abs().max() < 1e-3
@@ -93,10 +97,10 @@ def test_client_loader_statistics_and_batches(cuda, tmp_path):
                           rotation=10, scale=0.1, albu_prob=0.5, individual_albu_probs=0.5, noise_std=0.05, noise_prob=0.5,
                           randomgamma=True, blur=True)
     vl, _ = imagefolder.client_loader(str(tmp_path), van, cuda, 3, seed=1)
-    assert len(vl) == 18 // 4
+    assert len(vl) == 5                       # DataLoader's default drop_last = False: 4 whole batches + the last 2 images
     e1 = [x.clone() for x, _ in vl]
     e2 = [x.clone() for x, _ in vl]
-    assert all(x.shape == (4, 3, 64, 64) and torch.isfinite(x).all() for x in e1)
+    assert [x.shape[0] for x in e1] == [4, 4, 4, 4, 2] and all(torch.isfinite(x).all() for x in e1)
     assert not all(torch.equal(a, b) for a, b in zip(e1, e2))
 
 
