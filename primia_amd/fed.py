@@ -299,10 +299,11 @@ def federated_epoch(engine, loader, args, optimizer=None, group=None, ops=None, 
         if sched.trains(rank, batch_idx):
             data, target = next(it)
             optimizer.zero_grad()
-            eng = engine.sibling(data.shape[0])          # (the ragged final batch of a client's loader)
+            sib = getattr(engine, "sibling", None)       # (the ragged final batch of a client's loader)
+            eng = engine if sib is None else sib(data.shape[0])
             eng.forward(data)
             losses.append(eng.loss_backward(target, soft=soft_targets).clone())
-            optimizer.step(eng)
+            optimizer.step() if eng is engine else optimizer.step(eng)
         if sched.sync_after(batch_idx):
             sync(False, batch_idx)
             if not args.keep_optim_dict:

@@ -50,7 +50,7 @@ class EngineOptimizer:
         """`engine`: the engine whose backward pass produced the gradients, when it is a sibling of the one this optimizer
         was built on (ResNet18Engine.sibling: same parameters and optimizer state, another batch size)."""
         eng = self.engine if engine is None else engine
-        if eng._root is not self.engine._root:
+        if eng is not self.engine and getattr(eng, "_root", eng) is not getattr(self.engine, "_root", self.engine):
             raise ValueError("optimizer.step(engine): not a sibling of the optimizer's engine")
         g = self.param_groups[0]
         if self.kind == "SGD":

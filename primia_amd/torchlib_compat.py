@@ -299,10 +299,11 @@ def secure_aggregation_epoch(args, models, device, train_loaders, optimizers, ep
                 continue
             optimizers[i].zero_grad()
             data, target = next(it)
-            eng = models[i].sibling(data.shape[0])       # (the ragged final batch of a client's loader)
+            sib = getattr(models[i], "sibling", None)    # (the ragged final batch of a client's loader)
+            eng = models[i] if sib is None else sib(data.shape[0])
             eng.forward(data)
             loss = eng.loss_backward(target, soft=getattr(loss_fns.get(i), "soft", False) if loss_fns else False)
-            optimizers[i].step(eng)
+            optimizers[i].step() if eng is models[i] else optimizers[i].step(eng)
             avg_loss.append(loss.item())
         if batch_idx > 0 and batch_idx % args.sync_every_n_batch == 0:
             models["local_model"] = aggregation(models["local_model"], models, train_loaders.keys(), crypto_provider,
@@ -350,11 +351,11 @@ def train(args, model, device, train_loader, optimizer, epoch, loss_fn, num_clas
             soft = True
         # MixUp mixes the two halves of a batch with probability mixup_prob and passes it on whole otherwise: consecutive
         # steps see B or B / 2 samples (:1262-1267).  A sibling engine serves the other size on the same parameters.
-        eng = model if data.shape[0] == model.N else model.sibling(data.shape[0])
+        eng = model if data.shape[0] == getattr(model, "N", data.shape[0]) else model.sibling(data.shape[0])
         optimizer.zero_grad()
         eng.forward(data)
         loss = eng.loss_backward(target, soft=soft)
-        optimizer.step(eng)
+        optimizer.step() if eng is model else optimizer.step(eng)
         if batch_idx % args.log_interval == 0:
             losses.append(loss.item())
             if verbose:
@@ -412,7 +413,7 @@ def test(args, model, device, val_loader, epoch, loss_fn, num_classes, verbose=T
     for data, target in val_loader:
         # (a ragged final batch — every validation sample counts — runs on a sibling engine of that size; eval-mode
         # BatchNorm makes the logits independent of how the samples are batched)
-        logits = model.sibling(data.shape[0]).forward(data)
+        logits = (model.sibling(data.shape[0]) if hasattr(model, "sibling") else model).forward(data)
         ls = torch.log_softmax(logits, dim=1)
         nll.append(-ls.gather(1, target.view(-1, 1)).reshape(-1).double().cpu())
         scores.append(logits.detach().float().cpu().numpy().copy())
