@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <cstdint>
 
-enum Op { ADD32, ALIGNBIT, LSHLADD64, BITOP3, ADD64PAIR, XOR32, MIX };
+enum Op { ADD32, ALIGNBIT, LSHLADD64, BITOP3, ADD64PAIR, XOR32, MIX, FMA, FMAC, MULF, MAXF, CNDMASK, LSHLOR, ANDOR, PERM, CVTPK, MAX3F, PKFMA, PKMUL, MAXU, LSHLREV, FMA_SGPR };
 
 template <int OP, int CH>
 __global__ __launch_bounds__(512) void k(uint64_t* out, int iters, uint64_t* clk) {
@@ -33,6 +33,21 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int iters, uint64_t* clk
                     asm volatile("v_add_co_u32 %0, vcc, %0, %2\n\tv_addc_co_u32 %1, vcc, %1, %3, vcc"
                                  : "+v"(a[c]), "+v"(b[c]) : "v"(b[(c + 1) % CH]), "v"(a[(c + 1) % CH]) : "vcc");
                 }
+                if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[c]) : "v"(b[c]), "v"(b[(c + 1) % CH]));
+                if (OP == FMA_SGPR) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[c]) : "s"(iters), "v"(b[c]));
+                if (OP == FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[c]) : "v"(b[c]), "v"(b[(c + 1) % CH]));
+                if (OP == MULF) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]));
+                if (OP == MAXF) asm volatile("v_max_f32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]));
+                if (OP == MAXU) asm volatile("v_max_u32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]));
+                if (OP == LSHLREV) asm volatile("v_lshlrev_b32 %0, 3, %0" : "+v"(a[c]));
+                if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[c]) : "v"(b[c]) : );
+                if (OP == LSHLOR) asm volatile("v_lshl_or_b32 %0, %0, 4, %1" : "+v"(a[c]) : "v"(b[c]));
+                if (OP == ANDOR) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(a[c]) : "v"(b[c]), "v"(b[(c + 1) % CH]));
+                if (OP == PERM) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(a[c]) : "v"(b[c]), "v"(b[(c + 1) % CH]));
+                if (OP == CVTPK) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]));
+                if (OP == MAX3F) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[c]) : "v"(b[c]), "v"(b[(c + 1) % CH]));
+                if (OP == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(q[c]) : "v"(q[(c + 1) % CH]));
+                if (OP == PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(q[c]) : "v"(q[(c + 1) % CH]));
                 if (OP == MIX) {      // the SHA-512 round's proportions: 3 alignbit : 2 lshl_add_u64 : 2 bitop3
                     asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[c]) : "v"(b[c]));
                     asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[c]) : "v"(q[(c + 1) % CH]));
@@ -81,6 +96,21 @@ int main() {
     run<LSHLADD64, 8>("v_lshl_add_u64", 512, 1);
     run<ADD64PAIR, 8>("v_add_co + v_addc", 512, 2);
     run<MIX, 4>("SHA-512 mix 3:2:2", 512, 7);
-    run<MIX, 4>("SHA-512 mix 3:2:2", 1024, 7);
+    // the floating-point / packing instructions of the stem kernels (stem_bwd_fused, stem_fwd_fused, bn.hip pooling)
+    run<FMA, 8>("v_fma_f32 (3 VGPR sources)", 512, 1);
+    run<FMA_SGPR, 8>("v_fma_f32 (1 SGPR source)", 512, 1);
+    run<FMAC, 8>("v_fmac_f32 (VOP2)", 512, 1);
+    run<MULF, 8>("v_mul_f32", 512, 1);
+    run<MAXF, 8>("v_max_f32", 512, 1);
+    run<MAXU, 8>("v_max_u32", 512, 1);
+    run<LSHLREV, 8>("v_lshlrev_b32 (1 source)", 512, 1);
+    run<CNDMASK, 8>("v_cndmask_b32 (vcc)", 512, 1);
+    run<LSHLOR, 8>("v_lshl_or_b32", 512, 1);
+    run<ANDOR, 8>("v_and_or_b32", 512, 1);
+    run<PERM, 8>("v_perm_b32", 512, 1);
+    run<CVTPK, 8>("v_cvt_pk_bf16_f32", 512, 1);
+    run<MAX3F, 8>("v_max3_f32", 512, 1);
+    run<PKFMA, 8>("v_pk_fma_f32 (2 lanes-ops)", 512, 1);
+    run<PKMUL, 8>("v_pk_mul_f32 (2 lane-ops)", 512, 1);
     return 0;
 }
