@@ -374,6 +374,12 @@ def main():
                       "kernel + its ordered reduce)" % nprof,
             "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic, "traffic_offline": traffic_offline,
+            # `frac` is priced at the nominal 2.4 GHz peak.  Under matrix load the part runs at ~2.0 GHz (PMC: profiles/
+            # r04_stall_counters.txt) and a loop of nothing but MFMAs on random operands holds 1.79 PFLOP/s, a stage body that
+            # re-reads its fragments from LDS and meets a barrier 1.48 (tools/micro/mfma_stage.hip, profiles/r04_mfma_ceilings.txt)
+            "sustained_ceilings": {"mfma_only_random_operands_tflops": 1788.0, "frac_of_it": round(kernels[dom]["tflops"] / 1788.0, 4),
+                                   "lds_reread_and_barrier_tflops": 1476.0, "frac_of_that": round(kernels[dom]["tflops"] / 1476.0, 4),
+                                   "source": "profiles/r04_mfma_ceilings.txt"},
             "all_conv": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 3),
                          "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)},
             "kernels": kernels, "by_pass": by_pass}
