@@ -43,7 +43,8 @@ class ResNet18Engine:
         reads the environment; the kernel library's own switches are `_lib.set_option` (primia_set_option).
         `share`: another engine of the same network whose PARAMETERS this one uses (see `sibling`)."""
         self._root = self if share is None else share._root
-        for k, v in (options or {}).items():
+        self._options = dict(options or {})
+        for k, v in self._options.items():
             if not hasattr(type(self), k):
                 raise ValueError(f"unknown engine option {k!r}")
             setattr(self, k, v)
@@ -365,8 +366,11 @@ class ResNet18Engine:
         if n not in sib:
             sib[n] = ResNet18Engine(n, self.spec.num_classes, self.spec.in_channels, self.spec.input_size,
                                     self.spec.pooling, dtype=self.dtype, device=self.device, norm=self.norm,
-                                    groups=self.groups, share=self._root)
+                                    groups=self.groups, options=self._root._options, share=self._root)
+        # what the host sets on the root after construction travels with every call: the optimizer's fused tail and —
+        # above all — the DP-SGD parameters (a halved or ragged batch must be clipped and noised like every other)
         sib[n].fuse_sgd_tail = self._root.fuse_sgd_tail
+        sib[n].dp_params = self._root.dp_params
         sib[n].train(self.training)
         return sib[n]
 

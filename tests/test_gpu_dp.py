@@ -420,3 +420,21 @@ def test_dp_norm_pass_at_batch_256_against_explicit_slabs(cuda):
         assert e < 2e-5, (name, kern[name], e)
         del slab
     print(f"batch-256 norm pass vs explicit slabs: worst per-sample relative error {worst:.2e}")
+
+
+def test_sibling_engine_keeps_the_dp_parameters(cuda):
+    """A ragged or MixUp-halved batch runs on ResNet18Engine.sibling(n): it must be clipped and noised like every other
+    batch — the DP-SGD parameters set on the root engine after construction (train.py) travel with every sibling() call."""
+    eng = ResNet18Engine(4, 3, 3, 64, "max", dtype=torch.float32, device=cuda, norm="group")
+    eng.init_weights()
+    sib = eng.sibling(2)
+    assert sib.dp_params is None
+    eng.dp_params = {"max_grad_norm": 0.05, "noise_multiplier": 0.0}
+    sib = eng.sibling(2)
+    assert sib.dp_params == eng.dp_params and sib.norm == "group"
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.randn(2, 3, 64, 64, generator=g).to(cuda), torch.randint(0, 3, (2,), generator=g).to(cuda)
+    sib.forward(x)
+    sib.loss_backward(y)                       # -> dp_loss_backward(**dp_params)
+    assert sib.dp_stats["clip"].numel() == 2 and float(sib.dp_stats["clip"].max()) < 1.0
+    assert float(eng.grads.norm()) <= 0.05 * 1.001          # the shared gradient arena holds the CLIPPED mean
