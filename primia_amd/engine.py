@@ -369,8 +369,8 @@ class ResNet18Engine:
                                     groups=self.groups, options=self._root._options, share=self._root)
         # what the host sets on the root after construction travels with every call: the optimizer's fused tail and —
         # above all — the DP-SGD parameters (a halved or ragged batch must be clipped and noised like every other)
-        sib[n].fuse_sgd_tail = self._root.fuse_sgd_tail
-        sib[n].dp_params = self._root.dp_params
+        for attr in ("fuse_sgd_tail", "dp_params", "class_weight"):
+            setattr(sib[n], attr, getattr(self._root, attr))
         sib[n].train(self.training)
         return sib[n]
 

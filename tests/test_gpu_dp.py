@@ -432,6 +432,10 @@ def test_sibling_engine_keeps_the_dp_parameters(cuda):
     eng.dp_params = {"max_grad_norm": 0.05, "noise_multiplier": 0.0}
     sib = eng.sibling(2)
     assert sib.dp_params == eng.dp_params and sib.norm == "group"
+    eng.class_weight = torch.tensor([1.0, 2.0, 0.5], device=cuda)          # CrossEntropyLoss(weight=...) of train.py:316-319
+    assert eng.sibling(2).class_weight is eng.class_weight
+    eng.class_weight = None
+    assert eng.sibling(2).class_weight is None
     g = torch.Generator().manual_seed(3)
     x, y = torch.randn(2, 3, 64, 64, generator=g).to(cuda), torch.randint(0, 3, (2,), generator=g).to(cuda)
     sib.forward(x)
