@@ -23,6 +23,9 @@ primia_amd.torchlib_compat (which accept worker objects or their ids as keys).  
 """
 import torch
 
+hook = None              # the last TorchHook built (PySyft: sy.hook)
+local_worker = None      # ... and its local worker (sy.local_worker)
+
 __all__ = ["TorchHook", "VirtualWorker", "ObjectStore", "PrivateGridNetwork", "BaseDataset", "FederatedDataset",
            "FederatedDataLoader", "setup_pysyft"]
 
@@ -33,6 +36,15 @@ class TorchHook:
 
     def __init__(self, torch_module=torch, local_worker=None, is_client=True, verbose=False):
         self.local_worker = local_worker or VirtualWorker(self, id="me")
+        # PySyft publishes the hook and its local worker as module globals (`sy.hook`, `sy.local_worker`; the reference
+        # reads `sy.hook` when torch is already hooked, train.py:84-87, and sets `sy.local_worker.clients` /
+        # `.object_store.garbage_delay` in inference.py:158,233) and marks torch as hooked
+        import sys
+
+        for mod in (sys.modules[__name__], sys.modules.get("primia_syft_compat")):
+            if mod is not None:
+                mod.hook, mod.local_worker = self, self.local_worker
+        torch_module.torch_hooked = True
         if not hasattr(torch_module.Tensor, "tag"):
             def tag(t, *tags):
                 cur = set(getattr(t, "_primia_tags", ()))
@@ -46,6 +58,8 @@ class TorchHook:
 
 class ObjectStore:
     """worker.object_store (syft/generic/object_storage.py): id -> object, searchable by tag."""
+
+    garbage_delay = 0      # (PySyft's deferred deletion of remote objects: nothing to defer here)
 
     def __init__(self):
         self._objects = {}

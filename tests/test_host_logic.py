@@ -300,3 +300,18 @@ def test_augment_oracle_second_batch_properties():
     black = np.zeros((224, 224, 3), np.uint8)
     fl = A.add_sun_flare(black, cx, cy, circles)
     assert fl[cy, cx].tolist() == [255, 255, 255] and fl.max() == 255 and (fl >= black).all()
+
+
+def test_syft_shim_module_globals():
+    """PySyft publishes the hook and its local worker as module globals; the reference reads `sy.hook` when torch is
+    already hooked (train.py:84-87) and sets sy.local_worker.clients / .object_store.garbage_delay (inference.py:158,233)."""
+    import torch
+
+    import primia_syft_compat as sy
+
+    hook = sy.TorchHook(torch)
+    assert sy.hook is hook and sy.local_worker is hook.local_worker and torch.torch_hooked
+    sy.local_worker.clients = ["model_owner", "data_owner"]
+    sy.local_worker.object_store.garbage_delay = 1
+    assert sy.local_worker.clients == ["model_owner", "data_owner"] and sy.local_worker.object_store.garbage_delay == 1
+    assert sy.VirtualWorker(hook, id="alice").object_store.garbage_delay == 0
