@@ -440,3 +440,13 @@ class TrainTransform:
         out = torch.empty(C, S, S, dtype=torch.float32, device=dev)
         call("primia_image_finish", cur, S, C, self.mean, self.std, out)
         return out
+
+
+def create_albu_transform(args, mean, std, device="cuda:0", channels=None, seed=0):
+    """torchlib/dataloader.py:138-217 by its own name: the training transform chain for `args`, as a TrainTransform
+    (`tf(uint8 HWC device image, random.Random) -> fp32 [C, S, S]`).  `channels` defaults to 3 for `pretrained` presets and
+    1 otherwise, as the reference's end_transformations do."""
+    if channels is None:
+        channels = 3 if getattr(args, "pretrained", True) else 1
+    return TrainTransform(args, mean, std, device, channels, seed)
+

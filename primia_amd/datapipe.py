@@ -209,3 +209,20 @@ def calc_class_weights(args, train_loader, num_classes):
     `train_loader` is one loader, or {worker: loader} when federated; soft / one-hot targets (mixup or federated
     weight_classes) count for their arg-max class."""
     return class_weights_from_counts(class_counts(train_loader, num_classes))
+
+
+def random_split(dataset, lengths, generator=None):
+    """torchlib/dataloader.py:440-450 (torch 1.5's random_split, vendored there because torch 1.4 took no generator):
+    a seeded permutation of the indices, cut into consecutive Subsets of the given lengths."""
+    import torch
+    from torch.utils.data import Subset
+
+    if sum(lengths) != len(dataset):
+        raise ValueError("Sum of input lengths does not equal the length of the input dataset!")
+    indices = torch.randperm(sum(lengths), generator=generator).tolist()
+    out, offset = [], 0
+    for length in lengths:
+        offset += length
+        out.append(Subset(dataset, indices[offset - length:offset]))
+    return out
+

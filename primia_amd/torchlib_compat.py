@@ -460,3 +460,82 @@ def save_model(model, optim, path, args, epoch, val_mean_std):
     model = model["local_model"] if isinstance(model, dict) else model
     torch.save({"epoch": epoch, "model_state_dict": model.state_dict(), "optim_state_dict": opt_state_dict,
                 "args": args, "val_mean_std": val_mean_std}, path)
+
+
+class Cross_entropy_one_hot:
+    """torchlib/utils.py:404-437 — cross entropy on soft (one-hot / mixed) targets, optionally class-weighted:
+    mean_n( sum_c(weight_c t_nc) * sum_c(-t_nc log_softmax(o)_nc) ).  In the training loops the engine computes exactly this
+    inside loss_backward (primia_xent_soft); the object carries `soft = True` (what the loops read) and `weight`, and is
+    callable on (logits, targets) for host-side uses such as the validation loss."""
+    soft = True
+
+    def __init__(self, reduction="mean", weight=None):
+        if reduction not in ("mean", "sum"):
+            raise NotImplementedError("reduction must be mean or sum")
+        self.reduction, self.weight = reduction, weight
+
+    def __call__(self, output, target):
+        import torch
+
+        per = torch.sum(-target * torch.log_softmax(output.float(), dim=1), dim=1)
+        if self.weight is not None:
+            per = torch.sum(self.weight.to(target) * target, dim=1) * per
+        return per.mean() if self.reduction == "mean" else per.sum()
+
+    forward = __call__
+
+
+def save_config_results(args, score, timestamp, table):
+    """torchlib/utils.py:859-874 — one row per run (every non-callable attribute of `args`, the timestamp, the best
+    validation score) appended to the CSV `table`."""
+    from os.path import isfile
+
+    import pandas as pd
+
+    members = [a for a in dir(args) if not callable(getattr(args, a)) and not a.startswith("__")]
+    if not isfile(table):
+        print("Configuration table does not exist - Creating new")
+        df = pd.DataFrame(columns=members)
+    else:
+        df = pd.read_csv(table)
+    row = dict(zip(members, [getattr(args, x) for x in members]))
+    row["timestamp"] = timestamp
+    row["best_validation_score"] = score
+    df = pd.concat([df, pd.DataFrame([row])], ignore_index=True)      # (DataFrame.append of pandas < 2)
+    df.to_csv(table, index=False)
+
+
+def resnet18(pretrained=False, progress=True, in_channels=3, pooling="avg", num_classes=1000, input_size=224,
+             batch_size=None, adptpool=False, dtype=None, device="cuda:0", norm_layer=None, **kwargs):
+    """torchlib/models.py:499-516 with the keyword arguments train.py passes (:259-268): the same network as a
+    ResNet18Engine.  One thing the reference's module does not need must be given: `batch_size` (the engine's buffers are
+    sized for it; other sizes run on `engine.sibling(n)`).  `pretrained=True` loads the ImageNet weights the way train.py
+    does (a local file; refused when absent).  `adptpool` (an adaptive average pool in front of fc) is the identity at the
+    resolutions the engine serves (multiples of 32 whose last feature map the 7 x 7 / final pooling covers)."""
+    import torch
+
+    from .engine import ResNet18Engine
+
+    if batch_size is None:
+        raise TypeError("resnet18(): batch_size=... is required (the HIP engine allocates its activations up front)")
+    if kwargs:
+        raise TypeError("resnet18(): unsupported arguments {}".format(sorted(kwargs)))
+    norm = "batch"
+    if norm_layer is not None:      # train.py:308 passes a GroupNorm factory for differentially_private = yes
+        norm = "group"
+    eng = ResNet18Engine(batch_size, num_classes, in_channels, input_size, pooling,
+                         dtype=dtype or torch.bfloat16, device=device, norm=norm)
+    eng.init_weights()
+    if pretrained:
+        import train as _train        # the loader of the CLI (reads PRIMIA_PRETRAINED_RESNET18 / torch's hub cache)
+
+        _train.load_pretrained(eng, num_classes)
+    return eng
+
+
+def vgg16(*args, **kwargs):
+    raise NotImplementedError("vgg16 is outside the path this library accelerates (ResNet-18: BASELINE.json north_star)")
+
+
+def conv_at_resolution(*args, **kwargs):
+    raise NotImplementedError("the small ConvNets are outside the path this library accelerates (ResNet-18)")

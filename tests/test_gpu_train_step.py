@@ -586,3 +586,21 @@ def test_transition_forward_pair_gives_the_same_bits(cuda, batch, size):
         call("primia_conv2d_fwd_stats_pair", c1.desc, xin, c1.w_fwd, p1, q1, cd.desc, cd.w_fwd, pd, qd, eng.dt)
         assert torch.equal(p1.view(torch.int16), y1.view(torch.int16)) and torch.equal(pd.view(torch.int16), yd.view(torch.int16))
         assert torch.equal(q1, s1) and torch.equal(qd, sd), blk.prefix
+
+
+def test_torchlib_models_resnet18_builds_the_engine(cuda):
+    """`from torchlib.models import resnet18` with the keyword arguments /root/reference/train.py:259-268 passes (+ the
+    batch size the engine needs): the same network, state-dict compatible with the reference's 122 keys."""
+    from torchlib.models import resnet18
+
+    torch.manual_seed(3)
+    m = resnet18(pretrained=False, num_classes=3, in_channels=3, adptpool=False, input_size=64, pooling="max", batch_size=4,
+                 dtype=torch.float32, device=cuda)
+    assert isinstance(m, ResNet18Engine) and list(m.state_dict().keys()) == rs.state_dict_keys(m.spec)
+    x = torch.randn(4, 3, 64, 64).to(cuda)
+    m.eval()
+    ref = O.forward({k: v.clone().cpu() for k, v in m.state_dict().items()}, x.cpu(), training=False, input_size=64)
+    out = m.forward(x).cpu()
+    assert (out - ref).norm() / ref.norm() < 1e-5
+    g = resnet18(num_classes=3, input_size=64, pooling="max", batch_size=2, norm_layer=object(), dtype=torch.float32, device=cuda)
+    assert g.norm == "group"

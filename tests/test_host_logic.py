@@ -315,3 +315,53 @@ def test_syft_shim_module_globals():
     sy.local_worker.object_store.garbage_delay = 1
     assert sy.local_worker.clients == ["model_owner", "data_owner"] and sy.local_worker.object_store.garbage_delay == 1
     assert sy.VirtualWorker(hook, id="alice").object_store.garbage_delay == 0
+
+
+def test_torchlib_import_shim_covers_what_the_reference_scripts_import(tmp_path):
+    """`from torchlib.utils import ...`, `from torchlib.dataloader import ...`, `from torchlib.models import ...` as
+    /root/reference/train.py:27-51 and inference.py:27-35 write them (the PIL / DICOM file loaders excepted: host-side data
+    preparation outside the path)."""
+    import importlib
+
+    import numpy as np
+    import torch
+
+    want = {"torchlib.utils": ["Arguments", "Cross_entropy_one_hot", "LearningRateScheduler", "MixUp", "save_config_results",
+                               "save_model", "test", "train", "train_federated", "setup_pysyft", "calc_class_weights",
+                               "stats_table"],
+            "torchlib.dataloader": ["calc_mean_std", "random_split", "create_albu_transform"],
+            "torchlib.models": ["resnet18", "vgg16", "conv_at_resolution"],
+            "torchlib.run_websocket_server": ["read_websocket_config"]}
+    for mod, names in want.items():
+        m = importlib.import_module(mod)
+        assert [n for n in names if not hasattr(m, n)] == [], mod
+    from torchlib.dataloader import random_split
+    from torchlib.utils import Cross_entropy_one_hot, save_config_results
+
+    # Cross_entropy_one_hot: torch's soft-target cross entropy, class-weighted as utils.py:416-437
+    g = torch.Generator().manual_seed(0)
+    o, t = torch.randn(5, 3, generator=g), torch.softmax(torch.randn(5, 3, generator=g), dim=1)
+    w = torch.tensor([1.0, 2.0, 0.5])
+    ref = torch.mean(torch.sum(w * t, dim=1) * torch.sum(-t * torch.log_softmax(o, dim=1), dim=1))
+    assert torch.allclose(Cross_entropy_one_hot(weight=w)(o, t), ref) and Cross_entropy_one_hot().soft
+    assert torch.allclose(Cross_entropy_one_hot()(o, t), torch.nn.functional.cross_entropy(o, t))
+    # random_split: disjoint, complete, seeded
+    a, b = random_split(list(range(10)), [7, 3], generator=torch.Generator().manual_seed(1))
+    a2, _ = random_split(list(range(10)), [7, 3], generator=torch.Generator().manual_seed(1))
+    assert sorted(list(a) + list(b)) == list(range(10)) and list(a) == list(a2)
+    # save_config_results: one row per run
+    from types import SimpleNamespace
+
+    table = str(tmp_path / "runs.csv")
+    save_config_results(SimpleNamespace(lr=1e-3, model="resnet-18"), 81.5, "t0", table)
+    save_config_results(SimpleNamespace(lr=1e-4, model="resnet-18"), 83.0, "t1", table)
+    import pandas as pd
+
+    df = pd.read_csv(table)
+    assert list(df["best_validation_score"]) == [81.5, 83.0] and list(df["timestamp"]) == ["t0", "t1"] and np.isclose(df["lr"][1], 1e-4)
+    import pytest
+
+    with pytest.raises(NotImplementedError):
+        importlib.import_module("torchlib.models").vgg16()
+    with pytest.raises(TypeError, match="batch_size"):
+        importlib.import_module("torchlib.models").resnet18(num_classes=3)
