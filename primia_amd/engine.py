@@ -75,12 +75,12 @@ class ResNet18Engine:
                     share.dtype) != (num_classes, in_channels, input_size, pooling, norm, dtype):
                 raise ValueError("a sibling engine must be the same network, norm and dtype as the engine it shares with")
             self.flat, self._grads = share.flat, share._grads
-        self.views, self.gviews = {}, {}
+        self.views, self._gviews = {}, {}
         off = 0
         for k, s in self.p_entries:
             n = int(torch.Size(s).numel())
             self.views[k] = self.flat[off:off + n].view(s)
-            self.gviews[k] = self._grads[off:off + n].view(s)
+            self._gviews[k] = self._grads[off:off + n].view(s)
             off += n
         for k, s in self.b_entries:
             n = int(torch.Size(s).numel())
@@ -334,7 +334,7 @@ class ResNet18Engine:
                 wf=(ctypes.c_void_p * n)(*[vp(c.w_fwd) for c in cs]),
                 wd=(ctypes.c_void_p * n)(*[vp(c.w_dgrad) for c in cs]),
                 acc=(ctypes.c_void_p * n)(*[vp(c.acc) for c in cs]),
-                gw=(ctypes.c_void_p * n)(*[vp(self.gviews[c.spec.name + ".weight"]) for c in cs]))
+                gw=(ctypes.c_void_p * n)(*[vp(self._gviews[c.spec.name + ".weight"]) for c in cs]))
         return self._many
 
     # Adam's moments and step count belong to the PARAMETERS: siblings read and write the root engine's
@@ -353,6 +353,13 @@ class ResNet18Engine:
     @opt_steps.setter
     def opt_steps(self, v):
         self._root._opt_steps = v
+
+    @property
+    def gviews(self):
+        """{name: view of the gradient arena}.  Reading it finishes a deferred conv-gradient pass first (fuse_sgd_tail leaves
+        the conv gradients in their accumulators between loss_backward() and step()), like `grads`."""
+        self.materialize_grads()
+        return self._gviews
 
     def sibling(self, batch_size):
         """An engine for ANOTHER batch size on the SAME parameters, gradients, running statistics, kernel-layout weight
@@ -656,23 +663,23 @@ class ResNet18Engine:
                 call("primia_gn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, psg, psb, self.N,
                      y.shape[0] // self.N, C, self.groups, int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
             if self.dp is None:  # plain training: dgamma / dbeta = sum over samples
-                call("primia_weighted_colsum", psg, self.ones_n, self.gviews[b + ".weight"], self.N, C)
-                call("primia_weighted_colsum", psb, self.ones_n, self.gviews[b + ".bias"], self.N, C)
+                call("primia_weighted_colsum", psg, self.ones_n, self._gviews[b + ".weight"], self.N, C)
+                call("primia_weighted_colsum", psb, self.ones_n, self._gviews[b + ".bias"], self.N, C)
             return
         if relu and g_out is not None and b in self.relu_masks:
             call("primia_bn_bwd_mask", y, self.relu_masks[b], dz, dy, g_out if keep_g else None,
                  self.views[b + ".weight"], sm, si,
-                 self.gviews[b + ".weight"], self.gviews[b + ".bias"], y.shape[0], y.shape[1], self.bn_ws,
+                 self._gviews[b + ".weight"], self._gviews[b + ".bias"], y.shape[0], y.shape[1], self.bn_ws,
                  self.bn_ws_bytes, self.dt)
             return
         if relu and g_out is None:
             # z = relu(bn(y)), no residual: the mask is recomputed from y, z is not read
             call("primia_bn_relu_bwd", y, dz, dy, self.views[b + ".weight"], self.views[b + ".bias"], sm, si,
-                 self.gviews[b + ".weight"], self.gviews[b + ".bias"], y.shape[0], y.shape[1], self.bn_ws,
+                 self._gviews[b + ".weight"], self._gviews[b + ".bias"], y.shape[0], y.shape[1], self.bn_ws,
                  self.bn_ws_bytes, self.dt)
             return
-        call("primia_bn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, self.gviews[b + ".weight"],
-             self.gviews[b + ".bias"], y.shape[0], y.shape[1], int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
+        call("primia_bn_bwd", y, z, dz, dy, g_out, self.views[b + ".weight"], sm, si, self._gviews[b + ".weight"],
+             self._gviews[b + ".bias"], y.shape[0], y.shape[1], int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
 
     wgrad_pair = True
     gn_relu_recompute = True
@@ -762,7 +769,7 @@ class ResNet18Engine:
             self.dw_acc.zero_()
         # (under DP-SGD fc.weight / fc.bias gradients are overwritten later from the clipped dlogits)
         call("primia_linear_bwd", self.feat, self.views["fc.weight"], self.dlogits, None,
-             self.gviews["fc.weight"], self.gviews["fc.bias"], N, 512, nc)
+             self._gviews["fc.weight"], self._gviews["fc.bias"], N, 512, nc)
         last = self.spec.blocks[-1].prefix
         hw = self.final_hw
         call("primia_head_bwd", self.views["fc.weight"], self.dlogits, t[last + ".dout"], N, hw * hw, 512, nc, self.dt)
@@ -786,8 +793,8 @@ class ResNet18Engine:
                 (sm2, si2), (smd, sid) = self.save[b2], self.save[bd]
                 call("primia_bn_bwd_pair", t[p + ".y2"], t[p + ".yd"], dout, self.relu_masks[b2], t[p + ".dy2"],
                      t[p + ".dyd"], self.views[b2 + ".weight"], sm2, si2, self.views[bd + ".weight"], smd, sid,
-                     self.gviews[b2 + ".weight"], self.gviews[b2 + ".bias"], self.gviews[bd + ".weight"],
-                     self.gviews[bd + ".bias"], t[p + ".y2"].shape[0], t[p + ".y2"].shape[1], self.bn_ws,
+                     self._gviews[b2 + ".weight"], self._gviews[b2 + ".bias"], self._gviews[bd + ".weight"],
+                     self._gviews[bd + ".bias"], t[p + ".y2"].shape[0], t[p + ".y2"].shape[1], self.bn_ws,
                      self.bn_ws_bytes, self.dt)
             else:
                 # GroupNorm transition block: the downsample's backward pass applies bn2's ReLU mask to dout itself
@@ -815,8 +822,8 @@ class ResNet18Engine:
                          smd, sid, psg, psb, self.N, yd.shape[0] // self.N, yd.shape[1], self.groups, self.bn_ws,
                          self.bn_ws_bytes, self.dt)
                     if self.dp is None:
-                        call("primia_weighted_colsum", psg, self.ones_n, self.gviews[bd + ".weight"], self.N, yd.shape[1])
-                        call("primia_weighted_colsum", psb, self.ones_n, self.gviews[bd + ".bias"], self.N, yd.shape[1])
+                        call("primia_weighted_colsum", psg, self.ones_n, self._gviews[bd + ".weight"], self.N, yd.shape[1])
+                        call("primia_weighted_colsum", psb, self.ones_n, self._gviews[bd + ".bias"], self.N, yd.shape[1])
                 elif not bn_pair:
                     self._bn_bwd(blk.down.name, t[p + ".yd"], None, dout, t[p + ".dyd"], None, False)
                 c1, cd = self.convs[blk.conv1.name], self.convs[blk.down.name]
@@ -866,20 +873,20 @@ class ResNet18Engine:
             c = self.convs["conv1"]
             S = self.spec.input_size
             call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, None,
-                 self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self.gviews["bn1.weight"],
-                 self.gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
+                 self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self._gviews["bn1.weight"],
+                 self._gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
             self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call(
                 "primia_stem_bwd_fused", self.x0p, t["stem.y"], t["pool.dout"], self.pool_argmax,
-                self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self.gviews["bn1.weight"],
-                self.gviews["bn1.bias"], c.acc, self.wgrad_ws, self.wgrad_ws_bytes, N, S, S, self.dt)))
+                self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self._gviews["bn1.weight"],
+                self._gviews["bn1.bias"], c.acc, self.wgrad_ws, self.wgrad_ws_bytes, N, S, S, self.dt)))
             if self.dp is None:
                 self._finalize_wgrads()
             return
         if self._stem_fused:
             sm, si = self.save["bn1"]
             call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, t["stem.dy"],
-                 self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self.gviews["bn1.weight"],
-                 self.gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
+                 self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self._gviews["bn1.weight"],
+                 self._gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
         elif getattr(self, "_stem_fused_gn", False):
             sm, si = self.save["bn1"]
             psg, psb = self.ps_affine["bn1"]
@@ -887,8 +894,8 @@ class ResNet18Engine:
                  self.views["bn1.weight"], self.views["bn1.bias"], sm, si, psg, psb, N, hw, hw, 64, self.groups,
                  self.bn_ws, self.bn_ws_bytes, self.dt)
             if self.dp is None:
-                call("primia_weighted_colsum", psg, self.ones_n, self.gviews["bn1.weight"], N, 64)
-                call("primia_weighted_colsum", psb, self.ones_n, self.gviews["bn1.bias"], N, 64)
+                call("primia_weighted_colsum", psg, self.ones_n, self._gviews["bn1.weight"], N, 64)
+                call("primia_weighted_colsum", psb, self.ones_n, self._gviews["bn1.bias"], N, 64)
         else:
             if self.spec.pooling == "max":
                 call("primia_maxpool3x3s2_bwd", t["pool.dout"], self.pool_argmax, t["stem.dz"], N, hw, hw, 64, self.dt)
@@ -957,7 +964,7 @@ class ResNet18Engine:
             cs = list(self.convs.values())
             fus = [c for c in cs if query("primia_conv_sgd_fusable", c.desc, c.c_real) == 1 and c.w_dgrad is not None
                    and all(tt.data_ptr() % 16 == 0 for tt in (c.acc, c.w_fwd, c.w_dgrad, self.views[c.spec.name + ".weight"],
-                                                              self.gviews[c.spec.name + ".weight"]))]
+                                                              self._gviews[c.spec.name + ".weight"]))]
             rest = [c for c in cs if c not in fus]
             vp = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
 
@@ -971,7 +978,7 @@ class ResNet18Engine:
                     wf=(ctypes.c_void_p * n)(*[vp(c.w_fwd) for c in lst]),
                     wd=(ctypes.c_void_p * n)(*[vp(c.w_dgrad) for c in lst]),
                     acc=(ctypes.c_void_p * n)(*[vp(c.acc) for c in lst]),
-                    gw=(ctypes.c_void_p * n)(*[vp(self.gviews[c.spec.name + ".weight"]) for c in lst]))
+                    gw=(ctypes.c_void_p * n)(*[vp(self._gviews[c.spec.name + ".weight"]) for c in lst]))
 
             fused_keys = {c.spec.name + ".weight" for c in fus}
             ranges, off = [], 0
@@ -1148,16 +1155,16 @@ class ResNet18Engine:
                 xs, outs, ws_ = [], [], []
                 for b, (psg, psb) in self.ps_affine.items():
                     xs += [psg.data_ptr(), psb.data_ptr()]
-                    outs += [self.gviews[b + ".weight"].data_ptr(), self.gviews[b + ".bias"].data_ptr()]
+                    outs += [self._gviews[b + ".weight"].data_ptr(), self._gviews[b + ".bias"].data_ptr()]
                     ws_ += [psg.shape[1], psb.shape[1]]
                 self._colsum_many = (torch.tensor(xs, dtype=torch.int64, device=dev),
                                      torch.tensor(outs, dtype=torch.int64, device=dev),
                                      torch.tensor(ws_, dtype=torch.int32, device=dev), len(xs), max(ws_))
             xs_d, outs_d, ws_d, cnt, mw = self._colsum_many
             call("primia_weighted_colsum_many", xs_d, clip, outs_d, ws_d, cnt, mw, N)
-            call("primia_weighted_colsum", ps_fc[:, :nc * 512].contiguous(), clip, self.gviews["fc.weight"].view(-1), N,
+            call("primia_weighted_colsum", ps_fc[:, :nc * 512].contiguous(), clip, self._gviews["fc.weight"].view(-1), N,
                  nc * 512)
-            call("primia_weighted_colsum", ps_fc[:, nc * 512:].contiguous(), clip, self.gviews["fc.bias"], N, nc)
+            call("primia_weighted_colsum", ps_fc[:, nc * 512:].contiguous(), clip, self._gviews["fc.bias"], N, nc)
         finally:
             if getattr(self, "dp_keep_operands", False):      # tests: the (layer, x, dy) triples the norm pass walked
                 self.dp_operands = list(self.dp["wgrads"])
