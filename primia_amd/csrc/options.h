@@ -24,7 +24,7 @@ namespace primia {
     X(wgp_pairimg, 1)       /* DP-SGD norm pass of the patch kernel: whole images per half-block */                    \
     X(wgp_shape, -1)        /* sub-patch shape 0..2 = 8x8 | 8x4 | 16x2 (-1: by image size) */                          \
     X(wgp_blocks, 0)        /* block target of conv_wgrad_patch33_kernel (0: one per CU) */                            \
-    X(wgp_order, 0)         /* 1: half 0 multiplies first */                                                           \
+    X(wgp_order, 0)         /* block id order: 0 slab fastest (the slabs of a pixel range share x, dy in one L2), 1 pixel range fastest */                                                          \
     X(wgp_stages88, 3)      /* ring depth for 8 x 8 sub-patches: 3 | 4 */                                              \
     X(wgp_group, 1)         /* same-shape layers of a stage in one launch */                                           \
     X(wgp_group_minfill, 90) /* % of the CUs a grouped launch must fill */                                             \
