@@ -725,6 +725,9 @@ static int lh2_bm(int N, int H, int W, int Cs, int Nd) {
     return t392 >= lh2_num_cus() ? 392 : 196;
 }
 
+int conv3x3_lh4_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
+                         int accumulate, hipStream_t st, float* stat_partials, const uint8_t* acc_mask);
+
 int conv3x3_lh2_tiles_m(int N, int H, int W, int Cs, int Nd) {
     const int bm = lh2_bm(N, H, W, Cs, Nd);
     if (!bm) return PRIMIA_ERR_UNSUPPORTED;
@@ -752,6 +755,8 @@ int conv3x3_lh2_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
 #else
     p.prof = nullptr;
 #endif
+    if (bm == 196 && PRIMIA_OPT(lh4))
+        return conv3x3_lh4_dispatch(src, wt, dst, N, H, W, Cs, Nd, flip, accumulate, st, stat_partials, acc_mask);
     const int ncu = lh2_num_cus();
     const int grid = p.ntiles < ncu ? p.ntiles : ncu;
     void (*kern)(Lh2Params);

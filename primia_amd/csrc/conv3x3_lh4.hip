@@ -1,16 +1,23 @@
-// EXPERIMENT (round 4, not part of the library): the linear-halo 3x3 kernel rebuilt around what tools/micro/mfma_fill.hip measured —
-// a block of 8 MATRIX waves that never issue a DMA instruction and never wait on vmcnt, and 4 LOADER waves that do nothing else.
-//   * no ping-pong halves: every matrix wave runs read-fragments -> MFMAs per step, ONE barrier per step (the two waves of a
-//     SIMD drift apart on their own, as in the synthetic stage body: 1.3-1.6 PFLOP/s with a loader wave);
-//   * 196-pixel x 128-channel tiles (4 | 3 | 3 | 3 fragments of 16 pixels): 64 accumulator + 64 fragment registers, so that three
-//     waves fit a SIMD (<= 168 VGPRs);
-//   * weights: whole 128 x 64 step tiles through a ring of 3 (loaders run two steps ahead); halo: double buffer per 64-channel
-//     chunk, the next chunk's 32 pieces spread over the first seven taps of the current one;
-//   * tiles, summation order, write-back and BatchNorm partial sums are conv3x3_lh2's for its 196-pixel tiles: outputs must be
-//     bit-identical (tools/micro/lh4_bench.hip checks).
+// 3x3 / stride-1 / pad-1 convolution, forward and data gradient, 196-pixel x 128-channel tiles (ResNet-18 layer4 at batch 256, and
+// every wide shape too small for conv3x3_lh2's 392-pixel tiles) — the linear-halo scheme of conv3x3_lh2.hip rebuilt around what
+// tools/micro/mfma_fill.hip measured in round 4: what staging costs the matrix pipe is the ISSUE of the LDS-DMA instructions by
+// waves that also multiply (a blocked issue holds the wave's MFMAs behind it), not the data movement.
+//   * 12 waves: 8 MATRIX waves that never issue a DMA instruction and never wait on vmcnt (their own stores share that counter),
+//     4 LOADER waves that do nothing else.  Three waves per SIMD = at most 168 VGPRs: the 196-pixel tile (4 | 3 | 3 | 3 fragments
+//     of 16 pixels: 64 accumulator + 64 fragment registers) fits, a 392-pixel tile (7 fragments) does not.
+//   * no ping-pong halves: every matrix wave reads its fragments and multiplies, step after step, with ONE barrier per step (the
+//     waves of a SIMD drift apart on their own, as in the synthetic stage body).
+//   * weights: whole 128 x 64 step tiles through a ring of 3 — the loaders run two steps ahead; halo: double buffer per 64-channel
+//     chunk, the next chunk's 32 pieces spread over the first seven taps of the current one.
+//   * tiles, order of every sum, write-back and BatchNorm partial sums are conv3x3_lh2's for its 196-pixel tiles: outputs and
+//     partials are BIT-IDENTICAL to that kernel (tools/micro/lh4_bench.hip checks all nine cases), so every parity test of the 3x3
+//     layers holds unchanged.  Stand-alone (post-ReLU operands, batch 256): layer4 forward 55.2 -> 51.0 us, data gradient 53.7 ->
+//     48.2, accumulating data gradient 56.2 -> 51.3; in the training step (same-box A/B, 3 x 100 steps): 5.03 -> 5.00 ms.
+//     Forms that did NOT pay (profiles/r04_mfma_ceilings.txt): loader waves bolted onto lh2's ping-pong (+5 % stand-alone, nothing
+//     in the step), split weight rings + streamed fragments so that 392-pixel tiles fit 168 registers (slower everywhere).
 #include <stdlib.h>
 
-#include "../../../primia_amd/csrc/conv_common.h"
+#include "conv_common.h"
 
 namespace primia {
 
@@ -554,11 +561,26 @@ __global__ __launch_bounds__(768) void conv3x3_lh4_kernel(Lh4Params p) {
     else lh4_run<BM, J, J0 + 2 * J, FLIP, ACC>(p, smem, first, count);
 }
 
+static int lh4_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// Called by conv3x3_lh2_dispatch for the shapes that take 196-pixel tiles (option lh4); same contract as that function.
 int conv3x3_lh4_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
                          int accumulate, hipStream_t st, float* stat_partials, const uint8_t* acc_mask) {
     const int bm = 196;
     if (W > 28 || W < 2 || H < 2 || Cs % 64 || Nd % 128) return PRIMIA_ERR_UNSUPPORTED;
+    if (stat_partials && (flip || accumulate)) return PRIMIA_ERR_ARG;
+    if (accumulate && !flip) return PRIMIA_ERR_UNSUPPORTED;
     const long M = (long)N * H * W;
+    if (M * (Cs > Nd ? Cs : Nd) >= (1L << 30)) return PRIMIA_ERR_UNSUPPORTED;     // byte offsets stay below 2^31
     Lh4Params p;
     p.src = src; p.wt = wt; p.dst = dst;
     p.H = H; p.W = W; p.Cs = Cs; p.Nd = Nd; p.M = (int)M;
@@ -569,13 +591,19 @@ int conv3x3_lh4_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     p.magicW = (65536u + W - 1) / W;
     p.magicH = (65536u + H - 1) / H;
     p.prof = nullptr;
-    const int grid = p.ntiles < 256 ? p.ntiles : 256;
+    const int ncu = lh4_num_cus();
+    const int grid = p.ntiles < ncu ? p.ntiles : ncu;
     void (*kern)(Lh4Params) = !flip ? conv3x3_lh4_kernel<196, false, false>
                                     : (accumulate ? conv3x3_lh4_kernel<196, true, true> : conv3x3_lh4_kernel<196, true, false>);
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kL4Lds) != hipSuccess)
-        return PRIMIA_ERR_LAUNCH;
+    const int slot = !flip ? 0 : (accumulate ? 2 : 1);
+    static bool attr_set[3] = {false, false, false};
+    if (!attr_set[slot]) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, kL4Lds) != hipSuccess)
+            return PRIMIA_ERR_LAUNCH;
+        attr_set[slot] = true;
+    }
     kern<<<grid, 768, kL4Lds, st>>>(p);
-    return hipGetLastError() == hipSuccess ? 0 : PRIMIA_ERR_LAUNCH;
+    return launch_status();
 }
 
 }  // namespace primia

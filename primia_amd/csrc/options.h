@@ -8,6 +8,7 @@ namespace primia {
 #define PRIMIA_OPTIONS(X)                                                                                              \
     X(lh2, 1)               /* 0: the wide 3x3 / stride-1 layers stay on the implicit GEMM */                         \
     X(lh2_bm, 0)            /* 392 | 196: force the linear-halo tile height (0: by shape) */                          \
+    X(lh4, 1)               /* 196-pixel tiles on conv3x3_lh4_kernel (8 matrix + 4 loader waves, one barrier per step); 0: conv3x3_lh2 */ \
     X(lh_fwd_maxw, 30)      /* widest image the linear-halo kernel takes in the forward pass */                        \
     X(c64, 1)               /* 0: layer1's 64 -> 64 convolutions stay on the implicit GEMM */                          \
     X(c64_blocks, 512)      /* persistent blocks of conv3x3_c64_kernel (2 per CU) */                                   \

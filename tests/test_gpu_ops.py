@@ -699,6 +699,46 @@ def test_wide_conv_persistent_tiles(cuda, N, H, C, K, bm):
     assert relerr(from_nhwc(dx3, N, H, H), xr.grad + base) < tol(dtype)
 
 
+@pytest.mark.parametrize("N,H,C,K", [(100, 28, 128, 128), (37, 7, 256, 384), (256, 7, 512, 512), (3, 14, 256, 256)])
+def test_loader_wave_kernel_is_bit_identical_to_the_linear_halo_kernel(cuda, N, H, C, K):
+    """conv3x3_lh4_kernel (8 matrix + 4 loader waves, one barrier per step; serves the shapes that take 196-pixel tiles) against
+    conv3x3_lh2_kernel on the same tiles (option lh4 = 0): forward output, per-tile BatchNorm partials, data gradient, accumulating
+    and masked-accumulating data gradient — the SAME BITS (same tiles, same order of every sum)."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(7 * N + H)
+    x = rnd(torch.randn(N, C, H, H, generator=g).clamp(min=0), dtype)
+    w = rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype)
+    dy = rnd(torch.randn(N, K, H, H, generator=g), dtype)
+    desc = ConvDesc.make(N, H, H, C, K, 3, 3, 1, 1)
+    wf, wd = prep_weights(desc, w, dtype, cuda, C)
+    M = N * H * H
+    xd, dyd = to_nhwc(x, dtype, cuda), to_nhwc(dy, dtype, cuda)
+    base = to_nhwc(rnd(torch.randn(N, C, H, H, generator=g), dtype), dtype, cuda)
+    mask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).to(cuda)
+    outs = {}
+    try:
+        for lh4 in (1, 0):
+            _lib.set_option("lh4", lh4)
+            slots = query("primia_conv_stat_slots_for", desc, dt)
+            assert slots == (M + 195) // 196          # 196-pixel tiles either way
+            y = torch.full((M, K), float("nan"), dtype=dtype, device=cuda)
+            sums = torch.full((slots, 2, K), float("nan"), device=cuda)
+            call("primia_conv2d_fwd_stats", desc, xd, wf, y, sums, dt)
+            dx = torch.full((M, C), float("nan"), dtype=dtype, device=cuda)
+            call("primia_conv2d_dgrad", desc, dyd, wd, dx, 0, dt)
+            dxa = base.clone()
+            call("primia_conv2d_dgrad", desc, dyd, wd, dxa, 1, dt)
+            dxm = base.clone()
+            call("primia_conv2d_dgrad_masked_acc", desc, dyd, wd, dxm, mask, dt)
+            outs[lh4] = (y, sums, dx, dxa, dxm)
+    finally:
+        _lib.set_option("lh4", 1)
+    for a, b, name in zip(outs[1], outs[0], ("y", "partials", "dx", "dx +=", "dx += masked")):
+        assert torch.equal(a, b), name
+    assert torch.isfinite(outs[1][0].float()).all() and float(outs[1][0].float().abs().max()) > 0
+
+
 def test_stem_conv_emits_batchnorm_partials_and_fused_tail_from_sums(cuda):
     dtype = torch.bfloat16
     dt = _lib.dtype_code(dtype)

@@ -1,4 +1,4 @@
-// A/B of the round-4 experiment conv3x3_lh4 (8 matrix + 4 loader waves, 196-pixel tiles, one barrier per step) against
+// A/B of conv3x3_lh4 (csrc/conv3x3_lh4.hip: 8 matrix + 4 loader waves, 196-pixel tiles, one barrier per step) against
 // conv3x3_lh2 (as shipped, and forced to 196-pixel tiles): us per launch on the three wide stages, outputs and BatchNorm
 // partials of lh4 compared bit for bit with lh2's 196-pixel form.  argv[1] = batch (256), argv[2] = 1: dense uniform operands.
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/micro/lh4_bench.hip -o tools/micro/lh4_bench
@@ -11,7 +11,7 @@
 
 #include "../../primia_amd/csrc/conv3x3_lh2.hip"
 #include "../../primia_amd/csrc/options.hip"
-#include "experiments/conv3x3_lh4.hip"
+#include "../../primia_amd/csrc/conv3x3_lh4.hip"
 
 using namespace primia;
 
@@ -43,6 +43,7 @@ int main(int argc, char** argv) {
             std::vector<float> st[3];
             for (int v = 0; v < 3; ++v) {          // 0: lh2 as shipped, 1: lh2 with 196-pixel tiles, 2: lh4
                 primia_set_option("lh2_bm", v == 1 ? 196 : 0);
+                primia_set_option("lh4", 0);          // (the lh2 legs must not be re-routed to lh4)
                 hipMemset(y, 0, M * K * 2);
                 hipMemset(stats, 0, sb);
                 auto launch = [&]() {
