@@ -308,7 +308,7 @@ def main():
     from primia_amd import _lib
     from primia_amd._lib import query
 
-    KNAME = {1: "conv_igemm_kernel", 2: "conv3x3_c64_kernel (fwd + dgrad)", 4: "conv3x3_lh2_kernel (fwd + dgrad)",
+    KNAME = {1: "conv_igemm_kernel", 2: "conv3x3_c64_kernel (fwd + dgrad)", 4: "conv3x3_lh2_kernel + conv3x3_lh4_kernel (fwd + dgrad)",
              13: "conv_wgrad_dma_kernel (per-tap, stride 2 / 1x1)", 14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)",
              16: "conv_wgrad_patch33_kernel + wgrad_patch32_reduce_kernel",
              17: "conv_wgrad_tap_kernel + wgrad_tile_reduce_kernel (per-tap, stride 2 / 1x1)"}
@@ -365,10 +365,17 @@ def main():
         key = dom.split(" ")[0].split("<")[0]     # the kernel that ran; no record for it -> traffic_offline stays null
         if key in rec:
             same = rec.get("_source_sha256") == source_digest()
-            traffic_offline = {"hbm_bytes_per_launch": rec[key].get("hbm_bytes_per_launch"), "kernel": key,
+            per_launch = rec[key].get("hbm_bytes_per_launch")
+            if key == "conv3x3_lh2_kernel" and "conv3x3_lh4_kernel" in rec:
+                # the family's 196-pixel-tile launches run on conv3x3_lh4_kernel: launch-weighted mean of the two records
+                a_, b_ = rec[key], rec["conv3x3_lh4_kernel"]
+                per_launch = int((a_["hbm_bytes_per_launch"] * a_["launches"] + b_["hbm_bytes_per_launch"] * b_["launches"])
+                                 / (a_["launches"] + b_["launches"]))
+                key = "conv3x3_lh2_kernel + conv3x3_lh4_kernel"
+            traffic_offline = {"hbm_bytes_per_launch": per_launch, "kernel": key,
                                "source": "profiles/" + TRAFFIC_FILE, "same_sources_as_this_run": same}
             if same:
-                traffic = rec[key].get("hbm_bytes_per_launch")
+                traffic = per_launch
     roof = {"bound": "mfma", "kernel": dom,
             "launch": "median over %d steps of the HIP-event bracket around one C-ABI call (a weight-gradient call = the "
                       "kernel + its ordered reduce)" % nprof,
