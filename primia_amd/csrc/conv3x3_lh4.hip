@@ -15,6 +15,9 @@
 //     48.2, accumulating data gradient 56.2 -> 51.3; in the training step (same-box A/B, 3 x 100 steps): 5.03 -> 5.00 ms.
 //     Forms that did NOT pay (profiles/r04_mfma_ceilings.txt): loader waves bolted onto lh2's ping-pong (+5 % stand-alone, nothing
 //     in the step), split weight rings + streamed fragments so that 392-pixel tiles fit 168 registers (slower everywhere).
+// The per-tile code (tap validity masks, write-back from the accumulators incl. the accumulate / masked forms, BatchNorm partial
+// sums) is conv3x3_lh2.hip's, copied: the two kernels must produce the same bits on the same tiles, and
+// tests/test_gpu_ops.py::test_loader_wave_kernel_is_bit_identical_to_the_linear_halo_kernel fails the moment one copy drifts.
 #include <stdlib.h>
 
 #include "conv_common.h"
