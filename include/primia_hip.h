@@ -10,7 +10,10 @@
  *
  * Conventions
  *   - all pointers are DEVICE pointers unless the name ends in _host; the caller owns every
- *     buffer, workspaces are passed explicitly, there is no hidden allocation or global state;
+ *     buffer, workspaces are passed explicitly, there is no hidden allocation; the ONLY process-wide state is the
+ *     table of tuning options below (primia_set_option): word-sized atomic entries, safe to read and write from any
+ *     thread, but shared by every caller in the process — two engines cannot hold different options, and a change
+ *     invalidates sizes asked earlier (primia_options_epoch tells);
  *   - `stream` is a hipStream_t (0 = default stream); all work is enqueued asynchronously;
  *   - return value: PRIMIA_OK (0) or a negative PRIMIA_ERR_* code; bad arguments are reported,
  *     never dereferenced;
@@ -49,9 +52,13 @@ int primia_abi_version(void);
  * gradient on its own, ("dp_ghost", 0) takes the DP-SGD norms from the weight-gradient kernels, ...  The names, defaults
  * and meanings are listed in primia_amd/csrc/options.h; unknown names return PRIMIA_ERR_ARG.  Options are read when a
  * call dispatches (and by the *_bytes / *_ok / *_kernel_id queries, which therefore must be asked again after a
- * change); they are not thread-synchronised — set them before the streams start.  The reference has no counterpart
- * (torch picks its own kernels). */
+ * change).  Each entry is read and written atomically (no torn values, callable from any thread), but a SEQUENCE of
+ * changes is not a transaction: set options before the streams start.  primia_options_epoch() counts the changes made
+ * so far: a host object that sized workspaces from the queries keeps the epoch it saw and re-plans — or refuses to run,
+ * as primia_amd.engine.ResNet18Engine does — when it has moved.  The reference has no counterpart (torch picks its own
+ * kernels). */
 int primia_set_option(const char* name, int value);
+int64_t primia_options_epoch(void);
 int primia_get_option(const char* name, int* value);
 int primia_reset_options(void);
 int primia_option_count(void);

@@ -47,7 +47,7 @@ enum OptId : int {
 
 extern int g_options[kOptCount];
 
-inline int opt(OptId id) { return g_options[id]; }
+inline int opt(OptId id) { return __atomic_load_n(&g_options[id], __ATOMIC_RELAXED); }
 
 }  // namespace primia
 

@@ -1,6 +1,8 @@
 // The option table behind primia_set_option / primia_get_option (csrc/options.h).
 #include <string.h>
 
+#include <atomic>
+
 #include "common.h"
 #include "options.h"
 
@@ -24,6 +26,10 @@ static const int kOptDefaults[kOptCount] = {
 #undef PRIMIA_OPT_DEF
 };
 
+// Bumped by every primia_set_option / primia_reset_options: a host object that sized buffers from the *_bytes / *_slots
+// queries snapshots it and re-plans (or refuses to run) when it moved (primia_options_epoch).
+static std::atomic<int64_t> g_options_epoch{0};
+
 static int find_option(const char* name) {
     if (!name) return -1;
     for (int i = 0; i < kOptCount; ++i)
@@ -40,19 +46,23 @@ extern "C" {
 int primia_set_option(const char* name, int value) {
     const int i = find_option(name);
     if (i < 0) return PRIMIA_ERR_ARG;
-    g_options[i] = value;
+    __atomic_store_n(&g_options[i], value, __ATOMIC_RELAXED);
+    g_options_epoch.fetch_add(1, std::memory_order_release);
     return PRIMIA_OK;
 }
+
+int64_t primia_options_epoch(void) { return g_options_epoch.load(std::memory_order_acquire); }
 
 int primia_get_option(const char* name, int* value) {
     const int i = find_option(name);
     if (i < 0 || !value) return PRIMIA_ERR_ARG;
-    *value = g_options[i];
+    *value = __atomic_load_n(&g_options[i], __ATOMIC_RELAXED);
     return PRIMIA_OK;
 }
 
 int primia_reset_options(void) {
-    for (int i = 0; i < kOptCount; ++i) g_options[i] = kOptDefaults[i];
+    for (int i = 0; i < kOptCount; ++i) __atomic_store_n(&g_options[i], kOptDefaults[i], __ATOMIC_RELAXED);
+    g_options_epoch.fetch_add(1, std::memory_order_release);
     return PRIMIA_OK;
 }
 

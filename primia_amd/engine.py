@@ -51,6 +51,10 @@ class ResNet18Engine:
         if not torch.cuda.is_available():
             raise _lib.PrimiaError("ResNet18Engine needs a GPU (HIP kernels only, no CPU fallback)")
         _lib.lib()
+        # every buffer below is sized from the library's *_bytes / *_slots queries, which read the process-wide option
+        # table: remember its epoch — forward() refuses to run once it has moved (a later
+        # primia_set_option("c64_blocks" | "lh2" | ...) would make kernels write more partials than were allocated)
+        self._options_epoch = query("primia_options_epoch")
         self.spec: NetSpec = resnet18_spec(num_classes, in_channels, input_size, pooling)
         if norm not in ("batch", "group"):
             raise ValueError("norm must be 'batch' or 'group'")
@@ -508,6 +512,9 @@ class ResNet18Engine:
         if tuple(x_nchw.shape) != (N, self.spec.in_channels, S, S) or x_nchw.dtype != torch.float32:
             raise ValueError(f"expected fp32 input {(N, self.spec.in_channels, S, S)}, got {tuple(x_nchw.shape)}")
         x_nchw = x_nchw.contiguous()
+        if query("primia_options_epoch") != self._options_epoch:
+            raise _lib.PrimiaError("library options changed (primia_set_option) after this engine sized its buffers: "
+                                   "set options first, then construct the engine")
         if self.training and self.fuse_stats:
             self.stat_sums.zero_()
         self._stem_padded = self.x0p is not None and not (self.training and self.fuse_stats)

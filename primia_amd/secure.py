@@ -503,17 +503,28 @@ class SecureContext:
         return self._each(one)
 
     def _weight_t(self, w, O, K):
-        """weight.reshape(O, -1).t() of both parties' (static) weight shares, formed once per model."""
-        key = (w[0].data_ptr(), w[1].data_ptr(), O, K)
+        """weight.reshape(O, -1).t() of both parties' (static) weight shares, formed once per model.
+
+        The cache is keyed on the share TENSORS, which it keeps alive and compares by identity together with their
+        in-place version counters: an address the caching allocator hands out again, or shares rewritten in place,
+        can never hit a stale transpose (`invalidate_weight_cache()` drops everything when a model is re-shared)."""
+        key = (id(w[0]), id(w[1]), O, K)
         hit = self._wt_cache.get(key)
-        if hit is None:
-            hit = []
-            for j in (0, 1):
-                t = torch.empty(K, O, dtype=I64, device=w[j].device)
-                call("primia_col2out_syft", w[j], None, t, 1, O, K)
-                hit.append(t)
-            self._wt_cache[key] = hit
-        return hit
+        if hit is not None:
+            w0, w1, v0, v1, wt = hit
+            if w0 is w[0] and w1 is w[1] and v0 == w[0]._version and v1 == w[1]._version:
+                return wt
+        wt = []
+        for j in (0, 1):
+            t = torch.empty(K, O, dtype=I64, device=w[j].device)
+            call("primia_col2out_syft", w[j], None, t, 1, O, K)
+            wt.append(t)
+        self._wt_cache[key] = (w[0], w[1], w[0]._version, w[1]._version, wt)
+        return wt
+
+    def invalidate_weight_cache(self):
+        """Forget every cached transposed weight share (call after re-sharing or editing a model's weights)."""
+        self._wt_cache.clear()
 
     def reciprocal_newton(self, v):
         """FPT.reciprocal(method="newton") (precision.py:507-518), C = 20, 80 iterations.
@@ -697,6 +708,7 @@ class SecureResNet18:
         self.batched_newton = batched_newton
         dev = ctx.dealer.device
         self.p = {}
+        ctx.invalidate_weight_cache()      # (a model shared on this context before: its transposed shares go with it)
         # hook.py:624-632,738-765: every parameter is encoded and shared, THEN every buffer (`parameters()` before
         # `buffers()`); the 0-dim num_batches_tracked buffers draw no randomness (generate_shares sizes its random
         # share with LongTensor(torch.Size([])) = an empty tensor, additive_shared.py:352) and are never read.

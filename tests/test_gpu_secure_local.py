@@ -132,3 +132,41 @@ def test_whole_network_matches_the_chain_and_launches_less(cuda, pf):
     assert same(outs["fused"], outs["chain"]) and same(outs["fused"], ref)
     print("C-ABI calls per image: fused", counts["fused"], "chain", counts["chain"])
     assert counts["fused"] < 400 < counts["chain"]
+
+
+def test_transposed_weight_cache_follows_the_weights(cuda):
+    """the fused conv2d / linear cache weight.reshape(O, -1).t() per model.  Shares edited in place, or new
+    shares that the caching allocator puts at a freed model's address, must never meet a stale transpose."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 8, 6, 6, generator=g).to(cuda)
+    w1 = (torch.randn(16, 8, 3, 3, generator=g) * 0.1).to(cuda)
+    w2 = (torch.randn(16, 8, 3, 3, generator=g) * 0.1).to(cuda)
+
+    def plain_conv(ctx, xs, ws):      # what the fused path must equal: the chain re-transposes on every call
+        keep = ctx.local_fused
+        ctx.local_fused = False
+        try:
+            return ctx.decode(ctx.reconstruct(ctx.conv2d(xs, ws, 1, 1)))
+        finally:
+            ctx.local_fused = keep
+
+    ctx = SecureContext(Dealer(cuda, seed=9), 10, 16)
+    assert ctx._local
+    xs, ws = shares_of(ctx, x), shares_of(ctx, w1)
+    a = ctx.decode(ctx.reconstruct(ctx.conv2d(xs, ws, 1, 1)))
+    assert torch.allclose(a, plain_conv(ctx, xs, ws), atol=1e-3)
+    # in place: same tensors, new contents
+    new = shares_of(ctx, w2)
+    for j in (0, 1):
+        ws[j].copy_(new[j])
+    b = ctx.decode(ctx.reconstruct(ctx.conv2d(xs, ws, 1, 1)))
+    assert torch.allclose(b, plain_conv(ctx, xs, ws), atol=1e-3)
+    assert not torch.allclose(a, b, atol=1e-2)
+    # freed and re-allocated at (very likely) the same address
+    ptrs = (ws[0].data_ptr(), ws[1].data_ptr())
+    del ws, new
+    ws2 = shares_of(ctx, w1)
+    c = ctx.decode(ctx.reconstruct(ctx.conv2d(xs, ws2, 1, 1)))
+    assert torch.allclose(c, a, atol=1e-3), (ptrs, ws2[0].data_ptr())
+    ctx.invalidate_weight_cache()
+    assert not ctx._wt_cache
