@@ -308,7 +308,7 @@ def main():
     from primia_amd import _lib
     from primia_amd._lib import query
 
-    KNAME = {1: "conv_igemm_kernel", 2: "conv3x3_c64_kernel (fwd + dgrad)", 4: "conv3x3_lh2_kernel + conv3x3_lh4_kernel (fwd + dgrad)",
+    KNAME = {1: "conv_igemm_kernel", 5: "conv_s2lh_kernel (stride-2 3x3 + 1x1, fwd + dgrad)", 2: "conv3x3_c64_kernel (fwd + dgrad)", 4: "conv3x3_lh2_kernel + conv3x3_lh4_kernel (fwd + dgrad)",
              13: "conv_wgrad_dma_kernel (per-tap, stride 2 / 1x1)", 14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)",
              16: "conv_wgrad_patch33_kernel + wgrad_patch32_reduce_kernel",
              17: "conv_wgrad_tap_kernel + wgrad_tile_reduce_kernel (per-tap, stride 2 / 1x1)"}
@@ -325,14 +325,15 @@ def main():
         if kind == "wgrad":
             return KNAME[query("primia_conv_wgrad_kernel_id", d, dtc)]
         kid = query("primia_conv_kernel_id", d, 0 if kind == "fwd" else 1, dtc)
-        return KNAME[kid] + ("<%s>" % kind if kid == 1 else "")
+        return KNAME.get(kid, "kernel id %d" % kid) + ("<%s>" % kind if kid == 1 else "")
 
     per_launch = {}
     for kind, name, flops, e0, e1 in eng.prof:
         per_launch.setdefault((kind, name), (flops, []))[1].append(e0.elapsed_time(e1))
-    agg, fam = {}, {}
+    agg, fam, layers = {}, {}, {}
     for (kind, name), (flops, samples) in per_launch.items():
         samples.sort()
+        layers[f"{kind}:{name}"] = round(samples[len(samples) // 2] * 1e3, 1)     # median launch, us
         ms = samples[len(samples) // 2] * nprof   # median launch, scaled so the tables below stay per-nprof sums
         for table, key in ((agg, kind), (fam, family(kind, name))):
             d = table.setdefault(key, {"ms": 0.0, "flops": 0.0, "launches": 0})
@@ -389,7 +390,7 @@ def main():
                                    "source": "profiles/r04_mfma_ceilings.txt"},
             "all_conv": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 3),
                          "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)},
-            "kernels": kernels, "by_pass": by_pass}
+            "kernels": kernels, "by_pass": by_pass, "layers_us": layers}
 
     ms_per_step = dt / a.steps * 1e3
     total_ips = a.batch * world * a.steps / dt

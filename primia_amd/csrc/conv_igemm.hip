@@ -836,6 +836,22 @@ static bool use_c64(const ConvGeom& g) {
     return PRIMIA_OPT(c64) && !g.stem && g.R == 3 && g.S == 3 && g.stride == 1 && g.pad == 1 && g.C == 64 && g.K == 64;
 }
 
+// transition-block shapes served by conv_s2lh_kernel (bf16): 3x3 / 2 / pad 1 or 1x1 / 2 / pad 0 on an even-sized input
+// option s2lh (bits): 1 data gradient where it wins in the training step (dx with <= 128 channels: layer2.0 / layer3.0 —
+// in-step medians at batch 256: 100 / 74 / 69 us on the implicit GEMM, 84 / 70 / 72 on conv_s2lh_kernel), 2 forward too
+// (74 / 58 / 47 vs 85 / 85 / 95 us: off by default), 4 data gradient at every width.  Default 1.
+static bool s2_pass_on(int pass, int dx_channels = 0) {
+    const int o = PRIMIA_OPT(s2lh);
+    if (pass == 0) return (o & 2) != 0;
+    return (o & 4) != 0 || ((o & 1) != 0 && dx_channels <= 128);
+}
+static bool s2_conv1_shape(const ConvGeom& g) {
+    return !g.stem && g.R == 3 && g.S == 3 && g.stride == 2 && g.pad == 1 && conv_s2lh_ok(g.N, g.H, g.W, g.C, g.K);
+}
+static bool s2_ds_shape(const ConvGeom& g) {
+    return !g.stem && g.R == 1 && g.S == 1 && g.stride == 2 && g.pad == 0 && conv_s2lh_ok(g.N, g.H, g.W, g.C, g.K);
+}
+
 extern "C" {
 
 static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void* w_fwd, void* y, float* stat_sums,
@@ -869,6 +885,14 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
             const int rc2 = conv3x3_lh2_dispatch((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, g.N, g.H, g.W, g.C, g.K, 0,
                                                  0, st, stat_sums);
             if (rc2 != PRIMIA_ERR_UNSUPPORTED) return rc2;
+        } else if (s2_pass_on(0) && s2_conv1_shape(g)) {
+            const int rc3 = conv_s2lh_fwd((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, stat_sums, nullptr, nullptr, nullptr, g.N,
+                                          g.H, g.W, g.C, g.K, st);
+            if (rc3 != PRIMIA_ERR_UNSUPPORTED) return rc3;
+        } else if (s2_pass_on(0) && s2_ds_shape(g)) {
+            const int rc3 = conv_s2lh_fwd((const bf16*)x, nullptr, nullptr, nullptr, (const bf16*)w_fwd, (bf16*)y, stat_sums, g.N,
+                                          g.H, g.W, g.C, g.K, st);
+            if (rc3 != PRIMIA_ERR_UNSUPPORTED) return rc3;
         }
         p.nsteps = g.klen / 64;
         return dispatch_igemm<bf16, false>(p, g.stem, st);
@@ -904,6 +928,11 @@ int primia_conv2d_fwd_stats_pair(const primia_conv_desc* d, const void* x, const
     ConvGeom g, gd;
     PRIMIA_REQUIRE(g.init(*d) && gd.init(*d_ds));
     if (!fwd_pair_shape(g, gd, dtype)) return PRIMIA_ERR_UNSUPPORTED;
+    if (s2_pass_on(0) && s2_conv1_shape(g) && s2_ds_shape(gd) && g.pad == 1 && (stat_sums == nullptr) == (stat_sums_ds == nullptr)) {
+        const int rc = conv_s2lh_fwd((const bf16*)x, (const bf16*)w_fwd, (bf16*)y, stat_sums, (const bf16*)w_fwd_ds,
+                                     (bf16*)y_ds, stat_sums_ds, g.N, g.H, g.W, g.C, g.K, (hipStream_t)stream);
+        if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
+    }
     auto fill = [&](IgemmParams& p, const ConvGeom& c, const void* w, void* out, float* sums) {
         p.src = x; p.wt = w; p.dst = out;
         p.Nb = c.N; p.Hd = c.Ho; p.Wd = c.Wo; p.Nd = c.K;
@@ -935,6 +964,7 @@ int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype) {
         const int cs = pass == 0 ? g.C : g.K, nd = pass == 0 ? g.K : g.C;
         if (conv3x3_lh2_tiles_m(g.N, g.H, g.W, cs, nd) > 0) return 4;
     }
+    if (s2_pass_on(pass, g.C) && (s2_conv1_shape(g) || (pass == 0 && s2_ds_shape(g)))) return 5;
     return 1;
 }
 
@@ -952,6 +982,7 @@ static int conv_stat_slots_impl(const primia_conv_desc* d, int dtype, int* per_t
         const int t2 = conv3x3_lh2_tiles_m(g.N, g.H, g.W, g.C, g.K);
         if (t2 > 0) return t2;
     }
+    if (dtype == PRIMIA_BF16 && s2_pass_on(0) && (s2_conv1_shape(g) || s2_ds_shape(g))) return conv_s2lh_tiles_m(g.N, g.H, g.W);
     // bf16 implicit GEMM: one partial per 128-pixel tile out of its write-back (every tile config in use has BM = 128)
     if (dtype == PRIMIA_BF16 && !g.stem && g.K % 8 == 0) return (int)(((long)g.N * g.Ho * g.Wo + 127) / 128);
     *per_tile = 0;
@@ -1012,6 +1043,11 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
             const int rc2 = conv3x3_lh2_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C,
                                                  1, accumulate, st, nullptr, acc_mask);
             if (rc2 != PRIMIA_ERR_UNSUPPORTED) return rc2;
+        }
+        if (!accumulate && !acc_mask && s2_pass_on(1, g.C) && s2_conv1_shape(g)) {     // transition block: conv1 (+ the downsample) on the parity planes
+            const int rc3 = conv_s2lh_dgrad((const bf16*)dy, (const bf16*)w_dgrad, (const bf16*)dy2, (const bf16*)w_dgrad2,
+                                            (bf16*)dx, g.N, g.H, g.W, g.C, g.K, st);
+            if (rc3 != PRIMIA_ERR_UNSUPPORTED) return rc3;
         }
         if (acc_mask) return PRIMIA_ERR_UNSUPPORTED;   // only the 64->64 and linear-halo write-backs mask the old values
         p.nsteps = p.klen / 64;

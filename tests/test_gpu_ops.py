@@ -1124,3 +1124,88 @@ def test_batchnorm_forward_pair_is_bit_identical(cuda, dtype, N, H, C):
         assert torch.equal(a, b)
 
 
+
+
+S2LH_CASES = [
+    (2, 16, 64, 128),     # layer2.0 shape: dx has 64 channels -> two parity classes per tile (half-zero weight tiles)
+    (3, 28, 128, 256),    # layer3.0: one class per tile, ragged last pixel tile (588 = 3 x 192 + 12)
+    (4, 14, 256, 512),    # layer4.0: 4 channel tiles, 36-step programs
+    (1, 6, 64, 128),      # 3 x 3 parity grid: every shifted tap leaves the image somewhere
+    (5, 4, 128, 128),     # 2 x 2 parity grid, 20 parity pixels in all
+    (5, 2, 128, 128),     # 1 x 1 parity grid: not served (falls back)
+    (2, 56, 64, 128),     # widest grid the kernel takes (Wo = 28), 1,568 parity pixels = 8.17 tiles
+    (1, 58, 64, 128),     # Wo = 29: not served, falls back to the implicit GEMM
+]
+
+
+@pytest.mark.parametrize("N,H,C,K", S2LH_CASES)
+def test_parity_plane_kernel_every_mode(cuda, N, H, C, K):
+    """conv_s2lh_kernel (csrc/conv_s2lh.hip) — the transition blocks' stride-2 3x3 + 1x1 layers as stride-1 problems on
+    parity planes — in EVERY form it has, forced with option s2lh = 7 (by default only the data gradient of the narrow
+    layers takes it): conv1 alone, downsample alone, the paired forward with BatchNorm partial sums, the data gradient
+    alone and paired, each against torch autograd (torchlib/models.py:219-235, 433-436) at one bf16 rounding, and the
+    partial sums against the sums of the stored values."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(5 + H + C)
+    x = rnd(torch.randn(N, C, H, H, generator=g).clamp_min(0), dtype)
+    w1 = rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype)
+    wd_ = rnd(torch.randn(K, C, 1, 1, generator=g) * 0.1, dtype)
+    d1 = ConvDesc.make(N, H, H, C, K, 3, 3, 2, 1)
+    dd = ConvDesc.make(N, H, H, C, K, 1, 1, 2, 0)
+    xr = x.clone().requires_grad_(True)
+    y1_ref = F.conv2d(xr, w1, None, 2, 1)
+    yd_ref = F.conv2d(xr, wd_, None, 2, 0)
+    dy1 = rnd(torch.randn(y1_ref.shape, generator=g), dtype)
+    dyd = rnd(torch.randn(yd_ref.shape, generator=g), dtype)
+    g1 = torch.autograd.grad(y1_ref, xr, dy1, retain_graph=True)[0]
+    gd = torch.autograd.grad(yd_ref, xr, dyd)[0]
+    try:
+        _lib.set_option("s2lh", 7)
+        served = 2 <= H // 2 <= 28
+        assert query("primia_conv_kernel_id", d1, 0, dt) == (5 if served else 1)
+        assert query("primia_conv_kernel_id", d1, 1, dt) == (5 if served else 1)
+        w1f, w1d = prep_weights(d1, w1, dtype, cuda, C)
+        wdf, wdd = prep_weights(dd, wd_, dtype, cuda, C)
+        xd = to_nhwc(x, dtype, cuda)
+        M2 = N * d1.Ho * d1.Wo
+        # single launches
+        y1 = torch.full((M2, K), 7.0, dtype=dtype, device=cuda)
+        yd = torch.full((M2, K), 7.0, dtype=dtype, device=cuda)
+        call("primia_conv2d_fwd", d1, xd, w1f, y1, dt)
+        call("primia_conv2d_fwd", dd, xd, wdf, yd, dt)
+        assert relerr(from_nhwc(y1, N, d1.Ho, d1.Wo), y1_ref.detach()) < tol(dtype)
+        assert relerr(from_nhwc(yd, N, d1.Ho, d1.Wo), yd_ref.detach()) < tol(dtype)
+        # the pair, with partial sums
+        s1, sd = query("primia_conv_stat_slots_for", d1, dt), query("primia_conv_stat_slots_for", dd, dt)
+        assert s1 == sd and (not served or s1 == (M2 + 191) // 192)
+        q1 = torch.full((s1, 2, K), 9.0, device=cuda)
+        qd = torch.full((sd, 2, K), 9.0, device=cuda)
+        p1, pd = torch.empty_like(y1), torch.empty_like(yd)
+        call("primia_conv2d_fwd_stats_pair", d1, xd, w1f, p1, q1, dd, wdf, pd, qd, dt)
+        assert torch.equal(p1, y1) and torch.equal(pd, yd)
+        if query("primia_conv_stats_per_tile", d1, dt) == 1:
+            for q, y in ((q1, p1), (qd, pd)):
+                v = y.double()
+                assert relerr(q[:, 0].double().sum(0), v.sum(0)) < 1e-5
+                assert relerr(q[:, 1].double().sum(0), (v * v).sum(0)) < 1e-5
+        # data gradients: conv1 alone, then the pair (every element of dx written)
+        dy1d, dydd = to_nhwc(dy1, dtype, cuda), to_nhwc(dyd, dtype, cuda)
+        dx = torch.full((N * H * H, C), 3.0, dtype=dtype, device=cuda)
+        call("primia_conv2d_dgrad", d1, dy1d, w1d, dx, 0, dt)
+        assert relerr(from_nhwc(dx, N, H, H), g1) < tol(dtype)
+        dx.fill_(3.0)
+        call("primia_conv2d_dgrad_pair", d1, dy1d, w1d, dd, dydd, wdd, dx, dt)
+        assert relerr(from_nhwc(dx, N, H, H), g1 + gd) < tol(dtype)
+        # ... and bit-repeatable
+        dx2 = torch.empty_like(dx)
+        call("primia_conv2d_dgrad_pair", d1, dy1d, w1d, dd, dydd, wdd, dx2, dt)
+        assert torch.equal(dx, dx2)
+        # the implicit GEMM on the same operands: one bf16 rounding apart at most
+        _lib.set_option("s2lh", 0)
+        assert query("primia_conv_kernel_id", d1, 1, dt) == 1
+        dx3 = torch.empty_like(dx)
+        call("primia_conv2d_dgrad_pair", d1, dy1d, w1d, dd, dydd, wdd, dx3, dt)
+        assert relerr(dx, dx3) < 4e-3
+    finally:
+        _lib.set_option("s2lh", 1)
