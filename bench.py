@@ -308,7 +308,8 @@ def main():
     from primia_amd import _lib
     from primia_amd._lib import query
 
-    KNAME = {1: "conv_igemm_kernel", 5: "conv_s2lh_kernel (stride-2 3x3 + 1x1, fwd + dgrad)", 2: "conv3x3_c64_kernel (fwd + dgrad)", 4: "conv3x3_lh2_kernel + conv3x3_lh4_kernel (fwd + dgrad)",
+    KNAME = {1: "conv_igemm_kernel", 5: "conv_s2lh_kernel (stride-2 3x3 + 1x1, fwd + dgrad)", 2: "conv3x3_c64_kernel (fwd + dgrad)", 4: "conv3x3_lh2_kernel (fwd + dgrad)",
+             6: "conv3x3_lh4_kernel (fwd + dgrad)",
              13: "conv_wgrad_dma_kernel (per-tap, stride 2 / 1x1)", 14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)",
              16: "conv_wgrad_patch33_kernel + wgrad_patch32_reduce_kernel",
              17: "conv_wgrad_tap_kernel + wgrad_tile_reduce_kernel (per-tap, stride 2 / 1x1)"}
@@ -367,27 +368,26 @@ def main():
         if key in rec:
             same = rec.get("_source_sha256") == source_digest()
             per_launch = rec[key].get("hbm_bytes_per_launch")
-            if key == "conv3x3_lh2_kernel" and "conv3x3_lh4_kernel" in rec:
-                # the family's 196-pixel-tile launches run on conv3x3_lh4_kernel: launch-weighted mean of the two records
-                a_, b_ = rec[key], rec["conv3x3_lh4_kernel"]
-                per_launch = int((a_["hbm_bytes_per_launch"] * a_["launches"] + b_["hbm_bytes_per_launch"] * b_["launches"])
-                                 / (a_["launches"] + b_["launches"]))
-                key = "conv3x3_lh2_kernel + conv3x3_lh4_kernel"
             traffic_offline = {"hbm_bytes_per_launch": per_launch, "kernel": key,
                                "source": "profiles/" + TRAFFIC_FILE, "same_sources_as_this_run": same}
             if same:
                 traffic = per_launch
+    # the wide 3x3 / stride-1 layers (layer2-4 forward + data gradient) are ONE algorithm on two kernels — conv3x3_lh2_kernel
+    # (392-pixel tiles) and conv3x3_lh4_kernel (196-pixel tiles, loader waves): reported together beside the dominant kernel
+    wide = [k for k in fam if k.startswith("conv3x3_lh2_kernel") or k.startswith("conv3x3_lh4_kernel")]
+    family = None
+    if wide:
+        f_ms, f_fl, f_n = (sum(fam[k][q] for k in wide) for q in ("ms", "flops", "launches"))
+        family = {"kernels": wide, "tflops": round(f_fl / (f_ms * 1e-3) / 1e12, 2), "frac": round(f_fl / (f_ms * 1e-3) / 1e12 / peak, 4),
+                  "ms_per_step": round(f_ms / nprof, 4), "avg_launch_us": round(f_ms * 1e3 / f_n, 2), "launches_per_step": f_n // nprof}
     roof = {"bound": "mfma", "kernel": dom,
-            "launch": "median over %d steps of the HIP-event bracket around one C-ABI call (a weight-gradient call = the "
-                      "kernel + its ordered reduce)" % nprof,
+            "kernel_is": "the kernel (one C-ABI call; a weight-gradient call = the kernel + its ordered reduce) with the most time per step",
+            "launch": "median over %d steps of the HIP-event bracket around one C-ABI call" % nprof,
             "achieved": kernels[dom]["tflops"], "peak": peak, "unit": "TFLOP/s",
             "frac": round(kernels[dom]["tflops"] / peak, 4), "traffic": traffic, "traffic_offline": traffic_offline,
-            # `frac` is priced at the nominal 2.4 GHz peak.  Under matrix load the part runs at ~2.0 GHz (PMC: profiles/
-            # r04_stall_counters.txt) and a loop of nothing but MFMAs on random operands holds 1.79 PFLOP/s, a stage body that
-            # re-reads its fragments from LDS and meets a barrier 1.48 (tools/micro/mfma_stage.hip, profiles/r04_mfma_ceilings.txt)
-            "sustained_ceilings": {"mfma_only_random_operands_tflops": 1788.0, "frac_of_it": round(kernels[dom]["tflops"] / 1788.0, 4),
-                                   "lds_reread_and_barrier_tflops": 1476.0, "frac_of_that": round(kernels[dom]["tflops"] / 1476.0, 4),
-                                   "source": "profiles/r04_mfma_ceilings.txt"},
+            # (`frac` is priced at the nominal 2.4 GHz dense-bf16 peak; what the part sustains under matrix load is measured in
+            # profiles/r04_mfma_ceilings.txt and discussed in DESIGN.md — no constants from there are repeated here)
+            "wide3x3_family": family,
             "all_conv": {"tflops": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "ms_per_step": round(conv_ms, 3),
                          "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4)},
             "kernels": kernels, "by_pass": by_pass, "layers_us": layers}
@@ -410,6 +410,29 @@ def main():
         "fedavg_ms_per_sync": fedavg_ms,
         "roofline": roof,
     }
+    if world > 1:
+        # proof that the exchange ran on RCCL with `world` ranks, and BASELINE.md B2 beside it
+        ver = None
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+        # every rank reports the physical device it ran on (PCI bus id where the runtime gives it)
+        try:
+            me = torch.cuda.get_device_properties(dev)
+            ident = f"{local_rank}:{getattr(me, 'pci_bus_id', '?')}:{getattr(me, 'uuid', '')}"
+        except Exception:
+            ident = str(local_rank)
+        gpu_ids = [None] * world
+        dist.all_gather_object(gpu_ids, ident)
+        out["collective"] = {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "rccl_version": ver,
+                             "op": "all_reduce(SUM) of the 44.75 MB parameter + running-statistics arena per sync",
+                             "gpus_seen": sorted(set(gpu_ids))}
+        out["cpu_baseline_b2"] = {
+            "definition": "BASELINE.md B2: the reference's federated epoch visits its K in-process clients SEQUENTIALLY on the "
+                          "host cores (torchlib/utils.py:1159-1174), so its per-client rate is B1 / K and its aggregate rate is B1",
+            "K": world, "value_per_client": "cpu_baseline.value of the N = 1 line / %d" % world,
+            "note": "cpu_baseline is timed on rank 0 at N = 1 only (bench contract); B1 does not depend on N"}
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.cpu_baseline_batch, a.size)
     if rank == 0 and world == 1 and not a.no_secure:

@@ -193,6 +193,7 @@ int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_ac
  * actually ran).  pass 0 = forward, 1 = data gradient:
  *   1 conv_igemm_kernel   2 conv3x3_c64_kernel   4 conv3x3_lh2_kernel   (3: conv3x3_lh_kernel, removed in round 4)
  *   5 conv_s2lh_kernel (the stride-2 3x3 / 1x1 layers of the transition blocks on parity planes, round 5)
+ *   6 conv3x3_lh4_kernel (the linear-halo layers that take 196-pixel tiles: loader-wave form, round 4)
  * weight gradient:
  *   13 conv_wgrad_dma_kernel   14 conv_wgrad_kernel   (11 / 12: the first two patch kernels, removed in round 4)
  *   16 conv_wgrad_patch33_kernel (3 + 3 fragments per k-step; the default)   17 conv_wgrad_tap_kernel

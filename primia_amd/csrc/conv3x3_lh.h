@@ -8,6 +8,7 @@ namespace primia {
 // conv3x3_lh.hip — one tile per block, 74.8 us per launch against 55.6 — was superseded in round 3 and removed.)
 // pixel tiles (= partial slots) if the shape is served by the kernel, else PRIMIA_ERR_UNSUPPORTED
 int conv3x3_lh2_tiles_m(int N, int H, int W, int Cs, int Nd);
+int conv3x3_lh_kernel_of(int N, int H, int W, int Cs, int Nd);   // 4 conv3x3_lh2_kernel | 6 conv3x3_lh4_kernel | 0 neither
 int conv3x3_lh2_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
                          int accumulate, hipStream_t st, float* stat_partials = nullptr,
                          const uint8_t* acc_mask = nullptr);

@@ -734,6 +734,13 @@ int conv3x3_lh2_tiles_m(int N, int H, int W, int Cs, int Nd) {
     return (int)(((long)N * H * W + bm - 1) / bm);
 }
 
+// 4: conv3x3_lh2_kernel serves the shape, 6: conv3x3_lh4_kernel does (196-pixel tiles, option lh4), 0: neither
+int conv3x3_lh_kernel_of(int N, int H, int W, int Cs, int Nd) {
+    const int bm = lh2_bm(N, H, W, Cs, Nd);
+    if (!bm) return 0;
+    return bm == 196 && PRIMIA_OPT(lh4) ? 6 : 4;
+}
+
 int conv3x3_lh2_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
                          int accumulate, hipStream_t st, float* stat_partials, const uint8_t* acc_mask) {
     const int bm = lh2_bm(N, H, W, Cs, Nd);

@@ -962,7 +962,8 @@ int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype) {
     if (use_c64(g) && (long)g.N * g.H * g.W * 64 < (1L << 31)) return 2;
     if (lh_shape(g) && (pass == 1 || g.W <= lh_fwd_maxw())) {
         const int cs = pass == 0 ? g.C : g.K, nd = pass == 0 ? g.K : g.C;
-        if (conv3x3_lh2_tiles_m(g.N, g.H, g.W, cs, nd) > 0) return 4;
+        const int lk = conv3x3_lh_kernel_of(g.N, g.H, g.W, cs, nd);
+        if (lk) return lk;
     }
     if (s2_pass_on(pass, g.C) && (s2_conv1_shape(g) || (pass == 0 && s2_ds_shape(g)))) return 5;
     return 1;

@@ -136,6 +136,54 @@ class Dealer:
         return r
 
 
+    # ---- in-place regeneration (serving: GraphedSecureInference.refill) --------------------------------------------
+    # The same primitives with the same distribution, written straight into the buffers a captured graph reads: no
+    # temporaries handed over and copied (a DIF key is 1.2 KB per comparison, 3.3 M comparisons per image), and a
+    # triple's input shares are drawn directly (a = a0 + a1 with both shares uniform is the sharing of a uniform a that
+    # build_triple produces by drawing a and one share, mpc/beaver.py:7-63) — 9 launches per triple instead of 21.
+    def rand_into(self, out):
+        n = out.numel()
+        if not out.is_contiguous():
+            raise PrimiaError("rand_into needs a contiguous buffer")
+        call("primia_chacha20_fill", *self._key, self._nonce, self._block, out, n)
+        self._block += (n + 7) // 8
+        return out
+
+    def refill_entry(self, kind, args, kw, entry):
+        if kind == "const_mask":
+            self.rand_into(entry)
+        elif kind == "triple":
+            op, xshape, yshape = args
+            (a0, b0, c0), (a1, b1, c1) = entry
+            for t in (a0, a1, b0, b1, c0):
+                self.rand_into(t)
+            a, b = _empty_like(a0), _empty_like(b0)
+            call("primia_ring_add", a0, a1, a, a.numel(), a.numel())
+            call("primia_ring_add", b0, b1, b, b.numel(), b.numel())
+            c = _empty_like(c0)
+            if op == "mul":
+                big, small = (a, b) if a.numel() >= b.numel() else (b, a)
+                call("primia_ring_mul", big, small, c, big.numel(), small.numel())
+            else:
+                call("primia_ring_matmul", a, b, c, xshape[-2], xshape[-1], yshape[-1], 0)
+            call("primia_ring_sub", c, c0, c1, c.numel(), c.numel())
+        elif kind == "dif_keys":
+            (n,) = args
+            k0, k1 = entry
+            alpha = self.rand32(n)
+            s0 = self.rand64(2, 2, n)
+            s0[:, 0] &= 0x7FFFFFFFFFFFFFFF
+            call("primia_dif_keygen", alpha, s0, k0["bits"], k0["cw_sigma"], k0["cw_s"], k0["cw_leaf"], n)
+            k0["s0"].copy_(s0[0])
+            k1["s0"].copy_(s0[1])
+            r = self.rand_into(k1["alpha"])
+            r &= 0xFFFFFFFF
+            torch.sub(alpha, r, out=k0["alpha"])
+            k0["alpha"] &= 0xFFFFFFFF
+        else:
+            raise PrimiaError(f"unknown primitive kind {kind!r}")
+
+
 class PreloadedDealer:
     """Online phase only: hands out primitives that a Dealer generated earlier (its `tape`), in
     the same order — the reference's pre-provisioned crypto store (mpc/primitives.py:161-235)."""
@@ -837,7 +885,7 @@ class GraphedSecureInference:
         """Fresh per-image primitives from the dealer, written into the captured buffers."""
         for i in range(self._n_model, len(self.tape)):
             kind, args, kw = self.requests[i]
-            _copy_primitive(self.tape[i], getattr(self.dealer, kind)(*args, **kw))
+            self.dealer.refill_entry(kind, args, kw, self.tape[i])
 
     def __call__(self, image, refill=True):
         if refill:
@@ -845,6 +893,51 @@ class GraphedSecureInference:
         self.image.copy_(image)
         self.graph.replay()
         return self.out
+
+
+class PipelinedSecureInference:
+    """A stream of encrypted inferences with the crypto provider HIDDEN behind the online phase.
+
+    The reference provisions primitives on demand, serially with the protocol (mpc/fss.py:142-146, primitives.py:161-235).
+    Here two `GraphedSecureInference` slots (each its own dealer, static primitive buffers and captured online graph)
+    alternate: while image i replays slot i % 2 on the caller's stream, the dealer refills the OTHER slot for image i + 1
+    on its own stream — its ~3,000 small launches per image (ChaCha20 fills, share splits, copies into the captured
+    buffers) are host-bound and vanish behind the one graph launch; its 21 key generations share the vector ALUs with
+    the online evaluation.  Events order a slot's refill after the replay that consumed it and the next replay after
+    the refill.  Every image's shares are those of an eager SecureResNet18 on the slot's primitives (the graph is
+    bit-identical to it, tests/test_gpu_secure.py); nothing about the protocol changes, only who waits for whom.
+    In the three-role deployment the same overlap is physical: the dealer rank runs ahead of the parties on its own GPU."""
+
+    def __init__(self, state_dict, device, input_size=224, precision_fractional=16, base=10, seed=None, blocks=None, slots=2):
+        self.device = torch.device(device)
+        self.slots = [GraphedSecureInference(state_dict, device, input_size, precision_fractional, base,
+                                             None if seed is None else seed + 7919 * k, blocks) for k in range(slots)]
+        self.stats = self.slots[0].stats
+        self.dealer_stream = torch.cuda.Stream(device=self.device)
+        self._ready = [None] * slots       # event: slot k's primitives are fresh (None: fresh since construction)
+        self._n = 0
+
+    def __call__(self, image):
+        """One encrypted inference; returns what SecureResNet18 returns (a copy: the slot's buffers are reused)."""
+        k = self._n % len(self.slots)
+        slot = self.slots[k]
+        main = torch.cuda.current_stream()
+        if self._ready[k] is not None:
+            main.wait_event(self._ready[k])
+        slot.image.copy_(image)
+        slot.graph.replay()
+        out = slot.out.clone()
+        consumed = torch.cuda.Event()
+        consumed.record(main)
+        # the dealer regenerates this slot's primitives for image n + len(slots) while the next image runs on another slot
+        with torch.cuda.stream(self.dealer_stream):
+            self.dealer_stream.wait_event(consumed)
+            slot.refill()
+            ev = torch.cuda.Event()
+            ev.record(self.dealer_stream)
+        self._ready[k] = ev
+        self._n += 1
+        return out
 
 
 # ---- three-role deployment: party 0 (model owner), party 1 (data owner), crypto provider --------------------
