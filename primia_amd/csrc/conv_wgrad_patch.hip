@@ -82,10 +82,14 @@ __device__ __forceinline__ int key32(int slot) { return (slot >> 1) & 1; }
 
 // Epilogue shared by the stride-1 and stride-2 kernels: the two halves of the block meet in LDS (waves 4-7 park their
 // accumulators, waves 0-3 add them), then one of the three outputs: per-sample squared norm, partial slab, atomics.
+template <bool MERGE = true>
 __device__ __forceinline__ void wgrad32_epilogue(f32x16 (&acc)[9], const PatchParams& p, char* smem, int wave, int lane,
                                                  int half, int kg, int cg, int kt, int ct, int split) {
     // ---- the two halves meet in LDS: waves 4-7 park their accumulators, waves 0-3 add them ---------------------------
+    // (MERGE = false, the loader-wave form: four matrix waves own the whole slab, nothing to meet — and no block-wide
+    // barrier here: the loader waves have left)
     if ((WGP33_DBG & 1) && acc[0][0] != 12345.f) return;     // compile-time experiment switch (tools/micro/wgp33_bench.hip)
+    if constexpr (MERGE) {
     __syncthreads();                                   // every wave is done reading the stage ring
     {
         f32x4* park = (f32x4*)smem + ((wave & 3) * 36) * 64 + lane;     // [wave & 3][t * 4 + m][lane] chunks of 16 B
@@ -106,6 +110,7 @@ __device__ __forceinline__ void wgrad32_epilogue(f32x16 (&acc)[9], const PatchPa
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[t][4 * m + j] += v[j];
             }
+    }
     }
     // lane holds out-chan rows 32*kg + 8*m + 4*(lane>>5) + j (register 4*m + j), in-chan column 32*cg + (lane & 31)
     if (p.sqnorm) {
@@ -246,7 +251,15 @@ __device__ unsigned long long* wgp33_prof_buffer_dev;
 #else
 #define WGP33_MARK(slot)
 #endif
-template <int SW, int SH, int STAGES>
+// LW ("loader waves", round 5): waves 0-3 are the ONLY matrix waves — one per SIMD, wave (kg, cg) owns out-channels 32 kg ..,
+// in-channels 32 cg .. of all nine taps for EVERY sub-patch (both sub-patches of a stage, one after the other: no halves, no
+// meeting in LDS) and never issues a DMA instruction or waits on vmcnt; waves 4-7 issue every LDS-DMA piece, wait for their
+// own and meet the stage barrier.  r03's phase profile: a wave of the two-halves form spends as long blocked in its five DMA
+// issues per stage (~2,000 cycles: the memory pipe's queue is full) as it spends multiplying, and a stage is issue + compute,
+// not the maximum of the two, because a blocked issue also holds the wave's own MFMAs behind it.  A third wave per SIMD does
+// not fit beside 144 accumulator registers — but ONE matrix wave per SIMD with nine independent accumulators keeps the matrix
+// pipe fed by itself, so the second wave of each SIMD can be a pure loader.  (DP-SGD's per-sample forms stay on the two-halves kernel.)
+template <int SW, int SH, int STAGES, bool LW = false>
 __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
     constexpr int FR = SW == 8 ? 2 : 1;         // rows of a k-step fragment
     constexpr int NK = SH / FR;                 // k-steps per sub-patch
@@ -258,14 +271,17 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
     constexpr int HALF = (XSLOTS + DSLOTS) * 128;   // one sub-patch: [x image][dy image]
     constexpr int STAGE = 2 * HALF;
     constexpr int NPIECE = 2 * (XP + DP);
-    constexpr int MAXIT = (NPIECE + 7) / 8;
-    static_assert(MAXIT <= 9, "piece bookkeeping");
+    constexpr int NISSUE = LW ? 4 : 8;                 // waves that issue DMA pieces
+    constexpr int MAXIT = (NPIECE + NISSUE - 1) / NISSUE;
+    static_assert(MAXIT <= 12, "piece bookkeeping");
     typedef __attribute__((address_space(3))) bf16x4_t* lds4_t;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int half = wave >> 2, kg = (wave >> 1) & 1, cg = wave & 1;
+    const int half = LW ? 0 : wave >> 2, kg = (wave >> 1) & 1, cg = wave & 1;
+    const bool loader = LW && wave >= 4;
+    const int iw = LW ? (wave & 3) : wave;             // index among the issuing waves
 #ifdef WGP33_PROF
     unsigned long long prof_t[6] = {0, 0, 0, 0, 0, 0}, prof_prev = clock64();   // [5] = everything before the main loop ends... see marks
 #endif
@@ -298,10 +314,10 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
     int rel[MAXIT];
     unsigned lbits[MAXIT];
     int pq[MAXIT], pisx[MAXIT], pdst[MAXIT];
-    const int npc = (NPIECE - wave + 7) / 8;            // pieces of this wave (wave-uniform)
+    const int npc = (LW && !loader) ? 0 : (NPIECE - iw + NISSUE - 1) / NISSUE;            // pieces of this wave (wave-uniform)
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-        int idx = wave + 8 * it;
+        int idx = iw + NISSUE * it;
         if (idx >= NPIECE) idx = NPIECE - 1;            // (never issued)
         const int q = idx >= XP + DP;
         const int j = idx - q * (XP + DP);
@@ -443,9 +459,9 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
     // One stage of this wave's sub-patch: NK k-steps x 9 MFMAs.  Y[y] = dy fragment whose first row is image row y - 1
     // of the sub-patch; tap row r of k-step j needs Y[FR j + 2 - r].
     constexpr bool prio = false;       // (s_setprio around the MFMAs: measured, no gain — profiles/r03_negative_results.txt)
-    auto compute = [&](int buf) {
+    auto compute = [&](int buf, int q_half = 0) {
         typedef __attribute__((address_space(3))) char* ldsp_t;
-        const ldsp_t sb = (ldsp_t)(size_t)(lds0 + buf * STAGE);
+        const ldsp_t sb = (ldsp_t)(size_t)(lds0 + buf * STAGE + q_half * HALF);
         ldsp_t py_[2], px_[3][2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -518,13 +534,45 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
             case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
             case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
             case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-            default: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;   // n == 1 (npc >= 1 always)
+            case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+            case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+            case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (more pieces than the cases above: wait for all)
         }
     };
 
+    if (!LW || loader) {
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s)
-        if (s < nstages) stage(s);
+        for (int s = 0; s < STAGES - 1; ++s)
+            if (s < nstages) stage(s);
+    }
+    if constexpr (LW) {
+        int cur = 0, nxt = STAGES - 1;
+        if (loader) {
+            for (int s = 0; s < nstages; ++s) {
+                int ahead = nstages - 1 - s;
+                if (ahead > STAGES - 2) ahead = STAGES - 2;
+                wait_inflight(ahead);                  // this wave's pieces of stage s have landed
+                __builtin_amdgcn_s_barrier();          // ... everybody's have, and stage s - 1 has been multiplied
+                do_issue = s + STAGES - 1 < nstages && !(WGP33_DBG & 2);
+                if (do_issue) stage(nxt);              // into the buffer stage s - 1 occupied
+                nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
+            }
+            return;
+        }
+        for (int s = 0; s < nstages; ++s) {
+            __builtin_amdgcn_s_barrier();
+            compute(cur, 0);
+            compute(cur, 1);
+            cur = cur + 1 == STAGES ? 0 : cur + 1;
+        }
+        if (!(WGP33_DBG & 1)) wgrad32_epilogue<false>(acc, p, smem, wave, lane, 0, kg, cg, kt + gi * p.nkt, ct, split);
+        else {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) asm volatile("" ::"v"(acc[t]));
+        }
+        return;
+    }
     // the two waves of a SIMD belong to different halves: half 0 issues its DMA pieces and THEN multiplies, half 1
     // multiplies and THEN issues (see v2); two copies of the loop, one order each
     int sp_done = 0, img_pair = 0;     // pairimg: stages done of the current image pair; pairs done
@@ -606,6 +654,12 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
 template <int SW, int SH, int STAGES>
 __global__ __launch_bounds__(512) void conv_wgrad_patch33_kernel(PatchParams p) {
     patch33_body<SW, SH, STAGES>(p, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// the loader-wave form (option wgp_lw; the batched gradient only)
+template <int SW, int SH, int STAGES>
+__global__ __launch_bounds__(512) void conv_wgrad_patch33lw_kernel(PatchParams p) {
+    patch33_body<SW, SH, STAGES, true>(p, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 struct PatchGeom {
@@ -708,12 +762,13 @@ static int launch_patch33(const WgradParams& w, const PatchGeom& g, hipStream_t 
     // after the main loop
     size_t lds = (size_t)kSlab * 4;
     if (SW == 8 && SH == 8 && STAGES == 4) lds = 163840;
-    auto kern = conv_wgrad_patch33_kernel<SW, SH, STAGES>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const bool lw = PRIMIA_OPT(wgp_lw) && !p.pairimg && !p.sqnorm;
+    void (*kern)(PatchParams) = lw ? conv_wgrad_patch33lw_kernel<SW, SH, STAGES> : conv_wgrad_patch33_kernel<SW, SH, STAGES>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[lw]) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PRIMIA_ERR_LAUNCH;
-        attr_set = true;
+        attr_set[lw] = true;
     }
     kern<<<(unsigned)(g.combos * g.nsplit), 512, lds, st>>>(p);
     if (p.ws) {
@@ -781,12 +836,13 @@ int wgrad_patch_group_dispatch(const WgradParams* ws_, int n, hipStream_t st) {
         rg.dwg[i - 1] = ws_[i].dw;
     }
     const size_t lds = (size_t)kSlab * 4;
-    auto kern = conv_wgrad_patch33_kernel<8, 8, 3>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    const bool lw = PRIMIA_OPT(wgp_lw) != 0;
+    void (*kern)(PatchParams) = lw ? conv_wgrad_patch33lw_kernel<8, 8, 3> : conv_wgrad_patch33_kernel<8, 8, 3>;
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[lw]) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return PRIMIA_ERR_LAUNCH;
-        attr_set = true;
+        attr_set[lw] = true;
     }
     kern<<<(unsigned)(n * p.group_blocks), 512, lds, st>>>(p);
     const int ns = g.nsplit, all = n * g.combos;

@@ -31,6 +31,7 @@ namespace primia {
     X(wgp_order, 0)         /* block id order: 0 slab fastest (the slabs of a pixel range share x, dy in one L2), 1 pixel range fastest */                                                          \
     X(wgp_stages88, 3)      /* ring depth for 8 x 8 sub-patches: 3 | 4 */                                              \
     X(wgp_group, 1)         /* same-shape layers of a stage in one launch */                                           \
+    X(wgp_lw, 1)            /* 3x3 weight gradient: four matrix waves (one per SIMD) + four loader waves instead of the two halves */ \
     X(wgp_group_minfill, 90) /* % of the CUs a grouped launch must fill */                                             \
     X(dp_keep_mb, 160)      /* DP-SGD: per-sample tiles of a layer are kept up to this many MiB */                     \
     X(dp_ghost, 1)          /* DP-SGD: Gram-matrix norms for the 7 x 7 layers */                                       \

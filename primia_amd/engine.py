@@ -365,6 +365,8 @@ class ResNet18Engine:
         self.materialize_grads()
         return self._gviews
 
+    max_siblings = 6      # batch sizes kept besides the root's (each owns its activations and workspaces)
+
     def sibling(self, batch_size):
         """An engine for ANOTHER batch size on the SAME parameters, gradients, running statistics, kernel-layout weight
         copies and optimizer state (activations and workspaces are its own): forward / loss_backward / sgd_step /
@@ -373,7 +375,15 @@ class ResNet18Engine:
         n = int(batch_size)
         if n == self.N:
             return self
+        if n == self._root.N:         # (asked of a sibling: the root itself, not a second full-size engine)
+            self._root.train(self.training)
+            return self._root
         sib = self._root.__dict__.setdefault("_siblings", {})
+        if n not in sib and len(sib) >= self.max_siblings:
+            # activations and workspaces of an engine are ~12 MB per image: keep the most recent few batch sizes only
+            # (MixUp halves, the ragged final batch of train / validation loaders), evict the oldest
+            del sib[next(iter(sib))]
+            torch.cuda.empty_cache()
         if n not in sib:
             sib[n] = ResNet18Engine(n, self.spec.num_classes, self.spec.in_channels, self.spec.input_size,
                                     self.spec.pooling, dtype=self.dtype, device=self.device, norm=self.norm,

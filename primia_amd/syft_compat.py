@@ -166,15 +166,17 @@ class FederatedDataset:
 
 class FederatedDataLoader:
     """sy.FederatedDataLoader(fed_dataset, batch_size, shuffle) (fl/dataloader.py:143) over ONE client's registered
-    tensors: yields (data, target) batches that already sit on the client's GPU.  The engines run a fixed batch size, so
-    the ragged last batch is dropped (`len` = floor(n / batch_size)), as primia_amd.imagefolder.DeviceLoader does."""
+    tensors: yields (data, target) batches that already sit on the client's GPU.  `drop_last` is the reference's
+    (default False: the ragged final batch is yielded too — the training loops run it on `engine.sibling(n)` — so every
+    sample the class weights and total_L count is trained on)."""
 
-    def __init__(self, federated_dataset, batch_size=8, shuffle=False, num_iterators=1, drop_last=True, seed=0, **kw):
+    def __init__(self, federated_dataset, batch_size=8, shuffle=False, num_iterators=1, drop_last=False, seed=0, **kw):
         from .imagefolder import DeviceLoader
 
         self.federated_dataset = federated_dataset
         ds = federated_dataset.datasets[0]
-        self._loader = DeviceLoader(ds.data, ds.targets, batch_size, shuffle, seed)
+        self._loader = DeviceLoader(ds.data, ds.targets, batch_size, shuffle, seed, drop_last=drop_last)
+        self.drop_last = drop_last
         self.batch_size = batch_size
 
     @property

@@ -195,9 +195,13 @@ def test_syft_worker_shim_objects():
         train_loader[workers[w]] = sy.FederatedDataLoader(ds, batch_size=4, shuffle=True)
     assert train_loader["alice"] is train_loader[workers["alice"]]        # worker objects and ids key the same entry
     tl = train_loader[workers["bob"]]
-    assert len(tl) == 2 and torch.equal(tl.targets, held["bob"][1])
+    # sy.FederatedDataLoader's default drop_last = False (fl/dataloader.py:143): the ragged final batch is yielded too
+    n_bob = len(held["bob"][0])
+    assert len(tl) == (n_bob + 3) // 4 and torch.equal(tl.targets, held["bob"][1])
     seen = torch.cat([d for d, _ in tl])
-    assert seen.shape == (8, 3, 4, 4)
+    assert seen.shape == (n_bob, 3, 4, 4)
+    whole = sy.FederatedDataLoader(ds, batch_size=4, shuffle=True, drop_last=True)
+    assert len(whole) == len(held[w][0]) // 4
     rows = {tuple(r.reshape(-1).tolist()) for r in held["bob"][0]}
     assert all(tuple(r.reshape(-1).tolist()) in rows for r in seen)      # a shuffled selection of the registered samples
     workers["alice"].object_store.clear_objects()

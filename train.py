@@ -90,31 +90,41 @@ def load_pretrained(engine, num_classes, rank=0, world=1):
     if engine.norm != "batch":
         raise SystemExit("pretrained ImageNet weights carry BatchNorm statistics; differentially_private = yes builds "
                          "a GroupNorm network (train.py:304-334)")
-    found = True
+    # rank 0's outcome travels to every rank BEFORE anybody raises: 1 loaded, 0 no file, 2 the file does not fit / does
+    # not load (a SystemExit on rank 0 alone left the others blocked in the broadcast until the RCCL timeout)
+    status, problem = 1, ""
     if rank == 0:
         cands = [os.environ.get("PRIMIA_PRETRAINED_RESNET18")] + [
             path.join(path.expanduser("~"), ".cache", "torch", "hub", "checkpoints", f) for f in PRETRAINED_FILES]
         src = next((c for c in cands if c and path.isfile(c)), None)
-        found = src is not None
-        if found:
-            sd = torch.load(src, map_location="cpu", weights_only=True)
-            own = engine.state_dict()
-            for k, v in sd.items():
-                if k.startswith("fc."):
-                    continue
-                if k not in own or tuple(own[k].shape) != tuple(v.shape):
-                    raise SystemExit("{:s}: {:s} does not fit this network ({} vs {})".format(
-                        src, k, tuple(v.shape), tuple(own[k].shape) if k in own else None))
-                own[k] = v.to(torch.float32)
-            fc = torch.nn.Linear(512, num_classes)        # model.fc = nn.Linear(512 * block.expansion, num_classes)
-            own["fc.weight"], own["fc.bias"] = fc.weight.detach().clone(), fc.bias.detach().clone()
-            engine.load_state_dict(own)
+        if src is None:
+            status = 0
+        else:
+            try:
+                sd = torch.load(src, map_location="cpu", weights_only=True)
+                own = engine.state_dict()
+                for k, v in sd.items():
+                    if k.startswith("fc."):
+                        continue
+                    if k not in own or tuple(own[k].shape) != tuple(v.shape):
+                        raise ValueError("{:s} does not fit this network ({} vs {})".format(
+                            k, tuple(v.shape), tuple(own[k].shape) if k in own else None))
+                    own[k] = v.to(torch.float32)
+                fc = torch.nn.Linear(512, num_classes)        # model.fc = nn.Linear(512 * block.expansion, num_classes)
+                own["fc.weight"], own["fc.bias"] = fc.weight.detach().clone(), fc.bias.detach().clone()
+                engine.load_state_dict(own)
+            except Exception as e:  # noqa: BLE001 - reported on every rank below
+                status, problem = 2, "{:s}: {:s}".format(src, str(e))
     if world > 1:
         import torch.distributed as dist
 
-        flag = torch.tensor([1 if found else 0], device=engine.flat.device)
+        flag = torch.tensor([status], device=engine.flat.device)
         dist.broadcast(flag, 0)
-        found = bool(flag.item())
+        status = int(flag.item())
+    if status == 2:
+        raise SystemExit("pretrained = yes, but the ImageNet state dict could not be used" + (": " + problem if problem else
+                         " (see rank 0's message)"))
+    found = status == 1
     if not found:
         msg = ("pretrained = yes, but no ImageNet ResNet-18 state dict was found (set PRIMIA_PRETRAINED_RESNET18 to a "
                "torchvision resnet18 .pth)")
