@@ -29,7 +29,7 @@
 // Tiles cost 1 .. 36 steps: blocks take contiguous tile ranges of equal COST, column tiles interleaved cheap / expensive.
 #include <stdlib.h>
 
-#include "conv_common.h"
+#include "conv3x3_lh.h"
 #include "options.h"
 
 // compile-time experiment switches (tools/s2lh_variants.sh builds and times the variants on one box)
@@ -96,8 +96,6 @@ struct S2Params {
     int prog[kS2MaxTypes][kS2MaxSteps];
 };
 
-__device__ __forceinline__ int s2_key(int quad) { return (quad & 1) << 1; }   // conv3x3_lh4.hip: l4_key
-
 __device__ __forceinline__ void s2_dma(unsigned voff, i32x4_t rsrc, unsigned soff, unsigned lds_addr) {
     soff = __builtin_amdgcn_readfirstlane(soff);
     lds_addr = __builtin_amdgcn_readfirstlane(lds_addr);
@@ -115,20 +113,6 @@ __device__ __forceinline__ i32x4_t s2_rsrc(const void* base, long bytes) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) r[j] = __builtin_amdgcn_readfirstlane(r[j]);
     return r;
-}
-
-__device__ __forceinline__ float s2_row_sum(float v) {   // conv3x3_lh4.hip: l4_row_sum (same order)
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));
-    return v;
-}
-
-__device__ __forceinline__ void s2_swap16(uint32_t& a, uint32_t& b) {
-    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
-    a = r[0];
-    b = r[1];
 }
 
 constexpr int kS2Slots = 224;                       // 192 + Wo + 1 <= 221 live slots; the last slot is always zero
@@ -183,7 +167,7 @@ __device__ __forceinline__ void s2_run(const S2Params& p, char* smem, int tile_f
     const int Wo = p.Wo, Ho = p.Ho;
     const bool dg = p.mode == 1;
     const bool has_stat = !dg && p.stat[0] != nullptr;
-    const int aoff = (wn * 64 + fr) * 64 + ((fg ^ s2_key(fr >> 2)) << 4);
+    const int aoff = (wn * 64 + fr) * 64 + ((fg ^ lh_key(fr >> 2)) << 4);
     const int sgn = dg ? 1 : -1;
     int sj0 = 16 * F0 + fr + (dg ? 0 : Wo + 1);
     const int* prog = (const int*)(smem + kS2OffProg);
@@ -251,8 +235,8 @@ __device__ __forceinline__ void s2_run(const S2Params& p, char* smem, int tile_f
                 uint32_t x1 = (uint32_t)f32_to_bf16(acc[2 * bq][j][2]) | ((uint32_t)f32_to_bf16(acc[2 * bq][j][3]) << 16);
                 uint32_t y0 = (uint32_t)f32_to_bf16(acc[2 * bq + 1][j][0]) | ((uint32_t)f32_to_bf16(acc[2 * bq + 1][j][1]) << 16);
                 uint32_t y1 = (uint32_t)f32_to_bf16(acc[2 * bq + 1][j][2]) | ((uint32_t)f32_to_bf16(acc[2 * bq + 1][j][3]) << 16);
-                s2_swap16(x0, y0);
-                s2_swap16(x1, y1);
+                lh_swap16(x0, y0);
+                lh_swap16(x1, y1);
                 pc[bq] = u32x4{x0, x1, y0, y1};
             }
             u32x4 stA, stB;
@@ -292,7 +276,7 @@ __device__ __forceinline__ void s2_run(const S2Params& p, char* smem, int tile_f
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t1 = s2_row_sum(s1[i][e >> 1][e & 1]), t2 = s2_row_sum(s2[i][e >> 1][e & 1]);
+                    const float t1 = lh_row_sum(s1[i][e >> 1][e & 1]), t2 = lh_row_sum(s2[i][e >> 1][e & 1]);
                     if (fr == 0) {
                         const int ch = wn * 64 + 16 * i + 4 * fg + e;
                         scr[ch] = t1;
@@ -340,7 +324,7 @@ __device__ __forceinline__ void s2_run(const S2Params& p, char* smem, int tile_f
 #pragma unroll
             for (int i = 0; i < 4; ++i) a0[i] = *(const bf16x8_t*)(wp + (aoff + i * 1024));
             const int slot = sj0 + sgn * ((sh & 1) + (sh >> 1) * Wo);
-            const int offt = slot * 64 + ((fg ^ s2_key(slot >> 2)) << 4) + hbuf * kS2Halo;
+            const int offt = slot * 64 + ((fg ^ lh_key(slot >> 2)) << 4) + hbuf * kS2Halo;
             const int zoff = kS2ZeroSlot * 64 + hbuf * kS2Halo;
             const unsigned need = (unsigned)sh | 4u;
 #pragma unroll
@@ -452,7 +436,7 @@ __device__ __forceinline__ void s2_loader(const S2Params& p, char* smem, int til
     // (weight buffers: rows x klen; rows = the destination's channels)
     const i32x4_t rs_wt0 = s2_rsrc(p.wt[0], (long)p.ld[0] * p.klen[0] * 2);
     const i32x4_t rs_wt1 = s2_rsrc(p.wt[1] ? p.wt[1] : p.wt[0], (long)(dg ? p.ld[0] : p.ld[1]) * p.klen[1] * 2);
-    const int swz = (((lane & 3) ^ s2_key(lane >> 4)) << 3);       // element offset of this lane's 16-byte chunk (source side)
+    const int swz = (((lane & 3) ^ lh_key(lane >> 4)) << 3);       // element offset of this lane's 16-byte chunk (source side)
     const unsigned wvoff0 = (unsigned)(((lane >> 2) * p.klen[0] + swz) * 2);
     const unsigned wvoff1 = (unsigned)(((lane >> 2) * p.klen[1] + swz) * 2);
     const int hplane = l & 1, hr0 = l >> 1;

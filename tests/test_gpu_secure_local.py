@@ -150,23 +150,24 @@ def test_transposed_weight_cache_follows_the_weights(cuda):
         finally:
             ctx.local_fused = keep
 
-    ctx = SecureContext(Dealer(cuda, seed=9), 10, 16)
+    ctx = SecureContext(Dealer(cuda, seed=9), 10, 3)      # (three fractional digits: products stay inside the ring)
     assert ctx._local
     xs, ws = shares_of(ctx, x), shares_of(ctx, w1)
     a = ctx.decode(ctx.reconstruct(ctx.conv2d(xs, ws, 1, 1)))
-    assert torch.allclose(a, plain_conv(ctx, xs, ws), atol=1e-3)
+    assert a.abs().max() > 0.05
+    assert torch.allclose(a, plain_conv(ctx, xs, ws), atol=5e-3)
     # in place: same tensors, new contents
     new = shares_of(ctx, w2)
     for j in (0, 1):
         ws[j].copy_(new[j])
     b = ctx.decode(ctx.reconstruct(ctx.conv2d(xs, ws, 1, 1)))
-    assert torch.allclose(b, plain_conv(ctx, xs, ws), atol=1e-3)
-    assert not torch.allclose(a, b, atol=1e-2)
+    assert torch.allclose(b, plain_conv(ctx, xs, ws), atol=5e-3)
+    assert not torch.allclose(a, b, atol=2e-2)
     # freed and re-allocated at (very likely) the same address
     ptrs = (ws[0].data_ptr(), ws[1].data_ptr())
     del ws, new
     ws2 = shares_of(ctx, w1)
     c = ctx.decode(ctx.reconstruct(ctx.conv2d(xs, ws2, 1, 1)))
-    assert torch.allclose(c, a, atol=1e-3), (ptrs, ws2[0].data_ptr())
+    assert torch.allclose(c, a, atol=5e-3), (ptrs, ws2[0].data_ptr())
     ctx.invalidate_weight_cache()
     assert not ctx._wt_cache
