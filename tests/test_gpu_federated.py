@@ -183,6 +183,11 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, lines          # ONE JSON line on stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["clients"] == 2 and d["fedavg_ms_per_sync"] is not None
+    # the N > 1 line proves which collective ran on how many ranks (RCCL on a multi-GPU node; gloo on this one-GPU box)
+    # and carries BASELINE.md B2 beside it
+    assert d["collective"]["ranks"] == 2 and d["collective"]["backend"] == "gloo" and d["collective"]["gpus_seen"]
+    assert d["cpu_baseline_b2"]["K"] == 2
+    assert d["roofline"]["kernel"] in d["roofline"]["kernels"] and "layers_us" in d["roofline"]
 
 
 def test_aggregation_kernels_match_reference_aggregation(cuda, golden_dir):
