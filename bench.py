@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md
 GFLOP_PER_IMAGE = 10.881                            # SURVEY.md §8d (fwd 3.627 + bwd 7.254)
-TRAFFIC_FILE = "r04_hbm_traffic.json"               # rocprofv3 PMC passes over this command, see tools/hbm_traffic.py
+TRAFFIC_FILE = "r05_hbm_traffic.json"               # rocprofv3 PMC passes over this command, see tools/hbm_traffic.py
 
 
 def parse():
@@ -312,6 +312,7 @@ def main():
              6: "conv3x3_lh4_kernel (fwd + dgrad)",
              13: "conv_wgrad_dma_kernel (per-tap, stride 2 / 1x1)", 14: "conv_wgrad_kernel (per-tap, stride 2 / 1x1)",
              16: "conv_wgrad_patch33_kernel + wgrad_patch32_reduce_kernel",
+             18: "conv_wgrad_patch33lw_kernel + wgrad_patch32_reduce_kernel",
              17: "conv_wgrad_tap_kernel + wgrad_tile_reduce_kernel (per-tap, stride 2 / 1x1)"}
     dtc = _lib.dtype_code(dtype)
 

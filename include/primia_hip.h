@@ -196,7 +196,8 @@ int primia_stem_conv_wgrad_ws(const void* x_padded, const void* dy, float* dw_ac
  *   6 conv3x3_lh4_kernel (the linear-halo layers that take 196-pixel tiles: loader-wave form, round 4)
  * weight gradient:
  *   13 conv_wgrad_dma_kernel   14 conv_wgrad_kernel   (11 / 12: the first two patch kernels, removed in round 4)
- *   16 conv_wgrad_patch33_kernel (3 + 3 fragments per k-step; the default)   17 conv_wgrad_tap_kernel
+ *   16 conv_wgrad_patch33_kernel (3 + 3 fragments per k-step, two alternating halves)   17 conv_wgrad_tap_kernel
+ *   18 conv_wgrad_patch33lw_kernel (the same scheme on four matrix + four loader waves: the default since round 5)
  *   15 the stem's (stem_conv_wgrad_kernel on the padded bf16 input, conv_wgrad_kernel<STEM> otherwise) */
 int primia_conv_kernel_id(const primia_conv_desc* d, int pass, int dtype);
 int primia_conv_wgrad_kernel_id(const primia_conv_desc* d, int dtype);

@@ -896,10 +896,10 @@ int wgrad_patch_clipped_sum(const WgradParams& w, const float* slabs, const floa
     return launch_status();
 }
 
-// 16 = conv_wgrad_patch33_kernel, 11 = conv_wgrad_patch32_kernel, 12 = conv_wgrad_patch_kernel (round 1), 0 = shape not served
+// 16 = conv_wgrad_patch33_kernel, 18 = conv_wgrad_patch33lw_kernel, 11 = conv_wgrad_patch32_kernel, 12 = conv_wgrad_patch_kernel (round 1), 0 = shape not served
 int wgrad_patch_kernel_id(const WgradParams& w) {
     if (!patch_geom(w).ok) return 0;
-    return 16;
+    return PRIMIA_OPT(wgp_lw) ? 18 : 16;       // 18 = conv_wgrad_patch33lw_kernel (loader waves; the batched gradient)
 }
 
 // DP-SGD norm pass on this kernel: 0 shape not served, 24 one block per (image, slab), 25 whole images per half-block

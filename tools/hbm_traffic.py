@@ -4,7 +4,7 @@ FETCH_SIZE is doubled (gfx950 reports half of wide coalesced reads, MI355X_MICRO
 are in KiB... rocprofv3 reports them in KB units of 1024 B."""
 import json, re, sqlite3, sys
 
-FAMS = ["conv3x3_lh2_kernel", "conv3x3_lh4_kernel", "conv_wgrad_patch33_kernel", "conv_wgrad_tap_kernel", "stem_bwd_fused_kernel", "bn_relu_pool_fwd_key_kernel", "conv_wgrad_patch32_kernel", "wgrad_patch32_reduce_kernel", "conv_wgrad_patch_kernel", "wgrad_patch_reduce_kernel", "conv3x3_lh_kernel", "stem_conv_wgrad_kernel", "stem_conv_fwd_kernel", "conv3x3_c64_kernel",
+FAMS = ["conv3x3_lh2_kernel", "conv3x3_lh4_kernel", "conv_s2lh_kernel", "conv_wgrad_patch33lw_kernel", "conv_igemm_pair_kernel", "conv_wgrad_patch33_kernel", "conv_wgrad_tap_kernel", "stem_bwd_fused_kernel", "bn_relu_pool_fwd_key_kernel", "conv_wgrad_patch32_kernel", "wgrad_patch32_reduce_kernel", "conv_wgrad_patch_kernel", "wgrad_patch_reduce_kernel", "conv3x3_lh_kernel", "stem_conv_wgrad_kernel", "stem_conv_fwd_kernel", "conv3x3_c64_kernel",
         "conv_igemm_kernel", "conv_wgrad_kernel", "conv_wgrad_dma_kernel", "colreduce2_kernel", "bn_bwd_apply_kernel",
         "bn_apply_kernel", "bn_relu_pool_fwd_kernel"]
 

@@ -4,7 +4,7 @@ util = MFMA-busy cycles summed over the chip / (4 SIMDs x 256 CUs x kernel cycle
 summed over the 8 XCDs."""
 import json, re, sqlite3, sys
 
-FAMS = ["conv3x3_lh2_kernel", "conv3x3_lh4_kernel", "conv_wgrad_patch33_kernel", "conv_wgrad_tap_kernel", "stem_bwd_fused_kernel", "bn_relu_pool_fwd_key_kernel", "conv_wgrad_patch32_kernel", "wgrad_patch32_reduce_kernel", "conv_wgrad_patch_kernel", "wgrad_patch_reduce_kernel", "conv3x3_lh_kernel", "stem_conv_wgrad_kernel", "stem_conv_fwd_kernel", "conv3x3_c64_kernel",
+FAMS = ["conv3x3_lh2_kernel", "conv3x3_lh4_kernel", "conv_s2lh_kernel", "conv_wgrad_patch33lw_kernel", "conv_igemm_pair_kernel", "conv_wgrad_patch33_kernel", "conv_wgrad_tap_kernel", "stem_bwd_fused_kernel", "bn_relu_pool_fwd_key_kernel", "conv_wgrad_patch32_kernel", "wgrad_patch32_reduce_kernel", "conv_wgrad_patch_kernel", "wgrad_patch_reduce_kernel", "conv3x3_lh_kernel", "stem_conv_wgrad_kernel", "stem_conv_fwd_kernel", "conv3x3_c64_kernel",
         "conv_igemm_kernel", "conv_wgrad_kernel", "conv_wgrad_dma_kernel"]
 cur = sqlite3.connect(sys.argv[1]).cursor()
 rows = cur.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id), sum(duration) "
