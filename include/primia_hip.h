@@ -448,6 +448,15 @@ int primia_bn_fwd_train_mask(const void* y, const void* residual, void* z, uint8
                              float* save_invstd, const float* sums, int slots, int64_t M, int C, float eps,
                              float momentum, void* workspace, int64_t workspace_bytes, int dtype,
                              primia_stream_t stream);
+/* primia_bn_fwd_train_from_sums (relu_mask = NULL) / primia_bn_fwd_train_mask (relu_mask given, relu implied) with the
+ * one-block finalize launch folded into the apply kernel (round 5): its first C / 4 blocks combine the partial sums — same
+ * slicing and order as the finalize kernel, bit-identical mean / invstd / running statistics — and publish them behind one flag
+ * word each; every block waits for the flags of its channels.  `flags`: C / 4 uint32 words that are ZERO when the call starts
+ * (the caller zeroes them; primia_amd.engine keeps every layer's words in one buffer and clears it once per step). */
+int primia_bn_fwd_train_apply_inline(const void* y, const void* residual, void* z, uint8_t* relu_mask, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float* save_mean,
+                                     float* save_invstd, const float* sums, int slots, int64_t M, int C, float eps,
+                                     float momentum, int relu, uint32_t* flags, int dtype, primia_stream_t stream);
 int primia_bn_bwd_mask(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
                        const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
                        float* dbeta, int64_t M, int C, void* workspace, int64_t workspace_bytes, int dtype,

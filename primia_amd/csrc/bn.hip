@@ -202,6 +202,80 @@ __global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_kernel(const floa
     }
 }
 
+// ---- the finalize launch folded into its consumer (round 5) -------------------------------------------------------
+// The one-block-per-16-channels bn_finalize_kernel between a statistics producer and the apply pass costs 5.6 us of pure
+// latency 37 times per step.  Here the apply kernel's FIRST C / 4 blocks do that work themselves — 4 channels x 64
+// partial-slices each, the same slicing and the same order of additions as bn_finalize_kernel: bit-identical mean / invstd /
+// running statistics — publish the constants with write-through (agent-scope) stores and raise one flag word per block;
+// every block of the kernel then waits for the flags of the channels it reads.  No fence anywhere: the partial sums were
+// written by an EARLIER kernel (visible at the boundary), the constants and flags travel as agent-scope atomics, the
+// order "constants before flag" is a vmcnt wait + a block barrier.  (Round 3's hand-offs sat on the PRODUCER side and
+// needed either a device-scope fence per block behind 400 MB of dirty L2 lines or one block pulling the whole table;
+// int64 atomics from the producers serialise at 23 M/s per address: profiles/r05_bn_finalize_atomics.txt.)
+// `flags`: C / 4 words, zero when the kernel starts (the engine zeroes every layer's words once per step).
+struct BnInline {
+    const float* partials;   // [nblk][2][C]; null: the caller already ran the finalize launch
+    int nblk;
+    long M;
+    float eps, momentum;
+    float* running_mean;
+    float* running_var;
+    float* save_mean;
+    float* save_invstd;
+    unsigned* flags;
+};
+
+__device__ __forceinline__ void bn_inline_finalize_stats(const BnInline& q, int C, float* lds_mean, float* lds_invstd) {
+    const int nfin = (C + 3) >> 2;
+    if ((int)blockIdx.x < nfin) {
+        __shared__ double sa[kFinSlices][5], sb[kFinSlices][5];
+        const int cl = threadIdx.x & 3, ks = threadIdx.x >> 2;      // 256 threads: 4 channels x 64 slices
+        const int c = blockIdx.x * 4 + cl;
+        double acc2[2] = {0.0, 0.0};
+        if (c < C) fin_gather<2>(q.partials, q.nblk, C, c, ks, acc2);
+        double a = acc2[0], b = acc2[1];
+        sa[ks][cl] = a;
+        sb[ks][cl] = b;
+        __syncthreads();
+        if (ks < 4) {
+            for (int k = ks + 4; k < kFinSlices; k += 4) {
+                a += sa[k][cl];
+                b += sb[k][cl];
+            }
+        }
+        __syncthreads();
+        if (ks < 4) {
+            sa[ks][cl] = a;
+            sb[ks][cl] = b;
+        }
+        __syncthreads();
+        if (ks == 0 && c < C) {
+            // bn_finalize_kernel's two shuffles: (g0 + g2) + (g1 + g3)
+            a = (sa[0][cl] + sa[2][cl]) + (sa[1][cl] + sa[3][cl]);
+            b = (sb[0][cl] + sb[2][cl]) + (sb[1][cl] + sb[3][cl]);
+            const double mean = a / (double)q.M;
+            double var = b / (double)q.M - mean * mean;
+            if (var < 0.0) var = 0.0;
+            __hip_atomic_store(q.save_mean + c, (float)mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(q.save_invstd + c, (float)(1.0 / sqrt(var + (double)q.eps)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (q.running_mean) {
+                const double unb = q.M > 1 ? var * (double)q.M / (double)(q.M - 1) : var;
+                q.running_mean[c] = (float)((1.0 - q.momentum) * (double)q.running_mean[c] + (double)q.momentum * mean);
+                q.running_var[c] = (float)((1.0 - q.momentum) * (double)q.running_var[c] + (double)q.momentum * unb);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the constants have reached the coherence point
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(q.flags + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        while (__hip_atomic_load(q.flags + (c >> 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+        lds_mean[c] = __hip_atomic_load(q.save_mean + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lds_invstd[c] = __hip_atomic_load(q.save_invstd + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ float round_to(float v) {
     return v;
@@ -220,14 +294,24 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd_or_var, float eps,
                                                        int eval_mode, long nchunks, int C, int relu,
-                                                       uint8_t* __restrict__ mask_out = nullptr) {
+                                                       uint8_t* __restrict__ mask_out = nullptr, BnInline inl = BnInline{}) {
     constexpr int CH = Chunk<T>::N;
     __shared__ float sm[3][512];
+    if (inl.partials) {
+        // the finalize folded into this kernel: mean -> sm[0], invstd -> sm[1] (then scaled by gamma below)
+        bn_inline_finalize_stats(inl, C, sm[0], sm[1]);
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += 256) {
+            sm[1][c] = sm[1][c] * gamma[c];
+            sm[2][c] = beta[c];
+        }
+    } else {
     for (int c = threadIdx.x; c < C; c += 256) {
         const float is = eval_mode ? 1.f / sqrtf(invstd_or_var[c] + eps) : invstd_or_var[c];
         sm[0][c] = mean[c];
         sm[1][c] = is * gamma[c];
         sm[2][c] = beta[c];
+    }
     }
     __syncthreads();
     const int cpr = C / CH;
@@ -1284,6 +1368,42 @@ int primia_bn_fwd_train_from_sums(const void* y, const void* residual, void* z, 
     } else {
         return PRIMIA_ERR_ARG;
     }
+    return launch_status();
+}
+
+// primia_bn_fwd_train_from_sums / primia_bn_fwd_train_mask with the finalize launch folded into the apply kernel
+// (bn_inline_finalize_stats): same outputs, bit for bit.
+int primia_bn_fwd_train_apply_inline(const void* y, const void* residual, void* z, uint8_t* relu_mask, const float* gamma,
+                                     const float* beta, float* running_mean, float* running_var, float* save_mean,
+                                     float* save_invstd, const float* sums, int slots, int64_t M, int C, float eps,
+                                     float momentum, int relu, uint32_t* flags, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && z && gamma && beta && save_mean && save_invstd && sums && slots >= 1 && flags);
+    PRIMIA_REQUIRE((running_mean == nullptr) == (running_var == nullptr));
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype));
+    hipStream_t st = (hipStream_t)stream;
+    const long nchunks = M * C / (dtype == PRIMIA_F32 ? 4 : 8);
+    const int grid = stream_blocks(nchunks);
+    if (relu_mask) relu = 1;
+    if (grid < (C + 3) / 4) {      // fewer blocks than finalize slices (tiny tensors): the two-launch form
+        bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(sums, slots, C, M, 0, eps, momentum, save_mean, save_invstd,
+                                                           running_mean, running_var);
+        if (dtype == PRIMIA_F32)
+            bn_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)y, (const float*)residual, (float*)z, gamma, beta, save_mean,
+                                                          save_invstd, eps, 0, nchunks, C, relu, relu_mask);
+        else
+            bn_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y, (const bf16*)residual, (bf16*)z, gamma, beta, save_mean,
+                                                         save_invstd, eps, 0, nchunks, C, relu, relu_mask);
+        return launch_status();
+    }
+    BnInline q{sums, slots, (long)M, eps, momentum, running_mean, running_var, save_mean, save_invstd, flags};
+    if (dtype == PRIMIA_F32)
+        bn_apply_kernel<float><<<grid, 256, 0, st>>>((const float*)y, (const float*)residual, (float*)z, gamma, beta, save_mean,
+                                                      save_invstd, eps, 0, nchunks, C, relu, relu_mask, q);
+    else if (dtype == PRIMIA_BF16)
+        bn_apply_kernel<bf16><<<grid, 256, 0, st>>>((const bf16*)y, (const bf16*)residual, (bf16*)z, gamma, beta, save_mean,
+                                                     save_invstd, eps, 0, nchunks, C, relu, relu_mask, q);
+    else
+        return PRIMIA_ERR_ARG;
     return launch_status();
 }
 

@@ -275,6 +275,9 @@ class ResNet18Engine:
                               for c in self.spec.convs}
             self.ones_n = torch.ones(N, dtype=torch.float32, device=dev)
         self.bn_ws = torch.zeros(self.bn_ws_bytes, dtype=torch.uint8, device=dev)  # holds a completion counter
+        # bn_inline: one flag word per 4 channels and BatchNorm layer (primia_bn_fwd_train_apply_inline), cleared once per step
+        self.bn_flags = torch.zeros(len(self.spec.convs) * 128, dtype=torch.int32, device=dev)
+        self._bn_flag_of = {bn_name(c.name): i * 128 for i, c in enumerate(self.spec.convs)}
         self.dp = None  # set by dp_backward: {"wgrads": [...]} defers the weight gradients
         self.feat = torch.empty(N, 512, dtype=torch.float32, device=dev)
         self.dfeat = torch.empty(N, 512, dtype=torch.float32, device=dev)
@@ -434,13 +437,24 @@ class ResNet18Engine:
             if b not in self.relu_masks:
                 self.relu_masks[b] = torch.empty(y.numel() * y.element_size() // 16, dtype=torch.uint8, device=y.device)
             have_sums = self.fuse_stats or conv_name in self.free_stats
+            if have_sums and self.bn_inline:
+                fl = self.bn_flags[self._bn_flag_of[b]:self._bn_flag_of[b] + 128]
+                call("primia_bn_fwd_train_apply_inline", y, residual, z, self.relu_masks[b], g, be, rm, rv, sm, si,
+                     self.convs[conv_name].sums, self.convs[conv_name].stat_slots, M, C, BN_EPS, BN_MOMENTUM, 1, fl, self.dt)
+                self.num_batches_tracked[b] += 1
+                return
             call("primia_bn_fwd_train_mask", y, residual, z, self.relu_masks[b], g, be, rm, rv, sm, si,
                  self.convs[conv_name].sums if have_sums else None, self.convs[conv_name].stat_slots if have_sums else 0,
                  M, C, BN_EPS, BN_MOMENTUM, self.bn_ws, self.bn_ws_bytes, self.dt)
             self.num_batches_tracked[b] += 1
         elif self.training:
             sm, si = self.save[b]
-            if self.fuse_stats or conv_name in self.free_stats:
+            if (self.fuse_stats or conv_name in self.free_stats) and self.bn_inline:
+                fl = self.bn_flags[self._bn_flag_of[b]:self._bn_flag_of[b] + 128]
+                call("primia_bn_fwd_train_apply_inline", y, residual, z, None, g, be, rm, rv, sm, si,
+                     self.convs[conv_name].sums, self.convs[conv_name].stat_slots, M, C, BN_EPS, BN_MOMENTUM, int(relu), fl,
+                     self.dt)
+            elif self.fuse_stats or conv_name in self.free_stats:
                 call("primia_bn_fwd_train_from_sums", y, residual, z, g, be, rm, rv, sm, si,
                      self.convs[conv_name].sums, self.convs[conv_name].stat_slots, M, C, BN_EPS, BN_MOMENTUM,
                      int(relu), self.dt)
@@ -455,6 +469,10 @@ class ResNet18Engine:
     # `self.prof` is a list, every conv launch is bracketed by events on the launch stream.
     prof = None
 
+    # the BatchNorm finalize launch folded into the apply kernel (primia_bn_fwd_train_apply_inline): bit-identical, and
+    # SLOWER — 4.745 -> 4.79 ms per step, same box: 2,048 apply blocks each fetching 2C constants through agent-scope loads
+    # contend at the coherence point the way the producers' atomics did (profiles/r05_bn_finalize_atomics.txt).  Off.
+    bn_inline = False
     # conv1 + downsample data gradients of a transition block in one pass (primia_conv2d_dgrad_pair)
     pair_dgrad = True
     # identity blocks: conv1's accumulating data gradient applies bn2's ReLU mask to the old values itself
@@ -527,6 +545,8 @@ class ResNet18Engine:
                                    "set options first, then construct the engine")
         if self.training and self.fuse_stats:
             self.stat_sums.zero_()
+        if self.training and self.bn_inline and self.norm == "batch":
+            self.bn_flags.zero_()
         self._stem_padded = self.x0p is not None and not (self.training and self.fuse_stats)
         # (the unpadded copy is read only where the halo kernels on the padded one do not serve the shape)
         self._x0_valid = not self._stem_padded or (self.norm == "group" and self._stem_ws_bytes <= 0)

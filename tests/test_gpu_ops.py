@@ -1209,3 +1209,53 @@ def test_parity_plane_kernel_every_mode(cuda, N, H, C, K):
         assert relerr(dx, dx3) < 4e-3
     finally:
         _lib.set_option("s2lh", 1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C,mask", [(802816 // 16, 64, False), (12544, 512, True), (3000, 128, True), (64, 256, False)])
+def test_bn_apply_with_inline_finalize_is_bit_identical(cuda, dtype, M, C, mask):
+    """primia_bn_fwd_train_apply_inline — the finalize launch folded into the apply kernel (its first C / 4 blocks combine the
+    partial sums and raise one flag each, every block waits for its channels' flags) — against the two-launch forms
+    primia_bn_fwd_train_from_sums / primia_bn_fwd_train_mask on the same partial sums: z, the ReLU mask, mean, invstd and the
+    running statistics bit for bit; (64, 256): fewer apply blocks than finalize slices, the entry point falls back."""
+    g = torch.Generator().manual_seed(M + C)
+    dt = _lib.dtype_code(dtype)
+    y = (torch.randn(M, C, generator=g) * 1.5 + 0.3).to(dtype).to(cuda)
+    res = torch.randn(M, C, generator=g).to(dtype).to(cuda)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    beta = torch.randn(C, generator=g).to(cuda)
+    slots = 37
+    # partial sums of a ragged 37-way row split, as a conv epilogue would leave them
+    sums = torch.zeros(slots, 2, C, device=cuda)
+    yf = y.float()
+    bounds = torch.linspace(0, M, slots + 1).long().tolist()
+    for i in range(slots):
+        blk = yf[bounds[i]:bounds[i + 1]]
+        sums[i, 0], sums[i, 1] = blk.sum(0), (blk * blk).sum(0)
+
+    def run(inline):
+        z = torch.empty_like(y)
+        mk = torch.zeros(M * C * y.element_size() // 16, dtype=torch.uint8, device=cuda) if mask else None
+        rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+        sm, si = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+        if inline:
+            flags = torch.zeros(128, dtype=torch.int32, device=cuda)
+            call("primia_bn_fwd_train_apply_inline", y, res, z, mk, gamma, beta, rm, rv, sm, si, sums, slots, M, C, 1e-5, 0.1, 1,
+                 flags, dt)
+        elif mask:
+            ws = torch.zeros(query("primia_bn_workspace_bytes", M, C), dtype=torch.uint8, device=cuda)
+            call("primia_bn_fwd_train_mask", y, res, z, mk, gamma, beta, rm, rv, sm, si, sums, slots, M, C, 1e-5, 0.1, ws,
+                 ws.numel(), dt)
+        else:
+            call("primia_bn_fwd_train_from_sums", y, res, z, gamma, beta, rm, rv, sm, si, sums, slots, M, C, 1e-5, 0.1, 1, dt)
+        torch.cuda.synchronize()
+        return z, mk, rm, rv, sm, si
+
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        if u is not None:
+            assert torch.equal(u, v)
+    # and it is BatchNorm: against torch on the stored values
+    ref = torch.nn.functional.batch_norm(yf.cpu(), None, None, gamma.cpu(), beta.cpu(), True, 0.1, 1e-5)
+    ref = torch.relu(ref + res.float().cpu())
+    assert relerr(a[0].float().cpu(), ref) < (2e-5 if dtype == torch.float32 else 1e-2)
