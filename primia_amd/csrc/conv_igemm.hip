@@ -41,6 +41,7 @@ struct IgemmParams {
     float* stat_sums;  // optional [slots][2][Nd]: per-channel sum and sum of squares of the stored output
     int stat_tiles;    // 1: stat_sums holds one deterministic partial per pixel tile (written); 0: kStatSlots atomic slots
     int s2_classes;    // data-gradient of a stride-2 conv: dst pixels are processed in 4 parity classes
+    int cls_inner;     // ... the class index is the fastest tile coordinate (option dgrad_cls_inner)
     int ntm_class;     // pixel tiles per class
     // Transition block (3x3/2 conv1 beside a 1x1/2 downsample, both reading the same x): the downsample's data
     // gradient lands on the even/even pixels only, where conv1's only tap is the centre one and reads the SAME dy
@@ -125,8 +126,16 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmParams& p, int bid, i
     // (1 + 2 + 2 + 4 = 9 tap-GEMMs on quarter-size pixel sets instead of 9 on the full set).
     int cls_ph = 0, cls_pw = 0;
     if (DGRAD && p.s2_classes) {
-        const int cls = tm / p.ntm_class;
-        tm -= cls * p.ntm_class;
+        // class-major (all tiles of class 0, then class 1, ...) or, option dgrad_cls_inner, position-major: the four classes of
+        // a pixel tile are dispatched back to back, so that the dy rows they share are fetched into the XCD's L2 once
+        int cls;
+        if (p.cls_inner) {
+            cls = tm & 3;
+            tm >>= 2;
+        } else {
+            cls = tm / p.ntm_class;
+            tm -= cls * p.ntm_class;
+        }
         cls_ph = cls >> 1;
         cls_pw = cls & 1;
         // a class without taps (1x1 / stride 2: three of the four) adds nothing: when accumulating, leave its
@@ -843,7 +852,7 @@ static bool use_c64(const ConvGeom& g) {
 static bool s2_pass_on(int pass, int dx_channels = 0) {
     const int o = PRIMIA_OPT(s2lh);
     if (pass == 0) return (o & 2) != 0;
-    return (o & 4) != 0 || ((o & 1) != 0 && dx_channels <= 128);
+    return (o & 4) != 0 || ((o & 1) != 0 && dx_channels <= PRIMIA_OPT(s2lh_dx_max));
 }
 static bool s2_conv1_shape(const ConvGeom& g) {
     return !g.stem && g.R == 3 && g.S == 3 && g.stride == 2 && g.pad == 1 && conv_s2lh_ok(g.N, g.H, g.W, g.C, g.K);
@@ -870,6 +879,7 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
     p.stat_sums = stat_sums;
     p.stat_tiles = (stat_sums && dtype == PRIMIA_BF16 && !g.stem) ? 1 : 0;
     p.s2_classes = 0;
+    p.cls_inner = 0;
     p.ntm_class = 0;
     p.src2 = nullptr; p.wt2 = nullptr;
     hipStream_t st = (hipStream_t)stream;
@@ -945,6 +955,7 @@ int primia_conv2d_fwd_stats_pair(const primia_conv_desc* d, const void* x, const
         p.stat_sums = sums;
         p.stat_tiles = sums ? 1 : 0;
         p.s2_classes = 0;
+        p.cls_inner = 0;
         p.ntm_class = 0;
         p.src2 = nullptr; p.wt2 = nullptr;
     };
@@ -1029,6 +1040,7 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
     p.stat_tiles = 0;
     const bool no_classes = !PRIMIA_OPT(dgrad_classes);
     p.s2_classes = (g.stride == 2 && g.H % 2 == 0 && g.W % 2 == 0 && !no_classes) ? 1 : 0;
+    p.cls_inner = PRIMIA_OPT(dgrad_cls_inner) ? 1 : 0;
     p.ntm_class = 0;
     if (p.src2 && !p.s2_classes) return PRIMIA_ERR_UNSUPPORTED;   // the pairing lives in the parity-class walk
     hipStream_t st = (hipStream_t)stream;
