@@ -110,6 +110,7 @@ def cpu_baseline(batch, size, budget_s=30.0):
     probe = {c: sample(c, max(8, batch // 4), 1, 0.0)[0] for c in counts}
     best = max(probe, key=probe.get)
     v, n = sample(best, batch, 5, budget_s)
+    torch.set_num_threads(1)      # (the encrypted-inference child that follows is host-launch-bound: leave it the cores)
     return {"value": v, "unit": "images/s", "cores": best, "kind": "port", "cpu_model": model, "physical_cores": phys,
             "logical_cpus": logical,
             "sample": f"{n} fp32 train steps of batch {batch} at {size}x{size} on {best} threads, the best of "
