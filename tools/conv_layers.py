@@ -24,6 +24,9 @@ def timeit(fn, reps=10):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps
 
+for kv in os.environ.get("CONV_LAYERS_OPTS", "").split():      # e.g. CONV_LAYERS_OPTS="wgp_shape=1 wgp_lw=0"
+    k, _, v = kv.partition("=")
+    _lib.set_option(k, int(v))
 only = sys.argv[3] if len(sys.argv) > 3 else None
 if only:
     layers = [l for l in layers if l[0] == only]
