@@ -846,7 +846,7 @@ static bool use_c64(const ConvGeom& g) {
 }
 
 // transition-block shapes served by conv_s2lh_kernel (bf16): 3x3 / 2 / pad 1 or 1x1 / 2 / pad 0 on an even-sized input
-// option s2lh (bits): 1 data gradient where it wins in the training step (dx with <= 128 channels: layer2.0 / layer3.0 —
+// option s2lh (bits): 1 data gradient where it wins in the training step (dx with <= s2lh_dx_max = 64 channels: layer2.0 —
 // in-step medians at batch 256: 100 / 74 / 69 us on the implicit GEMM, 84 / 70 / 72 on conv_s2lh_kernel), 2 forward too
 // (74 / 58 / 47 vs 85 / 85 / 95 us: off by default), 4 data gradient at every width.  Default 1.
 static bool s2_pass_on(int pass, int dx_channels = 0) {
