@@ -89,7 +89,8 @@ struct S2Params {
     int split;            // data gradient, 64-channel dx: the two 64-channel halves of a tile are two classes
     unsigned magicWo, magicHo;   // ceil(2^32 / Wo), ceil(2^32 / Ho)
     int ntm, ncol, gcost, ntiles;
-    int dbg;              // option s2lh_dbg (measurement only): 1 no halo DMA after the prologue, 2 no weight DMA, 4 no MFMA, 8 no stores
+    int dbg;              // option s2lh_dbg (measurement only): 1 no halo DMA after the prologue, 2 no weight DMA, 4 no MFMA, 8 no stores,
+                          // 16 no write-back at all, 32 no BatchNorm partials, 64 the forward halo addressed linearly (no gather)
     int nsteps[kS2MaxTypes];
     int prefix[kS2MaxCols + 1];   // cost at which column tile tc starts inside its row of tiles
     S2Col col[kS2MaxCols];
@@ -491,7 +492,7 @@ __device__ __forceinline__ void s2_loader(const S2Params& p, char* smem, int til
             const int qq = q0 + 16 * row;
             if (live && i < nslots && qq >= 0 && qq < p.M2) {
                 unsigned pix = (unsigned)qq;
-                if (!dg) pix = 2u * pix + 2u * __umulhi(pix, p.magicWo) * (unsigned)Wo + (unsigned)planeoff;
+                if (!dg && !(dbg & 64)) pix = 2u * pix + 2u * __umulhi(pix, p.magicWo) * (unsigned)Wo + (unsigned)planeoff;
                 voff = (pix * (unsigned)Cs + (unsigned)swz) * 2u;
             }
             s2_dma(voff, rs, (unsigned)soff, lds0 + buf * kS2Halo + hplane * kS2Plane + row * 1024);

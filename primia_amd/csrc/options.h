@@ -18,7 +18,7 @@ namespace primia {
     X(s2lh, 1)              /* transition blocks on conv_s2lh_kernel (parity planes, linear halo), bits: 1 dgrad of <= 128-channel dx, 2 forward, 4 dgrad at every width; 0: implicit GEMM */ \
     X(s2lh_dx_max, 64)      /* bit 1 of s2lh: widest dx (channels) whose data gradient takes conv_s2lh_kernel */                    \
     X(s2lh_blocks, 0)       /* its block count (0: one per CU) */                                                    \
-    X(s2lh_dbg, 0)          /* measurement only (wrong results): 1 no halo DMA after the prologue, 2 no weight DMA, 4 no MFMA, 8 no stores */ \
+    X(s2lh_dbg, 0)          /* measurement only (wrong results): 1 no halo DMA after the prologue, 2 no weight DMA, 4 no MFMA, 8 no stores, 16 no write-back, 32 no BN partials, 64 linear halo */ \
     X(dgrad_classes, 1)     /* stride-2 data gradient as four parity classes */                                        \
     X(dgrad_cls_inner, 1)   /* ... the four classes of a pixel tile dispatched back to back (they share dy rows in L2); 0: class-major */ \
     X(wgrad_kernel, 0)      /* 0: by shape; 1 register-staged per-tap; 2 LDS-DMA per-tap (skips patch / tap kernels) */ \

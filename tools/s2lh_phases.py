@@ -1,5 +1,6 @@
 """Phase switches of conv_s2lh_kernel (GPU box): us per paired forward / data-gradient launch with parts of the kernel off
-(option s2lh_dbg: 1 no halo DMA after the prologue, 2 no weight DMA, 4 no MFMA, 8 no stores).  python tools/s2lh_phases.py [N]"""
+(option s2lh_dbg: 1 no halo DMA after the prologue, 2 no weight DMA, 4 no MFMA, 8 no stores, 16 no write-back at all, 32 no
+BatchNorm partials, 64 forward halo addressed linearly instead of gathered).  python tools/s2lh_phases.py [N]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -31,7 +32,7 @@ for name, H, C, K in [("layer2.0", 56, 64, 128), ("layer3.0", 28, 128, 256), ("l
     y1 = torch.empty(N * d1.Ho * d1.Wo, K, dtype=dtype, device=dev); yd = torch.empty_like(y1)
     dx = torch.empty(N * H * H, C, dtype=dtype, device=dev)
     out = []
-    for dbg in (0, 3, 8, 16, 32, 15, 31):
+    for dbg in (0, 1, 2, 3, 4, 8, 32, 64, 15):
         _lib.set_option("s2lh_dbg", dbg)
         tf = timeit(lambda: call("primia_conv2d_fwd_stats_pair", d1, x, wf1, y1, q1, dd, wfd, yd, qd, dt))
         tg = timeit(lambda: call("primia_conv2d_dgrad_pair", d1, dy1, wg1, dd, dyd, wgd, dx, dt))
