@@ -412,7 +412,9 @@ def test_cli_per_rank_training_on_a_real_folder_and_resume(tmp_path):
     out = run(base + ["--train_federated", "--training_name", "resumed", "--resume_checkpoint", ckpt],
               {"PRIMIA_WEBSOCKETS_CONFIG": str(csv)})
     assert "Resume training from a given checkpoint." in out
-    assert "Train Epoch: {:d}".format(state["epoch"]) in out and "Train Epoch: 1 " not in out
+    # (which epoch the "final" checkpoint carries is the best validation epoch: data- and rounding-dependent, 1 or 2 here)
+    assert "Train Epoch: {:d}".format(state["epoch"]) in out
+    assert all("Train Epoch: {:d} ".format(e) not in out for e in range(1, state["epoch"]))
     # federated -> vanilla
     out = run(base[:4] + ["--data_dir", os.path.join(data, "worker1"), "--training_name", "vanilla",
                           "--resume_checkpoint", ckpt])
