@@ -82,7 +82,13 @@ class Dealer:
     def triple(self, op, xshape, yshape):
         if self.requests is not None:
             self.requests.append(("triple", (op, tuple(xshape), tuple(yshape)), {}))
-        a, b = self.rand64(*xshape), self.rand64(*yshape)
+        # the input shares are drawn directly (a = a0 + a1 with both shares uniform IS the sharing of a uniform a that
+        # build_triple produces by drawing a and one share, mpc/beaver.py:7-63): 9 launches per triple instead of 21
+        sa = [self.rand64(*xshape), self.rand64(*xshape)]
+        sb = [self.rand64(*yshape), self.rand64(*yshape)]
+        a, b = _empty_like(sa[0]), _empty_like(sb[0])
+        call("primia_ring_add", sa[0], sa[1], a, a.numel(), a.numel())
+        call("primia_ring_add", sb[0], sb[1], b, b.numel(), b.numel())
         if op == "mul":
             # element-wise with the smaller operand broadcast over the leading dims
             big, small = (a, b) if a.numel() >= b.numel() else (b, a)
@@ -92,7 +98,7 @@ class Dealer:
             M, K, N = xshape[-2], xshape[-1], yshape[-1]
             c = torch.empty(*xshape[:-1], N, dtype=I64, device=self.device)
             call("primia_ring_matmul", a, b, c, M, K, N, 0)
-        sa, sb, sc = self._split(a), self._split(b), self._split(c)
+        sc = self._split(c)
         t = [(sa[j], sb[j], sc[j]) for j in range(2)]
         if self.log is not None:
             self.log.append(("triple", op, [tuple(x.cpu().numpy() for x in t[j]) for j in range(2)]))
