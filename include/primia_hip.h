@@ -223,6 +223,18 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
 /* dx[N,H,W,C] = conv_transpose(dy[N,Ho,Wo,K], w).  If accumulate != 0, dx += (dx is read). */
 int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                         int accumulate, int dtype, primia_stream_t stream);
+/* The plain data gradient of a wide 3x3 / stride-1 layer that also forms, in its write-back, the per-channel sums the BatchNorm
+ * backward of the layer IN FRONT of it needs — dx of this call is that layer's dz: sum g and sum g * xhat, g = dz * [bn(y) > 0],
+ * xhat = (y - mean) * invstd — as deterministic per-tile partials [slots][2][C]; primia_bn_relu_bwd_from_sums consumes them, the
+ * separate reduction pass over (y, dz) is gone (torch's batch_norm backward reads both tensors twice; here once).
+ * primia_conv_dgrad_bnsums_slots: rows of the partial table, 0 where the shape is not served (bf16 linear-halo layers only). */
+int primia_conv_dgrad_bnsums_slots(const primia_conv_desc* d, int dtype);
+int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* bn_y,
+                               const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                               float* sums, int dtype, primia_stream_t stream);
+int primia_bn_relu_bwd_from_sums(const void* y, const void* dz, void* dy, const float* gamma, const float* beta,
+                                 const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                                 const float* sums, int slots, int64_t M, int C, int dtype, primia_stream_t stream);
 /* Identity block (torchlib/models.py:268-284, `out += identity; out = relu(out)`): dx = mask(dx) + dgrad(dy), where dx
  * holds the gradient of the block's OUTPUT and relu_mask the bits of that ReLU (primia_bn_fwd_train_mask).  The
  * masked residual gradient is then never written by the BatchNorm backward pass (g_out = NULL there): one tensor

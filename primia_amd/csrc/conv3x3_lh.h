@@ -6,12 +6,21 @@ namespace primia {
 
 // Linear-halo 3x3 / stride-1 kernel (conv3x3_lh2.hip): persistent 392- / 196-pixel tiles.  (Its first generation,
 // conv3x3_lh.hip — one tile per block, 74.8 us per launch against 55.6 — was superseded in round 3 and removed.)
+// the BatchNorm whose backward sums a plain data-gradient launch forms in its write-back (lh_tile_writeback below)
+struct LhBnBwd {
+    const bf16* y;          // [M][Nd], the BatchNorm's input (null: forward statistics)
+    const float* mean;
+    const float* invstd;
+    const float* gamma;
+    const float* beta;
+};
+
 // pixel tiles (= partial slots) if the shape is served by the kernel, else PRIMIA_ERR_UNSUPPORTED
 int conv3x3_lh2_tiles_m(int N, int H, int W, int Cs, int Nd);
 int conv3x3_lh_kernel_of(int N, int H, int W, int Cs, int Nd);   // 4 conv3x3_lh2_kernel | 6 conv3x3_lh4_kernel | 0 neither
 int conv3x3_lh2_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
                          int accumulate, hipStream_t st, float* stat_partials = nullptr,
-                         const uint8_t* acc_mask = nullptr);
+                         const uint8_t* acc_mask = nullptr, const LhBnBwd* bnb = nullptr);
 
 // Transition blocks on the parity planes (conv_s2lh.hip): 3x3 / stride 2 / pad 1 and 1x1 / stride 2 forward (one launch, either
 // filter may be null) and data gradient (the downsample's optional).  PRIMIA_ERR_UNSUPPORTED where conv_s2lh_ok() is false.
@@ -63,10 +72,17 @@ __device__ __forceinline__ void lh_swap16(uint32_t& a, uint32_t& b) {
 //      stat_combine adds the four groups in a fixed order after the next barrier.
 // ACC: dst += tile (old rows requested before the first store), `acc_mask` (or null): ReLU mask bits applied to the OLD values.
 // NT: non-temporal stores in the plain form.  SKIP: measurement builds only (accumulators kept alive, nothing written).
-template <int BM, int JW, int F0, bool ACC, bool NT, bool SKIP>
+// BNB (data-gradient launches, plain form): the tile just written is dz, the gradient w.r.t. z = relu(bn(y)) of the layer BEFORE
+// this convolution; with `bnb.y` set the partial sums are the two sums that layer's BatchNorm backward needs —
+//     sum g   and   sum g * xhat,   g = dz AS STORED * [bn(y) > 0],   xhat = (y - mean) * invstd
+// — instead of the forward statistics, in the same [4 groups][2][128] scratch and the same per-tile partial table: the separate
+// reduction pass over (y, dz) is dropped (primia_conv2d_dgrad_bnsums + primia_bn_relu_bwd_from_sums; round 5).  The mask is the
+// expression bn_bwd_apply_kernel recomputes (one fma on y - mean with scale = invstd * gamma), xhat is BwdFn's.
+
+template <int BM, int JW, int F0, bool ACC, bool NT, bool SKIP, bool BNB = false>
 __device__ __forceinline__ void lh_tile_writeback(f32x4 (&acc)[4][JW], bf16* dst, const uint8_t* acc_mask, const bool stats,
                                                   float* scr_base, const int M, const int Nd, const int m0, const int n0,
-                                                  const int wn, const int fr, const int fg) {
+                                                  const int wn, const int fr, const int fg, const LhBnBwd bnb = LhBnBwd{}) {
         if (SKIP) {
 #pragma unroll
             for (int j = 0; j < JW; ++j)
@@ -191,7 +207,48 @@ __device__ __forceinline__ void lh_tile_writeback(f32x4 (&acc)[4][JW], bf16* dst
                 if (okB) *(u32x4*)((char*)dst + (size_t)(eoB * 2u)) = stB;
             }
         }
-        if (!ACC && stats) {
+        if (BNB && !ACC && stats && bnb.y) {
+            float* scr = scr_base + (F0 == 0 ? 0 : (F0 - 1) / (BM == 392 ? 6 : 3)) * 256;   // pixel group 0..3
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int c0 = n0 + wn * 64 + 16 * i + 4 * fg;       // this lane's four channels of fragment row i
+                const f32x4 mu = *(const f32x4*)(bnb.mean + c0), is = *(const f32x4*)(bnb.invstd + c0);
+                const f32x4 ga = *(const f32x4*)(bnb.gamma + c0), be = *(const f32x4*)(bnb.beta + c0);
+                u32x2 yr[JW];
+#pragma unroll
+                for (int j = 0; j < JW; ++j) {
+                    const int pl = 16 * (F0 + j) + fr;
+                    const bool ok = pl < BM && m0 + pl < M;
+                    yr[j] = u32x2{0u, 0u};
+                    if (ok) yr[j] = *(const u32x2*)(bnb.y + ((size_t)(m0 + pl) * Nd + c0));
+                }
+                float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < JW; ++j) {
+                    const int pl = 16 * (F0 + j) + fr;
+                    const bool ok = pl < BM && m0 + pl < M;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float yv = __uint_as_float((e & 1) ? (yr[j][e >> 1] & 0xffff0000u) : (yr[j][e >> 1] << 16));
+                        const float dz = bf16_to_f32(f32_to_bf16(acc[i][j][e]));
+                        const float t = yv - mu[e];
+                        const float zz = __builtin_fmaf(t, is[e] * ga[e], be[e]);
+                        const float g = (ok && zz > 0.f) ? dz : 0.f;
+                        s1[e] += g;
+                        s2[e] += g * (t * is[e]);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float t1 = lh_row_sum(s1[e]), t2 = lh_row_sum(s2[e]);
+                    if (fr == 0) {
+                        const int ch = wn * 64 + 16 * i + 4 * fg + e;
+                        scr[ch] = t1;
+                        scr[128 + ch] = t2;
+                    }
+                }
+            }
+        } else if (!ACC && stats) {
             // BatchNorm partial sums of the values AS STORED, formed while the stores drain: the accumulators are still
             // intact, rounding them again gives the stored bits.  Fold the 16 pixels of a row (same fg), then one lane per
             // fg parks the pixel group's partial in LDS; the B half adds the four groups in a fixed order after the next

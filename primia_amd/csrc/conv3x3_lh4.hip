@@ -33,7 +33,9 @@ struct Lh4Params {
     int H, W, Cs, Nd;
     int M;             // N*H*W
     const uint8_t* acc_mask;   // accumulate form: ReLU mask bits applied to the OLD values (one byte per 8 channels)
-    float* stat_partials;      // forward only: BatchNorm partial sums [tiles_m][2][Nd] of the values AS STORED (or null)
+    float* stat_partials;      // BatchNorm partial sums [tiles_m][2][Nd] (or null): forward: of the values AS STORED; plain data gradient
+                               // with bnb.y: of the BatchNorm backward of the layer before (conv3x3_lh.h: LhBnBwd)
+    LhBnBwd bnb;
     int ntile_n, ntiles;
     unsigned magicW, magicH;   // ceil(2^16 / W), ceil(2^16 / H)
     unsigned long long* prof;  // LH4_PROF builds: [block][wave][4] cycles in load / matrix / barrier-wait / write-back
@@ -189,8 +191,8 @@ __device__ __forceinline__ void lh4_run(const Lh4Params& p, char* smem, int tile
     //      16.1 B/clk for whole lines, 13.8 for half lines, 7.9 for 8-byte stores): a 100-KB tile is ~6,500 cycles of
     //      store issue, which is why the stores go FIRST and the BatchNorm sums are formed while they drain.
     auto epilogue = [&]() {
-        lh_tile_writeback<BM, JW, F0, ACC, LH4_NT != 0, (LH4_DBG & 1) != 0>(acc, p.dst, p.acc_mask, p.stat_partials != nullptr,
-                                                                            (float*)(smem + kL4OffScr), p.M, Nd, m0, n0, wn, fr, fg);
+        lh_tile_writeback<BM, JW, F0, ACC, LH4_NT != 0, (LH4_DBG & 1) != 0, FLIP && !ACC>(acc, p.dst, p.acc_mask, p.stat_partials != nullptr,
+                                                                            (float*)(smem + kL4OffScr), p.M, Nd, m0, n0, wn, fr, fg, p.bnb);
     };
     // B half, one segment after both halves' write-back: thread -> (q, channel); groups added in the order 0,1,2,3
     auto stat_combine = [&](int tm_, int n0_) {
@@ -401,10 +403,10 @@ static int lh4_num_cus() {
 
 // Called by conv3x3_lh2_dispatch for the shapes that take 196-pixel tiles (option lh4); same contract as that function.
 int conv3x3_lh4_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int Cs, int Nd, int flip,
-                         int accumulate, hipStream_t st, float* stat_partials, const uint8_t* acc_mask) {
+                         int accumulate, hipStream_t st, float* stat_partials, const uint8_t* acc_mask, const LhBnBwd* bnb) {
     const int bm = 196;
     if (W > 28 || W < 2 || H < 2 || Cs % 64 || Nd % 128) return PRIMIA_ERR_UNSUPPORTED;
-    if (stat_partials && (flip || accumulate)) return PRIMIA_ERR_ARG;
+    if (stat_partials && (accumulate || (flip != 0) != (bnb != nullptr && bnb->y != nullptr))) return PRIMIA_ERR_ARG;
     if (accumulate && !flip) return PRIMIA_ERR_UNSUPPORTED;
     const long M = (long)N * H * W;
     if (M * (Cs > Nd ? Cs : Nd) >= (1L << 30)) return PRIMIA_ERR_UNSUPPORTED;     // byte offsets stay below 2^31
@@ -413,6 +415,7 @@ int conv3x3_lh4_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     p.H = H; p.W = W; p.Cs = Cs; p.Nd = Nd; p.M = (int)M;
     p.acc_mask = accumulate ? acc_mask : nullptr;
     p.stat_partials = stat_partials;
+    p.bnb = (bnb && bnb->y) ? *bnb : LhBnBwd{nullptr, nullptr, nullptr, nullptr, nullptr};
     p.ntile_n = Nd / 128;
     p.ntiles = (int)((M + bm - 1) / bm) * p.ntile_n;
     p.magicW = (65536u + W - 1) / W;

@@ -1069,6 +1069,30 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
     return PRIMIA_ERR_ARG;
 }
 
+// The plain data gradient of a wide 3x3 / stride-1 layer that ALSO forms, in its write-back, the two sums the BatchNorm backward
+// of the layer in front of it needs (dx = dz of that layer: sum g and sum g * xhat per channel, g = dz * [bn(y) > 0]) as per-tile
+// partials — the separate reduction pass over (y, dz) is dropped (conv3x3_lh.h: LhBnBwd; primia_bn_relu_bwd_from_sums consumes
+// them).  Slots of the partial table [slots][2][C], or 0 where the linear-halo kernels do not serve the shape.
+int primia_conv_dgrad_bnsums_slots(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
+    if (dtype != PRIMIA_BF16 || use_c64(g) || !lh_shape(g)) return 0;
+    const int t = conv3x3_lh2_tiles_m(g.N, g.H, g.W, g.K, g.C);
+    return t > 0 ? t : 0;
+}
+
+int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* bn_y,
+                               const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
+                               float* sums, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && dy && w_dgrad && dx && bn_y && bn_mean && bn_invstd && bn_gamma && bn_beta && sums);
+    if (primia_conv_dgrad_bnsums_slots(d, dtype) <= 0) return PRIMIA_ERR_UNSUPPORTED;
+    ConvGeom g;
+    PRIMIA_REQUIRE(g.init(*d));
+    const LhBnBwd bnb{(const bf16*)bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta};
+    return conv3x3_lh2_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C, 1, 0,
+                                (hipStream_t)stream, sums, nullptr, &bnb);
+}
+
 int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                         int accumulate, int dtype, primia_stream_t stream) {
     return conv2d_dgrad_impl(d, dy, w_dgrad, dx, accumulate, nullptr, nullptr, dtype, stream);

@@ -473,6 +473,9 @@ class ResNet18Engine:
     # SLOWER — 4.745 -> 4.79 ms per step, same box: 2,048 apply blocks each fetching 2C constants through agent-scope loads
     # contend at the coherence point the way the producers' atomics did (profiles/r05_bn_finalize_atomics.txt).  Off.
     bn_inline = False
+    # conv2's data gradient also forms the backward sums of bn1 (primia_conv2d_dgrad_bnsums + primia_bn_relu_bwd_from_sums):
+    # the reduction pass over (y1, da1) is dropped where the linear-halo kernels serve conv2
+    dgrad_bnsums = True
     # conv1 + downsample data gradients of a transition block in one pass (primia_conv2d_dgrad_pair)
     pair_dgrad = True
     # identity blocks: conv1's accumulating data gradient applies bn2's ReLU mask to the old values itself
@@ -787,6 +790,20 @@ class ResNet18Engine:
             torch.cuda.current_stream().wait_stream(self._wg_stream)
             self._wg_pending = False
 
+    def _dgrad_bnsums_slots(self, name):
+        """Rows of the partial table conv `name`'s data gradient writes for the BatchNorm in front of it (0: not served)."""
+        c = self.convs[name]
+        if getattr(c, "bnsums_slots", None) is None:
+            c.bnsums_slots = (query("primia_conv_dgrad_bnsums_slots", c.desc, self.dt)
+                              if (self.dtype == torch.bfloat16 and self.dp is None) else 0)
+        return c.bnsums_slots if self.dp is None else 0
+
+    def _bwd_sums(self, name, slots, channels):
+        c = self.convs[name]
+        if getattr(c, "bwd_sums", None) is None or c.bwd_sums.numel() != slots * 2 * channels:
+            c.bwd_sums = torch.empty(slots * 2 * channels, dtype=torch.float32, device=self.device)
+        return c.bwd_sums
+
     def _dgrad(self, name, dy, dx, accumulate, consumer=None, consumer_y=None):
         """Data gradient of conv `name` into dx (`consumer`, `consumer_y`: the conv whose BatchNorm backward reads dx
         next — kept in the signature for the callers; the kernels no longer form that BatchNorm's sums, see __init__)."""
@@ -841,14 +858,28 @@ class ResNet18Engine:
                 self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True,
                              keep_g=not (masked_acc or gn_ds_mask))
             # data gradient first: the weight gradient (a leaf) then runs beside the BatchNorm chain that follows
+            fused_sums = self._dgrad_bnsums_slots(blk.conv2.name) if (self.dgrad_bnsums and self.norm == "batch") else 0
             if self.wgrad_first:   # weight gradient, then data gradient, so that the BatchNorm backward pass which
                 # follows finds the data gradient it reads still in the Infinity Cache
                 self._wgrad(blk.conv2.name, t[p + ".a1"], t[p + ".dy2"])
-                self._dgrad(blk.conv2.name, t[p + ".dy2"], t[p + ".da1"], False, blk.conv1.name, t[p + ".y1"])
+            if fused_sums:
+                c2, b1 = self.convs[blk.conv2.name], bn_name(blk.conv1.name)
+                sm1, si1 = self.save[b1]
+                sums = self._bwd_sums(blk.conv2.name, fused_sums, blk.conv1.cout)
+                self._timed("dgrad", c2, lambda: call(
+                    "primia_conv2d_dgrad_bnsums", c2.desc, t[p + ".dy2"], c2.w_dgrad, t[p + ".da1"], t[p + ".y1"], sm1, si1,
+                    self.views[b1 + ".weight"], self.views[b1 + ".bias"], sums, self.dt))
             else:
                 self._dgrad(blk.conv2.name, t[p + ".dy2"], t[p + ".da1"], False, blk.conv1.name, t[p + ".y1"])
+            if not self.wgrad_first:
                 self._wgrad(blk.conv2.name, t[p + ".a1"], t[p + ".dy2"])
-            self._bn_bwd(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], t[p + ".da1"], t[p + ".dy1"], None, True)
+            if fused_sums:
+                y1 = t[p + ".y1"]
+                call("primia_bn_relu_bwd_from_sums", y1, t[p + ".da1"], t[p + ".dy1"], self.views[b1 + ".weight"],
+                     self.views[b1 + ".bias"], sm1, si1, self._gviews[b1 + ".weight"], self._gviews[b1 + ".bias"], sums,
+                     fused_sums, y1.shape[0], y1.shape[1], self.dt)
+            else:
+                self._bn_bwd(blk.conv1.name, t[p + ".y1"], t[p + ".a1"], t[p + ".da1"], t[p + ".dy1"], None, True)
             if blk.down is not None and self.pair_dgrad:
                 # both BatchNorm backward passes first, then ONE data-gradient pass for conv1 + downsample
                 if not bn_pair and gn_ds_mask:

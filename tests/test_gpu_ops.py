@@ -1259,3 +1259,52 @@ def test_bn_apply_with_inline_finalize_is_bit_identical(cuda, dtype, M, C, mask)
     ref = torch.nn.functional.batch_norm(yf.cpu(), None, None, gamma.cpu(), beta.cpu(), True, 0.1, 1e-5)
     ref = torch.relu(ref + res.float().cpu())
     assert relerr(a[0].float().cpu(), ref) < (2e-5 if dtype == torch.float32 else 1e-2)
+
+
+@pytest.mark.parametrize("N,H,C,K", [(4, 28, 128, 128), (7, 9, 256, 192), (6, 7, 512, 512), (3, 14, 256, 256)])
+def test_dgrad_with_bn_backward_sums_matches_the_separate_reduction(cuda, N, H, C, K):
+    """primia_conv2d_dgrad_bnsums — the data gradient of a 3x3 / stride-1 layer whose write-back also forms the two sums the
+    BatchNorm backward of the layer in front of it needs — + primia_bn_relu_bwd_from_sums, against the chain they replace
+    (primia_conv2d_dgrad, then primia_bn_relu_bwd with its own reduction pass): dx bit-identical, dgamma / dbeta / dy to fp32
+    summation order (the partials are per conv tile instead of per row slab), and against torch autograd of
+    relu(batch_norm(y)) -> conv (torchlib/models.py:268-284)."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(N + H + C)
+    desc = ConvDesc.make(N, H, H, C, K, 3, 3, 1, 1)
+    slots = query("primia_conv_dgrad_bnsums_slots", desc, dt)
+    assert slots > 0
+    M = N * H * H
+    y = (torch.randn(M, C, generator=g) * 1.3 + 0.2).to(dtype).to(cuda)           # the BatchNorm's input (conv1's output)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    beta = (torch.randn(C, generator=g) * 0.3).to(cuda)
+    mean = y.float().mean(0)
+    invstd = 1.0 / torch.sqrt(y.float().var(0, unbiased=False) + 1e-5)
+    w = rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype)
+    _, wd = prep_weights(desc, w, dtype, cuda, C)
+    dy2 = (torch.randn(M, K, generator=g) * 0.1).to(dtype).to(cuda)               # gradient w.r.t. conv2's output
+    # the chain
+    dz_a = torch.empty(M, C, dtype=dtype, device=cuda)
+    call("primia_conv2d_dgrad", desc, dy2, wd, dz_a, 0, dt)
+    ws = torch.zeros(query("primia_bn_workspace_bytes", M, C), dtype=torch.uint8, device=cuda)
+    dy_a, dg_a, db_a = torch.empty_like(dz_a), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_relu_bwd", y, dz_a, dy_a, gamma, beta, mean, invstd, dg_a, db_a, M, C, ws, ws.numel(), dt)
+    # fused
+    dz_b = torch.empty_like(dz_a)
+    sums = torch.full((slots, 2, C), 7.0, device=cuda)
+    call("primia_conv2d_dgrad_bnsums", desc, dy2, wd, dz_b, y, mean, invstd, gamma, beta, sums, dt)
+    dy_b, dg_b, db_b = torch.empty_like(dz_a), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_relu_bwd_from_sums", y, dz_b, dy_b, gamma, beta, mean, invstd, dg_b, db_b, sums, slots, M, C, dt)
+    assert torch.equal(dz_a, dz_b)
+    assert relerr(dg_b, dg_a) < 2e-5 and relerr(db_b, db_a) < 2e-5
+    assert relerr(dy_b.float(), dy_a.float()) < 2e-3        # (dy is rounded to bf16 after constants that differ in the last bits)
+    # run to run
+    sums2 = torch.empty_like(sums)
+    call("primia_conv2d_dgrad_bnsums", desc, dy2, wd, dz_b, y, mean, invstd, gamma, beta, sums2, dt)
+    assert torch.equal(sums, sums2)
+    # and it is the gradient: dgamma / dbeta from torch on the stored tensors
+    yy = y.float().cpu().requires_grad_(True)
+    gg, bb = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+    z = torch.relu(torch.nn.functional.batch_norm(yy, None, None, gg, bb, True, 0.1, 1e-5))
+    z.backward(dz_a.float().cpu())
+    assert relerr(dg_b.cpu(), gg.grad) < 1e-3 and relerr(db_b.cpu(), bb.grad) < 1e-3
