@@ -229,6 +229,18 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
  * separate reduction pass over (y, dz) is gone (torch's batch_norm backward reads both tensors twice; here once).
  * primia_conv_dgrad_bnsums_slots: rows of the partial table, 0 where the shape is not served (bf16 linear-halo layers only). */
 int primia_conv_dgrad_bnsums_slots(const primia_conv_desc* d, int dtype);
+/* ... and the paired data gradient of a transition block (primia_conv2d_dgrad_pair) forming the backward sums of the RESIDUAL
+ * BatchNorm in front of the block (dx = gradient w.r.t. z = relu(bn(y) + identity); relu_mask = the bytes its forward pass wrote:
+ * g = dx * mask bit): primia_bn_bwd_mask_from_sums = primia_bn_bwd_mask without its reduction pass.  64-channel dx (layer2.0). */
+int primia_conv_dgrad_pair_bnsums_slots(const primia_conv_desc* d, int dtype);
+int primia_conv2d_dgrad_pair_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad,
+                                    const primia_conv_desc* d_ds, const void* dy_ds, const void* w_dgrad_ds, void* dx,
+                                    const void* bn_y, const uint8_t* relu_mask, const float* bn_mean, const float* bn_invstd,
+                                    float* sums, int dtype, primia_stream_t stream);
+int primia_bn_bwd_mask_from_sums(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
+                                 const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
+                                 float* dbeta, const float* sums, int slots, int64_t M, int C, int dtype,
+                                 primia_stream_t stream);
 int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx, const void* bn_y,
                                const float* bn_mean, const float* bn_invstd, const float* bn_gamma, const float* bn_beta,
                                float* sums, int dtype, primia_stream_t stream);

@@ -1669,4 +1669,35 @@ int primia_bn_relu_bwd_from_sums(const void* y, const void* dz, void* dy, const 
     return launch_status();
 }
 
+// primia_bn_bwd_mask with the reduction pass already done by the producer of dz (primia_conv2d_dgrad_pair_bnsums).
+int primia_bn_bwd_mask_from_sums(const void* y, const uint8_t* relu_mask, const void* dz, void* dy, void* g_out,
+                                 const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
+                                 float* dbeta, const float* sums, int slots, int64_t M, int C, int dtype,
+                                 primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && relu_mask && dz && dy && gamma && save_mean && save_invstd && dgamma && dbeta && sums && slots >= 1);
+    PRIMIA_REQUIRE(bn_shape_ok(M, C, dtype));
+    hipStream_t st = (hipStream_t)stream;
+    bn_finalize_kernel<<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(sums, slots, C, M, 1, 0.f, 0.f, dbeta, dgamma, nullptr, nullptr);
+    const float inv_m = (float)(1.0 / (double)M);
+    if (dtype == PRIMIA_F32) {
+        const long nchunks = M * C / 4;
+        bn_bwd_apply_kernel<float><<<stream_blocks(nchunks), 256, 0, st>>>((const float*)y, nullptr, (const float*)dz, (float*)dy,
+                                                                           (float*)g_out, gamma, save_mean, save_invstd, dbeta,
+                                                                           dgamma, inv_m, nchunks, C, nullptr, relu_mask);
+    } else if (dtype == PRIMIA_BF16) {
+        const long nchunks = M * C / 8;
+        if (PRIMIA_OPT(bn_unroll) == 2 && nchunks >= 4L * 2048 * 256)
+            bn_bwd_apply_kernel<bf16, 2><<<stream_blocks(nchunks), 256, 0, st>>>((const bf16*)y, nullptr, (const bf16*)dz, (bf16*)dy,
+                                                                                 (bf16*)g_out, gamma, save_mean, save_invstd, dbeta,
+                                                                                 dgamma, inv_m, nchunks, C, nullptr, relu_mask);
+        else
+            bn_bwd_apply_kernel<bf16><<<stream_blocks(nchunks), 256, 0, st>>>((const bf16*)y, nullptr, (const bf16*)dz, (bf16*)dy,
+                                                                              (bf16*)g_out, gamma, save_mean, save_invstd, dbeta,
+                                                                              dgamma, inv_m, nchunks, C, nullptr, relu_mask);
+    } else {
+        return PRIMIA_ERR_ARG;
+    }
+    return launch_status();
+}
+
 }  // extern "C"

@@ -28,8 +28,17 @@ bool conv_s2lh_ok(int N, int H, int W, int C, int K);
 int conv_s2lh_tiles_m(int N, int H, int W);
 int conv_s2lh_fwd(const bf16* x, const bf16* w, bf16* y, float* stat, const bf16* w_ds, bf16* y_ds, float* stat_ds, int N,
                   int H, int W, int C, int K, hipStream_t st);
+// (bnb: the residual BatchNorm in front of the block whose backward sums the write-back forms — 64-channel dx only; `sums`
+// [conv_s2lh_tiles_m * 2][2][64] partials)
+struct S2BnBwd {
+    const bf16* y;
+    const uint8_t* mask;
+    const float* mean;
+    const float* invstd;
+    float* sums;
+};
 int conv_s2lh_dgrad(const bf16* dy, const bf16* wd, const bf16* dy_ds, const bf16* wd_ds, bf16* dx, int N, int H, int W, int C,
-                    int K, hipStream_t st);
+                    int K, hipStream_t st, const S2BnBwd* bnb = nullptr);
 
 
 // =====================================================================================================================

@@ -1113,6 +1113,32 @@ int primia_conv2d_dgrad_masked_acc(const primia_conv_desc* d, const void* dy, co
     return conv2d_dgrad_impl(d, dy, w_dgrad, dx, 1, nullptr, nullptr, dtype, stream, relu_mask);
 }
 
+// primia_conv2d_dgrad_pair whose write-back also forms the backward sums of the residual BatchNorm in FRONT of the transition
+// block (dx = the gradient w.r.t. that layer's output z = relu(bn(y) + identity); its forward pass left one ReLU-mask byte per 8
+// channels): sum g, sum g * xhat with g = dx AS STORED * mask bit, as partials [slots][2][C] — primia_bn_bwd_mask_from_sums
+// consumes them.  Served by conv_s2lh_kernel for 64-channel dx (layer2.0); slots = 0 elsewhere.
+int primia_conv_dgrad_pair_bnsums_slots(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
+    if (dtype != PRIMIA_BF16 || g.C != 64 || !s2_pass_on(1, g.C) || !s2_conv1_shape(g)) return 0;
+    return 2 * conv_s2lh_tiles_m(g.N, g.H, g.W);
+}
+
+int primia_conv2d_dgrad_pair_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad,
+                                    const primia_conv_desc* d_ds, const void* dy_ds, const void* w_dgrad_ds, void* dx,
+                                    const void* bn_y, const uint8_t* relu_mask, const float* bn_mean, const float* bn_invstd,
+                                    float* sums, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(d && d_ds && dy && w_dgrad && dy_ds && w_dgrad_ds && dx && bn_y && relu_mask && bn_mean && bn_invstd && sums);
+    PRIMIA_REQUIRE(d_ds->R == 1 && d_ds->S == 1 && d_ds->stride == 2 && d_ds->pad == 0);
+    PRIMIA_REQUIRE(d_ds->N == d->N && d_ds->H == d->H && d_ds->W == d->W && d_ds->C == d->C && d_ds->K == d->K);
+    if (primia_conv_dgrad_pair_bnsums_slots(d, dtype) <= 0) return PRIMIA_ERR_UNSUPPORTED;
+    ConvGeom g;
+    PRIMIA_REQUIRE(g.init(*d));
+    const S2BnBwd bnb{(const bf16*)bn_y, relu_mask, bn_mean, bn_invstd, sums};
+    return conv_s2lh_dgrad((const bf16*)dy, (const bf16*)w_dgrad, (const bf16*)dy_ds, (const bf16*)w_dgrad_ds, (bf16*)dx, g.N, g.H,
+                           g.W, g.C, g.K, (hipStream_t)stream, &bnb);
+}
+
 int primia_conv2d_dgrad_pair(const primia_conv_desc* d, const void* dy, const void* w_dgrad,
                              const primia_conv_desc* d_ds, const void* dy_ds, const void* w_dgrad_ds, void* dx,
                              int dtype, primia_stream_t stream) {

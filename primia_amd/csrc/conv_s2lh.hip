@@ -80,7 +80,16 @@ struct S2Params {
     const bf16* src[2];
     const bf16* wt[2];
     bf16* dst[2];
-    float* stat[2];       // forward: BatchNorm partial sums [ntm][2][ld] of the values AS STORED (both or neither)
+    float* stat[2];       // forward: BatchNorm partial sums [ntm][2][ld] of the values AS STORED (both or neither);
+                          // data gradient with bnb_y (64-channel dx only): stat[0] = [ntm * ncol][2][64] backward sums, see below
+    // data gradient, split tiles: dx of this launch is the gradient w.r.t. z = relu(bn(y) + identity) of the layer in FRONT of
+    // the block (a residual layer whose forward pass left one ReLU-mask byte per 8 channels): with bnb_y set the write-back
+    // also forms that BatchNorm's backward sums, sum g and sum g * xhat with g = dx AS STORED * mask bit — the reduction pass
+    // over (y, dx, mask) is dropped (primia_conv2d_dgrad_pair_bnsums + primia_bn_bwd_mask_from_sums)
+    const bf16* bnb_y;
+    const uint8_t* bnb_mask;
+    const float* bnb_mean;
+    const float* bnb_invstd;
     int klen[2];          // elements per weight row
     int ld[2];            // elements per destination row
     int Cs;               // channels of the source(s)
@@ -167,7 +176,7 @@ __device__ __forceinline__ void s2_run(const S2Params& p, char* smem, int tile_f
     const int fr = lane & 15, fg = lane >> 4;
     const int Wo = p.Wo, Ho = p.Ho;
     const bool dg = p.mode == 1;
-    const bool has_stat = !dg && p.stat[0] != nullptr;
+    const bool has_stat = p.stat[0] != nullptr && (!dg || p.bnb_y != nullptr);
     const int aoff = (wn * 64 + fr) * 64 + ((fg ^ lh_key(fr >> 2)) << 4);
     const int sgn = dg ? 1 : -1;
     int sj0 = 16 * F0 + fr + (dg ? 0 : Wo + 1);
@@ -218,6 +227,16 @@ __device__ __forceinline__ void s2_run(const S2Params& p, char* smem, int tile_f
         auto ror8 = [](uint32_t v) {
             return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, true);   // row_ror:8
         };
+        float bs1[8], bs2[8], bmu[8], bis[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) bs1[k] = bs2[k] = bmu[k] = bis[k] = 0.f;
+        if (dg && has_stat) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                bmu[k] = p.bnb_mean[col0 + k];
+                bis[k] = p.bnb_invstd[col0 + k];
+            }
+        }
         auto row_elem = [&](int pl) -> unsigned {     // element offset of the row tile pixel pl is stored to
             const unsigned q = (unsigned)(m0 + pl);
             if (!dg) return q * ld;
@@ -250,8 +269,61 @@ __device__ __forceinline__ void s2_run(const S2Params& p, char* smem, int tile_f
             }
             if (okA && !((S2_DBG ? p.dbg : 0) & 8)) __builtin_nontemporal_store(stA, (u32x4*)((char*)dst + (size_t)eoA * 2u));
             if (okB && !((S2_DBG ? p.dbg : 0) & 8)) __builtin_nontemporal_store(stB, (u32x4*)((char*)dst + (size_t)eoB * 2u));
+            if (dg && has_stat) {
+                // backward sums of the BatchNorm in front of the block, from the values just stored (store layout: this lane
+                // holds channels col0 .. col0 + 7 of pixels A and B)
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const bool ok = r ? okB : okA;
+                    const unsigned eo = r ? eoB : eoA;
+                    const u32x4 dzv = r ? stB : stA;
+                    u32x4 yv = {0u, 0u, 0u, 0u};
+                    unsigned mk = 0u;
+                    if (ok) {
+                        yv = *(const u32x4*)((const char*)p.bnb_y + (size_t)eo * 2u);
+                        mk = p.bnb_mask[eo >> 3];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float yk = __uint_as_float((k & 1) ? (yv[k >> 1] & 0xffff0000u) : (yv[k >> 1] << 16));
+                        const float dk = __uint_as_float((k & 1) ? (dzv[k >> 1] & 0xffff0000u) : (dzv[k >> 1] << 16));
+                        const float g = ((mk >> k) & 1u) ? dk : 0.f;
+                        bs1[k] += g;
+                        bs2[k] += g * ((yk - bmu[k]) * bis[k]);
+                    }
+                }
+            }
         }
-        if (has_stat && !((S2_DBG ? p.dbg : 0) & 32)) {
+        if (dg && has_stat) {
+            // fold the 8 lanes that share these channels (fr & 7), park per pixel group; wn = 1 (the second class of a split tile:
+            // the SAME 64 channels at other pixels) parks in the upper half of the 128-wide row, stat_combine adds the halves
+            float* scr = (float*)(smem + kS2OffScr) + (F0 / 3) * 256;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                float a = bs1[k], b = bs2[k];
+#pragma unroll
+                for (int st = 0; st < 3; ++st) {
+                    const int ctrl = st == 0 ? 0xB1 : (st == 1 ? 0x4E : 0x141);      // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+                    if (st == 0) {
+                        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0xB1, 0xf, 0xf, true));
+                        b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0xB1, 0xf, 0xf, true));
+                    } else if (st == 1) {
+                        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x4E, 0xf, 0xf, true));
+                        b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x4E, 0xf, 0xf, true));
+                    } else {
+                        a += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a), 0x141, 0xf, 0xf, true));
+                        b += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b), 0x141, 0xf, 0xf, true));
+                    }
+                    (void)ctrl;
+                }
+                if ((fr & 7) == 0) {
+                    const int ch = wn * 64 + (int)colin + k;
+                    scr[ch] = a;
+                    scr[128 + ch] = b;
+                }
+            }
+        }
+        if (!dg && has_stat && !((S2_DBG ? p.dbg : 0) & 32)) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
             f32x2 s1[4][2], s2[4][2];
 #pragma unroll
@@ -296,6 +368,15 @@ __device__ __forceinline__ void s2_run(const S2Params& p, char* smem, int tile_f
         float s = scr[q * 128 + ch];
 #pragma unroll
         for (int g = 1; g < 4; ++g) s += scr[g * 256 + q * 128 + ch];
+        if (dg) {        // split tile: both 64-channel halves are the same channels; one partial row per (tm, column tile)
+            if (ch < 64) {
+                float s2v = scr[q * 128 + 64 + ch];
+#pragma unroll
+                for (int g = 1; g < 4; ++g) s2v += scr[g * 256 + q * 128 + 64 + ch];
+                p.stat[0][((long)(tm_ * p.ncol + tc_) * 2 + q) * 64 + ch] = s + s2v;
+            }
+            return;
+        }
         (dsel ? p.stat[1] : p.stat[0])[((long)tm_ * 2 + q) * (dsel ? p.ld[1] : p.ld[0]) + n0 + ch] = s;
     };
 
@@ -573,7 +654,7 @@ __device__ __forceinline__ void s2_loader(const S2Params& p, char* smem, int til
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (!dg && p.stat[0] != nullptr) __builtin_amdgcn_s_barrier();
+    if (p.stat[0] != nullptr && (!dg || p.bnb_y != nullptr)) __builtin_amdgcn_s_barrier();
 }
 
 __global__ __launch_bounds__(768) void conv_s2lh_kernel(S2Params p) {
@@ -706,9 +787,10 @@ int conv_s2lh_fwd(const bf16* x, const bf16* w, bf16* y, float* stat, const bf16
 // Data gradient: dx [N, H, W, C] = conv3x3/2^T(dy, wd) (+ conv1x1/2^T(dy_ds, wd_ds) when dy_ds is given); dy, dy_ds
 // [N, H/2, W/2, K]; wd [C][3][3][K], wd_ds [C][K].  Every element of dx is written.
 int conv_s2lh_dgrad(const bf16* dy, const bf16* wd, const bf16* dy_ds, const bf16* wd_ds, bf16* dx, int N, int H, int W, int C,
-                    int K, hipStream_t st) {
+                    int K, hipStream_t st, const S2BnBwd* bnb) {
     if (!conv_s2lh_ok(N, H, W, C, K)) return PRIMIA_ERR_UNSUPPORTED;
     if ((dy_ds == nullptr) != (wd_ds == nullptr)) return PRIMIA_ERR_ARG;
+    if (bnb && bnb->y && (C != 64 || !bnb->mask || !bnb->mean || !bnb->invstd || !bnb->sums)) return PRIMIA_ERR_UNSUPPORTED;
     S2Params p = {};
     p.mode = 1;
     p.src[0] = dy; p.src[1] = dy_ds;
@@ -721,6 +803,10 @@ int conv_s2lh_dgrad(const bf16* dy, const bf16* wd, const bf16* dy_ds, const bf1
     p.M2 = N * p.Ho * p.Wo;
     p.split = C == 64 ? 1 : 0;
     p.ntm = conv_s2lh_tiles_m(N, H, W);
+    if (bnb && bnb->y) {
+        p.bnb_y = bnb->y; p.bnb_mask = bnb->mask; p.bnb_mean = bnb->mean; p.bnb_invstd = bnb->invstd;
+        p.stat[0] = bnb->sums;
+    }
     const int nsl = K / 64;
     const bool ds = dy_ds != nullptr;
     auto tap = [](int r, int s) { return r * 3 + s; };

@@ -476,6 +476,10 @@ class ResNet18Engine:
     # conv2's data gradient also forms the backward sums of bn1 (primia_conv2d_dgrad_bnsums + primia_bn_relu_bwd_from_sums):
     # the reduction pass over (y1, da1) is dropped where the linear-halo kernels serve conv2
     dgrad_bnsums = True
+    # ... and the transition block's paired data gradient the sums of the residual BatchNorm in front of the block
+    # (primia_conv2d_dgrad_pair_bnsums, conv_s2lh_kernel, 64-channel dx).  Measured neutral — 4.770 vs 4.770 ms, three rounds:
+    # the write-back's vector work (+35-40 us on that launch) costs what the 45-us reduction pass it removes cost — and off.
+    pair_bnsums = False
     # conv1 + downsample data gradients of a transition block in one pass (primia_conv2d_dgrad_pair)
     pair_dgrad = True
     # identity blocks: conv1's accumulating data gradient applies bn2's ReLU mask to the old values itself
@@ -682,7 +686,7 @@ class ResNet18Engine:
         self.backward()
         return self.loss
 
-    def _bn_bwd(self, conv_name, y, z, dz, dy, g_out, relu, keep_g=True):
+    def _bn_bwd(self, conv_name, y, z, dz, dy, g_out, relu, keep_g=True, from_sums=None):
         """keep_g=False (residual layers with a 1-bit mask only): the masked gradient g is NOT written back over dz —
         the accumulating data gradient that consumes it applies the mask itself (primia_conv2d_dgrad_masked_acc)."""
         b = bn_name(conv_name)
@@ -705,6 +709,11 @@ class ResNet18Engine:
             if self.dp is None:  # plain training: dgamma / dbeta = sum over samples
                 call("primia_weighted_colsum", psg, self.ones_n, self._gviews[b + ".weight"], self.N, C)
                 call("primia_weighted_colsum", psb, self.ones_n, self._gviews[b + ".bias"], self.N, C)
+            return
+        if relu and g_out is not None and b in self.relu_masks and from_sums is not None:
+            call("primia_bn_bwd_mask_from_sums", y, self.relu_masks[b], dz, dy, g_out if keep_g else None,
+                 self.views[b + ".weight"], sm, si, self._gviews[b + ".weight"], self._gviews[b + ".bias"], from_sums[0],
+                 from_sums[1], y.shape[0], y.shape[1], self.dt)
             return
         if relu and g_out is not None and b in self.relu_masks:
             call("primia_bn_bwd_mask", y, self.relu_masks[b], dz, dy, g_out if keep_g else None,
@@ -799,10 +808,10 @@ class ResNet18Engine:
         return c.bnsums_slots if self.dp is None else 0
 
     def _bwd_sums(self, name, slots, channels):
-        c = self.convs[name]
-        if getattr(c, "bwd_sums", None) is None or c.bwd_sums.numel() != slots * 2 * channels:
-            c.bwd_sums = torch.empty(slots * 2 * channels, dtype=torch.float32, device=self.device)
-        return c.bwd_sums
+        tab = self.__dict__.setdefault("_bwd_sum_bufs", {})
+        if name not in tab or tab[name].numel() != slots * 2 * channels:
+            tab[name] = torch.empty(slots * 2 * channels, dtype=torch.float32, device=self.device)
+        return tab[name]
 
     def _dgrad(self, name, dy, dx, accumulate, consumer=None, consumer_y=None):
         """Data gradient of conv `name` into dx (`consumer`, `consumer_y`: the conv whose BatchNorm backward reads dx
@@ -817,6 +826,7 @@ class ResNet18Engine:
         N, t = self.N, self.t
         nc = self.spec.num_classes
         self._grads_pending = False      # (accumulators of an earlier pass that nobody consumed are overwritten now)
+        self._dout_sums = {}             # block prefix -> (partials, slots): backward sums of its bn2 formed by the producer of dout
         if self.wgrad_ws is not None and self.dp is None:
             self.dw_acc[:self._acc_zero_n].zero_()      # the other layers' accumulators are overwritten
         else:
@@ -856,7 +866,7 @@ class ResNet18Engine:
                 gn_ds_mask = (blk.down is not None and self.norm == "group" and self.pair_dgrad and self.gn_ds_mask
                               and b2 in self.relu_masks)
                 self._bn_bwd(blk.conv2.name, t[p + ".y2"], t[p + ".out"], dout, t[p + ".dy2"], dout, True,
-                             keep_g=not (masked_acc or gn_ds_mask))
+                             keep_g=not (masked_acc or gn_ds_mask), from_sums=self._dout_sums.pop(p, None))
             # data gradient first: the weight gradient (a leaf) then runs beside the BatchNorm chain that follows
             fused_sums = self._dgrad_bnsums_slots(blk.conv2.name) if (self.dgrad_bnsums and self.norm == "batch") else 0
             if self.wgrad_first:   # weight gradient, then data gradient, so that the BatchNorm backward pass which
@@ -899,9 +909,26 @@ class ResNet18Engine:
                     self._join_wgrad_stream()
                 if self.wgrad_first:
                     self._wgrad_transition(blk, x_in, t[p + ".dy1"], t[p + ".dyd"])
-                self._timed("dgrad", c1, lambda: call("primia_conv2d_dgrad_pair", c1.desc, t[p + ".dy1"], c1.w_dgrad,
-                                                      cd.desc, t[p + ".dyd"], cd.w_dgrad, dx_in, self.dt),
-                            extra_macs=self._macs(cd))
+                prev = blocks[i - 1] if i > 0 else None
+                pb2 = bn_name(prev.conv2.name) if prev is not None else None
+                pslots = 0
+                if (self.pair_bnsums and self.norm == "batch" and self.dp is None and prev is not None and prev.down is None
+                        and pb2 in self.relu_masks and self.dtype == torch.bfloat16):
+                    if getattr(c1, "pair_bnsums_slots", None) is None:
+                        c1.pair_bnsums_slots = query("primia_conv_dgrad_pair_bnsums_slots", c1.desc, self.dt)
+                    pslots = c1.pair_bnsums_slots
+                if pslots > 0:
+                    # ... and the backward sums of the previous block's bn2 out of the same write-back
+                    sums = self._bwd_sums(blk.conv1.name + ".pair", pslots, prev.conv2.cout)
+                    smp, sip = self.save[pb2]
+                    self._timed("dgrad", c1, lambda: call(
+                        "primia_conv2d_dgrad_pair_bnsums", c1.desc, t[p + ".dy1"], c1.w_dgrad, cd.desc, t[p + ".dyd"], cd.w_dgrad,
+                        dx_in, t[prev.prefix + ".y2"], self.relu_masks[pb2], smp, sip, sums, self.dt), extra_macs=self._macs(cd))
+                    self._dout_sums[prev.prefix] = (sums, pslots)
+                else:
+                    self._timed("dgrad", c1, lambda: call("primia_conv2d_dgrad_pair", c1.desc, t[p + ".dy1"], c1.w_dgrad,
+                                                          cd.desc, t[p + ".dyd"], cd.w_dgrad, dx_in, self.dt),
+                                extra_macs=self._macs(cd))
                 if not self.wgrad_first:
                     self._wgrad_transition(blk, x_in, t[p + ".dy1"], t[p + ".dyd"])
             elif blk.down is not None:

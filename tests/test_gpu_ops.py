@@ -1308,3 +1308,47 @@ def test_dgrad_with_bn_backward_sums_matches_the_separate_reduction(cuda, N, H, 
     z = torch.relu(torch.nn.functional.batch_norm(yy, None, None, gg, bb, True, 0.1, 1e-5))
     z.backward(dz_a.float().cpu())
     assert relerr(dg_b.cpu(), gg.grad) < 1e-3 and relerr(db_b.cpu(), bb.grad) < 1e-3
+
+
+@pytest.mark.parametrize("N,H", [(3, 16), (2, 56), (5, 12)])
+def test_transition_dgrad_pair_with_bn_backward_sums(cuda, N, H):
+    """primia_conv2d_dgrad_pair_bnsums (conv_s2lh_kernel, 64-channel dx): the paired data gradient of a transition block whose
+    write-back also forms the backward sums of the residual BatchNorm in front of the block, + primia_bn_bwd_mask_from_sums,
+    against primia_conv2d_dgrad_pair followed by primia_bn_bwd_mask with its own reduction pass: dx bit-identical, dgamma / dbeta
+    to summation order, dy to one bf16 rounding; partials bit-repeatable."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    C, K = 64, 128
+    g = torch.Generator().manual_seed(N * H)
+    d1 = ConvDesc.make(N, H, H, C, K, 3, 3, 2, 1)
+    dd = ConvDesc.make(N, H, H, C, K, 1, 1, 2, 0)
+    slots = query("primia_conv_dgrad_pair_bnsums_slots", d1, dt)
+    assert slots == 2 * ((N * (H // 2) ** 2 + 191) // 192)
+    _, w1d = prep_weights(d1, rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype), dtype, cuda, C)
+    _, wdd = prep_weights(dd, rnd(torch.randn(K, C, 1, 1, generator=g) * 0.1, dtype), dtype, cuda, C)
+    M2, M = N * (H // 2) ** 2, N * H * H
+    dy1 = (torch.randn(M2, K, generator=g) * 0.1).to(dtype).to(cuda)
+    dyd = (torch.randn(M2, K, generator=g) * 0.1).to(dtype).to(cuda)
+    y = (torch.randn(M, C, generator=g) * 1.2 - 0.1).to(dtype).to(cuda)          # the residual BatchNorm's input
+    mask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.uint8).to(cuda)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    mean = y.float().mean(0)
+    invstd = 1.0 / torch.sqrt(y.float().var(0, unbiased=False) + 1e-5)
+    # the chain
+    dx_a = torch.empty(M, C, dtype=dtype, device=cuda)
+    call("primia_conv2d_dgrad_pair", d1, dy1, w1d, dd, dyd, wdd, dx_a, dt)
+    ws = torch.zeros(query("primia_bn_workspace_bytes", M, C), dtype=torch.uint8, device=cuda)
+    dy_a, dg_a, db_a = torch.empty_like(dx_a), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_bwd_mask", y, mask, dx_a, dy_a, None, gamma, mean, invstd, dg_a, db_a, M, C, ws, ws.numel(), dt)
+    # fused
+    dx_b = torch.empty_like(dx_a)
+    sums = torch.full((slots, 2, C), 5.0, device=cuda)
+    call("primia_conv2d_dgrad_pair_bnsums", d1, dy1, w1d, dd, dyd, wdd, dx_b, y, mask, mean, invstd, sums, dt)
+    dy_b, dg_b, db_b = torch.empty_like(dx_a), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_bwd_mask_from_sums", y, mask, dx_b, dy_b, None, gamma, mean, invstd, dg_b, db_b, sums, slots, M, C, dt)
+    assert torch.equal(dx_a, dx_b)
+    assert relerr(dg_b, dg_a) < 2e-5 and relerr(db_b, db_a) < 2e-5
+    assert relerr(dy_b.float(), dy_a.float()) < 2e-3
+    sums2 = torch.empty_like(sums)
+    call("primia_conv2d_dgrad_pair_bnsums", d1, dy1, w1d, dd, dyd, wdd, dx_b, y, mask, mean, invstd, sums2, dt)
+    assert torch.equal(sums, sums2)
