@@ -231,25 +231,33 @@ __device__ __forceinline__ void lh_tile_writeback(f32x4 (&acc)[4][JW], bf16* dst
                     yr[j] = u32x2{0u, 0u};
                     if (ok) yr[j] = *(const u32x2*)(bnb.y + ((size_t)(m0 + pl) * Nd + c0));
                 }
+                // ~9 vector instructions per element (the write-back is bound by their issue): the stored dz re-made two at a time
+                // (one v_cvt_pk_bf16_f32), sum g * (y - mean) accumulated and scaled by invstd ONCE per channel below
+                const f32x4 sc = {is[0] * ga[0], is[1] * ga[1], is[2] * ga[2], is[3] * ga[3]};
                 float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < JW; ++j) {
                     const int pl = 16 * (F0 + j) + fr;
                     const bool ok = pl < BM && m0 + pl < M;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float yv = __uint_as_float((e & 1) ? (yr[j][e >> 1] & 0xffff0000u) : (yr[j][e >> 1] << 16));
-                        const float dz = bf16_to_f32(f32_to_bf16(acc[i][j][e]));
-                        const float t = yv - mu[e];
-                        const float zz = __builtin_fmaf(t, is[e] * ga[e], be[e]);
-                        const float g = (ok && zz > 0.f) ? dz : 0.f;
-                        s1[e] += g;
-                        s2[e] += g * (t * is[e]);
+                    for (int h = 0; h < 2; ++h) {
+                        const uint32_t pk = (uint32_t)f32_to_bf16(acc[i][j][2 * h]) | ((uint32_t)f32_to_bf16(acc[i][j][2 * h + 1]) << 16);
+                        const float dzv[2] = {__uint_as_float(pk << 16), __uint_as_float(pk & 0xffff0000u)};
+                        const float yv[2] = {__uint_as_float(yr[j][h] << 16), __uint_as_float(yr[j][h] & 0xffff0000u)};
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int e = 2 * h + u;
+                            const float t = yv[u] - mu[e];
+                            const float zz = __builtin_fmaf(t, sc[e], be[e]);
+                            const float g = (ok && zz > 0.f) ? dzv[u] : 0.f;
+                            s1[e] += g;
+                            s2[e] = __builtin_fmaf(g, t, s2[e]);
+                        }
                     }
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float t1 = lh_row_sum(s1[e]), t2 = lh_row_sum(s2[e]);
+                    const float t1 = lh_row_sum(s1[e]), t2 = lh_row_sum(s2[e]) * is[e];
                     if (fr == 0) {
                         const int ch = wn * 64 + 16 * i + 4 * fg + e;
                         scr[ch] = t1;
