@@ -317,7 +317,7 @@ def main():
              17: "conv_wgrad_tap_kernel + wgrad_tile_reduce_kernel (per-tap, stride 2 / 1x1)"}
     dtc = _lib.dtype_code(dtype)
 
-    def family(kind, name):
+    def family(kind, name):     # (also used as family_of below)
         sp = eng.convs[name].spec
         if sp.k == 7:
             if kind != "wgrad":
@@ -330,9 +330,11 @@ def main():
         kid = query("primia_conv_kernel_id", d, 0 if kind == "fwd" else 1, dtc)
         return KNAME.get(kid, "kernel id %d" % kid) + ("<%s>" % kind if kid == 1 else "")
 
+    family_of = family
     per_launch = {}
     for kind, name, flops, e0, e1 in eng.prof:
         per_launch.setdefault((kind, name), (flops, []))[1].append(e0.elapsed_time(e1))
+    launch_table = per_launch
     agg, fam, layers = {}, {}, {}
     for (kind, name), (flops, samples) in per_launch.items():
         samples.sort()
@@ -382,6 +384,17 @@ def main():
         f_ms, f_fl, f_n = (sum(fam[k][q] for k in wide) for q in ("ms", "flops", "launches"))
         family = {"kernels": wide, "tflops": round(f_fl / (f_ms * 1e-3) / 1e12, 2), "frac": round(f_fl / (f_ms * 1e-3) / 1e12 / peak, 4),
                   "ms_per_step": round(f_ms / nprof, 4), "avg_launch_us": round(f_ms * 1e3 / f_n, 2), "launches_per_step": f_n // nprof}
+        # the family's FORWARD launches alone: since round 5 six of its data-gradient launches also form the BatchNorm backward
+        # sums of the layer in front of them in their write-back (engine.dgrad_bnsums: the reduction passes they replace are
+        # gone from the step), so the family's own time per FLOP went UP while the step's went down
+        fw = [(fl_, sm_) for (kind_, name_), (fl_, sm_) in launch_table.items() if kind_ == "fwd" and family_of(kind_, name_) in wide]
+        if fw:
+            w_ms = sum(sorted(sm_)[len(sm_) // 2] for _, sm_ in fw)
+            w_fl = sum(fl_ for fl_, _ in fw)
+            family["forward_only"] = {"launches_per_step": len(fw), "tflops": round(w_fl / (w_ms * 1e-3) / 1e12, 2),
+                                      "frac": round(w_fl / (w_ms * 1e-3) / 1e12 / peak, 4)}
+            family["note"] = ("data-gradient launches with engine.dgrad_bnsums include the BatchNorm backward sums of the layer "
+                              "in front of them")
     roof = {"bound": "mfma", "kernel": dom,
             "kernel_is": "the kernel (one C-ABI call; a weight-gradient call = the kernel + its ordered reduce) with the most time per step",
             "launch": "median over %d steps of the HIP-event bracket around one C-ABI call" % nprof,
