@@ -24,7 +24,7 @@
 // the DMA (lane-linear destination).
 #include <stdlib.h>
 
-#include "conv_common.h"
+#include "conv3x3_lh.h"
 
 namespace primia {
 
@@ -51,7 +51,14 @@ struct C64Params {
     int PH, PW, PPI;  // 8x8 patches per image column / row / image
     int total;        // patches overall
     int per_block;    // patches per block
-    float* stat_partials;  // if set: per-block BatchNorm partial sums [grid][2][64] of the values AS STORED
+    float* stat_partials;  // if set: per-block BatchNorm partial sums [grid][2][64] of the values AS STORED — or, with bnb_y (plain
+                           // data gradient, round 5), of the BatchNorm BACKWARD of the layer in front: sum g, sum g * xhat with
+                           // g = dz AS STORED * [bn(y) > 0] (the reduction pass over (y, dz) is dropped)
+    const bf16* bnb_y;     // [N*H*W][64]: that BatchNorm's input (null: forward statistics)
+    const float* bnb_mean;
+    const float* bnb_invstd;
+    const float* bnb_gamma;
+    const float* bnb_beta;
     int debug;        // timing experiments only (set by tools/micro builds, 0 in the library): 1 no stores, 2 no staging, 4 no MFMA loop
 };
 
@@ -60,8 +67,9 @@ struct C64Params {
 // block's MFMAs.  (The 8-wave form ran every wave of the CU through those phases in lockstep: with staging and stores
 // switched off it still took 60 us for 32 us worth of MFMAs.)  Wave (kh, ph): out-channels 32*kh..+31, patch rows
 // 4*ph..4*ph+3 = two 16-pixel MFMA column blocks q = 0, 1; one 8x8 patch per stage.
-template <bool ACC, int STAGES = 3>
+template <bool ACC, int STAGES = 3, bool BNB = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(C64Params p) {
+    static_assert(!(ACC && BNB), "the BatchNorm-sums form is a plain data gradient");
     constexpr int HALO = 13 * 1024;        // 100 slots used, 104 staged (13 DMA instructions)
     constexpr int STAGE = HALO;            // one patch per stage
     // output rows of one stage: 64 pixels x 64 channels, bf16 — or fp32 in the accumulate form, which adds the old
@@ -72,7 +80,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     char* const sout = smem + STAGES * STAGE;
     // accumulate form: the OLD rows of the patch being computed, fetched by LDS-DMA one iteration before the write-back
     // adds them (64 pixels x 128 B, row group g at g * 1 KiB, lane-linear: pixel lane / 8, 16-B chunk lane % 8)
-    char* const sold = sout + 2 * OUTB;
+    char* const sold = sout + 2 * OUTB;       // (BNB: the BatchNorm input rows of the patch being written back, then 1 KiB of constants)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 1, ph = wave & 1;
@@ -252,13 +260,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // requested after them, so the counted wait at the top of the next iteration covers them.
     c64_i32x4 rsrc_dst = rsrc;
     unsigned mk[2] = {0xffu, 0xffu};
-    if constexpr (ACC) {
-        const unsigned long long a = (unsigned long long)p.dst;
+    if constexpr (ACC || BNB) {
+        const unsigned long long a = (unsigned long long)(BNB ? (const void*)p.bnb_y : (const void*)p.dst);
         rsrc_dst[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
         rsrc_dst[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
     }
+    // BNB: per-channel constants of the BatchNorm in LDS behind the row buffer: [mean | invstd * gamma | beta | invstd][64]
+    float* const bnc = (float*)(sold + 8192);
+    if constexpr (BNB) {
+        if (tid < 64) {
+            const float is = p.bnb_invstd[tid];
+            bnc[tid] = p.bnb_mean[tid];
+            bnc[64 + tid] = is * p.bnb_gamma[tid];
+            bnc[128 + tid] = p.bnb_beta[tid];
+            bnc[192 + tid] = is;
+        }
+    }
     auto prefetch_old = [&]() {
-        if constexpr (ACC) {
+        if constexpr (ACC || BNB) {
             const int px = lane >> 3, c16 = lane & 7;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + g * 1024);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                              ::"v"(voff), "s"(rsrc_dst), "s"(m0v) : "memory");
-                if (p.acc_mask) {
+                if (ACC && p.acc_mask) {
                     const uint8_t* mp = p.acc_mask + (live ? (eoff >> 3) : 0u);
                     asm volatile("global_load_ubyte %0, %1, off" : "=v"(mk[q]) : "v"(mp) : "memory");
                 }
@@ -322,7 +341,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             if (live[q] && !((p.debug & 1) && v[0] != 12345u)) {
                 *(u32x4*)gp[q] = v;      // (non-temporal stores: measured, no change — 4.862 vs 4.861 ms per step)
-                if (p.stat_partials) {
+                if constexpr (BNB) {
+                    // the BatchNorm input row chunk of this pixel (requested an iteration ago, by THIS wave, into `sold`)
+                    const u32x4 yv = *(const u32x4*)(sold + (2 * wave + q) * 1024 + lane * 16);
+                    const f32x4 mu0 = *(const f32x4*)(bnc + c16 * 8), mu1 = *(const f32x4*)(bnc + c16 * 8 + 4);
+                    const f32x4 sc0 = *(const f32x4*)(bnc + 64 + c16 * 8), sc1 = *(const f32x4*)(bnc + 64 + c16 * 8 + 4);
+                    const f32x4 be0 = *(const f32x4*)(bnc + 128 + c16 * 8), be1 = *(const f32x4*)(bnc + 128 + c16 * 8 + 4);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const float yk = __uint_as_float((k & 1) ? (yv[k >> 1] & 0xffff0000u) : (yv[k >> 1] << 16));
+                        const float dk = __uint_as_float((k & 1) ? (v[k >> 1] & 0xffff0000u) : (v[k >> 1] << 16));
+                        const float t = yk - (k < 4 ? mu0[k & 3] : mu1[k & 3]);
+                        const float zz = __builtin_fmaf(t, k < 4 ? sc0[k & 3] : sc1[k & 3], k < 4 ? be0[k & 3] : be1[k & 3]);
+                        const float gk = zz > 0.f ? dk : 0.f;
+                        st1[k] += gk;
+                        st2[k] = __builtin_fmaf(gk, t, st2[k]);      // (x invstd once per channel at the end)
+                    }
+                } else if (p.stat_partials) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const float lo = __uint_as_float(v[k] << 16), hi = __uint_as_float(v[k] & 0xffff0000u);
@@ -342,6 +377,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // images, the accumulate form (its loads are waited for by the compiler, conservatively) and the last stage use
     // vmcnt(0).
     const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !(p.debug & 3);
+    if constexpr (BNB) __syncthreads();        // (the constants in LDS are visible to every wave)
     prefetch_old();            // patch 0's old rows: older than every halo piece, landed by the first counted wait
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
@@ -377,7 +413,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
-    if constexpr (ACC) {
+    if constexpr (ACC || BNB) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("" : "+v"(mk[0]), "+v"(mk[1])::"memory");
     }
@@ -407,6 +443,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float a = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) a += red[w * 128 + tid];
+            if (BNB && tid >= 64) a *= p.bnb_invstd[tid - 64];   // sum g * (y - mean) -> sum g * xhat
             p.stat_partials[(long)blockIdx.x * 128 + tid] = a;   // [block][2][64]
         }
     }
@@ -422,9 +459,14 @@ int conv3x3_c64_grid(int N, int H, int W) {
 }
 
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
-                         hipStream_t st, float* stat_partials, const uint8_t* acc_mask) {
+                         hipStream_t st, float* stat_partials, const uint8_t* acc_mask, const LhBnBwd* bnb) {
     if ((long)N * H * W * 64 >= (1L << 31)) return PRIMIA_ERR_UNSUPPORTED;
+    const bool with_bnb = bnb && bnb->y;
+    if (with_bnb && (!flip || accumulate || !stat_partials)) return PRIMIA_ERR_ARG;
     C64Params p;
+    p.bnb_y = with_bnb ? bnb->y : nullptr;
+    p.bnb_mean = with_bnb ? bnb->mean : nullptr; p.bnb_invstd = with_bnb ? bnb->invstd : nullptr;
+    p.bnb_gamma = with_bnb ? bnb->gamma : nullptr; p.bnb_beta = with_bnb ? bnb->beta : nullptr;
     p.src = src; p.wt = wt; p.dst = dst;
     p.N = N; p.H = H; p.W = W; p.flip = flip; p.accumulate = accumulate;
     p.stat_partials = stat_partials;
@@ -439,22 +481,27 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     const int grid = (int)((p.total + per - 1) / per);
     // plain form: a 4-deep ring (68 KiB per block, two blocks per CU) keeps 78 KB per CU in flight instead of 52
     const int deep = PRIMIA_OPT(c64_stages);
-    const int stages = (!accumulate && deep == 4) ? 4 : 3;
-    const size_t lds = (size_t)stages * 13 * 1024 + 2 * 64 * (accumulate ? 256 : 128) + (accumulate ? 8192 : 0);
+    const int stages = (!accumulate && !with_bnb && deep == 4) ? 4 : 3;
+    const size_t lds = (size_t)stages * 13 * 1024 + 2 * 64 * (accumulate ? 256 : 128) + (accumulate ? 8192 : 0) + (with_bnb ? 8192 + 1024 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         const int lds_plain = 3 * 13 * 1024 + 2 * 64 * 128, lds_acc = 3 * 13 * 1024 + 2 * 64 * 256 + 8192;
         const int lds_plain4 = 4 * 13 * 1024 + 2 * 64 * 128;
+        const int lds_bnb = 3 * 13 * 1024 + 2 * 64 * 128 + 8192 + 1024;
         if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_plain) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_plain4) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                lds_bnb) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 lds_acc) != hipSuccess)
             return PRIMIA_ERR_LAUNCH;
         attr_set = true;
     }
-    if (accumulate)
+    if (with_bnb)
+        conv3x3_c64_kernel<false, 3, true><<<grid, 256, lds, st>>>(p);
+    else if (accumulate)
         conv3x3_c64_kernel<true, 3><<<grid, 256, lds, st>>>(p);
     else if (stages == 4)
         conv3x3_c64_kernel<false, 4><<<grid, 256, lds, st>>>(p);

@@ -827,7 +827,8 @@ using namespace primia;
 
 namespace primia {
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
-                         hipStream_t st, float* stat_partials = nullptr, const uint8_t* acc_mask = nullptr);
+                         hipStream_t st, float* stat_partials = nullptr, const uint8_t* acc_mask = nullptr,
+                         const LhBnBwd* bnb = nullptr);
 int conv3x3_c64_grid(int N, int H, int W);
 }
 
@@ -1076,7 +1077,8 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
 int primia_conv_dgrad_bnsums_slots(const primia_conv_desc* d, int dtype) {
     ConvGeom g;
     if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
-    if (dtype != PRIMIA_BF16 || use_c64(g) || !lh_shape(g)) return 0;
+    if (dtype != PRIMIA_BF16 || !lh_shape(g)) return 0;
+    if (use_c64(g)) return (PRIMIA_OPT(c64_bnsums) && (long)g.N * g.H * g.W * 64 < (1L << 31)) ? conv3x3_c64_grid(g.N, g.H, g.W) : 0;
     const int t = conv3x3_lh2_tiles_m(g.N, g.H, g.W, g.K, g.C);
     return t > 0 ? t : 0;
 }
@@ -1089,6 +1091,9 @@ int primia_conv2d_dgrad_bnsums(const primia_conv_desc* d, const void* dy, const 
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
     const LhBnBwd bnb{(const bf16*)bn_y, bn_mean, bn_invstd, bn_gamma, bn_beta};
+    if (use_c64(g))
+        return conv3x3_c64_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, 1, 0, (hipStream_t)stream, sums,
+                                    nullptr, &bnb);
     return conv3x3_lh2_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C, 1, 0,
                                 (hipStream_t)stream, sums, nullptr, &bnb);
 }

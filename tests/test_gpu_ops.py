@@ -1261,7 +1261,8 @@ def test_bn_apply_with_inline_finalize_is_bit_identical(cuda, dtype, M, C, mask)
     assert relerr(a[0].float().cpu(), ref) < (2e-5 if dtype == torch.float32 else 1e-2)
 
 
-@pytest.mark.parametrize("N,H,C,K", [(4, 28, 128, 128), (7, 9, 256, 192), (6, 7, 512, 512), (3, 14, 256, 256)])
+@pytest.mark.parametrize("N,H,C,K", [(4, 28, 128, 128), (7, 9, 256, 192), (6, 7, 512, 512), (3, 14, 256, 256),
+                                     (2, 56, 64, 64), (3, 12, 64, 64), (5, 8, 64, 64)])     # (64 -> 64: conv3x3_c64_kernel)
 def test_dgrad_with_bn_backward_sums_matches_the_separate_reduction(cuda, N, H, C, K):
     """primia_conv2d_dgrad_bnsums — the data gradient of a 3x3 / stride-1 layer whose write-back also forms the two sums the
     BatchNorm backward of the layer in front of it needs — + primia_bn_relu_bwd_from_sums, against the chain they replace
