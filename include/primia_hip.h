@@ -227,7 +227,8 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
  * backward of the layer IN FRONT of it needs — dx of this call is that layer's dz: sum g and sum g * xhat, g = dz * [bn(y) > 0],
  * xhat = (y - mean) * invstd — as deterministic per-tile partials [slots][2][C]; primia_bn_relu_bwd_from_sums consumes them, the
  * separate reduction pass over (y, dz) is gone (torch's batch_norm backward reads both tensors twice; here once).
- * primia_conv_dgrad_bnsums_slots: rows of the partial table, 0 where the shape is not served (bf16 linear-halo layers only). */
+ * primia_conv_dgrad_bnsums_slots: rows of the partial table, 0 where the shape is not served (bf16; the wide 3x3 / stride-1 layers on
+ * conv3x3_lh2 / lh4 and the 64 -> 64 layers on conv3x3_c64). */
 int primia_conv_dgrad_bnsums_slots(const primia_conv_desc* d, int dtype);
 /* ... and the paired data gradient of a transition block (primia_conv2d_dgrad_pair) forming the backward sums of the RESIDUAL
  * BatchNorm in front of the block (dx = gradient w.r.t. z = relu(bn(y) + identity); relu_mask = the bytes its forward pass wrote:

@@ -30,9 +30,12 @@ def source_digest(files=None):
     h = hashlib.sha256()
     for q in paths:
         h.update(os.path.basename(q).encode() + b"\0")
-        # CODE only: `//` comments, trailing blanks and empty lines do not change what a profile measured (no string literal
-        # of these sources contains `//`)
-        for line in open(q, "r", encoding="utf-8", errors="replace"):
+        # CODE only: comments (`//` and `/* */`), trailing blanks and empty lines do not change what a profile measured (no
+        # string literal of these sources contains a comment marker)
+        import re
+
+        text = re.sub(r"/\*.*?\*/", "", open(q, "r", encoding="utf-8", errors="replace").read(), flags=re.S)
+        for line in text.splitlines():
             code = line.split("//", 1)[0].rstrip()
             if code:
                 h.update(code.encode() + b"\n")
