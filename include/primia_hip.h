@@ -232,7 +232,9 @@ int primia_conv2d_dgrad(const primia_conv_desc* d, const void* dy, const void* w
 int primia_conv_dgrad_bnsums_slots(const primia_conv_desc* d, int dtype);
 /* ... and the paired data gradient of a transition block (primia_conv2d_dgrad_pair) forming the backward sums of the RESIDUAL
  * BatchNorm in front of the block (dx = gradient w.r.t. z = relu(bn(y) + identity); relu_mask = the bytes its forward pass wrote:
- * g = dx * mask bit): primia_bn_bwd_mask_from_sums = primia_bn_bwd_mask without its reduction pass.  64-channel dx (layer2.0). */
+ * g = dx * mask bit): primia_bn_bwd_mask_from_sums = primia_bn_bwd_mask without its reduction pass.  bf16; conv_s2lh_kernel
+ * for 64-channel dx (layer2.0), conv_igemm_kernel's parity-class walk for the wider ones (layer3.0 / layer4.0): one partial per
+ * (128-pixel tile, class). */
 int primia_conv_dgrad_pair_bnsums_slots(const primia_conv_desc* d, int dtype);
 int primia_conv2d_dgrad_pair_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad,
                                     const primia_conv_desc* d_ds, const void* dy_ds, const void* w_dgrad_ds, void* dx,

@@ -52,6 +52,13 @@ struct IgemmParams {
     // m * d < 2^32; fastdiv = 0 falls back to the long division
     unsigned magicW, magicH;
     int fastdiv;
+    // data gradient (round 5): with bnb_y the write-back also forms the backward sums of the RESIDUAL BatchNorm whose output
+    // gradient this launch writes (dst = dz): sum g, sum g * xhat with g = dz AS STORED * mask bit, one partial per tile into
+    // stat_sums [tiles][2][Nd] (tile = pixel tile x parity class)
+    const void* bnb_y;
+    const unsigned char* bnb_mask;
+    const float* bnb_mean;
+    const float* bnb_invstd;
 };
 
 template <typename T>
@@ -125,9 +132,11 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmParams& p, int bid, i
     // mod 2, so the pixels are split into 4 parity classes, each a dense problem over its own taps
     // (1 + 2 + 2 + 4 = 9 tap-GEMMs on quarter-size pixel sets instead of 9 on the full set).
     int cls_ph = 0, cls_pw = 0;
+    int slot_id = tm;
     if (DGRAD && p.s2_classes) {
         // class-major (all tiles of class 0, then class 1, ...) or, option dgrad_cls_inner, position-major: the four classes of
         // a pixel tile are dispatched back to back, so that the dy rows they share are fetched into the XCD's L2 once
+        slot_id = tm;          // unique per (pixel tile, class): the row of a BatchNorm-sums partial table
         int cls;
         if (p.cls_inner) {
             cls = tm & 3;
@@ -539,7 +548,7 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmParams& p, int bid, i
     // then one atomic per channel per wave — this replaces a full read pass over the conv output.
     T* __restrict__ dst = (T*)p.dst;
     if constexpr (sizeof(T) == 2 && GLDS) {
-        if ((!p.stat_sums || p.stat_tiles) && !(p.Nd & 7) &&
+        if ((!p.stat_sums || p.stat_tiles || p.bnb_y) && !(p.Nd & 7) &&
             BM * (p.accumulate ? BN * 4 : BN * 2) <= STAGES * (BM + BN) * 128) {
             // bf16, no fused statistics: the tile leaves through LDS as whole 16-byte chunks of its pixel rows (the
             // 8-byte-per-lane stores below are store-issue bound: T21 of the programming guide; the stride-2 classes
@@ -570,6 +579,11 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmParams& p, int bid, i
             float st1[8], st2[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) st1[e] = st2[e] = 0.f;
+            float bmu[8];
+            if (DGRAD && p.bnb_y) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bmu[e] = p.bnb_mean[n0 + (tid % CPR) * 8 + e];
+            }
             for (int q = tid; q < BM * CPR; q += NT) {
                 const int row = q / CPR, c8 = q - row * CPR;
                 const long mc = m0 + row;
@@ -597,7 +611,19 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmParams& p, int bid, i
                     v = *(const u32x4*)(smem + row * rb + ((c8 ^ (row & (CPR - 1))) << 4));
                 }
                 *(u32x4*)gq = v;
-                if (p.stat_sums) {
+                if (DGRAD && p.bnb_y) {
+                    const long eo = m * p.Nd + n0 + c8 * 8;
+                    const u32x4 yv = *(const u32x4*)((const T*)p.bnb_y + eo);
+                    const unsigned mk = p.bnb_mask[eo >> 3];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float yk = __uint_as_float((e & 1) ? (yv[e >> 1] & 0xffff0000u) : (yv[e >> 1] << 16));
+                        const float dk = __uint_as_float((e & 1) ? (v[e >> 1] & 0xffff0000u) : (v[e >> 1] << 16));
+                        const float gk = ((mk >> e) & 1u) ? dk : 0.f;
+                        st1[e] += gk;
+                        st2[e] = __builtin_fmaf(gk, yk - bmu[e], st2[e]);     // (x invstd below)
+                    }
+                } else if (p.stat_sums) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float lo = __uint_as_float(v[e] << 16), hi = __uint_as_float(v[e] & 0xffff0000u);
@@ -622,7 +648,12 @@ __device__ __forceinline__ void conv_igemm_body(const IgemmParams& p, int bid, i
                     const int qq = c / BN, cl = c - qq * BN;
                     float a = 0.f;
                     for (int g = 0; g < NT / CPR; ++g) a += red[(g * 2 + qq) * BN + cl];
-                    p.stat_sums[((long)tm * 2 + qq) * p.Nd + n0 + cl] = a;
+                    if (DGRAD && p.bnb_y) {
+                        if (qq) a *= p.bnb_invstd[n0 + cl];
+                        p.stat_sums[((long)slot_id * 2 + qq) * p.Nd + n0 + cl] = a;
+                    } else {
+                        p.stat_sums[((long)tm * 2 + qq) * p.Nd + n0 + cl] = a;
+                    }
                 }
             }
             return;
@@ -800,7 +831,7 @@ static int dispatch_igemm(const IgemmParams& p, bool stem, hipStream_t st) {
     }
     if ((long)p.Nb * p.Hs * p.Ws * p.Cs >= (1L << 31)) return PRIMIA_ERR_ARG;  // 32-bit element offsets
     const char cfg_env = (char)('a' + PRIMIA_OPT(conv_cfg));      // option conv_cfg 0..5 = a..f
-    const char cfg = p.stat_tiles ? 'e' : cfg_env;   // per-tile statistics assume the 128-pixel tile
+    const char cfg = (p.stat_tiles || p.bnb_y) ? 'e' : cfg_env;   // per-tile statistics assume the 128-pixel tile
     const bool wide = p.Nd % 128 == 0;
 #define PRIMIA_IGEMM_CASE(L, BM, WM_, WN_, ST)                                                   \
     case L:                                                                                      \
@@ -880,6 +911,7 @@ static int conv2d_fwd_impl(const primia_conv_desc* d, const void* x, const void*
     p.stat_sums = stat_sums;
     p.stat_tiles = (stat_sums && dtype == PRIMIA_BF16 && !g.stem) ? 1 : 0;
     p.s2_classes = 0;
+    p.bnb_y = nullptr; p.bnb_mask = nullptr; p.bnb_mean = nullptr; p.bnb_invstd = nullptr;
     p.cls_inner = 0;
     p.ntm_class = 0;
     p.src2 = nullptr; p.wt2 = nullptr;
@@ -956,6 +988,7 @@ int primia_conv2d_fwd_stats_pair(const primia_conv_desc* d, const void* x, const
         p.stat_sums = sums;
         p.stat_tiles = sums ? 1 : 0;
         p.s2_classes = 0;
+        p.bnb_y = nullptr; p.bnb_mask = nullptr; p.bnb_mean = nullptr; p.bnb_invstd = nullptr;
         p.cls_inner = 0;
         p.ntm_class = 0;
         p.src2 = nullptr; p.wt2 = nullptr;
@@ -1023,7 +1056,7 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
 
 static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                              int accumulate, const void* dy2, const void* w_dgrad2, int dtype, primia_stream_t stream,
-                             const uint8_t* acc_mask = nullptr) {
+                             const uint8_t* acc_mask = nullptr, const S2BnBwd* pair_bnb = nullptr) {
     PRIMIA_REQUIRE(d && dy && w_dgrad && dx);
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
@@ -1039,6 +1072,7 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
     p.accumulate = accumulate;
     p.stat_sums = nullptr;
     p.stat_tiles = 0;
+    p.bnb_y = nullptr; p.bnb_mask = nullptr; p.bnb_mean = nullptr; p.bnb_invstd = nullptr;
     const bool no_classes = !PRIMIA_OPT(dgrad_classes);
     p.s2_classes = (g.stride == 2 && g.H % 2 == 0 && g.W % 2 == 0 && !no_classes) ? 1 : 0;
     p.cls_inner = PRIMIA_OPT(dgrad_cls_inner) ? 1 : 0;
@@ -1064,6 +1098,10 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
             if (rc3 != PRIMIA_ERR_UNSUPPORTED) return rc3;
         }
         if (acc_mask) return PRIMIA_ERR_UNSUPPORTED;   // only the 64->64 and linear-halo write-backs mask the old values
+        if (pair_bnb) {
+            p.bnb_y = pair_bnb->y; p.bnb_mask = pair_bnb->mask; p.bnb_mean = pair_bnb->mean; p.bnb_invstd = pair_bnb->invstd;
+            p.stat_sums = pair_bnb->sums;
+        }
         p.nsteps = p.klen / 64;
         return dispatch_igemm<bf16, true>(p, false, st);
     }
@@ -1121,12 +1159,16 @@ int primia_conv2d_dgrad_masked_acc(const primia_conv_desc* d, const void* dy, co
 // primia_conv2d_dgrad_pair whose write-back also forms the backward sums of the residual BatchNorm in FRONT of the transition
 // block (dx = the gradient w.r.t. that layer's output z = relu(bn(y) + identity); its forward pass left one ReLU-mask byte per 8
 // channels): sum g, sum g * xhat with g = dx AS STORED * mask bit, as partials [slots][2][C] — primia_bn_bwd_mask_from_sums
-// consumes them.  Served by conv_s2lh_kernel for 64-channel dx (layer2.0); slots = 0 elsewhere.
+// consumes them.  Served by conv_s2lh_kernel for 64-channel dx (layer2.0) and by conv_igemm_kernel's LDS write-back loop (which
+// already walks whole 16-byte chunks of the scattered pixel rows) for the wider ones; slots = 0 elsewhere.
 int primia_conv_dgrad_pair_bnsums_slots(const primia_conv_desc* d, int dtype) {
     ConvGeom g;
     if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
-    if (dtype != PRIMIA_BF16 || g.C != 64 || !s2_pass_on(1, g.C) || !s2_conv1_shape(g)) return 0;
-    return 2 * conv_s2lh_tiles_m(g.N, g.H, g.W);
+    if (dtype != PRIMIA_BF16 || !s2_conv1_shape(g)) return 0;
+    if (s2_pass_on(1, g.C)) return g.C == 64 ? 2 * conv_s2lh_tiles_m(g.N, g.H, g.W) : 0;
+    // conv_igemm_kernel's parity-class walk: one partial per (128-pixel tile, class)
+    if (!PRIMIA_OPT(dgrad_classes) || g.C % 8) return 0;
+    return 4 * ceil_div((long)g.N * (g.H / 2) * (g.W / 2), 128);
 }
 
 int primia_conv2d_dgrad_pair_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad,
@@ -1140,6 +1182,7 @@ int primia_conv2d_dgrad_pair_bnsums(const primia_conv_desc* d, const void* dy, c
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
     const S2BnBwd bnb{(const bf16*)bn_y, relu_mask, bn_mean, bn_invstd, sums};
+    if (!s2_pass_on(1, g.C)) return conv2d_dgrad_impl(d, dy, w_dgrad, dx, 0, dy_ds, w_dgrad_ds, dtype, stream, nullptr, &bnb);
     return conv_s2lh_dgrad((const bf16*)dy, (const bf16*)w_dgrad, (const bf16*)dy_ds, (const bf16*)w_dgrad_ds, (bf16*)dx, g.N, g.H,
                            g.W, g.C, g.K, (hipStream_t)stream, &bnb);
 }

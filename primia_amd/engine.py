@@ -477,9 +477,10 @@ class ResNet18Engine:
     # the reduction pass over (y1, da1) is dropped where the linear-halo kernels serve conv2
     dgrad_bnsums = True
     # ... and the transition block's paired data gradient the sums of the residual BatchNorm in front of the block
-    # (primia_conv2d_dgrad_pair_bnsums, conv_s2lh_kernel, 64-channel dx).  Measured neutral — 4.770 vs 4.770 ms, three rounds:
-    # the write-back's vector work (+35-40 us on that launch) costs what the 45-us reduction pass it removes cost — and off.
-    pair_bnsums = False
+    # (primia_conv2d_dgrad_pair_bnsums: conv_s2lh_kernel for 64-channel dx, conv_igemm_kernel's parity-class walk for layer3.0 /
+    # layer4.0).  The 64-channel one alone measured neutral (4.770 vs 4.770 ms); with the two igemm launches, whose LDS
+    # write-back loop already walks 16-byte chunks of whole pixel rows, 4.882 -> 4.862 ms (8 alternating rounds, one box).
+    pair_bnsums = True
     # conv1 + downsample data gradients of a transition block in one pass (primia_conv2d_dgrad_pair)
     pair_dgrad = True
     # identity blocks: conv1's accumulating data gradient applies bn2's ReLU mask to the old values itself

@@ -1311,20 +1311,21 @@ def test_dgrad_with_bn_backward_sums_matches_the_separate_reduction(cuda, N, H, 
     assert relerr(dg_b.cpu(), gg.grad) < 1e-3 and relerr(db_b.cpu(), bb.grad) < 1e-3
 
 
-@pytest.mark.parametrize("N,H", [(3, 16), (2, 56), (5, 12)])
-def test_transition_dgrad_pair_with_bn_backward_sums(cuda, N, H):
-    """primia_conv2d_dgrad_pair_bnsums (conv_s2lh_kernel, 64-channel dx): the paired data gradient of a transition block whose
+@pytest.mark.parametrize("N,H,C", [(3, 16, 64), (2, 56, 64), (5, 12, 64), (3, 28, 128), (5, 14, 256), (2, 10, 128)])
+def test_transition_dgrad_pair_with_bn_backward_sums(cuda, N, H, C):
+    """primia_conv2d_dgrad_pair_bnsums (conv_s2lh_kernel for 64-channel dx, conv_igemm_kernel's parity-class walk for the wider
+    ones): the paired data gradient of a transition block whose
     write-back also forms the backward sums of the residual BatchNorm in front of the block, + primia_bn_bwd_mask_from_sums,
     against primia_conv2d_dgrad_pair followed by primia_bn_bwd_mask with its own reduction pass: dx bit-identical, dgamma / dbeta
     to summation order, dy to one bf16 rounding; partials bit-repeatable."""
     dtype = torch.bfloat16
     dt = _lib.dtype_code(dtype)
-    C, K = 64, 128
+    K = 2 * C
     g = torch.Generator().manual_seed(N * H)
     d1 = ConvDesc.make(N, H, H, C, K, 3, 3, 2, 1)
     dd = ConvDesc.make(N, H, H, C, K, 1, 1, 2, 0)
     slots = query("primia_conv_dgrad_pair_bnsums_slots", d1, dt)
-    assert slots == 2 * ((N * (H // 2) ** 2 + 191) // 192)
+    assert slots == (2 * ((N * (H // 2) ** 2 + 191) // 192) if C == 64 else 4 * ((N * (H // 2) ** 2 + 127) // 128))
     _, w1d = prep_weights(d1, rnd(torch.randn(K, C, 3, 3, generator=g) * 0.05, dtype), dtype, cuda, C)
     _, wdd = prep_weights(dd, rnd(torch.randn(K, C, 1, 1, generator=g) * 0.1, dtype), dtype, cuda, C)
     M2, M = N * (H // 2) ** 2, N * H * H
