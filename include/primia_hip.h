@@ -258,6 +258,18 @@ int primia_bn_relu_bwd_from_sums(const void* y, const void* dz, void* dy, const 
 int primia_conv_dgrad_masked_acc_ok(const primia_conv_desc* d, int dtype);
 int primia_conv2d_dgrad_masked_acc(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                                    const uint8_t* relu_mask, int dtype, primia_stream_t stream);
+/* ... whose write-back also forms the backward sums of the BatchNorm whose OUTPUT gradient the call completes (dx after the call
+ * is that gradient): sum g and sum g * xhat over g = dx AS STORED where the layer's ReLU passed, as per-block partials
+ * [slots][2][64].  mode 2 — a residual BatchNorm in front of an identity block: aux = its input y, aux_mask = the ReLU-mask bytes
+ * its forward pass wrote, c0 = saved mean, c1 = saved invstd; consumer primia_bn_bwd_mask_from_sums.  mode 3 — the stem's
+ * BatchNorm seen through the 3x3 / 2 max-pool (reference: torchlib/models.py conv1 -> bn1 -> relu -> maxpool): aux = the pooled
+ * activation p, ReLU = [p > 0], xhat = (p - beta) / gamma, c0 = beta, c1 = gamma, aux_mask unused; consumer
+ * primia_bn_relu_maxpool_bwd_from_sums (which also serves channels with gamma == 0 from y at the argmax).  64 -> 64 bf16 layers;
+ * primia_conv_dgrad_masked_acc_bnsums_slots = rows of the partial table, 0 where not served. */
+int primia_conv_dgrad_masked_acc_bnsums_slots(const primia_conv_desc* d, int dtype);
+int primia_conv2d_dgrad_masked_acc_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                                          const uint8_t* relu_mask, int mode, const void* aux, const uint8_t* aux_mask,
+                                          const float* c0, const float* c1, float* sums, int dtype, primia_stream_t stream);
 /* Transition block (torchlib/models.py:268-284 with a downsample, :232-235): dx = dgrad(conv1 3x3/2, dy) +
  * dgrad(downsample 1x1/2, dy_ds) in ONE pass — both convolutions read the same x, the downsample's gradient lands
  * on the even/even pixels, where conv1's only tap is the centre one at the same dy pixel, so it is folded into
@@ -543,6 +555,14 @@ int primia_bn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dp
                                const float* save_invstd, float* dgamma, float* dbeta, int N, int H, int W,
                                int C, void* workspace, int64_t workspace_bytes, int dtype,
                                primia_stream_t stream);
+/* primia_bn_relu_maxpool_bwd(dy = NULL) — dgamma / dbeta only — when the reduction over (pooled, dpooled) already happened in the
+ * write-back of the data gradient that produced dpooled (primia_conv2d_dgrad_masked_acc_bnsums, mode 3): `sums` = its partials
+ * [slots][2][C].  A channel with gamma == 0 (constant activation, xhat not recoverable from the pooled value) is served from
+ * y at the argmax positions, as in the unfused call. */
+int primia_bn_relu_maxpool_bwd_from_sums(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax,
+                                         const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
+                                         float* dbeta, const float* sums, int slots, int N, int H, int W, int C, int dtype,
+                                         primia_stream_t stream);
 /* The stem's backward tail without the 411 MB dy (batch 256, 224 x 224): primia_bn_relu_maxpool_bwd with dy = NULL
  * forms dgamma / dbeta only, and this call is conv1's weight gradient (primia_stem_conv_wgrad_ws) whose dy tiles are
  * produced on the fly, per 8 x 16 output patch, from y, dpooled, the argmax codes and bn1's statistics — the apply

@@ -202,6 +202,62 @@ __global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_kernel(const floa
     }
 }
 
+// Finalize of the stem's BatchNorm backward sums when their partials came out of a data-gradient write-back at POOLED resolution
+// (conv3x3_c64_kernel<true, 3, 3>: sum g, sum g * (p - beta) / gamma with g = dpooled * [p > 0]).  A channel with gamma == 0 has
+// a constant activation and xhat cannot be recovered from p: this kernel then reads y at the argmax positions for that channel
+// (what PoolScatterFn does in its rare branch) — one block walks the pooled tensor for it; never taken by a trained network.
+template <typename T>
+__global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_pool_kernel(
+    const float* __restrict__ partials, int nblk, int C, float* __restrict__ dbeta, float* __restrict__ dgamma,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd, const T* __restrict__ p,
+    const T* __restrict__ dp, const uint8_t* __restrict__ argmax, const T* __restrict__ y, int N, int H, int W, int Ho, int Wo) {
+    __shared__ double sa[kFinSlices][17], sb[kFinSlices][17];
+    __shared__ double sfix[16 * kFinSlices / 64];
+    const int cl = threadIdx.x & 15, ks = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double acc2[2] = {0.0, 0.0};
+    if (c < C) fin_gather<2>(partials, nblk, C, c, ks, acc2);
+    sa[ks][cl] = acc2[0];
+    sb[ks][cl] = acc2[1];
+    __syncthreads();
+    if (ks == 0 && c < C) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < kFinSlices; ++k) {
+            a += sa[k][cl];
+            b += sb[k][cl];
+        }
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)b;
+    }
+    for (int j = 0; j < 16; ++j) {          // (block-uniform)
+        const int cj = blockIdx.x * 16 + j;
+        if (cj >= C || gamma[cj] != 0.f) continue;
+        const long Mp = (long)N * Ho * Wo;
+        const float mu = mean[cj], is = invstd[cj];
+        double t = 0.0;
+        for (long r = threadIdx.x; r < Mp; r += blockDim.x) {
+            const float pv = Elem<T>::load(p + r * C + cj);
+            if (!(pv > 0.f)) continue;
+            const int wo = (int)(r % Wo);
+            const long q = r / Wo;
+            const int ho = (int)(q % Ho), n = (int)(q / Ho);
+            const int code = argmax[r * C + cj];
+            const int h = 2 * ho - 1 + code / 3, w = 2 * wo - 1 + code % 3;
+            const float yv = Elem<T>::load(y + (((long)n * H + h) * W + w) * C + cj);
+            t += (double)(Elem<T>::load(dp + r * C + cj) * ((yv - mu) * is));
+        }
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sfix[threadIdx.x >> 6] = t;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0.0;
+            for (int k = 0; k < 16 * kFinSlices / 64; ++k) a += sfix[k];
+            dgamma[cj] = (float)a;
+        }
+    }
+}
+
 // ---- the finalize launch folded into its consumer (round 5) -------------------------------------------------------
 // The one-block-per-16-channels bn_finalize_kernel between a statistics producer and the apply pass costs 5.6 us of pure
 // latency 37 times per step.  Here the apply kernel's FIRST C / 4 blocks do that work themselves — 4 channels x 64
@@ -1515,6 +1571,29 @@ int primia_bn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dp
         return bn_relu_pool_bwd_impl<bf16>(y, pooled, dpooled, argmax, dy, gamma, beta, save_mean, save_invstd, dgamma,
                                            dbeta, N, H, W, C, (float*)workspace, st);
     return PRIMIA_ERR_ARG;
+}
+
+// primia_bn_relu_maxpool_bwd(dy = null) whose reduction pass over (pooled, dpooled) already happened in the write-back of the data
+// gradient that produced dpooled (primia_conv2d_dgrad_masked_acc_bnsums, mode 3): `sums` = its partials [slots][2][C].
+int primia_bn_relu_maxpool_bwd_from_sums(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax,
+                                         const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
+                                         float* dbeta, const float* sums, int slots, int N, int H, int W, int C, int dtype,
+                                         primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && pooled && dpooled && argmax && gamma && save_mean && save_invstd && dgamma && dbeta && sums);
+    PRIMIA_REQUIRE(N > 0 && H > 0 && W > 0 && slots >= 1 && bn_shape_ok((long)N * H * W, C, dtype));
+    const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == PRIMIA_BF16)
+        bn_finalize_pool_kernel<bf16><<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(
+            sums, slots, C, dbeta, dgamma, gamma, save_mean, save_invstd, (const bf16*)pooled, (const bf16*)dpooled, argmax,
+            (const bf16*)y, N, H, W, Ho, Wo);
+    else if (dtype == PRIMIA_F32)
+        bn_finalize_pool_kernel<float><<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(
+            sums, slots, C, dbeta, dgamma, gamma, save_mean, save_invstd, (const float*)pooled, (const float*)dpooled, argmax,
+            (const float*)y, N, H, W, Ho, Wo);
+    else
+        return PRIMIA_ERR_ARG;
+    return launch_status();
 }
 
 int primia_bn_fwd_train_mask(const void* y, const void* residual, void* z, uint8_t* relu_mask, const float* gamma,

@@ -59,7 +59,9 @@ struct C64Params {
     const float* bnb_invstd;
     const float* bnb_gamma;
     const float* bnb_beta;
-    int debug;        // timing experiments only (set by tools/micro builds, 0 in the library): 1 no stores, 2 no staging, 4 no MFMA loop
+    const uint8_t* bnb_mask;   // BNB = 2: the ReLU-mask bytes of the layer whose sums are formed (one per pixel and 8 channels)
+    int debug;        // timing experiments only (option c64_dbg, 0 otherwise): 1 no stores, 2 no staging, 4 no MFMA loop,
+                      // 8 no BatchNorm-sum arithmetic, 16 no BatchNorm-row prefetch, 32 no mask-word loads, 64 no old-row prefetch
 };
 
 // Block = 4 waves (256 threads), TWO blocks per CU: the two waves of a SIMD belong to different blocks, so they are
@@ -67,20 +69,39 @@ struct C64Params {
 // block's MFMAs.  (The 8-wave form ran every wave of the CU through those phases in lockstep: with staging and stores
 // switched off it still took 60 us for 32 us worth of MFMAs.)  Wave (kh, ph): out-channels 32*kh..+31, patch rows
 // 4*ph..4*ph+3 = two 16-pixel MFMA column blocks q = 0, 1; one 8x8 patch per stage.
-template <bool ACC, int STAGES = 3, bool BNB = false>
+// BNB: the write-back also forms the two backward sums of a BatchNorm whose OUTPUT gradient this launch writes (sum g, sum g * xhat;
+// g = the value AS STORED where the layer's ReLU passed):
+//   1  plain data gradient; ReLU recomputed: [fma(y - mean, invstd * gamma, beta) > 0]          (bn1 of a block, conv2's data gradient)
+//   2  accumulate form; ReLU from the stored mask bytes; xhat = (y - mean) * invstd             (residual bn2 in front of an identity block)
+//   3  accumulate form; [p > 0]; xhat = (p - beta) / gamma from the POOLED activation p         (the stem's bn1, seen through the max-pool:
+//      a window's gradient reaches exactly its argmax, whose activation is the pooled value — PoolScatterFn of bn.hip)
+template <bool ACC, int STAGES = 3, int BNB = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(C64Params p) {
-    static_assert(!(ACC && BNB), "the BatchNorm-sums form is a plain data gradient");
+    static_assert(ACC ? BNB != 1 : BNB < 2, "1: plain data gradient; 2, 3: accumulate form");
     constexpr int HALO = 13 * 1024;        // 100 slots used, 104 staged (13 DMA instructions)
     constexpr int STAGE = HALO;            // one patch per stage
-    // output rows of one stage: 64 pixels x 64 channels, bf16 — or fp32 in the accumulate form, which adds the old
-    // values in the write-back phase (coalesced row loads, fp32 add, ONE rounding)
-    constexpr int OPIX = ACC ? 256 : 128;  // bytes per staged pixel row
+    // output rows of one stage: 64 pixels x 64 channels, bf16.  (The accumulate form used to stage fp32 rows and add the old
+    // values in the write-back lanes: 32 KiB of LDS and 40 KiB of LDS traffic per patch.  It now adds them to the ACCUMULATORS
+    // — the old rows arrive by LDS-DMA in a layout the accumulator lanes read without bank conflicts — rounds once, and
+    // shares the plain form's bf16 write-back: 63 KiB per block, which is what lets the BatchNorm rows in beside them.)
+    constexpr int OPIX = 128;              // bytes per staged pixel row
     constexpr int OUTB = 64 * OPIX;
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE + 2 * OUTB (+ 8 KiB of old rows: ACC)
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // STAGES * STAGE + 2 * OUTB (+ 8 KiB old rows: ACC) (+ 9 KiB: BNB)
     char* const sout = smem + STAGES * STAGE;
-    // accumulate form: the OLD rows of the patch being computed, fetched by LDS-DMA one iteration before the write-back
-    // adds them (64 pixels x 128 B, row group g at g * 1 KiB, lane-linear: pixel lane / 8, 16-B chunk lane % 8)
-    char* const sold = sout + 2 * OUTB;       // (BNB: the BatchNorm input rows of the patch being written back, then 1 KiB of constants)
+    // accumulate form: the OLD rows of the patch being computed.  Wave (kh, ph) fetches and reads exactly its own part — patch
+    // rows 4 * ph .. + 3 x channel half kh = two DMA instructions of 16 pixels x 64 B — so no barrier stands between the DMA
+    // and the read; LDS position (pixel, 16-B slot c) holds chunk c ^ ((pixel >> 1) & 3): conflict-free ds_read_b64
+    char* const sold = sout + 2 * OUTB;
+    // BNB: the BatchNorm input rows of the patch being written back (row group g at g * 1 KiB, lane-linear: pixel lane / 8,
+    // 16-B chunk lane % 8), then 1 KiB of per-channel constants
+    char* const saux = sold + (ACC ? 8192 : 0);
+    // the ReLU-mask words of both side streams also travel by LDS-DMA (a dword per lane, [wave][q][64 lanes]): an inline-asm
+    // load into a REGISTER that is consumed an iteration later is a loop-carried value the compiler may copy right after the
+    // load was issued — before its data arrived (seen: v_mov of the two mask registers at the loop latch, wrong masks once a
+    // block ran more than a few patches)
+    constexpr int SMK_OFF = STAGES * STAGE + 2 * OUTB + (ACC ? 8192 : 0) + (BNB ? 8192 + 1024 : 0);
+    char* const smk = smem + SMK_OFF;                 // accumulate form: 2 KiB
+    char* const sbm = smk + (ACC ? 2048 : 0);         // BNB = 2: 2 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 1, ph = wave & 1;
@@ -194,7 +215,97 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // output staging: pixel opix = 32*ph + 16*q + fr of the patch, 8-byte column 8*kh + 4*i + fg of its 128-B row,
     // stored at 16-B chunk (col >> 1) ^ ((opix >> 1) & 7): conflict-free ds_write_b64 / ds_read_b128
 
-    auto compute = [&](int buf, int obuf) {
+    // ---- side streams of the write-back ------------------------------------------------------------------------------
+    // Accumulate form: the old rows (and their ReLU-mask bytes) of patch s are requested at the END of compute(s - 1) and
+    // added to the accumulators at the end of compute(s): a whole iteration of latency, one 8-KiB buffer, and the issuing
+    // wave is the reading wave.  (History: loaded inside the write-back, a full memory latency per stage stood in front of
+    // the stores and the compiler's conservative vmcnt(0) drained the DMA ring on top: 93 us against 58 for the plain form.)
+    // The mask words travel by an inline-asm load the compiler's wait counting does not see.
+    // BNB: the BatchNorm rows of patch s are requested in iteration s (after the write-back of patch s - 1 has read the
+    // buffer) and read by the write-back of patch s in iteration s + 1 — older than the halo pieces requested after them,
+    // so the counted wait at the top of the loop covers them.
+    constexpr int NOLD = ACC ? 4 : 0;                          // vector-memory loads of one prefetch_old()
+    constexpr int NAUX = BNB ? (BNB == 2 ? 4 : 2) : 0;         // ... of one prefetch_aux()
+    c64_i32x4 rsrc_dst = rsrc, rsrc_aux = rsrc;
+    if constexpr (ACC) {
+        const unsigned long long a = (unsigned long long)(const void*)p.dst;
+        rsrc_dst[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rsrc_dst[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+    }
+    if constexpr (BNB != 0) {
+        const unsigned long long a = (unsigned long long)(const void*)p.bnb_y;
+        rsrc_aux[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rsrc_aux[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+    }
+    // BNB: per-channel constants in LDS behind the row buffer.  1: [mean | invstd * gamma | beta][64]; 2: [mean]; 3: [beta]
+    float* const bnc = (float*)(saux + 8192);
+    if constexpr (BNB != 0) {
+        if (tid < 64) {
+            if constexpr (BNB == 1) {
+                bnc[tid] = p.bnb_mean[tid];
+                bnc[64 + tid] = p.bnb_invstd[tid] * p.bnb_gamma[tid];
+                bnc[128 + tid] = p.bnb_beta[tid];
+            } else {
+                bnc[tid] = BNB == 2 ? p.bnb_mean[tid] : p.bnb_beta[tid];
+            }
+        }
+    }
+    Cursor co = make_cursor(t0);       // patch whose old rows are requested next
+    auto prefetch_old = [&]() {
+        if constexpr (ACC) {
+            const int pxl = lane >> 2, cc = lane & 3;     // pixel of the 16 (two patch rows), 16-B slot of the 64-B half row
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ho = co.ph * 8 + 4 * ph + 2 * q + (pxl >> 3), wo = co.pw * 8 + (pxl & 7);
+                const bool live = co.t < t1 && ho < p.H && wo < p.W && !(p.debug & 64);
+                const unsigned pix = (unsigned)((co.n * p.H + ho) * p.W + wo);
+                const unsigned voff = live ? (pix * 64u + (unsigned)(4 * kh + (cc ^ ((pxl >> 1) & 3))) * 8u) * 2u : kOob;
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + (wave * 2 + q) * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(voff), "s"(rsrc_dst), "s"(m0v) : "memory");
+            }
+            // the mask word of accumulator pixel fr (the write order above is by pixel lane / 4; the READ is by fr)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int ho = co.ph * 8 + 4 * ph + 2 * q + (fr >> 3), wo = co.pw * 8 + (fr & 7);
+                const bool live = co.t < t1 && ho < p.H && wo < p.W;
+                const unsigned pix = (unsigned)((co.n * p.H + ho) * p.W + wo);
+                // (no mask: the load is issued all the same — the wait counts below are per prefetch — and ignored)
+                const uint8_t* mp = p.acc_mask ? p.acc_mask + (live ? pix * 8u + 4u * kh : 0u) : (const uint8_t*)p.wt;
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + SMK_OFF + (wave * 2 + q) * 256);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(mp), "s"(m0v) : "memory");
+            }
+            advance(co);
+        }
+    };
+    auto prefetch_aux = [&]() {
+        if (BNB != 0 && !(p.debug & 32)) {
+            const int px = lane >> 3, c16 = lane & 7;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int g = 2 * wave + q;
+                const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
+                const bool live = cw.t < t1 && ho < p.H && wo < p.W && !(p.debug & 16);
+                const unsigned eoff = (unsigned)(((cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8);   // elements (< 2^31)
+                const unsigned voff = live ? eoff * 2u : kOob;
+                const unsigned m0v =
+                    __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + (ACC ? 8192 : 0) + g * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(voff), "s"(rsrc_aux), "s"(m0v) : "memory");
+                if constexpr (BNB == 2) {     // the dword that holds the lane's mask byte (pixel * 8 + chunk)
+                    const uint8_t* mp = p.bnb_mask + (live ? ((eoff >> 3) & ~3u) : 0u);
+                    const unsigned m1v = __builtin_amdgcn_readfirstlane(lds0 + SMK_OFF + (ACC ? 2048 : 0) + g * 256);
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(mp), "s"(m1v) : "memory");
+                }
+            }
+        }
+    };
+
+    const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !(p.debug & 3);
+    const int dstage = wave == 0 ? 4 : 3;      // halo pieces per stage issued by this wave
+
+    // `younger` = vector-memory loads this wave issued after the old rows of the patch being computed (0: unknown, drain)
+    auto compute = [&](int buf, int obuf, int younger) {
         const char* sb = smem + buf * STAGE;
         f32x4 acc[2][2];
 #pragma unroll
@@ -223,22 +334,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        // ---- results -> LDS rows (bf16; fp32 for the accumulate form) ---------------------------------------
+        if constexpr (ACC) {
+            // the old rows of this patch have landed once only the loads issued after them remain in flight (loads retire
+            // in order; stores do not count against them: see the loop's wait below)
+            switch (younger) {
+                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const char* ob = sold + (wave * 2 + q) * 1024 + fr * 64 + (fg & 1) * 8;
+                // ReLU-mask bytes of the wave's channel half (4 chunks) for accumulator pixel fr
+                const unsigned mkq = p.acc_mask ? *(const unsigned*)(smk + (wave * 2 + q) * 256 + lane * 4) : 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int c4 = 2 * i + (fg >> 1);          // 16-B chunk of the wave's channel half
+                    const u32x2 o = *(const u32x2*)(ob + ((c4 ^ ((fr >> 1) & 3)) << 4));
+                    const unsigned m = (mkq >> (8 * c4 + 4 * (fg & 1))) & 15u;   // old value = gradient through a ReLU whose
+                                                                                  // mask is applied here, not stored
+                    acc[q][i][0] += (m & 1u) ? __uint_as_float(o[0] << 16) : 0.f;
+                    acc[q][i][1] += (m & 2u) ? __uint_as_float(o[0] & 0xffff0000u) : 0.f;
+                    acc[q][i][2] += (m & 4u) ? __uint_as_float(o[1] << 16) : 0.f;
+                    acc[q][i][3] += (m & 8u) ? __uint_as_float(o[1] & 0xffff0000u) : 0.f;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next patch's rows may land
+            prefetch_old();
+        }
+        // ---- results -> LDS rows (bf16, ONE rounding) -----------------------------------------------------------
+        // pixel opix = 32*ph + 16*q + fr of the patch, 8-byte column 8*kh + 4*i + fg of its 128-B row,
+        // stored at 16-B chunk (col >> 1) ^ ((opix >> 1) & 7): conflict-free ds_write_b64 / ds_read_b128
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int opix = 32 * ph + 16 * q + fr;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int col = 8 * kh + 4 * i + fg;   // 4-channel column of the pixel's row
-                if constexpr (ACC) {
-                    // 16-byte fp32 chunks, chunk index swizzled with the pixel: conflict-free ds_write_b128
-                    *(f32x4*)(sout + obuf * OUTB + opix * OPIX + ((col ^ (opix & 15)) << 4)) = acc[q][i];
-                } else {
-                    u32x2 o;
-                    o[0] = (uint32_t)f32_to_bf16(acc[q][i][0]) | ((uint32_t)f32_to_bf16(acc[q][i][1]) << 16);
-                    o[1] = (uint32_t)f32_to_bf16(acc[q][i][2]) | ((uint32_t)f32_to_bf16(acc[q][i][3]) << 16);
-                    *(u32x2*)(sout + obuf * OUTB + opix * 128 + ((((col >> 1) ^ ((opix >> 1) & 7)) << 4) | ((col & 1) << 3))) = o;
-                }
+                u32x2 o;
+                o[0] = (uint32_t)f32_to_bf16(acc[q][i][0]) | ((uint32_t)f32_to_bf16(acc[q][i][1]) << 16);
+                o[1] = (uint32_t)f32_to_bf16(acc[q][i][2]) | ((uint32_t)f32_to_bf16(acc[q][i][3]) << 16);
+                *(u32x2*)(sout + obuf * OUTB + opix * 128 + ((((col >> 1) ^ ((opix >> 1) & 7)) << 4) | ((col & 1) << 3))) = o;
             }
         }
     };
@@ -251,111 +392,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.f;
 
-    // Accumulate form: the old rows (and their ReLU-mask bytes) of the patch the write-back cursor points at, requested
-    // one iteration AHEAD of the write-back that adds them — the first version loaded them inside the write-back, a full
-    // memory latency per stage in front of the stores, with the compiler's conservative vmcnt(0) draining the DMA ring
-    // on top (93 us against 58 us for the plain form, for 103 MB more).  The rows travel by LDS-DMA (a row group = 8
-    // pixels x 128 B = one instruction, no registers across the matrix phase: the kernel sits at 242 of 256), the mask
-    // bytes by an inline-asm byte load the compiler's wait counting does not see; both are older than the halo pieces
-    // requested after them, so the counted wait at the top of the next iteration covers them.
-    c64_i32x4 rsrc_dst = rsrc;
-    unsigned mk[2] = {0xffu, 0xffu};
-    if constexpr (ACC || BNB) {
-        const unsigned long long a = (unsigned long long)(BNB ? (const void*)p.bnb_y : (const void*)p.dst);
-        rsrc_dst[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-        rsrc_dst[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
-    }
-    // BNB: per-channel constants of the BatchNorm in LDS behind the row buffer: [mean | invstd * gamma | beta | invstd][64]
-    float* const bnc = (float*)(sold + 8192);
-    if constexpr (BNB) {
-        if (tid < 64) {
-            const float is = p.bnb_invstd[tid];
-            bnc[tid] = p.bnb_mean[tid];
-            bnc[64 + tid] = is * p.bnb_gamma[tid];
-            bnc[128 + tid] = p.bnb_beta[tid];
-            bnc[192 + tid] = is;
-        }
-    }
-    auto prefetch_old = [&]() {
-        if constexpr (ACC || BNB) {
-            const int px = lane >> 3, c16 = lane & 7;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int g = 2 * wave + q;
-                const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
-                const bool live = cw.t < t1 && ho < p.H && wo < p.W;
-                const unsigned eoff = (unsigned)(((cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8);   // elements (< 2^31)
-                const unsigned voff = live ? eoff * 2u : kOob;
-                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + g * 1024);
-                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-                             ::"v"(voff), "s"(rsrc_dst), "s"(m0v) : "memory");
-                if (ACC && p.acc_mask) {
-                    const uint8_t* mp = p.acc_mask + (live ? (eoff >> 3) : 0u);
-                    asm volatile("global_load_ubyte %0, %1, off" : "=v"(mk[q]) : "v"(mp) : "memory");
-                }
-            }
-        }
-    };
-
     auto writeback = [&](int obuf) {
         const int px = lane >> 3, c16 = lane & 7;  // pixel of the row, 16-B chunk
         bool live[2];
         bf16* gp[2];
-        u32x4 old[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int g = 2 * wave + q;                // patch row handled by this wave
             const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
             live[q] = cw.t < t1 && ho < p.H && wo < p.W;
             gp[q] = p.dst + ((long)(cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8;
-            old[q] = u32x4{0, 0, 0, 0};
-            if constexpr (ACC) {
-                // (requested by prefetch_old() an iteration ago, by THIS wave: no barrier between the DMA and this read)
-                old[q] = *(const u32x4*)(sold + g * 1024 + lane * 16);
-                if (p.acc_mask) {   // old value = gradient through a ReLU whose mask is applied here, not stored
-                    const unsigned m = mk[q];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        old[q][k] &= ((m >> (2 * k)) & 1u ? 0x0000ffffu : 0u) | ((m >> (2 * k + 1)) & 1u ? 0xffff0000u : 0u);
-                }
-            }
         }
         advance(cw);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int opx2 = (2 * wave + q) * 8 + px;
-            u32x4 v;
-            if constexpr (ACC) {
-                const char* row = sout + obuf * OUTB + opx2 * OPIX;
-                const f32x4 lo = *(const f32x4*)(row + (((2 * c16) ^ (opx2 & 15)) << 4));
-                const f32x4 hi = *(const f32x4*)(row + (((2 * c16 + 1) ^ (opx2 & 15)) << 4));
-                float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    f[2 * k] += __uint_as_float(old[q][k] << 16);
-                    f[2 * k + 1] += __uint_as_float(old[q][k] & 0xffff0000u);
-                    v[k] = (uint32_t)f32_to_bf16(f[2 * k]) | ((uint32_t)f32_to_bf16(f[2 * k + 1]) << 16);
-                }
-            } else {
-                v = *(const u32x4*)(sout + obuf * OUTB + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
-            }
+            const u32x4 v = *(const u32x4*)(sout + obuf * OUTB + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
             if (live[q] && !((p.debug & 1) && v[0] != 12345u)) {
                 *(u32x4*)gp[q] = v;      // (non-temporal stores: measured, no change — 4.862 vs 4.861 ms per step)
-                if constexpr (BNB) {
-                    // the BatchNorm input row chunk of this pixel (requested an iteration ago, by THIS wave, into `sold`)
-                    const u32x4 yv = *(const u32x4*)(sold + (2 * wave + q) * 1024 + lane * 16);
+                if (BNB != 0 && !(p.debug & 8)) {
+                    // the BatchNorm input row chunk of this pixel (requested an iteration ago, by THIS wave)
+                    const u32x4 yv = *(const u32x4*)(saux + (2 * wave + q) * 1024 + lane * 16);
+                    unsigned bmq = 0;
+                    if constexpr (BNB == 2) bmq = *(const unsigned*)(sbm + (2 * wave + q) * 256 + lane * 4) >> (8 * (c16 & 3));
                     const f32x4 mu0 = *(const f32x4*)(bnc + c16 * 8), mu1 = *(const f32x4*)(bnc + c16 * 8 + 4);
-                    const f32x4 sc0 = *(const f32x4*)(bnc + 64 + c16 * 8), sc1 = *(const f32x4*)(bnc + 64 + c16 * 8 + 4);
-                    const f32x4 be0 = *(const f32x4*)(bnc + 128 + c16 * 8), be1 = *(const f32x4*)(bnc + 128 + c16 * 8 + 4);
+                    f32x4 sc0, sc1, be0, be1;
+                    if constexpr (BNB == 1) {
+                        sc0 = *(const f32x4*)(bnc + 64 + c16 * 8), sc1 = *(const f32x4*)(bnc + 64 + c16 * 8 + 4);
+                        be0 = *(const f32x4*)(bnc + 128 + c16 * 8), be1 = *(const f32x4*)(bnc + 128 + c16 * 8 + 4);
+                    }
 #pragma unroll
                     for (int k = 0; k < 8; ++k) {
                         const float yk = __uint_as_float((k & 1) ? (yv[k >> 1] & 0xffff0000u) : (yv[k >> 1] << 16));
                         const float dk = __uint_as_float((k & 1) ? (v[k >> 1] & 0xffff0000u) : (v[k >> 1] << 16));
                         const float t = yk - (k < 4 ? mu0[k & 3] : mu1[k & 3]);
-                        const float zz = __builtin_fmaf(t, k < 4 ? sc0[k & 3] : sc1[k & 3], k < 4 ? be0[k & 3] : be1[k & 3]);
-                        const float gk = zz > 0.f ? dk : 0.f;
+                        bool on;
+                        if constexpr (BNB == 1)
+                            on = __builtin_fmaf(t, k < 4 ? sc0[k & 3] : sc1[k & 3], k < 4 ? be0[k & 3] : be1[k & 3]) > 0.f;
+                        else if constexpr (BNB == 2)
+                            on = (bmq >> k) & 1u;
+                        else
+                            on = yk > 0.f;
+                        const float gk = on ? dk : 0.f;
                         st1[k] += gk;
-                        st2[k] = __builtin_fmaf(gk, t, st2[k]);      // (x invstd once per channel at the end)
+                        st2[k] = __builtin_fmaf(gk, t, st2[k]);      // (x invstd, or 1 / gamma, once per channel at the end)
                     }
                 } else if (p.stat_partials) {
 #pragma unroll
@@ -371,30 +451,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    // STAGES-deep LDS ring, one raw barrier per stage, counted vmcnt.  Per iteration a wave issues, in this order,
-    // 2 row stores (write-back of the previous stage) and d DMA instructions (d = 4 for wave 0, else 3).  At the top
-    // of iteration s, DMA(s) has landed once at most the d instructions of DMA(s+1) remain in flight.  Ragged
-    // images, the accumulate form (its loads are waited for by the compiler, conservatively) and the last stage use
-    // vmcnt(0).
-    const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !(p.debug & 3);
-    if constexpr (BNB) __syncthreads();        // (the constants in LDS are visible to every wave)
-    prefetch_old();            // patch 0's old rows: older than every halo piece, landed by the first counted wait
+    // STAGES-deep LDS ring, one raw barrier per stage, counted vmcnt.  Per iteration s a wave issues, in this order: 2 row
+    // stores (write-back of patch s - 1), NAUX loads (BatchNorm rows of patch s), d halo pieces of patch s + STAGES - 1
+    // (d = 4 for wave 0, else 3), and at the end of compute(s) NOLD loads (old rows of patch s + 1).  Loads retire in order,
+    // so "at most n in flight" means "only the n youngest": at the top of iteration s the halo of patch s (and the
+    // BatchNorm rows requested after it) have landed once only the younger halo pieces and the old rows remain.
+    // Ragged images and the last stage drain (vmcnt(0)).
+    // (Counting the row stores in as well is WRONG: stores and loads retire out of order with respect to each other, so two
+    // early store completions would let the wave through with two halo pieces still in flight.  Seen as run-to-run
+    // differences of the training loss once every other source of nondeterminism was gone.)
+    if constexpr (BNB != 0) __syncthreads();        // (the constants in LDS are visible to every wave)
+    prefetch_aux();            // patch 0's BatchNorm rows: older than every halo piece, landed by the first counted wait
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nstages) stage(s);
+    prefetch_old();            // patch 0's old rows: the youngest loads at the top of iteration 0, as in every iteration
     int cur = 0, nxt = STAGES - 1;
     for (int s = 0; s < nstages; ++s) {
-        if (exact && STAGES == 4 && s + 2 < nstages) {
-            // 4-deep ring: DMA(s+1) and DMA(s+2) may stay in flight
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        } else if (exact && s + 1 < nstages) {
-            // only DMA(s+1) may stay in flight.  (Counting the row stores of iteration s-1 in as well — vmcnt(d + 2) —
-            // is WRONG: stores and loads retire out of order with respect to each other, so two early store
-            // completions let the wave through with two pieces of DMA(s) still in flight.  Seen as run-to-run
-            // differences of the training loss once every other source of nondeterminism was gone.)
-            if (wave == 0) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        // 4-deep ring (plain / accumulate): patches s + 1 and s + 2 may stay in flight; with BatchNorm rows (3-deep): s + 1 only
+        const int keep = (STAGES == 4 && s + 2 < nstages) ? 2 : (s + 1 < nstages ? 1 : 0);
+        if (exact && keep) {
+            // (4-deep accumulate form: the old rows of patch s - 1, long landed, still sit between the two halos in issue order)
+            switch (keep * dstage + (keep == 2 && s > 0 ? 2 : 1) * NOLD) {
+                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+                case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+                case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+            }
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -402,21 +491,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the other waves read them (a raw s_barrier does not wait for the wave's own outstanding ds_write; with two
         // blocks per CU competing for the LDS the write-back occasionally read a stale 1-KiB row)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (ACC) asm volatile("" : "+v"(mk[0]), "+v"(mk[1])::"memory");   // (the mask bytes are valid from here)
         __builtin_amdgcn_s_barrier();
+        int younger = 0;       // loads issued in this iteration, after the old rows of patch s
         if (s > 0) {
             writeback((s - 1) & 1);
-            prefetch_old();    // the cursor now points at patch s, written back in iteration s + 1
+            prefetch_aux();    // the cursor now points at patch s, written back in iteration s + 1
+            younger += (p.debug & 32) ? 0 : NAUX;
         }
-        if (s + STAGES - 1 < nstages && !(p.debug & 2)) stage(nxt);
-        compute(cur, s & 1);
+        if (s + STAGES - 1 < nstages && !(p.debug & 2)) {
+            stage(nxt);
+            younger += dstage;
+        }
+        compute(cur, s & 1, exact ? younger : 0);
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
-    if constexpr (ACC || BNB) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("" : "+v"(mk[0]), "+v"(mk[1])::"memory");
-    }
+    if constexpr (ACC || BNB != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     writeback((nstages - 1) & 1);
     if (p.stat_partials) {
@@ -443,7 +533,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             float a = 0.f;
 #pragma unroll
             for (int w = 0; w < 4; ++w) a += red[w * 128 + tid];
-            if (BNB && tid >= 64) a *= p.bnb_invstd[tid - 64];   // sum g * (y - mean) -> sum g * xhat
+            if (BNB != 0 && tid >= 64) {      // sum g * (y - mean) -> sum g * xhat
+                if constexpr (BNB == 3) {
+                    const float gm = p.bnb_gamma[tid - 64];
+                    a *= gm != 0.f ? 1.f / gm : 0.f;      // (gamma == 0: xhat is not recoverable from p — the consumer's rare path)
+                } else {
+                    a *= p.bnb_invstd[tid - 64];
+                }
+            }
             p.stat_partials[(long)blockIdx.x * 128 + tid] = a;   // [block][2][64]
         }
     }
@@ -459,14 +556,24 @@ int conv3x3_c64_grid(int N, int H, int W) {
 }
 
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
-                         hipStream_t st, float* stat_partials, const uint8_t* acc_mask, const LhBnBwd* bnb) {
+                         hipStream_t st, float* stat_partials, const uint8_t* acc_mask, const LhBnBwd* bnb,
+                         const C64AccBnb* abnb) {
     if ((long)N * H * W * 64 >= (1L << 31)) return PRIMIA_ERR_UNSUPPORTED;
     const bool with_bnb = bnb && bnb->y;
-    if (with_bnb && (!flip || accumulate || !stat_partials)) return PRIMIA_ERR_ARG;
+    const int amode = (abnb && abnb->aux) ? abnb->mode : 0;
+    if (with_bnb && (!flip || accumulate || !stat_partials || amode)) return PRIMIA_ERR_ARG;
+    if (amode && (!flip || !accumulate || !stat_partials || (amode != 2 && amode != 3) || (amode == 2 && !abnb->mask)))
+        return PRIMIA_ERR_ARG;
     C64Params p;
     p.bnb_y = with_bnb ? bnb->y : nullptr;
     p.bnb_mean = with_bnb ? bnb->mean : nullptr; p.bnb_invstd = with_bnb ? bnb->invstd : nullptr;
     p.bnb_gamma = with_bnb ? bnb->gamma : nullptr; p.bnb_beta = with_bnb ? bnb->beta : nullptr;
+    p.bnb_mask = nullptr;
+    if (amode == 2) {          // residual BatchNorm: mask bytes, mean, invstd
+        p.bnb_y = abnb->aux; p.bnb_mask = abnb->mask; p.bnb_mean = abnb->c0; p.bnb_invstd = abnb->c1;
+    } else if (amode == 3) {   // through the max-pool: pooled activation, beta, gamma
+        p.bnb_y = abnb->aux; p.bnb_beta = abnb->c0; p.bnb_gamma = abnb->c1;
+    }
     p.src = src; p.wt = wt; p.dst = dst;
     p.N = N; p.H = H; p.W = W; p.flip = flip; p.accumulate = accumulate;
     p.stat_partials = stat_partials;
@@ -477,30 +584,36 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     long per = (p.total + target - 1) / target;
     if (per < 1) per = 1;
     p.per_block = (int)per;
-    p.debug = 0;       // (timing-experiment bits of tools/micro; never set by the library)
+    p.debug = PRIMIA_OPT(c64_dbg);       // (timing experiments: option c64_dbg, 0 in every product run)
     const int grid = (int)((p.total + per - 1) / per);
-    // plain form: a 4-deep ring (68 KiB per block, two blocks per CU) keeps 78 KB per CU in flight instead of 52
+    // a 4-deep ring (plain 68 KiB, accumulate 76 KiB per block, two blocks per CU) keeps 78 KB per CU in flight instead of 52
     const int deep = PRIMIA_OPT(c64_stages);
-    const int stages = (!accumulate && !with_bnb && deep == 4) ? 4 : 3;
-    const size_t lds = (size_t)stages * 13 * 1024 + 2 * 64 * (accumulate ? 256 : 128) + (accumulate ? 8192 : 0) + (with_bnb ? 8192 + 1024 : 0);
+    const int stages = (!with_bnb && !amode && deep == 4) ? 4 : 3;
+    auto lds_of = [](int stg, bool acc, bool aux) {
+        return stg * 13 * 1024 + 2 * 64 * 128 + (acc ? 8192 + 2048 : 0) + (aux ? 8192 + 1024 : 0);
+    };
+    const size_t lds = (size_t)lds_of(stages, accumulate != 0, with_bnb || amode) + (amode == 2 ? 2048 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        const int lds_plain = 3 * 13 * 1024 + 2 * 64 * 128, lds_acc = 3 * 13 * 1024 + 2 * 64 * 256 + 8192;
-        const int lds_plain4 = 4 * 13 * 1024 + 2 * 64 * 128;
-        const int lds_bnb = 3 * 13 * 1024 + 2 * 64 * 128 + 8192 + 1024;
-        if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_plain) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_plain4) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bnb) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_acc) != hipSuccess)
+        const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
+        if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3>, attr, lds_of(3, false, false)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 4>, attr, lds_of(4, false, false)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3, 1>, attr, lds_of(3, false, true)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3>, attr, lds_of(3, true, false)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 4>, attr, lds_of(4, true, false)) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3, 2>, attr, lds_of(3, true, true) + 2048) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3, 3>, attr, lds_of(3, true, true)) != hipSuccess)
             return PRIMIA_ERR_LAUNCH;
         attr_set = true;
     }
     if (with_bnb)
-        conv3x3_c64_kernel<false, 3, true><<<grid, 256, lds, st>>>(p);
+        conv3x3_c64_kernel<false, 3, 1><<<grid, 256, lds, st>>>(p);
+    else if (amode == 2)
+        conv3x3_c64_kernel<true, 3, 2><<<grid, 256, lds, st>>>(p);
+    else if (amode == 3)
+        conv3x3_c64_kernel<true, 3, 3><<<grid, 256, lds, st>>>(p);
+    else if (accumulate && stages == 4)
+        conv3x3_c64_kernel<true, 4><<<grid, 256, lds, st>>>(p);
     else if (accumulate)
         conv3x3_c64_kernel<true, 3><<<grid, 256, lds, st>>>(p);
     else if (stages == 4)

@@ -15,6 +15,17 @@ struct LhBnBwd {
     const float* beta;
 };
 
+// ... and of an ACCUMULATING 64 -> 64 data gradient (conv3x3_c64.hip): mode 2 = a residual BatchNorm, ReLU from its stored mask
+// bytes (aux = its input y, c0 = mean, c1 = invstd); mode 3 = the stem's BatchNorm seen through the max-pool (aux = the pooled
+// activation p, [p > 0], xhat = (p - beta) / gamma: c0 = beta, c1 = gamma)
+struct C64AccBnb {
+    int mode;
+    const bf16* aux;
+    const uint8_t* mask;
+    const float* c0;
+    const float* c1;
+};
+
 // pixel tiles (= partial slots) if the shape is served by the kernel, else PRIMIA_ERR_UNSUPPORTED
 int conv3x3_lh2_tiles_m(int N, int H, int W, int Cs, int Nd);
 int conv3x3_lh_kernel_of(int N, int H, int W, int Cs, int Nd);   // 4 conv3x3_lh2_kernel | 6 conv3x3_lh4_kernel | 0 neither

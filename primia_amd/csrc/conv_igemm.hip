@@ -859,7 +859,7 @@ using namespace primia;
 namespace primia {
 int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int H, int W, int flip, int accumulate,
                          hipStream_t st, float* stat_partials = nullptr, const uint8_t* acc_mask = nullptr,
-                         const LhBnBwd* bnb = nullptr);
+                         const LhBnBwd* bnb = nullptr, const C64AccBnb* abnb = nullptr);
 int conv3x3_c64_grid(int N, int H, int W);
 }
 
@@ -1056,7 +1056,8 @@ int primia_conv2d_fwd_stats(const primia_conv_desc* d, const void* x, const void
 
 static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
                              int accumulate, const void* dy2, const void* w_dgrad2, int dtype, primia_stream_t stream,
-                             const uint8_t* acc_mask = nullptr, const S2BnBwd* pair_bnb = nullptr) {
+                             const uint8_t* acc_mask = nullptr, const S2BnBwd* pair_bnb = nullptr,
+                             const C64AccBnb* acc_bnb = nullptr, float* acc_sums = nullptr) {
     PRIMIA_REQUIRE(d && dy && w_dgrad && dx);
     ConvGeom g;
     PRIMIA_REQUIRE(g.init(*d));
@@ -1085,9 +1086,11 @@ static int conv2d_dgrad_impl(const primia_conv_desc* d, const void* dy, const vo
     } else if (dtype == PRIMIA_BF16) {
         if (use_c64(g)) {
             const int rc = conv3x3_c64_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, 1,
-                                                accumulate, st, nullptr, acc_mask);
+                                                accumulate, st, acc_sums, acc_mask, nullptr, acc_bnb);
             if (rc != PRIMIA_ERR_UNSUPPORTED) return rc;
-        } else if (lh_shape(g) && !p.src2) {
+        }
+        if (acc_bnb) return PRIMIA_ERR_UNSUPPORTED;     // only the 64 -> 64 accumulate form carries these sums
+        if (!use_c64(g) && lh_shape(g) && !p.src2) {
             const int rc2 = conv3x3_lh2_dispatch((const bf16*)dy, (const bf16*)w_dgrad, (bf16*)dx, g.N, g.H, g.W, g.K, g.C,
                                                  1, accumulate, st, nullptr, acc_mask);
             if (rc2 != PRIMIA_ERR_UNSUPPORTED) return rc2;
@@ -1154,6 +1157,28 @@ int primia_conv2d_dgrad_masked_acc(const primia_conv_desc* d, const void* dy, co
     PRIMIA_REQUIRE(relu_mask);
     if (dtype != PRIMIA_BF16) return PRIMIA_ERR_UNSUPPORTED;
     return conv2d_dgrad_impl(d, dy, w_dgrad, dx, 1, nullptr, nullptr, dtype, stream, relu_mask);
+}
+
+// primia_conv2d_dgrad_masked_acc whose write-back also forms the backward sums of the BatchNorm whose OUTPUT gradient the call
+// completes (dx after the call = that gradient): sum g, sum g * xhat over g = dx AS STORED where the layer's ReLU passed, as
+// per-block partials [slots][2][64].  mode 2: a residual BatchNorm (aux = its input y, aux_mask = the ReLU-mask bytes of its
+// forward pass, c0 = saved mean, c1 = saved invstd) -> primia_bn_bwd_mask_from_sums; mode 3: the stem's BatchNorm seen through
+// the 3x3 / 2 max-pool (aux = the pooled activation p: ReLU = [p > 0], xhat = (p - beta) / gamma; c0 = beta, c1 = gamma)
+// -> primia_bn_relu_maxpool_bwd_from_sums.  64 -> 64 layers (conv3x3_c64_kernel<true, 3, mode>); slots = 0 elsewhere.
+int primia_conv_dgrad_masked_acc_bnsums_slots(const primia_conv_desc* d, int dtype) {
+    ConvGeom g;
+    if (!d || !g.init(*d)) return PRIMIA_ERR_ARG;
+    if (dtype != PRIMIA_BF16 || !use_c64(g) || (long)g.N * g.H * g.W * 64 >= (1L << 31)) return 0;
+    return PRIMIA_OPT(c64_bnsums) ? conv3x3_c64_grid(g.N, g.H, g.W) : 0;
+}
+
+int primia_conv2d_dgrad_masked_acc_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
+                                          const uint8_t* relu_mask, int mode, const void* aux, const uint8_t* aux_mask,
+                                          const float* c0, const float* c1, float* sums, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(relu_mask && aux && c0 && c1 && sums && (mode == 2 || mode == 3) && (mode == 3 || aux_mask));
+    if (primia_conv_dgrad_masked_acc_bnsums_slots(d, dtype) <= 0) return PRIMIA_ERR_UNSUPPORTED;
+    const C64AccBnb ab{mode, (const bf16*)aux, aux_mask, c0, c1};
+    return conv2d_dgrad_impl(d, dy, w_dgrad, dx, 1, nullptr, nullptr, dtype, stream, relu_mask, nullptr, &ab, sums);
 }
 
 // primia_conv2d_dgrad_pair whose write-back also forms the backward sums of the residual BatchNorm in FRONT of the transition

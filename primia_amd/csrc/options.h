@@ -13,6 +13,7 @@ namespace primia {
     X(c64, 1)               /* 0: layer1's 64 -> 64 convolutions stay on the implicit GEMM */                          \
     X(c64_blocks, 512)      /* persistent blocks of conv3x3_c64_kernel (2 per CU) */                                   \
     X(c64_bnsums, 1)        /* primia_conv2d_dgrad_bnsums also on the 64 -> 64 layers (layer1) */                                   \
+    X(c64_dbg, 0)           /* timing experiments only (results are WRONG when set): conv3x3_c64_kernel's debug bits */           \
     X(c64_stages, 4)        /* ring depth of conv3x3_c64_kernel: 3 | 4 */                                              \
     X(conv_cfg, 4)          /* implicit-GEMM tile configuration 0..5 (conv_igemm.hip, a..f) */                         \
     X(fwd_pair, 1)          /* transition blocks: conv1 + downsample forward in one grid */                            \

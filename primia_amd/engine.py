@@ -481,6 +481,10 @@ class ResNet18Engine:
     # layer4.0).  The 64-channel one alone measured neutral (4.770 vs 4.770 ms); with the two igemm launches, whose LDS
     # write-back loop already walks 16-byte chunks of whole pixel rows, 4.882 -> 4.862 ms (8 alternating rounds, one box).
     pair_bnsums = True
+    # ... and the ACCUMULATING data gradient of a 64 -> 64 identity block's conv1 the sums of the BatchNorm whose output gradient
+    # it completes: layer1.0's bn2 (layer1.1.conv1) and the stem's bn1 through the max-pool (layer1.0.conv1) —
+    # primia_conv2d_dgrad_masked_acc_bnsums; the two most expensive reduction passes of the step (43 + 48 us)
+    acc_bnsums = True
     # conv1 + downsample data gradients of a transition block in one pass (primia_conv2d_dgrad_pair)
     pair_dgrad = True
     # identity blocks: conv1's accumulating data gradient applies bn2's ReLU mask to the old values itself
@@ -800,6 +804,14 @@ class ResNet18Engine:
             torch.cuda.current_stream().wait_stream(self._wg_stream)
             self._wg_pending = False
 
+    def _stem_bwd_fused_wanted(self):
+        """The stem's backward tail runs as primia_bn_relu_maxpool_bwd (sums only) + primia_stem_bwd_fused."""
+        if getattr(self, "_stem_bwd_fused_ok", None) is None:     # asked once: the library's own gate for this shape
+            S0 = self.spec.input_size
+            self._stem_bwd_fused_ok = query("primia_stem_bwd_fused_ok", self.N, S0, S0, self.dt) == 1
+        return bool(self._stem_fused and self._stem_padded and self.dp is None and self.stem_bwd_fused
+                    and self.wgrad_ws is not None and self._stem_bwd_fused_ok)
+
     def _dgrad_bnsums_slots(self, name):
         """Rows of the partial table conv `name`'s data gradient writes for the BatchNorm in front of it (0: not served)."""
         c = self.convs[name]
@@ -946,8 +958,37 @@ class ResNet18Engine:
                     c1 = self.convs[blk.conv1.name]
                     if self.wgrad_overlap == 1:
                         self._join_wgrad_stream()
-                    self._timed("dgrad", c1, lambda: call("primia_conv2d_dgrad_masked_acc", c1.desc, t[p + ".dy1"],
-                                                          c1.w_dgrad, dx_in, self.relu_masks[b2], self.dt))
+                    # ... whose write-back also forms the backward sums of the BatchNorm whose output gradient it completes:
+                    # the previous block's bn2 (mode 2), or the stem's bn1 through the max-pool (mode 3)
+                    aslots, amode = 0, 0
+                    if self.acc_bnsums and self.norm == "batch" and self.dp is None and self.dtype == torch.bfloat16:
+                        prev = blocks[i - 1] if i > 0 else None
+                        pb2 = bn_name(prev.conv2.name) if prev is not None else None
+                        if prev is not None and prev.down is None and pb2 in self.relu_masks:
+                            amode = 2
+                        elif prev is None and self._stem_bwd_fused_wanted():
+                            amode = 3
+                        if amode:
+                            if getattr(c1, "acc_bnsums_slots", None) is None:
+                                c1.acc_bnsums_slots = query("primia_conv_dgrad_masked_acc_bnsums_slots", c1.desc, self.dt)
+                            aslots = c1.acc_bnsums_slots
+                    if aslots > 0 and amode == 2:
+                        sums = self._bwd_sums(blk.conv1.name + ".acc", aslots, prev.conv2.cout)
+                        smp, sip = self.save[pb2]
+                        self._timed("dgrad", c1, lambda: call(
+                            "primia_conv2d_dgrad_masked_acc_bnsums", c1.desc, t[p + ".dy1"], c1.w_dgrad, dx_in,
+                            self.relu_masks[b2], 2, t[prev.prefix + ".y2"], self.relu_masks[pb2], smp, sip, sums, self.dt))
+                        self._dout_sums[prev.prefix] = (sums, aslots)
+                    elif aslots > 0 and amode == 3:
+                        sums = self._bwd_sums(blk.conv1.name + ".acc", aslots, 64)
+                        self._timed("dgrad", c1, lambda: call(
+                            "primia_conv2d_dgrad_masked_acc_bnsums", c1.desc, t[p + ".dy1"], c1.w_dgrad, dx_in,
+                            self.relu_masks[b2], 3, t["pool.out"], None, self.views["bn1.bias"], self.views["bn1.weight"],
+                            sums, self.dt))
+                        self._pool_sums = (sums, aslots)
+                    else:
+                        self._timed("dgrad", c1, lambda: call("primia_conv2d_dgrad_masked_acc", c1.desc, t[p + ".dy1"],
+                                                              c1.w_dgrad, dx_in, self.relu_masks[b2], self.dt))
                 elif i > 0:
                     self._dgrad(blk.conv1.name, t[p + ".dy1"], dx_in, True, blocks[i - 1].conv2.name,
                                 t[blocks[i - 1].prefix + ".y2"])
@@ -958,19 +999,21 @@ class ResNet18Engine:
         hw = self.stem_hw
         # the stem's tail in two launches less and without the dy tensor (411 MB at batch 256): bn1's backward sums at
         # pooled resolution, then conv1's weight gradient forming its dy tiles on the fly (primia_stem_bwd_fused)
-        if getattr(self, "_stem_bwd_fused_ok", None) is None:     # asked once: the library's own gate for this shape
-            S0 = self.spec.input_size
-            self._stem_bwd_fused_ok = query("primia_stem_bwd_fused_ok", N, S0, S0, self.dt) == 1
-        stem_bwd_fused = (self._stem_fused and self._stem_padded and self.dp is None and self.stem_bwd_fused
-                          and self.wgrad_ws is not None and self._stem_bwd_fused_ok)
+        stem_bwd_fused = self._stem_bwd_fused_wanted()
         self.stem_bwd_fused_active = stem_bwd_fused
+        pool_sums, self._pool_sums = getattr(self, "_pool_sums", None), None
         if stem_bwd_fused:
             sm, si = self.save["bn1"]
             c = self.convs["conv1"]
             S = self.spec.input_size
-            call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, None,
-                 self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self._gviews["bn1.weight"],
-                 self._gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
+            if pool_sums is not None:     # the reduction over (pooled, dpooled) happened in layer1.0.conv1's data gradient
+                call("primia_bn_relu_maxpool_bwd_from_sums", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax,
+                     self.views["bn1.weight"], sm, si, self._gviews["bn1.weight"], self._gviews["bn1.bias"], pool_sums[0],
+                     pool_sums[1], N, hw, hw, 64, self.dt)
+            else:
+                call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, None,
+                     self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self._gviews["bn1.weight"],
+                     self._gviews["bn1.bias"], N, hw, hw, 64, self.bn_ws, self.bn_ws_bytes, self.dt)
             self._on_wgrad_stream(lambda: self._timed("wgrad", c, lambda: call(
                 "primia_stem_bwd_fused", self.x0p, t["stem.y"], t["pool.dout"], self.pool_argmax,
                 self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self._gviews["bn1.weight"],

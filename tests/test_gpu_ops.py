@@ -1029,13 +1029,16 @@ def test_conv_dgrad_pair_matches_two_passes(cuda, dtype, N, H, C, K):
         call("primia_conv2d_dgrad_pair", d1, dy1d, w1d, d1, dydd, wdd, dx, dt)
 
 
-@pytest.mark.parametrize("N,H,C", [(2, 16, 64), (1, 56, 64), (2, 28, 128), (4, 14, 256), (5, 7, 512)])
-def test_dgrad_masked_accumulate(cuda, N, H, C):
+@pytest.mark.parametrize("N,H,C", [(2, 16, 64), (1, 56, 64), (2, 28, 128), (4, 14, 256), (5, 7, 512), (3, 56, -64), (2, 20, -64)])
+def test_dgrad_masked_accumulate(cuda, c64_blocks, N, H, C):
     """primia_conv2d_dgrad_masked_acc: dx = relu_mask(dx) + dgrad(dy), bit-identical to masking dx first and then
     calling primia_conv2d_dgrad(accumulate = 1) (identity blocks: the BatchNorm backward no longer writes the
     masked residual gradient)."""
     dtype = torch.bfloat16
     dt = _lib.dtype_code(dtype)
+    if C < 0:      # 64 channels on a handful of persistent blocks: many patches per block (the counted waits of the ring)
+        C = -C
+        c64_blocks(3)
     desc = ConvDesc.make(N, H, H, C, C, 3, 3, 1, 1)
     assert query("primia_conv_dgrad_masked_acc_ok", desc, dt) == 1
     g = torch.Generator().manual_seed(3 * H + C)
@@ -1055,6 +1058,114 @@ def test_dgrad_masked_accumulate(cuda, N, H, C):
     d2 = ConvDesc.make(2, 16, 16, 64, 128, 3, 3, 2, 1)
     assert query("primia_conv_dgrad_masked_acc_ok", d2, dt) == 0
     assert query("primia_conv_dgrad_masked_acc_ok", desc, _lib.dtype_code(torch.float32)) == 0
+
+
+@pytest.fixture
+def c64_blocks():
+    """set the number of persistent blocks of conv3x3_c64_kernel (few blocks = many patches per block: the counted waits of
+    its staging ring only run then); restored afterwards"""
+    def set_blocks(n):
+        _lib.set_option("c64_blocks", n)
+    yield set_blocks
+    _lib.set_option("c64_blocks", 0)
+
+
+@pytest.mark.parametrize("N,H,blocks", [(2, 16, 0), (1, 56, 0), (3, 12, 0), (9, 8, 0), (2, 24, 0), (2, 24, 3), (4, 56, 5), (3, 12, 2)])
+def test_masked_accumulate_dgrad_with_residual_bn_backward_sums(cuda, c64_blocks, N, H, blocks):
+    """primia_conv2d_dgrad_masked_acc_bnsums, mode 2 (conv3x3_c64_kernel<true, 3, 2>): the accumulating data gradient of an
+    identity block's conv1 also forms the backward sums of the residual BatchNorm of the block in FRONT of it, +
+    primia_bn_bwd_mask_from_sums, against primia_conv2d_dgrad_masked_acc followed by primia_bn_bwd_mask with its own reduction
+    pass: dx bit-identical, dgamma / dbeta to summation order, dy to one bf16 rounding; partials bit-repeatable."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    C = 64
+    g = torch.Generator().manual_seed(11 * N + H)
+    c64_blocks(blocks)
+    desc = ConvDesc.make(N, H, H, C, C, 3, 3, 1, 1)
+    slots = query("primia_conv_dgrad_masked_acc_bnsums_slots", desc, dt)
+    assert slots > 0 and (blocks == 0 or slots <= blocks)
+    assert query("primia_conv_dgrad_masked_acc_bnsums_slots", ConvDesc.make(N, H, H, 128, 128, 3, 3, 1, 1), dt) == 0
+    _, wd = prep_weights(desc, rnd(torch.randn(C, C, 3, 3, generator=g) * 0.05, dtype), dtype, cuda, C)
+    M = N * H * H
+    dy1 = (torch.randn(M, C, generator=g) * 0.3).to(dtype).to(cuda)
+    base = (torch.randn(M, C, generator=g)).to(dtype).to(cuda)                 # gradient of the block's output
+    acc_mask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.int32).to(torch.uint8).to(cuda)
+    y = (torch.randn(M, C, generator=g) * 1.2 - 0.1).to(dtype).to(cuda)        # the residual BatchNorm's input
+    mask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.int32).to(torch.uint8).to(cuda)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    mean = y.float().mean(0)
+    invstd = 1.0 / torch.sqrt(y.float().var(0, unbiased=False) + 1e-5)
+    # the chain
+    dx_a = base.clone()
+    call("primia_conv2d_dgrad_masked_acc", desc, dy1, wd, dx_a, acc_mask, dt)
+    ws = torch.zeros(query("primia_bn_workspace_bytes", M, C), dtype=torch.uint8, device=cuda)
+    dy_a, dg_a, db_a = torch.empty_like(dx_a), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_bwd_mask", y, mask, dx_a, dy_a, None, gamma, mean, invstd, dg_a, db_a, M, C, ws, ws.numel(), dt)
+    # fused
+    dx_b = base.clone()
+    sums = torch.full((slots, 2, C), 5.0, device=cuda)
+    call("primia_conv2d_dgrad_masked_acc_bnsums", desc, dy1, wd, dx_b, acc_mask, 2, y, mask, mean, invstd, sums, dt)
+    dy_b, dg_b, db_b = torch.empty_like(dx_a), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_bwd_mask_from_sums", y, mask, dx_b, dy_b, None, gamma, mean, invstd, dg_b, db_b, sums, slots, M, C, dt)
+    assert torch.equal(dx_a, dx_b)
+    assert relerr(dg_b, dg_a) < 2e-5 and relerr(db_b, db_a) < 2e-5
+    assert relerr(dy_b.float(), dy_a.float()) < 2e-3
+    dx_c, sums2 = base.clone(), torch.empty_like(sums)
+    call("primia_conv2d_dgrad_masked_acc_bnsums", desc, dy1, wd, dx_c, acc_mask, 2, y, mask, mean, invstd, sums2, dt)
+    assert torch.equal(sums, sums2) and torch.equal(dx_c, dx_b)
+    with pytest.raises(_lib.PrimiaError):
+        call("primia_conv2d_dgrad_masked_acc_bnsums", desc, dy1, wd, dx_c, acc_mask, 2, y, None, mean, invstd, sums2, dt)
+    with pytest.raises(_lib.PrimiaError):
+        call("primia_conv2d_dgrad_masked_acc_bnsums", desc, dy1, wd, dx_c, acc_mask, 1, y, mask, mean, invstd, sums2, dt)
+
+
+@pytest.mark.parametrize("N,Hs,blocks", [(2, 32, 0), (1, 112, 0), (3, 24, 0), (2, 18, 0), (2, 112, 4), (3, 48, 2), (2, 18, 2)])
+def test_masked_accumulate_dgrad_with_stem_bn_backward_sums(cuda, c64_blocks, N, Hs, blocks):
+    """primia_conv2d_dgrad_masked_acc_bnsums, mode 3 (conv3x3_c64_kernel<true, 3, 3>): layer1.0.conv1's accumulating data
+    gradient writes the max-pool's output gradient and forms the stem BatchNorm's backward sums at pooled resolution, +
+    primia_bn_relu_maxpool_bwd_from_sums, against primia_conv2d_dgrad_masked_acc followed by primia_bn_relu_maxpool_bwd(dy = NULL)
+    — its PoolScatterFn reduction pass: dx bit-identical, dgamma / dbeta to summation order — one channel with gamma == 0
+    (served from y at the argmax by the finalize kernel)."""
+    dtype = torch.bfloat16
+    dt = _lib.dtype_code(dtype)
+    C = 64
+    g = torch.Generator().manual_seed(5 * N + Hs)
+    Ho = (Hs - 1) // 2 + 1
+    Ms, M = N * Hs * Hs, N * Ho * Ho
+    ystem = to_nhwc(rnd(torch.randn(N, C, Hs, Hs, generator=g) * 2 + 0.3, dtype), dtype, cuda)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    beta = (torch.randn(C, generator=g) * 0.5).to(cuda)
+    gamma[5], beta[5] = 0.0, 0.7
+    gamma[9] = -0.8
+    ws = torch.zeros(query("primia_bn_workspace_bytes", Ms, C), dtype=torch.uint8, device=cuda)
+    rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
+    sm, si = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    pool = torch.empty(M, C, dtype=dtype, device=cuda)
+    am = torch.empty(M, C, dtype=torch.uint8, device=cuda)
+    call("primia_bn_relu_maxpool_fwd", ystem, pool, am, gamma, beta, rm, rv, sm, si, N, Hs, Hs, C, 1e-5, 0.1, ws, ws.numel(), dt)
+    c64_blocks(blocks)
+    desc = ConvDesc.make(N, Ho, Ho, C, C, 3, 3, 1, 1)
+    slots = query("primia_conv_dgrad_masked_acc_bnsums_slots", desc, dt)
+    assert slots > 0
+    _, wd = prep_weights(desc, rnd(torch.randn(C, C, 3, 3, generator=g) * 0.05, dtype), dtype, cuda, C)
+    dy1 = (torch.randn(M, C, generator=g) * 0.3).to(dtype).to(cuda)
+    base = (torch.randn(M, C, generator=g)).to(dtype).to(cuda)
+    acc_mask = torch.randint(0, 256, (M * C // 8,), generator=g, dtype=torch.int32).to(torch.uint8).to(cuda)
+    # the chain
+    dp_a = base.clone()
+    call("primia_conv2d_dgrad_masked_acc", desc, dy1, wd, dp_a, acc_mask, dt)
+    dg_a, db_a = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_relu_maxpool_bwd", ystem, pool, dp_a, am, None, gamma, beta, sm, si, dg_a, db_a, N, Hs, Hs, C, ws,
+         ws.numel(), dt)
+    # fused
+    dp_b = base.clone()
+    sums = torch.full((slots, 2, C), 5.0, device=cuda)
+    call("primia_conv2d_dgrad_masked_acc_bnsums", desc, dy1, wd, dp_b, acc_mask, 3, pool, None, beta, gamma, sums, dt)
+    dg_b, db_b = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_relu_maxpool_bwd_from_sums", ystem, pool, dp_b, am, gamma, sm, si, dg_b, db_b, sums, slots, N, Hs, Hs, C, dt)
+    assert torch.equal(dp_a, dp_b)
+    assert relerr(db_b, db_a) < 2e-5 and relerr(dg_b, dg_a) < 2e-5
+    assert abs(float(dg_b[5]) - float(dg_a[5])) <= 2e-5 * max(1.0, abs(float(dg_a[5])))
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
