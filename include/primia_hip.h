@@ -677,6 +677,13 @@ int primia_head_fwd(const void* x, const float* w, const float* b, float* feat, 
                     int out_f, int dtype, primia_stream_t stream);
 int primia_head_bwd(const float* w, const float* dlogits, void* dx, int N, int HW, int C, int out_f, int dtype,
                     primia_stream_t stream);
+/* primia_head_bwd that also forms the backward sums of the residual BatchNorm whose output gradient it writes (the last block's
+ * bn2; dx = the gradient w.r.t. z = relu(bn(y) + identity), relu_mask = the bytes that layer's forward pass wrote): partials
+ * [N][2][C] of sum g and sum g * xhat for primia_bn_bwd_mask_from_sums(slots = N).  PRIMIA_ERR_UNSUPPORTED unless 256 is a
+ * multiple of C / (channels per 16-byte chunk). */
+int primia_head_bwd_bnsums(const float* w, const float* dlogits, void* dx, const void* bn_y, const uint8_t* relu_mask,
+                           const float* bn_mean, const float* bn_invstd, float* sums, int N, int HW, int C, int out_f, int dtype,
+                           primia_stream_t stream);
 /* ------------------------------------------------------------------------------------------
  * Classifier head and loss — replaces F.linear (models.py:479,495), nn.CrossEntropyLoss
  * (train.py:335-340) and Cross_entropy_one_hot (torchlib/utils.py:404-441).  All fp32.

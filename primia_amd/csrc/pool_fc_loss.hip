@@ -264,6 +264,68 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
     }
 }
 
+// ... that also forms the backward sums of the residual BatchNorm whose output gradient it writes (the last block's bn2:
+// dx = dz of z = relu(bn(y) + identity)): sum g, sum g * xhat with g = dx AS STORED * mask bit — the gradient is one value per
+// (image, channel), so the sums are that value times the count / the xhat sum of the unmasked pixels — as partials
+// [N][2][C] (primia_bn_bwd_mask_from_sums consumes them; the 11-us reduction pass over (y, dz) is dropped).
+template <typename T>
+__global__ __launch_bounds__(256) void head_bwd_bnsums_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                              T* __restrict__ dx, const T* __restrict__ bn_y,
+                                                              const uint8_t* __restrict__ relu_mask,
+                                                              const float* __restrict__ bn_mean,
+                                                              const float* __restrict__ bn_invstd, float* __restrict__ sums,
+                                                              int HW, int C, int out_f) {
+    constexpr int CH = Chunk<T>::N;
+    extern __shared__ float sh[];              // [C] gradient | [256 / cpr][2][C] partial sums
+    const int n = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float a = 0.f;
+        for (int j = 0; j < out_f; ++j) a += dy[(long)n * out_f + j] * w[(long)j * C + c];
+        sh[c] = a / (float)HW;
+    }
+    __syncthreads();
+    const int cpr = C / CH;                    // (256 % cpr == 0: a thread keeps its channel chunk)
+    const int c0 = (threadIdx.x % cpr) * CH;
+    float v[CH], vr[CH], mu[CH], cnt[CH], sx[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        v[i] = sh[c0 + i];
+        mu[i] = bn_mean[c0 + i];
+        cnt[i] = sx[i] = 0.f;
+    }
+    const u32x4 packed = Chunk<T>::pack(v);
+    Chunk<T>::unpack(packed, vr);              // the value as stored
+    for (int q = threadIdx.x; q < HW * cpr; q += 256) {
+        const long off = (long)n * HW * C + (long)q * CH;
+        *(u32x4*)(dx + off) = packed;
+        float yv[CH];
+        Chunk<T>::unpack(*(const u32x4*)(bn_y + off), yv);
+        const unsigned m = relu_mask[off / CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const bool on = (m >> i) & 1u;
+            cnt[i] += on ? 1.f : 0.f;
+            sx[i] += on ? yv[i] - mu[i] : 0.f;
+        }
+    }
+    float* red = sh + C;
+    const int grp = threadIdx.x / cpr;
+#pragma unroll
+    for (int i = 0; i < CH; ++i) {
+        red[(grp * 2 + 0) * C + c0 + i] = vr[i] * cnt[i];
+        red[(grp * 2 + 1) * C + c0 + i] = vr[i] * sx[i];
+    }
+    __syncthreads();
+    const int ngrp = 256 / cpr;
+    for (int c = threadIdx.x; c < 2 * C; c += 256) {
+        const int qq = c / C, cc = c - qq * C;
+        float a = 0.f;
+        for (int g = 0; g < ngrp; ++g) a += red[(g * 2 + qq) * C + cc];
+        if (qq) a *= bn_invstd[cc];
+        sums[((long)n * 2 + qq) * C + cc] = a;
+    }
+}
+
 // ---- cross entropy (single block; N is a batch size) ---------------------------------------------
 __device__ __forceinline__ float block_sum_256(float v, float* sh) {
     v = wave_sum(v);
@@ -455,6 +517,25 @@ int primia_head_bwd(const float* w, const float* dlogits, void* dx, int N, int H
         head_bwd_kernel<float><<<N, 256, lds, st>>>(w, dlogits, (float*)dx, HW, C, out_f);
     else
         head_bwd_kernel<bf16><<<N, 256, lds, st>>>(w, dlogits, (bf16*)dx, HW, C, out_f);
+    return launch_status();
+}
+
+int primia_head_bwd_bnsums(const float* w, const float* dlogits, void* dx, const void* bn_y, const uint8_t* relu_mask,
+                           const float* bn_mean, const float* bn_invstd, float* sums, int N, int HW, int C, int out_f, int dtype,
+                           primia_stream_t stream) {
+    PRIMIA_REQUIRE(w && dlogits && dx && bn_y && relu_mask && bn_mean && bn_invstd && sums && N > 0 && HW > 0 && C > 0 && out_f > 0);
+    PRIMIA_REQUIRE((dtype == PRIMIA_F32 || dtype == PRIMIA_BF16) && head_shape_ok(C, dtype));
+    const int cpr = C / (dtype == PRIMIA_F32 ? 4 : 8);
+    if (cpr > 256 || 256 % cpr) return PRIMIA_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = (size_t)(1 + 2 * (256 / cpr)) * C * sizeof(float);
+    if (lds > 48 * 1024) return PRIMIA_ERR_UNSUPPORTED;
+    if (dtype == PRIMIA_F32)
+        head_bwd_bnsums_kernel<float><<<N, 256, lds, st>>>(w, dlogits, (float*)dx, (const float*)bn_y, relu_mask, bn_mean,
+                                                           bn_invstd, sums, HW, C, out_f);
+    else
+        head_bwd_bnsums_kernel<bf16><<<N, 256, lds, st>>>(w, dlogits, (bf16*)dx, (const bf16*)bn_y, relu_mask, bn_mean,
+                                                          bn_invstd, sums, HW, C, out_f);
     return launch_status();
 }
 

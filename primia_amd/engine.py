@@ -485,6 +485,8 @@ class ResNet18Engine:
     # it completes: layer1.0's bn2 (layer1.1.conv1) and the stem's bn1 through the max-pool (layer1.0.conv1) —
     # primia_conv2d_dgrad_masked_acc_bnsums; the two most expensive reduction passes of the step (43 + 48 us)
     acc_bnsums = True
+    # ... and the head's backward pass the sums of the last block's bn2 (primia_head_bwd_bnsums)
+    head_bnsums = True
     # conv1 + downsample data gradients of a transition block in one pass (primia_conv2d_dgrad_pair)
     pair_dgrad = True
     # identity blocks: conv1's accumulating data gradient applies bn2's ReLU mask to the old values itself
@@ -804,6 +806,10 @@ class ResNet18Engine:
             torch.cuda.current_stream().wait_stream(self._wg_stream)
             self._wg_pending = False
 
+    def _head_bnsums_ok(self):
+        # primia_head_bwd_bnsums: 256 threads must be a multiple of the 16-byte chunks of a 512-channel row
+        return 256 % (512 // (4 if self.dtype == torch.float32 else 8)) == 0
+
     def _stem_bwd_fused_wanted(self):
         """The stem's backward tail runs as primia_bn_relu_maxpool_bwd (sums only) + primia_stem_bwd_fused."""
         if getattr(self, "_stem_bwd_fused_ok", None) is None:     # asked once: the library's own gate for this shape
@@ -849,8 +855,18 @@ class ResNet18Engine:
              self._gviews["fc.weight"], self._gviews["fc.bias"], N, 512, nc)
         last = self.spec.blocks[-1].prefix
         hw = self.final_hw
-        call("primia_head_bwd", self.views["fc.weight"], self.dlogits, t[last + ".dout"], N, hw * hw, 512, nc, self.dt)
         blocks = self.spec.blocks
+        lb2 = bn_name(blocks[-1].conv2.name)
+        if (self.head_bnsums and self.norm == "batch" and self.dp is None and blocks[-1].down is None and lb2 in self.relu_masks
+                and self._head_bnsums_ok()):
+            # ... forming the backward sums of the last block's bn2 on the way (one value per image and channel)
+            sums = self._bwd_sums("head", N, 512)
+            sml, sil = self.save[lb2]
+            call("primia_head_bwd_bnsums", self.views["fc.weight"], self.dlogits, t[last + ".dout"], t[last + ".y2"],
+                 self.relu_masks[lb2], sml, sil, sums, N, hw * hw, 512, nc, self.dt)
+            self._dout_sums[last] = (sums, N)
+        else:
+            call("primia_head_bwd", self.views["fc.weight"], self.dlogits, t[last + ".dout"], N, hw * hw, 512, nc, self.dt)
         for i in range(len(blocks) - 1, -1, -1):
             blk = blocks[i]
             p = blk.prefix

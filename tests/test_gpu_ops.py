@@ -336,6 +336,38 @@ def test_head_fused_resnet_shape(cuda, dtype):
     assert relerr(from_nhwc(dx, N, 7, 7), xr.grad) < tol(dtype)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_head_backward_with_bn_backward_sums(cuda, dtype):
+    """primia_head_bwd_bnsums: the head's backward pass also forms the backward sums of the last block's residual BatchNorm, +
+    primia_bn_bwd_mask_from_sums, against primia_head_bwd followed by primia_bn_bwd_mask with its own reduction pass: dx
+    bit-identical, dgamma / dbeta to summation order, dy to one rounding."""
+    N, C, NC, HW = 5, 512, 3, 49
+    dt = _lib.dtype_code(dtype)
+    g = torch.Generator().manual_seed(31)
+    w = (torch.randn(NC, C, generator=g) * 0.05).to(cuda)
+    dl = torch.randn(N, NC, generator=g).to(cuda)
+    M = N * HW
+    ch = 4 if dtype == torch.float32 else 8
+    y = (torch.randn(M, C, generator=g) * 1.2 - 0.1).to(dtype).to(cuda)
+    mask = torch.randint(0, 1 << ch, (M * C // ch,), generator=g, dtype=torch.int32).to(torch.uint8).to(cuda)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(cuda)
+    mean = y.float().mean(0)
+    invstd = 1.0 / torch.sqrt(y.float().var(0, unbiased=False) + 1e-5)
+    dx_a = torch.empty(M, C, dtype=dtype, device=cuda)
+    call("primia_head_bwd", w, dl, dx_a, N, HW, C, NC, dt)
+    ws = torch.zeros(query("primia_bn_workspace_bytes", M, C), dtype=torch.uint8, device=cuda)
+    dy_a, dg_a, db_a = torch.empty_like(dx_a), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_bwd_mask", y, mask, dx_a, dy_a, None, gamma, mean, invstd, dg_a, db_a, M, C, ws, ws.numel(), dt)
+    dx_b = torch.empty_like(dx_a)
+    sums = torch.full((N, 2, C), 5.0, device=cuda)
+    call("primia_head_bwd_bnsums", w, dl, dx_b, y, mask, mean, invstd, sums, N, HW, C, NC, dt)
+    dy_b, dg_b, db_b = torch.empty_like(dx_a), torch.empty(C, device=cuda), torch.empty(C, device=cuda)
+    call("primia_bn_bwd_mask_from_sums", y, mask, dx_b, dy_b, None, gamma, mean, invstd, dg_b, db_b, sums, N, M, C, dt)
+    assert torch.equal(dx_a, dx_b)
+    assert relerr(dg_b, dg_a) < 2e-5 and relerr(db_b, db_a) < 2e-5
+    assert relerr(dy_b.float(), dy_a.float()) < (1e-5 if dtype == torch.float32 else 2e-3)
+
+
 @pytest.mark.parametrize("weighted", [False, True])
 def test_xent(cuda, weighted):
     import sys, os
