@@ -3,4 +3,4 @@
 for o in ${C64_DBG_BITS:-0 8 16 24 64 88}; do
   python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-secure --sustain-s 0 --opt c64_dbg=$o 2>/dev/null > gpurun_out/c64dbg_$o.log
 done
-python tools/show_layers.py gpurun_out/c64dbg_*.log
+python tools/show_layers.py dgrad:layer1 gpurun_out/c64dbg_*.log

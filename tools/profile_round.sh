@@ -18,4 +18,4 @@ python3 tools/hbm_traffic.py $(find $O/fetch -name "*.db" | head -1) $(find $O/w
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $O/insts --output-format rocpd -- $B > $O/insts.log 2>&1
 python3 tools/rocpd_pmc.py $(find $O/insts -name "*.db" | head -1) kernel | cut -c1-250 > profiles/${R}_inst_mix_latest.txt
 head -12 profiles/${R}_bench_kernel_stats.csv
-cp profiles/${R}_* gpurun_out/ 2>/dev/null
+for f in bench_kernel_stats.csv mfma_util.json hbm_traffic.json inst_mix_latest.txt; do cp profiles/${R}_$f gpurun_out/ 2>/dev/null; done   # (only what this script made: the box's gpurun_out/ is merged back)
