@@ -40,6 +40,25 @@ __device__ __forceinline__ int c64_key(int slot) {
     return (0x265a9888u >> (3 * ((slot >> 1) % 10))) & 7;
 }
 
+// C64_PROBE (experiment builds only: hipcc -DC64_PROBE=1, tools/micro/c64_probe.sh): per-wave cycles (s_memtime) spent in the
+// phases of an iteration — [top wait | barrier | rows + requests | stores + sums | matrix loop | tail], summed over the block's
+// patches, + the iteration count; tools/micro/c64_probe.py reads them.  s_memtime returns through lgkmcnt, so every probe also
+// drains the wave's LDS queue.
+#ifndef C64_PROBE
+#define C64_PROBE 0
+#endif
+#if C64_PROBE
+__device__ unsigned long long c64_probe_buf[1024 * 4 * 8];
+#define C64_T(i)                                                      \
+    {                                                                 \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        tacc[i] += now_ - tlast;                                      \
+        tlast = now_;                                                 \
+    }
+#else
+#define C64_T(i)
+#endif
+
 struct C64Params {
     const bf16* src;
     const bf16* wt;   // [64][576] forward-layout weights (fwd: w_fwd, dgrad: w_dgrad)
@@ -112,6 +131,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (t1 > p.total) t1 = p.total;
     const int nstages = t1 - t0;
     if (nstages <= 0) return;
+#if C64_PROBE
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tlast = 0;
+#endif
 
     // ---- weights -> registers: A fragment (i, j): row 32*kh + 16*i + fr, elements j*32 + 8*fg .. +7 -------
     bf16x8_t wreg[18][2];
@@ -226,11 +249,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // so the counted wait at the top of the loop covers them.
     constexpr int NOLD = ACC ? 4 : 0;                          // vector-memory loads of one prefetch_old()
     constexpr int NAUX = BNB ? (BNB == 2 ? 4 : 2) : 0;         // ... of one prefetch_aux()
-    c64_i32x4 rsrc_dst = rsrc, rsrc_aux = rsrc;
-    if constexpr (ACC) {
+    c64_i32x4 rsrc_aux = rsrc;
+    // (the output rows leave through a buffer descriptor too: scalar base + 32-bit lane offset, out-of-image lanes get an offset
+    // beyond num_records and are dropped — no 64-bit pointers, no exec-mask branch around the store; the accumulate form's old
+    // rows come in through the same descriptor)
+    c64_i32x4 rsrc_st = rsrc;
+    {
         const unsigned long long a = (unsigned long long)(const void*)p.dst;
-        rsrc_dst[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-        rsrc_dst[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+        rsrc_st[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+        rsrc_st[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
     }
     if constexpr (BNB != 0) {
         const unsigned long long a = (unsigned long long)(const void*)p.bnb_y;
@@ -262,7 +289,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const unsigned voff = live ? (pix * 64u + (unsigned)(4 * kh + (cc ^ ((pxl >> 1) & 3))) * 8u) * 2u : kOob;
                 const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + (wave * 2 + q) * 1024);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-                             ::"v"(voff), "s"(rsrc_dst), "s"(m0v) : "memory");
+                             ::"v"(voff), "s"(rsrc_st), "s"(m0v) : "memory");
             }
             // the mask word of accumulator pixel fr (the write order above is by pixel lane / 4; the READ is by fr)
 #pragma unroll
@@ -312,7 +339,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int i = 0; i < 2; ++i) acc[q][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // B fragments: 3-deep register ring, reads run two steps ahead of the MFMAs that consume them
+        // B fragments: 3-deep register ring, reads run two steps ahead of the MFMAs that consume them (4-deep: measured, no
+        // change — the matrix loop does not wait for its fragments)
         bf16x8_t bq[3][2];
         auto rd = [&](int step, int slot) {
             const int x = (step & 1) * 64;
@@ -334,6 +362,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+#if C64_PROBE
+        {
+            const unsigned long long now_ = __builtin_readcyclecounter();
+            tacc[4] += now_ - tlast;
+            tlast = now_;
+        }
+#endif
         if constexpr (ACC) {
             // the old rows of this patch have landed once only the loads issued after them remain in flight (loads retire
             // in order; stores do not count against them: see the loop's wait below)
@@ -392,29 +427,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
     for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.f;
 
-    auto writeback = [&](int obuf) {
-        const int px = lane >> 3, c16 = lane & 7;  // pixel of the row, 16-B chunk
+    // The write-back of a patch in two parts, so that the loop can put its requests between them: wb_load reads the rows (and,
+    // sums forms, the BatchNorm rows and mask words) from LDS into registers — the fragment ring and the accumulators are dead
+    // here, the registers are free — wb_finish stores the rows and does the arithmetic.
+    struct WbRegs {
+        u32x4 v[2], yv[2];
+        unsigned bm[2], so[2];     // mask byte of the lane's chunk; byte offset of the lane's 16-byte chunk in dst
         bool live[2];
-        bf16* gp[2];
+    };
+    auto wb_load = [&](int obuf, WbRegs& r) {
+        const int px = lane >> 3, c16 = lane & 7;  // pixel of the row, 16-B chunk
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int g = 2 * wave + q;                // patch row handled by this wave
             const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
-            live[q] = cw.t < t1 && ho < p.H && wo < p.W;
-            gp[q] = p.dst + ((long)(cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8;
+            r.live[q] = cw.t < t1 && ho < p.H && wo < p.W;
+            r.so[q] = r.live[q] && !(p.debug & 1) ? (unsigned)(((cw.n * p.H + ho) * p.W + wo) * 128 + c16 * 16) : kOob;
+            const int opx2 = g * 8 + px;
+            r.v[q] = *(const u32x4*)(sout + obuf * OUTB + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
+            if constexpr (BNB != 0) {
+                // the BatchNorm input row chunk of this pixel (requested an iteration ago, by THIS wave)
+                r.yv[q] = *(const u32x4*)(saux + g * 1024 + lane * 16);
+                if constexpr (BNB == 2) r.bm[q] = *(const unsigned*)(sbm + g * 256 + lane * 4) >> (8 * (c16 & 3));
+            }
         }
         advance(cw);
+    };
+    auto wb_finish = [&](const WbRegs& r) {
+        const int c16 = lane & 7;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int opx2 = (2 * wave + q) * 8 + px;
-            const u32x4 v = *(const u32x4*)(sout + obuf * OUTB + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
-            if (live[q] && !((p.debug & 1) && v[0] != 12345u)) {
-                *(u32x4*)gp[q] = v;      // (non-temporal stores: measured, no change — 4.862 vs 4.861 ms per step)
+            const u32x4 v = r.v[q];
+            // rows out through the buffer descriptor: out-of-image lanes carry an offset beyond num_records and are dropped
+            // (non-temporal stores: measured, no change — 4.862 vs 4.861 ms per step)
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(r.so[q]), "s"(rsrc_st) : "memory");
+            if (r.live[q]) {
                 if (BNB != 0 && !(p.debug & 8)) {
-                    // the BatchNorm input row chunk of this pixel (requested an iteration ago, by THIS wave)
-                    const u32x4 yv = *(const u32x4*)(saux + (2 * wave + q) * 1024 + lane * 16);
-                    unsigned bmq = 0;
-                    if constexpr (BNB == 2) bmq = *(const unsigned*)(sbm + (2 * wave + q) * 256 + lane * 4) >> (8 * (c16 & 3));
+                    const u32x4 yv = r.yv[q];
+                    const unsigned bmq = r.bm[q];
                     const f32x4 mu0 = *(const f32x4*)(bnc + c16 * 8), mu1 = *(const f32x4*)(bnc + c16 * 8 + 4);
                     f32x4 sc0, sc1, be0, be1;
                     if constexpr (BNB == 1) {
@@ -451,9 +501,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    // STAGES-deep LDS ring, one raw barrier per stage, counted vmcnt.  Per iteration s a wave issues, in this order: 2 row
-    // stores (write-back of patch s - 1), NAUX loads (BatchNorm rows of patch s), d halo pieces of patch s + STAGES - 1
-    // (d = 4 for wave 0, else 3), and at the end of compute(s) NOLD loads (old rows of patch s + 1).  Loads retire in order,
+    // STAGES-deep LDS ring, one raw barrier per stage, counted vmcnt.  Per iteration s a wave issues, in this order: NAUX
+    // loads (BatchNorm rows of patch s), d halo pieces of patch s + STAGES - 1 (d = 4 for wave 0, else 3), 2 row stores
+    // (write-back of patch s - 1), and at the end of compute(s) NOLD loads (old rows of patch s + 1).  Loads retire in order,
     // so "at most n in flight" means "only the n youngest": at the top of iteration s the halo of patch s (and the
     // BatchNorm rows requested after it) have landed once only the younger halo pieces and the old rows remain.
     // Ragged images and the last stage drain (vmcnt(0)).
@@ -467,11 +517,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (s < nstages) stage(s);
     prefetch_old();            // patch 0's old rows: the youngest loads at the top of iteration 0, as in every iteration
     int cur = 0, nxt = STAGES - 1;
+#if C64_PROBE
+    tlast = __builtin_readcyclecounter();
+#endif
     for (int s = 0; s < nstages; ++s) {
         // 4-deep ring (plain / accumulate): patches s + 1 and s + 2 may stay in flight; with BatchNorm rows (3-deep): s + 1 only
         const int keep = (STAGES == 4 && s + 2 < nstages) ? 2 : (s + 1 < nstages ? 1 : 0);
         if (exact && keep) {
             // (4-deep accumulate form: the old rows of patch s - 1, long landed, still sit between the two halos in issue order)
+            // (what this wait waits for is the halo, not the row stores that also count: allowing two more — unsafe, timing
+            // only — moved it from 507 to 483 cycles per patch; with the write-back phase shortened the kernel runs at 4.0 TB/s
+            // and the requests of three patches ahead queue behind the memory system's throughput)
             switch (keep * dstage + (keep == 2 && s > 0 ? 2 : 1) * NOLD) {
                 case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
                 case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
@@ -490,11 +546,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // the result rows this wave wrote to LDS in the previous iteration must have LANDED before the barrier lets
         // the other waves read them (a raw s_barrier does not wait for the wave's own outstanding ds_write; with two
         // blocks per CU competing for the LDS the write-back occasionally read a stale 1-KiB row)
+        C64_T(0)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        C64_T(1)
+        // Outside the matrix loop the wave issues its vector-memory instructions ahead of the other block's wave on this SIMD,
+        // which is multiplying (the reverse — matrix loop first — is slower than no priorities at all: 73.8 us).
+        __builtin_amdgcn_s_setprio(3);
         int younger = 0;       // loads issued in this iteration, after the old rows of patch s
-        if (s > 0) {
-            writeback((s - 1) & 1);
+        // Order: the previous patch's rows LDS -> registers; then this iteration's requests — the BatchNorm rows of patch s
+        // (their buffer has just been read), the halo pieces — and only then the row stores, which fill the memory pipe, and
+        // the arithmetic.  Layer1's forward convolution alone (tools/micro/c64_probe.py): 71.7 us with the stores first through
+        // 64-bit pointers, 68.3 with the priority and the descriptor, 64.7 with the halo requests before the stores, 63.4 with
+        // the LDS reads before the requests.
+        WbRegs wb;
+        if (s > 0) wb_load((s - 1) & 1, wb);
+        if (BNB != 0 && s > 0) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the reads above are done before new rows may land in the buffer
             prefetch_aux();    // the cursor now points at patch s, written back in iteration s + 1
             younger += (p.debug & 32) ? 0 : NAUX;
         }
@@ -502,13 +570,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             stage(nxt);
             younger += dstage;
         }
+        C64_T(2)
+        if (s > 0) wb_finish(wb);
+        C64_T(3)
+        __builtin_amdgcn_s_setprio(0);
         compute(cur, s & 1, exact ? younger : 0);
+        C64_T(5)
         cur = cur + 1 == STAGES ? 0 : cur + 1;
         nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
     }
+#if C64_PROBE
+    if (lane == 0 && blockIdx.x < 1024) {
+        for (int i = 0; i < 6; ++i) c64_probe_buf[(blockIdx.x * 4 + wave) * 8 + i] = tacc[i];
+        c64_probe_buf[(blockIdx.x * 4 + wave) * 8 + 6] = (unsigned long long)nstages;
+    }
+#endif
     if constexpr (ACC || BNB != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    writeback((nstages - 1) & 1);
+    {
+        WbRegs wb;
+        wb_load((nstages - 1) & 1, wb);
+        wb_finish(wb);
+    }
     if (p.stat_partials) {
         // lanes with equal (lane & 7) hold the same 8 channels: fold the 8 pixel lanes, then the 4 waves
 #pragma unroll
@@ -624,3 +707,9 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
 }
 
 }  // namespace primia
+
+#if C64_PROBE
+extern "C" int primia_c64_probe_read(unsigned long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(primia::c64_probe_buf), (size_t)n * 8) == hipSuccess ? 0 : 1;
+}
+#endif

@@ -68,6 +68,9 @@ struct Lh2Params {
 #ifndef LH2_PRIO
 #define LH2_PRIO 1
 #endif
+#ifndef LH2_PRIO_LOAD
+#define LH2_PRIO_LOAD 0      // priority outside the matrix segments (experiment: 3 with LH2_PRIO 0 = the reverse of the default)
+#endif
 #ifndef LH2_SWAP
 #define LH2_SWAP 0
 #endif
@@ -295,7 +298,7 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
         tri = tri == 2 ? 0 : tri + 1;
     };
     auto mfma_segment = [&]() {
-#if LH2_PRIO
+#if LH2_PRIO || LH2_PRIO_LOAD
         __builtin_amdgcn_s_setprio(LH2_PRIO);   // the partner's load segment must not take issue slots from the MFMAs
 #endif
         if (!(LH2_DBG & 8)) {
@@ -327,8 +330,8 @@ __device__ __forceinline__ void lh2_run(const Lh2Params& p, char* smem, int tile
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#if LH2_PRIO
-        __builtin_amdgcn_s_setprio(0);
+#if LH2_PRIO || LH2_PRIO_LOAD
+        __builtin_amdgcn_s_setprio(LH2_PRIO_LOAD);
 #endif
     };
 
