@@ -48,7 +48,7 @@ __device__ __forceinline__ int c64_key(int slot) {
 #define C64_PROBE 0
 #endif
 #if C64_PROBE
-__device__ unsigned long long c64_probe_buf[1024 * 4 * 8];
+__device__ unsigned long long c64_probe_buf[1024 * 4 * 16];
 #define C64_T(i)                                                      \
     {                                                                 \
         const unsigned long long now_ = __builtin_readcyclecounter(); \
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int nstages = t1 - t0;
     if (nstages <= 0) return;
 #if C64_PROBE
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long tacc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};     // 6 .. 8: the accumulate form's tail in parts
     unsigned long long tlast = 0;
 #endif
 
@@ -382,6 +382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
                 default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
             }
+            C64_T(6)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const char* ob = sold + (wave * 2 + q) * 1024 + fr * 64 + (fg & 1) * 8;
@@ -400,7 +401,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next patch's rows may land
+            C64_T(7)
             prefetch_old();
+            C64_T(8)
         }
         // ---- results -> LDS rows (bf16, ONE rounding) -----------------------------------------------------------
         // pixel opix = 32*ph + 16*q + fr of the patch, 8-byte column 8*kh + 4*i + fg of its 128-B row,
@@ -581,8 +584,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 #if C64_PROBE
     if (lane == 0 && blockIdx.x < 1024) {
-        for (int i = 0; i < 6; ++i) c64_probe_buf[(blockIdx.x * 4 + wave) * 8 + i] = tacc[i];
-        c64_probe_buf[(blockIdx.x * 4 + wave) * 8 + 6] = (unsigned long long)nstages;
+        for (int i = 0; i < 10; ++i) c64_probe_buf[(blockIdx.x * 4 + wave) * 16 + i] = tacc[i];
+        c64_probe_buf[(blockIdx.x * 4 + wave) * 16 + 10] = (unsigned long long)nstages;
     }
 #endif
     if constexpr (ACC || BNB != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

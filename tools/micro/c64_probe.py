@@ -52,15 +52,15 @@ for _ in range(10):
 e1.record()
 torch.cuda.synchronize()
 print(f"{variant}: launch {e0.elapsed_time(e1) * 100:.1f} us (probe build)")
-n = slots * 4 * 8
+n = slots * 4 * 16
 buf = (ctypes.c_ulonglong * n)()
 fn = lib().primia_c64_probe_read
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
 assert fn(ctypes.cast(buf, ctypes.c_void_p), n) == 0
-a = np.frombuffer(buf, dtype=np.uint64).reshape(slots, 4, 8).astype(np.float64)
-it = a[:, :, 6]
-names = ["top wait", "barrier", "rows + requests", "stores + sums", "matrix loop", "tail"]
-per = a[:, :, :6] / it[:, :, None]
+a = np.frombuffer(buf, dtype=np.uint64).reshape(slots, 4, 16).astype(np.float64)
+it = a[:, :, 10]
+names = ["top wait", "barrier", "rows + requests", "stores + sums", "matrix loop", "tail (rest)", "tail: old-row wait", "tail: old rows + add", "tail: next old rows"]
+per = a[:, :, :9] / it[:, :, None]
 print(f"{slots} blocks x 4 waves, {it.mean():.1f} patches per block; cycles per patch and wave (mean over blocks | wave 0..3):")
 for i, nm in enumerate(names):
     print(f"  {nm:14s} {per[:, :, i].mean():8.0f}   | " + " ".join(f"{per[:, wv, i].mean():7.0f}" for wv in range(4)))
