@@ -119,8 +119,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // load was issued — before its data arrived (seen: v_mov of the two mask registers at the loop latch, wrong masks once a
     // block ran more than a few patches)
     constexpr int SMK_OFF = STAGES * STAGE + 2 * OUTB + (ACC ? 8192 : 0) + (BNB ? 8192 + 1024 : 0);
-    char* const smk = smem + SMK_OFF;                 // accumulate form: 2 KiB
-    char* const sbm = smk + (ACC ? 2048 : 0);         // BNB = 2: 2 KiB
+    char* const smk = smem + SMK_OFF;                 // accumulate form: 1 KiB ([wave][64 lanes])
+    char* const sbm = smk + (ACC ? 1024 : 0);         // BNB = 2: 1 KiB
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int kh = wave >> 1, ph = wave & 1;
@@ -247,8 +247,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // BNB: the BatchNorm rows of patch s are requested in iteration s (after the write-back of patch s - 1 has read the
     // buffer) and read by the write-back of patch s in iteration s + 1 — older than the halo pieces requested after them,
     // so the counted wait at the top of the loop covers them.
-    constexpr int NOLD = ACC ? 4 : 0;                          // vector-memory loads of one prefetch_old()
-    constexpr int NAUX = BNB ? (BNB == 2 ? 4 : 2) : 0;         // ... of one prefetch_aux()
+    constexpr int NOLD = ACC ? 3 : 0;                          // vector-memory loads of one prefetch_old()
+    constexpr int NAUX = BNB ? (BNB == 2 ? 3 : 2) : 0;         // ... of one prefetch_aux()
     c64_i32x4 rsrc_aux = rsrc;
     // (the output rows leave through a buffer descriptor too: scalar base + 32-bit lane offset, out-of-image lanes get an offset
     // beyond num_records and are dropped — no 64-bit pointers, no exec-mask branch around the store; the accumulate form's old
@@ -291,15 +291,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                              ::"v"(voff), "s"(rsrc_st), "s"(m0v) : "memory");
             }
-            // the mask word of accumulator pixel fr (the write order above is by pixel lane / 4; the READ is by fr)
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int ho = co.ph * 8 + 4 * ph + 2 * q + (fr >> 3), wo = co.pw * 8 + (fr & 7);
+            // the mask words of the accumulator pixels (the write order above is by pixel lane / 4; the READ is by fr): ONE
+            // instruction for both column blocks — lane l fetches the word of (q = (l >> 4) & 1, pixel l & 15); an LDS-DMA
+            // instruction costs ~300 cycles of issue in this phase whatever it moves (tools/micro/c64_probe.py)
+            {
+                const int q = (lane >> 4) & 1, f = lane & 15;
+                const int ho = co.ph * 8 + 4 * ph + 2 * q + (f >> 3), wo = co.pw * 8 + (f & 7);
                 const bool live = co.t < t1 && ho < p.H && wo < p.W;
                 const unsigned pix = (unsigned)((co.n * p.H + ho) * p.W + wo);
                 // (no mask: the load is issued all the same — the wait counts below are per prefetch — and ignored)
                 const uint8_t* mp = p.acc_mask ? p.acc_mask + (live ? pix * 8u + 4u * kh : 0u) : (const uint8_t*)p.wt;
-                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + SMK_OFF + (wave * 2 + q) * 256);
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + SMK_OFF + wave * 256);
                 asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(mp), "s"(m0v) : "memory");
             }
             advance(co);
@@ -319,11 +321,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + (ACC ? 8192 : 0) + g * 1024);
                 asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
                              ::"v"(voff), "s"(rsrc_aux), "s"(m0v) : "memory");
-                if constexpr (BNB == 2) {     // the dword that holds the lane's mask byte (pixel * 8 + chunk)
-                    const uint8_t* mp = p.bnb_mask + (live ? ((eoff >> 3) & ~3u) : 0u);
-                    const unsigned m1v = __builtin_amdgcn_readfirstlane(lds0 + SMK_OFF + (ACC ? 2048 : 0) + g * 256);
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(mp), "s"(m1v) : "memory");
-                }
+            }
+            if constexpr (BNB == 2) {     // the dwords that hold the wave's mask bytes (pixel * 8 + chunk): ONE instruction for both
+                                          // row groups — lane l: row group l >> 5, pixel (l >> 2) & 7, word (l >> 1) & 1
+                const int q = lane >> 5, pxm = (lane >> 2) & 7, hw = (lane >> 1) & 1;
+                const int ho = cw.ph * 8 + 2 * wave + q, wo = cw.pw * 8 + pxm;
+                const bool live = cw.t < t1 && ho < p.H && wo < p.W && !(p.debug & 16);
+                const unsigned pix = (unsigned)((cw.n * p.H + ho) * p.W + wo);
+                const uint8_t* mp = p.bnb_mask + (live ? pix * 8u + 4u * hw : 0u);
+                const unsigned m1v = __builtin_amdgcn_readfirstlane(lds0 + SMK_OFF + (ACC ? 1024 : 0) + wave * 256);
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(mp), "s"(m1v) : "memory");
             }
         }
     };
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int q = 0; q < 2; ++q) {
                 const char* ob = sold + (wave * 2 + q) * 1024 + fr * 64 + (fg & 1) * 8;
                 // ReLU-mask bytes of the wave's channel half (4 chunks) for accumulator pixel fr
-                const unsigned mkq = p.acc_mask ? *(const unsigned*)(smk + (wave * 2 + q) * 256 + lane * 4) : 0xffffffffu;
+                const unsigned mkq = p.acc_mask ? *(const unsigned*)(smk + wave * 256 + (q * 16 + fr) * 4) : 0xffffffffu;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int c4 = 2 * i + (fg >> 1);          // 16-B chunk of the wave's channel half
@@ -451,7 +458,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if constexpr (BNB != 0) {
                 // the BatchNorm input row chunk of this pixel (requested an iteration ago, by THIS wave)
                 r.yv[q] = *(const u32x4*)(saux + g * 1024 + lane * 16);
-                if constexpr (BNB == 2) r.bm[q] = *(const unsigned*)(sbm + g * 256 + lane * 4) >> (8 * (c16 & 3));
+                if constexpr (BNB == 2)
+                    r.bm[q] = *(const unsigned*)(sbm + wave * 256 + (q * 32 + px * 4 + (c16 >> 2) * 2) * 4) >> (8 * (c16 & 3));
             }
         }
         advance(cw);
@@ -537,7 +545,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
                 case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
                 case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
                 case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+                case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
                 case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
                 case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
                 case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
@@ -676,9 +686,9 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     const int deep = PRIMIA_OPT(c64_stages);
     const int stages = (!with_bnb && !amode && deep == 4) ? 4 : 3;
     auto lds_of = [](int stg, bool acc, bool aux) {
-        return stg * 13 * 1024 + 2 * 64 * 128 + (acc ? 8192 + 2048 : 0) + (aux ? 8192 + 1024 : 0);
+        return stg * 13 * 1024 + 2 * 64 * 128 + (acc ? 8192 + 1024 : 0) + (aux ? 8192 + 1024 : 0);
     };
-    const size_t lds = (size_t)lds_of(stages, accumulate != 0, with_bnb || amode) + (amode == 2 ? 2048 : 0);
+    const size_t lds = (size_t)lds_of(stages, accumulate != 0, with_bnb || amode) + (amode == 2 ? 1024 : 0);
     static bool attr_set = false;
     if (!attr_set) {
         const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
@@ -687,7 +697,7 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
             hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3, 1>, attr, lds_of(3, false, true)) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3>, attr, lds_of(3, true, false)) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 4>, attr, lds_of(4, true, false)) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3, 2>, attr, lds_of(3, true, true) + 2048) != hipSuccess ||
+            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3, 2>, attr, lds_of(3, true, true) + 1024) != hipSuccess ||
             hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3, 3>, attr, lds_of(3, true, true)) != hipSuccess)
             return PRIMIA_ERR_LAUNCH;
         attr_set = true;
