@@ -470,8 +470,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 2; ++q) {
             const u32x4 v = r.v[q];
             // rows out through the buffer descriptor: out-of-image lanes carry an offset beyond num_records and are dropped
+            // (s_nop 1: a 16-byte store reads its data registers for two more cycles; the hazard recognizer does not look inside asm)
             // (non-temporal stores: measured, no change — 4.862 vs 4.861 ms per step)
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen" ::"v"(v), "v"(r.so[q]), "s"(rsrc_st) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(r.so[q]), "s"(rsrc_st) : "memory");
             if (r.live[q]) {
                 if (BNB != 0 && !(p.debug & 8)) {
                     const u32x4 yv = r.yv[q];
