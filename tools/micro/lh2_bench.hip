@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "../../primia_amd/csrc/conv3x3_lh2.hip"
+#include "../../primia_amd/csrc/conv3x3_lh4.hip"   // (conv3x3_lh2_dispatch hands the 196-pixel tiles to it)
 #include "../../primia_amd/csrc/options.hip"   // the option table the dispatch code reads
 
 using namespace primia;
