@@ -553,19 +553,32 @@ __device__ __forceinline__ void patch33_body(const PatchParams& p, int bid_in) {
                 int ahead = nstages - 1 - s;
                 if (ahead > STAGES - 2) ahead = STAGES - 2;
                 wait_inflight(ahead);                  // this wave's pieces of stage s have landed
+                WGP33_MARK(1)
                 __builtin_amdgcn_s_barrier();          // ... everybody's have, and stage s - 1 has been multiplied
+                WGP33_MARK(2)
                 do_issue = s + STAGES - 1 < nstages && !(WGP33_DBG & 2);
                 if (do_issue) stage(nxt);              // into the buffer stage s - 1 occupied
+                WGP33_MARK(0)
                 nxt = nxt + 1 == STAGES ? 0 : nxt + 1;
             }
+#ifdef WGP33_PROF
+            if (lane == 0 && wgp33_prof_buffer_dev)
+                for (int k = 0; k < 6; ++k) wgp33_prof_buffer_dev[((long)blockIdx.x * 8 + wave) * 6 + k] = prof_t[k];
+#endif
             return;
         }
         for (int s = 0; s < nstages; ++s) {
             __builtin_amdgcn_s_barrier();
+            WGP33_MARK(2)
             compute(cur, 0);
             compute(cur, 1);
+            WGP33_MARK(3)
             cur = cur + 1 == STAGES ? 0 : cur + 1;
         }
+#ifdef WGP33_PROF
+        if (lane == 0 && wgp33_prof_buffer_dev)
+            for (int k = 0; k < 6; ++k) wgp33_prof_buffer_dev[((long)blockIdx.x * 8 + wave) * 6 + k] = prof_t[k];
+#endif
         if (!(WGP33_DBG & 1)) wgrad32_epilogue<false>(acc, p, smem, wave, lane, 0, kg, cg, kt + gi * p.nkt, ct, split);
         else {
 #pragma unroll

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "../../primia_amd/csrc/conv_wgrad_patch.hip"
+#include "../../primia_amd/csrc/options.hip"   // the option table the dispatch code reads
 
 using namespace primia;
 
