@@ -7,7 +7,7 @@
 #include <cstdio>
 #include <cstdint>
 
-enum Op { ADD32, ALIGNBIT, LSHLADD64, BITOP3, ADD64PAIR, XOR32, MIX, FMA, FMAC, MULF, MAXF, CNDMASK, LSHLOR, ANDOR, PERM, CVTPK, MAX3F, PKFMA, PKMUL, MAXU, LSHLREV, FMA_SGPR };
+enum Op { ADD32, ALIGNBIT, LSHLADD64, BITOP3, ADD64PAIR, XOR32, MIX, FMA, FMAC, MULF, MAXF, CNDMASK, LSHLOR, ANDOR, PERM, CVTPK, MAX3F, PKFMA, PKMUL, MAXU, LSHLREV, FMA_SGPR, DOT2C, PKADD, BFE, CMPCND, CMPCND_S, MULCLAMP };
 
 template <int OP, int CH>
 __global__ __launch_bounds__(512) void k(uint64_t* out, int iters, uint64_t* clk) {
@@ -48,6 +48,12 @@ __global__ __launch_bounds__(512) void k(uint64_t* out, int iters, uint64_t* clk
                 if (OP == MAX3F) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[c]) : "v"(b[c]), "v"(b[(c + 1) % CH]));
                 if (OP == PKFMA) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(q[c]) : "v"(q[(c + 1) % CH]));
                 if (OP == PKMUL) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(q[c]) : "v"(q[(c + 1) % CH]));
+                if (OP == PKADD) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(q[c]) : "v"(q[(c + 1) % CH]));
+                if (OP == DOT2C) asm volatile("v_dot2c_f32_bf16 %0, %1, %2" : "+v"(a[c]) : "v"(b[c]), "v"(b[(c + 1) % CH]));
+                if (OP == BFE) asm volatile("v_bfe_i32 %0, %0, 3, 1" : "+v"(a[c]));
+                if (OP == CMPCND) asm volatile("v_cmp_gt_f32 vcc, %1, %0\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[c]) : "v"(b[c]) : "vcc");
+                if (OP == CMPCND_S) asm volatile("v_cmp_gt_f32 s[20:21], %1, %0\n\tv_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a[c]) : "v"(b[c]) : "s20", "s21");
+                if (OP == MULCLAMP) asm volatile("v_mul_f32 %0, %1, %0 clamp\n\tv_mul_f32 %0, %0, %1" : "+v"(a[c]) : "v"(b[c]));
                 if (OP == MIX) {      // the SHA-512 round's proportions: 3 alignbit : 2 lshl_add_u64 : 2 bitop3
                     asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(a[c]) : "v"(b[c]));
                     asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(q[c]) : "v"(q[(c + 1) % CH]));
@@ -112,5 +118,11 @@ int main() {
     run<MAX3F, 8>("v_max3_f32", 512, 1);
     run<PKFMA, 8>("v_pk_fma_f32 (2 lanes-ops)", 512, 1);
     run<PKMUL, 8>("v_pk_mul_f32 (2 lane-ops)", 512, 1);
+    run<PKADD, 8>("v_pk_add_f32 (2 lane-ops)", 512, 1);
+    run<DOT2C, 8>("v_dot2c_f32_bf16", 512, 1);
+    run<BFE, 8>("v_bfe_i32", 512, 1);
+    run<CMPCND, 8>("v_cmp_gt_f32 vcc + v_cndmask_b32 vcc", 512, 2);
+    run<CMPCND_S, 8>("v_cmp_gt_f32 sgpr + v_cndmask_b32 sgpr", 512, 2);
+    run<MULCLAMP, 8>("v_mul_f32 clamp + v_mul_f32", 512, 2);
     return 0;
 }
