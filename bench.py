@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-fuse-sgd", action="store_true", help="gradient finalize, SGD and weight refresh as three passes")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="primia_set_option(NAME, VALUE) before anything is built (A/B runs; csrc/options.h)")
+    ap.add_argument("--lib", default=None, metavar="PATH",
+                    help="load this build of the kernel library instead of primia_amd/libprimia_hip.so (same-box A/B of two "
+                         "builds; probe builds: python -m primia_amd.build --probe)")
     ap.add_argument("--engine-opt", action="append", default=[], metavar="NAME=VALUE",
                     help="ResNet18Engine(options={NAME: VALUE}) (schedule switches of the engine)")
     return ap.parse_args()
@@ -165,6 +168,8 @@ def main():
 
     from primia_amd import _lib as _plib
 
+    if a.lib:
+        _plib.LIB_PATH = os.path.abspath(a.lib)      # before the first call loads it; no fallback: a missing file raises
     for kv in a.opt:
         k, _, v = kv.partition("=")
         _plib.set_option(k, int(v))

@@ -54,9 +54,11 @@ int primia_abi_version(void);
  * call dispatches (and by the *_bytes / *_ok / *_kernel_id queries, which therefore must be asked again after a
  * change).  Each entry is read and written atomically (no torn values, callable from any thread), but a SEQUENCE of
  * changes is not a transaction: set options before the streams start.  primia_options_epoch() counts the changes made
- * so far: a host object that sized workspaces from the queries keeps the epoch it saw and re-plans — or refuses to run,
- * as primia_amd.engine.ResNet18Engine does — when it has moved.  The reference has no counterpart (torch picks its own
- * kernels). */
+ * so far (a call that leaves a value as it was does not count): a host object that sized workspaces from the queries
+ * keeps the epoch it saw and re-plans — or refuses to run, as primia_amd.engine.ResNet18Engine does — when it has moved.
+ * The two timing-experiment switches c64_dbg / s2lh_dbg (they SKIP parts of a kernel: wrong results) are honoured by
+ * probe builds only (-DPRIMIA_PROBE=1, tools/micro); this library returns PRIMIA_ERR_UNSUPPORTED for a non-zero value.
+ * The reference has no counterpart (torch picks its own kernels). */
 int primia_set_option(const char* name, int value);
 int64_t primia_options_epoch(void);
 int primia_get_option(const char* name, int* value);
@@ -264,7 +266,8 @@ int primia_conv2d_dgrad_masked_acc(const primia_conv_desc* d, const void* dy, co
  * its forward pass wrote, c0 = saved mean, c1 = saved invstd; consumer primia_bn_bwd_mask_from_sums.  mode 3 — the stem's
  * BatchNorm seen through the 3x3 / 2 max-pool (reference: torchlib/models.py conv1 -> bn1 -> relu -> maxpool): aux = the pooled
  * activation p, ReLU = [p > 0], xhat = (p - beta) / gamma, c0 = beta, c1 = gamma, aux_mask unused; consumer
- * primia_bn_relu_maxpool_bwd_from_sums (which also serves channels with gamma == 0 from y at the argmax).  64 -> 64 bf16 layers;
+ * primia_bn_relu_maxpool_bwd_from_sums (which also serves the channels whose gamma is 0 or below 2^-6 |beta| — xhat is not
+ * recoverable from the STORED p there, the producer writes a zero partial for them — from y at the argmax).  64 -> 64 bf16 layers;
  * primia_conv_dgrad_masked_acc_bnsums_slots = rows of the partial table, 0 where not served. */
 int primia_conv_dgrad_masked_acc_bnsums_slots(const primia_conv_desc* d, int dtype);
 int primia_conv2d_dgrad_masked_acc_bnsums(const primia_conv_desc* d, const void* dy, const void* w_dgrad, void* dx,
@@ -557,12 +560,13 @@ int primia_bn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dp
                                primia_stream_t stream);
 /* primia_bn_relu_maxpool_bwd(dy = NULL) — dgamma / dbeta only — when the reduction over (pooled, dpooled) already happened in the
  * write-back of the data gradient that produced dpooled (primia_conv2d_dgrad_masked_acc_bnsums, mode 3): `sums` = its partials
- * [slots][2][C].  A channel with gamma == 0 (constant activation, xhat not recoverable from the pooled value) is served from
- * y at the argmax positions, as in the unfused call. */
+ * [slots][2][C].  A channel with |gamma| < 2^-6 * |beta| or gamma == 0 (the rounding error of the stored pooled value divided by
+ * gamma would swamp xhat; pretrained bn1 layers have such channels) is served from y at the argmax positions, as in the
+ * unfused call. */
 int primia_bn_relu_maxpool_bwd_from_sums(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax,
-                                         const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
-                                         float* dbeta, const float* sums, int slots, int N, int H, int W, int C, int dtype,
-                                         primia_stream_t stream);
+                                         const float* gamma, const float* beta, const float* save_mean,
+                                         const float* save_invstd, float* dgamma, float* dbeta, const float* sums, int slots,
+                                         int N, int H, int W, int C, int dtype, primia_stream_t stream);
 /* The stem's backward tail without the 411 MB dy (batch 256, 224 x 224): primia_bn_relu_maxpool_bwd with dy = NULL
  * forms dgamma / dbeta only, and this call is conv1's weight gradient (primia_stem_conv_wgrad_ws) whose dy tiles are
  * produced on the fly, per 8 x 16 output patch, from y, dpooled, the argmax codes and bn1's statistics — the apply
@@ -761,6 +765,21 @@ int primia_open2(int64_t* buf, int64_t n, void* comm, primia_stream_t stream);
  * tensors/interpreters/additive_shared.py:336-365, mpc/fss.py:344-358,495-501).  `out` must be 16-byte aligned. */
 int primia_chacha20_fill(uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3, uint64_t nonce, uint64_t block0,
                          int64_t* out, int64_t n, primia_stream_t stream);
+/* The same keystream with the provider's block counter kept ON THE DEVICE: block = *counter + block_offset + i.  A serving
+ * deployment captures its whole refill (mpc/primitives.py:161-235: the provider re-provisions the crypto store between
+ * requests) as ONE hipGraph; a host-side counter would be frozen into the graph and every replay would hand out the same
+ * masks.  primia_u64_add(counter, blocks drawn) is the graph's last node: every replay draws fresh keystream. */
+int primia_chacha20_fill_ctr(uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3, uint64_t nonce, const uint64_t* counter,
+                             uint64_t block_offset, int64_t* out, int64_t n, primia_stream_t stream);
+int primia_u64_add(uint64_t* word, uint64_t delta, primia_stream_t stream);
+/* build_triple's second product share from input shares that were drawn directly (mpc/beaver.py:7-63: a, b uniform, c = a o b
+ * split additively; a = a0 + a1 with both shares uniform IS a sharing of a uniform a): c1 = (x0 + x1) o (y0 + y1) - c0.
+ * _mul_: element-wise, (y0, y1) of nb elements broadcast over the leading dims of the n-element x (nb divides n);
+ * _matmul_: [M, K] @ [K, N], scratch = K * N int64. */
+int primia_triple_mul_c1(const int64_t* x0, const int64_t* x1, const int64_t* y0, const int64_t* y1, const int64_t* c0,
+                         int64_t* c1, int64_t n, int64_t nb, primia_stream_t stream);
+int primia_triple_matmul_c1(const int64_t* a0, const int64_t* a1, const int64_t* b0, const int64_t* b1, const int64_t* c0,
+                            int64_t* c1, int64_t* scratch, int M, int K, int N, primia_stream_t stream);
 
 /* out[i] = a[i] (+|-|*) b[i % nb]  mod 2^64.  nb == n: plain element-wise; nb < n broadcasts b
  * over the leading dims ([HW, C] op [C], additive_shared.py:489-524, beaver.py:33-53). */
@@ -903,6 +922,12 @@ int primia_dif_eval(int b, const uint32_t* x, const uint64_t* s0, const uint8_t*
 int primia_dpf_eval(int b, const uint32_t* x, const uint64_t* s0, const uint8_t* cw_bits,
                     const uint64_t* cw_s, const int64_t* cw_n, int64_t* out, int64_t n,
                     primia_stream_t stream);
+/* Dealer, build_fss_keys' arithmetic on raw keystream words, in place (mpc/primitives.py:237-253: alpha and its mask are
+ * drawn below 2^32, party 0 receives (alpha - mask) mod 2^32 and party 1 the mask; mpc/fss.py:495-501: word 0 of a seed
+ * carries 63 bits): alpha [n] &= 2^32 - 1, r [n] &= 2^32 - 1, s0_pair [2][2][n] word 0 of both parties &= 2^63 - 1,
+ * alpha0 [n] = (alpha - r) mod 2^32. */
+int primia_fss_alpha_split(uint64_t* alpha, uint64_t* s0_pair, uint64_t* r, uint64_t* alpha0, int64_t n,
+                           primia_stream_t stream);
 /* Dealer: DIF.keygen / DPF.keygen (fss.py:344-398, 286-318) from explicit randomness:
  * alpha uint64 [n] (< 2^32), s0_pair uint64 [2 parties][2][n].  Correction words are common to
  * both parties; party b's key = (s0_pair[b], cw_*). */

@@ -92,5 +92,37 @@ def build(force=False, verbose=True):
     return LIB
 
 
+PROBE_LIB = os.path.join(HERE, "..", "tools", "micro", "libprimia_probe.so")
+PROBE_SOURCES = ("conv3x3_c64.hip", "conv_s2lh.hip", "options.hip")
+
+
+def build_probe(extra_flags=()):
+    """tools/micro/libprimia_probe.so: the library with the timing-experiment switches compiled IN (-DPRIMIA_PROBE=1: the
+    c64_dbg / s2lh_dbg options skip parts of a kernel — wrong results, phase timings only).  The shipped library refuses
+    those options; tools load this one explicitly (bench.py --lib, `_lib.LIB_PATH = ...`).  Never loaded by the product."""
+    build(verbose=False)
+    objs = []
+    for f in sorted(x for x in os.listdir(CSRC) if x.endswith(".hip")):
+        if f in PROBE_SOURCES:
+            os.makedirs(os.path.join(OBJ, "probe"), exist_ok=True)      # (its own directory: tools glob OBJ/*.o)
+            obj = os.path.join(OBJ, "probe", f[:-4] + ".o")
+            cmd = [_hipcc(), *FLAGS, "-DPRIMIA_PROBE=1", *extra_flags, "-c", os.path.join(CSRC, f), "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"hipcc failed for {f} (probe):\n{r.stdout}{r.stderr}")
+        else:
+            obj = os.path.join(OBJ, f[:-4] + ".o")
+        objs.append(obj)
+    r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", PROBE_LIB, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout + r.stderr)
+    print(f"[primia build] linked {os.path.normpath(PROBE_LIB)}")
+    return PROBE_LIB
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--probe" in sys.argv:
+        build_probe()
+    else:
+        build(force="--force" in sys.argv)

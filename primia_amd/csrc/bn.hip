@@ -203,14 +203,16 @@ __global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_kernel(const floa
 }
 
 // Finalize of the stem's BatchNorm backward sums when their partials came out of a data-gradient write-back at POOLED resolution
-// (conv3x3_c64_kernel<true, 3, 3>: sum g, sum g * (p - beta) / gamma with g = dpooled * [p > 0]).  A channel with gamma == 0 has
-// a constant activation and xhat cannot be recovered from p: this kernel then reads y at the argmax positions for that channel
-// (what PoolScatterFn does in its rare branch) — one block walks the pooled tensor for it; never taken by a trained network.
+// (conv3x3_c64_kernel<true, 3, 3>: sum g, sum g * (p - beta) / gamma with g = dpooled * [p > 0]).  For a channel whose gamma is 0
+// or tiny against beta (common.h pool_xhat_recoverable) xhat cannot be recovered from the stored p: the producer wrote a zero
+// partial and this kernel reads y at the argmax positions for that channel (what PoolScatterFn does in its rare branch) — one
+// block walks the pooled tensor for it.
 template <typename T>
 __global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_pool_kernel(
     const float* __restrict__ partials, int nblk, int C, float* __restrict__ dbeta, float* __restrict__ dgamma,
-    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd, const T* __restrict__ p,
-    const T* __restrict__ dp, const uint8_t* __restrict__ argmax, const T* __restrict__ y, int N, int H, int W, int Ho, int Wo) {
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, const T* __restrict__ p, const T* __restrict__ dp, const uint8_t* __restrict__ argmax,
+    const T* __restrict__ y, int N, int H, int W, int Ho, int Wo) {
     __shared__ double sa[kFinSlices][17], sb[kFinSlices][17];
     __shared__ double sfix[16 * kFinSlices / 64];
     const int cl = threadIdx.x & 15, ks = threadIdx.x >> 4;
@@ -231,7 +233,7 @@ __global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_pool_kernel(
     }
     for (int j = 0; j < 16; ++j) {          // (block-uniform)
         const int cj = blockIdx.x * 16 + j;
-        if (cj >= C || gamma[cj] != 0.f) continue;
+        if (cj >= C || pool_xhat_recoverable(gamma[cj], beta[cj])) continue;
         const long Mp = (long)N * Ho * Wo;
         const float mu = mean[cj], is = invstd[cj];
         double t = 0.0;
@@ -865,10 +867,11 @@ struct PoolScatterFn {
         for (int i = 0; i < Chunk<T>::N; ++i) {
             const float g = gamma[c0 + i];
             k_beta[i] = beta[c0 + i];
-            k_rgamma[i] = g != 0.f ? 1.f / g : 0.f;
+            const bool rec = pool_xhat_recoverable(g, k_beta[i]);
+            k_rgamma[i] = rec ? 1.f / g : 0.f;
             k_mean[i] = mean[c0 + i];
             k_invstd[i] = invstd[c0 + i];
-            any_zero_gamma |= g == 0.f;
+            any_zero_gamma |= !rec;
         }
     }
     __device__ __forceinline__ void operator()(long row, long off, int c0, float* s1, float* s2) const {
@@ -882,7 +885,7 @@ struct PoolScatterFn {
             s1[i] += g;
             s2[i] += g * ((vp[i] - k_beta[i]) * k_rgamma[i]);
         }
-        if (any_zero_gamma) {  // rare: xhat of a gamma == 0 channel from y at the argmax position
+        if (any_zero_gamma) {  // rare: xhat of a channel whose gamma is 0 or tiny against beta, from y at the argmax position
             const int wo = (int)(row % Wo);
             const long t = row / Wo;
             const int ho = (int)(t % Ho), n = (int)(t / Ho);
@@ -1576,20 +1579,20 @@ int primia_bn_relu_maxpool_bwd(const void* y, const void* pooled, const void* dp
 // primia_bn_relu_maxpool_bwd(dy = null) whose reduction pass over (pooled, dpooled) already happened in the write-back of the data
 // gradient that produced dpooled (primia_conv2d_dgrad_masked_acc_bnsums, mode 3): `sums` = its partials [slots][2][C].
 int primia_bn_relu_maxpool_bwd_from_sums(const void* y, const void* pooled, const void* dpooled, const uint8_t* argmax,
-                                         const float* gamma, const float* save_mean, const float* save_invstd, float* dgamma,
-                                         float* dbeta, const float* sums, int slots, int N, int H, int W, int C, int dtype,
-                                         primia_stream_t stream) {
-    PRIMIA_REQUIRE(y && pooled && dpooled && argmax && gamma && save_mean && save_invstd && dgamma && dbeta && sums);
+                                         const float* gamma, const float* beta, const float* save_mean,
+                                         const float* save_invstd, float* dgamma, float* dbeta, const float* sums, int slots,
+                                         int N, int H, int W, int C, int dtype, primia_stream_t stream) {
+    PRIMIA_REQUIRE(y && pooled && dpooled && argmax && gamma && beta && save_mean && save_invstd && dgamma && dbeta && sums);
     PRIMIA_REQUIRE(N > 0 && H > 0 && W > 0 && slots >= 1 && bn_shape_ok((long)N * H * W, C, dtype));
     const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == PRIMIA_BF16)
         bn_finalize_pool_kernel<bf16><<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(
-            sums, slots, C, dbeta, dgamma, gamma, save_mean, save_invstd, (const bf16*)pooled, (const bf16*)dpooled, argmax,
+            sums, slots, C, dbeta, dgamma, gamma, beta, save_mean, save_invstd, (const bf16*)pooled, (const bf16*)dpooled, argmax,
             (const bf16*)y, N, H, W, Ho, Wo);
     else if (dtype == PRIMIA_F32)
         bn_finalize_pool_kernel<float><<<(C + 15) / 16, 16 * kFinSlices, 0, st>>>(
-            sums, slots, C, dbeta, dgamma, gamma, save_mean, save_invstd, (const float*)pooled, (const float*)dpooled, argmax,
+            sums, slots, C, dbeta, dgamma, gamma, beta, save_mean, save_invstd, (const float*)pooled, (const float*)dpooled, argmax,
             (const float*)y, N, H, W, Ho, Wo);
     else
         return PRIMIA_ERR_ARG;

@@ -25,11 +25,13 @@ struct ChaChaKey {
     uint32_t n[2];
 };
 
-__global__ __launch_bounds__(256) void chacha20_kernel(ChaChaKey key, uint64_t block0, uint64_t* __restrict__ out,
-                                                       int64_t nwords) {
+// `counter`: null, or a device word added to block0 — the serving form keeps the provider's block counter ON THE DEVICE so
+// that a captured refill (hipGraph) draws fresh keystream at every replay (primia_chacha20_fill_ctr).
+__global__ __launch_bounds__(256) void chacha20_kernel(ChaChaKey key, uint64_t block0, const uint64_t* __restrict__ counter,
+                                                       uint64_t* __restrict__ out, int64_t nwords) {
     const int64_t blk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (blk * 8 >= nwords) return;
-    const uint64_t ctr = block0 + (uint64_t)blk;
+    const uint64_t ctr = block0 + (counter ? *counter : 0) + (uint64_t)blk;
     uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u,
                       key.k[0], key.k[1], key.k[2], key.k[3], key.k[4], key.k[5], key.k[6], key.k[7],
                       (uint32_t)ctr, (uint32_t)(ctr >> 32), key.n[0], key.n[1]};   // 12,13 counter; 14,15 nonce
@@ -75,6 +77,36 @@ extern "C" int primia_chacha20_fill(uint64_t k0, uint64_t k1, uint64_t k2, uint6
     key.n[0] = (uint32_t)nonce;
     key.n[1] = (uint32_t)(nonce >> 32);
     const int64_t blocks = (n + 7) / 8;
-    chacha20_kernel<<<ceil_div(blocks, 256), 256, 0, (hipStream_t)st>>>(key, block0, (uint64_t*)out, n);
+    chacha20_kernel<<<ceil_div(blocks, 256), 256, 0, (hipStream_t)st>>>(key, block0, nullptr, (uint64_t*)out, n);
+    return launch_status();
+}
+
+namespace primia {
+__global__ void u64_add_kernel(uint64_t* word, uint64_t delta) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *word += delta;
+}
+}  // namespace primia
+
+extern "C" int primia_chacha20_fill_ctr(uint64_t k0, uint64_t k1, uint64_t k2, uint64_t k3, uint64_t nonce,
+                                        const uint64_t* counter, uint64_t block_offset, int64_t* out, int64_t n,
+                                        primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(counter && out && n > 0 && ((uintptr_t)out & 15) == 0);
+    ChaChaKey key;
+    const uint64_t kk[4] = {k0, k1, k2, k3};
+    for (int i = 0; i < 4; ++i) {
+        key.k[2 * i] = (uint32_t)kk[i];
+        key.k[2 * i + 1] = (uint32_t)(kk[i] >> 32);
+    }
+    key.n[0] = (uint32_t)nonce;
+    key.n[1] = (uint32_t)(nonce >> 32);
+    const int64_t blocks = (n + 7) / 8;
+    chacha20_kernel<<<ceil_div(blocks, 256), 256, 0, (hipStream_t)st>>>(key, block_offset, counter, (uint64_t*)out, n);
+    return launch_status();
+}
+
+extern "C" int primia_u64_add(uint64_t* word, uint64_t delta, primia_stream_t st) {
+    PRIMIA_REQUIRE(word);
+    u64_add_kernel<<<1, 64, 0, (hipStream_t)st>>>(word, delta);
     return launch_status();
 }

@@ -120,6 +120,15 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// The stem's BatchNorm seen through ReLU + max-pool: where ReLU was active the pooled value IS the activation, so
+// xhat = (p - beta) / gamma can be read off the pooled tensor (bn.hip PoolScatterFn, gn.hip GnPoolScatterFn,
+// conv3x3_c64.hip mode 3).  p is a STORED value: its rounding error |p| * 2^-9 (bf16) is divided by gamma, so a channel
+// whose gamma is small against beta (pretrained torchvision bn1 has such channels) would get xhat = rounding noise /
+// gamma — those channels, and gamma == 0, take y at the argmax position instead.  ONE predicate for every site.
+__host__ __device__ __forceinline__ bool pool_xhat_recoverable(float gamma, float beta) {
+    return fabsf(gamma) >= 0x1p-6f * fmaxf(fabsf(beta), 1e-30f);
+}
+
 // torch.optim.SGD without momentum: d_p = g + wd*p ; p = p - lr*d_p.  ONE definition for the flat optimizer kernel
 // (optim.hip) and the fused gradient-finalize + step + weight-refresh tiles (layout.hip): the two must agree bit for bit.
 __device__ __forceinline__ float sgd_update(float p, float g, float lr, float wd) { return p - lr * (g + wd * p); }

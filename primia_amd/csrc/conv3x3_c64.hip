@@ -26,6 +26,17 @@
 
 #include "conv3x3_lh.h"
 
+// timing-experiment bits (option c64_dbg; results are WRONG when set): compiled in by probe builds only (-DPRIMIA_PROBE=1,
+// tools/micro/c64_probe.sh) — the shipped kernel carries no p.debug branch and primia_set_option refuses the option
+#ifndef PRIMIA_PROBE
+#define PRIMIA_PROBE 0
+#endif
+#if PRIMIA_PROBE
+#define C64_DBG(bit) (p.debug & (bit))
+#else
+#define C64_DBG(bit) 0
+#endif
+
 namespace primia {
 
 __device__ __attribute__((aligned(16))) const unsigned char kC64ZeroPage[16] = {0};
@@ -284,7 +295,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int ho = co.ph * 8 + 4 * ph + 2 * q + (pxl >> 3), wo = co.pw * 8 + (pxl & 7);
-                const bool live = co.t < t1 && ho < p.H && wo < p.W && !(p.debug & 64);
+                const bool live = co.t < t1 && ho < p.H && wo < p.W && !C64_DBG(64);
                 const unsigned pix = (unsigned)((co.n * p.H + ho) * p.W + wo);
                 const unsigned voff = live ? (pix * 64u + (unsigned)(4 * kh + (cc ^ ((pxl >> 1) & 3))) * 8u) * 2u : kOob;
                 const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + (wave * 2 + q) * 1024);
@@ -308,13 +319,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto prefetch_aux = [&]() {
-        if (BNB != 0 && !(p.debug & 32)) {
+        if (BNB != 0 && !C64_DBG(32)) {
             const int px = lane >> 3, c16 = lane & 7;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int g = 2 * wave + q;
                 const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
-                const bool live = cw.t < t1 && ho < p.H && wo < p.W && !(p.debug & 16);
+                const bool live = cw.t < t1 && ho < p.H && wo < p.W && !C64_DBG(16);
                 const unsigned eoff = (unsigned)(((cw.n * p.H + ho) * p.W + wo) * 64 + c16 * 8);   // elements (< 2^31)
                 const unsigned voff = live ? eoff * 2u : kOob;
                 const unsigned m0v =
@@ -326,7 +337,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                           // row groups — lane l: row group l >> 5, pixel (l >> 2) & 7, word (l >> 1) & 1
                 const int q = lane >> 5, pxm = (lane >> 2) & 7, hw = (lane >> 1) & 1;
                 const int ho = cw.ph * 8 + 2 * wave + q, wo = cw.pw * 8 + pxm;
-                const bool live = cw.t < t1 && ho < p.H && wo < p.W && !(p.debug & 16);
+                const bool live = cw.t < t1 && ho < p.H && wo < p.W && !C64_DBG(16);
                 const unsigned pix = (unsigned)((cw.n * p.H + ho) * p.W + wo);
                 const uint8_t* mp = p.bnb_mask + (live ? pix * 8u + 4u * hw : 0u);
                 const unsigned m1v = __builtin_amdgcn_readfirstlane(lds0 + SMK_OFF + (ACC ? 1024 : 0) + wave * 256);
@@ -335,7 +346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !(p.debug & 3);
+    const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !C64_DBG(3);
     const int dstage = wave == 0 ? 4 : 3;      // halo pieces per stage issued by this wave
 
     // `younger` = vector-memory loads this wave issued after the old rows of the patch being computed (0: unknown, drain)
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             bq[slot][0] = *(const bf16x8_t*)q0;
             bq[slot][1] = *(const bf16x8_t*)(q0 + 20 * 128);
         };
-        if (!(p.debug & 4)) {
+        if (!C64_DBG(4)) {
             rd(0, 0);
             rd(1, 1);
 #pragma unroll
@@ -452,7 +463,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int g = 2 * wave + q;                // patch row handled by this wave
             const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
             r.live[q] = cw.t < t1 && ho < p.H && wo < p.W;
-            r.so[q] = r.live[q] && !(p.debug & 1) ? (unsigned)(((cw.n * p.H + ho) * p.W + wo) * 128 + c16 * 16) : kOob;
+            r.so[q] = r.live[q] && !C64_DBG(1) ? (unsigned)(((cw.n * p.H + ho) * p.W + wo) * 128 + c16 * 16) : kOob;
             const int opx2 = g * 8 + px;
             r.v[q] = *(const u32x4*)(sout + obuf * OUTB + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
             if constexpr (BNB != 0) {
@@ -474,7 +485,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // (non-temporal stores: measured, no change — 4.862 vs 4.861 ms per step)
             asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(r.so[q]), "s"(rsrc_st) : "memory");
             if (r.live[q]) {
-                if (BNB != 0 && !(p.debug & 8)) {
+                if (BNB != 0 && !C64_DBG(8)) {
                     const u32x4 yv = r.yv[q];
                     const unsigned bmq = r.bm[q];
                     const f32x4 mu0 = *(const f32x4*)(bnc + c16 * 8), mu1 = *(const f32x4*)(bnc + c16 * 8 + 4);
@@ -578,9 +589,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (BNB != 0 && s > 0) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the reads above are done before new rows may land in the buffer
             prefetch_aux();    // the cursor now points at patch s, written back in iteration s + 1
-            younger += (p.debug & 32) ? 0 : NAUX;
+            younger += C64_DBG(32) ? 0 : NAUX;
         }
-        if (s + STAGES - 1 < nstages && !(p.debug & 2)) {
+        if (s + STAGES - 1 < nstages && !C64_DBG(2)) {
             stage(nxt);
             younger += dstage;
         }
@@ -632,8 +643,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int w = 0; w < 4; ++w) a += red[w * 128 + tid];
             if (BNB != 0 && tid >= 64) {      // sum g * (y - mean) -> sum g * xhat
                 if constexpr (BNB == 3) {
+                    // (gamma 0 or tiny against beta: xhat is not recoverable from the stored p — the consumer's rare path)
                     const float gm = p.bnb_gamma[tid - 64];
-                    a *= gm != 0.f ? 1.f / gm : 0.f;      // (gamma == 0: xhat is not recoverable from p — the consumer's rare path)
+                    a *= pool_xhat_recoverable(gm, p.bnb_beta[tid - 64]) ? 1.f / gm : 0.f;
                 } else {
                     a *= p.bnb_invstd[tid - 64];
                 }
@@ -681,7 +693,7 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
     long per = (p.total + target - 1) / target;
     if (per < 1) per = 1;
     p.per_block = (int)per;
-    p.debug = PRIMIA_OPT(c64_dbg);       // (timing experiments: option c64_dbg, 0 in every product run)
+    p.debug = PRIMIA_PROBE ? PRIMIA_OPT(c64_dbg) : 0;       // (timing experiments: probe builds only, tools/micro/c64_probe.sh)
     const int grid = (int)((p.total + per - 1) / per);
     // a 4-deep ring (plain 68 KiB, accumulate 76 KiB per block, two blocks per CU) keeps 78 KB per CU in flight instead of 52
     const int deep = PRIMIA_OPT(c64_stages);

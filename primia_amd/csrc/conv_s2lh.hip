@@ -33,8 +33,11 @@
 #include "options.h"
 
 // compile-time experiment switches (tools/s2lh_variants.sh builds and times the variants on one box)
+#ifndef PRIMIA_PROBE
+#define PRIMIA_PROBE 0
+#endif
 #ifndef S2_DBG
-#define S2_DBG 1          // 0: the s2lh_dbg phase switches are compiled out
+#define S2_DBG PRIMIA_PROBE   // the s2lh_dbg phase switches (wrong results when set) exist in probe builds only
 #endif
 #ifndef S2_PROG_KARG
 #define S2_PROG_KARG 0    // 1: the loaders read the step words from the kernel arguments (scalar loads), not from LDS

@@ -292,6 +292,22 @@ __global__ __launch_bounds__(256) void dpf_eval_kernel(int b, const u32* __restr
     out[i] = sgn * ((long)t * cw_n[i] + conv31(sb));
 }
 
+// ---- build_fss_keys' host arithmetic on raw keystream words (mpc/primitives.py:237-253, mpc/fss.py:344-358,495-501), in place:
+// alpha and its mask r are reduced mod 2^32, word 0 of both parties' seeds keeps 63 bits (randbit), and party 0's share of alpha
+// is (alpha - r) mod 2^32 (party 1's is r) — what primia_amd.secure.Dealer did with torch `&` / `-` before round 6.
+__global__ __launch_bounds__(256) void fss_alpha_split_kernel(u64* __restrict__ alpha, u64* __restrict__ s0p, u64* __restrict__ r,
+                                                              u64* __restrict__ alpha0, long n) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const u64 m32 = 0xFFFFFFFFull, m63 = 0x7FFFFFFFFFFFFFFFull;
+    const u64 a = alpha[i] & m32, rr = r[i] & m32;
+    alpha[i] = a;
+    r[i] = rr;
+    alpha0[i] = (a - rr) & m32;
+    s0p[i] &= m63;              // [party 0][word 0]
+    s0p[2 * n + i] &= m63;      // [party 1][word 0]
+}
+
 // ---- DIF.keygen (fss.py:344-398), one comparison per lane --------------------------------------------
 __global__ __launch_bounds__(256, 2) void dif_keygen_kernel(const u64* __restrict__ alpha, const u64* __restrict__ s0p,
                                                          uint8_t* __restrict__ cw_bits, u64* __restrict__ cw_sigma,
@@ -499,6 +515,13 @@ int primia_dif_keygen(const uint64_t* alpha, const uint64_t* s0_pair, uint8_t* c
     if (n == 0) return PRIMIA_OK;
     dif_keygen_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)st>>>((const u64*)alpha, (const u64*)s0_pair, cw_bits,
                                                                       (u64*)cw_sigma, (u64*)cw_s, cw_leaf, n);
+    return launch_status();
+}
+
+int primia_fss_alpha_split(uint64_t* alpha, uint64_t* s0_pair, uint64_t* r, uint64_t* alpha0, int64_t n, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(alpha && s0_pair && r && alpha0 && n > 0);
+    fss_alpha_split_kernel<<<ceil_div(n, 256), 256, 0, (hipStream_t)st>>>((u64*)alpha, (u64*)s0_pair, (u64*)r, (u64*)alpha0, n);
     return launch_status();
 }
 

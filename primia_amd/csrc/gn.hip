@@ -408,10 +408,11 @@ struct GnPoolScatterFn {
         for (int i = 0; i < Chunk<T>::N; ++i) {
             const float g = gamma[c0 + i];
             k_beta[i] = beta[c0 + i];
-            k_rgamma[i] = g != 0.f ? 1.f / g : 0.f;
+            const bool rec = pool_xhat_recoverable(g, k_beta[i]);
+            k_rgamma[i] = rec ? 1.f / g : 0.f;
             k_mean[i] = mean[n * G + (c0 + i) / cpg];
             k_invstd[i] = invstd[n * G + (c0 + i) / cpg];
-            any_zero_gamma |= g == 0.f;
+            any_zero_gamma |= !rec;
         }
     }
     __device__ __forceinline__ void operator()(long off, int n, int c0, float* s1, float* s2) const {
@@ -425,7 +426,7 @@ struct GnPoolScatterFn {
             s1[i] += g;
             s2[i] += g * ((vp[i] - k_beta[i]) * k_rgamma[i]);
         }
-        if (any_zero_gamma) {  // rare: xhat of a gamma == 0 channel from y at the argmax position
+        if (any_zero_gamma) {  // rare: xhat of a channel whose gamma is 0 or tiny against beta, from y at the argmax position
             const long row = (off - c0) / C - (long)n * Ho * Wo;
             const int ho = (int)(row / Wo), wo = (int)(row - (long)ho * Wo);
 #pragma unroll

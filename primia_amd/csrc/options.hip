@@ -6,6 +6,10 @@
 #include "common.h"
 #include "options.h"
 
+#ifndef PRIMIA_PROBE
+#define PRIMIA_PROBE 0
+#endif
+
 namespace primia {
 
 int g_options[kOptCount] = {
@@ -26,7 +30,7 @@ static const int kOptDefaults[kOptCount] = {
 #undef PRIMIA_OPT_DEF
 };
 
-// Bumped by every primia_set_option / primia_reset_options: a host object that sized buffers from the *_bytes / *_slots
+// Bumped by every primia_set_option / primia_reset_options that CHANGES a value: a host object that sized buffers from the *_bytes / *_slots
 // queries snapshots it and re-plans (or refuses to run) when it moved (primia_options_epoch).
 static std::atomic<int64_t> g_options_epoch{0};
 
@@ -46,8 +50,13 @@ extern "C" {
 int primia_set_option(const char* name, int value) {
     const int i = find_option(name);
     if (i < 0) return PRIMIA_ERR_ARG;
-    __atomic_store_n(&g_options[i], value, __ATOMIC_RELAXED);
-    g_options_epoch.fetch_add(1, std::memory_order_release);
+#if !PRIMIA_PROBE
+    // the *_dbg switches skip parts of a kernel (timing experiments, WRONG results): only a probe build honours them
+    if ((i == kOpt_c64_dbg || i == kOpt_s2lh_dbg) && value != 0) return PRIMIA_ERR_UNSUPPORTED;
+#endif
+    // the epoch moves only when a value does: restoring an option to what it already is must not invalidate engines
+    if (__atomic_exchange_n(&g_options[i], value, __ATOMIC_RELAXED) != value)
+        g_options_epoch.fetch_add(1, std::memory_order_release);
     return PRIMIA_OK;
 }
 
@@ -61,8 +70,9 @@ int primia_get_option(const char* name, int* value) {
 }
 
 int primia_reset_options(void) {
-    for (int i = 0; i < kOptCount; ++i) __atomic_store_n(&g_options[i], kOptDefaults[i], __ATOMIC_RELAXED);
-    g_options_epoch.fetch_add(1, std::memory_order_release);
+    bool moved = false;
+    for (int i = 0; i < kOptCount; ++i) moved |= __atomic_exchange_n(&g_options[i], kOptDefaults[i], __ATOMIC_RELAXED) != kOptDefaults[i];
+    if (moved) g_options_epoch.fetch_add(1, std::memory_order_release);
     return PRIMIA_OK;
 }
 

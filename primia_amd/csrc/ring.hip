@@ -18,6 +18,11 @@ __global__ __launch_bounds__(256) void ring_ew_kernel(const u64* __restrict__ a,
     }
 }
 
+__global__ __launch_bounds__(256) void ring_sub_inplace_kernel(u64* __restrict__ x, const u64* __restrict__ y, long n) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) x[i] -= y[i];
+}
+
 __global__ __launch_bounds__(256) void ring_scale_kernel(const u64* __restrict__ a, u64 k, u64* __restrict__ out,
                                                          long n) {
     const long stride = (long)gridDim.x * 256;
@@ -286,6 +291,18 @@ __global__ __launch_bounds__(256) void ring_gemm_kernel(GemmPair p1, GemmPair p2
     }
 }
 
+// The crypto provider's side of a Beaver triple whose input shares were drawn directly (a = a0 + a1, b = b0 + b1, all four
+// uniform; c0 uniform): the second share of the product, c1 = a * b - c0 (mpc/beaver.py:7-63 splits c the same way).
+__global__ __launch_bounds__(256) void triple_mul_c1_kernel(const u64* __restrict__ x0, const u64* __restrict__ x1,
+                                                            const u64* __restrict__ y0, const u64* __restrict__ y1,
+                                                            const u64* __restrict__ c0, u64* __restrict__ c1, long n, long nb) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const long j = nb == n ? i : i % nb;
+        c1[i] = (x0[i] + x1[i]) * (y0[j] + y1[j]) - c0[i];
+    }
+}
+
 static inline int ew_blocks(long n) {
     long b = (n + 255) / 256;
     return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -460,6 +477,29 @@ int primia_beaver_combine_matmul(int j, const int64_t* delta, const int64_t* eps
     }
     return launch_gemm(GemmPair{(const u64*)delta, b2}, GemmPair{(const u64*)a, (const u64*)eps}, (const u64*)c,
                        (u64*)z, M, K, N, s);
+}
+
+int primia_triple_mul_c1(const int64_t* x0, const int64_t* x1, const int64_t* y0, const int64_t* y1, const int64_t* c0,
+                         int64_t* c1, int64_t n, int64_t nb, primia_stream_t st) {
+    if (n == 0) return PRIMIA_OK;
+    PRIMIA_REQUIRE(x0 && x1 && y0 && y1 && c0 && c1 && n > 0 && nb > 0 && nb <= n && n % nb == 0);
+    triple_mul_c1_kernel<<<ew_blocks(n), 256, 0, (hipStream_t)st>>>((const u64*)x0, (const u64*)x1, (const u64*)y0,
+                                                                     (const u64*)y1, (const u64*)c0, (u64*)c1, n, nb);
+    return launch_status();
+}
+
+int primia_triple_matmul_c1(const int64_t* a0, const int64_t* a1, const int64_t* b0, const int64_t* b1, const int64_t* c0,
+                            int64_t* c1, int64_t* scratch, int M, int K, int N, primia_stream_t st) {
+    PRIMIA_REQUIRE(a0 && a1 && b0 && b1 && c0 && c1 && scratch && M > 0 && K > 0 && N > 0);
+    hipStream_t s = (hipStream_t)st;
+    const long kn = (long)K * N, mn = (long)M * N;
+    // b = b0 + b1; c1 = a0 @ b + a1 @ b (= a @ b: the ring is distributive); c1 -= c0
+    ring_ew_kernel<0><<<ew_blocks(kn), 256, 0, s>>>((const u64*)b0, (const u64*)b1, (u64*)scratch, kn, kn);
+    const int rc = launch_gemm(GemmPair{(const u64*)a0, (const u64*)scratch}, GemmPair{(const u64*)a1, (const u64*)scratch},
+                               nullptr, (u64*)c1, M, K, N, s);
+    if (rc != PRIMIA_OK) return rc;
+    ring_sub_inplace_kernel<<<ew_blocks(mn), 256, 0, s>>>((u64*)c1, (const u64*)c0, mn);
+    return launch_status();
 }
 
 }  // extern "C"

@@ -382,11 +382,13 @@ class ResNet18Engine:
             self._root.train(self.training)
             return self._root
         sib = self._root.__dict__.setdefault("_siblings", {})
-        if n not in sib and len(sib) >= self.max_siblings:
-            # activations and workspaces of an engine are ~12 MB per image: keep the most recent few batch sizes only
-            # (MixUp halves, the ragged final batch of train / validation loaders), evict the oldest
+        if n in sib:
+            sib[n] = sib.pop(n)       # (a hit moves the entry to the back of the dict: the front is the least recently USED)
+        elif len(sib) >= self.max_siblings:
+            # activations and workspaces of an engine are ~12 MB per image: keep the most recently used few batch sizes only
+            # (MixUp halves, the ragged final batch of train / validation loaders); the freed blocks stay in torch's
+            # caching allocator for the engine that replaces them
             del sib[next(iter(sib))]
-            torch.cuda.empty_cache()
         if n not in sib:
             sib[n] = ResNet18Engine(n, self.spec.num_classes, self.spec.in_channels, self.spec.input_size,
                                     self.spec.pooling, dtype=self.dtype, device=self.device, norm=self.norm,
@@ -468,6 +470,10 @@ class ResNet18Engine:
     # Optional per-launch timing of the convolution kernels (bench.py roofline leg): when
     # `self.prof` is a list, every conv launch is bracketed by events on the launch stream.
     prof = None
+    # Optional copies of buffers the backward pass consumes IN PLACE (tests): when `self.taps` is a dict, backward() stores
+    # "<block>.dout_in" — the gradient w.r.t. the block's output as its bn2 backward pass reads it, before conv1's
+    # accumulating data gradient turns the same buffer into the gradient of the block in front.
+    taps = None
 
     # the BatchNorm finalize launch folded into the apply kernel (primia_bn_fwd_train_apply_inline): bit-identical, and
     # SLOWER — 4.745 -> 4.79 ms per step, same box: 2,048 apply blocks each fetching 2C constants through agent-scope loads
@@ -821,9 +827,8 @@ class ResNet18Engine:
     def _dgrad_bnsums_slots(self, name):
         """Rows of the partial table conv `name`'s data gradient writes for the BatchNorm in front of it (0: not served)."""
         c = self.convs[name]
-        if getattr(c, "bnsums_slots", None) is None:
-            c.bnsums_slots = (query("primia_conv_dgrad_bnsums_slots", c.desc, self.dt)
-                              if (self.dtype == torch.bfloat16 and self.dp is None) else 0)
+        if getattr(c, "bnsums_slots", None) is None:      # (a property of the layer: asked once, whatever self.dp is then)
+            c.bnsums_slots = query("primia_conv_dgrad_bnsums_slots", c.desc, self.dt) if self.dtype == torch.bfloat16 else 0
         return c.bnsums_slots if self.dp is None else 0
 
     def _bwd_sums(self, name, slots, channels):
@@ -844,6 +849,8 @@ class ResNet18Engine:
     def backward(self):
         N, t = self.N, self.t
         nc = self.spec.num_classes
+        if query("primia_options_epoch") != self._options_epoch:
+            raise _lib.PrimiaError("library options changed (primia_set_option) after this engine sized its buffers")
         self._grads_pending = False      # (accumulators of an earlier pass that nobody consumed are overwritten now)
         self._dout_sums = {}             # block prefix -> (partials, slots): backward sums of its bn2 formed by the producer of dout
         if self.wgrad_ws is not None and self.dp is None:
@@ -873,6 +880,8 @@ class ResNet18Engine:
             x_in = t[blocks[i - 1].prefix + ".out"] if i > 0 else t["pool.out"]
             dx_in = t[blocks[i - 1].prefix + ".dout"] if i > 0 else t["pool.dout"]
             dout = t[p + ".dout"]
+            if self.taps is not None:
+                self.taps[p + ".dout_in"] = dout.clone()
             # bn2 (+residual, relu): dy2, and the masked gradient g written back over dout — unless this is an identity
             # block whose conv1 data gradient can mask the old values itself (one tensor write less)
             b2 = bn_name(blk.conv2.name)
@@ -904,6 +913,8 @@ class ResNet18Engine:
             if fused_sums:
                 c2, b1 = self.convs[blk.conv2.name], bn_name(blk.conv1.name)
                 sm1, si1 = self.save[b1]
+                if self.wgrad_overlap == 1:
+                    self._join_wgrad_stream()   # (as _dgrad does: two MFMA-bound kernels never run side by side)
                 sums = self._bwd_sums(blk.conv2.name, fused_sums, blk.conv1.cout)
                 self._timed("dgrad", c2, lambda: call(
                     "primia_conv2d_dgrad_bnsums", c2.desc, t[p + ".dy2"], c2.w_dgrad, t[p + ".da1"], t[p + ".y1"], sm1, si1,
@@ -1024,8 +1035,8 @@ class ResNet18Engine:
             S = self.spec.input_size
             if pool_sums is not None:     # the reduction over (pooled, dpooled) happened in layer1.0.conv1's data gradient
                 call("primia_bn_relu_maxpool_bwd_from_sums", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax,
-                     self.views["bn1.weight"], sm, si, self._gviews["bn1.weight"], self._gviews["bn1.bias"], pool_sums[0],
-                     pool_sums[1], N, hw, hw, 64, self.dt)
+                     self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self._gviews["bn1.weight"],
+                     self._gviews["bn1.bias"], pool_sums[0], pool_sums[1], N, hw, hw, 64, self.dt)
             else:
                 call("primia_bn_relu_maxpool_bwd", t["stem.y"], t["pool.out"], t["pool.dout"], self.pool_argmax, None,
                      self.views["bn1.weight"], self.views["bn1.bias"], sm, si, self._gviews["bn1.weight"],

@@ -69,10 +69,6 @@ class Dealer:
         self._block += (n + 7) // 8
         return out
 
-    def rand32(self, *shape):
-        """uniform in [0, 2^32) as int64 (alpha and its mask, mpc/fss.py:346, mpc/primitives.py:249)."""
-        return self.rand64(*shape) & 0xFFFFFFFF
-
     def _split(self, v):
         r = self.rand64(*v.shape)
         s1 = _empty_like(v)
@@ -86,19 +82,10 @@ class Dealer:
         # build_triple produces by drawing a and one share, mpc/beaver.py:7-63): 9 launches per triple instead of 21
         sa = [self.rand64(*xshape), self.rand64(*xshape)]
         sb = [self.rand64(*yshape), self.rand64(*yshape)]
-        a, b = _empty_like(sa[0]), _empty_like(sb[0])
-        call("primia_ring_add", sa[0], sa[1], a, a.numel(), a.numel())
-        call("primia_ring_add", sb[0], sb[1], b, b.numel(), b.numel())
-        if op == "mul":
-            # element-wise with the smaller operand broadcast over the leading dims
-            big, small = (a, b) if a.numel() >= b.numel() else (b, a)
-            c = _empty_like(big)
-            call("primia_ring_mul", big, small, c, big.numel(), small.numel())
-        else:
-            M, K, N = xshape[-2], xshape[-1], yshape[-1]
-            c = torch.empty(*xshape[:-1], N, dtype=I64, device=self.device)
-            call("primia_ring_matmul", a, b, c, M, K, N, 0)
-        sc = self._split(c)
+        c0 = self.rand64(*_triple_c_shape(op, xshape, yshape))
+        c1 = _empty_like(c0)
+        self.triple_c1(op, xshape, yshape, sa[0], sa[1], sb[0], sb[1], c0, c1)
+        sc = [c0, c1]
         t = [(sa[j], sb[j], sc[j]) for j in range(2)]
         if self.log is not None:
             self.log.append(("triple", op, [tuple(x.cpu().numpy() for x in t[j]) for j in range(2)]))
@@ -106,23 +93,38 @@ class Dealer:
             self.tape.append(t)
         return t
 
+    def triple_c1(self, op, xshape, yshape, a0, a1, b0, b1, c0, c1, scratch=None):
+        """c1 = (a0 + a1) o (b0 + b1) - c0: the product share that completes a triple whose other five shares are uniform."""
+        if op == "mul":
+            # element-wise with the smaller operand broadcast over the leading dims
+            if a0.numel() >= b0.numel():
+                call("primia_triple_mul_c1", a0, a1, b0, b1, c0, c1, a0.numel(), b0.numel())
+            else:
+                call("primia_triple_mul_c1", b0, b1, a0, a1, c0, c1, b0.numel(), a0.numel())
+        else:
+            M, K, N = xshape[-2], xshape[-1], yshape[-1]
+            if scratch is None:
+                scratch = torch.empty(K * N, dtype=I64, device=self.device)
+            call("primia_triple_matmul_c1", a0, a1, b0, b1, c0, c1, scratch, M, K, N)
+
     def dif_keys(self, n):
         if self.requests is not None:
             self.requests.append(("dif_keys", (n,), {}))
         dev = self.device
-        alpha = self.rand32(n)
+        # raw keystream words, then build_fss_keys' arithmetic in place (primia_fss_alpha_split): alpha and its mask r below
+        # 2^32 (mpc/fss.py:346, mpc/primitives.py:249), word 0 of each seed 63 bits (randbit, fss.py:495-501), and
+        # primitives.py:249-251: party 0 receives (alpha - mask) mod 2^32, party 1 the mask
+        alpha = self.rand64(n)
         s0 = self.rand64(2, 2, n)
-        s0[:, 0] &= 0x7FFFFFFFFFFFFFFF  # randbit: word 0 carries 63 bits (fss.py:495-501)
+        r = self.rand64(n)
+        a0 = torch.empty(n, dtype=I64, device=dev)
+        call("primia_fss_alpha_split", alpha, s0, r, a0, n)
         bits = torch.empty(32, n, dtype=torch.uint8, device=dev)
         cw_sigma = torch.empty(32, 2, n, dtype=I64, device=dev)
         cw_s = torch.empty(32, 2, n, dtype=I64, device=dev)
         leaf = torch.empty(33, n, dtype=torch.int32, device=dev)
         call("primia_dif_keygen", alpha, s0, bits, cw_sigma, cw_s, leaf, n)
-        # primitives.py:249-251: party 0 receives (alpha - mask) mod 2^32, party 1 the mask
-        r = self.rand32(n)
-        a0 = (alpha - r) & 0xFFFFFFFF
-        keys = [dict(alpha=[a0, r][b], s0=s0[b].contiguous(), bits=bits, cw_sigma=cw_sigma, cw_s=cw_s, cw_leaf=leaf)
-                for b in range(2)]
+        keys = [dict(alpha=[a0, r][b], s0=s0[b], bits=bits, cw_sigma=cw_sigma, cw_s=cw_s, cw_leaf=leaf) for b in range(2)]
         if self.log is not None:
             self.log.append(("dif", n, alpha.cpu().numpy(), s0.cpu().numpy(), r.cpu().numpy()))
         if self.tape is not None:
@@ -140,54 +142,6 @@ class Dealer:
         if self.tape is not None:
             self.tape.append(r)
         return r
-
-
-    # ---- in-place regeneration (serving: GraphedSecureInference.refill) --------------------------------------------
-    # The same primitives with the same distribution, written straight into the buffers a captured graph reads: no
-    # temporaries handed over and copied (a DIF key is 1.2 KB per comparison, 3.3 M comparisons per image), and a
-    # triple's input shares are drawn directly (a = a0 + a1 with both shares uniform is the sharing of a uniform a that
-    # build_triple produces by drawing a and one share, mpc/beaver.py:7-63) — 9 launches per triple instead of 21.
-    def rand_into(self, out):
-        n = out.numel()
-        if not out.is_contiguous():
-            raise PrimiaError("rand_into needs a contiguous buffer")
-        call("primia_chacha20_fill", *self._key, self._nonce, self._block, out, n)
-        self._block += (n + 7) // 8
-        return out
-
-    def refill_entry(self, kind, args, kw, entry):
-        if kind == "const_mask":
-            self.rand_into(entry)
-        elif kind == "triple":
-            op, xshape, yshape = args
-            (a0, b0, c0), (a1, b1, c1) = entry
-            for t in (a0, a1, b0, b1, c0):
-                self.rand_into(t)
-            a, b = _empty_like(a0), _empty_like(b0)
-            call("primia_ring_add", a0, a1, a, a.numel(), a.numel())
-            call("primia_ring_add", b0, b1, b, b.numel(), b.numel())
-            c = _empty_like(c0)
-            if op == "mul":
-                big, small = (a, b) if a.numel() >= b.numel() else (b, a)
-                call("primia_ring_mul", big, small, c, big.numel(), small.numel())
-            else:
-                call("primia_ring_matmul", a, b, c, xshape[-2], xshape[-1], yshape[-1], 0)
-            call("primia_ring_sub", c, c0, c1, c.numel(), c.numel())
-        elif kind == "dif_keys":
-            (n,) = args
-            k0, k1 = entry
-            alpha = self.rand32(n)
-            s0 = self.rand64(2, 2, n)
-            s0[:, 0] &= 0x7FFFFFFFFFFFFFFF
-            call("primia_dif_keygen", alpha, s0, k0["bits"], k0["cw_sigma"], k0["cw_s"], k0["cw_leaf"], n)
-            k0["s0"].copy_(s0[0])
-            k1["s0"].copy_(s0[1])
-            r = self.rand_into(k1["alpha"])
-            r &= 0xFFFFFFFF
-            torch.sub(alpha, r, out=k0["alpha"])
-            k0["alpha"] &= 0xFFFFFFFF
-        else:
-            raise PrimiaError(f"unknown primitive kind {kind!r}")
 
 
 class PreloadedDealer:
@@ -842,24 +796,23 @@ class SecureResNet18:
         return c.decode(c.reconstruct(out))
 
 
-def _copy_primitive(dst, src):
-    """In-place refill of one tape entry (tensor, tuple/list of tensors, or key dicts) from a fresh one."""
-    if torch.is_tensor(dst):
-        dst.copy_(src)
-    elif isinstance(dst, dict):
-        for k in dst:
-            _copy_primitive(dst[k], src[k])
-    else:
-        for d, s_ in zip(dst, src):
-            _copy_primitive(d, s_)
-
-
 class GraphedSecureInference:
     """Serving form of the encrypted forward: the online phase (about 6,500 small launches per image) is
     captured ONCE as a hipGraph over static buffers — the input image and every correlated-randomness
     primitive — and replayed per image; `refill()` has the dealer regenerate all per-image primitives into
     the same buffers (the reference's pre-provisioned crypto store, mpc/primitives.py:161-235, refilled
-    between requests).  Results are bit-identical to the eager SecureResNet18 fed the same primitives."""
+    between requests).  Results are bit-identical to the eager SecureResNet18 fed the same primitives.
+
+    The refill is ONE graph launch too (round 6).  Every uniformly random word of an image's primitives — triple input
+    shares and c0, re-sharing masks, FSS alpha / seeds / alpha masks — lives in ONE int64 arena that the tape entries are
+    views of: a single ChaCha20 launch fills it (`primia_chacha20_fill_ctr`: the block counter is a DEVICE word the graph's
+    last node advances, so every replay draws fresh keystream — a host counter would be frozen into the graph and every
+    image would get the same masks), then one launch per triple forms c1 = a o b - c0 and two per comparison batch form
+    the key (alpha split, DIF keygen).  ~3,000 eager launches per image became ~450 graph nodes; `refill_graph = False`
+    launches the same calls eagerly (same bits).  The constructor ends with one refill: no image is ever served on the
+    primitives the all-zero warm-up image consumed (opened values on a known input reveal the masks)."""
+
+    refill_graph = True
 
     def __init__(self, state_dict, device, input_size=224, precision_fractional=16, base=10, seed=None, blocks=None):
         self.device = torch.device(device)
@@ -874,6 +827,7 @@ class GraphedSecureInference:
         self.tape, self.requests = self.dealer.tape, self.dealer.requests
         self.dealer.tape = self.dealer.requests = None
         self.stats = dict(ctx.stats)
+        self._rehome_tape()                            # per-image random words -> one arena (before any pointer is captured)
         pre = PreloadedDealer(self.tape, self.device)
         self._ctx = SecureContext(pre, base, precision_fractional)
         self._model = SecureResNet18(self._ctx, state_dict, input_size, blocks)   # re-shares with the same masks
@@ -886,14 +840,107 @@ class GraphedSecureInference:
             with torch.cuda.graph(self.graph, stream=side):
                 self.out = self._model(self.image)
         torch.cuda.current_stream().wait_stream(side)
+        # the provider's block counter moves to the device, behind everything the offline pass drew
+        self._ctr = torch.tensor([self.dealer._block], dtype=I64, device=self.device)
+        self.dealer._block = None                      # (the host counter is dead from here on: rand64 would raise)
+        self.refills = 0
+        self._refill_launches()                        # eager: warms the dealer kernels AND replaces the warm-up primitives
+        self.refills = 1
+        self._refill_g = None
+        if self.refill_graph:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                self._refill_g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self._refill_g, stream=side):
+                    self._refill_launches()
+            torch.cuda.current_stream().wait_stream(side)
+
+    def _rehome_tape(self):
+        """Move every uniformly random tensor of the per-image primitives into ONE int64 arena (64-byte aligned slices, current
+        values kept) and record, per primitive, the launches that complete it after a fill."""
+        dev = self.device
+        al = lambda n: (n + 7) // 8 * 8
+        total, plan = 0, []
+        for i in range(self._n_model, len(self.tape)):
+            kind, args, _ = self.requests[i]
+            e = self.tape[i]
+            if kind == "const_mask":
+                sizes = [e.numel()]
+            elif kind == "triple":
+                (a0, b0, c0), (a1, b1, _c1) = e
+                sizes = [a0.numel(), a1.numel(), b0.numel(), b1.numel(), c0.numel()]
+            elif kind == "dif_keys":
+                sizes = [args[0], 4 * args[0], args[0]]        # raw alpha, both parties' seeds, alpha's mask
+            else:
+                raise _lib.PrimiaError(f"unknown primitive kind {kind!r}")
+            offs = []
+            for n in sizes:
+                offs.append(total)
+                total += al(n)
+            plan.append(offs)
+        self._arena = torch.empty(max(total, 8), dtype=I64, device=dev)
+
+        def view(off, src=None, shape=None):
+            shape = tuple(src.shape) if src is not None else shape
+            n = 1
+            for d in shape:
+                n *= d
+            v = self._arena[off:off + n].view(shape)
+            if src is not None:
+                v.copy_(src)
+            return v
+
+        self._ops, max_kn = [], 1
+        for i, offs in zip(range(self._n_model, len(self.tape)), plan):
+            kind, args, _ = self.requests[i]
+            e = self.tape[i]
+            if kind == "const_mask":
+                self.tape[i] = view(offs[0], e)
+            elif kind == "triple":
+                op, xshape, yshape = args
+                (a0, b0, c0), (a1, b1, c1) = e
+                a0, a1, b0, b1, c0 = (view(o, t) for o, t in zip(offs, (a0, a1, b0, b1, c0)))
+                self.tape[i] = [(a0, b0, c0), (a1, b1, c1)]
+                self._ops.append(("triple", op, xshape, yshape, a0, a1, b0, b1, c0, c1))
+                if op != "mul":
+                    max_kn = max(max_kn, xshape[-1] * yshape[-1])
+            else:
+                (n,) = args
+                k0, k1 = e
+                alpha = view(offs[0], shape=(n,))
+                s0 = view(offs[1], shape=(2, 2, n))
+                s0[0].copy_(k0["s0"])
+                s0[1].copy_(k1["s0"])
+                r = view(offs[2], k1["alpha"])
+                k0["s0"], k1["s0"], k1["alpha"] = s0[0], s0[1], r
+                self._ops.append(("dif", n, alpha, s0, r, k0["alpha"], k0["bits"], k0["cw_sigma"], k0["cw_s"], k0["cw_leaf"]))
+        self._mm_scratch = torch.empty(max_kn, dtype=I64, device=dev)
+
+    def _refill_launches(self):
+        d = self.dealer
+        n = self._arena.numel()
+        call("primia_chacha20_fill_ctr", *d._key, d._nonce, self._ctr, 0, self._arena, n)
+        for op in self._ops:
+            if op[0] == "triple":
+                _, kind, xshape, yshape, a0, a1, b0, b1, c0, c1 = op
+                d.triple_c1(kind, xshape, yshape, a0, a1, b0, b1, c0, c1, scratch=self._mm_scratch)
+            else:
+                _, m, alpha, s0, r, a0, bits, cw_sigma, cw_s, leaf = op
+                call("primia_fss_alpha_split", alpha, s0, r, a0, m)
+                call("primia_dif_keygen", alpha, s0, bits, cw_sigma, cw_s, leaf, m)
+        call("primia_u64_add", self._ctr, (n + 7) // 8)
 
     def refill(self):
-        """Fresh per-image primitives from the dealer, written into the captured buffers."""
-        for i in range(self._n_model, len(self.tape)):
-            kind, args, kw = self.requests[i]
-            self.dealer.refill_entry(kind, args, kw, self.tape[i])
+        """Fresh per-image primitives from the dealer, written into the captured buffers (on the current stream)."""
+        if self._refill_g is not None:
+            self._refill_g.replay()
+        else:
+            self._refill_launches()
+        self.refills += 1
 
     def __call__(self, image, refill=True):
+        """refill=False replays on the primitives the buffers hold (bit-identity checks against an eager forward on the
+        same tape; a deployment never serves two images on one set of primitives)."""
         if refill:
             self.refill()
         self.image.copy_(image)
@@ -907,9 +954,8 @@ class PipelinedSecureInference:
     The reference provisions primitives on demand, serially with the protocol (mpc/fss.py:142-146, primitives.py:161-235).
     Here two `GraphedSecureInference` slots (each its own dealer, static primitive buffers and captured online graph)
     alternate: while image i replays slot i % 2 on the caller's stream, the dealer refills the OTHER slot for image i + 1
-    on its own stream — its ~3,000 small launches per image (ChaCha20 fills, share splits, copies into the captured
-    buffers) are host-bound and vanish behind the one graph launch; its 21 key generations share the vector ALUs with
-    the online evaluation.  Events order a slot's refill after the replay that consumed it and the next replay after
+    on its own stream — one graph launch of its own (round 6; ~3,000 eager launches before) whose 21 key generations share the
+    vector ALUs with the online evaluation.  Events order a slot's refill after the replay that consumed it and the next replay after
     the refill.  Every image's shares are those of an eager SecureResNet18 on the slot's primitives (the graph is
     bit-identical to it, tests/test_gpu_secure.py); nothing about the protocol changes, only who waits for whom.
     In the three-role deployment the same overlap is physical: the dealer rank runs ahead of the parties on its own GPU."""
@@ -920,7 +966,10 @@ class PipelinedSecureInference:
                                              None if seed is None else seed + 7919 * k, blocks) for k in range(slots)]
         self.stats = self.slots[0].stats
         self.dealer_stream = torch.cuda.Stream(device=self.device)
-        self._ready = [None] * slots       # event: slot k's primitives are fresh (None: fresh since construction)
+        # event: slot k's primitives are fresh.  None = fresh since construction: GraphedSecureInference ends its constructor
+        # with a refill, so the first image of a slot never runs on the primitives the all-zero warm-up image consumed
+        assert all(sl.refills >= 1 for sl in self.slots)
+        self._ready = [None] * slots
         self._n = 0
 
     def __call__(self, image):

@@ -39,3 +39,26 @@ def test_product_fails_loudly_without_gpu():
 
     with pytest.raises(_lib.PrimiaError):
         ResNet18Engine(batch_size=2)
+
+
+def test_option_table_epoch_and_probe_only_switches():
+    """primia_set_option (host-side table, no GPU needed): the epoch counts CHANGES — restoring a value to what it already
+    is does not invalidate engines that sized buffers under it — unknown names are refused, and the two
+    timing-experiment switches that skip parts of a kernel (wrong results) are refused by the shipped library: only a probe
+    build (python -m primia_amd.build --probe, loaded explicitly by tools/) honours them."""
+    lib = _lib.lib()
+    assert lib.primia_reset_options() == 0
+    e0 = lib.primia_options_epoch()
+    _lib.set_option("lh2", _lib.get_option("lh2"))
+    assert lib.primia_options_epoch() == e0
+    _lib.set_option("c64_blocks", 300)
+    assert lib.primia_options_epoch() == e0 + 1 and _lib.get_option("c64_blocks") == 300
+    assert lib.primia_reset_options() == 0 and lib.primia_options_epoch() == e0 + 2
+    assert lib.primia_reset_options() == 0 and lib.primia_options_epoch() == e0 + 2
+    with pytest.raises(_lib.PrimiaError):
+        _lib.set_option("no_such_option", 1)
+    for name in ("c64_dbg", "s2lh_dbg"):
+        _lib.set_option(name, 0)
+        with pytest.raises(_lib.PrimiaError, match="UNSUPPORTED"):
+            _lib.set_option(name, 1)
+        assert _lib.get_option(name) == 0

@@ -1157,7 +1157,10 @@ def test_masked_accumulate_dgrad_with_stem_bn_backward_sums(cuda, c64_blocks, N,
     gradient writes the max-pool's output gradient and forms the stem BatchNorm's backward sums at pooled resolution, +
     primia_bn_relu_maxpool_bwd_from_sums, against primia_conv2d_dgrad_masked_acc followed by primia_bn_relu_maxpool_bwd(dy = NULL)
     — its PoolScatterFn reduction pass: dx bit-identical, dgamma / dbeta to summation order — one channel with gamma == 0
-    (served from y at the argmax by the finalize kernel)."""
+    and one with gamma = 1e-6 against beta = 0.3 (a pretrained bn1 has such channels): xhat = (p - beta) / gamma
+    from the STORED p would be bf16 rounding noise / gamma there, both are served from y at the argmax by the finalize
+    kernel.  dgamma / dbeta are also held to the float64 sums over (dpooled, y at the argmax): the two special channels
+    exactly (1e-4), the others within the rounding of the stored p (5e-2)."""
     dtype = torch.bfloat16
     dt = _lib.dtype_code(dtype)
     C = 64
@@ -1169,6 +1172,8 @@ def test_masked_accumulate_dgrad_with_stem_bn_backward_sums(cuda, c64_blocks, N,
     beta = (torch.randn(C, generator=g) * 0.5).to(cuda)
     gamma[5], beta[5] = 0.0, 0.7
     gamma[9] = -0.8
+    gamma[17], beta[17] = 1e-6, 0.3
+    gamma[23], beta[23] = -2e-4, 0.25
     ws = torch.zeros(query("primia_bn_workspace_bytes", Ms, C), dtype=torch.uint8, device=cuda)
     rm, rv = torch.zeros(C, device=cuda), torch.ones(C, device=cuda)
     sm, si = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
@@ -1194,10 +1199,24 @@ def test_masked_accumulate_dgrad_with_stem_bn_backward_sums(cuda, c64_blocks, N,
     sums = torch.full((slots, 2, C), 5.0, device=cuda)
     call("primia_conv2d_dgrad_masked_acc_bnsums", desc, dy1, wd, dp_b, acc_mask, 3, pool, None, beta, gamma, sums, dt)
     dg_b, db_b = torch.empty(C, device=cuda), torch.empty(C, device=cuda)
-    call("primia_bn_relu_maxpool_bwd_from_sums", ystem, pool, dp_b, am, gamma, sm, si, dg_b, db_b, sums, slots, N, Hs, Hs, C, dt)
+    call("primia_bn_relu_maxpool_bwd_from_sums", ystem, pool, dp_b, am, gamma, beta, sm, si, dg_b, db_b, sums, slots, N, Hs, Hs,
+         C, dt)
     assert torch.equal(dp_a, dp_b)
     assert relerr(db_b, db_a) < 2e-5 and relerr(dg_b, dg_a) < 2e-5
     assert abs(float(dg_b[5]) - float(dg_a[5])) <= 2e-5 * max(1.0, abs(float(dg_a[5])))
+    # float64 reference from the tensors the kernels read: g = dpooled * [p > 0] lands on y's argmax element
+    pv, dpv, code = pool.double().cpu().view(N, Ho, Ho, C), dp_b.double().cpu().view(N, Ho, Ho, C), am.cpu().view(N, Ho, Ho, C).long()
+    yv = ystem.double().cpu().view(N, Hs, Hs, C)
+    hh = (2 * torch.arange(Ho).view(1, Ho, 1, 1) - 1 + code // 3).clamp(0, Hs - 1)
+    ww = (2 * torch.arange(Ho).view(1, 1, Ho, 1) - 1 + code % 3).clamp(0, Hs - 1)
+    nn_, cc = torch.arange(N).view(N, 1, 1, 1).expand_as(code), torch.arange(C).view(1, 1, 1, C).expand_as(code)
+    xh = (yv[nn_, hh, ww, cc] - sm.double().cpu()) * si.double().cpu()
+    gg = dpv * (pv > 0)
+    db_ref, dg_ref = gg.sum((0, 1, 2)), (gg * xh).sum((0, 1, 2))
+    assert relerr(db_b.double().cpu(), db_ref) < 1e-5
+    for c in (5, 17, 23):       # served from y: exact up to summation order
+        assert abs(float(dg_b[c]) - float(dg_ref[c])) <= 1e-4 * max(1.0, abs(float(dg_ref[c]))), (c, float(dg_b[c]), float(dg_ref[c]))
+    assert relerr(dg_b.double().cpu(), dg_ref) < 5e-2
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -98,6 +98,58 @@ def test_ring_matmul(cuda, M, K, N):
     assert np.array_equal(host(c), S.radd(c0, S.rmatmul(a, b)))
 
 
+@pytest.mark.parametrize("op,xs,ys", [("mul", (37, 64), (37, 64)), ("mul", (64,), (49, 64)), ("mul", (1, 3, 5, 7), (7,)),
+                                      ("matmul", (1, 49, 256), (256, 512)), ("matmul", (196, 130), (130, 70)),
+                                      ("matmul", (1, 512), (512, 3))])
+def test_dealer_triple_completion_kernels(cuda, op, xs, ys):
+    """primia_triple_mul_c1 / primia_triple_matmul_c1 (mpc/beaver.py:7-63): with five uniform shares given, c1 completes the
+    triple: (a0 + a1) o (b0 + b1) == c0 + c1 in the ring, against the oracle's numpy ring arithmetic."""
+    rng = np.random.default_rng(len(xs) * 100 + len(ys))
+    rnd = lambda sh: rng.integers(-2 ** 63, 2 ** 63 - 1, size=sh, dtype=np.int64)
+    a0, a1, b0, b1 = rnd(xs), rnd(xs), rnd(ys), rnd(ys)
+    a, b = S.radd(a0, a1), S.radd(b0, b1)
+    want = S.rmul(a, b) if op == "mul" else S.rmatmul(a.reshape(xs[-2], xs[-1]), b).reshape(xs[:-1] + (ys[-1],))
+    c0 = rnd(want.shape)
+    d = Dealer(cuda, seed=1)
+    c1 = torch.empty(want.shape, dtype=I64, device=cuda)
+    d.triple_c1(op, xs, ys, dev(a0, cuda), dev(a1, cuda), dev(b0, cuda), dev(b1, cuda), dev(c0, cuda), c1)
+    assert np.array_equal(S.radd(c0, host(c1)), want)
+    # the dealer's own triples are complete ones
+    t = d.triple(op, xs, ys)
+    aa, bb, cc = (S.radd(host(t[0][k]), host(t[1][k])) for k in range(3))
+    assert np.array_equal(cc, S.rmul(aa, bb) if op == "mul" else S.rmatmul(aa.reshape(xs[-2], xs[-1]), bb).reshape(cc.shape))
+
+
+def test_dealer_keystream_counter_on_the_device_and_alpha_split(cuda):
+    """primia_chacha20_fill_ctr draws the block (device counter + offset) of primia_chacha20_fill's stream — the RFC 8439
+    checked keystream — and primia_u64_add advances the counter; primia_fss_alpha_split is build_fss_keys' host arithmetic
+    (mpc/primitives.py:249-251, mpc/fss.py:346,495-501) in place, against numpy."""
+    key, nonce = [3, 5, 7, 11], 77
+    n = 8 * 300 + 5
+    ref = torch.empty(n, dtype=I64, device=cuda)
+    call("primia_chacha20_fill", *key, nonce, 1000 + 17, ref, n)
+    ctr = torch.tensor([1000], dtype=I64, device=cuda)
+    out = torch.empty(n, dtype=I64, device=cuda)
+    call("primia_chacha20_fill_ctr", *key, nonce, ctr, 17, out, n)
+    assert torch.equal(out, ref)
+    call("primia_u64_add", ctr, 17)
+    call("primia_chacha20_fill_ctr", *key, nonce, ctr, 0, out, n)
+    assert torch.equal(out, ref) and int(ctr.item()) == 1017
+    m = 1000
+    rng = np.random.default_rng(9)
+    raw = lambda *sh: rng.integers(0, 2 ** 64, size=sh, dtype=np.uint64)
+    alpha, s0, r = raw(m), raw(2, 2, m), raw(m)
+    ta, ts, tr = dev(alpha, cuda), dev(s0, cuda), dev(r, cuda)
+    a0 = torch.empty(m, dtype=I64, device=cuda)
+    call("primia_fss_alpha_split", ta, ts, tr, a0, m)
+    m32, m63 = np.uint64(0xFFFFFFFF), np.uint64(0x7FFFFFFFFFFFFFFF)
+    want_s0 = s0.copy()
+    want_s0[:, 0] &= m63
+    assert np.array_equal(host(ta).view(np.uint64), alpha & m32) and np.array_equal(host(tr).view(np.uint64), r & m32)
+    assert np.array_equal(host(ts).view(np.uint64), want_s0)
+    assert np.array_equal(host(a0).view(np.uint64), ((alpha & m32) - (r & m32)) & m32)
+
+
 @pytest.mark.parametrize("kind", ["dif", "dpf"])
 def test_fss_kernels_golden(cuda, golden_dir, kind):
     """Keys generated on the GPU from the fixture's (alpha, s0) equal the reference's keys, and
@@ -250,10 +302,42 @@ def test_graphed_inference_matches_eager_and_refills(cuda):
     out_e = SecureResNet18(ctx, sd, 16, blocks)(img)
     assert torch.equal(out_g, out_e)
     before = g.tape[-1].clone() if torch.is_tensor(g.tape[-1]) else None
+    arena = g._arena.clone()
     out_r = g(img).clone()          # new primitives, same image
     assert torch.allclose(out_r, out_g, atol=1e-3)
     if before is not None:
         assert not torch.equal(before, g.tape[-1])
+    # every replay of the captured refill draws FRESH keystream (the block counter is a device word the graph advances),
+    # and the refilled primitives are complete: every triple multiplies out, on the tape the online graph reads
+    assert g.refills == 2 and g._refill_g is not None
+    assert int((g._arena == arena).sum()) <= 2          # (64-bit coincidences aside, no word repeats)
+    arena2 = g._arena.clone()
+    g.refill()
+    assert int((g._arena == arena2).sum()) <= 2
+    n_tr = 0
+    for i in range(g._n_model, len(g.tape)):
+        kind, args, _ = g.requests[i]
+        if kind != "triple":
+            continue
+        op, xs, ys = args
+        t = g.tape[i]
+        aa, bb, cc = (S.radd(host(t[0][k]), host(t[1][k])) for k in range(3))
+        want = S.rmul(aa, bb) if op == "mul" else S.rmatmul(aa.reshape(xs[-2], xs[-1]), bb).reshape(cc.shape)
+        assert np.array_equal(cc, want), i
+        n_tr += 1
+    assert n_tr > 20
+    # the eager form of the refill (refill_graph = False) hands out the same primitives: same logits, bit for bit
+    outs = []
+    for use_graph in (True, False):
+        GraphedSecureInference.refill_graph = use_graph
+        try:
+            h = GraphedSecureInference(sd, cuda, input_size=16, precision_fractional=16, seed=5, blocks=blocks)
+        finally:
+            GraphedSecureInference.refill_graph = True
+        assert (h._refill_g is not None) == use_graph
+        outs.append([h(img).clone() for _ in range(3)])
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
 
 
 @pytest.mark.parametrize("pf", [16])
@@ -320,6 +404,8 @@ def test_pipelined_inference_hides_the_dealer_without_changing_a_bit(cuda):
     runs = []
     for _ in range(2):
         p = PipelinedSecureInference(sd, cuda, input_size=16, precision_fractional=16, seed=11, blocks=blocks)
+        # no image runs on the primitives the all-zero warm-up image consumed: every slot was refilled once
+        assert all(sl.refills == 1 for sl in p.slots)
         runs.append([p(im) for im in imgs])
         torch.cuda.synchronize()
     for a, b in zip(*runs):

@@ -172,15 +172,163 @@ def test_fp32_gradients_hold_1e5_once_relu_branches_agree(cuda, batch, size, see
         assert (mine - ref32).norm() <= 1.5e-5 * ref32.norm(), f"{k}: {((mine - ref32).norm() / ref32.norm()).item():.2e}"
 
 
+def _bn_ref(sd, yt, name, B):
+    """float64 training BatchNorm of the STORED tensor yt: (xhat, invstd, gamma, bn(y))."""
+    yv = _nchw(yt, B).double()
+    mean = yv.mean((0, 2, 3), keepdim=True)
+    invstd = (yv.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-5).rsqrt()
+    gam = sd[name + ".weight"].double().view(1, -1, 1, 1)
+    bet = sd[name + ".bias"].double().view(1, -1, 1, 1)
+    xh = (yv - mean) * invstd
+    return xh, invstd, gam, xh * gam + bet
+
+
+def _bn_bwd_ref(g, xh, invstd, gam):
+    """(dy, dgamma, dbeta) of training BatchNorm for the output gradient g, float64."""
+    m = g.numel() / g.shape[1]
+    dbeta, dgamma = g.sum((0, 2, 3)), (g * xh).sum((0, 2, 3))
+    return gam * invstd * (g - dbeta.view(1, -1, 1, 1) / m - xh * dgamma.view(1, -1, 1, 1) / m), dgamma, dbeta
+
+
+def _full_size_links(eng, sd, x, B, idxs, stem=True):
+    """Every link of the step at full size on the ENGINE'S OWN operands (what the kernels read and wrote), float64 / fp32
+    references formed here.  Returns {label: (relative error, bound)}; the caller asserts."""
+    import torch.nn.functional as F
+
+    def rel(a, b):
+        return ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30)).item()
+
+    errs = {}
+    blocks = eng.spec.blocks
+    for i in idxs:
+        blk = blocks[i]
+        p = blk.prefix
+        xin = eng.t["pool.out"] if i == 0 else eng.t[blocks[i - 1].prefix + ".out"]
+        layers = [(blk.conv1, xin, "y1", "dy1", None), (blk.conv2, eng.t[p + ".a1"], "y2", "dy2", "da1")]
+        if blk.down is not None:
+            layers.append((blk.down, xin, "yd", "dyd", None))
+        for c, xt, yn, dyn, dxn in layers:
+            d = eng.convs[c.name].desc
+            xc, yc, dyc = _nchw(xt, B), _nchw(eng.t[f"{p}.{yn}"], B), _nchw(eng.t[f"{p}.{dyn}"], B)
+            w = sd[c.name + ".weight"].bfloat16().float()
+            errs[f"{c.name} forward"] = (rel(yc, F.conv2d(xc, w, None, d.stride, d.pad)), 3e-3)
+            gref = torch.nn.grad.conv2d_weight(xc, w.shape, dyc, d.stride, d.pad)
+            errs[f"{c.name} wgrad"] = (rel(eng.gviews[c.name + ".weight"].float().cpu(), gref), 1e-4)
+            if dxn is not None:
+                dxref = torch.nn.grad.conv2d_input(xc.shape, w, dyc, d.stride, d.pad)
+                errs[f"{c.name} dgrad"] = (rel(_nchw(eng.t[f"{p}.{dxn}"], B), dxref), 3e-3)
+        # the BatchNorm passes of the block: forward a1 = relu(bn1(y1)), out = relu(bn2(y2) + residual) with batch statistics
+        # (one bf16 rounding: 3e-3); backward of bn1 from the buffers it read (da1 = conv2's data gradient, y1) and wrote
+        # (dy1, dgamma, dbeta); backward of bn2 (and of the downsample branch's BatchNorm) from the gradient w.r.t. the
+        # block's output AS ITS BACKWARD PASS READ IT (engine.taps: the buffer is consumed in place afterwards), the ReLU
+        # mask of the stored output and y2 / yd.  These are the passes whose reductions round 5 moved into the write-backs of
+        # the data-gradient kernels (head_bnsums, pair_bnsums, acc_bnsums) — dy 3e-3, dgamma / dbeta 1e-4, as bn1.
+        b1, b2 = rs.bn_name(blk.conv1.name), rs.bn_name(blk.conv2.name)
+        xh1, invstd1, gam1, z1 = _bn_ref(sd, eng.t[p + ".y1"], b1, B)
+        a1 = _nchw(eng.t[p + ".a1"], B).double()
+        errs[f"{p} bn1 forward"] = (rel(a1, z1.clamp_min(0)), 3e-3)
+        dyref, dgamma, dbeta = _bn_bwd_ref(_nchw(eng.t[p + ".da1"], B).double() * (a1 > 0), xh1, invstd1, gam1)
+        errs[f"{p} bn1 backward dy"] = (rel(_nchw(eng.t[p + ".dy1"], B), dyref), 3e-3)
+        errs[f"{p} bn1 dbeta"] = (rel(eng.gviews[b1 + ".bias"].cpu(), dbeta), 1e-4)
+        errs[f"{p} bn1 dgamma"] = (rel(eng.gviews[b1 + ".weight"].cpu(), dgamma), 1e-4)
+        del xh1, z1, dyref
+        xh2, invstd2, gam2, z2 = _bn_ref(sd, eng.t[p + ".y2"], b2, B)
+        if blk.down is None:
+            res = _nchw(xin, B).double()
+        else:   # the downsample branch's BatchNorm output is rounded to the storage type before the add
+            bd = rs.bn_name(blk.down.name)
+            xhd, invstdd, gamd, zd = _bn_ref(sd, eng.t[p + ".yd"], bd, B)
+            res = zd.float().bfloat16().double()
+        outv = _nchw(eng.t[p + ".out"], B).double()
+        errs[f"{p} bn2 forward"] = (rel(outv, (z2 + res).clamp_min(0)), 3e-3)
+        g = _nchw(eng.taps[p + ".dout_in"], B).double() * (outv > 0)
+        dyref, dgamma, dbeta = _bn_bwd_ref(g, xh2, invstd2, gam2)
+        errs[f"{p} bn2 backward dy"] = (rel(_nchw(eng.t[p + ".dy2"], B), dyref), 3e-3)
+        errs[f"{p} bn2 dbeta"] = (rel(eng.gviews[b2 + ".bias"].cpu(), dbeta), 1e-4)
+        errs[f"{p} bn2 dgamma"] = (rel(eng.gviews[b2 + ".weight"].cpu(), dgamma), 1e-4)
+        if blk.down is not None:
+            dyref, dgamma, dbeta = _bn_bwd_ref(g, xhd, invstdd, gamd)
+            errs[f"{p} downsample bn backward dy"] = (rel(_nchw(eng.t[p + ".dyd"], B), dyref), 3e-3)
+            errs[f"{p} downsample bn dbeta"] = (rel(eng.gviews[bd + ".bias"].cpu(), dbeta), 1e-4)
+            errs[f"{p} downsample bn dgamma"] = (rel(eng.gviews[bd + ".weight"].cpu(), dgamma), 1e-4)
+            del xhd, zd
+        del xh2, z2, g, dyref, outv, res
+    if not stem:
+        return errs
+    # ---- the stem's tail: conv1 <- bn1 <- relu <- maxpool, from the pool's output gradient (complete once layer1.0.conv1's
+    # accumulating data gradient has run; nothing overwrites it), the pooled activation, the argmax codes and conv1's stored
+    # output.  A window's gradient lands on its argmax element; bn1's sums (formed at pooled resolution inside that data
+    # gradient's write-back, acc_bnsums mode 3, with xhat = (p - beta) / gamma read off the STORED pooled value: its bf16
+    # rounding is zero-mean noise of 2^-9 per element, hence 1e-3 for dgamma) and conv1's weight gradient, whose dy tiles the
+    # fused kernel forms on the fly in the storage type (primia_stem_bwd_fused).  16 channels at a time: 1.6 GB per float64
+    # tensor otherwise.
+    hw, ph = eng.stem_hw, eng.pool_hw
+    assert eng.stem_bwd_fused_active
+    gp_all = eng.t["pool.dout"].float().cpu().view(B, ph, ph, 64)
+    pv_all = eng.t["pool.out"].float().cpu().view(B, ph, ph, 64)
+    code_all = eng.pool_argmax.cpu().view(B, ph, ph, 64).long()
+    y_all = eng.t["stem.y"].cpu().view(B, hw, hw, 64)
+    # forward: pooled = maxpool(relu(bn1(y))) and the argmax element holds that maximum
+    dy_ref = torch.empty(B, 64, hw, hw, dtype=torch.bfloat16)
+    dbeta_all, dgamma_all = torch.empty(64, dtype=torch.float64), torch.empty(64, dtype=torch.float64)
+    fwd_num = fwd_den = 0.0
+    oo = torch.arange(ph)
+    for c0 in range(0, 64, 16):
+        cs = slice(c0, c0 + 16)
+        yv = y_all[..., cs].double().permute(0, 3, 1, 2)                     # [B, 16, hw, hw]
+        mean = yv.mean((0, 2, 3), keepdim=True)
+        invstd = (yv.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        gam, bet = sd["bn1.weight"][cs].double().view(1, -1, 1, 1), sd["bn1.bias"][cs].double().view(1, -1, 1, 1)
+        xh = (yv - mean) * invstd
+        z = (xh * gam + bet).clamp_min(0)
+        pooled = F.max_pool2d(z, 3, 2, 1)
+        pv = pv_all[..., cs].double().permute(0, 3, 1, 2)
+        fwd_num += float((pv - pooled).pow(2).sum())
+        fwd_den += float(pooled.pow(2).sum())
+        code = code_all[..., cs].permute(0, 3, 1, 2)
+        hh = 2 * oo.view(1, 1, ph, 1) - 1 + code // 3
+        ww = 2 * oo.view(1, 1, 1, ph) - 1 + code % 3
+        assert int(hh.min()) >= 0 and int(hh.max()) < hw and int(ww.min()) >= 0 and int(ww.max()) < hw
+        nn_ = torch.arange(B).view(B, 1, 1, 1).expand_as(code)
+        cc = torch.arange(16).view(1, 16, 1, 1).expand_as(code)
+        # the argmax element IS the window maximum (of the values as stored: within one bf16 rounding of the float64 z)
+        zmax = z[nn_, cc, hh, ww]
+        assert float((zmax - pooled).abs().max()) <= 2.0 ** -7 * float(pooled.abs().max())
+        gwin = gp_all[..., cs].double().permute(0, 3, 1, 2) * (pv > 0)
+        dz = torch.zeros_like(yv)
+        dz.index_put_((nn_, cc, hh, ww), gwin, accumulate=True)
+        dyc, dgamma, dbeta = _bn_bwd_ref(dz, xh, invstd, gam)
+        dy_ref[:, cs] = dyc.float().bfloat16()
+        dbeta_all[cs], dgamma_all[cs] = dbeta, dgamma
+        del yv, xh, z, dz, dyc
+    errs["stem pooled forward"] = ((fwd_num / fwd_den) ** 0.5, 3e-3)
+    errs["stem bn1 dbeta"] = (rel(eng.gviews["bn1.bias"].cpu(), dbeta_all), 1e-4)
+    errs["stem bn1 dgamma (xhat from the stored pooled value)"] = (rel(eng.gviews["bn1.weight"].cpu(), dgamma_all), 1e-3)
+    xq = x.bfloat16().float()
+    gref = torch.nn.grad.conv2d_weight(xq, sd["conv1.weight"].shape, dy_ref.float(), 2, 3)
+    errs["conv1 wgrad (dy tiles formed on the fly)"] = (rel(eng.gviews["conv1.weight"].float().cpu(), gref), 1e-3)
+    return errs
+
+
+def _assert_links(errs):
+    bad = {k: v for k, v in errs.items() if not v[0] <= v[1]}
+    table = "\n".join(f"  {k:58s} {v[0]:.2e}  (bound {v[1]:.0e})" for k, v in errs.items())
+    print("full-size links, relative errors:\n" + table)
+    assert not bad, "\n".join(f"{k}: {v[0]:.2e} > {v[1]:.0e}" for k, v in bad.items())
+
+
 def test_bf16_full_size_step_against_oracle(cuda):
     """BASELINE configs[1] exactly (batch 256, 3x224x224, bf16 storage / fp32 accumulate), the kernels the benchmark times:
       1. logits within 3e-2 and loss within 2e-3 of the fp32 CPU oracle on the same batch;
-      2. every convolution at full size on the ENGINE'S OWN operands: forward output within 3e-3 of
-         conv2d(x, w) in fp32 (= one bf16 rounding of the result), weight gradient within 1e-4 of
+      2. every link of the step at full size on the ENGINE'S OWN operands (_full_size_links): every convolution — forward
+         output within 3e-3 of conv2d(x, w) in fp32 (= one bf16 rounding of the result), weight gradient within 1e-4 of
          conv2d_weight(x, dy), data gradient (where it lands in a buffer of its own; the conv1 + downsample pair of the
-         transition blocks: test_transition_dgrad_pair_at_full_size) within 3e-3; every block's BatchNorm forward passes (batch statistics, ReLU, residual /
-         downsample branch) within 3e-3 and bn1's backward pass (dy within 3e-3, dgamma / dbeta within 1e-4) from the
-         buffers the kernels read and wrote — each link of the backward chain is held at full size, not only the ends;
+         transition blocks: test_transition_dgrad_pair_at_full_size) within 3e-3; every block's BatchNorm forward passes
+         (batch statistics, ReLU, residual / downsample branch) within 3e-3; the backward pass of EVERY BatchNorm — bn1 of
+         each block, bn2 of each block (residual and downsample branch; their reductions ride in the data-gradient
+         write-backs of the head, the transition pairs and layer1's accumulate forms since round 5), the stem's bn1 through
+         the max-pool and conv1's weight gradient behind it — dy within 3e-3, dgamma / dbeta within 1e-4, from the buffers
+         the kernels read and wrote;
       3. end-to-end gradients against the fp32 oracle: bf16 STORAGE makes them deviate by 25-50 % per tensor on this
          randomly initialised network — the CPU oracle with nothing but bf16 rounding at the engine's storage points
          (O.forward(bf16_storage=True)) is as far from the fp32 oracle as the engine is — so the bound is that band,
@@ -195,63 +343,18 @@ def test_bf16_full_size_step_against_oracle(cuda):
     y = torch.randint(0, 3, (B,), generator=g)
     eng = ResNet18Engine(B, 3, 3, S, "max", dtype=torch.bfloat16, device=cuda)
     eng.load_state_dict(sd)
+    eng.taps = {}
     logits = eng.forward(x.to(cuda)).float().cpu()
     loss = eng.loss_backward(y.to(cuda)).item()
+    # the fused reductions are the paths taken
+    assert eng.dgrad_bnsums and eng.pair_bnsums and eng.acc_bnsums and eng.head_bnsums
+    assert set(eng._bwd_sum_bufs) >= {"head", "layer1.0.conv1.acc", "layer1.1.conv1.acc", "layer2.0.conv1.pair",
+                                      "layer3.0.conv1.pair", "layer4.0.conv1.pair"}
     ologits, oloss, ograds = O.train_step(sd, x, y, 0.0, 0.0)
     assert (logits - ologits).norm() / ologits.norm() < 3e-2
     assert abs(loss - oloss.item()) < 2e-3 * abs(oloss.item())
     # ---- 2. per layer, full size, the engine's own bf16 operands -------------------------------------------------
-    blocks = eng.spec.blocks
-    for i, blk in enumerate(blocks):
-        p = blk.prefix
-        xin = eng.t["pool.out"] if i == 0 else eng.t[blocks[i - 1].prefix + ".out"]
-        layers = [(blk.conv1, xin, "y1", "dy1", None), (blk.conv2, eng.t[p + ".a1"], "y2", "dy2", "da1")]
-        if blk.down is not None:
-            layers.append((blk.down, xin, "yd", "dyd", None))
-        for c, xt, yn, dyn, dxn in layers:
-            d = eng.convs[c.name].desc
-            xc, yc, dyc = _nchw(xt, B), _nchw(eng.t[f"{p}.{yn}"], B), _nchw(eng.t[f"{p}.{dyn}"], B)
-            w = sd[c.name + ".weight"].bfloat16().float()
-            yref = F.conv2d(xc, w, None, d.stride, d.pad)
-            assert (yc - yref).norm() <= 3e-3 * yref.norm(), f"{c.name} forward"
-            gref = torch.nn.grad.conv2d_weight(xc, w.shape, dyc, d.stride, d.pad)
-            got = eng.gviews[c.name + ".weight"].float().cpu()
-            assert (got - gref).norm() <= 1e-4 * gref.norm(), f"{c.name} wgrad {((got - gref).norm() / gref.norm()).item():.2e}"
-            if dxn is not None:
-                dxref = torch.nn.grad.conv2d_input(xc.shape, w, dyc, d.stride, d.pad)
-                dx = _nchw(eng.t[f"{p}.{dxn}"], B)
-                assert (dx - dxref).norm() <= 3e-3 * dxref.norm(), f"{c.name} dgrad"
-        # ---- 2b. the BatchNorm passes of the block at full size, on the engine's own operands -------------------------
-        # forward: a1 = relu(bn1(y1)), out = relu(bn2(y2) + residual) with batch statistics (one bf16 rounding: 3e-3);
-        # backward of bn1 from the buffers it read (da1 = conv2's data gradient, y1) and wrote (dy1, dgamma, dbeta)
-        def bn_ref(yt, name):
-            yv = _nchw(yt, B).double()
-            mean = yv.mean((0, 2, 3), keepdim=True)
-            invstd = (yv.var((0, 2, 3), unbiased=False, keepdim=True) + 1e-5).rsqrt()
-            gam = sd[name + ".weight"].double().view(1, -1, 1, 1)
-            bet = sd[name + ".bias"].double().view(1, -1, 1, 1)
-            xh = (yv - mean) * invstd
-            return xh, invstd, gam, xh * gam + bet
-
-        xh1, invstd1, gam1, z1 = bn_ref(eng.t[p + ".y1"], rs.bn_name(blk.conv1.name))
-        a1 = _nchw(eng.t[p + ".a1"], B).double()
-        assert (a1 - z1.clamp_min(0)).norm() <= 3e-3 * a1.norm(), f"{p} bn1 forward"
-        _, _, _, z2 = bn_ref(eng.t[p + ".y2"], rs.bn_name(blk.conv2.name))
-        if blk.down is None:
-            res = _nchw(xin, B).double()
-        else:   # the downsample branch's BatchNorm output is rounded to the storage type before the add
-            res = bn_ref(eng.t[p + ".yd"], rs.bn_name(blk.down.name))[3].float().bfloat16().double()
-        outv = _nchw(eng.t[p + ".out"], B).double()
-        assert (outv - (z2 + res).clamp_min(0)).norm() <= 3e-3 * outv.norm(), f"{p} bn2 forward"
-        gin = _nchw(eng.t[p + ".da1"], B).double() * (a1 > 0)
-        m = gin.numel() / gin.shape[1]
-        dbeta, dgamma = gin.sum((0, 2, 3)), (gin * xh1).sum((0, 2, 3))
-        dyref = gam1 * invstd1 * (gin - dbeta.view(1, -1, 1, 1) / m - xh1 * dgamma.view(1, -1, 1, 1) / m)
-        dy1 = _nchw(eng.t[p + ".dy1"], B).double()
-        assert (dy1 - dyref).norm() <= 3e-3 * dyref.norm(), f"{p} bn1 backward {((dy1 - dyref).norm() / dyref.norm()).item():.2e}"
-        b1 = rs.bn_name(blk.conv1.name)
-        assert (eng.gviews[b1 + ".bias"].double().cpu() - dbeta).norm() <= 1e-4 * dbeta.norm() + 1e-9, f"{p} bn1 dbeta"
-        assert (eng.gviews[b1 + ".weight"].double().cpu() - dgamma).norm() <= 1e-4 * dgamma.norm() + 1e-9, f"{p} bn1 dgamma"
+    _assert_links(_full_size_links(eng, sd, x, B, range(len(eng.spec.blocks))))
     # ---- 3. end to end ------------------------------------------------------------------------------------------------
     osd = {k: v.clone() for k, v in sd.items()}
     for k in O.param_keys(osd):
@@ -265,6 +368,35 @@ def test_bf16_full_size_step_against_oracle(cuda):
         e_engine, e_model = rel(eng.gviews[k].cpu(), ograds[k]), rel(osd[k].grad, ograds[k])
         assert e_engine < 0.6, f"{k}: {e_engine:.2f}"
         assert e_engine < 1.25 * e_model + 0.02, f"{k}: engine {e_engine:.3f} vs bf16-storage model {e_model:.3f}"
+
+
+@pytest.mark.parametrize("c64_blocks,c64_stages", [(300, 4), (437, 3)])
+def test_bf16_full_size_layer1_links_on_other_block_counts(cuda, c64_blocks, c64_stages):
+    """The same full-size links for layer1 and the stem with conv3x3_c64_kernel on a NON-default number of persistent blocks
+    (and ring depth): at 512 blocks every block walks the same number of patches; other counts give ragged ranges, so the
+    kernel's counted waits on its LDS-DMA ring (halo pieces, old rows, BatchNorm rows, mask words one iteration ahead) see
+    other phase relations at batch 256 than the default run above — the size at which round 5's asm-store hazard showed."""
+    from primia_amd import _lib
+
+    B, S = 256, 224
+    torch.manual_seed(42)
+    sd = rs.init_state_dict(rs.resnet18_spec(3, 3, S, "max"))
+    g = torch.Generator().manual_seed(43)
+    x = torch.randn(B, 3, S, S, generator=g)
+    y = torch.randint(0, 3, (B,), generator=g)
+    _lib.set_option("c64_blocks", c64_blocks)
+    _lib.set_option("c64_stages", c64_stages)
+    try:
+        eng = ResNet18Engine(B, 3, 3, S, "max", dtype=torch.bfloat16, device=cuda)
+        eng.load_state_dict(sd)
+        eng.taps = {}
+        eng.forward(x.to(cuda))
+        eng.loss_backward(y.to(cuda))
+        torch.cuda.synchronize()
+        _assert_links(_full_size_links(eng, sd, x, B, [0, 1]))
+    finally:
+        _lib.set_option("c64_blocks", 512)      # (the table's defaults, csrc/options.h)
+        _lib.set_option("c64_stages", 4)
 
 
 def test_bf16_engine_tracks_oracle(cuda):

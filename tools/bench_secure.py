@@ -160,7 +160,7 @@ def main():
     # The online phase as ONE hipGraph (6,500 small launches per image): primitives sit in static buffers (a
     # deployment refills them from the dealer between images), the replay is checked bit for bit against the
     # eager run with the same primitives.
-    graph_ms = refill_ms = pipe_ms = None
+    graph_ms = refill_ms = pipe_ms = refill_nodes = arena_mb = None
     if not a.no_graph:
         try:
             from primia_amd.secure import GraphedSecureInference
@@ -174,10 +174,15 @@ def main():
                 gi(img, refill=False)
             torch.cuda.synchronize()
             graph_ms = (time.perf_counter() - t0) / 3 * 1e3
+            # the dealer's refill: ONE graph launch since round 6 (an eager loop of ~3,000 launches before)
+            gi.refill(); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            gi.refill()
+            for _ in range(3):
+                gi.refill()
             torch.cuda.synchronize()
-            refill_ms = (time.perf_counter() - t0) * 1e3
+            refill_ms = (time.perf_counter() - t0) / 3 * 1e3
+            refill_nodes = 2 + sum(1 if op[0] == "triple" and op[1] == "mul" else (3 if op[0] == "triple" else 2) for op in gi._ops)
+            arena_mb = gi._arena.numel() * 8 / 1e6
             del gi
             # a STREAM of images with the dealer hidden behind the online phase (two graph slots, the dealer refills one
             # on its own stream while the other replays): wall time per image, every image on fresh primitives
@@ -214,6 +219,7 @@ def main():
     print(json.dumps({"metric": "encrypted_inference_ms_per_image", "online_ms": round(to * 1e3, 1),
                       "online_graph_ms": None if graph_ms is None else round(graph_ms, 1),
                       "dealer_refill_ms": None if refill_ms is None else round(refill_ms, 1),
+                      "dealer_refill_launches": refill_nodes, "dealer_keystream_mb_per_image": None if arena_mb is None else round(arena_mb, 1),
                       "with_dealer_ms": round(tt * 1e3, 1), "dealer_ms": round((tt - to) * 1e3, 1),
                       "with_dealer_pipelined_ms": None if pipe_ms is None else round(pipe_ms, 1),
                       "precision_fractional": a.pf, "size": a.size, "dif_evals": ctx.stats["dif_evals"],

@@ -5,6 +5,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from primia_amd import _lib
+
+# the phase switches exist in probe builds only (python -m primia_amd.build --probe); the shipped library refuses s2lh_dbg
+_lib.LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "micro", "libprimia_probe.so")
 from primia_amd._lib import ConvDesc, call, query
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256

@@ -5,6 +5,7 @@
 cd "$(dirname "$0")/.."
 C=primia_amd/csrc
 cp primia_amd/libprimia_hip.so /tmp/_shipped.so
+trap 'cp /tmp/_shipped.so primia_amd/libprimia_hip.so' EXIT INT TERM     # an interrupted run must not leave a variant installed
 for v in "$@"; do
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-result $v -c $C/conv_s2lh.hip -o /tmp/s2v.o 2>/dev/null || { echo "build failed: $v"; continue; }
   objs=$(ls $C/_build/*.o | grep -v conv_s2lh.o)
