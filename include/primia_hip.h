@@ -775,7 +775,7 @@ int primia_u64_add(uint64_t* word, uint64_t delta, primia_stream_t stream);
 /* build_triple's second product share from input shares that were drawn directly (mpc/beaver.py:7-63: a, b uniform, c = a o b
  * split additively; a = a0 + a1 with both shares uniform IS a sharing of a uniform a): c1 = (x0 + x1) o (y0 + y1) - c0.
  * _mul_: element-wise, (y0, y1) of nb elements broadcast over the leading dims of the n-element x (nb divides n);
- * _matmul_: [M, K] @ [K, N], scratch = K * N int64. */
+ * _matmul_: [M, K] @ [K, N], scratch = M * K + K * N int64. */
 int primia_triple_mul_c1(const int64_t* x0, const int64_t* x1, const int64_t* y0, const int64_t* y1, const int64_t* c0,
                          int64_t* c1, int64_t n, int64_t nb, primia_stream_t stream);
 int primia_triple_matmul_c1(const int64_t* a0, const int64_t* a1, const int64_t* b0, const int64_t* b1, const int64_t* c0,

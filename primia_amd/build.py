@@ -6,12 +6,14 @@ cross-compiles without a GPU.
 """
 import concurrent.futures
 import os
+import shutil
 import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_build")
+ISA = os.path.join(OBJ, "isa")      # device assembly of every object (kept by the build, see compile_one)
 LIB = os.path.join(HERE, "libprimia_hip.so")
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result"]
@@ -65,13 +67,25 @@ def build(force=False, verbose=True):
     for f in sources:
         src = os.path.join(CSRC, f)
         obj = os.path.join(OBJ, f[:-4] + ".o")
-        if force or _newer(src, obj, headers):
+        if force or _newer(src, obj, headers) or not os.path.exists(os.path.join(ISA, f[:-4] + ".s")):
             jobs.append((src, obj))
 
     def compile_one(job):
+        # -save-temps: the device ISA of THIS object is kept as csrc/_build/isa/<name>.s (with the ;;#ASMSTART / ;;#ASMEND
+        # markers of inline asm) — what tools/check_asm_hazards.py and tools/isa_budget.py read.  The flag does not change
+        # the code (checked: the unbundled gfx950 code objects disassemble identically with and without it).
         src, obj = job
-        cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+        name = os.path.basename(src)[:-4]
+        tmp = os.path.join(OBJ, "tmp_" + name)
+        shutil.rmtree(tmp, ignore_errors=True)
+        os.makedirs(tmp)
+        cmd = [_hipcc(), *FLAGS, "-save-temps=obj", "-c", src, "-o", os.path.join(tmp, name + ".o")]
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            os.makedirs(ISA, exist_ok=True)
+            os.replace(os.path.join(tmp, f"{name}-hip-amdgcn-amd-amdhsa-{ARCH}.s"), os.path.join(ISA, name + ".s"))
+            os.replace(os.path.join(tmp, name + ".o"), obj)
+        shutil.rmtree(tmp, ignore_errors=True)
         return src, r.returncode, r.stdout + r.stderr
 
     if jobs:

@@ -492,11 +492,13 @@ int primia_triple_matmul_c1(const int64_t* a0, const int64_t* a1, const int64_t*
                             int64_t* c1, int64_t* scratch, int M, int K, int N, primia_stream_t st) {
     PRIMIA_REQUIRE(a0 && a1 && b0 && b1 && c0 && c1 && scratch && M > 0 && K > 0 && N > 0);
     hipStream_t s = (hipStream_t)st;
-    const long kn = (long)K * N, mn = (long)M * N;
-    // b = b0 + b1; c1 = a0 @ b + a1 @ b (= a @ b: the ring is distributive); c1 -= c0
-    ring_ew_kernel<0><<<ew_blocks(kn), 256, 0, s>>>((const u64*)b0, (const u64*)b1, (u64*)scratch, kn, kn);
-    const int rc = launch_gemm(GemmPair{(const u64*)a0, (const u64*)scratch}, GemmPair{(const u64*)a1, (const u64*)scratch},
-                               nullptr, (u64*)c1, M, K, N, s);
+    const long kn = (long)K * N, mn = (long)M * N, mk = (long)M * K;
+    // a = a0 + a1, b = b0 + b1 (scratch: [M K | K N]); c1 = a @ b; c1 -= c0
+    u64* sa = (u64*)scratch;
+    u64* sb = sa + mk;
+    ring_ew_kernel<0><<<ew_blocks(mk), 256, 0, s>>>((const u64*)a0, (const u64*)a1, sa, mk, mk);
+    ring_ew_kernel<0><<<ew_blocks(kn), 256, 0, s>>>((const u64*)b0, (const u64*)b1, sb, kn, kn);
+    const int rc = launch_gemm(GemmPair{sa, sb}, GemmPair{nullptr, nullptr}, nullptr, (u64*)c1, M, K, N, s);
     if (rc != PRIMIA_OK) return rc;
     ring_sub_inplace_kernel<<<ew_blocks(mn), 256, 0, s>>>((u64*)c1, (const u64*)c0, mn);
     return launch_status();

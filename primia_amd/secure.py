@@ -104,7 +104,7 @@ class Dealer:
         else:
             M, K, N = xshape[-2], xshape[-1], yshape[-1]
             if scratch is None:
-                scratch = torch.empty(K * N, dtype=I64, device=self.device)
+                scratch = torch.empty(M * K + K * N, dtype=I64, device=self.device)
             call("primia_triple_matmul_c1", a0, a1, b0, b1, c0, c1, scratch, M, K, N)
 
     def dif_keys(self, n):
@@ -903,7 +903,7 @@ class GraphedSecureInference:
                 self.tape[i] = [(a0, b0, c0), (a1, b1, c1)]
                 self._ops.append(("triple", op, xshape, yshape, a0, a1, b0, b1, c0, c1))
                 if op != "mul":
-                    max_kn = max(max_kn, xshape[-1] * yshape[-1])
+                    max_kn = max(max_kn, xshape[-2] * xshape[-1] + xshape[-1] * yshape[-1])
             else:
                 (n,) = args
                 k0, k1 = e

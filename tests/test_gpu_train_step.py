@@ -258,10 +258,13 @@ def _full_size_links(eng, sd, x, B, idxs, stem=True):
     # ---- the stem's tail: conv1 <- bn1 <- relu <- maxpool, from the pool's output gradient (complete once layer1.0.conv1's
     # accumulating data gradient has run; nothing overwrites it), the pooled activation, the argmax codes and conv1's stored
     # output.  A window's gradient lands on its argmax element; bn1's sums (formed at pooled resolution inside that data
-    # gradient's write-back, acc_bnsums mode 3, with xhat = (p - beta) / gamma read off the STORED pooled value: its bf16
-    # rounding is zero-mean noise of 2^-9 per element, hence 1e-3 for dgamma) and conv1's weight gradient, whose dy tiles the
-    # fused kernel forms on the fly in the storage type (primia_stem_bwd_fused).  16 channels at a time: 1.6 GB per float64
-    # tensor otherwise.
+    # gradient's write-back, acc_bnsums mode 3) and conv1's weight gradient, whose dy tiles the fused kernel forms on the fly
+    # in the storage type (primia_stem_bwd_fused).  dgamma there uses xhat = (p - beta) / gamma read off the STORED pooled
+    # value p: p carries one bf16 rounding (half an ulp, uniform, zero mean), so sum g * xhat carries per channel a random
+    # error of standard deviation sigma_c = sqrt(sum (g * ulp(p) / sqrt(12) / gamma)^2) — measured 4.7e-3 of |dgamma| over
+    # the 64 channels at batch 256, because dgamma is itself a sum of 800 k terms of both signs.  The bound is therefore that
+    # noise model: every channel within 5 sigma_c (+ 1e-4 |dgamma_c|), no common sign (a bias would show as a mean z-score
+    # away from 0), 2e-2 overall.  16 channels at a time: 1.6 GB per float64 tensor otherwise.
     hw, ph = eng.stem_hw, eng.pool_hw
     assert eng.stem_bwd_fused_active
     gp_all = eng.t["pool.dout"].float().cpu().view(B, ph, ph, 64)
@@ -271,6 +274,7 @@ def _full_size_links(eng, sd, x, B, idxs, stem=True):
     # forward: pooled = maxpool(relu(bn1(y))) and the argmax element holds that maximum
     dy_ref = torch.empty(B, 64, hw, hw, dtype=torch.bfloat16)
     dbeta_all, dgamma_all = torch.empty(64, dtype=torch.float64), torch.empty(64, dtype=torch.float64)
+    sigma_all = torch.empty(64, dtype=torch.float64)
     fwd_num = fwd_den = 0.0
     oo = torch.arange(ph)
     for c0 in range(0, 64, 16):
@@ -295,6 +299,8 @@ def _full_size_links(eng, sd, x, B, idxs, stem=True):
         zmax = z[nn_, cc, hh, ww]
         assert float((zmax - pooled).abs().max()) <= 2.0 ** -7 * float(pooled.abs().max())
         gwin = gp_all[..., cs].double().permute(0, 3, 1, 2) * (pv > 0)
+        ulp = torch.where(pv > 0, torch.exp2(torch.floor(torch.log2(pv.clamp_min(1e-30))) - 7), torch.zeros_like(pv))
+        sigma_all[cs] = ((gwin * ulp / 12 ** 0.5 / gam) ** 2).sum((0, 2, 3)).sqrt()
         dz = torch.zeros_like(yv)
         dz.index_put_((nn_, cc, hh, ww), gwin, accumulate=True)
         dyc, dgamma, dbeta = _bn_bwd_ref(dz, xh, invstd, gam)
@@ -303,7 +309,12 @@ def _full_size_links(eng, sd, x, B, idxs, stem=True):
         del yv, xh, z, dz, dyc
     errs["stem pooled forward"] = ((fwd_num / fwd_den) ** 0.5, 3e-3)
     errs["stem bn1 dbeta"] = (rel(eng.gviews["bn1.bias"].cpu(), dbeta_all), 1e-4)
-    errs["stem bn1 dgamma (xhat from the stored pooled value)"] = (rel(eng.gviews["bn1.weight"].cpu(), dgamma_all), 1e-3)
+    dg = eng.gviews["bn1.weight"].double().cpu()
+    errs["stem bn1 dgamma (xhat from the stored pooled value)"] = (rel(dg, dgamma_all), 2e-2)
+    zs = (dg - dgamma_all) / sigma_all.clamp_min(1e-30)
+    worst = float(((dg - dgamma_all).abs() / (5 * sigma_all + 1e-4 * dgamma_all.abs())).max())
+    errs["stem bn1 dgamma, worst channel / (5 sigma of the stored value's rounding)"] = (worst, 1.0)
+    errs["stem bn1 dgamma, |mean z-score| over the channels (bias)"] = (abs(float(zs.mean())), 0.75)
     xq = x.bfloat16().float()
     gref = torch.nn.grad.conv2d_weight(xq, sd["conv1.weight"].shape, dy_ref.float(), 2, 3)
     errs["conv1 wgrad (dy tiles formed on the fly)"] = (rel(eng.gviews["conv1.weight"].float().cpu(), gref), 1e-3)
