@@ -1083,8 +1083,19 @@ class ResNet18Engine:
         if self.dp is None:
             self._finalize_wgrads()
 
+    # measurement hook (tools/power_idle_ab.py): called after every grouped 3x3 weight-gradient launch; None in every product run
+    after_wgrad_hook = None
+
     def _flush_wgrad_group(self, key):
         held = self._wg_held.pop(key, [])
+        if self.after_wgrad_hook is not None and held:
+            try:
+                return self._flush_wgrad_group_inner(held)
+            finally:
+                self.after_wgrad_hook()
+        return self._flush_wgrad_group_inner(held)
+
+    def _flush_wgrad_group_inner(self, held):
         if len(held) >= 2:
             c = self.convs[held[0][0]]
             args = []
