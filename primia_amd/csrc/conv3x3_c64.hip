@@ -70,6 +70,37 @@ __device__ unsigned long long c64_probe_buf[1024 * 4 * 16];
 #define C64_T(i)
 #endif
 
+typedef float c64_f32x2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+__device__ __forceinline__ void c64_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// s_waitcnt vmcnt(n) for a wave-uniform n: the two values the steady state takes first (A, B: compile-time), then the rest
+template <int A, int B>
+__device__ __forceinline__ void c64_wait_vm_pick(int n) {
+    if (n == A) c64_wait_vm<A>();
+    else if (n == B) c64_wait_vm<B>();
+    else {
+        switch (n) {
+            case 2: c64_wait_vm<2>(); break;
+            case 3: c64_wait_vm<3>(); break;
+            case 4: c64_wait_vm<4>(); break;
+            case 5: c64_wait_vm<5>(); break;
+            case 6: c64_wait_vm<6>(); break;
+            case 7: c64_wait_vm<7>(); break;
+            case 8: c64_wait_vm<8>(); break;
+            case 9: c64_wait_vm<9>(); break;
+            case 10: c64_wait_vm<10>(); break;
+            case 11: c64_wait_vm<11>(); break;
+            case 12: c64_wait_vm<12>(); break;
+            case 14: c64_wait_vm<14>(); break;
+            case 16: c64_wait_vm<16>(); break;
+            default: c64_wait_vm<0>(); break;
+        }
+    }
+}
+
 struct C64Params {
     const bf16* src;
     const bf16* wt;   // [64][576] forward-layout weights (fwd: w_fwd, dgrad: w_dgrad)
@@ -105,7 +136,12 @@ struct C64Params {
 //   2  accumulate form; ReLU from the stored mask bytes; xhat = (y - mean) * invstd             (residual bn2 in front of an identity block)
 //   3  accumulate form; [p > 0]; xhat = (p - beta) / gamma from the POOLED activation p         (the stem's bn1, seen through the max-pool:
 //      a window's gradient reaches exactly its argmax, whose activation is the pooled value — PoolScatterFn of bn.hip)
-template <bool ACC, int STAGES = 3, int BNB = 0>
+// EXACT (round 6): H and W multiples of 8 (layer1 at every input size that is a multiple of 32).  Every patch is whole, so a
+// pixel's liveness is the patch's (a scalar), and its address is the patch origin (one scalar per cursor, advanced by
+// additions) + a per-lane constant computed once per block: the side streams' per-patch address arithmetic (~110 vector and
+// ~70 scalar instructions per patch in the accumulate + sums forms, profiles/r06_isa_budget.txt) shrinks to an add and a
+// select per request; the mask words travel through buffer descriptors like the rows (no 64-bit pointer arithmetic).
+template <bool ACC, int STAGES = 3, int BNB = 0, bool EXACT = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void conv3x3_c64_kernel(C64Params p) {
     static_assert(ACC ? BNB != 1 : BNB < 2, "1: plain data gradient; 2, 3: accumulate form");
     constexpr int HALO = 13 * 1024;        // 100 slots used, 104 staged (13 DMA instructions)
@@ -160,6 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // patch cursor: (n, ph, pw) of consecutive patch ids, advanced by one
     struct Cursor {
         int n, ph, pw, t;
+        int org;      // EXACT: pixel index of the patch origin, (n * H + 8 ph) * W + 8 pw
     };
     auto make_cursor = [&](int t) {
         Cursor c;
@@ -168,16 +205,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int rem = t - c.n * p.PPI;
         c.ph = rem / p.PW;
         c.pw = rem - c.ph * p.PW;
+        c.org = (c.n * p.H + c.ph * 8) * p.W + c.pw * 8;
         return c;
     };
     auto advance = [&](Cursor& c) {
         ++c.t;
         if (++c.pw == p.PW) {
             c.pw = 0;
+            c.org += 7 * p.W + 8;     // (EXACT: 8 PW = W; the next image follows the last patch row: 8 PH = H)
             if (++c.ph == p.PH) {
                 c.ph = 0;
                 ++c.n;
             }
+        } else {
+            c.org += 8;
         }
     };
     Cursor cs = make_cursor(t0), cw = make_cursor(t0);  // staging / write-back
@@ -214,14 +255,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     auto stage = [&](int buf) {
         const bool live = cs.t < t1;
-        const int rb = cs.ph * 8, cb = cs.pw * 8;
-        const int org = ((cs.n * p.H + rb) * p.W + cb) * 128;
-        // valid halo rows hy: 0 <= rb + hy - 1 < H, columns likewise
-        int rhi = p.H - rb + 1, chi = p.W - cb + 1;
-        rhi = rhi > 10 ? 10 : rhi;
-        chi = chi > 10 ? 10 : chi;
-        const unsigned rowm = ((1u << rhi) - 1u) & ~(rb == 0 ? 1u : 0u);
-        const unsigned colm = ((1u << chi) - 1u) & ~(cb == 0 ? 1u : 0u);
+        int org;
+        unsigned rowm, colm;
+        if constexpr (EXACT) {      // whole patches: only the image's first / last patch row and column lose a halo line
+            org = cs.org * 128;
+            rowm = (cs.ph + 1 == p.PH ? 0x1ffu : 0x3ffu) & ~(cs.ph == 0 ? 1u : 0u);
+            colm = (cs.pw + 1 == p.PW ? 0x1ffu : 0x3ffu) & ~(cs.pw == 0 ? 1u : 0u);
+        } else {
+            const int rb = cs.ph * 8, cb = cs.pw * 8;
+            org = ((cs.n * p.H + rb) * p.W + cb) * 128;
+            // valid halo rows hy: 0 <= rb + hy - 1 < H, columns likewise
+            int rhi = p.H - rb + 1, chi = p.W - cb + 1;
+            rhi = rhi > 10 ? 10 : rhi;
+            chi = chi > 10 ? 10 : chi;
+            rowm = ((1u << rhi) - 1u) & ~(rb == 0 ? 1u : 0u);
+            colm = ((1u << chi) - 1u) & ~(cb == 0 ? 1u : 0u);
+        }
         const unsigned m = live ? rowm | (colm << 16) : 0u;
         advance(cs);
 #pragma unroll
@@ -275,6 +324,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         rsrc_aux[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
         rsrc_aux[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
     }
+    // EXACT: the mask bytes through descriptors too, and the per-lane parts of every side-stream address, once per block
+    c64_i32x4 rsrc_mk = rsrc, rsrc_bm = rsrc;
+    unsigned old_off[2] = {0u, 0u}, aux_off[2] = {0u, 0u}, mk_off = 0u, bm_off = 0u;
+    if constexpr (EXACT) {
+        const long mbytes = (long)p.N * p.H * p.W * 8;
+        const int nrec = (int)(unsigned)(mbytes > 0xfffffff0L ? 0xfffffff0L : mbytes);
+        if constexpr (ACC) {
+            const unsigned long long a = (unsigned long long)(const void*)(p.acc_mask ? (const void*)p.acc_mask : (const void*)p.wt);
+            rsrc_mk[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+            rsrc_mk[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+            rsrc_mk[2] = __builtin_amdgcn_readfirstlane(p.acc_mask ? nrec : 0);     // (no mask: every lane out of range)
+            const int pxl = lane >> 2, cc = lane & 3;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+                old_off[q] = (unsigned)((((4 * ph + 2 * q + (pxl >> 3)) * p.W + (pxl & 7)) * 64 + (4 * kh + (cc ^ ((pxl >> 1) & 3))) * 8) * 2);
+            const int qm = (lane >> 4) & 1, f = lane & 15;
+            mk_off = (unsigned)(((4 * ph + 2 * qm + (f >> 3)) * p.W + (f & 7)) * 8 + 4 * kh);
+        }
+        {
+            const int px = lane >> 3, c16 = lane & 7;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) aux_off[q] = (unsigned)((((2 * wave + q) * p.W + px) * 64 + c16 * 8) * 2);
+        }
+        if constexpr (BNB == 2) {
+            const unsigned long long a = (unsigned long long)(const void*)p.bnb_mask;
+            rsrc_bm[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+            rsrc_bm[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+            rsrc_bm[2] = __builtin_amdgcn_readfirstlane(nrec);
+            const int q = lane >> 5, pxm = (lane >> 2) & 7, hw = (lane >> 1) & 1;
+            bm_off = (unsigned)(((2 * wave + q) * p.W + pxm) * 8 + 4 * hw);
+        }
+    }
     // BNB: per-channel constants in LDS behind the row buffer.  1: [mean | invstd * gamma | beta][64]; 2: [mean]; 3: [beta]
     float* const bnc = (float*)(saux + 8192);
     if constexpr (BNB != 0) {
@@ -290,7 +371,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
     Cursor co = make_cursor(t0);       // patch whose old rows are requested next
     auto prefetch_old = [&]() {
-        if constexpr (ACC) {
+        if constexpr (ACC && EXACT) {
+            const bool live = co.t < t1;
+            const unsigned base = (unsigned)co.org * 128u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned voff = live && !C64_DBG(64) ? base + old_off[q] : kOob;
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + (wave * 2 + q) * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(voff), "s"(rsrc_st), "s"(m0v) : "memory");
+            }
+            {   // the mask words of the accumulator pixels: one dword per lane (see below), descriptor-addressed
+                const unsigned voff = live ? (unsigned)co.org * 8u + mk_off : kOob;
+                const unsigned m0v = __builtin_amdgcn_readfirstlane(lds0 + SMK_OFF + wave * 256);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen lds"
+                             ::"v"(voff), "s"(rsrc_mk), "s"(m0v) : "memory");
+            }
+            advance(co);
+        } else if constexpr (ACC) {
             const int pxl = lane >> 2, cc = lane & 3;     // pixel of the 16 (two patch rows), 16-B slot of the 64-B half row
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -319,7 +417,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
     auto prefetch_aux = [&]() {
-        if (BNB != 0 && !C64_DBG(32)) {
+        if (BNB != 0 && EXACT && !C64_DBG(32)) {
+            const bool live = cw.t < t1 && !C64_DBG(16);
+            const unsigned base = (unsigned)cw.org * 128u;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const unsigned voff = live ? base + aux_off[q] : kOob;
+                const unsigned m0v =
+                    __builtin_amdgcn_readfirstlane(lds0 + STAGES * STAGE + 2 * OUTB + (ACC ? 8192 : 0) + (2 * wave + q) * 1024);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                             ::"v"(voff), "s"(rsrc_aux), "s"(m0v) : "memory");
+            }
+            if constexpr (BNB == 2) {
+                const unsigned voff = live ? (unsigned)cw.org * 8u + bm_off : kOob;
+                const unsigned m1v = __builtin_amdgcn_readfirstlane(lds0 + SMK_OFF + (ACC ? 1024 : 0) + wave * 256);
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %0, %1, 0 offen lds"
+                             ::"v"(voff), "s"(rsrc_bm), "s"(m1v) : "memory");
+            }
+        } else if (BNB != 0 && !C64_DBG(32)) {
             const int px = lane >> 3, c16 = lane & 7;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -346,7 +461,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
     };
 
-    const bool exact = (p.H % 8 == 0) && (p.W % 8 == 0) && !C64_DBG(3);
+    const bool exact = EXACT || ((p.H % 8 == 0) && (p.W % 8 == 0) && !C64_DBG(3));
     const int dstage = wave == 0 ? 4 : 3;      // halo pieces per stage issued by this wave
 
     // `younger` = vector-memory loads this wave issued after the old rows of the patch being computed (0: unknown, drain)
@@ -390,16 +505,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if constexpr (ACC) {
             // the old rows of this patch have landed once only the loads issued after them remain in flight (loads retire
             // in order; stores do not count against them: see the loop's wait below)
-            switch (younger) {
-                case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            }
+            c64_wait_vm_pick<NAUX + 3, NAUX + 4>(younger);
             C64_T(6)
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -410,12 +516,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 for (int i = 0; i < 2; ++i) {
                     const int c4 = 2 * i + (fg >> 1);          // 16-B chunk of the wave's channel half
                     const u32x2 o = *(const u32x2*)(ob + ((c4 ^ ((fr >> 1) & 3)) << 4));
-                    const unsigned m = (mkq >> (8 * c4 + 4 * (fg & 1))) & 15u;   // old value = gradient through a ReLU whose
-                                                                                  // mask is applied here, not stored
-                    acc[q][i][0] += (m & 1u) ? __uint_as_float(o[0] << 16) : 0.f;
-                    acc[q][i][1] += (m & 2u) ? __uint_as_float(o[0] & 0xffff0000u) : 0.f;
-                    acc[q][i][2] += (m & 4u) ? __uint_as_float(o[1] << 16) : 0.f;
-                    acc[q][i][3] += (m & 8u) ? __uint_as_float(o[1] & 0xffff0000u) : 0.f;
+                    // old value = gradient through a ReLU whose mask is applied here, not stored: bit -> all-ones / zero word
+                    // (v_bfe_i32) ANDed onto the value's bits — two instructions per element where test + compare + select were three
+                    const int m = (int)(mkq >> (8 * c4 + 4 * (fg & 1)));
+                    acc[q][i][0] += __uint_as_float((o[0] << 16) & (unsigned)__builtin_amdgcn_sbfe(m, 0, 1));
+                    acc[q][i][1] += __uint_as_float((o[0] & 0xffff0000u) & (unsigned)__builtin_amdgcn_sbfe(m, 1, 1));
+                    acc[q][i][2] += __uint_as_float((o[1] << 16) & (unsigned)__builtin_amdgcn_sbfe(m, 2, 1));
+                    acc[q][i][3] += __uint_as_float((o[1] & 0xffff0000u) & (unsigned)__builtin_amdgcn_sbfe(m, 3, 1));
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the reads are done before the next patch's rows may land
@@ -444,9 +551,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // BatchNorm batch statistics of the NEXT layer, for free: the write-back lane holds 8 stored channels of one
     // pixel; per-lane fp32 sums over the block's pixels, combined per block at the end (deterministic), replace
     // a full read pass over the output (primia_bn_fwd_train_from_sums consumes the per-block partials).
-    float st1[8], st2[8];
+    // (pairs of channels in 64-bit registers: v_pk_add_f32 / v_pk_fma_f32 form two sums per instruction — the same additions and
+    // fused multiply-adds per element as before, half the instructions)
+    c64_f32x2 sp1[4], sp2[4];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) st1[k] = st2[k] = 0.f;
+    for (int k = 0; k < 4; ++k) sp1[k] = sp2[k] = c64_f32x2{0.f, 0.f};
 
     // The write-back of a patch in two parts, so that the loop can put its requests between them: wb_load reads the rows (and,
     // sums forms, the BatchNorm rows and mask words) from LDS into registers — the fragment ring and the accumulators are dead
@@ -461,9 +570,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int g = 2 * wave + q;                // patch row handled by this wave
-            const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
-            r.live[q] = cw.t < t1 && ho < p.H && wo < p.W;
-            r.so[q] = r.live[q] && !C64_DBG(1) ? (unsigned)(((cw.n * p.H + ho) * p.W + wo) * 128 + c16 * 16) : kOob;
+            if constexpr (EXACT) {
+                r.live[q] = cw.t < t1;
+                r.so[q] = r.live[q] && !C64_DBG(1) ? (unsigned)cw.org * 128u + aux_off[q] : kOob;
+            } else {
+                const int ho = cw.ph * 8 + g, wo = cw.pw * 8 + px;
+                r.live[q] = cw.t < t1 && ho < p.H && wo < p.W;
+                r.so[q] = r.live[q] && !C64_DBG(1) ? (unsigned)(((cw.n * p.H + ho) * p.W + wo) * 128 + c16 * 16) : kOob;
+            }
             const int opx2 = g * 8 + px;
             r.v[q] = *(const u32x4*)(sout + obuf * OUTB + opx2 * 128 + ((c16 ^ ((opx2 >> 1) & 7)) << 4));
             if constexpr (BNB != 0) {
@@ -487,7 +601,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (r.live[q]) {
                 if (BNB != 0 && !C64_DBG(8)) {
                     const u32x4 yv = r.yv[q];
-                    const unsigned bmq = r.bm[q];
+                    const int bmq = (int)r.bm[q];
                     const f32x4 mu0 = *(const f32x4*)(bnc + c16 * 8), mu1 = *(const f32x4*)(bnc + c16 * 8 + 4);
                     f32x4 sc0, sc1, be0, be1;
                     if constexpr (BNB == 1) {
@@ -495,29 +609,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         be0 = *(const f32x4*)(bnc + 128 + c16 * 8), be1 = *(const f32x4*)(bnc + 128 + c16 * 8 + 4);
                     }
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const float yk = __uint_as_float((k & 1) ? (yv[k >> 1] & 0xffff0000u) : (yv[k >> 1] << 16));
-                        const float dk = __uint_as_float((k & 1) ? (v[k >> 1] & 0xffff0000u) : (v[k >> 1] << 16));
-                        const float t = yk - (k < 4 ? mu0[k & 3] : mu1[k & 3]);
-                        bool on;
-                        if constexpr (BNB == 1)
-                            on = __builtin_fmaf(t, k < 4 ? sc0[k & 3] : sc1[k & 3], k < 4 ? be0[k & 3] : be1[k & 3]) > 0.f;
-                        else if constexpr (BNB == 2)
-                            on = (bmq >> k) & 1u;
-                        else
-                            on = yk > 0.f;
-                        const float gk = on ? dk : 0.f;
-                        st1[k] += gk;
-                        st2[k] = __builtin_fmaf(gk, t, st2[k]);      // (x invstd, or 1 / gamma, once per channel at the end)
+                    for (int kk = 0; kk < 4; ++kk) {     // channels 2 kk, 2 kk + 1 of the lane's chunk
+                        const unsigned yw = yv[kk], dw = v[kk];
+                        const c64_f32x2 y2 = {__uint_as_float(yw << 16), __uint_as_float(yw & 0xffff0000u)};
+                        const c64_f32x2 mu2 = kk < 2 ? c64_f32x2{mu0[2 * kk], mu0[2 * kk + 1]} : c64_f32x2{mu1[2 * kk - 4], mu1[2 * kk - 3]};
+                        const c64_f32x2 t2 = y2 - mu2;
+                        c64_f32x2 g2;
+                        if constexpr (BNB == 1) {
+                            const c64_f32x2 sc2 = kk < 2 ? c64_f32x2{sc0[2 * kk], sc0[2 * kk + 1]} : c64_f32x2{sc1[2 * kk - 4], sc1[2 * kk - 3]};
+                            const c64_f32x2 be2 = kk < 2 ? c64_f32x2{be0[2 * kk], be0[2 * kk + 1]} : c64_f32x2{be1[2 * kk - 4], be1[2 * kk - 3]};
+                            const c64_f32x2 z2 = __builtin_elementwise_fma(t2, sc2, be2);
+                            g2 = c64_f32x2{z2[0] > 0.f ? __uint_as_float(dw << 16) : 0.f, z2[1] > 0.f ? __uint_as_float(dw & 0xffff0000u) : 0.f};
+                        } else if constexpr (BNB == 2) {   // mask bit -> all-ones / zero word, ANDed onto the value's bits
+                            g2 = c64_f32x2{__uint_as_float((dw << 16) & (unsigned)__builtin_amdgcn_sbfe(bmq, 2 * kk, 1)),
+                                           __uint_as_float((dw & 0xffff0000u) & (unsigned)__builtin_amdgcn_sbfe(bmq, 2 * kk + 1, 1))};
+                        } else {
+                            g2 = c64_f32x2{y2[0] > 0.f ? __uint_as_float(dw << 16) : 0.f, y2[1] > 0.f ? __uint_as_float(dw & 0xffff0000u) : 0.f};
+                        }
+                        sp1[kk] += g2;
+                        sp2[kk] = __builtin_elementwise_fma(g2, t2, sp2[kk]);      // (x invstd, or 1 / gamma, once per channel at the end)
                     }
                 } else if (p.stat_partials) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const float lo = __uint_as_float(v[k] << 16), hi = __uint_as_float(v[k] & 0xffff0000u);
-                        st1[2 * k] += lo;
-                        st2[2 * k] += lo * lo;
-                        st1[2 * k + 1] += hi;
-                        st2[2 * k + 1] += hi * hi;
+                        const c64_f32x2 x2 = {__uint_as_float(v[k] << 16), __uint_as_float(v[k] & 0xffff0000u)};
+                        sp1[k] += x2;
+                        sp2[k] = __builtin_elementwise_fma(x2, x2, sp2[k]);
                     }
                 }
             }
@@ -551,20 +668,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // (what this wait waits for is the halo, not the row stores that also count: allowing two more — unsafe, timing
             // only — moved it from 507 to 483 cycles per patch; with the write-back phase shortened the kernel runs at 4.0 TB/s
             // and the requests of three patches ahead queue behind the memory system's throughput)
-            switch (keep * dstage + (keep == 2 && s > 0 ? 2 : 1) * NOLD) {
-                case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-                case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-                case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-                case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-                case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-                case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-                case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-                case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-                case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-                case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
-                default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-            }
+            constexpr int kSteady = STAGES == 4 ? 6 + 2 * NOLD : 3 + NOLD;      // waves 1-3 (3 pieces); wave 0: + 2 | + 1
+            c64_wait_vm_pick<kSteady, kSteady + (STAGES == 4 ? 2 : 1)>(keep * dstage + (keep == 2 && s > 0 ? 2 : 1) * NOLD);
         } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
@@ -618,6 +723,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         wb_finish(wb);
     }
     if (p.stat_partials) {
+        float st1[8], st2[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            st1[k] = sp1[k >> 1][k & 1];
+            st2[k] = sp2[k >> 1][k & 1];
+        }
         // lanes with equal (lane & 7) hold the same 8 channels: fold the 8 pixel lanes, then the 4 waves
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
@@ -702,33 +813,27 @@ int conv3x3_c64_dispatch(const bf16* src, const bf16* wt, bf16* dst, int N, int 
         return stg * 13 * 1024 + 2 * 64 * 128 + (acc ? 8192 + 1024 : 0) + (aux ? 8192 + 1024 : 0);
     };
     const size_t lds = (size_t)lds_of(stages, accumulate != 0, with_bnb || amode) + (amode == 2 ? 1024 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        const auto attr = hipFuncAttributeMaxDynamicSharedMemorySize;
-        if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3>, attr, lds_of(3, false, false)) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 4>, attr, lds_of(4, false, false)) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, 3, 1>, attr, lds_of(3, false, true)) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3>, attr, lds_of(3, true, false)) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 4>, attr, lds_of(4, true, false)) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3, 2>, attr, lds_of(3, true, true) + 1024) != hipSuccess ||
-            hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, 3, 3>, attr, lds_of(3, true, true)) != hipSuccess)
+    // EXACT forms (whole 8 x 8 patches: layer1 at every input size that is a multiple of 32) — the general forms serve ragged images
+    const bool ex = (H % 8 == 0) && (W % 8 == 0) && !p.debug;
+    const int form = with_bnb ? 2 : (amode == 2 ? 5 : (amode == 3 ? 6 : (accumulate ? (stages == 4 ? 4 : 3) : (stages == 4 ? 1 : 0))));
+    typedef void (*kern_t)(C64Params);
+    static const kern_t kerns[2][7] = {
+        {conv3x3_c64_kernel<false, 3>, conv3x3_c64_kernel<false, 4>, conv3x3_c64_kernel<false, 3, 1>, conv3x3_c64_kernel<true, 3>,
+         conv3x3_c64_kernel<true, 4>, conv3x3_c64_kernel<true, 3, 2>, conv3x3_c64_kernel<true, 3, 3>},
+        {conv3x3_c64_kernel<false, 3, 0, true>, conv3x3_c64_kernel<false, 4, 0, true>, conv3x3_c64_kernel<false, 3, 1, true>,
+         conv3x3_c64_kernel<true, 3, 0, true>, conv3x3_c64_kernel<true, 4, 0, true>, conv3x3_c64_kernel<true, 3, 2, true>,
+         conv3x3_c64_kernel<true, 3, 3, true>}};
+    static bool attr_set[2][7] = {{false}};
+    const kern_t kern = kerns[ex ? 1 : 0][form];
+    if (!attr_set[ex ? 1 : 0][form]) {
+        // the largest request of the form: plain 3 / 4 stages, + BatchNorm rows, accumulate 3 / 4 stages, + rows (+ mask words)
+        const int need[7] = {lds_of(3, false, false), lds_of(4, false, false), lds_of(3, false, true), lds_of(3, true, false),
+                             lds_of(4, true, false), lds_of(3, true, true) + 1024, lds_of(3, true, true)};
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, need[form]) != hipSuccess)
             return PRIMIA_ERR_LAUNCH;
-        attr_set = true;
+        attr_set[ex ? 1 : 0][form] = true;
     }
-    if (with_bnb)
-        conv3x3_c64_kernel<false, 3, 1><<<grid, 256, lds, st>>>(p);
-    else if (amode == 2)
-        conv3x3_c64_kernel<true, 3, 2><<<grid, 256, lds, st>>>(p);
-    else if (amode == 3)
-        conv3x3_c64_kernel<true, 3, 3><<<grid, 256, lds, st>>>(p);
-    else if (accumulate && stages == 4)
-        conv3x3_c64_kernel<true, 4><<<grid, 256, lds, st>>>(p);
-    else if (accumulate)
-        conv3x3_c64_kernel<true, 3><<<grid, 256, lds, st>>>(p);
-    else if (stages == 4)
-        conv3x3_c64_kernel<false, 4><<<grid, 256, lds, st>>>(p);
-    else
-        conv3x3_c64_kernel<false, 3><<<grid, 256, lds, st>>>(p);
+    kern<<<grid, 256, lds, st>>>(p);
     return launch_status();
 }
 
