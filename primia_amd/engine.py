@@ -761,7 +761,7 @@ class ResNet18Engine:
                 and self._pair_ws.get(blk.conv1.name, 0) > 0):
             self._on_wgrad_stream(lambda: self._timed(
                 "wgrad", c1, lambda: call("primia_conv2d_wgrad_pair_ws", c1.desc, x, dy1, c1.acc, cd.desc, dyd, cd.acc,
-                                          self.wgrad_ws, self.wgrad_ws_bytes, self.dt), extra_macs=self._macs(cd)))
+                                          self.wgrad_ws, self.wgrad_ws_bytes, self.dt), extra_macs=self._macs(cd)), transition=True)
             return
         self._wgrad(blk.conv1.name, x, dy1)
         self._wgrad(blk.down.name, x, dyd)
@@ -791,12 +791,20 @@ class ResNet18Engine:
     # narrower: a layer's wgrad starts after its sibling dgrad and runs beside the BatchNorm backward chain that
     # follows (HBM-bound kernels and 7-us finalize launches); the next dgrad waits for it.  Also slower on
     # MI355X (7.10 ms serial -> 7.30 ms): kept as an option for other shapes, off by default.
+    # wgrad_overlap = 3: see _on_wgrad_stream.
     # Re-measured in round 3 with the workspace kernels (wgrad_overlap = 1: the schedule above; = 2: the weight
     # gradients free-running on the second stream until the finalize): see profiles/r03_negative_results.txt.
     wgrad_overlap = 0
     stem_bwd_fused = True
 
-    def _on_wgrad_stream(self, fn):
+    def _on_wgrad_stream(self, fn, transition=False):
+        if self.wgrad_overlap == 3 and not transition and self.prof is None:
+            # mode 3 (round 6): ONLY a transition block's paired weight gradient leaves the main stream — it runs beside the
+            # block's paired data gradient, two launches that each leave the matrix pipe idle 80 % of the time (short reduction
+            # axes: their tiles are write-back and staging latency) — and every other weight gradient stays in line, behind it
+            # (one workspace)
+            self._join_wgrad_stream()
+            return fn()
         if not self.wgrad_overlap or self.prof is not None:
             return fn()
         if getattr(self, "_wg_stream", None) is None:

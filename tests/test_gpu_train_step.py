@@ -600,7 +600,7 @@ def test_weight_gradients_on_a_second_stream_give_the_same_bits(cuda, batch, siz
     x = torch.randn(batch, 3, size, size, generator=g).to(cuda)
     y = torch.randint(0, 3, (batch,), generator=g).to(cuda)
     outs = []
-    for mode in (0, 1, 2):
+    for mode in (0, 1, 2, 3):
         eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.bfloat16, device=cuda)
         eng.wgrad_overlap = mode
         eng.load_state_dict(sd)

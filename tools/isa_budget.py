@@ -39,7 +39,7 @@ def classify(t):
 def functions(path):
     """[(name, first instruction index, last + 1)] from the symbol labels of a kept .s, with the parsed instruction list."""
     ins, labels = H.parse(path)
-    starts = sorted((i, n) for n, i in labels.items() if n.startswith("_Z") or not n.startswith("."))
+    starts = sorted((i, n) for n, i in labels.items() if n.startswith("_Z"))
     out = []
     for k, (i, n) in enumerate(starts):
         end = starts[k + 1][0] if k + 1 < len(starts) else len(ins)
