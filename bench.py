@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}  # dense, MI355X_MICROARCH.md
 GFLOP_PER_IMAGE = 10.881                            # SURVEY.md §8d (fwd 3.627 + bwd 7.254)
-TRAFFIC_FILE = "r05_hbm_traffic.json"               # rocprofv3 PMC passes over this command, see tools/hbm_traffic.py
+TRAFFIC_FILE = "r06_hbm_traffic.json"               # rocprofv3 PMC passes over this command, see tools/hbm_traffic.py
 
 
 def parse():

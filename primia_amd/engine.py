@@ -164,6 +164,8 @@ class ResNet18Engine:
         # layers of a stage share a shape; a layer's (x, dy) is held back until its siblings' are ready
         self._wg_group = {}        # conv name -> (shape key, preferred group size)
         self._wg_held = {}         # shape key -> [(name, x, dy), ...]
+        self._wg_count = {}        # shape key -> layers of that shape in the network
+        self._wg_seen = {}         # shape key -> layers of that shape this backward pass has reached
         group_ws = [0]
         if dtype == torch.bfloat16 and self.wgrad_group:
             shapes = {}
@@ -177,6 +179,7 @@ class ResNet18Engine:
                 if n >= 2:
                     for nm in names:
                         self._wg_group[nm] = (key, n)
+                    self._wg_count[key] = len(names)
                     group_ws.append(query("primia_conv_wgrad_group_ws_bytes", d, n, self.dt))
         ws_bytes = max(max(ws_need.values()), self._stem_ws_bytes, max(list(self._pair_ws.values()) + [0]), max(group_ws))
         self.wgrad_ws = torch.empty(max(ws_bytes, 16) // 4, dtype=torch.float32, device=dev) if ws_bytes > 0 else None
@@ -775,7 +778,10 @@ class ResNet18Engine:
             key, n = self._wg_group[name]
             held = self._wg_held.setdefault(key, [])
             held.append((name, x, dy))
-            if len(held) == n:
+            self._wg_seen[key] = self._wg_seen.get(key, 0) + 1
+            # a full group — or the stage's last layer (layer4 at batch 256: groups of 2 for 3 layers): it runs NOW, while its
+            # dy is the newest tensor in the Infinity Cache, not at the end of the backward pass
+            if len(held) == n or self._wg_seen[key] == self._wg_count.get(key, 0):
                 self._flush_wgrad_group(key)
             return
         if self.wgrad_ws is not None:   # (one workspace: the weight gradients stay in order on whichever stream)
@@ -860,6 +866,7 @@ class ResNet18Engine:
         if query("primia_options_epoch") != self._options_epoch:
             raise _lib.PrimiaError("library options changed (primia_set_option) after this engine sized its buffers")
         self._grads_pending = False      # (accumulators of an earlier pass that nobody consumed are overwritten now)
+        self._wg_seen = {}
         self._dout_sums = {}             # block prefix -> (partials, slots): backward sums of its bn2 formed by the producer of dout
         if self.wgrad_ws is not None and self.dp is None:
             self.dw_acc[:self._acc_zero_n].zero_()      # the other layers' accumulators are overwritten

@@ -316,8 +316,16 @@ class SecureContext:
     def sub_public_scalar(self, a, value):
         """AST - int (additive_shared.py:453-484, 506-524): the constant becomes a FRESH random
         sharing of shape [1] that is subtracted share-wise (broadcast)."""
-        c = torch.full((1,), int(value), dtype=I64, device=self._ref(a).device)  # device-side fill: graph-capturable
-        return self.sub(a, self.share(c))
+        return self.sub(a, self.share(self._const(int(value), self._ref(a).device)))
+
+    def _const(self, value, device, n=1):
+        """A public constant as a device tensor, uploaded once per (value, length) and kept (no fill kernel per use; a captured
+        forward finds it in the cache its eager pass filled — an upload cannot be captured)."""
+        cache = self.__dict__.setdefault("_consts", {})
+        key = (value, n, str(device))
+        if key not in cache:
+            cache[key] = torch.full((n,), value, dtype=I64).to(device)
+        return cache[key]
 
     # ---- Beaver -----------------------------------------------------------------------------------
     fuse_beaver = True
@@ -431,7 +439,7 @@ class SecureContext:
             call("primia_fss_open", r[0], r[1], masked, n)
         else:  # the parties exchange their masked shares; the sum is taken mod 2^32 (fss.py:158-170)
             opened = self.opener.open(r)
-            call("primia_fss_open", opened, torch.zeros_like(opened), masked, n)
+            call("primia_fss_open", opened, self._const(0, opened.device, opened.numel()), masked, n)
 
         def one(j):  # evaluate
             o = _empty_like(xr)
@@ -510,23 +518,32 @@ class SecureContext:
 
         return self._each(one)
 
+    _wt_cache_max = 64      # a ResNet-18 has 21 shared weight matrices: room for three models on one context
+
     def _weight_t(self, w, O, K):
         """weight.reshape(O, -1).t() of both parties' (static) weight shares, formed once per model.
 
-        The cache is keyed on the share TENSORS, which it keeps alive and compares by identity together with their
-        in-place version counters: an address the caching allocator hands out again, or shares rewritten in place,
-        can never hit a stale transpose (`invalidate_weight_cache()` drops everything when a model is re-shared)."""
+        The cache is keyed on the share TENSORS, which it keeps alive (so an address the caching allocator hands out again
+        can never alias an entry) and compares by identity together with their in-place version counters.  torch bumps a
+        version counter for ITS in-place writes only: a caller that rewrites shares in place through the C ABI (a kernel
+        launched on `data_ptr()` — nothing in this module does that to model shares) must call `invalidate_weight_cache()`,
+        as `SecureResNet18.__init__` does when a model is (re-)shared.  At most `_wt_cache_max` entries, least recently used
+        evicted: a long-lived context fed changing weight objects does not grow."""
         key = (id(w[0]), id(w[1]), O, K)
         hit = self._wt_cache.get(key)
         if hit is not None:
             w0, w1, v0, v1, wt = hit
             if w0 is w[0] and w1 is w[1] and v0 == w[0]._version and v1 == w[1]._version:
+                self._wt_cache[key] = self._wt_cache.pop(key)      # most recently used: to the back
                 return wt
+            del self._wt_cache[key]
         wt = []
         for j in (0, 1):
             t = torch.empty(K, O, dtype=I64, device=w[j].device)
             call("primia_col2out_syft", w[j], None, t, 1, O, K)
             wt.append(t)
+        while len(self._wt_cache) >= self._wt_cache_max:
+            del self._wt_cache[next(iter(self._wt_cache))]
         self._wt_cache[key] = (w[0], w[1], w[0]._version, w[1]._version, wt)
         return wt
 
@@ -747,7 +764,7 @@ class SecureResNet18:
         the batched triple that channel receives)."""
         c = self.ctx
         names = self.bn_prefixes()
-        var = c._each(lambda j: torch.cat([self.p[n + ".running_var"][j] for n in names]))
+        var = self._var_cat()
         inv = c.reciprocal_newton(var)
         out, off = {}, 0
         for n in names:
@@ -755,6 +772,25 @@ class SecureResNet18:
             out[n] = c._each(lambda j: inv[j][off:off + k].contiguous())
             off += k
         return out
+
+    def _var_cat(self):
+        """Every BatchNorm layer's running_var shares side by side (static per model: formed once, by the library's own copy —
+        a ring scale by 1 — not by torch.cat)."""
+        if getattr(self, "_var_cat_cache", None) is None:
+            c, names = self.ctx, self.bn_prefixes()
+            total = sum(c._ref(self.p[n + ".running_var"]).numel() for n in names)
+
+            def one(j):
+                out = torch.empty(total, dtype=I64, device=self.p[names[0] + ".running_var"][j].device)
+                off = 0
+                for n in names:
+                    v = self.p[n + ".running_var"][j]
+                    call("primia_ring_scale", v, 1, out[off:off + v.numel()], v.numel())
+                    off += v.numel()
+                return out
+
+            self._var_cat_cache = c._each(one)
+        return self._var_cat_cache
 
     def _bn(self, x, prefix):
         p = self.p
@@ -816,8 +852,8 @@ class GraphedSecureInference:
 
     def __init__(self, state_dict, device, input_size=224, precision_fractional=16, base=10, seed=None, blocks=None):
         self.device = torch.device(device)
-        self.image = torch.zeros(1, state_dict["conv1.weight"].shape[1], input_size, input_size, dtype=torch.float32,
-                                 device=self.device)
+        # (an all-zero warm-up image, uploaded: no fill kernel of torch's on the path)
+        self.image = torch.zeros(1, state_dict["conv1.weight"].shape[1], input_size, input_size, dtype=torch.float32).to(self.device)
         self.dealer = Dealer(self.device, seed)
         self.dealer.tape, self.dealer.requests = [], []
         ctx = SecureContext(self.dealer, base, precision_fractional)

@@ -171,3 +171,13 @@ def test_transposed_weight_cache_follows_the_weights(cuda):
     assert torch.allclose(c, a, atol=5e-3), (ptrs, ws2[0].data_ptr())
     ctx.invalidate_weight_cache()
     assert not ctx._wt_cache
+    # bounded, least recently used first out: a long-lived context fed changing weight objects does not grow
+    ctx._wt_cache_max = 3
+    kept = [shares_of(ctx, w1) for _ in range(5)]
+    for ws_k in kept[:3]:
+        ctx.conv2d(xs, ws_k, 1, 1)
+    ctx.conv2d(xs, kept[0], 1, 1)                     # a hit: entry 0 becomes the most recently used
+    ctx.conv2d(xs, kept[3], 1, 1)                     # evicts entry 1, not entry 0
+    keys = list(ctx._wt_cache)
+    assert len(keys) == 3 and (id(kept[0][0]), id(kept[0][1]), 16, 72) in keys
+    assert (id(kept[1][0]), id(kept[1][1]), 16, 72) not in keys

@@ -76,7 +76,7 @@ def main():
         torch.cuda.synchronize()
         return time.perf_counter() - t0, out, ctx
 
-    PMC_FILE = "r04_secure_valu_pmc.json"
+    PMC_FILE = "r06_secure_valu_pmc.json"
 
     def valu_pmc():
         """Counted vector instructions of the DIF kernels from the committed rocprofv3 --pmc pass (tools/pmc_secure.sh)."""
@@ -93,7 +93,7 @@ def main():
         a register-only loop on the same chip (tools/micro/valu_rate.hip, profiles/r04_valu_issue_rate.txt): the
         three-operand forms issue every ~4 cycles (518-584 G/s), two-operand adds / xors at 828-868 G/s.
         `achieved` = the kernel's COUNTED instructions per launch (SQ_INSTS_VALU of the committed PMC pass over this very
-        command, profiles/r04_secure_valu_pmc.json) / the launch time measured here."""
+        command, profiles/r06_secure_valu_pmc.json) / the launch time measured here."""
         n = 1 << 20
         d = Dealer(dev, seed=7)
         keys = d.dif_keys(n)
@@ -104,7 +104,7 @@ def main():
         args = (None, None, 1, 0, x2[0], x2[1], 1, 0, 1, k0["alpha"], k1["alpha"], k0["s0"], k1["s0"], k0["bits"],
                 k0["cw_sigma"], k0["cw_s"], k0["cw_leaf"], out[0], out[1], n)
         # (the per-party kernel of the three-role deployment, so that the PMC pass over this command counts it too)
-        masked = (d.rand64(n) & 0xFFFFFFFF).to(torch.int32)
+        masked = torch.randint(0, 2 ** 31, (n,), dtype=torch.int32).to(dev)      # (host-drawn: no torch kernel in the trace)
         call("primia_dif_eval", 0, masked, k0["s0"], k0["bits"], k0["cw_sigma"], k0["cw_s"], k0["cw_leaf"], out[0], n)
         for _ in range(2):
             call("primia_dif_eval_local", *args)
@@ -152,7 +152,7 @@ def main():
         d = Dealer(dev, seed=100 + i); d.tape = []
         t_total, out_a, ctx = run(d)
         t_online, out_b, _ = run(PreloadedDealer(d.tape, dev))
-        assert torch.equal(out_a, out_b), "replayed run must be bit-identical"
+        assert torch.equal(out_a.cpu(), out_b.cpu()), "replayed run must be bit-identical"
         res.append((t_total, t_online))
         del d
     tt = sum(r[0] for r in res) / len(res); to = sum(r[1] for r in res) / len(res)
@@ -168,7 +168,7 @@ def main():
             gi = GraphedSecureInference(sd, dev, input_size=a.size, precision_fractional=a.pf, seed=999)
             ctx_e = SecureContext(PreloadedDealer(gi.tape, dev), 10, a.pf)
             out_ref = SecureResNet18(ctx_e, sd, input_size=a.size)(img)
-            assert torch.equal(gi(img, refill=False), out_ref), "graph replay must be bit-identical"
+            assert torch.equal(gi(img, refill=False).cpu(), out_ref.cpu()), "graph replay must be bit-identical"
             torch.cuda.synchronize(); t0 = time.perf_counter()
             for _ in range(3):
                 gi(img, refill=False)
