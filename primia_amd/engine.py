@@ -747,6 +747,9 @@ class ResNet18Engine:
              self._gviews[b + ".bias"], y.shape[0], y.shape[1], int(relu), self.bn_ws, self.bn_ws_bytes, self.dt)
 
     wgrad_pair = True
+    # a stage's LAST same-shape layer does not wait for a group that can no longer fill (layer4 at batch 256: groups of 2 for 3
+    # layers): its weight gradient runs as soon as its dy exists instead of at the end of the backward pass (round 6)
+    wgrad_flush_last = True
     gn_relu_recompute = True
     # GroupNorm residual layers with the BatchNorm path's 1-bit ReLU masks (and its mask-applying accumulate dgrad)
     gn_relu_masks = True
@@ -781,7 +784,7 @@ class ResNet18Engine:
             self._wg_seen[key] = self._wg_seen.get(key, 0) + 1
             # a full group — or the stage's last layer (layer4 at batch 256: groups of 2 for 3 layers): it runs NOW, while its
             # dy is the newest tensor in the Infinity Cache, not at the end of the backward pass
-            if len(held) == n or self._wg_seen[key] == self._wg_count.get(key, 0):
+            if len(held) == n or (self.wgrad_flush_last and self._wg_seen[key] == self._wg_count.get(key, 0)):
                 self._flush_wgrad_group(key)
             return
         if self.wgrad_ws is not None:   # (one workspace: the weight gradients stay in order on whichever stream)

@@ -877,7 +877,7 @@ class GraphedSecureInference:
                 self.out = self._model(self.image)
         torch.cuda.current_stream().wait_stream(side)
         # the provider's block counter moves to the device, behind everything the offline pass drew
-        self._ctr = torch.tensor([self.dealer._block], dtype=I64, device=self.device)
+        self._ctr = torch.tensor([self.dealer._block], dtype=I64).to(self.device)      # (uploaded: no fill kernel)
         self.dealer._block = None                      # (the host counter is dead from here on: rand64 would raise)
         self.refills = 0
         self._refill_launches()                        # eager: warms the dealer kernels AND replaces the warm-up primitives
