@@ -141,6 +141,8 @@ class ResNet18Engine:
                 acc_total += (c.wfwd_n + 3) // 4 * 4
             if not overwriting:
                 self._acc_zero_n = acc_total
+                # ... and nothing but conv1's slab may be in it: the padded-input stem kernels overwrite that one too
+                self._acc_zero_only_stem = all(ws_need[c.spec.name] > 0 for c in self.convs.values() if c.spec.name != "conv1")
         self.dw_acc = torch.zeros(acc_total, dtype=torch.float32, device=dev)
         for c in self.convs.values():
             if share is not None:       # kernel-layout weight copies do not depend on the batch size: one set
@@ -872,7 +874,12 @@ class ResNet18Engine:
         self._wg_seen = {}
         self._dout_sums = {}             # block prefix -> (partials, slots): backward sums of its bn2 formed by the producer of dout
         if self.wgrad_ws is not None and self.dp is None:
-            self.dw_acc[:self._acc_zero_n].zero_()      # the other layers' accumulators are overwritten
+            # the other layers' accumulators are overwritten — conv1's too where its weight gradient runs on the padded input
+            # (primia_stem_bwd_fused ends in an ordered reduce that WRITES the slab): then the step has
+            # no fill launch at all (tests: test_weight_gradient_accumulators_are_overwritten poisons the arena between steps)
+            stem_overwrites = self._acc_zero_only_stem and self._stem_bwd_fused_wanted()
+            if not stem_overwrites:
+                self.dw_acc[:self._acc_zero_n].zero_()
         else:
             self.dw_acc.zero_()
         # (under DP-SGD fc.weight / fc.bias gradients are overwritten later from the clipped dlogits)

@@ -560,6 +560,38 @@ def test_training_step_is_bitwise_deterministic(cuda, dtype, batch, size):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("batch,size,fused_tail", [(8, 64, False), (8, 64, True), (16, 224, True)])
+def test_weight_gradient_accumulators_are_overwritten(cuda, batch, size, fused_tail):
+    """The bf16 step has no fill launch: every convolution's weight-gradient accumulator — conv1's included, where its weight
+    gradient runs on the padded input (primia_stem_bwd_fused) — is WRITTEN by an ordered reduce, never accumulated into.
+    Poison the whole arena (and the workspace) with NaN between two steps on the same batch: same gradients, bit for bit."""
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(batch, 3, size, size, generator=g).to(cuda)
+    y = torch.randint(0, 3, (batch,), generator=g).to(cuda)
+    eng = ResNet18Engine(batch, 3, 3, size, "max", dtype=torch.bfloat16, device=cuda)
+    torch.manual_seed(5)
+    eng.init_weights()
+    eng.fuse_sgd_tail = fused_tail
+    eng.forward(x)
+    eng.loss_backward(y)
+    assert eng.stem_bwd_fused_active and eng._acc_zero_only_stem
+    ref = eng.grads.clone()
+    assert bool(torch.isfinite(ref).all()) and float(ref.abs().max()) > 0
+    eng.dw_acc.fill_(float("nan"))
+    eng.wgrad_ws.fill_(float("nan"))
+    eng._grads.fill_(float("nan"))
+    eng.forward(x)
+    eng.loss_backward(y)
+    assert torch.equal(eng.grads, ref)
+    # ... and the weights the fused tail makes from them are finite
+    eng.forward(x)
+    eng.loss_backward(y)
+    eng.sgd_step(1e-2, 5e-4)
+    assert bool(torch.isfinite(eng.flat).all())
+    for c in eng.convs.values():
+        assert bool(torch.isfinite(c.w_fwd.float()).all()), c.spec.name
+
+
 def test_full_size_forward_and_step_are_repeatable(cuda):
     """BASELINE configs[1] size (batch 256, 224x224, bf16): the same batch gives bit-identical activations forward
     after forward, and the same gradients step after step.  (Small shapes never put two blocks of the 64->64 kernel on
