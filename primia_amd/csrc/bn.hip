@@ -166,6 +166,20 @@ __global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_kernel(const floa
     __shared__ double sa[kFinSlices][17], sb[kFinSlices][17];
     const int cl = threadIdx.x & 15, ks = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
+    // what the last line needs from memory besides the sums is requested FIRST: left where they are used, these loads start
+    // after the reduction and the kernel — pure latency, 33 launches per training step — is one memory round trip longer
+    // (round 6, same-box A/B: 4.713 -> 4.696 ms per step.  The same idea in the streaming apply kernels — first trip's rows
+    // requested before the constants' barrier — measured SLOWER, 4.740 -> 4.761 ms: the rows then live in registers across the
+    // barrier and the loop carries a select; reverted)
+    float rm0 = 0.f, rv0 = 0.f, sc2v = 1.f;
+    if (ks == 0 && c < C) {
+        if (mode == 0 && running_mean) {
+            rm0 = running_mean[c];
+            rv0 = running_var[c];
+        } else if (mode != 0 && scale2) {
+            sc2v = scale2[c];
+        }
+    }
     double acc2[2] = {0.0, 0.0};
     if (c < C) fin_gather<2>(partials, nblk, C, c, ks, acc2);
     double a = acc2[0], b = acc2[1];
@@ -192,13 +206,13 @@ __global__ __launch_bounds__(16 * kFinSlices) void bn_finalize_kernel(const floa
         out2[c] = (float)(1.0 / sqrt(var + (double)eps));
         if (running_mean) {
             const double unb = M > 1 ? var * (double)M / (double)(M - 1) : var;
-            running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + (double)momentum * mean);
-            running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + (double)momentum * unb);
+            running_mean[c] = (float)((1.0 - momentum) * (double)rm0 + (double)momentum * mean);
+            running_var[c] = (float)((1.0 - momentum) * (double)rv0 + (double)momentum * unb);
         }
     } else {
         out1[c] = (float)a;  // dbeta
         // dgamma; mode 1 with scale2: the second sum is sum g*(y - mean) and still lacks the factor invstd
-        out2[c] = scale2 ? (float)(b * (double)scale2[c]) : (float)b;
+        out2[c] = scale2 ? (float)(b * (double)sc2v) : (float)b;
     }
 }
 

@@ -191,7 +191,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
         for (int j = 0; j < 18; ++j) wreg[j][i] = *(const bf16x8_t*)(wrow + j * 32);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // weights resident before any counted wait below
+    // (no wait here: the first patches' halo, BatchNorm and old rows are requested behind these loads and ONE wait below covers
+    // both — the block's prologue is one memory round trip, not two; round 6)
 
     // patch cursor: (n, ph, pw) of consecutive patch ids, advanced by one
     struct Cursor {
@@ -656,6 +657,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int s = 0; s < STAGES - 1; ++s)
         if (s < nstages) stage(s);
     prefetch_old();            // patch 0's old rows: the youngest loads at the top of iteration 0, as in every iteration
+    // weights resident — and everything requested so far landed — before any counted wait below.  The builtin, not inline asm:
+    // it tells the compiler's wait-count pass that the weight registers are ready, so that it puts no wait of its own in front
+    // of their first use INSIDE the loop (which would drain the LDS-DMA ring every iteration).
+    __builtin_amdgcn_s_waitcnt(0x0f70);     // vmcnt(0)
     int cur = 0, nxt = STAGES - 1;
 #if C64_PROBE
     tlast = __builtin_readcyclecounter();
