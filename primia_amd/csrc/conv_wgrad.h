@@ -64,6 +64,8 @@ bool stem_wgrad_halo_blocks(int N, int H, int W, int* total, int* per_block, int
 // (wgt: DP-SGD clipped sum — split s is sample s, weighted by wgt[s])
 void wgrad_tile_reduce(const float* ws, float* dw, int nsplit, int combos, int BMK, int BNC, int nkt, int nct, int C,
                        int klen, int stem, hipStream_t st, const float* wgt = nullptr);
+void wgrad_tile_reduce_pair(const float* ws, float* dw, float* dw2, int nsplit, int combos1, int combos2, int BMK, int BNC,
+                            int nkt, int nct, int C, int klen, int klen2, hipStream_t st);
 // DP-SGD: the patch kernel's norm pass keeping every sample's tiles ([combo][image][slab]); bytes (0: not served / too
 // large to be worth it), the pass, and the clipped sum over the kept tiles
 size_t wgrad_patch_keep_bytes(const WgradParams& p);

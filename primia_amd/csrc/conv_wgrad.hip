@@ -275,7 +275,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
 template <int SL>
 __global__ __launch_bounds__(256) void wgrad_tile_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                                 int nsplit, int BMK, int BNC, int nkt, int nct, int C,
-                                                                int klen, int stem, const float* __restrict__ wgt) {
+                                                                int klen, int stem, const float* __restrict__ wgt,
+                                                                int combos1 = 0x7fffffff, float* __restrict__ dw2 = nullptr,
+                                                                int klen2 = 0) {
+    // (combos1, dw2, klen2: a transition block's pair — the tiles from combos1 on are the 1x1 downsample's, a second filter
+    // with its own row length; one launch reduces both, round 6)
     constexpr int CL = 256 / SL;
     __shared__ f32x4 red[SL][CL];
     const int tile4 = BMK * BNC / 4;                // float4 chunks per tile
@@ -308,10 +312,12 @@ __global__ __launch_bounds__(256) void wgrad_tile_reduce_kernel(const float* __r
         for (int k = 1; k < SL; ++k) a += red[k][threadIdx.x % CL];
     }
     if (!live) return;
-    const int ct = combo % nct, kt = (combo / nct) % nkt, tap = combo / (nct * nkt);
+    const bool second = combo >= combos1;
+    const int cb = second ? combo - combos1 : combo;
+    const int ct = cb % nct, kt = (cb / nct) % nkt, tap = cb / (nct * nkt);
     const int kl = (q * 4) / BNC, cl = (q * 4) % BNC;
     const int ebase = stem ? tap * 32 : tap * C + ct * BNC;
-    *(f32x4*)(dw + (long)(kt * BMK + kl) * klen + ebase + cl) = a;
+    *(f32x4*)((second ? dw2 : dw) + (long)(kt * BMK + kl) * (second ? klen2 : klen) + ebase + cl) = a;
 }
 
 void wgrad_tile_reduce(const float* ws, float* dw, int nsplit, int combos, int BMK, int BNC, int nkt, int nct, int C,
@@ -326,6 +332,21 @@ void wgrad_tile_reduce(const float* ws, float* dw, int nsplit, int combos, int B
     else
         wgrad_tile_reduce_kernel<1><<<combos * ((tile4 + 255) / 256), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C,
                                                                                   klen, stem, wgt);
+}
+
+// conv1 (combos1 tiles) + downsample (combos2 tiles, stored behind them) of a transition block in ONE launch
+void wgrad_tile_reduce_pair(const float* ws, float* dw, float* dw2, int nsplit, int combos1, int combos2, int BMK, int BNC,
+                            int nkt, int nct, int C, int klen, int klen2, hipStream_t st) {
+    const int tile4 = BMK * BNC / 4, combos = combos1 + combos2;
+    if (nsplit >= 32)
+        wgrad_tile_reduce_kernel<16><<<combos * ((tile4 + 15) / 16), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C, klen, 0,
+                                                                                 nullptr, combos1, dw2, klen2);
+    else if (nsplit >= 4)
+        wgrad_tile_reduce_kernel<4><<<combos * ((tile4 + 63) / 64), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C, klen, 0,
+                                                                                nullptr, combos1, dw2, klen2);
+    else
+        wgrad_tile_reduce_kernel<1><<<combos * ((tile4 + 255) / 256), 256, 0, st>>>(ws, dw, nsplit, BMK, BNC, nkt, nct, C, klen, 0,
+                                                                                  nullptr, combos1, dw2, klen2);
 }
 
 static void launch_tile_reduce(const WgradParams& p, int BMK, int BNC, int stem, hipStream_t st) {

@@ -410,9 +410,9 @@ static int launch_tap_pair(const WgradParams& w, const WgradParams& w2, const Ta
         return PRIMIA_ERR_LAUNCH;
     const int combos2 = g.nkt * g.nct;
     kern<<<(g.combos + combos2) * g.nsplit, 512, lds, st>>>(p);
-    wgrad_tile_reduce(w.ws, w.dw, g.nsplit, g.combos, BMK, BNC, g.nkt, g.nct, w.C, w.klen, 0, st);
-    wgrad_tile_reduce(w.ws + (size_t)g.combos * g.nsplit * BMK * BNC, w2.dw, g.nsplit, combos2, BMK, BNC, g.nkt, g.nct, w2.C,
-                      w2.klen, 0, st);
+    // (both filters' tiles in one reduce launch: the downsample's sit behind conv1's in the workspace, same split count and
+    // tile shape, w2.C == w.C)
+    wgrad_tile_reduce_pair(w.ws, w.dw, w2.dw, g.nsplit, g.combos, combos2, BMK, BNC, g.nkt, g.nct, w.C, w.klen, w2.klen, st);
     return launch_status();
 }
 

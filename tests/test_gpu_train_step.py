@@ -763,6 +763,33 @@ def test_transition_forward_pair_gives_the_same_bits(cuda, batch, size):
         assert torch.equal(q1, s1) and torch.equal(qd, sd), blk.prefix
 
 
+def test_schedule_switches_of_round_6_give_the_same_bits(cuda):
+    """engine.wgrad_flush_last (a stage's last same-shape weight gradient runs as soon as its dy exists instead of at the end of
+    the backward pass — batch 256's layer4 groups 2 of its 3 layers; here a batch where the grouping leaves a remainder too)
+    only moves a launch: gradients and weights after two steps are bit-equal.  Siblings are evicted least-recently-USED."""
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(32, 3, 224, 224, generator=g).to(cuda)
+    y = torch.randint(0, 3, (32,), generator=g).to(cuda)
+    outs = []
+    for flush in (True, False):
+        eng = ResNet18Engine(32, 3, 3, 224, "max", dtype=torch.bfloat16, device=cuda, options={"wgrad_flush_last": flush})
+        torch.manual_seed(5)
+        eng.init_weights()
+        for _ in range(2):
+            eng.forward(x)
+            eng.loss_backward(y)
+            eng.sgd_step(1e-2, 5e-4)
+        outs.append((eng.flat.clone(), eng.grads.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    root = ResNet18Engine(4, 3, 3, 64, "max", dtype=torch.bfloat16, device=cuda)
+    root.max_siblings = 3
+    for n in (1, 2, 3):
+        root.sibling(n)
+    root.sibling(1)                  # a hit: batch 1 becomes the most recently used
+    root.sibling(5)                  # evicts batch 2, not batch 1
+    assert list(root._siblings) == [3, 1, 5]
+
+
 def test_torchlib_models_resnet18_builds_the_engine(cuda):
     """`from torchlib.models import resnet18` with the keyword arguments /root/reference/train.py:259-268 passes (+ the
     batch size the engine needs): the same network, state-dict compatible with the reference's 122 keys."""
