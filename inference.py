@@ -140,7 +140,7 @@ if __name__ == "__main__":
             model = SecureResNet18(ctx, sd, input_size=size)
         logits = []
         for i in range(0 if cmd_args.three_role else images.shape[0]):
-            out = model(images[i:i + 1])
+            out = model(images[i:i + 1]).clone()      # (the graphed form returns its static output buffer: keep a copy)
             logits.append(out)
             total_pred.append(int(out.argmax(dim=1).item()))
         if logits and os.environ.get("PRIMIA_DUMP_LOGITS"):

@@ -148,6 +148,15 @@ def test_cli_train_federated_then_inference(tmp_path):
               {"PRIMIA_DUMP_LOGITS": dist3, "MASTER_ADDR": "127.0.0.1"})
     assert "Inference Results" in out
     assert torch.equal(torch.load(local), torch.load(dist3))
+    # ... and as the serving form (--hip_graph: captured online phase + one-launch dealer refill per image): other primitives,
+    # so the logits agree up to fixed-point noise — for EVERY image (the graphed form returns a static buffer; the CLI keeps
+    # copies: round 6 found the dump holding the last image's logits twice)
+    graphed = str(tmp_path / "graph.pt")
+    out = run(["inference.py"] + base + ["--hip_graph"], {"PRIMIA_DUMP_LOGITS": graphed})
+    lg, ll = torch.load(graphed), torch.load(local)
+    assert lg.shape == ll.shape == (2, 3)
+    assert torch.allclose(lg, ll, atol=5e-3), (lg, ll)
+    assert not torch.equal(lg[0], lg[1])
     os.remove(ckpt)
 
 
