@@ -326,6 +326,13 @@ def test_graphed_inference_matches_eager_and_refills(cuda):
         assert np.array_equal(cc, want), i
         n_tr += 1
     assert n_tr > 20
+    # the serving form returns its STATIC output buffer (the graph writes it in place): a caller that keeps results copies them,
+    # as inference.py --hip_graph does since round 6 (its logits dump used to hold the last image's row twice)
+    img2 = torch.randn(1, 3, 16, 16, generator=gen).to(cuda)
+    r1 = g(img)
+    keep1 = r1.clone()
+    r2 = g(img2)
+    assert r1 is r2 and not torch.equal(keep1, r2)
     # the eager form of the refill (refill_graph = False) hands out the same primitives: same logits, bit for bit
     outs = []
     for use_graph in (True, False):
